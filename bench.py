@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Bench of the graph-evaluator hot path (contract: see the task statement).
+
+A "step" is one pass of the evaluator over one batch of synthetic leaf values
+already resident in HBM: ``fdg_eval_device`` on B samples.  Metric:
+graph-evaluations/sec, whole job.  N > 1 (launched with torch.distributed.run):
+samples shard across ranks (weak scaling, no data-path collective); after the
+timed steps every rank accumulates its roots and ONE all-reduce (RCCL) combines
+the observable -- that reduce is inside the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6    # AMD spec, FMA counted as 2 (not in the local guide)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sigma4_standin")
+    ap.add_argument("--samples", type=int, default=0, help="samples per step per GPU (0 = workload default)")
+    ap.add_argument("--layout", default="sample_major", choices=["sample_major", "leaf_major"])
+    ap.add_argument("--interp", action="store_true", help="use the table interpreter instead of the JIT kernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import feynmandiagram_jl_amd as fd
+    from feynmandiagram_jl_amd import capi, workloads
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    t = workloads.get(args.workload)
+    st = t.stats()
+    L, R = t.n_leaf, t.n_root
+    default_B = {"sigma2": 1 << 26, "sigma4_standin": 1 << 21, "synthetic_small": 1 << 23}.get(args.workload, 1 << 20)
+    B = args.samples or default_B
+    f = fd.compile_table(t, specialize=not args.interp)
+
+    if args.layout == "sample_major":
+        leaf = torch.empty((B, L), dtype=torch.float64, device=dev)
+    else:
+        leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
+    root = torch.empty((B, R), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream()
+    # per-rank Philox offset: results do not depend on how samples are sharded
+    capi.fill_uniform_device(leaf.data_ptr(), B, L, leaf.stride(0), leaf.stride(1), 1234, rank * B, stream.cuda_stream)
+
+    def step():
+        f(root, leaf)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record(stream)
+    for i in range(args.steps):
+        step()
+        ev[i + 1].record(stream)          # same stream the kernel is launched on
+    acc = root.sum(dim=0)                 # final observable accumulation
+    if dist:
+        dist.all_reduce(acc)              # the one collective: R doubles over xGMI
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    avg_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3
+
+    total_evals = float(B) * args.steps * world
+    value = total_evals / elapsed
+    info = f.info()
+    out = {
+        "metric": "graph-evaluations/sec",
+        "value": value,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": args.workload + (" (seeded stand-in for the 4-loop Parquet self-energy; the real graph needs the Julia front end)" if args.workload == "sigma4_standin" else ""),
+                   "graph": t.name, "n_leaf": L, "n_node": t.n_node, "n_edge": t.n_edge, "n_root": R,
+                   "flops_per_eval": st["flops_alg"], "bytes_per_eval": st["bytes_alg"],
+                   "samples_per_step_per_gpu": B, "layout": args.layout,
+                   "kernel": "interpreter" if args.interp else "specialized",
+                   "parallelism": f"samples sharded x{world}, one all-reduce of {R} doubles"},
+    }
+    if rank == 0:
+        bytes_per_launch = st["bytes_alg"] * B
+        achieved = bytes_per_launch / avg_kernel_s / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "fdg_interp" if args.interp else ("fdg_spec_sm" if args.layout == "sample_major" else "fdg_spec_gen"),
+                           "avg_kernel_ms": avg_kernel_s * 1e3,
+                           "algorithmic_bytes_per_launch": bytes_per_launch}
+        out["valu_fp64"] = {"achieved_tflops": st["flops_alg"] * B / avg_kernel_s / 1e12,
+                            "peak_tflops_fma": FP64_VALU_PEAK_TFLOPS,
+                            "note": "secondary ceiling: add/mul only (no FMA contraction allowed), so the usable peak is half"}
+        out["kernel_info"] = {k: info[k] for k in ("max_live", "n_slot_lds", "n_slot_mem", "spec_vgpr", "spec_scratch_bytes")}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(t, leaf, root, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(t, leaf, root, budget_s):
+    """The reference's own C back-end text (to_Cstr shape, static.jl:155-197)
+    compiled by gcc -O2 -ffp-contract=off and called once per sample on the host
+    cores, on a bounded sample of the same leaf data; also checks the GPU roots
+    of that sample against it."""
+    import numpy as np
+    import oracle
+    from feynmandiagram_jl_amd.lowering import table_to_Cstr
+    cores = os.cpu_count() or 1
+    cb = oracle.CBaseline(table_to_Cstr(t), t.n_leaf, t.n_root)
+    n0 = 2048
+    h = leaf[:n0].cpu().numpy()
+    t0 = time.perf_counter()
+    cb(h, cores)
+    rate = n0 / max(time.perf_counter() - t0, 1e-6)
+    n = int(min(leaf.shape[0], max(n0, rate * budget_s)))
+    h = leaf[:n].cpu().numpy()
+    t0 = time.perf_counter()
+    ref = cb(h, cores)
+    dt = time.perf_counter() - t0
+    got = root[:n].cpu().numpy()
+    t1 = time.perf_counter()
+    n1 = max(256, n // (4 * cores))
+    cb(h[:n1], 1)
+    dt1 = time.perf_counter() - t1
+    return {"value": n / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"{n} samples of the same leaf batch, {dt:.1f} s; reference's to_Cstr text compiled by gcc -O2 -ffp-contract=off (the Julia evaluator cannot run here)",
+            "single_core_evals_per_s": n1 / dt1, "gcc_compile_s": cb.compile_seconds,
+            "gpu_matches_cpu_bitwise": bool(np.array_equal(got, ref)),
+            "max_abs_dev": float(np.abs(got - ref).max())}
+
+
+if __name__ == "__main__":
+    main()

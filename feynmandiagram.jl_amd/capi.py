@@ -1,0 +1,186 @@
+"""ctypes binding of the C ABI declared in include/fdg.h (libfdg.so).
+
+This is the reference-side binding a maintainer would add, written for the
+Python host (the Julia ``ccall`` twin is julia/hip_compiler.jl).  It is a thin
+1:1 wrapper: no arithmetic happens on this side, and there is no fallback --
+when the shared library (the HIP extension) is missing, importing any
+evaluation entry point raises ``FdgLibraryMissing``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .nodetable import NodeTable
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfdg.so")
+KERNEL_CACHE = os.path.join(_HERE, "kernel_cache")
+
+FDG_OK = 0
+FDG_E_INVALID, FDG_E_UNSUPPORTED, FDG_E_NO_DEVICE, FDG_E_NOMEM, FDG_E_JIT, FDG_E_INTERNAL = -1, -2, -3, -4, -5, -6
+FDG_SPEC_DEFAULT, FDG_SPEC_KEEP_SOURCE, FDG_SPEC_FAST_MATH = 0, 1, 2
+
+EXPORTS = [
+    "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
+    "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
+    "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_graph_release_device", "fdg_powi",
+]
+
+
+class FdgLibraryMissing(ImportError):
+    pass
+
+
+class FdgError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"fdg error {code}: {msg}")
+        self.code = code
+
+
+class GraphDesc(C.Structure):
+    _fields_ = [("n_leaf", C.c_uint32), ("n_node", C.c_uint32), ("n_root", C.c_uint32), ("n_edge", C.c_uint32),
+                ("op", C.POINTER(C.c_uint8)), ("power", C.POINTER(C.c_int32)),
+                ("child_off", C.POINTER(C.c_uint32)), ("child_idx", C.POINTER(C.c_uint32)),
+                ("child_fac", C.POINTER(C.c_double)), ("root_slot", C.POINTER(C.c_uint32))]
+
+
+class GraphInfo(C.Structure):
+    _fields_ = [("n_leaf", C.c_uint32), ("n_node", C.c_uint32), ("n_root", C.c_uint32), ("n_edge", C.c_uint32),
+                ("n_live_node", C.c_uint32), ("n_live_leaf", C.c_uint32),
+                ("flops_alg", C.c_uint64), ("bytes_alg", C.c_uint64),
+                ("max_live", C.c_uint32), ("n_slot_lds", C.c_uint32), ("n_slot_mem", C.c_uint32),
+                ("n_ops", C.c_uint32), ("specialized", C.c_int32),
+                ("spec_vgpr", C.c_uint32), ("spec_lds_bytes", C.c_uint32), ("spec_scratch_bytes", C.c_uint32)]
+
+    def asdict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Load libfdg.so once; fail loudly when the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FdgLibraryMissing(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C feynmandiagram.jl_amd/csrc). "
+            "There is no CPU fallback for the evaluator.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, u64, u32, dp = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p
+    L.fdg_last_error.restype = C.c_char_p
+    L.fdg_version.restype = C.c_int
+    L.fdg_graph_create.argtypes = [C.POINTER(GraphDesc), C.POINTER(vp)]
+    L.fdg_graph_destroy.argtypes = [vp]
+    L.fdg_graph_query.argtypes = [vp, C.POINTER(GraphInfo)]
+    L.fdg_graph_emit_source.argtypes = [vp, C.c_uint, C.POINTER(C.c_char_p)]
+    L.fdg_free.argtypes = [vp]
+    L.fdg_free.restype = None
+    L.fdg_graph_specialize.argtypes = [vp, C.c_char_p, C.c_uint]
+    L.fdg_eval_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, i64, vp]
+    L.fdg_eval.argtypes = [vp, dp, dp, i64]
+    L.fdg_accumulate_device.argtypes = [vp, dp, i64, i64, dp, dp, i64, vp]
+    L.fdg_fill_uniform_device.argtypes = [dp, i64, u32, i64, i64, u64, u64, vp]
+    L.fdg_graph_release_device.argtypes = [vp]
+    L.fdg_powi.argtypes = [C.c_double, C.c_int32]
+    L.fdg_powi.restype = C.c_double
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise FdgError(rc, lib().fdg_last_error().decode("utf-8", "replace"))
+
+
+class GraphHandle:
+    """Owns one ``fdg_graph*``."""
+
+    def __init__(self, table: NodeTable):
+        t = table.normalized()
+        t.validate()
+        self.table = t
+        d = GraphDesc()
+        d.n_leaf, d.n_node, d.n_root, d.n_edge = t.n_leaf, t.n_node, t.n_root, t.n_edge
+        d.op = t.op.ctypes.data_as(C.POINTER(C.c_uint8))
+        d.power = t.power.ctypes.data_as(C.POINTER(C.c_int32))
+        d.child_off = t.child_off.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.child_idx = t.child_idx.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.child_fac = t.child_fac.ctypes.data_as(C.POINTER(C.c_double))
+        d.root_slot = t.root_slot.ctypes.data_as(C.POINTER(C.c_uint32))
+        h = C.c_void_p()
+        check(lib().fdg_graph_create(C.byref(d), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().fdg_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def info(self) -> dict:
+        gi = GraphInfo()
+        check(lib().fdg_graph_query(self._h, C.byref(gi)))
+        return gi.asdict()
+
+    def emit_source(self, flags: int = 0) -> str:
+        s = C.c_char_p()
+        check(lib().fdg_graph_emit_source(self._h, flags, C.byref(s)))
+        try:
+            return s.value.decode()
+        finally:
+            lib().fdg_free(s)
+
+    def specialize(self, cache_dir: Optional[str] = None, flags: int = 0):
+        cd = cache_dir if cache_dir is not None else os.environ.get("FDG_CACHE_DIR", KERNEL_CACHE)
+        os.makedirs(cd, exist_ok=True)
+        check(lib().fdg_graph_specialize(self._h, cd.encode(), flags))
+
+    # raw-pointer device entry points (ints are device addresses) ----------- #
+    def eval_device(self, d_leaf: int, ss: int, ls: int, d_root: int, rs: int, rk: int, B: int, stream: int = 0):
+        check(lib().fdg_eval_device(self._h, d_leaf, ss, ls, d_root, rs, rk, B, stream))
+
+    def accumulate_device(self, d_leaf: int, ss: int, ls: int, d_weight: int, d_acc: int, B: int, stream: int = 0):
+        check(lib().fdg_accumulate_device(self._h, d_leaf, ss, ls, d_weight or None, d_acc, B, stream))
+
+    def eval_host(self, leaf: np.ndarray, root: Optional[np.ndarray] = None) -> np.ndarray:
+        leaf = np.ascontiguousarray(leaf, dtype=np.float64)
+        if leaf.ndim != 2 or leaf.shape[1] < self.table.n_leaf:
+            raise IndexError("BoundsError: leafVal has fewer columns than the graph has leaves")
+        if leaf.shape[1] != self.table.n_leaf:
+            leaf = np.ascontiguousarray(leaf[:, :self.table.n_leaf])
+        B = leaf.shape[0]
+        if root is None:
+            root = np.zeros((B, self.table.n_root), dtype=np.float64)
+        if root.dtype != np.float64 or not root.flags.c_contiguous or root.shape != (B, self.table.n_root):
+            raise ValueError("root must be a C-contiguous float64 [B, R] array")
+        check(lib().fdg_eval(self._h, leaf.ctypes.data, root.ctypes.data, B))
+        return root
+
+    def release_device(self):
+        check(lib().fdg_graph_release_device(self._h))
+
+
+def fill_uniform_device(d_leaf: int, B: int, L: int, ss: int, ls: int, seed: int, sample_offset: int = 0,
+                        stream: int = 0):
+    check(lib().fdg_fill_uniform_device(d_leaf, B, L, ss, ls, seed, sample_offset, stream))
+
+
+def powi(x: float, n: int) -> float:
+    return float(lib().fdg_powi(x, n))

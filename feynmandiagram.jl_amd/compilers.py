@@ -1,0 +1,177 @@
+"""``Compilers`` -- the back-end API surface of the reference, with the HIP
+evaluator as the product path.
+
+Mirrors src/backend/compiler.jl:16-18 + static.jl + compiler_python.jl:
+
+* ``compile(graphs; root) -> (GraphFunc, leafmap)``  (static.jl:221-227).  The
+  returned callable has the generated function's semantics:
+  ``f(root, leafVal)`` mutates ``root`` in place and returns the last assigned
+  root value (test/compiler.jl:15,28); it also accepts a ``[B, L]`` leaf matrix
+  with a ``[B, R]`` root matrix (the batched layout of compile_Python,
+  compiler_python.jl:23,28,45-47) and torch CUDA tensors (zero copy).
+* ``compile_Julia / compile_C / compile_Python(graphs, filename; root,
+  func_name)`` append source text to a file and return ``leafmap``
+  (static.jl:244-251, 269-279; compiler_python.jl:53-60).
+* ``to_julia_str / to_Cstr / to_python_str`` (re-exported from lowering).
+
+``GraphFunc`` is the name BASELINE.json's north_star uses for the callable; the
+reference itself returns a RuntimeGeneratedFunction.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import capi
+from .graph import Graph
+from .lowering import lower, to_Cstr, to_julia_str, to_python_str
+from .nodetable import FDG_NO_ROOT, NodeTable
+
+__all__ = ["compile", "compile_hip", "compile_table", "GraphFunc", "compile_Julia", "compile_C",
+           "compile_Python", "to_julia_str", "to_Cstr", "to_python_str"]
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+class GraphFunc:
+    """Callable evaluator bound to one lowered graph set (one ``fdg_graph``)."""
+
+    def __init__(self, table: NodeTable, specialize: bool = False, cache_dir: Optional[str] = None,
+                 flags: int = 0):
+        self.table = table.normalized()
+        self.handle = capi.GraphHandle(self.table)
+        self.n_leaf, self.n_root = self.table.n_leaf, self.table.n_root
+        if specialize:
+            self.handle.specialize(cache_dir, flags)
+
+    # -- introspection ------------------------------------------------------- #
+    def info(self) -> dict:
+        return self.handle.info()
+
+    def specialize(self, cache_dir: Optional[str] = None, flags: int = 0) -> "GraphFunc":
+        self.handle.specialize(cache_dir, flags)
+        return self
+
+    def _last_root_value(self, root_row):
+        slots = [k for k in range(self.n_root) if int(self.table.root_slot[k]) != FDG_NO_ROOT]
+        if not slots:
+            return None
+        # the generated function returns its last assignment: the root whose
+        # statement comes last in emission order (static.jl:126-128)
+        k = max(slots, key=lambda k: self._emission_rank(int(self.table.root_slot[k])))
+        return float(root_row[k])
+
+    def _emission_rank(self, v: int):
+        L = self.table.n_leaf
+        if v >= L:
+            return (v - L + 1, 1)
+        return (int(self.table.leaf_positions()[v]), 0) if L else (0, 0)
+
+    # -- the call ------------------------------------------------------------- #
+    def __call__(self, root, leafVal):
+        if _is_torch(leafVal):
+            return self._call_torch(root, leafVal)
+        leaf = np.asarray(leafVal, dtype=np.float64)
+        if leaf.ndim == 1:
+            if leaf.shape[0] < self.n_leaf:
+                raise IndexError(f"BoundsError: attempt to access {leaf.shape[0]}-element leafVal at index [{self.n_leaf}]")
+            if len(root) < self.n_root:
+                raise IndexError(f"BoundsError: attempt to access {len(root)}-element root at index [{self.n_root}]")
+            r = np.array([float(root[k]) for k in range(self.n_root)], dtype=np.float64).reshape(1, -1)
+            self.handle.eval_host(leaf[None, :self.n_leaf], r)
+            for k in range(self.n_root):
+                root[k] = r[0, k]
+            return self._last_root_value(r[0])
+        if leaf.ndim != 2:
+            raise ValueError("leafVal must be a vector or a [B, L] matrix")
+        B = leaf.shape[0]
+        if root is None:
+            root = np.zeros((B, self.n_root), dtype=np.float64)
+        if not (isinstance(root, np.ndarray) and root.dtype == np.float64 and root.flags.c_contiguous
+                and root.shape == (B, self.n_root)):
+            raise ValueError("root must be a C-contiguous float64 array of shape [B, R]")
+        self.handle.eval_host(leaf, root)
+        return root
+
+    def _call_torch(self, root, leaf):
+        import torch
+        if not leaf.is_cuda:
+            raise RuntimeError("torch leafVal must live on the GPU (no CPU fallback); pass a numpy array for host data")
+        if leaf.dtype != torch.float64:
+            raise TypeError("leafVal must be float64")
+        squeeze = leaf.dim() == 1
+        if squeeze:
+            leaf = leaf[None, :]
+        B, Lc = leaf.shape
+        if Lc < self.n_leaf:
+            raise IndexError("BoundsError: leafVal has fewer columns than the graph has leaves")
+        if root is None:
+            root = torch.zeros((B, self.n_root), dtype=torch.float64, device=leaf.device)
+        r2 = root[None, :] if squeeze else root
+        if r2.dtype != torch.float64 or r2.shape[0] != B or r2.shape[1] < self.n_root:
+            raise ValueError("root must be a float64 [B, R] tensor on the same device")
+        st = torch.cuda.current_stream(leaf.device).cuda_stream
+        with torch.cuda.device(leaf.device):
+            self.handle.eval_device(leaf.data_ptr(), leaf.stride(0), leaf.stride(1), r2.data_ptr(),
+                                    r2.stride(0), r2.stride(1), B, st)
+        return root
+
+    def accumulate(self, leaf, weight=None, acc=None):
+        """``acc[k] += sum_b weight[b] * root_k(b)`` on device (torch tensors)."""
+        import torch
+        if not leaf.is_cuda or leaf.dtype != torch.float64 or leaf.dim() != 2:
+            raise TypeError("leaf must be a float64 [B, L] CUDA tensor")
+        if acc is None:
+            acc = torch.zeros(self.n_root, dtype=torch.float64, device=leaf.device)
+        w = 0
+        if weight is not None:
+            weight = weight.contiguous()
+            w = weight.data_ptr()
+        st = torch.cuda.current_stream(leaf.device).cuda_stream
+        with torch.cuda.device(leaf.device):
+            self.handle.accumulate_device(leaf.data_ptr(), leaf.stride(0), leaf.stride(1), w, acc.data_ptr(),
+                                          leaf.shape[0], st)
+        return acc
+
+
+def compile_table(table: NodeTable, specialize: bool = False, **kw) -> GraphFunc:
+    return GraphFunc(table, specialize=specialize, **kw)
+
+
+def compile(graphs: Sequence[Graph], root: Optional[Sequence[int]] = None, specialize: bool = False,
+            **kw) -> Tuple[GraphFunc, Dict[int, Graph]]:
+    """``Compilers.compile`` (static.jl:221-227): returns ``(f, leafmap)``."""
+    table, leafmap, _ = lower(graphs, root)
+    return GraphFunc(table, specialize=specialize, **kw), leafmap
+
+
+compile_hip = compile
+
+
+def _append(filename: str, text: str, header: str = "") -> None:
+    with open(filename, "a") as f:
+        if header and f.tell() == 0:
+            f.write(header)
+        f.write(text)
+
+
+def compile_Julia(graphs, filename: str, root=None, func_name: str = "eval_graph!"):
+    s, leafmap = to_julia_str(graphs, root=root, name=func_name)
+    _append(filename, s)
+    return leafmap
+
+
+def compile_C(graphs, filename: str, datatype: str = "double ", root=None, func_name: str = "eval_graph"):
+    s, leafmap = to_Cstr(graphs, root=root, datatype=datatype, name=func_name)
+    _append(filename, s, "#include <math.h>\n")    # static.jl:272-276
+    return leafmap
+
+
+def compile_Python(graphs, filename: str, root=None, func_name: str = "eval_graph"):
+    s, leafmap = to_python_str(graphs, root=root, name=func_name)
+    _append(filename, s)
+    return leafmap

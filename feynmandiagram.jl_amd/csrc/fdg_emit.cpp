@@ -1,0 +1,189 @@
+// Straight-line HIP source for one graph: the GPU analogue of the reference's
+// to_Cstr (src/backend/static.jl:155-197).  One lane evaluates one sample; the
+// statement order and each statement's association are the reference's
+// (static.jl:13-46: n-ary + and * are left folds, factors equal to 1 are not
+// applied); the compiler is told not to contract (-ffp-contract=off) unless
+// FDG_SPEC_FAST_MATH is requested.
+//
+// Two kernels are emitted per graph:
+//   fdg_spec_sm  : sample-major leaves (leaf stride 1): a lane reads its own
+//                  row with 16-byte loads; roots written as one row per lane.
+//   fdg_spec_gen : arbitrary strides (covers the leaf-major / Julia layout,
+//                  where consecutive lanes read consecutive addresses).
+// mode 0 writes roots, mode 1 accumulates weight*root per lane and leaves one
+// partial sum per block and root in `partial` (reduced by fdg_reduce_partials).
+#include <cinttypes>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+#include "fdg_internal.h"
+
+namespace fdg {
+
+static void put_double(std::ostringstream &os, double f) {
+  // hex float: exact, locale independent
+  char buf[64];
+  std::snprintf(buf, sizeof buf, "%a", f);
+  os << buf;
+}
+
+static const char *kPrelude = R"SRC(
+typedef double fdg_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double fdg_powi_dev(double x, int n) {
+  if (n == 2) return x * x;
+  if (n == 3) return x * x * x;
+  if (n == -1) return 1.0 / x;
+  if (n == -2) { double r = 1.0 / x; return r * r; }
+  double y = 1.0, xnlo = 0.0, ynlo = 0.0;
+  long m = n;
+  if (m < 0) {
+    double rx = 1.0 / x;
+    if (__builtin_isfinite(x)) xnlo = -__builtin_fma(x, rx, -1.0) * rx;
+    x = rx; m = -m;
+  }
+  while (m > 1) {
+    if (m & 1) {
+      double err = __builtin_fma(y, xnlo, x * ynlo);
+      double yh = x * y; double yl = __builtin_fma(x, y, -yh);
+      y = yh; ynlo = yl + err;
+    }
+    double err = x * 2 * xnlo;
+    double xh = x * x; double xl = __builtin_fma(x, x, -xh);
+    x = xh; xnlo = xl + err;
+    m >>= 1;
+  }
+  double err = __builtin_fma(y, xnlo, x * ynlo);
+  return (__builtin_isfinite(x) && __builtin_isfinite(err)) ? __builtin_fma(x, y, err) : x * y;
+}
+__device__ __forceinline__ double fdg_block_sum(double v, double *sh) {
+  // fixed-shape pairwise tree over the 256 lanes of the block: deterministic
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) sh[t] = sh[t] + sh[t + s];
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+)SRC";
+
+// A node's expression as explicit left folds.  Sum: terms (c*f or c) folded
+// with +.  Prod: the interleaved sequence c1, f1?, c2, f2?, ... folded with *,
+// i.e. (((c1*f1)*c2)*f2) -- exactly how Julia parses "(g1 * f1 * g2 * f2)".
+static void emit_node_expr(std::ostringstream &os, const Lowered &p, uint32_t n) {
+  const uint32_t L = p.L;
+  (void)L;
+  const uint32_t a = p.off[n], b = p.off[n + 1];
+  if (p.op[n] == FDG_OP_POWER) {
+    os << "fdg_powi_dev(g" << p.idx[a] << ", " << p.power[n] << ")";
+    if (p.fac[a] != 1.0) { os << " * "; put_double(os, p.fac[a]); }
+    return;
+  }
+  // sequence of fold steps
+  std::vector<std::string> terms;
+  if (p.op[n] == FDG_OP_SUM) {
+    for (uint32_t e = a; e < b; ++e) {
+      std::ostringstream t;
+      if (p.fac[e] != 1.0) { t << "(g" << p.idx[e] << " * "; put_double(t, p.fac[e]); t << ")"; }
+      else t << "g" << p.idx[e];
+      terms.push_back(t.str());
+    }
+  } else {
+    for (uint32_t e = a; e < b; ++e) {
+      terms.push_back("g" + std::to_string(p.idx[e]));
+      if (p.fac[e] != 1.0) { std::ostringstream t; put_double(t, p.fac[e]); terms.push_back(t.str()); }
+    }
+  }
+  const char *sep = p.op[n] == FDG_OP_SUM ? " + " : " * ";
+  for (size_t i = 1; i < terms.size(); ++i) os << "(";
+  os << terms[0];
+  for (size_t i = 1; i < terms.size(); ++i) os << sep << terms[i] << ")";
+}
+
+static void emit_kernel(std::ostringstream &os, const Lowered &p, bool sample_major) {
+  const uint32_t L = p.L;
+  os << "extern \"C\" __global__ void __launch_bounds__(256) " << (sample_major ? "fdg_spec_sm" : "fdg_spec_gen")
+     << "(const double *__restrict__ leaf, long ss, long ls, double *__restrict__ root, long rs, long rk,\n"
+        "    const double *__restrict__ weight, double *__restrict__ partial, long B, int mode) {\n";
+  os << "  __shared__ double fdg_sh[256];\n";
+  for (uint32_t k = 0; k < p.R; ++k) os << "  double acc" << k << " = 0.0;\n";
+  os << "  const long nblk = (B + 255) / 256;\n";
+  os << "  _Pragma(\"unroll 1\")\n";
+  os << "  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {\n";
+  os << "    const long b0 = blk * 256 + threadIdx.x;\n";
+  os << "    const bool valid = b0 < B;\n";
+  os << "    const long b = valid ? b0 : (B - 1);\n";
+  // body
+  if (sample_major) {
+    os << "    const double *lp = leaf + b * ss;\n";
+    os << "    const bool al = ((((unsigned long)leaf) & 15ul) == 0ul) && ((ss & 1l) == 0l);\n";
+    uint32_t i = 0;
+    while (i < L) {
+      if (i + 1 < L && p.live[i] && p.live[i + 1] && (i % 2 == 0)) {
+        os << "    double g" << i << ", g" << (i + 1) << ";\n";
+        os << "    if (al) { fdg_d2 t = __builtin_nontemporal_load((const fdg_d2 *)(lp + " << i << ")); g" << i
+           << " = t.x; g" << (i + 1) << " = t.y; } else { g" << i << " = __builtin_nontemporal_load(lp + " << i
+           << "); g" << (i + 1) << " = __builtin_nontemporal_load(lp + " << (i + 1) << "); }\n";
+        i += 2;
+      } else {
+        if (p.live[i]) os << "    const double g" << i << " = __builtin_nontemporal_load(lp + " << i << ");\n";
+        i += 1;
+      }
+    }
+  } else {
+    os << "    const double *lp = leaf + b * ss;\n";
+    for (uint32_t i = 0; i < L; ++i)
+      if (p.live[i]) os << "    const double g" << i << " = __builtin_nontemporal_load(lp + " << i << "l * ls);\n";
+  }
+  for (uint32_t n : p.order) {
+    os << "    const double g" << (L + n) << " = ";
+    emit_node_expr(os, p, n);
+    os << ";\n";
+  }
+  // outputs
+  os << "    if (mode == 0) {\n      if (valid) {\n";
+  os << "        double *rp = root + b * rs;\n";
+  bool pair_ok = sample_major;
+  for (uint32_t k = 0; k < p.R; ++k) {
+    if (p.root_slot[k] == FDG_NO_ROOT) continue;
+    if (pair_ok && k % 2 == 0 && k + 1 < p.R && p.root_slot[k + 1] != FDG_NO_ROOT) {
+      os << "        if (rk == 1 && ((rs & 1l) == 0l) && ((((unsigned long)root) & 15ul) == 0ul)) { fdg_d2 t; t.x = g"
+         << p.root_slot[k] << "; t.y = g" << p.root_slot[k + 1] << "; __builtin_nontemporal_store(t, (fdg_d2 *)(rp + " << k
+         << ")); } else { rp[" << k << "l * rk] = g" << p.root_slot[k] << "; rp[" << (k + 1) << "l * rk] = g"
+         << p.root_slot[k + 1] << "; }\n";
+      ++k;
+    } else {
+      os << "        rp[" << k << "l * rk] = g" << p.root_slot[k] << ";\n";
+    }
+  }
+  os << "      }\n    } else {\n";
+  os << "      const double w = valid ? (weight ? weight[b] : 1.0) : 0.0;\n";
+  for (uint32_t k = 0; k < p.R; ++k)
+    if (p.root_slot[k] != FDG_NO_ROOT) os << "      acc" << k << " = acc" << k << " + w * g" << p.root_slot[k] << ";\n";
+  os << "    }\n";
+  os << "  }\n";
+  os << "  if (mode != 0) {\n";
+  for (uint32_t k = 0; k < p.R; ++k) {
+    os << "    { double s = fdg_block_sum(acc" << k << ", fdg_sh); if (threadIdx.x == 0) partial[(long)blockIdx.x * "
+       << p.R << " + " << k << "] = s; }\n";
+  }
+  os << "  }\n}\n\n";
+}
+
+std::string emit_hip_source(const Lowered &p, unsigned flags) {
+  (void)flags;
+  std::ostringstream os;
+  os << "// generated by fdg_graph_emit_source: L=" << p.L << " N=" << p.N << " (live " << p.order.size() << ") R=" << p.R
+     << " flops_alg=" << p.flops_alg << "\n";
+  os << "#include <hip/hip_runtime.h>\n";
+  os << kPrelude;
+  emit_kernel(os, p, true);
+  emit_kernel(os, p, false);
+  return os.str();
+}
+
+}  // namespace fdg

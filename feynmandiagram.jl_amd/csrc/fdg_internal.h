@@ -1,0 +1,88 @@
+// Internal structures shared by the host-side lowering (fdg_lower.cpp), the
+// source emitter (fdg_emit.cpp) and the device runtime (fdg_runtime.hip).
+#pragma once
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/fdg.h"
+
+namespace fdg {
+
+// ---- operand / destination location words of the interpreter stream --------
+// bits 31..30 : space   0 = LDS slot, 1 = workspace (HBM panel) slot, 2 = leaf
+// bit  29     : operand carries a factor (two more words: lo, hi of the f64)
+// bits 28..0  : index
+constexpr uint32_t SP_LDS = 0u, SP_MEM = 1u, SP_LEAF = 2u;
+constexpr uint32_t LOC_FAC = 1u << 29;
+constexpr uint32_t LOC_IDX_MASK = (1u << 29) - 1u;
+inline uint32_t mkloc(uint32_t space, uint32_t idx) { return (space << 30) | idx; }
+
+// ---- micro-op header word ---------------------------------------------------
+// bits 3..0  : opcode;  bits 31..4 : operand count (SUM/PROD), exponent (POW,
+//              signed, stored biased by 2^27), root index (ROOT)
+constexpr uint32_t UOP_SUM = 0, UOP_PROD = 1, UOP_POW = 2, UOP_ROOT = 3, UOP_LEAF = 4, UOP_END = 5;
+// layouts (words):
+//   SUM/PROD : hdr, dst, then per operand: loc [, fac_lo, fac_hi]
+//   POW      : hdr(exponent), dst, loc [, fac_lo, fac_hi]
+//   ROOT     : hdr(k), loc                      -- root[k] = value at loc
+//   LEAF     : hdr(0), dst, leaf_index          -- copy a leaf into an LDS slot
+//   END      : hdr
+
+struct Lowered {
+  // copy of the table
+  uint32_t L = 0, N = 0, R = 0, E = 0;
+  std::vector<uint8_t> op;
+  std::vector<int32_t> power;
+  std::vector<uint32_t> off, idx;
+  std::vector<double> fac;
+  std::vector<uint32_t> root_slot;
+
+  // analysis
+  std::vector<uint8_t> live;       // [L+N] reachable from a root
+  std::vector<uint32_t> order;     // live internal nodes (index into 0..N-1), evaluation order
+  uint32_t n_live_leaf = 0;
+  uint64_t flops_alg = 0;
+  uint32_t max_live = 0;
+
+  // interpreter program
+  uint32_t lds_slots = 0;          // slots per sample in LDS
+  uint32_t mem_slots = 0;          // slots per sample in the workspace panel
+  std::vector<uint32_t> code;      // micro-op stream
+  uint32_t n_ops = 0;
+  uint64_t opnd_lds = 0, opnd_mem = 0, opnd_leaf = 0;  // operand reads by space (statistics)
+};
+
+// lowering entry points (fdg_lower.cpp)
+int validate_desc(const fdg_graph_desc *d, std::string &err);
+void analyse(Lowered &p);
+void build_interpreter_program(Lowered &p, uint32_t lds_slot_budget);
+
+// source emitter (fdg_emit.cpp)
+std::string emit_hip_source(const Lowered &p, unsigned flags);
+
+// thread-local error
+void set_error(const std::string &s);
+
+double powi(double x, int32_t n);
+
+}  // namespace fdg
+
+struct fdg_graph {
+  fdg::Lowered prog;
+  // specialization
+  std::vector<char> code_object;   // gfx950 code object of the specialized kernels
+  std::string spec_source_hash;
+  unsigned spec_flags = 0;
+  uint32_t spec_vgpr = 0, spec_lds = 0, spec_scratch = 0;
+  // device state (guarded by mu)
+  std::mutex mu;
+  void *d_code = nullptr;          // interpreter stream
+  void *d_ws = nullptr;            // workspace panels + block partials
+  size_t ws_bytes = 0;
+  void *module = nullptr;          // hipModule_t
+  void *fn_eval_sm = nullptr, *fn_eval_gen = nullptr;  // hipFunction_t
+  int device = -1;
+  int n_cu = 0;
+};

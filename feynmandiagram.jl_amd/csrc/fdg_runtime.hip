@@ -1,0 +1,549 @@
+// Device runtime behind include/fdg.h: the table-walking interpreter kernel,
+// the Philox leaf generator, the partial-sum reducer, the hiprtc/hipcc JIT for
+// per-graph straight-line kernels, and the C ABI entry points.
+//
+// Written for gfx950 only (wave64, 256 CUs, 160 KiB LDS per CU).  There is no
+// CPU path here: every evaluation entry point needs a device.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "fdg_internal.h"
+#include "fdg_powi.h"
+
+namespace fdg {
+const char *last_error_cstr();
+}
+using namespace fdg;
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+      return FDG_E_NO_DEVICE;                                                           \
+    }                                                                                   \
+  } while (0)
+
+// ============================================================================
+// kernels
+// ============================================================================
+typedef const __attribute__((address_space(4))) uint32_t cword;  // constant AS: wave-uniform reads become s_load
+
+__device__ __forceinline__ double fdg_block_sum256(double v, double *sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) sh[t] = sh[t] + sh[t + s];
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// One lane = one sample; the block walks the micro-op stream in lock step
+// (no divergence: every branch below depends on stream words only).
+// Per-sample values live in LDS columns lds[slot][lane] and, past the LDS
+// budget, in the block's HBM panel ws[slot][lane] (both lane-contiguous, so
+// every access of a wave is one coalesced 512-byte transaction).
+template <int MODE, bool STAGED>
+__global__ void __launch_bounds__(256)
+fdg_interp(const uint32_t *code_, const double *__restrict__ leaf, long ss, long ls,
+           double *__restrict__ root, long rs, long rk, const double *__restrict__ weight,
+           double *__restrict__ partial, long B, double *__restrict__ ws, uint32_t lds_slots,
+           uint32_t mem_slots, uint32_t L, uint32_t R) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  cword *code = (cword *)(uintptr_t)code_;
+  const int t = threadIdx.x;
+  const size_t per_block = (size_t)(mem_slots + (STAGED ? L : 0u) + (MODE ? R : 0u)) * 256u;
+  double *mem = ws + (size_t)blockIdx.x * per_block + t;
+  double *lpanel = mem + (size_t)mem_slots * 256u;
+  double *accp = lpanel + (STAGED ? (size_t)L * 256u : 0u);
+  double *ldsl = lds + t;
+  if (MODE)
+    for (uint32_t k = 0; k < R; ++k) accp[(size_t)k * 256u] = 0.0;
+
+  const long nblk = (B + 255) / 256;
+#pragma unroll 1
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long b0 = blk * 256 + t;
+    const bool valid = b0 < B;
+    const long b = valid ? b0 : (B - 1);
+    const double *lp = leaf + b * ss;
+    if (STAGED) {
+      // sample-major input: every lane streams its own row into the panel once,
+      // so later leaf reads are lane-contiguous
+      for (uint32_t i = 0; i < L; ++i) lpanel[(size_t)i * 256u] = lp[(long)i * ls];
+    }
+    double w = 0.0;
+    if (MODE) w = valid ? (weight ? weight[b] : 1.0) : 0.0;
+
+    auto fetch = [&](uint32_t loc) -> double {
+      const uint32_t sp = loc >> 30, ix = loc & LOC_IDX_MASK;
+      if (sp == SP_LDS) return ldsl[(size_t)ix * 256u];
+      if (sp == SP_MEM) return mem[(size_t)ix * 256u];
+      return STAGED ? lpanel[(size_t)ix * 256u] : lp[(long)ix * ls];
+    };
+    auto factor = [&](uint32_t pc) -> double {
+      const uint64_t u = (uint64_t)code[pc] | ((uint64_t)code[pc + 1] << 32);
+      return __longlong_as_double((long long)u);
+    };
+
+    uint32_t pc = 0;
+#pragma unroll 1
+    for (;;) {
+      const uint32_t h = code[pc];
+      const uint32_t opc = h & 15u, arg = h >> 4;
+      if (opc == UOP_END) break;
+      if (opc == UOP_ROOT) {
+        const double v = fetch(code[pc + 1]);
+        pc += 2;
+        if (MODE) accp[(size_t)arg * 256u] = accp[(size_t)arg * 256u] + w * v;
+        else if (valid) root[b * rs + (long)arg * rk] = v;
+        continue;
+      }
+      if (opc == UOP_LEAF) {
+        const uint32_t dst = code[pc + 1], li = code[pc + 2];
+        pc += 3;
+        ldsl[(size_t)(dst & LOC_IDX_MASK) * 256u] = STAGED ? lpanel[(size_t)li * 256u] : lp[(long)li * ls];
+        continue;
+      }
+      const uint32_t dst = code[pc + 1];
+      pc += 2;
+      double acc;
+      if (opc == UOP_POW) {
+        const uint32_t w0 = code[pc++];
+        acc = fdg_powi_impl(fetch(w0), (int32_t)arg - (1 << 27));
+        if (w0 & LOC_FAC) { acc = acc * factor(pc); pc += 2; }
+      } else {
+        const uint32_t w0 = code[pc++];
+        acc = fetch(w0);
+        if (w0 & LOC_FAC) { acc = acc * factor(pc); pc += 2; }
+        if (opc == UOP_SUM) {
+#pragma unroll 1
+          for (uint32_t j = 1; j < arg; ++j) {
+            const uint32_t wj = code[pc++];
+            double x = fetch(wj);
+            if (wj & LOC_FAC) { x = x * factor(pc); pc += 2; }
+            acc = acc + x;
+          }
+        } else {
+#pragma unroll 1
+          for (uint32_t j = 1; j < arg; ++j) {
+            const uint32_t wj = code[pc++];
+            acc = acc * fetch(wj);
+            if (wj & LOC_FAC) { acc = acc * factor(pc); pc += 2; }
+          }
+        }
+      }
+      if ((dst >> 30) == SP_LDS) ldsl[(size_t)(dst & LOC_IDX_MASK) * 256u] = acc;
+      else mem[(size_t)(dst & LOC_IDX_MASK) * 256u] = acc;
+    }
+  }
+  if (MODE) {
+    double *sh = lds + (size_t)lds_slots * 256u;
+    for (uint32_t k = 0; k < R; ++k) {
+      const double s = fdg_block_sum256(accp[(size_t)k * 256u], sh);
+      if (t == 0) partial[(size_t)blockIdx.x * R + k] = s;
+    }
+  }
+}
+
+// acc[k] += sum over blocks of partial[blk][k], fixed order (deterministic for
+// a given grid size)
+__global__ void fdg_reduce_partials(const double *__restrict__ partial, uint32_t nblk, uint32_t R,
+                                    double *__restrict__ acc) {
+  __shared__ double sh[256];
+  for (uint32_t k = blockIdx.x; k < R; k += gridDim.x) {
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < nblk; i += 256) s = s + partial[(size_t)i * R + k];
+    s = fdg_block_sum256(s, sh);
+    if (threadIdx.x == 0) acc[k] = acc[k] + s;
+  }
+}
+
+// Philox4x32-10 (Salmon et al., SC'11), key = seed, counter = (sample, leaf)
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void __launch_bounds__(256)
+fdg_fill_uniform(double *__restrict__ leaf, long B, uint32_t L, long ss, long ls, uint64_t seed,
+                 uint64_t off, int leaf_fastest) {
+  const long total = B * (long)L;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    long b, i;
+    if (leaf_fastest) { b = e / L; i = e - b * L; } else { i = e / B; b = e - i * B; }
+    const uint64_t s = off + (uint64_t)b;
+    uint32_t o[4];
+    philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), (uint32_t)i, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    const uint64_t m = ((uint64_t)(o[0] >> 5) << 26) | (uint64_t)(o[1] >> 6);  // 53 random bits
+    leaf[b * ss + i * ls] = (double)m * 0x1.0p-53;
+  }
+}
+
+// ============================================================================
+// host side
+// ============================================================================
+static int ensure_device(fdg_graph *g) {
+  if (g->device >= 0) return FDG_OK;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error("no HIP device available (the evaluator has no CPU fallback)");
+    return FDG_E_NO_DEVICE;
+  }
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    return FDG_E_NO_DEVICE;
+  }
+  g->device = dev;
+  g->n_cu = prop.multiProcessorCount;
+  return FDG_OK;
+}
+
+static int ensure_ws(fdg_graph *g, size_t bytes) {
+  if (g->ws_bytes >= bytes && g->d_ws) return FDG_OK;
+  if (g->d_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws)); g->d_ws = nullptr; g->ws_bytes = 0; }
+  hipError_t e = hipMalloc(&g->d_ws, bytes);
+  if (e != hipSuccess) { set_error("hipMalloc(workspace) failed: " + std::string(hipGetErrorString(e))); return FDG_E_NOMEM; }
+  g->ws_bytes = bytes;
+  return FDG_OK;
+}
+
+static int ensure_code(fdg_graph *g) {
+  if (g->d_code) return FDG_OK;
+  const size_t nb = g->prog.code.size() * sizeof(uint32_t);
+  HIP_TRY(hipMalloc(&g->d_code, nb));
+  HIP_TRY(hipMemcpy(g->d_code, g->prog.code.data(), nb, hipMemcpyHostToDevice));
+  return FDG_OK;
+}
+
+static int ensure_module(fdg_graph *g) {
+  if (g->module || g->code_object.empty()) return FDG_OK;
+  hipModule_t m;
+  hipError_t e = hipModuleLoadData(&m, g->code_object.data());
+  if (e != hipSuccess) { set_error("hipModuleLoadData failed: " + std::string(hipGetErrorString(e))); return FDG_E_JIT; }
+  hipFunction_t f1, f2;
+  HIP_TRY(hipModuleGetFunction(&f1, m, "fdg_spec_sm"));
+  HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_spec_gen"));
+  g->module = m; g->fn_eval_sm = f1; g->fn_eval_gen = f2;
+  int v = 0;
+  if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_NUM_REGS, f1) == hipSuccess) g->spec_vgpr = (uint32_t)v;
+  if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, f1) == hipSuccess) g->spec_lds = (uint32_t)v;
+  if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f1) == hipSuccess) g->spec_scratch = (uint32_t)v;
+  return FDG_OK;
+}
+
+// mode 0: roots -> d_root; mode 1: partial sums -> d_acc
+static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
+               int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st) {
+  if (!g) { set_error("null handle"); return FDG_E_INVALID; }
+  if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
+  if (B == 0) return FDG_OK;
+  if ((g->prog.L && !d_leaf) || (mode == 0 && g->prog.R && !d_root) || (mode == 1 && !d_acc)) {
+    set_error("null device buffer"); return FDG_E_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(g->mu);
+  int rc = ensure_device(g);
+  if (rc) return rc;
+  const Lowered &p = g->prog;
+  const long nblk = (long)((B + 255) / 256);
+  const uint32_t R = p.R;
+
+  if (!g->code_object.empty()) {
+    rc = ensure_module(g);
+    if (rc) return rc;
+    const long grid = std::min<long>(nblk, (long)g->n_cu * 8);
+    double *partial = nullptr;
+    if (mode == 1) {
+      rc = ensure_ws(g, (size_t)grid * R * sizeof(double));
+      if (rc) return rc;
+      partial = (double *)g->d_ws;
+    }
+    hipFunction_t fn = (hipFunction_t)((ls == 1) ? g->fn_eval_sm : g->fn_eval_gen);
+    long a_ss = ss, a_ls = ls, a_rs = rs, a_rk = rk, a_B = B;
+    int a_mode = mode;
+    void *args[] = {(void *)&d_leaf, &a_ss, &a_ls, (void *)&d_root, &a_rs, &a_rk, (void *)&d_weight,
+                    (void *)&partial, &a_B, &a_mode};
+    HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, st, args, nullptr));
+    if (mode == 1) {
+      hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial,
+                         (uint32_t)grid, R, d_acc);
+      HIP_TRY(hipGetLastError());
+    }
+    return FDG_OK;
+  }
+
+  // interpreter
+  rc = ensure_code(g);
+  if (rc) return rc;
+  const bool staged = (ls == 1 && ss != 1 && p.L > 0);
+  const size_t lds_bytes = ((size_t)p.lds_slots + (mode ? 1u : 0u)) * 256u * sizeof(double);
+  int per_cu = lds_bytes ? (int)std::min<size_t>(8, (160u * 1024u) / lds_bytes) : 8;
+  if (per_cu < 1) { set_error("interpreter LDS budget exceeded"); return FDG_E_INTERNAL; }
+  const long grid = std::min<long>(nblk, (long)g->n_cu * per_cu);
+  const size_t per_block = (size_t)(p.mem_slots + (staged ? p.L : 0u) + (mode ? R : 0u)) * 256u;
+  const size_t ws_doubles = (size_t)grid * per_block + (mode ? (size_t)grid * R : 0u);
+  rc = ensure_ws(g, std::max<size_t>(ws_doubles, 1) * sizeof(double));
+  if (rc) return rc;
+  double *ws = (double *)g->d_ws;
+  double *partial = ws + (size_t)grid * per_block;
+  const uint32_t *code = (const uint32_t *)g->d_code;
+#define FDG_LAUNCH(M, S)                                                                              \
+  do {                                                                                                \
+    if (lds_bytes > 64 * 1024)                                                                        \
+      HIP_TRY(hipFuncSetAttribute((const void *)fdg_interp<M, S>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds_bytes));                                                   \
+    hipLaunchKernelGGL((fdg_interp<M, S>), dim3((unsigned)grid), dim3(256), lds_bytes, st, code, d_leaf, \
+                       (long)ss, (long)ls, d_root, (long)rs, (long)rk, d_weight, partial, (long)B, ws,  \
+                       p.lds_slots, p.mem_slots, p.L, R);                                              \
+  } while (0)
+  if (mode == 0) { if (staged) FDG_LAUNCH(0, true); else FDG_LAUNCH(0, false); }
+  else { if (staged) FDG_LAUNCH(1, true); else FDG_LAUNCH(1, false); }
+#undef FDG_LAUNCH
+  HIP_TRY(hipGetLastError());
+  if (mode == 1) {
+    hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial,
+                       (uint32_t)grid, R, d_acc);
+    HIP_TRY(hipGetLastError());
+  }
+  return FDG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// JIT
+// ---------------------------------------------------------------------------
+static uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull) {
+  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+
+static bool read_file(const std::string &path, std::vector<char> &out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  out.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  return !out.empty();
+}
+
+static bool write_file(const std::string &path, const char *data, size_t n) {
+  const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+  { std::ofstream f(tmp, std::ios::binary); if (!f) return false; f.write(data, (std::streamsize)n); if (!f) return false; }
+  return std::rename(tmp.c_str(), path.c_str()) == 0;
+}
+
+static int compile_hiprtc(const std::string &src, bool fast, std::vector<char> &co, std::string &log) {
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "fdg_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    log = "hiprtcCreateProgram failed"; return -1;
+  }
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", fast ? "-ffp-contract=fast" : "-ffp-contract=off"};
+  hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+  size_t ls = 0;
+  hiprtcGetProgramLogSize(prog, &ls);
+  if (ls > 1) { log.resize(ls); hiprtcGetProgramLog(prog, &log[0]); }
+  if (r != HIPRTC_SUCCESS) { hiprtcDestroyProgram(&prog); if (log.empty()) log = hiprtcGetErrorString(r); return -1; }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  co.resize(cs);
+  hiprtcGetCode(prog, co.data());
+  hiprtcDestroyProgram(&prog);
+  return 0;
+}
+
+static int compile_hipcc(const std::string &src_path, const std::string &out_path, bool fast, std::string &log) {
+  const char *hipcc = std::getenv("FDG_HIPCC");
+  std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " --genco --offload-arch=gfx950 -O3 " +
+                    (fast ? "-ffp-contract=fast" : "-ffp-contract=off") + " -o '" + out_path + "' '" + src_path +
+                    "' > '" + out_path + ".log' 2>&1";
+  int rc = std::system(cmd.c_str());
+  std::vector<char> l;
+  if (read_file(out_path + ".log", l)) log.assign(l.begin(), l.end());
+  std::remove((out_path + ".log").c_str());
+  return rc == 0 ? 0 : -1;
+}
+
+extern "C" {
+
+const char *fdg_last_error(void) { return fdg::last_error_cstr(); }
+int fdg_version(void) { return FDG_VERSION; }
+double fdg_powi(double x, int32_t n) { return fdg_powi_impl(x, n); }
+void fdg_free(void *p) { std::free(p); }
+
+int fdg_graph_create(const fdg_graph_desc *d, fdg_graph **out) {
+  if (!out) { set_error("null out pointer"); return FDG_E_INVALID; }
+  *out = nullptr;
+  std::string err;
+  int rc = validate_desc(d, err);
+  if (rc) { set_error(err); return rc; }
+  fdg_graph *g = new (std::nothrow) fdg_graph();
+  if (!g) { set_error("out of memory"); return FDG_E_NOMEM; }
+  Lowered &p = g->prog;
+  p.L = d->n_leaf; p.N = d->n_node; p.R = d->n_root; p.E = d->n_edge;
+  p.op.assign(d->op, d->op + p.N);
+  p.power.assign(d->power, d->power + p.N);
+  if (p.N) p.off.assign(d->child_off, d->child_off + p.N + 1); else p.off.assign(1, 0);
+  p.idx.assign(d->child_idx, d->child_idx + p.E);
+  p.fac.assign(d->child_fac, d->child_fac + p.E);
+  p.root_slot.assign(d->root_slot, d->root_slot + p.R);
+  analyse(p);
+  // LDS budget of the interpreter: enough slots for the whole live set when it
+  // is small (8 blocks/CU), otherwise 40 slots = 80 KiB per block (2 blocks/CU)
+  uint32_t budget = 40;
+  const char *env = std::getenv("FDG_LDS_SLOTS");
+  if (env) budget = (uint32_t)std::max(1, std::atoi(env));
+  budget = std::min(budget, 79u);
+  build_interpreter_program(p, budget);
+  *out = g;
+  return FDG_OK;
+}
+
+int fdg_graph_release_device(fdg_graph *g) {
+  if (!g) return FDG_OK;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->d_code) { hipFree(g->d_code); g->d_code = nullptr; }
+  if (g->d_ws) { hipFree(g->d_ws); g->d_ws = nullptr; g->ws_bytes = 0; }
+  if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; g->fn_eval_sm = g->fn_eval_gen = nullptr; }
+  return FDG_OK;
+}
+
+int fdg_graph_destroy(fdg_graph *g) {
+  if (!g) return FDG_OK;
+  fdg_graph_release_device(g);
+  delete g;
+  return FDG_OK;
+}
+
+int fdg_graph_query(const fdg_graph *g, fdg_graph_info *o) {
+  if (!g || !o) { set_error("null argument"); return FDG_E_INVALID; }
+  const Lowered &p = g->prog;
+  std::memset(o, 0, sizeof *o);
+  o->n_leaf = p.L; o->n_node = p.N; o->n_root = p.R; o->n_edge = p.E;
+  o->n_live_node = (uint32_t)p.order.size(); o->n_live_leaf = p.n_live_leaf;
+  o->flops_alg = p.flops_alg; o->bytes_alg = 8ull * ((uint64_t)p.L + p.R);
+  o->max_live = p.max_live; o->n_slot_lds = p.lds_slots; o->n_slot_mem = p.mem_slots; o->n_ops = p.n_ops;
+  o->specialized = g->code_object.empty() ? 0 : 1;
+  o->spec_vgpr = g->spec_vgpr; o->spec_lds_bytes = g->spec_lds; o->spec_scratch_bytes = g->spec_scratch;
+  return FDG_OK;
+}
+
+int fdg_graph_emit_source(const fdg_graph *g, unsigned flags, char **source) {
+  if (!g || !source) { set_error("null argument"); return FDG_E_INVALID; }
+  std::string s = emit_hip_source(g->prog, flags);
+  char *m = (char *)std::malloc(s.size() + 1);
+  if (!m) { set_error("out of memory"); return FDG_E_NOMEM; }
+  std::memcpy(m, s.c_str(), s.size() + 1);
+  *source = m;
+  return FDG_OK;
+}
+
+int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
+  if (!g) { set_error("null handle"); return FDG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  const bool fast = (flags & FDG_SPEC_FAST_MATH) != 0;
+  const std::string src = emit_hip_source(g->prog, flags);
+  char hbuf[40];
+  std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a(fast ? "fast" : "strict")));
+  std::string dir = cache_dir ? cache_dir : (std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache");
+  mkdir(dir.c_str(), 0777);
+  const std::string base = dir + "/fdg_" + hbuf;
+  std::vector<char> co;
+  if (!read_file(base + ".hsaco", co)) {
+    std::string log;
+    const char *force = std::getenv("FDG_JIT");  // "hipcc" forces the subprocess path
+    int rc = -1;
+    if (!(force && std::strcmp(force, "hipcc") == 0)) rc = compile_hiprtc(src, fast, co, log);
+    if (rc != 0) {
+      std::string log2;
+      if (!write_file(base + ".hip", src.c_str(), src.size())) { set_error("cannot write " + base + ".hip"); return FDG_E_JIT; }
+      rc = compile_hipcc(base + ".hip", base + ".hsaco", fast, log2);
+      if (!(flags & FDG_SPEC_KEEP_SOURCE)) std::remove((base + ".hip").c_str());
+      if (rc != 0 || !read_file(base + ".hsaco", co)) {
+        set_error("kernel specialization failed.\nhiprtc: " + log + "\nhipcc: " + log2);
+        return FDG_E_JIT;
+      }
+    } else {
+      write_file(base + ".hsaco", co.data(), co.size());
+    }
+  }
+  if ((flags & FDG_SPEC_KEEP_SOURCE)) write_file(base + ".hip", src.c_str(), src.size());
+  if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
+  g->code_object.swap(co);
+  g->spec_source_hash = hbuf;
+  g->spec_flags = flags;
+  return FDG_OK;
+}
+
+int fdg_eval_device(fdg_graph *g, const double *d_leaf, int64_t ss, int64_t ls, double *d_root, int64_t rs,
+                    int64_t rk, int64_t B, void *stream) {
+  return run(g, 0, d_leaf, ss, ls, d_root, rs, rk, nullptr, nullptr, B, (hipStream_t)stream);
+}
+
+int fdg_accumulate_device(fdg_graph *g, const double *d_leaf, int64_t ss, int64_t ls, const double *d_weight,
+                          double *d_acc, int64_t B, void *stream) {
+  return run(g, 1, d_leaf, ss, ls, nullptr, 0, 0, d_weight, d_acc, B, (hipStream_t)stream);
+}
+
+int fdg_eval(fdg_graph *g, const double *leaf, double *root, int64_t B) {
+  if (!g) { set_error("null handle"); return FDG_E_INVALID; }
+  if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
+  if (B == 0) return FDG_OK;
+  const size_t L = g->prog.L, R = g->prog.R;
+  if ((L && !leaf) || (R && !root)) { set_error("null host buffer"); return FDG_E_INVALID; }
+  { std::lock_guard<std::mutex> lk(g->mu); int rc = ensure_device(g); if (rc) return rc; }
+  double *dl = nullptr, *dr = nullptr;
+  HIP_TRY(hipMalloc(&dl, std::max<size_t>(1, (size_t)B * L) * 8));
+  if (hipMalloc(&dr, std::max<size_t>(1, (size_t)B * R) * 8) != hipSuccess) { hipFree(dl); set_error("hipMalloc failed"); return FDG_E_NOMEM; }
+  int rc = FDG_OK;
+  do {
+    if (L && hipMemcpy(dl, leaf, (size_t)B * L * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = FDG_E_NO_DEVICE; break; }
+    // eval_graph! leaves root entries it does not assign untouched: start from the caller's values
+    if (R && hipMemcpy(dr, root, (size_t)B * R * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = FDG_E_NO_DEVICE; break; }
+    rc = run(g, 0, dl, (int64_t)L, 1, dr, (int64_t)R, 1, nullptr, nullptr, B, nullptr);
+    if (rc) break;
+    if (hipDeviceSynchronize() != hipSuccess) { set_error("kernel execution failed"); rc = FDG_E_NO_DEVICE; break; }
+    if (R && hipMemcpy(root, dr, (size_t)B * R * 8, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H copy failed"); rc = FDG_E_NO_DEVICE; break; }
+  } while (0);
+  hipFree(dl); hipFree(dr);
+  return rc;
+}
+
+int fdg_fill_uniform_device(double *d_leaf, int64_t B, uint32_t L, int64_t ss, int64_t ls, uint64_t seed,
+                            uint64_t off, void *stream) {
+  if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
+  if (B == 0 || L == 0) return FDG_OK;
+  if (!d_leaf) { set_error("null device buffer"); return FDG_E_INVALID; }
+  const long total = (long)B * L;
+  const long grid = std::min<long>((total + 255) / 256, 256L * 16);
+  hipLaunchKernelGGL(fdg_fill_uniform, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_leaf, (long)B, L,
+                     (long)ss, (long)ls, seed, off, (ls <= ss) ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  return FDG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+"""Named graphs used by bench.py, the tests and ``__graft_entry__``.
+
+Each maps to a config of BASELINE.json:
+  sigma2            configs 1-2: optimized 2-loop Parquet self-energy (fixture)
+  sigma4_standin    config 3: seeded stand-in for the 4-loop Parquet self-energy
+                    (N = 10^4 nodes, L = 300; the real graph needs the Julia front end)
+  sigma4_taylor_standin  config 4: the same enlarged x3 with 2 % Power{2} nodes
+  synthetic_small   a 1000-node graph for quick parity runs
+"""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+
+from .nodetable import NodeTable, OP_POWER, OP_PROD, from_program, synthetic_parquet_like
+
+PREBUILT = ("sigma2", "synthetic_small", "sigma4_standin")
+
+
+@functools.lru_cache(maxsize=None)
+def get(name: str) -> NodeTable:
+    if name == "sigma2":
+        from .fixtures import sigma2_graphs
+        from .lowering import lower
+        t, _, _ = lower(sigma2_graphs()[0], name="sigma2")
+        t.name = "sigma2_parquet_nohartree_optimized"
+        return t
+    if name == "sigma4_standin":
+        return synthetic_parquet_like(10000, 300, 2, seed=20241220)
+    if name == "synthetic_small":
+        return synthetic_parquet_like(1000, 64, 2, seed=7)
+    if name == "sigma4_taylor_standin":
+        return _with_powers(synthetic_parquet_like(30000, 300, 6, seed=20241221), 0.02, 99)
+    raise KeyError(name)
+
+
+def _with_powers(t: NodeTable, frac: float, seed: int) -> NodeTable:
+    """Turn a fraction of two-child Prod nodes with equal children ... into
+    Power{2}: here simply re-type random single-use Prod nodes as Power{2} of
+    their first child (keeps the table topologically valid)."""
+    rng = np.random.default_rng(seed)
+    nodes = []
+    for n in range(t.n_node):
+        ch = t.children(n)
+        if int(t.op[n]) == OP_PROD and rng.random() < frac * 1.5:
+            nodes.append((OP_POWER, 2, [ch[0]]))
+        else:
+            nodes.append((int(t.op[n]), int(t.power[n]), ch))
+    return from_program(t.n_leaf, nodes, [int(r) for r in t.root_slot], t.name + "_pow")

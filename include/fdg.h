@@ -1,0 +1,173 @@
+/*
+ * fdg.h -- C ABI of the MI355X-native evaluator back end for
+ * FeynmanDiagram.jl's static computational graphs.
+ *
+ * This is the drop-in boundary.  The reference has no
+ * FFI for this path; each entry point below names the reference interface it
+ * stands in for (paths relative to the reference checkout):
+ *
+ *   fdg_graph_create      <- Compilers.compile / to_julia_str
+ *                            (src/backend/static.jl:98-133, 221-227): the host
+ *                            (Julia shim or the Python mirror) walks the graphs
+ *                            in the reference's order and hands over the flat
+ *                            node table; this call plays the role of
+ *                            Meta.parse + @RuntimeGeneratedFunction.
+ *   fdg_graph_specialize  <- the JIT step of compile (static.jl:225-226): emits
+ *                            a straight-line CDNA4 kernel for this one graph.
+ *   fdg_eval              <- the generated eval_graph!(root, leafVal)
+ *                            (static.jl:100,131) for B samples at once, in the
+ *                            batched layout of compile_Python
+ *                            (src/backend/compiler_python.jl:23,28,45-47).
+ *   fdg_eval_device       <- same, buffers already resident in HBM.
+ *   fdg_accumulate_device <- the user integrand's "sum weight*root over
+ *                            samples" step around eval_graph!
+ *                            (example/benchmark.jl:58-87), fused so roots never
+ *                            travel to HBM.
+ *   fdg_fill_uniform_device <- test/bench harness: counter-based leaf values on
+ *                            device (the examples draw them from MCIntegration).
+ *   fdg_graph_destroy, fdg_graph_query, fdg_last_error: lifetime / errors
+ *                            (Julia exceptions in the reference, static.jl:6-11).
+ *
+ * Conventions: every function returns 0 on success and a negative FDG_E_* code
+ * on failure; fdg_last_error() returns a thread-local message.  All buffers are
+ * owned by the caller.  A handle is immutable after create/specialize, so the
+ * eval entry points are re-entrant across streams and threads.  There is no CPU
+ * fallback anywhere behind this ABI: device entry points fail with
+ * FDG_E_NO_DEVICE when no gfx950 device is usable.
+ *
+ * Node table (value index space): leaves 0..n_leaf-1 in leafVal order, then
+ * internal nodes n_leaf..n_leaf+n_node-1 in statement order; every child index
+ * is smaller than its node's index.
+ *
+ * Arithmetic contract (what "identical results" means): fp64, no FMA
+ * contraction, n-ary Sum/Prod evaluated as the left folds the reference's
+ * generated code performs (static.jl:13-31 + Julia's left-associative n-ary
+ * + and *):  Sum  = (((c1[*f1]) + (c2[*f2])) + ...),
+ *            Prod = ((((c1[*f1]) * c2)[*f2]) * ...),
+ *            Power{2} = c*c, Power{3} = c*c*c, other N = fdg_powi(c, N),
+ * a factor is applied only when it differs from 1 (static.jl:15,18,25,28).
+ */
+#ifndef FDG_H
+#define FDG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDG_VERSION 100 /* 0.1.0 */
+
+#define FDG_OP_SUM 0u
+#define FDG_OP_PROD 1u
+#define FDG_OP_POWER 2u
+#define FDG_NO_ROOT 0xFFFFFFFFu /* root id not present in any graph: root[k] left untouched */
+
+enum {
+  FDG_OK = 0,
+  FDG_E_INVALID = -1,    /* malformed table / bad argument */
+  FDG_E_UNSUPPORTED = -2,/* unknown operator (static.jl:6-11) */
+  FDG_E_NO_DEVICE = -3,  /* no usable gfx950 device / HIP runtime failure */
+  FDG_E_NOMEM = -4,
+  FDG_E_JIT = -5,        /* kernel specialization failed */
+  FDG_E_INTERNAL = -6
+};
+
+typedef struct fdg_graph_desc {
+  uint32_t n_leaf;            /* L */
+  uint32_t n_node;            /* N internal nodes */
+  uint32_t n_root;            /* R */
+  uint32_t n_edge;            /* E = child_off[n_node] */
+  const uint8_t *op;          /* [N] FDG_OP_* */
+  const int32_t *power;       /* [N] exponent for FDG_OP_POWER, ignored otherwise */
+  const uint32_t *child_off;  /* [N+1] */
+  const uint32_t *child_idx;  /* [E] value index of each operand */
+  const double *child_fac;    /* [E] subgraph_factors */
+  const uint32_t *root_slot;  /* [R] value index written to root[k], or FDG_NO_ROOT */
+} fdg_graph_desc;
+
+typedef struct fdg_graph fdg_graph; /* opaque */
+
+/* What the lowering did; all counts are per graph, not per sample. */
+typedef struct fdg_graph_info {
+  uint32_t n_leaf, n_node, n_root, n_edge;
+  uint32_t n_live_node;     /* internal nodes reachable from a root */
+  uint32_t n_live_leaf;     /* leaves reachable from a root */
+  uint64_t flops_alg;       /* adds + mults + factor mults + power mults, reachable part */
+  uint64_t bytes_alg;       /* 8*(L+R): algorithmic HBM bytes per evaluation */
+  uint32_t max_live;        /* peak number of simultaneously live values (leaves on demand) */
+  uint32_t n_slot_lds;      /* per-sample fp64 slots kept in LDS by the interpreter */
+  uint32_t n_slot_mem;      /* per-sample fp64 slots kept in the HBM workspace panel */
+  uint32_t n_ops;           /* micro-ops in the interpreter stream */
+  int32_t specialized;      /* 1 when a straight-line kernel is loaded */
+  uint32_t spec_vgpr, spec_lds_bytes, spec_scratch_bytes; /* of the specialized kernel */
+} fdg_graph_info;
+
+/* flags for fdg_graph_specialize */
+#define FDG_SPEC_DEFAULT 0u
+#define FDG_SPEC_KEEP_SOURCE 1u   /* leave the generated source next to the code object */
+#define FDG_SPEC_FAST_MATH 2u     /* allow FMA contraction: NOT parity-exact, reported separately */
+
+const char *fdg_last_error(void);
+int fdg_version(void);
+
+/* Host-only: validates and lowers the table (dead-code elimination, slot
+ * allocation, interpreter stream).  Needs no device. */
+int fdg_graph_create(const fdg_graph_desc *desc, fdg_graph **out);
+int fdg_graph_destroy(fdg_graph *g);
+int fdg_graph_query(const fdg_graph *g, fdg_graph_info *info);
+
+/* Emits HIP source for a straight-line kernel of this graph (one lane = one
+ * sample, values in VGPRs, compiler-managed overflow) and returns it as a
+ * malloc'ed NUL-terminated string the caller frees with fdg_free.  Host-only. */
+int fdg_graph_emit_source(const fdg_graph *g, unsigned flags, char **source);
+void fdg_free(void *p);
+
+/* JIT: emit + compile for gfx950 (hiprtc, else `hipcc --genco`) + cache the code
+ * object in cache_dir (NULL: $FDG_CACHE_DIR or /tmp/fdg-cache).  The module is
+ * loaded lazily on first device use, so this works without a device present
+ * (cross-compile at build time, run on the GPU box). */
+int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags);
+
+/* Evaluate B samples, buffers in device memory.
+ *   leaf value i of sample b : d_leaf[b*leaf_sample_stride + i*leaf_leaf_stride]
+ *   root value k of sample b : d_root[b*root_sample_stride + k*root_root_stride]
+ * (strides in elements).  compile_Python's row-major [B,L] / [B,R] is
+ * (L,1)/(R,1); a Julia column-major B x L matrix is (1,B)/(1,B).
+ * stream: hipStream_t (NULL = default stream).  Asynchronous. */
+int fdg_eval_device(fdg_graph *g, const double *d_leaf, int64_t leaf_sample_stride,
+                    int64_t leaf_leaf_stride, double *d_root, int64_t root_sample_stride,
+                    int64_t root_root_stride, int64_t n_sample, void *stream);
+
+/* Host-buffer convenience: row-major leaf[B,L] -> root[B,R]; H2D, eval, D2H,
+ * synchronous.  Same in-place semantics as eval_graph!(root, leafVal). */
+int fdg_eval(fdg_graph *g, const double *leaf, double *root, int64_t n_sample);
+
+/* d_acc[k] += sum_b weight[b] * root_k(b)   (d_weight may be NULL: weight 1).
+ * Block-level pairwise reduction, one fp64 atomicAdd per block and root.
+ * d_acc must hold n_root doubles and be zeroed by the caller. */
+int fdg_accumulate_device(fdg_graph *g, const double *d_leaf, int64_t leaf_sample_stride,
+                          int64_t leaf_leaf_stride, const double *d_weight, double *d_acc,
+                          int64_t n_sample, void *stream);
+
+/* d_leaf[b*ss + i*ls] = U[0,1) from Philox4x32-10, key = seed, counter =
+ * (sample_offset + b, i): independent of launch geometry and of how samples
+ * are sharded over GPUs. */
+int fdg_fill_uniform_device(double *d_leaf, int64_t n_sample, uint32_t n_leaf,
+                            int64_t leaf_sample_stride, int64_t leaf_leaf_stride, uint64_t seed,
+                            uint64_t sample_offset, void *stream);
+
+/* Device workspace control: the interpreter keeps per-sample overflow slots in
+ * an HBM panel owned by the handle; it is sized on first use for the number of
+ * resident waves.  This releases it (and any loaded module). */
+int fdg_graph_release_device(fdg_graph *g);
+
+/* Integer power used for Power{N}, |N| >= 4 (and N < 0): exposed so host-side
+ * checkers can call the very same routine.  Pure host function. */
+double fdg_powi(double x, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDG_H */

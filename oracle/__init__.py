@@ -1,0 +1,251 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY (not shipped, never on the product path).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package.  It holds
+
+* ``eval_static`` / ``eval_interp``: ctypes front end of ``fdg_oracle.c``, the C
+  restatement of the reference's compiled evaluator (src/backend/static.jl:13-46,
+  98-133) and of its tree interpreter (src/computational_graph/eval.jl:1-39);
+* ``eval_static_numpy``: an independent numpy twin of the same arithmetic
+  (vectorised over samples; IEEE elementwise ops, so bit-identical to the C);
+* ``philox_uniform``: numpy twin of the device leaf generator (Philox4x32-10);
+* ``CBaseline``: compiles C text of the reference's ``to_Cstr`` shape
+  (static.jl:155-197) with gcc and times it -- the CPU baseline of bench.py.
+
+Parity status: pinned by the reference's own known-answer tests for this path
+(tests/test_oracle_kat.py); the reference (Julia) cannot run here, so there is
+no oracle/_ref build.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import tempfile
+import time
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libfdg_oracle.so")
+OP_SUM, OP_PROD, OP_POWER = 0, 1, 2
+NO_ROOT = 0xFFFFFFFF
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "fdg_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libfdg_oracle.so"])
+    return _LIB
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        u32, i64, p = C.c_uint32, C.c_int64, C.c_void_p
+        sig = [u32, u32, u32, p, p, p, p, p, p, p, i64, i64, p, i64, i64, i64]
+        L.oracle_eval_static.argtypes = sig
+        L.oracle_eval_interp.argtypes = sig
+        L.oracle_root_scale.argtypes = [u32, u32, u32, p, p, p, p, p, p, p, i64, i64, p, i64]
+        L.oracle_powi.argtypes = [C.c_double, C.c_int32]
+        L.oracle_powi.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _arrs(t):
+    return (np.ascontiguousarray(t.op, np.uint8), np.ascontiguousarray(t.power, np.int32),
+            np.ascontiguousarray(t.child_off, np.uint32), np.ascontiguousarray(t.child_idx, np.uint32),
+            np.ascontiguousarray(t.child_fac, np.float64), np.ascontiguousarray(t.root_slot, np.uint32))
+
+
+def _eval(fn_name: str, t, leaf: np.ndarray, root: Optional[np.ndarray]) -> np.ndarray:
+    leaf = np.ascontiguousarray(leaf, dtype=np.float64)
+    if leaf.ndim == 1:
+        leaf = leaf[None, :]
+    B = leaf.shape[0]
+    L, N, R = int(t.n_leaf), int(t.op.shape[0]), int(t.root_slot.shape[0])
+    if leaf.shape[1] < L:
+        raise IndexError("leafVal too short")
+    if root is None:
+        root = np.zeros((B, R), dtype=np.float64)
+    op, pw, off, idx, fac, rs = _arrs(t)
+    rc = getattr(_load(), fn_name)(L, N, R, op.ctypes.data, pw.ctypes.data, off.ctypes.data, idx.ctypes.data,
+                                   fac.ctypes.data, rs.ctypes.data, leaf.ctypes.data, leaf.shape[1], 1,
+                                   root.ctypes.data, R, 1, B)
+    if rc != 0:
+        raise RuntimeError(f"oracle failed: {rc}")
+    return root
+
+
+def eval_static(table, leaf, root=None) -> np.ndarray:
+    """Compiled-evaluator arithmetic (static.jl).  leaf [B, >=L] -> root [B, R]."""
+    return _eval("oracle_eval_static", table, leaf, root)
+
+
+def eval_interp(table, leaf, root=None) -> np.ndarray:
+    """Interpreter arithmetic (eval.jl)."""
+    return _eval("oracle_eval_interp", table, leaf, root)
+
+
+def root_scale(table, leaf) -> np.ndarray:
+    """S_k(b): sum of |terms| of each root's Sum node (comparison scale)."""
+    leaf = np.ascontiguousarray(leaf, dtype=np.float64)
+    B = leaf.shape[0]
+    L, N, R = int(table.n_leaf), int(table.op.shape[0]), int(table.root_slot.shape[0])
+    out = np.zeros((B, R), dtype=np.float64)
+    op, pw, off, idx, fac, rs = _arrs(table)
+    rc = _load().oracle_root_scale(L, N, R, op.ctypes.data, pw.ctypes.data, off.ctypes.data, idx.ctypes.data,
+                                   fac.ctypes.data, rs.ctypes.data, leaf.ctypes.data, leaf.shape[1], 1,
+                                   out.ctypes.data, B)
+    if rc != 0:
+        raise RuntimeError(f"oracle failed: {rc}")
+    return out
+
+
+def powi(x: float, n: int) -> float:
+    return float(_load().oracle_powi(float(x), int(n)))
+
+
+def _powi_numpy(x: np.ndarray, n: int) -> np.ndarray:
+    if n == 2:
+        return x * x
+    if n == 3:
+        return x * x * x
+    return np.array([powi(v, n) for v in x.ravel()], dtype=np.float64).reshape(x.shape)
+
+
+def eval_static_numpy(table, leaf: np.ndarray) -> np.ndarray:
+    """Independent twin of ``eval_static`` in numpy (python loop over nodes)."""
+    leaf = np.asarray(leaf, dtype=np.float64)
+    if leaf.ndim == 1:
+        leaf = leaf[None, :]
+    L = int(table.n_leaf)
+    N = int(table.op.shape[0])
+    vals = [leaf[:, i] for i in range(L)] + [None] * N
+    off, idx, fac = table.child_off, table.child_idx, table.child_fac
+    for n in range(N):
+        a, b = int(off[n]), int(off[n + 1])
+        o = int(table.op[n])
+        if o == OP_POWER:
+            acc = _powi_numpy(vals[int(idx[a])], int(table.power[n]))
+            if fac[a] != 1.0:
+                acc = acc * fac[a]
+        elif o == OP_SUM:
+            acc = vals[int(idx[a])]
+            if fac[a] != 1.0:
+                acc = acc * fac[a]
+            for e in range(a + 1, b):
+                t = vals[int(idx[e])]
+                if fac[e] != 1.0:
+                    t = t * fac[e]
+                acc = acc + t
+        elif o == OP_PROD:
+            acc = vals[int(idx[a])]
+            if fac[a] != 1.0:
+                acc = acc * fac[a]
+            for e in range(a + 1, b):
+                acc = acc * vals[int(idx[e])]
+                if fac[e] != 1.0:
+                    acc = acc * fac[e]
+        else:
+            raise NotImplementedError("operator")
+        vals[L + n] = acc
+    R = int(table.root_slot.shape[0])
+    out = np.zeros((leaf.shape[0], R), dtype=np.float64)
+    for k in range(R):
+        s = int(table.root_slot[k])
+        if s != NO_ROOT:
+            out[:, k] = vals[s]
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# Philox4x32-10 twin of the device generator (fdg_fill_uniform_device)
+# --------------------------------------------------------------------------- #
+def philox_uniform(B: int, L: int, seed: int, sample_offset: int = 0) -> np.ndarray:
+    b = (np.arange(B, dtype=np.uint64) + np.uint64(sample_offset))[:, None]
+    i = np.arange(L, dtype=np.uint64)[None, :]
+    c0 = np.broadcast_to(b & np.uint64(0xFFFFFFFF), (B, L)).copy()
+    c1 = np.broadcast_to(b >> np.uint64(32), (B, L)).copy()
+    c2 = np.broadcast_to(i, (B, L)).copy()
+    c3 = np.zeros((B, L), dtype=np.uint64)
+    k0 = np.uint64(seed & 0xFFFFFFFF)
+    k1 = np.uint64((seed >> 32) & 0xFFFFFFFF)
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ k0
+        n1 = p1 & MASK
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ k1
+        n3 = p0 & MASK
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & MASK
+        k1 = (k1 + np.uint64(0xBB67AE85)) & MASK
+    m = ((c0 >> np.uint64(5)) << np.uint64(26)) | (c1 >> np.uint64(6))
+    return m.astype(np.float64) * 2.0 ** -53
+
+
+# --------------------------------------------------------------------------- #
+# CPU baseline: the reference's C back-end text compiled by gcc
+# --------------------------------------------------------------------------- #
+_DRIVER = r"""
+#include <pthread.h>
+#include <stdint.h>
+typedef struct { const double *leaf; double *root; int64_t b0, b1, L, R; } job_t;
+static void *worker(void *p) {
+  job_t *j = (job_t *)p;
+  for (int64_t b = j->b0; b < j->b1; ++b)
+    eval_graph(j->root + b * j->R, (double *)(j->leaf + b * j->L));   /* one sample per call (static.jl:100) */
+  return 0;
+}
+int run_batch(const double *leaf, double *root, int64_t B, int64_t L, int64_t R, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  pthread_t th[256]; job_t jobs[256];
+  for (int t = 0; t < nthreads; ++t) {
+    jobs[t].leaf = leaf; jobs[t].root = root; jobs[t].L = L; jobs[t].R = R;
+    jobs[t].b0 = B * t / nthreads; jobs[t].b1 = B * (t + 1) / nthreads;
+    if (t) pthread_create(&th[t], 0, worker, &jobs[t]);
+  }
+  worker(&jobs[0]);
+  for (int t = 1; t < nthreads; ++t) pthread_join(th[t], 0);
+  return 0;
+}
+"""
+
+
+class CBaseline:
+    """gcc -O2 -ffp-contract=off build of ``void eval_graph(double *root, double
+    *leafVal)`` text in the reference's to_Cstr shape, called once per sample."""
+
+    def __init__(self, c_text: str, n_leaf: int, n_root: int, opt: str = "-O2"):
+        self.n_leaf, self.n_root = n_leaf, n_root
+        self._dir = tempfile.mkdtemp(prefix="fdg_cbase_")
+        src = os.path.join(self._dir, "eval_graph.c")
+        with open(src, "w") as f:
+            f.write("#include <math.h>\n")       # compile_C header (static.jl:272-276)
+            f.write(c_text)
+            f.write("\n")
+            f.write(_DRIVER)
+        so = os.path.join(self._dir, "eval_graph.so")
+        t0 = time.time()
+        subprocess.check_call(["gcc", opt, "-ffp-contract=off", "-fPIC", "-shared", "-pthread", src, "-o", so, "-lm"])
+        self.compile_seconds = time.time() - t0
+        self._lib = C.CDLL(so)
+        self._lib.run_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int]
+
+    def __call__(self, leaf: np.ndarray, nthreads: int = 1) -> np.ndarray:
+        leaf = np.ascontiguousarray(leaf, dtype=np.float64)
+        B = leaf.shape[0]
+        assert leaf.shape[1] == self.n_leaf
+        root = np.zeros((B, self.n_root), dtype=np.float64)
+        self._lib.run_batch(leaf.ctypes.data, root.ctypes.data, B, self.n_leaf, self.n_root, nthreads)
+        return root

@@ -1,0 +1,61 @@
+"""Generates the committed fixtures under tests/golden/.
+
+Two kinds of data, kept apart:
+
+* ``kat.json`` -- known answers copied from the reference's own tests (values
+  only; see the ``source`` field of each entry for file:line).
+* ``*.npz`` -- node tables plus seeded leaf inputs and the roots our CPU
+  restatement (oracle/fdg_oracle.c) produces for them.  SELF-GENERATED, NOT
+  PRODUCED BY JULIA: Julia is not installed in this environment, so the
+  reference evaluator itself cannot be run.  They guard
+  against regressions of the oracle and give the GPU tests fixed vectors.
+
+Run from the repository root:  python tests/golden/make_golden.py
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import oracle  # noqa: E402
+from feynmandiagram_jl_amd import workloads  # noqa: E402
+
+
+def main():
+    kat = [
+        dict(name="compiler_jl", source="test/compiler.jl:4-15,19-28", leaf=[1.0, 2.0], expect=[4.5],
+             note="eval_graph!(root, leaf) ≈ (leaf[1]+leaf[2])*1.5 and returns that value"),
+        dict(name="evaluation_g3_g4_g5", source="test/computational_graph.jl:874-887", leaf="ones",
+             expect=[26.0, 27.0, 702.0], note="exact =="),
+        dict(name="taylor_getdiagram_spin0.5", source="test/taylor.jl:115-161,181-202", leaf="ones",
+             expect=[(-2 + 0.5) / (2 * math.pi) ** 3], note="≈ (rtol sqrt(eps))"),
+        dict(name="front_end_getdiagram_spin1.0", source="test/front_end.jl:287-309", leaf="ones",
+             expect=[(-2 + 1.0) / (2 * math.pi) ** 3], note="≈"),
+        dict(name="sigma2_all_ones", source="assets/sigma_o2.svg + README.md:59-72 (structure); value by restated evaluation",
+             leaf="ones", expect=[1.0, -1.0], note="not a Julia-produced value"),
+    ]
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat, f, indent=1, ensure_ascii=False)
+
+    for name, B, seed in (("sigma2", 257, 1234), ("synthetic_small", 64, 1234), ("sigma4_standin", 16, 1234)):
+        t = workloads.get(name)
+        leaf = oracle.philox_uniform(B, t.n_leaf, seed)
+        root = oracle.eval_static(t, leaf)
+        root_interp = oracle.eval_interp(t, leaf)
+        assert np.array_equal(root, oracle.eval_static_numpy(t, leaf))
+        tn = t.normalized()
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), n_leaf=np.int64(tn.n_leaf), op=tn.op, power=tn.power,
+                            child_off=tn.child_off, child_idx=tn.child_idx, child_fac=tn.child_fac,
+                            root_slot=tn.root_slot, name=np.array(tn.name),
+                            leaf_pos=tn.leaf_positions().astype(np.uint32),
+                            seed=np.int64(seed), leaf=leaf, root_static=root, root_interp=root_interp)
+        print(name, t.stats(), root[0])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,206 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the
+oracle on the same seeded inputs.  fp64; the bar is bit-exact (the kernels keep
+the reference's association and never contract), the stated tolerance of
+BASELINE.json (1e-12, scaled by the root's term magnitudes) is the fallback bar
+for accumulate mode only, where the summation order over samples differs."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import feynmandiagram_jl_amd as fd
+from feynmandiagram_jl_amd import capi, fixtures, workloads
+from feynmandiagram_jl_amd.lowering import lower
+from feynmandiagram_jl_amd.nodetable import FDG_NO_ROOT, NodeTable, OP_POWER, OP_PROD, OP_SUM, from_program
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-12
+
+
+def dev_leaves(cuda, B, L, seed=1234, offset=0, layout="sample_major"):
+    import torch
+    if layout == "sample_major":
+        leaf = torch.empty((B, L), dtype=torch.float64, device=cuda)
+    elif layout == "leaf_major":          # a Julia column-major B x L matrix
+        leaf = torch.empty((L, B), dtype=torch.float64, device=cuda).t()
+    else:                                  # padded rows: stride L+3
+        leaf = torch.empty((B, L + 3), dtype=torch.float64, device=cuda)[:, :L]
+    capi.fill_uniform_device(leaf.data_ptr(), B, L, leaf.stride(0), leaf.stride(1), seed, offset,
+                             torch.cuda.current_stream().cuda_stream)
+    return leaf
+
+
+def run(f, leaf):
+    import torch
+    root = f(None, leaf)
+    torch.cuda.synchronize()
+    return root.cpu().numpy()
+
+
+@pytest.mark.parametrize("spec", [False, True], ids=["interp", "specialized"])
+@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin"])
+def test_golden_vectors_on_device(libfdg, cuda, name, spec):
+    import torch
+    z = np.load(os.path.join(GOLD, f"{name}.npz"))
+    t = NodeTable.load(os.path.join(GOLD, f"{name}.npz"))
+    f = fd.compile_table(t, specialize=spec)
+    leaf = torch.from_numpy(z["leaf"]).to(cuda)
+    assert np.array_equal(run(f, leaf), z["root_static"])
+    # host-buffer entry point (fdg_eval): same result
+    assert np.array_equal(f(None, z["leaf"]), z["root_static"])
+
+
+def test_device_philox_matches_twin(libfdg, cuda):
+    for B, L, seed, off in ((1000, 8, 1234, 0), (257, 300, 7, 10**12), (3, 1, 2**63 + 5, 2**40)):
+        for layout in ("sample_major", "leaf_major", "padded"):
+            leaf = dev_leaves(cuda, B, L, seed, off, layout)
+            assert np.array_equal(leaf.cpu().numpy(), oracle.philox_uniform(B, L, seed, off)), (B, L, layout)
+
+
+@pytest.mark.parametrize("spec", [False, True], ids=["interp", "specialized"])
+@pytest.mark.parametrize("layout", ["sample_major", "leaf_major", "padded"])
+@pytest.mark.parametrize("name,B", [("sigma2", 100003), ("synthetic_small", 5000), ("sigma4_standin", 1500)])
+def test_parity_layouts(libfdg, cuda, name, B, layout, spec):
+    t = workloads.get(name)
+    f = fd.compile_table(t, specialize=spec)
+    leaf = dev_leaves(cuda, B, t.n_leaf, 4321, 17, layout)
+    got = run(f, leaf)
+    want = oracle.eval_static(t, leaf.cpu().numpy())
+    assert np.array_equal(got, want), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("spec", [False, True], ids=["interp", "specialized"])
+def test_kat_through_device(libfdg, cuda, spec):
+    # test/compiler.jl:4-15 through the GraphFunc call convention
+    g, leaf, expect = fixtures.kat_compiler_jl()
+    f, leafmap = fd.Compilers.compile([g], specialize=spec)
+    root = [0.0]
+    ret = f(root, leaf)
+    assert root == [4.5] and ret == 4.5 and len(leafmap) == 2
+    # test/computational_graph.jl:874-887
+    graphs, exp = fixtures.kat_evaluation()
+    f, lm = fd.Compilers.compile(list(graphs), specialize=spec)
+    root = [0.0, 0.0, 0.0]
+    ret = f(root, [1.0] * len(lm))
+    assert root == list(exp) and ret == exp[-1]
+    # vectors too short: BoundsError like the generated Julia function
+    with pytest.raises(IndexError):
+        f(root, [1.0])
+    with pytest.raises(IndexError):
+        f([0.0], [1.0] * len(lm))
+    # taylor.jl getdiagram
+    r, e = fixtures.kat_taylor_getdiagram(0.5)
+    f, lm = fd.Compilers.compile([r], specialize=spec)
+    root = [0.0]
+    f(root, [1.0] * 6)
+    assert abs(root[0] - e) <= 1.5e-8 * abs(e)
+
+
+@pytest.mark.parametrize("spec", [False, True], ids=["interp", "specialized"])
+def test_edge_cases(libfdg, cuda, spec):
+    import torch
+    # leaf as root, interior root, missing root id (left untouched), duplicate id, Power nodes, fan-in 40
+    a, b, c = fd.Graph([]), fd.Graph([]), fd.Graph([])
+    s = a + b
+    wide = fd.Graph([a, b, c] * 13 + [s], subgraph_factors=[(-1.0) ** i * (1 + i % 3) for i in range(40)], operator=fd.Sum())
+    p = fd.Graph([wide, s, a, a], subgraph_factors=[1.0, -0.5, 1.0, 3.0], operator=fd.Prod())
+    pw = [s ** 2, s ** 3, c ** 5, c ** -1, c ** -2, c ** -4, fd.Graph([p], operator=fd.Power(7), subgraph_factors=[0.125])]
+    graphs = [p, wide] + pw
+    roots = [a.id, p.id, 424242, p.id, wide.id] + [g.id for g in pw]
+    t, _, _ = lower(graphs, root=roots)
+    assert int(t.root_slot[2]) == FDG_NO_ROOT
+    f = fd.compile_table(t, specialize=spec)
+    for B in (1, 63, 64, 255, 256, 257, 1025):
+        leaf = dev_leaves(cuda, B, t.n_leaf, 99, 0) + 0.25
+        root = torch.full((B, t.n_root), -7.0, dtype=torch.float64, device=cuda)
+        f(root, leaf)
+        torch.cuda.synchronize()
+        want = oracle.eval_static(t, leaf.cpu().numpy(), np.full((B, t.n_root), -7.0))
+        got = root.cpu().numpy()
+        assert np.array_equal(got[:, 2], np.full(B, -7.0))
+        assert np.array_equal(got, want), (B, np.abs(got - want).max())
+    # empty batch: nothing happens, nothing fails
+    leaf0 = torch.empty((0, t.n_leaf), dtype=torch.float64, device=cuda)
+    out0 = f(None, leaf0)
+    assert out0.shape == (0, t.n_root)
+    # non-contiguous root (column-major), same values
+    B = 300
+    leaf = dev_leaves(cuda, B, t.n_leaf, 5, 0) + 0.25
+    root = torch.full((t.n_root, B), -7.0, dtype=torch.float64, device=cuda).t()
+    f(root, leaf)
+    torch.cuda.synchronize()
+    assert np.array_equal(root.cpu().numpy(), oracle.eval_static(t, leaf.cpu().numpy(), np.full((B, t.n_root), -7.0)))
+
+
+@pytest.mark.parametrize("spec", [False, True], ids=["interp", "specialized"])
+def test_accumulate(libfdg, cuda, spec):
+    import torch
+    for name, B in (("sigma2", 200001), ("synthetic_small", 3000)):
+        t = workloads.get(name)
+        f = fd.compile_table(t, specialize=spec)
+        leaf = dev_leaves(cuda, B, t.n_leaf, 77, 0)
+        w = torch.rand(B, dtype=torch.float64, device=cuda)
+        acc = f.accumulate(leaf, w)
+        acc1 = f.accumulate(leaf, None)
+        torch.cuda.synchronize()
+        ref = oracle.eval_static(t, leaf.cpu().numpy())
+        wn = w.cpu().numpy()[:, None]
+        want = (ref * wn).sum(0)
+        scale = np.abs(ref * wn).sum(0)
+        assert np.all(np.abs(acc.cpu().numpy() - want) <= TOL * np.maximum(1.0, scale))
+        assert np.all(np.abs(acc1.cpu().numpy() - ref.sum(0)) <= TOL * np.maximum(1.0, np.abs(ref).sum(0)))
+        # accumulates on top of the previous content, deterministically
+        acc2 = f.accumulate(leaf, w, acc.clone())
+        acc3 = f.accumulate(leaf, w, acc.clone())
+        torch.cuda.synchronize()
+        assert torch.equal(acc2, acc3)
+        assert np.all(np.abs(acc2.cpu().numpy() - 2 * want) <= 2 * TOL * np.maximum(1.0, scale))
+
+
+def test_config2_sigma2_ten_million_samples(libfdg, cuda):
+    """BASELINE.json config 2: 2-loop sigma, fp64, 10^7 samples, compared with the
+    CPU reference within 1e-12 (scaled); we additionally require 0 ulp."""
+    import torch
+    t = workloads.get("sigma2")
+    B = 10_000_000
+    leaf = dev_leaves(cuda, B, 8, 1234, 0)
+    h_leaf = leaf.cpu().numpy()
+    want = oracle.eval_static(t, h_leaf)
+    scale = oracle.root_scale(t, h_leaf)
+    for spec in (True, False):
+        f = fd.compile_table(t, specialize=spec)
+        got = run(f, leaf)
+        assert np.all(np.abs(got - want) <= TOL * np.maximum(1.0, scale))
+        assert np.array_equal(got, want)
+
+
+def test_full_size_properties_sigma4(libfdg, cuda):
+    """Size-independent properties at a large batch of the headline graph (no CPU
+    oracle over the whole batch): chunk invariance (a sample's roots do not
+    depend on where it sits in the batch or on the batch size), interpreter ==
+    specialized kernel bit for bit, layout invariance, determinism, and a
+    seeded spot check of 2000 scattered samples against the oracle."""
+    import torch
+    t = workloads.get("sigma4_standin")
+    B = 1 << 19
+    fs = fd.compile_table(t, specialize=True)
+    fi = fd.compile_table(t, specialize=False)
+    leaf = dev_leaves(cuda, B, t.n_leaf, 2024, 0)
+    r_spec = fs(None, leaf)
+    r_spec2 = fs(None, leaf)
+    r_int = fi(None, leaf[: B // 8])
+    torch.cuda.synchronize()
+    assert torch.equal(r_spec, r_spec2)
+    assert torch.equal(r_spec[: B // 8], r_int)
+    a = fs(None, leaf[12345:12345 + 70001])
+    torch.cuda.synchronize()
+    assert torch.equal(a, r_spec[12345:12345 + 70001])
+    lt = leaf.t().contiguous().t()
+    b = fs(None, lt)
+    torch.cuda.synchronize()
+    assert torch.equal(b, r_spec)
+    idx = np.random.default_rng(0).choice(B, 2000, replace=False)
+    sub = leaf[torch.from_numpy(idx).to(cuda)].cpu().numpy()
+    assert np.array_equal(r_spec.cpu().numpy()[idx], oracle.eval_static(t, sub))

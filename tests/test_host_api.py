@@ -1,0 +1,245 @@
+"""Host-side mirror of the reference interface (graph model, lowering order,
+text emitters, Compilers API) and the C-ABI library surface.  CPU only: no
+compute call is made through the library here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import feynmandiagram_jl_amd as fd
+from feynmandiagram_jl_amd import Compilers, capi, fixtures, workloads
+from feynmandiagram_jl_amd.graph import Graph, Power, Prod, Sum, Unitary, PostOrderDFS, reset_uid
+from feynmandiagram_jl_amd.lowering import lower
+from feynmandiagram_jl_amd.nodetable import OP_POWER, OP_PROD, OP_SUM, from_program
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- graph model ---------------------------------------------------------- #
+def test_factor_becomes_wrapping_prod():
+    # graph.jl:69-73
+    g = Graph.new([], factor=2)
+    assert isinstance(g.operator, Prod) and len(g.subgraphs) == 1 and g.subgraph_factors == [2.0]
+    assert Graph.new([], factor=1.0).subgraphs == []
+    with pytest.raises(ValueError):
+        Graph([], factor=2.0)
+
+
+def test_scalar_mul_merges_trivial_unary():
+    # graph.jl:136-144
+    g1 = Graph([])
+    g2 = Graph.new([], factor=2)
+    h = 5 * g2
+    assert h.subgraphs[0] is g2.subgraphs[0] and h.subgraph_factors == [10.0]
+    h2 = (3 * g1) * 4
+    assert h2.subgraphs[0] is g1 and h2.subgraph_factors == [12.0]
+
+
+def test_linear_combination_rules():
+    # graph.jl:178-207, 228-262
+    g1, g2 = Graph([]), Graph([])
+    s = g1 + g1
+    assert len(s.subgraphs) == 1 and s.subgraph_factors == [2.0] and isinstance(s.operator, Sum)
+    d = g1 - g2
+    assert d.subgraph_factors == [1.0, -1.0]
+    lc = fd.linear_combination([g1, g2, g1], [1, 2, 3])
+    assert [x.id for x in lc.subgraphs] == [g1.id, g2.id] and lc.subgraph_factors == [4.0, 2.0]
+
+
+def test_multi_product_rules():
+    # graph.jl:304-331, 350-401
+    g1, g2 = Graph([]), Graph([])
+    p = g1 * g2
+    assert isinstance(p.operator, Prod) and p.subgraph_factors == [1.0, 1.0]
+    sq = fd.multi_product(g1, g1, 2.0, 3.0)
+    assert isinstance(sq.operator, Power) and sq.operator.N == 2 and sq.subgraph_factors == [6.0]
+    mp = fd.multi_product([g1, g2, g1], [1, 2, 3])
+    assert isinstance(mp.operator, Prod) and len(mp.subgraphs) == 2
+    assert isinstance(mp.subgraphs[0].operator, Power) and mp.subgraph_factors == [3.0, 2.0]
+
+
+def test_power_and_unitary_assertions():
+    with pytest.raises(AssertionError):
+        Power(1)
+    with pytest.raises(AssertionError):
+        Power(0)
+    with pytest.raises(AssertionError):
+        Graph([Graph([]), Graph([])], operator=Power(2))
+    with pytest.raises(AssertionError):
+        Graph([Graph([])], operator=Unitary())
+
+
+def test_postorder_is_tree_expansion():
+    a, b = Graph([]), Graph([])
+    s = Graph([a, b], operator=Sum())
+    r = Graph([s, s, a], operator=Prod())
+    assert [g.id for g in PostOrderDFS(r)] == [a.id, b.id, s.id, a.id, b.id, s.id, a.id, r.id]
+
+
+# ---- lowering / emitters --------------------------------------------------- #
+def test_sigma2_text_equals_reference_program():
+    gs, _ = fixtures.sigma2_graphs()
+    s, leafmap = Compilers.to_julia_str(gs)
+    lines = s.split("\n")
+    assert lines[1] == "function eval_graph!(root::AbstractVector, leafVal::AbstractVector)" and lines[-1] == "end"
+    assert "\n".join(lines[2:-1]) + "\n" == fixtures.SIGMA2_JULIA_BODY
+    assert [leafmap[i].id for i in range(1, 9)] == [18636, 18643, 18637, 18650, 18630, 18676, 18708, 18709]
+    assert [leafmap[i].name for i in range(1, 9)] == list("GGVGVVGG")     # G1 G2 V3 G4 V5 V6 G7 G8 (to_dot labels)
+
+
+def test_leaf_numbering_and_statement_interleaving():
+    a, b, c = Graph([], _id=101), Graph([], _id=102), Graph([], _id=103)
+    n0 = Graph([b, c], operator=Sum(), _id=201)
+    r = Graph([a, n0, a], operator=Prod(), subgraph_factors=[1, 2, 1], _id=301)
+    s, lm = Compilers.to_julia_str([r])
+    assert s == ("\nfunction eval_graph!(root::AbstractVector, leafVal::AbstractVector)\n"
+                 "    g101 = leafVal[1]\n    g102 = leafVal[2]\n    g103 = leafVal[3]\n"
+                 "    g201 = (g102 + g103)\n    g301 = (g101 * g201 * 2.0 * g101)\n    root[1] = g301\nend")
+    cs, lm2 = Compilers.to_Cstr([r])
+    assert cs == ("\nvoid eval_graph(double *root, double *leafVal)\n{\n"
+                  "    double  g101, g102, g103, g201, g301;\n"
+                  "    g101 = leafVal[0];\n    g102 = leafVal[1];\n    g103 = leafVal[2];\n"
+                  "    g201 = (g102 + g103);\n    g301 = (g101 * g201 * 2.0 * g101);\n    root[0] = g301;\n}")
+    ps, _ = Compilers.to_python_str([r])
+    assert ps == ("import torch\ndef eval_graph(leafVal):\n"
+                  "    root = torch.empty(leafVal.shape[0], 1, dtype=leafVal.dtype, device=leafVal.device)\n"
+                  "    g101 = leafVal[:, 0]\n    g102 = leafVal[:, 1]\n    g103 = leafVal[:, 2]\n"
+                  "    g201 = (g102 + g103)\n    g301 = (g101 * g201 * 2.0 * g101)\n    root[:, 0] = g301\n"
+                  "    return root\n\n")
+    assert sorted(lm) == [1, 2, 3] and lm[1] is a and lm2[3] is c
+
+
+def test_power_text_forms():
+    a = Graph([], _id=1)
+    p = Graph([a], operator=Power(3), subgraph_factors=[2.0], _id=2)
+    assert "g2 = ((g1)^3 * 2.0)" in Compilers.to_julia_str([p])[0]          # static.jl:45
+    assert "g2 = pow(g1, 3) * 2.0;" in Compilers.to_Cstr([p])[0]            # static.jl:38-39
+    assert "g2 = ((g1)**3 * 2.0)" in Compilers.to_python_str([p])[0]
+
+
+def test_unknown_operator_is_rejected_at_lowering():
+    class Weird(fd.ComputationalGraphs.AbstractOperator):
+        pass
+    a = Graph([])
+    g = Graph([a], operator=Weird())
+    with pytest.raises(NotImplementedError, match="not yet implemented"):     # static.jl:6-11
+        lower([g])
+    # a Unitary node has no children, so it is a leaf for the compiler (graph.jl:118-125)
+    c = fd.constant_graph()
+    t, lm, _ = lower([Graph([c, a], operator=Sum())])
+    assert t.n_leaf == 2 and t.n_node == 1
+
+
+def test_shared_subgraph_emitted_once_and_dag_order():
+    a, b = Graph([]), Graph([])
+    s = a + b
+    p1 = s * a
+    p2 = s * b
+    t, lm, ids = lower([p1, p2])
+    assert t.n_leaf == 2 and t.n_node == 3
+    assert ids[s.id] == 2 and ids[p1.id] == 3 and ids[p2.id] == 4
+    assert t.root_slot.tolist() == [3, 4]
+
+
+def test_compile_file_emitters_append(tmp_path):
+    g, _, _ = fixtures.kat_compiler_jl()
+    fn = tmp_path / "out.c"
+    lm = Compilers.compile_C([g], str(fn))
+    Compilers.compile_C([g], str(fn), func_name="second")
+    txt = fn.read_text()
+    assert txt.startswith("#include <math.h>\n") and txt.count("#include") == 1       # static.jl:272-276
+    assert "void eval_graph(double *root, double *leafVal)" in txt and "void second(" in txt
+    assert sorted(lm) == [1, 2]
+    fj = tmp_path / "out.jl"
+    Compilers.compile_Julia([g], str(fj))
+    assert "function eval_graph!(root::AbstractVector, leafVal::AbstractVector)" in fj.read_text()
+    fp = tmp_path / "out.py"
+    Compilers.compile_Python([g], str(fp))
+    ns = {}
+    exec(fp.read_text(), ns)                          # the emitted torch function runs as is
+    import torch
+    out = ns["eval_graph"](torch.tensor([[1.0, 2.0], [3.0, 4.0]], dtype=torch.float64))
+    assert out[:, 0].tolist() == [4.5, 10.5]
+
+
+# ---- C ABI surface ----------------------------------------------------------- #
+def test_library_exports_every_declared_symbol(libfdg):
+    hdr = open(os.path.join(ROOT, "include", "fdg.h")).read()
+    declared = sorted(set(re.findall(r"\b(fdg_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(libfdg, name), f"libfdg.so does not export {name}"
+    assert sorted(capi.EXPORTS) == declared
+    assert libfdg.fdg_version() == 100
+
+
+def test_graph_create_validation_and_info(libfdg):
+    t = workloads.get("sigma2")
+    h = capi.GraphHandle(t)
+    info = h.info()
+    assert (info["n_leaf"], info["n_node"], info["n_root"], info["n_edge"]) == (8, 18, 2, 37)
+    assert info["flops_alg"] == 32 and info["bytes_alg"] == 80 and info["n_live_node"] == 18
+    assert info["specialized"] == 0
+    # not topologically sorted
+    bad = from_program(2, [(OP_SUM, 0, [(0, 1.0), (1, 1.0)])], [2])
+    bad.child_idx = np.array([0, 5], dtype=np.uint32)
+    with pytest.raises(ValueError):
+        capi.GraphHandle(bad)
+    # bypass the python-side validate: the C side must reject too
+    d = capi.GraphDesc()
+    tn = bad
+    d.n_leaf, d.n_node, d.n_root, d.n_edge = 2, 1, 1, 2
+    arrs = [np.array([7], np.uint8), np.array([0], np.int32), np.array([0, 2], np.uint32),
+            np.array([0, 1], np.uint32), np.array([1.0, 1.0]), np.array([2], np.uint32)]
+    d.op = arrs[0].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    d.power = arrs[1].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    d.child_off = arrs[2].ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    d.child_idx = arrs[3].ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    d.child_fac = arrs[4].ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    d.root_slot = arrs[5].ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    hp = ctypes.c_void_p()
+    rc = libfdg.fdg_graph_create(ctypes.byref(d), ctypes.byref(hp))
+    assert rc == capi.FDG_E_UNSUPPORTED and b"not yet implemented" in libfdg.fdg_last_error()   # static.jl:6-11
+    arrs[0][0] = OP_POWER
+    arrs[1][0] = 2
+    rc = libfdg.fdg_graph_create(ctypes.byref(d), ctypes.byref(hp))
+    assert rc == capi.FDG_E_INVALID and b"one and only one" in libfdg.fdg_last_error()            # graph.jl:61-62
+
+
+def test_dead_code_is_dropped_but_roots_kept(libfdg):
+    nodes = [(OP_SUM, 0, [(0, 1.0), (1, 2.0)]),      # live
+             (OP_PROD, 0, [(1, 1.0), (2, 1.0)]),     # dead
+             (OP_PROD, 0, [(3, 1.0), (0, -1.0)])]    # root
+    t = from_program(3, nodes, [5])
+    info = capi.GraphHandle(t).info()
+    assert info["n_live_node"] == 2 and info["n_live_leaf"] == 2 and info["flops_alg"] == 4
+
+
+def test_emit_source_and_jit_without_device(libfdg, tmp_path):
+    t = workloads.get("sigma2")
+    h = capi.GraphHandle(t)
+    src = h.emit_source()
+    assert 'extern "C" __global__' in src and "fdg_spec_sm" in src and "fdg_spec_gen" in src
+    assert "fma" not in src.split("fdg_block_sum")[1].split("fdg_spec_gen")[0].replace("fdg_powi", "")
+    h.specialize(str(tmp_path))                          # hiprtc cross-compiles for gfx950 without a GPU
+    assert h.info()["specialized"] == 1
+    assert any(f.endswith(".hsaco") for f in os.listdir(tmp_path))
+
+
+def test_no_cpu_fallback_without_gpu(libfdg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    f = fd.compile_table(workloads.get("sigma2"))
+    with pytest.raises(capi.FdgError) as e:
+        f(np.zeros(2), np.ones(8))
+    assert e.value.code == capi.FDG_E_NO_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(capi.FdgLibraryMissing, match="no CPU fallback"):
+        capi.lib()
