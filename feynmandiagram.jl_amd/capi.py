@@ -73,6 +73,15 @@ def lib():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C feynmandiagram.jl_amd/csrc). "
             "There is no CPU fallback for the evaluator.")
+    # PyTorch wheels bundle their own libamdhip64/libhsa-runtime64.  One process
+    # must use ONE HIP runtime, or device pointers and streams cannot be shared:
+    # when torch is installed, load it first so libfdg.so binds to the runtime
+    # torch already mapped (same SONAME) instead of a second copy from /opt/rocm.
+    if not os.environ.get("FDG_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i64, u64, u32, dp = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p
     L.fdg_last_error.restype = C.c_char_p
