@@ -22,12 +22,13 @@ KERNEL_CACHE = os.path.join(_HERE, "kernel_cache")
 
 FDG_OK = 0
 FDG_E_INVALID, FDG_E_UNSUPPORTED, FDG_E_NO_DEVICE, FDG_E_NOMEM, FDG_E_JIT, FDG_E_INTERNAL = -1, -2, -3, -4, -5, -6
-FDG_SPEC_DEFAULT, FDG_SPEC_KEEP_SOURCE, FDG_SPEC_FAST_MATH = 0, 1, 2
+FDG_SPEC_DEFAULT, FDG_SPEC_KEEP_SOURCE, FDG_SPEC_FAST_MATH, FDG_SPEC_ISA = 0, 1, 2, 4
 
 EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
     "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_graph_release_device", "fdg_powi",
+    "fdg_graph_set_opt_params", "fdg_graph_opt_program",
 ]
 
 
@@ -59,6 +60,19 @@ class GraphInfo(C.Structure):
     def asdict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
+
+class OptParams(C.Structure):
+    _fields_ = [("n_reg", C.c_uint32), ("n_lds", C.c_uint32), ("lookahead_lds", C.c_uint32),
+                ("lookahead_mem", C.c_uint32)]
+
+
+class MOp(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("nega", C.c_uint8), ("negb", C.c_uint8), ("pad", C.c_uint8),
+                ("d", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("imm", C.c_double)]
+
+
+MOP_DTYPE = np.dtype([("kind", "u1"), ("nega", "u1"), ("negb", "u1"), ("pad", "u1"),
+                      ("d", "<u4"), ("a", "<u4"), ("b", "<u4"), ("imm", "<f8")])
 
 _lib = None
 
@@ -98,6 +112,9 @@ def lib():
     L.fdg_accumulate_device.argtypes = [vp, dp, i64, i64, dp, dp, i64, vp]
     L.fdg_fill_uniform_device.argtypes = [dp, i64, u32, i64, i64, u64, u64, vp]
     L.fdg_graph_release_device.argtypes = [vp]
+    L.fdg_graph_set_opt_params.argtypes = [vp, C.POINTER(OptParams)]
+    L.fdg_graph_opt_program.argtypes = [vp, C.POINTER(OptParams), C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64),
+                                        C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.fdg_powi.argtypes = [C.c_double, C.c_int32]
     L.fdg_powi.restype = C.c_double
     _lib = L
@@ -155,6 +172,25 @@ class GraphHandle:
             return s.value.decode()
         finally:
             lib().fdg_free(s)
+
+    def set_opt_params(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0):
+        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem)
+        check(lib().fdg_graph_set_opt_params(self._h, C.byref(q)))
+
+    def opt_program(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0):
+        """Returns ``(ops, n_reg_used, n_lds_used, n_mem_used)``; ops is a numpy record array (MOP_DTYPE)."""
+        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem)
+        ops = C.POINTER(MOp)()
+        n = C.c_uint64()
+        nr, nl, nm = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().fdg_graph_opt_program(self._h, C.byref(q), C.byref(ops), C.byref(n), C.byref(nr), C.byref(nl),
+                                          C.byref(nm)))
+        try:
+            buf = C.string_at(ops, n.value * C.sizeof(MOp))
+            arr = np.frombuffer(buf, dtype=MOP_DTYPE).copy()
+        finally:
+            lib().fdg_free(ops)
+        return arr, nr.value, nl.value, nm.value
 
     def specialize(self, cache_dir: Optional[str] = None, flags: int = 0):
         cd = cache_dir if cache_dir is not None else os.environ.get("FDG_CACHE_DIR", KERNEL_CACHE)

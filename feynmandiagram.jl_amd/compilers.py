@@ -40,12 +40,18 @@ def _is_torch(x) -> bool:
 class GraphFunc:
     """Callable evaluator bound to one lowered graph set (one ``fdg_graph``)."""
 
-    def __init__(self, table: NodeTable, specialize: bool = False, cache_dir: Optional[str] = None,
-                 flags: int = 0):
+    def __init__(self, table: NodeTable, specialize=False, cache_dir: Optional[str] = None,
+                 flags: int = 0, opt: Optional[dict] = None):
+        """``specialize``: False (table interpreter), True / "hip" (straight-line HIP
+        source through hiprtc) or "isa" (optimizing back end, gfx950 assembly)."""
         self.table = table.normalized()
         self.handle = capi.GraphHandle(self.table)
         self.n_leaf, self.n_root = self.table.n_leaf, self.table.n_root
-        if specialize:
+        if specialize == "isa":
+            if opt:
+                self.handle.set_opt_params(**opt)
+            self.handle.specialize(cache_dir, flags | capi.FDG_SPEC_ISA)
+        elif specialize:
             self.handle.specialize(cache_dir, flags)
 
     # -- introspection ------------------------------------------------------- #

@@ -83,6 +83,12 @@ struct fdg_graph {
   size_t ws_bytes = 0;
   void *module = nullptr;          // hipModule_t
   void *fn_eval_sm = nullptr, *fn_eval_gen = nullptr;  // hipFunction_t
+  // ISA specialization (fdg_isa.cpp): one wave = 64 samples, persistent grid
+  bool isa = false;
+  void *fn_isa = nullptr;
+  uint32_t isa_vgpr = 0, isa_lds_bytes = 0, isa_mem_slots = 0;
+  void *d_ws2 = nullptr;           // roots scratch for accumulate through the ISA kernel
+  size_t ws2_bytes = 0;
   int device = -1;
   int n_cu = 0;
 };

@@ -1,0 +1,295 @@
+// See fdg_opt.h.  Everything here is host-side graph compilation; it decides
+// *where* values live and *when* they move, never what is computed: each
+// micro-op is one IEEE fp64 add or multiply of the reference's left fold
+// (src/backend/static.jl:13-31), and a factor of -1 is carried as a sign on the
+// operand (x * -1.0 == -x exactly).
+#include <algorithm>
+#include <cstring>
+#include <deque>
+#include <limits>
+
+#include "fdg_opt.h"
+
+namespace fdg {
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct UOp {      // micro-op over virtual values; refs are (vid << 1) | neg
+  uint8_t kind;   // M_MUL / M_ADD / M_MULC / M_ROOT
+  uint32_t d;     // destination vid (root index for M_ROOT)
+  uint32_t a, b;  // operand refs (b unused for MULC / ROOT)
+  double imm;
+};
+
+struct Builder {
+  const Lowered &p;
+  std::vector<UOp> u;
+  uint32_t next_vid;
+  std::vector<uint32_t> ref_of;   // table value -> ref, NONE when not computed yet
+  bool ok = true;
+  std::string why;
+
+  explicit Builder(const Lowered &p_) : p(p_), next_vid(p_.L), ref_of((size_t)p_.L + p_.N, NONE) {
+    for (uint32_t i = 0; i < p.L; ++i) ref_of[i] = i << 1;
+  }
+  uint32_t fresh() { return next_vid++; }
+  uint32_t op2(uint8_t k, uint32_t a, uint32_t b) {
+    uint32_t d = fresh();
+    u.push_back(UOp{k, d, a, b, 0.0});
+    return d << 1;
+  }
+  uint32_t mulc(uint32_t a, double f) {
+    if (f == 1.0) return a;
+    if (f == -1.0) return a ^ 1u;
+    uint32_t d = fresh();
+    u.push_back(UOp{M_MULC, d, a, 0, f});
+    return d << 1;
+  }
+};
+
+struct Frame { uint32_t n, i, acc; };
+
+void build_uops(Builder &B) {
+  const Lowered &p = B.p;
+  const uint32_t L = p.L;
+  std::vector<std::vector<uint32_t>> roots_of((size_t)0);
+  std::vector<std::pair<uint32_t, uint32_t>> rootlist;
+  for (uint32_t k = 0; k < p.R; ++k)
+    if (p.root_slot[k] != FDG_NO_ROOT) rootlist.push_back({p.root_slot[k], k});
+  std::sort(rootlist.begin(), rootlist.end());
+  auto emit_roots = [&](uint32_t v) {
+    auto it = std::lower_bound(rootlist.begin(), rootlist.end(), std::make_pair(v, 0u));
+    for (; it != rootlist.end() && it->first == v; ++it) B.u.push_back(UOp{M_ROOT, it->second, B.ref_of[v], 0, 0.0});
+  };
+  for (auto &rk : rootlist)
+    if (rk.first < L) B.u.push_back(UOp{M_ROOT, rk.second, rk.first << 1, 0, 0.0});
+
+  std::vector<Frame> st;
+  // roots in statement order of the reference (increasing node index)
+  std::vector<uint32_t> tops;
+  for (auto &rk : rootlist) if (rk.first >= L) tops.push_back(rk.first - L);
+  tops.erase(std::unique(tops.begin(), tops.end()), tops.end());
+  for (uint32_t top : tops) {
+    if (B.ref_of[L + top] != NONE) continue;
+    st.push_back(Frame{top, 0, NONE});
+    while (!st.empty()) {
+      Frame &f = st.back();
+      const uint32_t n = f.n, a = p.off[n], k = p.off[n + 1] - a;
+      if (f.i < k) {
+        const uint32_t c = p.idx[a + f.i];
+        if (B.ref_of[c] == NONE) { st.push_back(Frame{c - L, 0, NONE}); continue; }
+        const uint32_t cr = B.ref_of[c];
+        const double fc = p.fac[a + f.i];
+        uint32_t acc = f.acc;
+        if (p.op[n] == FDG_OP_SUM) {
+          const uint32_t t = B.mulc(cr, fc);                       // c_i * f_i   (static.jl:18)
+          acc = (f.i == 0) ? t : B.op2(M_ADD, acc, t);
+        } else if (p.op[n] == FDG_OP_PROD) {
+          acc = (f.i == 0) ? cr : B.op2(M_MUL, acc, cr);           // ((acc * c_i) * f_i)  (static.jl:28)
+          acc = B.mulc(acc, fc);
+        } else {  // Power: exactly one child
+          const int32_t N = p.power[n];
+          if (N == 2) acc = B.op2(M_MUL, cr, cr);
+          else if (N == 3) acc = B.op2(M_MUL, B.op2(M_MUL, cr, cr), cr);
+          else { B.ok = false; B.why = "Power{N} with N outside {2,3}"; acc = cr; }
+          acc = B.mulc(acc, fc);
+        }
+        // st may have been reallocated by nothing here (no push), safe to write back
+        st.back().acc = acc;
+        st.back().i++;
+        continue;
+      }
+      B.ref_of[L + n] = f.acc;
+      emit_roots(L + n);
+      st.pop_back();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct Alloc {
+  const Lowered &p;
+  const OptParams &prm;
+  const std::vector<UOp> &u;
+  uint32_t nv;
+  std::vector<std::vector<uint32_t>> uses;   // positions per vid
+  std::vector<uint32_t> up;                  // cursor into uses
+  std::vector<uint32_t> reg_of;              // vid -> reg or NONE
+  std::vector<uint8_t> home_kind;            // 0 none, 1 lds, 2 mem, 3 leaf source
+  std::vector<uint32_t> home_slot;
+  std::vector<uint32_t> owner;               // reg -> vid or NONE
+  std::vector<uint32_t> lock;                // reg -> op position it is pinned for
+  std::deque<uint32_t> free_regs;
+  std::vector<uint32_t> free_lds, free_mem;
+  uint32_t lds_next = 0, mem_next = 0, reg_hw = 0;
+  std::vector<MOp> out;
+  OptProgram &prog;
+
+  Alloc(const Lowered &p_, const OptParams &prm_, const std::vector<UOp> &u_, uint32_t nv_, OptProgram &pr)
+      : p(p_), prm(prm_), u(u_), nv(nv_), prog(pr) {}
+
+  uint32_t next_use(uint32_t v) const {
+    return up[v] < uses[v].size() ? uses[v][up[v]] : std::numeric_limits<uint32_t>::max();
+  }
+  bool get_lds(uint32_t &s) {
+    if (!free_lds.empty()) { s = free_lds.back(); free_lds.pop_back(); return true; }
+    if (lds_next < prm.n_lds) { s = lds_next++; return true; }
+    return false;
+  }
+  uint32_t get_mem() {
+    if (!free_mem.empty()) { uint32_t s = free_mem.back(); free_mem.pop_back(); return s; }
+    return mem_next++;
+  }
+  void release_home(uint32_t v) {
+    if (home_kind[v] == 1) free_lds.push_back(home_slot[v]);
+    else if (home_kind[v] == 2) free_mem.push_back(home_slot[v]);
+    if (home_kind[v] != 3) home_kind[v] = 0;
+  }
+  void kill(uint32_t v) {   // no further use
+    if (reg_of[v] != NONE) { owner[reg_of[v]] = NONE; free_regs.push_back(reg_of[v]); reg_of[v] = NONE; }
+    release_home(v);
+  }
+  // take a register for use at op position `pos`
+  uint32_t take_reg(uint32_t pos) {
+    if (!free_regs.empty()) { uint32_t r = free_regs.front(); free_regs.pop_front(); reg_hw = std::max(reg_hw, r + 1); return r; }
+    // Belady: evict the resident value whose next use is farthest away
+    uint32_t best = NONE, best_nu = 0;
+    for (uint32_t r = 0; r < prm.n_reg; ++r) {
+      if (owner[r] == NONE || lock[r] == pos) continue;
+      const uint32_t nu = next_use(owner[r]);
+      if (best == NONE || nu > best_nu) { best = r; best_nu = nu; }
+    }
+    const uint32_t v = owner[best];
+    if (home_kind[v] == 0) {            // only copy is in the register: spill it
+      uint32_t s;
+      if (get_lds(s)) { out.push_back(MOp{M_ST_LDS, 0, 0, s, best, 0, 0.0}); home_kind[v] = 1; home_slot[v] = s; prog.n_st_lds++; }
+      else { s = get_mem(); out.push_back(MOp{M_ST_MEM, 0, 0, s, best, 0, 0.0}); home_kind[v] = 2; home_slot[v] = s; prog.n_st_mem++; }
+    } else if (home_kind[v] == 3) {
+      // a leaf: re-loadable from its source; park it in LDS when there is room so
+      // the next use does not go back to HBM
+      uint32_t s;
+      if (next_use(v) != std::numeric_limits<uint32_t>::max() && get_lds(s)) {
+        out.push_back(MOp{M_ST_LDS, 0, 0, s, best, 0, 0.0}); home_kind[v] = 1; home_slot[v] = s; prog.n_st_lds++;
+      }
+    }
+    reg_of[v] = NONE;
+    owner[best] = NONE;
+    return best;
+  }
+  uint32_t ensure_in_reg(uint32_t v, uint32_t pos) {
+    if (reg_of[v] != NONE) { lock[reg_of[v]] = pos; return reg_of[v]; }
+    const uint32_t r = take_reg(pos);
+    switch (home_kind[v]) {
+      case 1: out.push_back(MOp{M_LD_LDS, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_lds++; break;
+      case 2: out.push_back(MOp{M_LD_MEM, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_mem++; break;
+      default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v, 0, 0.0}); prog.n_ld_leaf++; break;   // leaves only
+    }
+    reg_of[v] = r; owner[r] = v; lock[r] = pos;
+    return r;
+  }
+  void run() {
+    uses.assign(nv, {});
+    for (uint32_t j = 0; j < u.size(); ++j) {
+      const UOp &o = u[j];
+      uses[o.a >> 1].push_back(j);
+      if (o.kind == M_MUL || o.kind == M_ADD) uses[o.b >> 1].push_back(j);
+    }
+    up.assign(nv, 0);
+    reg_of.assign(nv, NONE);
+    home_kind.assign(nv, 0);
+    home_slot.assign(nv, 0);
+    for (uint32_t i = 0; i < p.L; ++i) home_kind[i] = 3;
+    owner.assign(prm.n_reg, NONE);
+    lock.assign(prm.n_reg, NONE);
+    for (uint32_t r = 0; r < prm.n_reg; ++r) free_regs.push_back(r);
+    uint32_t live = 0;
+    for (uint32_t j = 0; j < u.size(); ++j) {
+      const UOp &o = u[j];
+      const bool two = (o.kind == M_MUL || o.kind == M_ADD);
+      const uint32_t va = o.a >> 1, vb = two ? (o.b >> 1) : NONE;
+      const uint32_t ra = ensure_in_reg(va, j);
+      const uint32_t rb = two ? ensure_in_reg(vb, j) : 0;
+      // advance use cursors, free dead operands (so the destination may reuse a register)
+      up[va]++;
+      if (two) up[vb]++;     // (a == b: two entries at position j)
+      if (next_use(va) == std::numeric_limits<uint32_t>::max()) kill(va);
+      if (two && vb != va && next_use(vb) == std::numeric_limits<uint32_t>::max()) kill(vb);
+      if (o.kind == M_ROOT) {
+        out.push_back(MOp{M_ROOT, (uint8_t)(o.a & 1), 0, o.d, ra, 0, 0.0});
+        continue;
+      }
+      const uint32_t rd = take_reg(j);
+      reg_of[o.d] = rd; owner[rd] = o.d; lock[rd] = j;
+      if (o.kind == M_MULC) out.push_back(MOp{M_MULC, (uint8_t)(o.a & 1), 0, rd, ra, 0, o.imm});
+      else out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), (uint8_t)(o.b & 1), rd, ra, rb, 0.0});
+      prog.n_valu++;
+      if (uses[o.d].empty()) kill(o.d);   // cannot happen for reachable values; keeps the state sane
+      (void)live;
+    }
+    prog.n_reg_used = reg_hw;
+    prog.n_lds_used = lds_next;
+    prog.n_mem_used = mem_next;
+  }
+};
+
+// Move every load as far up as its destination register and its source slot
+// allow (bounded by the prefetch distances): the allocator places loads right
+// before their consumer, which would expose the full LDS / HBM latency with one
+// wave per SIMD.
+void hoist_loads(std::vector<MOp> &ops, const OptParams &prm) {
+  const size_t n = ops.size();
+  std::vector<int64_t> last_reg(prm.n_reg, -1), last_st_lds, last_st_mem;
+  std::vector<std::pair<double, uint32_t>> key(n);
+  for (size_t q = 0; q < n; ++q) {
+    MOp &o = ops[q];
+    double k = (double)q;
+    auto touch = [&](uint32_t r) { last_reg[r] = (int64_t)q; };
+    switch (o.kind) {
+      case M_LD_LEAF: case M_LD_LDS: case M_LD_MEM: {
+        int64_t lo = last_reg[o.d] + 1;
+        const uint32_t dist = (o.kind == M_LD_LDS) ? prm.lookahead_lds : prm.lookahead_mem;
+        if (o.kind == M_LD_LDS && o.a < last_st_lds.size()) lo = std::max(lo, last_st_lds[o.a] + 1);
+        if (o.kind == M_LD_MEM && o.a < last_st_mem.size()) lo = std::max(lo, last_st_mem[o.a] + 1);
+        lo = std::max<int64_t>(lo, (int64_t)q - (int64_t)dist);
+        if (lo < (int64_t)q) k = (double)lo - 0.5;
+        touch(o.d);
+        break;
+      }
+      case M_ST_LDS:
+        if (last_st_lds.size() <= o.d) last_st_lds.resize(o.d + 1, -1);
+        last_st_lds[o.d] = (int64_t)q; touch(o.a); break;
+      case M_ST_MEM:
+        if (last_st_mem.size() <= o.d) last_st_mem.resize(o.d + 1, -1);
+        last_st_mem[o.d] = (int64_t)q; touch(o.a); break;
+      case M_MUL: case M_ADD: touch(o.a); touch(o.b); touch(o.d); break;
+      case M_MULC: case M_MOV: touch(o.a); touch(o.d); break;
+      case M_ROOT: touch(o.a); break;
+    }
+    key[q] = {k, (uint32_t)q};
+  }
+  std::stable_sort(key.begin(), key.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+  std::vector<MOp> r;
+  r.reserve(n);
+  for (auto &kq : key) r.push_back(ops[kq.second]);
+  ops.swap(r);
+}
+
+}  // namespace
+
+void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) {
+  out = OptProgram();
+  out.params = prm;
+  Builder B(p);
+  build_uops(B);
+  out.supported = B.ok;
+  out.why = B.why;
+  if (!B.ok) return;
+  if (prm.n_reg < 4) { out.supported = false; out.why = "too few registers"; return; }
+  Alloc A(p, prm, B.u, B.next_vid, out);
+  A.run();
+  out.ops.swap(A.out);
+  hoist_loads(out.ops, prm);
+}
+
+}  // namespace fdg

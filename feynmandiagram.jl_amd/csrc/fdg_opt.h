@@ -1,0 +1,62 @@
+// Optimizing back end, host side: the node table is expanded into binary
+// micro-ops (keeping the reference's left-fold association), scheduled
+// depth-first so that every fold step runs as soon as its operand exists, and
+// register-allocated with Belady's rule over a three-level per-lane store:
+//   REG  (VGPR pairs)      -- operands of every VALU op
+//   LDS  (lds[slot][lane]) -- first overflow level, on chip
+//   MEM  (ws[slot][lane])  -- second overflow level, HBM/L2 workspace panel
+// Leaves are re-loadable from their source (the input matrix when it is
+// leaf-major, the staged panel otherwise), so evicting a leaf never stores.
+// The result is a linear list of machine ops that fdg_isa.cpp prints as gfx950
+// assembly, one instruction per op.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "fdg_internal.h"
+
+namespace fdg {
+
+enum MKind : uint8_t {
+  M_LD_LEAF = 0,  // r[d] = leaf[a]
+  M_LD_LDS,       // r[d] = lds[a]
+  M_LD_MEM,       // r[d] = ws[a]
+  M_ST_LDS,       // lds[d] = r[a]
+  M_ST_MEM,       // ws[d] = r[a]
+  M_MUL,          // r[d] = (+-r[a]) * (+-r[b])
+  M_ADD,          // r[d] = (+-r[a]) + (+-r[b])
+  M_MULC,         // r[d] = (+-r[a]) * imm
+  M_ROOT,         // root[d] = +-r[a]
+  M_MOV,          // r[d] = +-r[a]        (only for a root that aliases a negated value)
+};
+
+struct MOp {
+  uint8_t kind;
+  uint8_t nega, negb;
+  uint32_t d, a, b;
+  double imm;
+};
+
+struct OptParams {
+  uint32_t n_reg = 120;     // fp64 registers available to values
+  uint32_t n_lds = 80;      // LDS slots per lane
+  uint32_t lookahead_lds = 24;   // micro-ops of prefetch distance for LDS loads
+  uint32_t lookahead_mem = 160;  // ... for HBM/L2 loads
+};
+
+struct OptProgram {
+  OptParams params;
+  std::vector<MOp> ops;
+  uint32_t n_reg_used = 0, n_lds_used = 0, n_mem_used = 0;
+  // statistics
+  uint64_t n_valu = 0, n_ld_leaf = 0, n_ld_lds = 0, n_ld_mem = 0, n_st_lds = 0, n_st_mem = 0;
+  uint32_t max_live = 0;
+  bool supported = true;    // false: graph uses something the ISA path does not cover
+  std::string why;
+};
+
+void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out);
+std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname);
+
+}  // namespace fdg

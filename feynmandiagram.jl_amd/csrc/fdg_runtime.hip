@@ -16,6 +16,7 @@
 #include <sstream>
 
 #include "fdg_internal.h"
+#include "fdg_opt.h"
 #include "fdg_powi.h"
 
 namespace fdg {
@@ -171,6 +172,20 @@ __global__ void fdg_reduce_partials(const double *__restrict__ partial, uint32_t
   }
 }
 
+// partial[blk][k] = sum over the block's samples of w[b] * root[b][k]  (row-major roots)
+__global__ void __launch_bounds__(256)
+fdg_weighted_partials(const double *__restrict__ root, const double *__restrict__ weight, long B, uint32_t R,
+                      double *__restrict__ partial) {
+  __shared__ double sh[256];
+  for (uint32_t k = 0; k < R; ++k) {
+    double s = 0.0;
+    for (long b = blockIdx.x * 256L + threadIdx.x; b < B; b += (long)gridDim.x * 256L)
+      s = s + (weight ? weight[b] : 1.0) * root[b * R + k];
+    s = fdg_block_sum256(s, sh);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * R + k] = s;
+  }
+}
+
 // Philox4x32-10 (Salmon et al., SC'11), key = seed, counter = (sample, leaf)
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -249,6 +264,12 @@ static int ensure_module(fdg_graph *g) {
   hipModule_t m;
   hipError_t e = hipModuleLoadData(&m, g->code_object.data());
   if (e != hipSuccess) { set_error("hipModuleLoadData failed: " + std::string(hipGetErrorString(e))); return FDG_E_JIT; }
+  if (g->isa) {
+    hipFunction_t f;
+    HIP_TRY(hipModuleGetFunction(&f, m, "fdg_isa_eval"));
+    g->module = m; g->fn_isa = f;
+    return FDG_OK;
+  }
   hipFunction_t f1, f2;
   HIP_TRY(hipModuleGetFunction(&f1, m, "fdg_spec_sm"));
   HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_spec_gen"));
@@ -275,6 +296,46 @@ static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t
   const Lowered &p = g->prog;
   const long nblk = (long)((B + 255) / 256);
   const uint32_t R = p.R;
+
+  if (!g->code_object.empty() && g->isa) {
+    rc = ensure_module(g);
+    if (rc) return rc;
+    // resident waves: one wave per workgroup; bounded by VGPRs, LDS and 32 waves/CU
+    const uint32_t valloc = std::max<uint32_t>(8, (g->isa_vgpr + 7) & ~7u);
+    uint32_t per_cu = std::min<uint32_t>(8, 512 / valloc) * 4;
+    if (g->isa_lds_bytes) per_cu = std::min<uint32_t>(per_cu, (160u * 1024u) / g->isa_lds_bytes);
+    per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32));
+    const char *env = std::getenv("FDG_ISA_WAVES_PER_CU");
+    if (env) per_cu = (uint32_t)std::max(1, std::atoi(env));
+    const long ntiles = (long)((B + 63) / 64);
+    const long grid = std::min<long>(ntiles, (long)g->n_cu * per_cu);
+    const size_t panel = (size_t)std::max<uint32_t>(g->isa_mem_slots, 1) * 512u;
+    rc = ensure_ws(g, (size_t)grid * panel + 4096);
+    if (rc) return rc;
+    double *roots = d_root;
+    long a_rs = rs, a_rk = rk;
+    if (mode == 1) {
+      const size_t need = (size_t)B * std::max<uint32_t>(R, 1) * sizeof(double) + (size_t)2048 * R * sizeof(double);
+      if (g->ws2_bytes < need) {
+        if (g->d_ws2) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws2)); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
+        if (hipMalloc(&g->d_ws2, need) != hipSuccess) { set_error("hipMalloc(root scratch) failed"); return FDG_E_NOMEM; }
+        g->ws2_bytes = need;
+      }
+      roots = (double *)g->d_ws2; a_rs = R; a_rk = 1;
+    }
+    long a_ss = ss, a_ls = ls, a_B = B, a_nwg = grid;
+    void *a_ws = g->d_ws;
+    void *args[] = {(void *)&d_leaf, &a_ss, &a_ls, (void *)&roots, &a_rs, &a_rk, &a_ws, &a_B, &a_nwg};
+    HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa, (unsigned)grid, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+    if (mode == 1) {
+      double *partial = roots + (size_t)B * R;
+      const uint32_t pb = (uint32_t)std::min<long>(2048, nblk);
+      hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb), dim3(256), 0, st, roots, d_weight, (long)B, R, partial);
+      hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, pb, R, d_acc);
+      HIP_TRY(hipGetLastError());
+    }
+    return FDG_OK;
+  }
 
   if (!g->code_object.empty()) {
     rc = ensure_module(g);
@@ -428,7 +489,8 @@ int fdg_graph_release_device(fdg_graph *g) {
   std::lock_guard<std::mutex> lk(g->mu);
   if (g->d_code) { hipFree(g->d_code); g->d_code = nullptr; }
   if (g->d_ws) { hipFree(g->d_ws); g->d_ws = nullptr; g->ws_bytes = 0; }
-  if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; g->fn_eval_sm = g->fn_eval_gen = nullptr; }
+  if (g->d_ws2) { hipFree(g->d_ws2); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
+  if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; g->fn_eval_sm = g->fn_eval_gen = nullptr; g->fn_isa = nullptr; }
   return FDG_OK;
 }
 
@@ -462,9 +524,106 @@ int fdg_graph_emit_source(const fdg_graph *g, unsigned flags, char **source) {
   return FDG_OK;
 }
 
+static fdg::OptParams to_params(const fdg_opt_params *q) {
+  fdg::OptParams prm;
+  if (q) {
+    if (q->n_reg) prm.n_reg = std::min<uint32_t>(q->n_reg, 125);
+    if (q->n_lds) prm.n_lds = std::min<uint32_t>(q->n_lds, 127);
+    if (q->lookahead_lds) prm.lookahead_lds = q->lookahead_lds;
+    if (q->lookahead_mem) prm.lookahead_mem = q->lookahead_mem;
+  }
+  return prm;
+}
+
+static fdg_opt_params g_default_opt = {0, 0, 0, 0};
+struct OptStore { std::mutex mu; std::vector<std::pair<const fdg_graph *, fdg_opt_params>> v; };
+static OptStore &opt_store() { static OptStore s; return s; }
+
+int fdg_graph_set_opt_params(fdg_graph *g, const fdg_opt_params *prm) {
+  if (!g || !prm) { set_error("null argument"); return FDG_E_INVALID; }
+  OptStore &s = opt_store();
+  std::lock_guard<std::mutex> lk(s.mu);
+  for (auto &e : s.v) if (e.first == g) { e.second = *prm; return FDG_OK; }
+  s.v.push_back({g, *prm});
+  return FDG_OK;
+}
+
+static fdg_opt_params get_opt_params(const fdg_graph *g) {
+  OptStore &s = opt_store();
+  std::lock_guard<std::mutex> lk(s.mu);
+  for (auto &e : s.v) if (e.first == g) return e.second;
+  return g_default_opt;
+}
+
+int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop **ops, uint64_t *n_ops,
+                          uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used) {
+  if (!g || !ops || !n_ops) { set_error("null argument"); return FDG_E_INVALID; }
+  fdg::OptProgram prog;
+  fdg::build_opt_program(g->prog, to_params(q), prog);
+  if (!prog.supported) { set_error("optimizing back end does not cover this graph: " + prog.why); return FDG_E_UNSUPPORTED; }
+  fdg_mop *m = (fdg_mop *)std::malloc(std::max<size_t>(1, prog.ops.size()) * sizeof(fdg_mop));
+  if (!m) { set_error("out of memory"); return FDG_E_NOMEM; }
+  for (size_t i = 0; i < prog.ops.size(); ++i) {
+    const fdg::MOp &o = prog.ops[i];
+    m[i] = fdg_mop{o.kind, o.nega, o.negb, 0, o.d, o.a, o.b, o.imm};
+  }
+  *ops = m; *n_ops = prog.ops.size();
+  if (n_reg_used) *n_reg_used = prog.n_reg_used;
+  if (n_lds_used) *n_lds_used = prog.n_lds_used;
+  if (n_mem_used) *n_mem_used = prog.n_mem_used;
+  return FDG_OK;
+}
+
+static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
+  const fdg_opt_params q = get_opt_params(g);
+  fdg::OptProgram prog;
+  fdg::build_opt_program(g->prog, to_params(&q), prog);
+  if (!prog.supported) { set_error("optimizing back end does not cover this graph: " + prog.why); return FDG_E_UNSUPPORTED; }
+  const std::string src = fdg::emit_isa(g->prog, prog, "fdg_isa_eval");
+  char hbuf[40];
+  std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
+  const std::string base = dir + "/fdg_isa_" + hbuf;
+  std::vector<char> co;
+  if (!read_file(base + ".hsaco", co)) {
+    if (!write_file(base + ".s", src.c_str(), src.size())) { set_error("cannot write " + base + ".s"); return FDG_E_JIT; }
+    const char *llvm = std::getenv("FDG_LLVM_BIN");
+    const std::string bin = llvm ? llvm : "/opt/rocm/lib/llvm/bin";
+    const std::string cmd = bin + "/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c '" + base + ".s' -o '" + base +
+                            ".o' > '" + base + ".log' 2>&1 && " + bin + "/ld.lld -shared '" + base + ".o' -o '" + base +
+                            ".hsaco' >> '" + base + ".log' 2>&1";
+    const int rc = std::system(cmd.c_str());
+    std::vector<char> l;
+    std::string log;
+    if (read_file(base + ".log", l)) log.assign(l.begin(), l.end());
+    std::remove((base + ".log").c_str());
+    std::remove((base + ".o").c_str());
+    if (!(flags & FDG_SPEC_KEEP_SOURCE)) std::remove((base + ".s").c_str());
+    if (rc != 0 || !read_file(base + ".hsaco", co)) { set_error("assembling the ISA kernel failed:\n" + log.substr(0, 2000)); return FDG_E_JIT; }
+  } else if (flags & FDG_SPEC_KEEP_SOURCE) {
+    write_file(base + ".s", src.c_str(), src.size());
+  }
+  if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
+  g->code_object.swap(co);
+  g->isa = true;
+  g->fn_isa = nullptr;
+  g->isa_vgpr = (6 + 2 * std::max<uint32_t>(prog.n_reg_used, 1) + 3) & ~3u;
+  g->isa_lds_bytes = prog.n_lds_used * 512u;
+  g->isa_mem_slots = prog.n_mem_used;
+  g->spec_vgpr = g->isa_vgpr; g->spec_lds = g->isa_lds_bytes; g->spec_scratch = 0;
+  g->spec_source_hash = hbuf;
+  g->spec_flags = flags;
+  return FDG_OK;
+}
+
 int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
   if (!g) { set_error("null handle"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
+  if (flags & FDG_SPEC_ISA) {
+    std::string dir0 = cache_dir ? cache_dir : (std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache");
+    mkdir(dir0.c_str(), 0777);
+    return specialize_isa(g, dir0, flags);
+  }
+  g->isa = false;
   const bool fast = (flags & FDG_SPEC_FAST_MATH) != 0;
   const std::string src = emit_hip_source(g->prog, flags);
   char hbuf[40];

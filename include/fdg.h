@@ -108,6 +108,8 @@ typedef struct fdg_graph_info {
 #define FDG_SPEC_DEFAULT 0u
 #define FDG_SPEC_KEEP_SOURCE 1u   /* leave the generated source next to the code object */
 #define FDG_SPEC_FAST_MATH 2u     /* allow FMA contraction: NOT parity-exact, reported separately */
+#define FDG_SPEC_ISA 4u           /* optimizing back end: own scheduler + register allocator, gfx950
+                                     assembly printed directly (one VALU instruction per fold step) */
 
 const char *fdg_last_error(void);
 int fdg_version(void);
@@ -129,6 +131,30 @@ void fdg_free(void *p);
  * loaded lazily on first device use, so this works without a device present
  * (cross-compile at build time, run on the GPU box). */
 int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags);
+
+/* Tuning knobs of the FDG_SPEC_ISA back end; zero fields take the default. */
+typedef struct fdg_opt_params {
+  uint32_t n_reg;          /* fp64 values kept in VGPR pairs (<= 125) */
+  uint32_t n_lds;          /* fp64 LDS slots per lane (<= 127) */
+  uint32_t lookahead_lds;  /* prefetch distance, in ops, of LDS loads */
+  uint32_t lookahead_mem;  /* prefetch distance, in ops, of HBM/L2 loads */
+} fdg_opt_params;
+
+/* One op of the register-allocated program (for inspection and for host-side
+ * checkers that replay it): kind 0 LD_LEAF r[d]=leaf[a], 1 LD_LDS r[d]=lds[a],
+ * 2 LD_MEM r[d]=ws[a], 3 ST_LDS lds[d]=r[a], 4 ST_MEM ws[d]=r[a],
+ * 5 MUL r[d]=(+-r[a])*(+-r[b]), 6 ADD, 7 MULC r[d]=(+-r[a])*imm, 8 ROOT root[d]=+-r[a]. */
+typedef struct fdg_mop {
+  uint8_t kind, nega, negb, pad;
+  uint32_t d, a, b;
+  double imm;
+} fdg_mop;
+
+/* Sets the parameters used by the next fdg_graph_specialize(..., FDG_SPEC_ISA). */
+int fdg_graph_set_opt_params(fdg_graph *g, const fdg_opt_params *prm);
+/* Runs scheduler + allocator and returns the op list (malloc'ed; fdg_free).  Host-only. */
+int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *prm, fdg_mop **ops, uint64_t *n_ops,
+                          uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used);
 
 /* Evaluate B samples, buffers in device memory.
  *   leaf value i of sample b : d_leaf[b*leaf_sample_stride + i*leaf_leaf_stride]
