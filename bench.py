@@ -30,8 +30,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sigma4_standin")
     ap.add_argument("--samples", type=int, default=0, help="samples per step per GPU (0 = workload default)")
-    ap.add_argument("--layout", default="sample_major", choices=["sample_major", "leaf_major"])
-    ap.add_argument("--interp", action="store_true", help="use the table interpreter instead of the JIT kernel")
+    ap.add_argument("--layout", default="leaf_major", choices=["sample_major", "leaf_major"],
+                    help="leaf_major = a Julia column-major B x L matrix (the host language's native layout); "
+                         "sample_major = compile_Python's row-major [B, L]")
+    ap.add_argument("--backend", default="isa", choices=["isa", "hip", "interp"],
+                    help="isa: optimizing back end, gfx950 assembly; hip: straight-line HIP source via hiprtc; interp: table interpreter")
+    ap.add_argument("--interp", action="store_true", help="same as --backend interp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -57,9 +61,12 @@ def main():
     t = workloads.get(args.workload)
     st = t.stats()
     L, R = t.n_leaf, t.n_root
-    default_B = {"sigma2": 1 << 26, "sigma4_standin": 1 << 21, "synthetic_small": 1 << 23}.get(args.workload, 1 << 20)
+    default_B = {"sigma2": 1 << 26, "sigma4_standin": 1 << 21, "sigma4_worstcase": 1 << 20, "synthetic_small": 1 << 23,
+                 "gv_sigma4": 1 << 23, "gv_sigma5": 1 << 21, "gv_sigma6": 1 << 19}.get(args.workload, 1 << 20)
     B = args.samples or default_B
-    f = fd.compile_table(t, specialize=not args.interp)
+    if args.interp:
+        args.backend = "interp"
+    f = fd.compile_table(t, specialize={"isa": "isa", "hip": True, "interp": False}[args.backend])
 
     if args.layout == "sample_major":
         leaf = torch.empty((B, L), dtype=torch.float64, device=dev)
@@ -116,11 +123,14 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": args.workload + (" (seeded stand-in for the 4-loop Parquet self-energy; the real graph needs the Julia front end)" if args.workload == "sigma4_standin" else ""),
+        "config": {"workload": args.workload + {"sigma4_standin": " (seeded parquet-recursion stand-in for the 4-loop Parquet self-energy, ~10^4 nodes; the real graph needs the Julia front end)",
+                                                "gv_sigma5": " (reference GV catalog Sigma5_0_0.diag through the restated reader + optimize!)",
+                                                "gv_sigma6": " (reference GV catalog Sigma6_0_0.diag through the restated reader + optimize!)"}.get(args.workload, ""),
                    "graph": t.name, "n_leaf": L, "n_node": t.n_node, "n_edge": t.n_edge, "n_root": R,
                    "flops_per_eval": st["flops_alg"], "bytes_per_eval": st["bytes_alg"],
                    "samples_per_step_per_gpu": B, "layout": args.layout,
-                   "kernel": "interpreter" if args.interp else "specialized",
+                   "kernel": {"isa": "fdg_isa_eval (per-graph gfx950 assembly)", "hip": "fdg_spec (per-graph HIP source, hiprtc)",
+                              "interp": "fdg_interp (table interpreter)"}[args.backend],
                    "parallelism": f"samples sharded x{world}, one all-reduce of {R} doubles"},
     }
     if rank == 0:
@@ -128,13 +138,14 @@ def main():
         achieved = bytes_per_launch / avg_kernel_s / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                           "kernel": "fdg_interp" if args.interp else ("fdg_spec_sm" if args.layout == "sample_major" else "fdg_spec_gen"),
+                           "kernel": {"isa": "fdg_isa_eval", "interp": "fdg_interp",
+                                      "hip": "fdg_spec_sm" if args.layout == "sample_major" else "fdg_spec_gen"}[args.backend],
                            "avg_kernel_ms": avg_kernel_s * 1e3,
                            "algorithmic_bytes_per_launch": bytes_per_launch}
         out["valu_fp64"] = {"achieved_tflops": st["flops_alg"] * B / avg_kernel_s / 1e12,
                             "peak_tflops_fma": FP64_VALU_PEAK_TFLOPS,
                             "note": "secondary ceiling: add/mul only (no FMA contraction allowed), so the usable peak is half"}
-        out["kernel_info"] = {k: info[k] for k in ("max_live", "n_slot_lds", "n_slot_mem", "spec_vgpr", "spec_scratch_bytes")}
+        out["kernel_info"] = {k: info[k] for k in ("max_live", "spec_vgpr", "spec_lds_bytes", "spec_scratch_bytes")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(t, leaf, root, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -63,7 +63,7 @@ class GraphInfo(C.Structure):
 
 class OptParams(C.Structure):
     _fields_ = [("n_reg", C.c_uint32), ("n_lds", C.c_uint32), ("lookahead_lds", C.c_uint32),
-                ("lookahead_mem", C.c_uint32)]
+                ("lookahead_mem", C.c_uint32), ("lookahead_leaf", C.c_uint32), ("n_acc", C.c_uint32)]
 
 
 class MOp(C.Structure):
@@ -114,7 +114,7 @@ def lib():
     L.fdg_graph_release_device.argtypes = [vp]
     L.fdg_graph_set_opt_params.argtypes = [vp, C.POINTER(OptParams)]
     L.fdg_graph_opt_program.argtypes = [vp, C.POINTER(OptParams), C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64),
-                                        C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+                                        C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.fdg_powi.argtypes = [C.c_double, C.c_int32]
     L.fdg_powi.restype = C.c_double
     _lib = L
@@ -173,23 +173,24 @@ class GraphHandle:
         finally:
             lib().fdg_free(s)
 
-    def set_opt_params(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0):
-        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem)
+    def set_opt_params(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0):
+        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc)
         check(lib().fdg_graph_set_opt_params(self._h, C.byref(q)))
 
-    def opt_program(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0):
+    def opt_program(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0):
         """Returns ``(ops, n_reg_used, n_lds_used, n_mem_used)``; ops is a numpy record array (MOP_DTYPE)."""
-        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem)
+        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc)
         ops = C.POINTER(MOp)()
         n = C.c_uint64()
-        nr, nl, nm = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        nr, nl, nm, na = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(lib().fdg_graph_opt_program(self._h, C.byref(q), C.byref(ops), C.byref(n), C.byref(nr), C.byref(nl),
-                                          C.byref(nm)))
+                                          C.byref(nm), C.byref(na)))
         try:
             buf = C.string_at(ops, n.value * C.sizeof(MOp))
             arr = np.frombuffer(buf, dtype=MOP_DTYPE).copy()
         finally:
             lib().fdg_free(ops)
+        self.last_n_acc = na.value
         return arr, nr.value, nl.value, nm.value
 
     def specialize(self, cache_dir: Optional[str] = None, flags: int = 0):

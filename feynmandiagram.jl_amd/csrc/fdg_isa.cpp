@@ -16,6 +16,7 @@
 //   leaf value i of sample b: leaf[b*ss + i*ls]; root k: root[b*rs + k*rk]
 #include <cinttypes>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -128,6 +129,10 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   auto S2 = [](int r) { return "s[" + std::to_string(r) + ":" + std::to_string(r + 1) + "]"; };
   auto V = [](int r) { return "v" + std::to_string(r); };
 
+  const char *dbg = std::getenv("FDG_ISA_DEBUG");
+  const bool dbg_noleaf = dbg && std::strstr(dbg, "noleaf");
+  const bool dbg_nolds = dbg && std::strstr(dbg, "nolds");
+  const bool dbg_panelin = dbg && std::strstr(dbg, "panelin");   // timing only: read leaves as [tile][L][64]
   // ---- prologue ------------------------------------------------------------
   E.ins("s_load_dwordx8 s[4:11], s[0:1], 0x0");
   E.ins("s_load_dwordx8 s[12:19], s[0:1], 0x20");
@@ -181,12 +186,27 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   };
   tile_base(S_LT, S_LEAF, S_SS);
   tile_base(S_RT, S_ROOT, S_RS);
+  if (dbg_panelin) {
+    E.ins("s_mul_i32 " + S(S_A) + ", " + S(S_TILE) + ", " + hex32(p.L * 512u));
+    E.ins("s_mul_hi_u32 " + S(S_A + 1) + ", " + S(S_TILE) + ", " + hex32(p.L * 512u));
+    E.ins("s_add_u32 " + S(S_LT) + ", " + S(S_LEAF) + ", " + S(S_A));
+    E.ins("s_addc_u32 " + S(S_LT + 1) + ", " + S(S_LEAF + 1) + ", " + S(S_A + 1));
+  }
 
   // ---- body ------------------------------------------------------------------
   for (const MOp &o : prog.ops) {
     switch (o.kind) {
       case M_LD_LEAF: {
+        if (dbg_noleaf) break;   // timing experiments only (results are garbage)
         E.wait_reg(o.d);
+        if (dbg_panelin) {
+          const uint64_t byte = (uint64_t)o.a * 512u;
+          E.ins("s_add_u32 " + S(S_A) + ", " + S(S_LT) + ", " + hex32((uint32_t)(byte & ~4095ull)));
+          E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_LT + 1) + ", 0");
+          E.ins("global_load_dwordx2 " + E.vr(o.d) + ", " + V(V_LANE8) + ", " + S2(S_A) + " offset:" + std::to_string(byte & 4095ull));
+          E.pend[o.d] = {1, ++E.vm_issued};
+          break;
+        }
         emit_scaled_addr(E, S_A, S_LT, S_LS8, o.a);
         E.ins("global_load_dwordx2 " + E.vr(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_A));
         E.pend[o.d] = {1, ++E.vm_issued};
@@ -207,11 +227,13 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
         break;
       }
       case M_LD_LDS:
+        if (dbg_nolds) break;
         E.wait_reg(o.d);
         E.ins("ds_read_b64 " + E.vr(o.d) + ", " + V(V_LANE8) + " offset:" + std::to_string(o.a * 512u));
         E.pend[o.d] = {2, ++E.lg_issued};
         break;
       case M_ST_LDS:
+        if (dbg_nolds) break;
         E.wait_reg(o.a);
         E.ins("ds_write_b64 " + V(V_LANE8) + ", " + E.vr(o.a) + " offset:" + std::to_string(o.d * 512u));
         ++E.lg_issued;
@@ -240,6 +262,16 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
         E.ins("v_mul_f64 " + E.vr(o.d) + ", " + (o.nega ? "-" : "") + E.vr(o.a) + ", " + c);
         break;
       }
+      case M_LD_ACC:
+        E.wait_reg(o.d);
+        E.ins("v_accvgpr_read_b32 v" + std::to_string(V_BASE + 2 * o.d) + ", a" + std::to_string(2 * o.a));
+        E.ins("v_accvgpr_read_b32 v" + std::to_string(V_BASE + 2 * o.d + 1) + ", a" + std::to_string(2 * o.a + 1));
+        break;
+      case M_ST_ACC:
+        E.wait_reg(o.a);
+        E.ins("v_accvgpr_write_b32 a" + std::to_string(2 * o.d) + ", v" + std::to_string(V_BASE + 2 * o.a));
+        E.ins("v_accvgpr_write_b32 a" + std::to_string(2 * o.d + 1) + ", v" + std::to_string(V_BASE + 2 * o.a + 1));
+        break;
       case M_ROOT: {
         E.wait_reg(o.a);
         emit_scaled_addr(E, S_A, S_RT, S_RK8, o.d);
@@ -281,13 +313,14 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size 72\n\t\t.amdhsa_user_sgpr_count 2\n";
   os << "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1\n\t\t.amdhsa_system_sgpr_workgroup_id_x 1\n";
   os << "\t\t.amdhsa_system_vgpr_workitem_id 0\n";
-  os << "\t\t.amdhsa_next_free_vgpr " << accum << "\n\t\t.amdhsa_next_free_sgpr " << S_END << "\n";
+  const uint32_t n_agpr = 2 * prog.n_acc_used;
+  os << "\t\t.amdhsa_next_free_vgpr " << (accum + n_agpr) << "\n\t\t.amdhsa_next_free_sgpr " << S_END << "\n";
   os << "\t\t.amdhsa_accum_offset " << accum << "\n\t\t.amdhsa_reserve_vcc 1\n";
   os << "\t\t.amdhsa_float_round_mode_32 0\n\t\t.amdhsa_float_round_mode_16_64 0\n";
   os << "\t\t.amdhsa_float_denorm_mode_32 3\n\t\t.amdhsa_float_denorm_mode_16_64 3\n";
   os << "\t\t.amdhsa_dx10_clamp 1\n\t\t.amdhsa_ieee_mode 1\n";
   os << "\t.end_amdhsa_kernel\n\t.text\n";
-  os << "\t.amdgpu_metadata\n---\namdhsa.kernels:\n  - .agpr_count: 0\n    .args:\n";
+  os << "\t.amdgpu_metadata\n---\namdhsa.kernels:\n  - .agpr_count: " << n_agpr << "\n    .args:\n";
   const char *kinds[9] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",
                           "global_buffer", "by_value", "by_value"};
   for (int i = 0; i < 9; ++i) {
@@ -297,7 +330,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   os << "    .group_segment_fixed_size: " << lds_bytes << "\n    .kernarg_segment_align: 8\n    .kernarg_segment_size: 72\n";
   os << "    .max_flat_workgroup_size: 64\n    .name: " << kname << "\n    .private_segment_fixed_size: 0\n";
   os << "    .sgpr_count: " << (S_END + 6) << "\n    .sgpr_spill_count: 0\n    .symbol: " << kname << ".kd\n";
-  os << "    .uniform_work_group_size: 1\n    .uses_dynamic_stack: false\n    .vgpr_count: " << accum
+  os << "    .uniform_work_group_size: 1\n    .uses_dynamic_stack: false\n    .vgpr_count: " << (accum + n_agpr)
      << "\n    .vgpr_spill_count: 0\n    .wavefront_size: 64\n";
   os << "amdhsa.target: amdgcn-amd-amdhsa--gfx950\namdhsa.version:\n  - 1\n  - 2\n...\n\t.end_amdgpu_metadata\n";
   (void)p;

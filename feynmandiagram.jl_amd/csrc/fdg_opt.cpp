@@ -121,8 +121,8 @@ struct Alloc {
   std::vector<uint32_t> owner;               // reg -> vid or NONE
   std::vector<uint32_t> lock;                // reg -> op position it is pinned for
   std::deque<uint32_t> free_regs;
-  std::vector<uint32_t> free_lds, free_mem;
-  uint32_t lds_next = 0, mem_next = 0, reg_hw = 0;
+  std::vector<uint32_t> free_lds, free_mem, free_acc;
+  uint32_t lds_next = 0, mem_next = 0, acc_next = 0, reg_hw = 0;
   std::vector<MOp> out;
   OptProgram &prog;
 
@@ -137,6 +137,11 @@ struct Alloc {
     if (lds_next < prm.n_lds) { s = lds_next++; return true; }
     return false;
   }
+  bool get_acc(uint32_t &s) {
+    if (!free_acc.empty()) { s = free_acc.back(); free_acc.pop_back(); return true; }
+    if (acc_next < prm.n_acc) { s = acc_next++; return true; }
+    return false;
+  }
   uint32_t get_mem() {
     if (!free_mem.empty()) { uint32_t s = free_mem.back(); free_mem.pop_back(); return s; }
     return mem_next++;
@@ -144,15 +149,25 @@ struct Alloc {
   void release_home(uint32_t v) {
     if (home_kind[v] == 1) free_lds.push_back(home_slot[v]);
     else if (home_kind[v] == 2) free_mem.push_back(home_slot[v]);
+    else if (home_kind[v] == 4) free_acc.push_back(home_slot[v]);
     if (home_kind[v] != 3) home_kind[v] = 0;
   }
   void kill(uint32_t v) {   // no further use
     if (reg_of[v] != NONE) { owner[reg_of[v]] = NONE; free_regs.push_back(reg_of[v]); reg_of[v] = NONE; }
     release_home(v);
   }
-  // take a register for use at op position `pos`
-  uint32_t take_reg(uint32_t pos) {
-    if (!free_regs.empty()) { uint32_t r = free_regs.front(); free_regs.pop_front(); reg_hw = std::max(reg_hw, r + 1); return r; }
+  // take a register for use at op position `pos`.  Results of VALU ops take the
+  // most recently freed register (usually an operand that just died), loads the
+  // one that has been idle longest: that keeps a pool of long-idle registers, so
+  // hoist_loads() can issue loads hundreds of ops ahead of their consumer.
+  uint32_t take_reg(uint32_t pos, bool for_load = false, uint32_t not_before = NONE) {
+    if (!free_regs.empty()) {
+      uint32_t r;
+      if (for_load) { r = free_regs.front(); free_regs.pop_front(); }
+      else { r = free_regs.back(); free_regs.pop_back(); }
+      reg_hw = std::max(reg_hw, r + 1);
+      return r;
+    }
     // Belady: evict the resident value whose next use is farthest away
     uint32_t best = NONE, best_nu = 0;
     for (uint32_t r = 0; r < prm.n_reg; ++r) {
@@ -160,17 +175,20 @@ struct Alloc {
       const uint32_t nu = next_use(owner[r]);
       if (best == NONE || nu > best_nu) { best = r; best_nu = nu; }
     }
+    if (not_before != NONE && best_nu <= not_before) return NONE;   // prefetch would displace something needed sooner
     const uint32_t v = owner[best];
     if (home_kind[v] == 0) {            // only copy is in the register: spill it
       uint32_t s;
       if (get_lds(s)) { out.push_back(MOp{M_ST_LDS, 0, 0, s, best, 0, 0.0}); home_kind[v] = 1; home_slot[v] = s; prog.n_st_lds++; }
+      else if (get_acc(s)) { out.push_back(MOp{M_ST_ACC, 0, 0, s, best, 0, 0.0}); home_kind[v] = 4; home_slot[v] = s; prog.n_st_acc++; }
       else { s = get_mem(); out.push_back(MOp{M_ST_MEM, 0, 0, s, best, 0, 0.0}); home_kind[v] = 2; home_slot[v] = s; prog.n_st_mem++; }
     } else if (home_kind[v] == 3) {
       // a leaf: re-loadable from its source; park it in LDS when there is room so
       // the next use does not go back to HBM
       uint32_t s;
-      if (next_use(v) != std::numeric_limits<uint32_t>::max() && get_lds(s)) {
-        out.push_back(MOp{M_ST_LDS, 0, 0, s, best, 0, 0.0}); home_kind[v] = 1; home_slot[v] = s; prog.n_st_lds++;
+      if (next_use(v) != std::numeric_limits<uint32_t>::max()) {
+        if (get_lds(s)) { out.push_back(MOp{M_ST_LDS, 0, 0, s, best, 0, 0.0}); home_kind[v] = 1; home_slot[v] = s; prog.n_st_lds++; }
+        else if (get_acc(s)) { out.push_back(MOp{M_ST_ACC, 0, 0, s, best, 0, 0.0}); home_kind[v] = 4; home_slot[v] = s; prog.n_st_acc++; }
       }
     }
     reg_of[v] = NONE;
@@ -179,14 +197,41 @@ struct Alloc {
   }
   uint32_t ensure_in_reg(uint32_t v, uint32_t pos) {
     if (reg_of[v] != NONE) { lock[reg_of[v]] = pos; return reg_of[v]; }
-    const uint32_t r = take_reg(pos);
+    const uint32_t r = take_reg(pos, true);
     switch (home_kind[v]) {
       case 1: out.push_back(MOp{M_LD_LDS, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_lds++; break;
       case 2: out.push_back(MOp{M_LD_MEM, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_mem++; break;
+      case 4: out.push_back(MOp{M_LD_ACC, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_acc++; break;
       default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v, 0, 0.0}); prog.n_ld_leaf++; break;   // leaves only
     }
     reg_of[v] = r; owner[r] = v; lock[r] = pos;
     return r;
+  }
+  // Issue the load of value v now (op position j) for its use at op q > j.
+  void prefetch(uint32_t v, uint32_t j, uint32_t q) {
+    if (reg_of[v] != NONE || home_kind[v] == 0 || home_kind[v] == 4) return;
+    const uint32_t r = take_reg(j, true, q);
+    if (r == NONE) return;
+    switch (home_kind[v]) {
+      case 1: out.push_back(MOp{M_LD_LDS, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_lds++; break;
+      case 2: out.push_back(MOp{M_LD_MEM, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_mem++; break;
+      default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v, 0, 0.0}); prog.n_ld_leaf++; break;
+    }
+    reg_of[v] = r; owner[r] = v;
+  }
+  // scan pointer `pf` up to j + dist and prefetch operands whose home is of `kind`
+  void prefetch_window(uint32_t &pf, uint32_t j, uint32_t dist, uint8_t kind) {
+    const uint64_t lim = std::min<uint64_t>((uint64_t)u.size(), (uint64_t)j + dist + 1);
+    if (pf <= j) pf = j + 1;
+    for (; pf < lim; ++pf) {
+      const UOp &o = u[pf];
+      const uint32_t va = o.a >> 1;
+      if (home_kind[va] == kind) prefetch(va, j, pf);
+      if (o.kind == M_MUL || o.kind == M_ADD) {
+        const uint32_t vb = o.b >> 1;
+        if (home_kind[vb] == kind) prefetch(vb, j, pf);
+      }
+    }
   }
   void run() {
     uses.assign(nv, {});
@@ -204,8 +249,12 @@ struct Alloc {
     lock.assign(prm.n_reg, NONE);
     for (uint32_t r = 0; r < prm.n_reg; ++r) free_regs.push_back(r);
     uint32_t live = 0;
+    uint32_t pf_leaf = 0, pf_lds = 0, pf_mem = 0;
     for (uint32_t j = 0; j < u.size(); ++j) {
       const UOp &o = u[j];
+      if (prm.lookahead_leaf) prefetch_window(pf_leaf, j, prm.lookahead_leaf, 3);
+      if (prm.lookahead_mem) prefetch_window(pf_mem, j, prm.lookahead_mem, 2);
+      if (prm.lookahead_lds) prefetch_window(pf_lds, j, prm.lookahead_lds, 1);
       const bool two = (o.kind == M_MUL || o.kind == M_ADD);
       const uint32_t va = o.a >> 1, vb = two ? (o.b >> 1) : NONE;
       const uint32_t ra = ensure_in_reg(va, j);
@@ -230,6 +279,7 @@ struct Alloc {
     prog.n_reg_used = reg_hw;
     prog.n_lds_used = lds_next;
     prog.n_mem_used = mem_next;
+    prog.n_acc_used = acc_next;
   }
 };
 
@@ -248,7 +298,7 @@ void hoist_loads(std::vector<MOp> &ops, const OptParams &prm) {
     switch (o.kind) {
       case M_LD_LEAF: case M_LD_LDS: case M_LD_MEM: {
         int64_t lo = last_reg[o.d] + 1;
-        const uint32_t dist = (o.kind == M_LD_LDS) ? prm.lookahead_lds : prm.lookahead_mem;
+        const uint32_t dist = (o.kind == M_LD_LDS) ? prm.lookahead_lds : (o.kind == M_LD_MEM ? prm.lookahead_mem : prm.lookahead_leaf);
         if (o.kind == M_LD_LDS && o.a < last_st_lds.size()) lo = std::max(lo, last_st_lds[o.a] + 1);
         if (o.kind == M_LD_MEM && o.a < last_st_mem.size()) lo = std::max(lo, last_st_mem[o.a] + 1);
         lo = std::max<int64_t>(lo, (int64_t)q - (int64_t)dist);
@@ -265,6 +315,8 @@ void hoist_loads(std::vector<MOp> &ops, const OptParams &prm) {
       case M_MUL: case M_ADD: touch(o.a); touch(o.b); touch(o.d); break;
       case M_MULC: case M_MOV: touch(o.a); touch(o.d); break;
       case M_ROOT: touch(o.a); break;
+      case M_LD_ACC: touch(o.d); break;
+      case M_ST_ACC: touch(o.a); break;
     }
     key[q] = {k, (uint32_t)q};
   }

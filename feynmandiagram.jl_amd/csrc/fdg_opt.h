@@ -29,6 +29,8 @@ enum MKind : uint8_t {
   M_MULC,         // r[d] = (+-r[a]) * imm
   M_ROOT,         // root[d] = +-r[a]
   M_MOV,          // r[d] = +-r[a]        (only for a root that aliases a negated value)
+  M_LD_ACC,       // r[d] = acc[a]        (AGPR pair -> VGPR pair, two v_accvgpr_read_b32)
+  M_ST_ACC,       // acc[d] = r[a]
 };
 
 struct MOp {
@@ -41,16 +43,18 @@ struct MOp {
 struct OptParams {
   uint32_t n_reg = 120;     // fp64 registers available to values
   uint32_t n_lds = 80;      // LDS slots per lane
-  uint32_t lookahead_lds = 24;   // micro-ops of prefetch distance for LDS loads
-  uint32_t lookahead_mem = 160;  // ... for HBM/L2 loads
+  uint32_t n_acc = 0;       // AGPR pairs per lane used as a spill level (needs 1 wave/SIMD)
+  uint32_t lookahead_lds = 32;    // micro-ops of prefetch distance for LDS loads
+  uint32_t lookahead_mem = 128;   // ... for loads from the workspace panel (L2 / HBM)
+  uint32_t lookahead_leaf = 300;  // ... for first-use loads of leaves (HBM)
 };
 
 struct OptProgram {
   OptParams params;
   std::vector<MOp> ops;
-  uint32_t n_reg_used = 0, n_lds_used = 0, n_mem_used = 0;
+  uint32_t n_reg_used = 0, n_lds_used = 0, n_mem_used = 0, n_acc_used = 0;
   // statistics
-  uint64_t n_valu = 0, n_ld_leaf = 0, n_ld_lds = 0, n_ld_mem = 0, n_st_lds = 0, n_st_mem = 0;
+  uint64_t n_valu = 0, n_ld_leaf = 0, n_ld_lds = 0, n_ld_mem = 0, n_st_lds = 0, n_st_mem = 0, n_ld_acc = 0, n_st_acc = 0;
   uint32_t max_live = 0;
   bool supported = true;    // false: graph uses something the ISA path does not cover
   std::string why;

@@ -531,11 +531,13 @@ static fdg::OptParams to_params(const fdg_opt_params *q) {
     if (q->n_lds) prm.n_lds = std::min<uint32_t>(q->n_lds, 127);
     if (q->lookahead_lds) prm.lookahead_lds = q->lookahead_lds;
     if (q->lookahead_mem) prm.lookahead_mem = q->lookahead_mem;
+    if (q->lookahead_leaf) prm.lookahead_leaf = q->lookahead_leaf;
+    if (q->n_acc) prm.n_acc = std::min<uint32_t>(q->n_acc, 124);
   }
   return prm;
 }
 
-static fdg_opt_params g_default_opt = {0, 0, 0, 0};
+static fdg_opt_params g_default_opt = {0, 0, 0, 0, 0, 0};
 struct OptStore { std::mutex mu; std::vector<std::pair<const fdg_graph *, fdg_opt_params>> v; };
 static OptStore &opt_store() { static OptStore s; return s; }
 
@@ -556,7 +558,7 @@ static fdg_opt_params get_opt_params(const fdg_graph *g) {
 }
 
 int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop **ops, uint64_t *n_ops,
-                          uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used) {
+                          uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used) {
   if (!g || !ops || !n_ops) { set_error("null argument"); return FDG_E_INVALID; }
   fdg::OptProgram prog;
   fdg::build_opt_program(g->prog, to_params(q), prog);
@@ -571,13 +573,37 @@ int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop *
   if (n_reg_used) *n_reg_used = prog.n_reg_used;
   if (n_lds_used) *n_lds_used = prog.n_lds_used;
   if (n_mem_used) *n_mem_used = prog.n_mem_used;
+  if (n_acc_used) *n_acc_used = prog.n_acc_used;
   return FDG_OK;
 }
 
+static bool has_opt_params(const fdg_graph *g) {
+  OptStore &s = opt_store();
+  std::lock_guard<std::mutex> lk(s.mu);
+  for (auto &e : s.v) if (e.first == g) return true;
+  return false;
+}
+
 static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
-  const fdg_opt_params q = get_opt_params(g);
   fdg::OptProgram prog;
-  fdg::build_opt_program(g->prog, to_params(&q), prog);
+  if (has_opt_params(g)) {
+    const fdg_opt_params q = get_opt_params(g);
+    fdg::build_opt_program(g->prog, to_params(&q), prog);
+  } else {
+    // automatic configuration.  A: two waves per SIMD (120 VGPR pairs + 40 LDS
+    // slots each) -- best when the live set fits, the second wave hides what the
+    // prefetcher cannot.  B: one wave per SIMD with the idle half of the register
+    // file (124 AGPR pairs) and 80 LDS slots as on-chip spill levels -- taken as
+    // soon as A would have to spill to the HBM panel.
+    fdg::OptParams A; A.n_reg = 120; A.n_lds = 40; A.n_acc = 0;
+    fdg::build_opt_program(g->prog, A, prog);
+    if (prog.supported && (prog.n_ld_mem + prog.n_st_mem) > 0) {
+      fdg::OptParams Bc; Bc.n_reg = 120; Bc.n_lds = 80; Bc.n_acc = 124;
+      fdg::OptProgram pb;
+      fdg::build_opt_program(g->prog, Bc, pb);
+      if (pb.supported) prog = std::move(pb);
+    }
+  }
   if (!prog.supported) { set_error("optimizing back end does not cover this graph: " + prog.why); return FDG_E_UNSUPPORTED; }
   const std::string src = fdg::emit_isa(g->prog, prog, "fdg_isa_eval");
   char hbuf[40];
@@ -606,7 +632,7 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
   g->code_object.swap(co);
   g->isa = true;
   g->fn_isa = nullptr;
-  g->isa_vgpr = (6 + 2 * std::max<uint32_t>(prog.n_reg_used, 1) + 3) & ~3u;
+  g->isa_vgpr = ((6 + 2 * std::max<uint32_t>(prog.n_reg_used, 1) + 3) & ~3u) + 2 * prog.n_acc_used;
   g->isa_lds_bytes = prog.n_lds_used * 512u;
   g->isa_mem_slots = prog.n_mem_used;
   g->spec_vgpr = g->isa_vgpr; g->spec_lds = g->isa_lds_bytes; g->spec_scratch = 0;

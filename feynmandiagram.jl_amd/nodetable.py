@@ -25,7 +25,7 @@ OP_SUM, OP_PROD, OP_POWER = 0, 1, 2
 FDG_NO_ROOT = 0xFFFFFFFF
 
 __all__ = ["NodeTable", "OP_SUM", "OP_PROD", "OP_POWER", "FDG_NO_ROOT",
-           "synthetic_parquet_like", "from_program"]
+           "synthetic_parquet_like", "from_program", "postorder_renumber"]
 
 
 @dataclass
@@ -168,19 +168,153 @@ def from_program(n_leaf: int, nodes: Sequence[Tuple[int, int, Sequence[Tuple[int
 
 
 def synthetic_parquet_like(n_node: int = 10000, n_leaf: int = 300, n_root: int = 2,
-                           seed: int = 20241220, reuse_window: int = 0,
+                           seed: int = 20241220, structure: str = "recursive",
                            name: Optional[str] = None) -> NodeTable:
     """Seeded stand-in for the 4-loop Parquet self-energy graph (SURVEY.md 8d,
     config 3): the real graph needs the Julia front end, which is unavailable.
 
-    Shape follows the survey's spec: Prod:Sum about 2:1, Prod fan-in 2-3, Sum
-    fan-in geometric (mean about 3), about 35 % of edges with a factor from
+    Shape follows the survey's spec: about ``n_node`` internal nodes, ``n_leaf``
+    leaves, ``n_root`` Sum roots, Prod:Sum about 2:1, Prod fan-in 2-3, Sum fan-in
+    geometric (mean about 3), about 35 % of edges with a factor from
     {-1, -0.5, 0.5, 2, -2}, duplicate-child Prods allowed (cf. g18706 in the
-    2-loop fixture), every node reachable from a root (an optimized graph has
-    no dead code), ``n_root`` Sum roots.  ``reuse_window`` bounds how far back a
-    shared sub-diagram may be re-used (0 = anywhere, the pessimistic case for
-    the live set).
+    2-loop fixture), every node reachable from a root.
+
+    ``structure`` decides how sub-diagrams are shared, which the spec leaves open:
+
+    * ``"recursive"`` (default) mimics the parquet recursion the reference's
+      builder runs (src/frontend/parquet/vertex4.jl:66-99,125-201, sigma.jl:20-136):
+      vertex functions Gamma(l, variant) of loop order l = 0..3 are sums over
+      channels and loop splits l1 + l2 = l - 1 of
+      ``Gamma(l1, v1) * (G*G) * Gamma(l2, v2)``; each Gamma(l, variant) is built
+      once and shared by every parent that needs it (low orders are shared
+      widely, high orders by few parents); Sigma = sum of ``G * Gamma(3, v)``.
+    * ``"random"``: every operand is drawn uniformly from all earlier nodes -- no
+      locality at all, about a quarter of all values alive at once.  Kept as the
+      worst case for the register allocator (workload ``sigma4_worstcase``).
     """
+    if structure == "random":
+        return _synthetic_random(n_node, n_leaf, n_root, seed, name)
+    rng = random.Random(seed)
+    facs = (-1.0, -0.5, 0.5, 2.0, -2.0)
+    L = n_leaf
+    n_g = (L * 5) // 6                 # propagator leaves G; the rest are interaction leaves V
+    nodes: List[Tuple[int, int, List[Tuple[int, float]]]] = []
+
+    def fac() -> float:
+        return rng.choice(facs) if rng.random() < 0.35 else 1.0
+
+    def add(op: int, ch) -> int:
+        nodes.append((op, 0, list(ch)))
+        return L + len(nodes) - 1
+
+    gg_cache = {}
+
+    def gg() -> int:                   # a shared pair of propagators G_a * G_b
+        a, b = rng.randrange(n_g), rng.randrange(n_g)
+        if (a, b) not in gg_cache:
+            gg_cache[(a, b)] = add(OP_PROD, [(a, 1.0), (b, fac())])
+        return gg_cache[(a, b)]
+
+    # variants per loop order, sized so that the total lands near n_node
+    scale = max(n_node, 200) / 10000.0
+    n_var = [max(4, int(round(x * scale))) for x in (32, 128, 500, 1250)]
+    gamma: List[List[int]] = [[] for _ in range(4)]
+    # order 0: direct - exchange combinations of bare interaction leaves
+    for _v in range(n_var[0]):
+        k = 2
+        while rng.random() < 0.4 and k < 4:
+            k += 1
+        gamma[0].append(add(OP_SUM, [(n_g + rng.randrange(L - n_g), fac()) for _ in range(k)]))
+    for l in range(1, 4):
+        for _v in range(n_var[l]):
+            terms = []
+            n_terms = 2
+            while rng.random() < 0.5 and n_terms < 12:      # geometric, mean about 3
+                n_terms += 1
+            for _t in range(n_terms):
+                l1 = rng.randrange(l)
+                l2 = l - 1 - l1
+                left = rng.choice(gamma[l1])
+                right = rng.choice(gamma[l2])               # left == right happens: duplicate-child Prod
+                if _t and rng.random() < 0.3 and l >= 2:
+                    terms.append((rng.choice(gamma[l - 1]), fac()))     # lower-order piece re-used as is
+                elif rng.random() < 0.5:
+                    terms.append((add(OP_PROD, [(left, fac()), (gg(), fac()), (right, fac())]), fac()))
+                else:
+                    terms.append((add(OP_PROD, [(left, fac()), (right, fac())]), fac()))
+            gamma[l].append(add(OP_SUM, terms))
+    # Sigma roots: sum over G * Gamma(3, v), every top-level vertex used once
+    tops = list(gamma[3])
+    rng.shuffle(tops)
+    used = set()
+    for lst in nodes:
+        for c, _f in lst[2]:
+            used.add(c)
+    # lower-order vertex functions nobody picked hang directly under a root too
+    extra = [v for l in range(3) for v in gamma[l] if v not in used]
+    tops += extra
+    roots = []
+    for r in range(n_root):
+        grp = tops[r::n_root]
+        terms = [(add(OP_PROD, [(rng.randrange(n_g), 1.0), (v, fac())]), fac()) for v in grp]
+        roots.append(add(OP_SUM, terms))
+    t = from_program(L, nodes, roots, "")
+    t = postorder_renumber(t)          # statement order of to_julia_str (static.jl:98-133)
+    t.name = name or f"synthetic_parquet_recursive_N{t.n_node}_L{t.n_leaf}_seed{seed}"
+    return t
+
+
+def postorder_renumber(t: NodeTable) -> NodeTable:
+    """Renumber leaves and nodes in the order the reference's code generator
+    visits them: post-order DFS from the roots in order, children left to right,
+    first visit wins; unreachable nodes are dropped, unreachable leaves keep
+    their relative order after the visited ones."""
+    L, N = t.n_leaf, t.n_node
+    new_leaf: dict = {}
+    new_node: dict = {}
+    order: List[int] = []
+    leaf_pos: List[int] = []
+    for top in [int(r) for r in t.root_slot if int(r) != FDG_NO_ROOT]:
+        stack = [(top, 0)]
+        while stack:
+            v, i = stack[-1]
+            if v < L:
+                stack.pop()
+                if v not in new_leaf:
+                    new_leaf[v] = len(new_leaf)
+                    leaf_pos.append(len(order))
+                continue
+            n = v - L
+            if i == 0 and n in new_node:
+                stack.pop()
+                continue
+            a, b = int(t.child_off[n]), int(t.child_off[n + 1])
+            if i < b - a:
+                stack[-1] = (v, i + 1)
+                stack.append((int(t.child_idx[a + i]), 0))
+            else:
+                stack.pop()
+                new_node[n] = len(order)
+                order.append(n)
+    for v in range(L):
+        if v not in new_leaf:
+            new_leaf[v] = len(new_leaf)
+            leaf_pos.append(len(order))
+    nodes = []
+    for n in order:
+        ch = [((new_leaf[c] if c < L else L + new_node[c - L]), f) for c, f in t.children(n)]
+        nodes.append((int(t.op[n]), int(t.power[n]), ch))
+    roots = []
+    for r in t.root_slot:
+        r = int(r)
+        roots.append(FDG_NO_ROOT if r == FDG_NO_ROOT else (new_leaf[r] if r < L else L + new_node[r - L]))
+    out = from_program(L, nodes, roots, t.name)
+    out.leaf_pos = np.array(leaf_pos, dtype=np.uint32)
+    return out
+
+
+def _synthetic_random(n_node: int, n_leaf: int, n_root: int, seed: int, name: Optional[str]) -> NodeTable:
+    reuse_window = 0
     rng = random.Random(seed)
     facs = (-1.0, -0.5, 0.5, 2.0, -2.0)
     L = n_leaf
@@ -219,4 +353,4 @@ def synthetic_parquet_like(n_node: int = 10000, n_leaf: int = 300, n_root: int =
         roots.append(nvals)
         nvals += 1
     return from_program(L, nodes, roots,
-                        name or f"synthetic_parquet_like_N{n_node}_L{n_leaf}_seed{seed}")
+                        name or f"synthetic_random_dag_N{n_node}_L{n_leaf}_seed{seed}")

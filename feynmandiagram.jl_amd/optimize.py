@@ -210,8 +210,9 @@ def remove_duplicated_nodes_(graphs: Sequence[Graph]) -> Sequence[Graph]:
     (orders, operator, properties, multiset of (child class, factor)), which is
     the same relation."""
     nodes = _all_nodes_postorder(graphs)
-    cls: Dict[int, int] = {}
-    rep: Dict[object, Graph] = {}
+    cls: Dict[int, int] = {}          # object id -> equivalence class number
+    rep: Dict[object, Graph] = {}     # class key -> representative node
+    cls_of_key: Dict[object, int] = {}
     canon: Dict[int, Graph] = {}
     for n in nodes:
         for i, sg in enumerate(n.subgraphs):
@@ -225,11 +226,9 @@ def remove_duplicated_nodes_(graphs: Sequence[Graph]) -> Sequence[Graph]:
             k = (type(n).__name__, tuple(n.orders), repr(n.operator), pk, kids)
         if k not in rep:
             rep[k] = n
-        r = rep[k]
-        canon[id(n)] = r
-        cls[id(n)] = cls.get(id(r), len(cls)) if r is not n else len(cls)
-        if r is n:
-            cls[id(n)] = len(rep) - 1
+            cls_of_key[k] = len(cls_of_key)
+        canon[id(n)] = rep[k]
+        cls[id(n)] = cls_of_key[k]
     out = [canon[id(g)] for g in graphs]
     if isinstance(graphs, list):
         graphs[:] = out

@@ -3,7 +3,12 @@
 Each maps to a config of BASELINE.json:
   sigma2            configs 1-2: optimized 2-loop Parquet self-energy (fixture)
   sigma4_standin    config 3: seeded stand-in for the 4-loop Parquet self-energy
-                    (N = 10^4 nodes, L = 300; the real graph needs the Julia front end)
+                    (N ~ 10^4 nodes, L = 300, parquet-recursion sharing; the real
+                    graph needs the Julia front end)
+  sigma4_worstcase  same size, operands drawn uniformly at random (no locality)
+  gv_sigma4/5/6     real reference data: GV self-energy catalogs of order 4/5/6
+                    read from the reference's .diag files and run through the
+                    restated optimize! (tests/golden/make_gv_tables.py)
   sigma4_taylor_standin  config 4: the same enlarged x3 with 2 % Power{2} nodes
   synthetic_small   a 1000-node graph for quick parity runs
 """
@@ -15,7 +20,8 @@ import numpy as np
 
 from .nodetable import NodeTable, OP_POWER, OP_PROD, from_program, synthetic_parquet_like
 
-PREBUILT = ("sigma2", "synthetic_small", "sigma4_standin")
+PREBUILT = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma4", "gv_sigma5", "gv_sigma6")
+PREBUILT_HIP = ("sigma2", "synthetic_small", "sigma4_standin", "gv_sigma5")
 
 
 @functools.lru_cache(maxsize=None)
@@ -28,8 +34,14 @@ def get(name: str) -> NodeTable:
         return t
     if name == "sigma4_standin":
         return synthetic_parquet_like(10000, 300, 2, seed=20241220)
+    if name == "sigma4_worstcase":
+        return synthetic_parquet_like(10000, 300, 2, seed=20241220, structure="random")
     if name == "synthetic_small":
-        return synthetic_parquet_like(1000, 64, 2, seed=7)
+        return synthetic_parquet_like(1000, 64, 2, seed=7, structure="random")
+    if name.startswith("gv_sigma"):
+        import os
+        return NodeTable.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                           "tests", "golden", name + ".npz"))
     if name == "sigma4_taylor_standin":
         return _with_powers(synthetic_parquet_like(30000, 300, 6, seed=20241221), 0.02, 99)
     raise KeyError(name)

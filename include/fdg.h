@@ -137,13 +137,16 @@ typedef struct fdg_opt_params {
   uint32_t n_reg;          /* fp64 values kept in VGPR pairs (<= 125) */
   uint32_t n_lds;          /* fp64 LDS slots per lane (<= 127) */
   uint32_t lookahead_lds;  /* prefetch distance, in ops, of LDS loads */
-  uint32_t lookahead_mem;  /* prefetch distance, in ops, of HBM/L2 loads */
+  uint32_t lookahead_mem;  /* prefetch distance, in ops, of workspace-panel (L2/HBM) loads */
+  uint32_t lookahead_leaf; /* prefetch distance, in ops, of first-use leaf loads (HBM) */
+  uint32_t n_acc;          /* AGPR pairs per lane used as a spill level (<= 124; 0 with two waves per SIMD) */
 } fdg_opt_params;
 
 /* One op of the register-allocated program (for inspection and for host-side
  * checkers that replay it): kind 0 LD_LEAF r[d]=leaf[a], 1 LD_LDS r[d]=lds[a],
  * 2 LD_MEM r[d]=ws[a], 3 ST_LDS lds[d]=r[a], 4 ST_MEM ws[d]=r[a],
- * 5 MUL r[d]=(+-r[a])*(+-r[b]), 6 ADD, 7 MULC r[d]=(+-r[a])*imm, 8 ROOT root[d]=+-r[a]. */
+ * 5 MUL r[d]=(+-r[a])*(+-r[b]), 6 ADD, 7 MULC r[d]=(+-r[a])*imm, 8 ROOT root[d]=+-r[a],
+ * 10 LD_ACC r[d]=acc[a], 11 ST_ACC acc[d]=r[a]. */
 typedef struct fdg_mop {
   uint8_t kind, nega, negb, pad;
   uint32_t d, a, b;
@@ -154,7 +157,7 @@ typedef struct fdg_mop {
 int fdg_graph_set_opt_params(fdg_graph *g, const fdg_opt_params *prm);
 /* Runs scheduler + allocator and returns the op list (malloc'ed; fdg_free).  Host-only. */
 int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *prm, fdg_mop **ops, uint64_t *n_ops,
-                          uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used);
+                          uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used);
 
 /* Evaluate B samples, buffers in device memory.
  *   leaf value i of sample b : d_leaf[b*leaf_sample_stride + i*leaf_leaf_stride]

@@ -42,7 +42,13 @@ def main():
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(kat, f, indent=1, ensure_ascii=False)
 
-    for name, B, seed in (("sigma2", 257, 1234), ("synthetic_small", 64, 1234), ("sigma4_standin", 16, 1234)):
+    kat.append(dict(name="gv_sigma_all_ones", source="src/frontend/GV_diagrams/groups_sigma/Sigma{4,5,6}_0_0.diag: sum over diagrams of SymFactor*sum(SpinFactor), per external-tau group (tests/golden/make_gv_tables.py)",
+                    leaf="ones", expect={"4": [21.0, 3.0], "5": [-31.0, -77.0], "6": [233.0, 167.0]},
+                    note="computed from the catalog text, independent of the reader/optimizer restatements"))
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat, f, indent=1, ensure_ascii=False)
+    for name, B, seed in (("sigma2", 257, 1234), ("synthetic_small", 64, 1234), ("sigma4_standin", 16, 1234),
+                          ("sigma4_worstcase", 8, 1234), ("gv_sigma5", 16, 1234)):
         t = workloads.get(name)
         leaf = oracle.philox_uniform(B, t.n_leaf, seed)
         root = oracle.eval_static(t, leaf)

@@ -39,8 +39,8 @@ def run(f, leaf):
     return root.cpu().numpy()
 
 
-@pytest.mark.parametrize("spec", [False, True], ids=["interp", "specialized"])
-@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin"])
+@pytest.mark.parametrize("spec", [False, True, "isa"], ids=["interp", "hipjit", "isa"])
+@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma5"])
 def test_golden_vectors_on_device(libfdg, cuda, name, spec):
     import torch
     z = np.load(os.path.join(GOLD, f"{name}.npz"))
@@ -59,9 +59,9 @@ def test_device_philox_matches_twin(libfdg, cuda):
             assert np.array_equal(leaf.cpu().numpy(), oracle.philox_uniform(B, L, seed, off)), (B, L, layout)
 
 
-@pytest.mark.parametrize("spec", [False, True], ids=["interp", "specialized"])
+@pytest.mark.parametrize("spec", [False, True, "isa"], ids=["interp", "hipjit", "isa"])
 @pytest.mark.parametrize("layout", ["sample_major", "leaf_major", "padded"])
-@pytest.mark.parametrize("name,B", [("sigma2", 100003), ("synthetic_small", 5000), ("sigma4_standin", 1500)])
+@pytest.mark.parametrize("name,B", [("sigma2", 100003), ("synthetic_small", 5000), ("sigma4_standin", 1500), ("gv_sigma5", 3001)])
 def test_parity_layouts(libfdg, cuda, name, B, layout, spec):
     t = workloads.get(name)
     f = fd.compile_table(t, specialize=spec)
@@ -71,7 +71,7 @@ def test_parity_layouts(libfdg, cuda, name, B, layout, spec):
     assert np.array_equal(got, want), np.abs(got - want).max()
 
 
-@pytest.mark.parametrize("spec", [False, True], ids=["interp", "specialized"])
+@pytest.mark.parametrize("spec", [False, True, "isa"], ids=["interp", "hipjit", "isa"])
 def test_kat_through_device(libfdg, cuda, spec):
     # test/compiler.jl:4-15 through the GraphFunc call convention
     g, leaf, expect = fixtures.kat_compiler_jl()
@@ -98,7 +98,7 @@ def test_kat_through_device(libfdg, cuda, spec):
     assert abs(root[0] - e) <= 1.5e-8 * abs(e)
 
 
-@pytest.mark.parametrize("spec", [False, True], ids=["interp", "specialized"])
+@pytest.mark.parametrize("spec", [False, True, "isa"], ids=["interp", "hipjit", "isa"])
 def test_edge_cases(libfdg, cuda, spec):
     import torch
     # leaf as root, interior root, missing root id (left untouched), duplicate id, Power nodes, fan-in 40
@@ -106,7 +106,10 @@ def test_edge_cases(libfdg, cuda, spec):
     s = a + b
     wide = fd.Graph([a, b, c] * 13 + [s], subgraph_factors=[(-1.0) ** i * (1 + i % 3) for i in range(40)], operator=fd.Sum())
     p = fd.Graph([wide, s, a, a], subgraph_factors=[1.0, -0.5, 1.0, 3.0], operator=fd.Prod())
-    pw = [s ** 2, s ** 3, c ** 5, c ** -1, c ** -2, c ** -4, fd.Graph([p], operator=fd.Power(7), subgraph_factors=[0.125])]
+    if spec == "isa":       # the ISA back end covers Power{2,3}; other exponents go through the HIP-source JIT
+        pw = [s ** 2, s ** 3, fd.Graph([p], operator=fd.Power(3), subgraph_factors=[0.125]), fd.Graph([c], operator=fd.Power(2), subgraph_factors=[-1.0])]
+    else:
+        pw = [s ** 2, s ** 3, c ** 5, c ** -1, c ** -2, c ** -4, fd.Graph([p], operator=fd.Power(7), subgraph_factors=[0.125])]
     graphs = [p, wide] + pw
     roots = [a.id, p.id, 424242, p.id, wide.id] + [g.id for g in pw]
     t, _, _ = lower(graphs, root=roots)
@@ -134,7 +137,7 @@ def test_edge_cases(libfdg, cuda, spec):
     assert np.array_equal(root.cpu().numpy(), oracle.eval_static(t, leaf.cpu().numpy(), np.full((B, t.n_root), -7.0)))
 
 
-@pytest.mark.parametrize("spec", [False, True], ids=["interp", "specialized"])
+@pytest.mark.parametrize("spec", [False, True, "isa"], ids=["interp", "hipjit", "isa"])
 def test_accumulate(libfdg, cuda, spec):
     import torch
     for name, B in (("sigma2", 200001), ("synthetic_small", 3000)):
@@ -169,11 +172,14 @@ def test_config2_sigma2_ten_million_samples(libfdg, cuda):
     h_leaf = leaf.cpu().numpy()
     want = oracle.eval_static(t, h_leaf)
     scale = oracle.root_scale(t, h_leaf)
-    for spec in (True, False):
+    for spec in ("isa", True, False):
         f = fd.compile_table(t, specialize=spec)
         got = run(f, leaf)
         assert np.all(np.abs(got - want) <= TOL * np.maximum(1.0, scale))
         assert np.array_equal(got, want)
+    # the Julia-native layout (column-major B x L matrix) through the ISA kernel
+    lt = leaf.t().contiguous().t()
+    assert np.array_equal(run(fd.compile_table(t, specialize="isa"), lt), want)
 
 
 def test_full_size_properties_sigma4(libfdg, cuda):
@@ -185,7 +191,8 @@ def test_full_size_properties_sigma4(libfdg, cuda):
     import torch
     t = workloads.get("sigma4_standin")
     B = 1 << 19
-    fs = fd.compile_table(t, specialize=True)
+    fs = fd.compile_table(t, specialize="isa")
+    fh = fd.compile_table(t, specialize=True)
     fi = fd.compile_table(t, specialize=False)
     leaf = dev_leaves(cuda, B, t.n_leaf, 2024, 0)
     r_spec = fs(None, leaf)
@@ -194,6 +201,7 @@ def test_full_size_properties_sigma4(libfdg, cuda):
     torch.cuda.synchronize()
     assert torch.equal(r_spec, r_spec2)
     assert torch.equal(r_spec[: B // 8], r_int)
+    assert torch.equal(r_spec[: B // 4], fh(None, leaf[: B // 4]))
     a = fs(None, leaf[12345:12345 + 70001])
     torch.cuda.synchronize()
     assert torch.equal(a, r_spec[12345:12345 + 70001])

@@ -1,0 +1,215 @@
+"""SURVEY.md 8f rows 1-2 on the host side: the GV ``.diag`` reader and the
+``optimize!`` passes, pinned by the reference's own tests
+(test/computational_graph.jl:364-491) and by an independent reading of the
+catalogs; plus the optimizing back end's register-allocated program, replayed
+on the CPU against the oracle (no GPU needed)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import feynmandiagram_jl_amd as fd
+from feynmandiagram_jl_amd import capi, optimize, workloads
+from feynmandiagram_jl_amd.graph import AbstractOperator, Graph, Power, Prod, Sum
+from feynmandiagram_jl_amd.lowering import lower
+from feynmandiagram_jl_amd.optimize import isequiv
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REF_GV = "/root/reference/src/frontend/GV_diagrams"
+
+
+class O(AbstractOperator):
+    pass
+
+
+def ev(g, leaf=None):
+    t, _, _ = lower([g])
+    x = np.ones((1, t.n_leaf)) if leaf is None else leaf
+    return oracle.eval_interp(t, x)[0, 0]
+
+
+# ---- optimize! passes (test/computational_graph.jl:364-491) ----------------- #
+def test_flatten_all_chains():
+    l0 = Graph([])
+    l1 = Graph([l0], subgraph_factors=[2])
+    l2 = Graph.new([], factor=3)
+    g1 = Graph([l1, l2], subgraph_factors=[-1, 1])
+    g2 = 2 * g1
+    g3 = Graph([g2], subgraph_factors=[3], operator=Prod())
+    g4 = Graph([g3], subgraph_factors=[5], operator=Prod())
+    r1 = Graph([g4], subgraph_factors=[7], operator=Prod())
+    r2 = Graph([g4], subgraph_factors=[-1], operator=Prod())
+    r3 = Graph([g3, g4], subgraph_factors=[2, 7], operator=O())
+    optimize.flatten_all_chains_([r1])
+    assert isequiv(g1, Graph([l0, l0], subgraph_factors=[-2, 3]), "id")
+    assert isequiv(r1, 210 * g1, "id")
+    assert isequiv(g2, 2 * g1, "id") and isequiv(g3, 6 * g1, "id") and isequiv(g4, 30 * g1, "id")
+    optimize.flatten_all_chains_([r2])
+    assert isequiv(r2, -30 * g1, "id")
+    optimize.flatten_all_chains_([r3])
+    assert isequiv(r3, Graph([g1, g1], subgraph_factors=[12, 210], operator=O()), "id")
+
+
+def test_merge_all_linear_combinations():
+    g1 = Graph([])
+    g3 = Graph.new([], factor=3.0)
+    h = Graph([g1, g1, g3], subgraph_factors=[-1, 3, 1])
+    _h = Graph([g1, g3], subgraph_factors=[2, 1])
+    optimize.merge_all_linear_combinations_([h])
+    assert isequiv(h, _h, "id")
+
+
+def test_remove_zero_valued_subgraphs():
+    l = [Graph.new([], factor=k) for k in range(1, 9)]
+    l1, l2, l3, l4, l5, l6, l7, l8 = l
+    ssg1 = Graph([l7], subgraph_factors=[0], operator=O())
+    sg2 = Graph([l2, l3], subgraph_factors=[1.0, 0.0], operator=Sum())
+    sg2_test = Graph([l2], subgraph_factors=[1.0], operator=Sum())
+    sg3 = Graph([l4], subgraph_factors=[0], operator=Sum())
+    sg4 = Graph([l5, l6, ssg1], subgraph_factors=[0, 0, 3], operator=Sum())
+    sg4_test = Graph([ssg1], subgraph_factors=[3], operator=Sum())
+    g = Graph([l1, sg2, sg3, sg4, l8], subgraph_factors=[1, 1, 1, 1, 0], operator=Sum())
+    g_test = Graph([l1, sg2_test, sg4_test], subgraph_factors=[1, 1, 1], operator=Sum())
+    gp = Graph([sg3, sg4, l8], subgraph_factors=[1, 0, 0], operator=Sum())
+    gp_test = Graph([sg3], subgraph_factors=[0], operator=Sum())
+    optimize.remove_all_zero_valued_subgraphs_([g])
+    optimize.remove_all_zero_valued_subgraphs_([gp])
+    assert isequiv(g, g_test, "id")
+    assert isequiv(gp, gp_test, "id")
+
+
+def test_optimize_pipeline_and_value_invariance():
+    # test/computational_graph.jl:471-491
+    g1 = Graph([])
+    g2 = 2 * g1
+    g3 = Graph([g2], subgraph_factors=[3], operator=Prod())
+    g4 = Graph([g3], subgraph_factors=[5], operator=Prod())
+    g5 = Graph.new([], factor=3.0, operator=O())
+    h0 = Graph([g1, g4, g5], subgraph_factors=[2, -1, 1])
+    h1 = Graph([h0], operator=Prod(), subgraph_factors=[2])
+    h = Graph([h1, g5])
+    g1p = Graph([], operator=O())
+    _h = Graph([Graph([g1, g1p], subgraph_factors=[-28, 3]), g1p], subgraph_factors=[2, 3])
+    before = ev(h)
+    optimize.optimize_([h])
+    assert isequiv(h, _h, "id", "weight")
+    assert ev(h) == before == ev(_h) == (-28 + 3) * 2 + 3
+
+
+def test_remove_duplicated_nodes_level1():
+    a, b = Graph([], properties="a"), Graph([], properties="b")
+    s1 = Graph([a, b], subgraph_factors=[1, 2])
+    s2 = Graph([b, a], subgraph_factors=[2, 1])       # same multiset of (child, factor)
+    p = Graph([s1, s2], operator=Prod())
+    before = ev(p, np.array([[1.5, -2.0]]))
+    optimize.optimize_([p], level=1)
+    assert p.subgraphs[0] is p.subgraphs[1]
+    assert ev(p, np.array([[1.5, -2.0]])) == before
+
+
+# ---- GV reader ---------------------------------------------------------------- #
+def test_gv_tables_match_catalog_sums():
+    kat = {k["name"]: k for k in json.load(open(os.path.join(GOLD, "kat.json")))}["gv_sigma_all_ones"]["expect"]
+    sizes = {4: (111, 382, 1665), 5: (357, 3897, 21376), 6: (1283, 49390, 327481)}
+    for order in (4, 5, 6):
+        t = workloads.get(f"gv_sigma{order}")
+        st = t.stats()
+        assert (st["n_leaf"], st["n_node"], st["n_edge"]) == sizes[order]
+        assert oracle.eval_static(t, np.ones((1, t.n_leaf)))[0].tolist() == kat[str(order)]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_GV), reason="reference checkout not present (GPU box)")
+def test_gv_reader_reproduces_committed_tables():
+    from feynmandiagram_jl_amd import gv
+    # leaf counts before/after optimize for sigma 2..4
+    for order, (l_raw, l_opt, n_feyn) in {2: (12, 8, 3), 3: (117, 32, 24), 4: (1329, 111, 243)}.items():
+        graphs = gv.diagsGV("sigma", order, REF_GV)
+        assert len(graphs) == 2
+        raw, _, _ = lower(graphs)
+        assert raw.n_leaf == l_raw
+        optimize.optimize_(graphs)
+        t, _, _ = lower(graphs)
+        assert t.n_leaf == l_opt
+    graphs = gv.diagsGV("sigma", 4, REF_GV)
+    optimize.optimize_(graphs)
+    t, _, _ = lower(graphs)
+    w = workloads.get("gv_sigma4")
+    for a in ("op", "power", "child_off", "child_idx", "child_fac", "root_slot"):
+        assert np.array_equal(getattr(t.normalized(), a), getattr(w, a))
+
+
+def test_gv_interaction_equal_time_equivalence():
+    from feynmandiagram_jl_amd.gv import BareGreenId, BareInteractionId, mirror_symmetrize
+    # diagram_id.jl:49-69, 81-96
+    assert BareInteractionId("ChargeCharge", [0, 1, 0], (1, 1)) == BareInteractionId("ChargeCharge", [0, -1, 0], (2, 2))
+    assert BareInteractionId("ChargeCharge", [0, 1, 0], (1, 2)) != BareInteractionId("ChargeCharge", [0, 1, 0], (2, 1))
+    assert BareGreenId([0, -1, 1], (1, 2)) == BareGreenId([0, 1, -1], (1, 2))
+    assert BareGreenId([0, 1, 1], (1, 2)) != BareGreenId([0, 1, 1], (2, 1))
+    assert mirror_symmetrize([0, 0, 0]) == (0.0, 0.0, 0.0)
+
+
+# ---- optimizing back end: replay of the allocated program --------------------- #
+def replay(ops, n_reg, n_lds, n_mem, n_acc, leaf, R):
+    B = leaf.shape[0]
+    reg = np.full((max(n_reg, 1), B), np.nan)
+    lds = np.full((max(n_lds, 1), B), np.nan)
+    mem = np.full((max(n_mem, 1), B), np.nan)
+    acc = np.full((max(n_acc, 1), B), np.nan)
+    root = np.zeros((B, R))
+    for o in ops:
+        k, d, a, b = int(o["kind"]), int(o["d"]), int(o["a"]), int(o["b"])
+        sa = -1.0 if o["nega"] else 1.0
+        sb = -1.0 if o["negb"] else 1.0
+        if k == 0: reg[d] = leaf[:, a]
+        elif k == 1: reg[d] = lds[a]
+        elif k == 2: reg[d] = mem[a]
+        elif k == 3: lds[d] = reg[a]
+        elif k == 4: mem[d] = reg[a]
+        elif k == 5: reg[d] = (sa * reg[a]) * (sb * reg[b])
+        elif k == 6: reg[d] = (sa * reg[a]) + (sb * reg[b])
+        elif k == 7: reg[d] = (sa * reg[a]) * o["imm"]
+        elif k == 8: root[:, d] = sa * reg[a]
+        elif k == 10: reg[d] = acc[a]
+        elif k == 11: acc[d] = reg[a]
+        else: raise AssertionError(k)
+    return root
+
+
+@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma4", "gv_sigma5"])
+@pytest.mark.parametrize("budget", [dict(), dict(n_reg=120, n_lds=80, n_acc=124), dict(n_reg=9, n_lds=3, n_acc=2, lookahead_leaf=40)])
+def test_allocated_program_replays_exactly(libfdg, name, budget):
+    """Scheduler + Belady allocator + load hoisting move values, never change them:
+    replaying the machine-op list with IEEE ops gives the oracle's bits."""
+    t = workloads.get(name)
+    h = capi.GraphHandle(t)
+    ops, nr, nl, nm = h.opt_program(**budget)
+    assert nr <= (budget.get("n_reg") or 120) and nl <= (budget.get("n_lds") or 80)
+    leaf = oracle.philox_uniform(9, t.n_leaf, 77)
+    got = replay(ops, nr, nl, nm, h.last_n_acc, leaf, t.n_root)
+    assert np.array_equal(got, oracle.eval_static(t, leaf))
+    valu = int(np.isin(ops["kind"], (5, 6, 7)).sum())
+    st = t.stats()
+    assert valu <= st["flops_alg"]          # factor -1 rides on source modifiers
+
+
+def test_isa_jit_assembles_without_device(libfdg, tmp_path):
+    t = workloads.get("gv_sigma4")
+    h = capi.GraphHandle(t)
+    h.specialize(str(tmp_path), capi.FDG_SPEC_ISA | capi.FDG_SPEC_KEEP_SOURCE)
+    files = os.listdir(tmp_path)
+    assert any(f.endswith(".hsaco") for f in files) and any(f.endswith(".s") for f in files)
+    src = open(os.path.join(tmp_path, [f for f in files if f.endswith(".s")][0])).read()
+    assert "v_fma_f64" not in src and "v_mul_f64" in src and "v_add_f64" in src     # no contraction by construction
+    assert h.info()["specialized"] == 1
+
+
+def test_isa_rejects_unsupported_power(libfdg, tmp_path):
+    a = fd.Graph([])
+    t, _, _ = lower([a ** 5])
+    h = capi.GraphHandle(t)
+    with pytest.raises(capi.FdgError) as e:
+        h.specialize(str(tmp_path), capi.FDG_SPEC_ISA)
+    assert e.value.code == capi.FDG_E_UNSUPPORTED
+    h.specialize(str(tmp_path))              # the HIP-source JIT covers it

@@ -18,12 +18,19 @@ def leaves(B, L, layout, seed=11):
     return leaf
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["sigma2", "synthetic_small", "sigma4_standin", "gv_sigma5"]
 check = "--nocheck" not in sys.argv
+timeonly = "--timeonly" in sys.argv
+opt = {}
+for a in sys.argv:
+    if a.startswith("--opt="):
+        for kv in a[6:].split(","):
+            k, v = kv.split("="); opt[k] = int(v)
+spec_kw = dict(specialize="isa", opt=opt or None)
 for name in names:
     t = table(name)
     st = t.stats()
-    for layout in ("leaf_major", "sample_major"):
+    for layout in (() if timeonly else ("leaf_major", "sample_major")):
         for B in (1, 63, 64, 1000, 20000):
-            f = fd.compile_table(t, specialize="isa")
+            f = fd.compile_table(t, **spec_kw)
             leaf = leaves(B, t.n_leaf, layout)
             root = torch.full((B, t.n_root), -3.0, dtype=torch.float64, device=dev)
             f(root, leaf); torch.cuda.synchronize()
@@ -35,7 +42,7 @@ for name in names:
                 if not ok: print(got[:3], want[:3])
     # timing
     for layout in ("leaf_major",):
-        f = fd.compile_table(t, specialize="isa")
+        f = fd.compile_table(t, **spec_kw)
         B = max(1 << 14, min(1 << 22, int(2e9 / (8 * t.n_leaf))))
         leaf = leaves(B, t.n_leaf, layout)
         root = torch.empty((B, t.n_root), dtype=torch.float64, device=dev)
