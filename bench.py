@@ -37,7 +37,7 @@ def main():
                     help="isa: optimizing back end, gfx950 assembly; hip: straight-line HIP source via hiprtc; interp: table interpreter")
     ap.add_argument("--interp", action="store_true", help="same as --backend interp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
     import numpy as np
@@ -155,32 +155,32 @@ def main():
 
 def cpu_baseline(t, leaf, root, budget_s):
     """The reference's own C back-end text (to_Cstr shape, static.jl:155-197)
-    compiled by gcc -O2 -ffp-contract=off and called once per sample on the host
-    cores, on a bounded sample of the same leaf data; also checks the GPU roots
-    of that sample against it."""
+    compiled by gcc -O2 -ffp-contract=off (-O1 above 2*10^4 nodes, where -O2
+    needs minutes) and called once per sample on the host cores, on a bounded
+    sample of the same leaf data; also checks the GPU roots of that sample."""
     import numpy as np
     import oracle
     from feynmandiagram_jl_amd.lowering import table_to_Cstr
     cores = os.cpu_count() or 1
-    cb = oracle.CBaseline(table_to_Cstr(t), t.n_leaf, t.n_root)
-    n0 = 2048
-    h = leaf[:n0].cpu().numpy()
+    opt = "-O2" if t.n_node <= 20000 else "-O1"
+    cb = oracle.CBaseline(table_to_Cstr(t), t.n_leaf, t.n_root, opt=opt)
+    # single-core rate first (also the calibration for the threaded run)
+    n1 = min(int(leaf.shape[0]), 4096)
+    h1 = np.ascontiguousarray(leaf[:n1].cpu().numpy())
+    cb(h1[:256], 1)
     t0 = time.perf_counter()
-    cb(h, cores)
-    rate = n0 / max(time.perf_counter() - t0, 1e-6)
-    n = int(min(leaf.shape[0], max(n0, rate * budget_s)))
-    h = leaf[:n].cpu().numpy()
+    cb(h1, 1)
+    rate1 = n1 / max(time.perf_counter() - t0, 1e-9)
+    n = int(min(leaf.shape[0], max(4096, rate1 * cores * budget_s * 0.6)))
+    h = np.ascontiguousarray(leaf[:n].cpu().numpy())
+    cb(h[: min(n, 64 * cores)], cores)           # thread start-up outside the clock
     t0 = time.perf_counter()
     ref = cb(h, cores)
     dt = time.perf_counter() - t0
     got = root[:n].cpu().numpy()
-    t1 = time.perf_counter()
-    n1 = max(256, n // (4 * cores))
-    cb(h[:n1], 1)
-    dt1 = time.perf_counter() - t1
     return {"value": n / dt, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": f"{n} samples of the same leaf batch, {dt:.1f} s; reference's to_Cstr text compiled by gcc -O2 -ffp-contract=off (the Julia evaluator cannot run here)",
-            "single_core_evals_per_s": n1 / dt1, "gcc_compile_s": cb.compile_seconds,
+            "sample": f"{n} samples of the same leaf batch in {dt:.2f} s on {cores} threads; reference's to_Cstr text compiled by gcc {opt} -ffp-contract=off (the Julia evaluator cannot run here)",
+            "single_core_evals_per_s": rate1, "gcc_compile_s": cb.compile_seconds,
             "gpu_matches_cpu_bitwise": bool(np.array_equal(got, ref)),
             "max_abs_dev": float(np.abs(got - ref).max())}
 

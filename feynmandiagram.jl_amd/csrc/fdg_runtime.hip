@@ -595,10 +595,10 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
     // prefetcher cannot.  B: one wave per SIMD with the idle half of the register
     // file (124 AGPR pairs) and 80 LDS slots as on-chip spill levels -- taken as
     // soon as A would have to spill to the HBM panel.
-    fdg::OptParams A; A.n_reg = 120; A.n_lds = 40; A.n_acc = 0;
+    fdg::OptParams A; A.n_reg = 120; A.n_lds = 40; A.n_acc = 0; A.lookahead_leaf = 300;
     fdg::build_opt_program(g->prog, A, prog);
     if (prog.supported && (prog.n_ld_mem + prog.n_st_mem) > 0) {
-      fdg::OptParams Bc; Bc.n_reg = 120; Bc.n_lds = 80; Bc.n_acc = 124;
+      fdg::OptParams Bc; Bc.n_reg = 120; Bc.n_lds = 80; Bc.n_acc = 124; Bc.lookahead_leaf = 100; Bc.lookahead_mem = 64;
       fdg::OptProgram pb;
       fdg::build_opt_program(g->prog, Bc, pb);
       if (pb.supported) prog = std::move(pb);

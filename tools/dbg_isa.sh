@@ -1,7 +1,7 @@
 #!/bin/bash
-for G in gv_sigma5 sigma4_standin sigma4_worstcase gv_sigma6 synthetic_small; do
-for opt in "n_reg=120,n_lds=40,lookahead_leaf=300" "n_reg=120,n_lds=80,n_acc=124,lookahead_leaf=300" "n_reg=120,n_lds=80,lookahead_leaf=300"; do
-  echo "== $G $opt"; python tools/gpu_isa_check.py $G --timeonly --opt=$opt 2>&1 | grep TIME
+for w in 1 2 3 4; do
+  echo "== sigma4_standin waves/CU=$w"; FDG_ISA_WAVES_PER_CU=$w python tools/gpu_isa_check.py sigma4_standin --timeonly 2>&1 | grep TIME
 done
+for opt in "n_reg=120,n_lds=100,n_acc=124" "n_reg=120,n_lds=80,n_acc=124,lookahead_mem=64" "n_reg=120,n_lds=80,n_acc=124,lookahead_mem=300" "n_reg=120,n_lds=80,n_acc=124,lookahead_leaf=100"; do
+  echo "== sigma4_standin $opt"; python tools/gpu_isa_check.py sigma4_standin --timeonly --opt=$opt 2>&1 | grep TIME
 done
-python tools/gpu_isa_check.py sigma4_standin,synthetic_small --opt=n_reg=120,n_lds=80,n_acc=124 2>&1 | grep -v "exact\|amdgpu"
