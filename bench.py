@@ -142,6 +142,15 @@ def main():
                                       "hip": "fdg_spec_sm" if args.layout == "sample_major" else "fdg_spec_gen"}[args.backend],
                            "avg_kernel_ms": avg_kernel_s * 1e3,
                            "algorithmic_bytes_per_launch": bytes_per_launch}
+        # HBM traffic per launch: measured separately with rocprofv3 --pmc (bench.py cannot collect
+        # counters on itself); profiles/r01_traffic.json holds bytes per evaluation for the default configs
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(args.workload)
+            if tr and tr["layout"] == args.layout and args.backend == "isa":
+                out["roofline"]["traffic"] = tr["bytes_per_eval"] * B
+                out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_b_isa_*.txt (per evaluation, scaled to this batch)"
+        except (OSError, ValueError):
+            pass
         out["valu_fp64"] = {"achieved_tflops": st["flops_alg"] * B / avg_kernel_s / 1e12,
                             "peak_tflops_fma": FP64_VALU_PEAK_TFLOPS,
                             "note": "secondary ceiling: add/mul only (no FMA contraction allowed), so the usable peak is half"}
