@@ -44,6 +44,7 @@ def main():
     import torch
     import feynmandiagram_jl_amd as fd
     from feynmandiagram_jl_amd import capi, workloads
+    from feynmandiagram_jl_amd.sharding import reduce_observable, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -51,7 +52,7 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("FDG_BENCH_FORCE_DIST"):   # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
@@ -75,7 +76,9 @@ def main():
     root = torch.empty((B, R), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream()
     # per-rank Philox offset: results do not depend on how samples are sharded
-    capi.fill_uniform_device(leaf.data_ptr(), B, L, leaf.stride(0), leaf.stride(1), 1234, rank * B, stream.cuda_stream)
+    start, count = shard_range(B * world, rank, world)          # weak scaling: B samples per GPU
+    assert count == B
+    capi.fill_uniform_device(leaf.data_ptr(), B, L, leaf.stride(0), leaf.stride(1), 1234, start, stream.cuda_stream)
 
     def step():
         f(root, leaf)
@@ -93,8 +96,7 @@ def main():
         step()
         ev[i + 1].record(stream)          # same stream the kernel is launched on
     acc = root.sum(dim=0)                 # final observable accumulation
-    if dist:
-        dist.all_reduce(acc)              # the one collective: R doubles over xGMI
+    reduce_observable(acc)                # the one collective: R doubles over xGMI (RCCL)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
