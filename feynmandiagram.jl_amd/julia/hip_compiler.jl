@@ -1,0 +1,177 @@
+# hip_compiler.jl -- Julia host side of the MI355X evaluator back end.
+#
+# Drop into src/backend/ of FeynmanDiagram.jl and `include("hip_compiler.jl")`
+# from src/backend/compiler.jl after the existing includes (compiler.jl:16-18).
+# It adds
+#
+#     Compilers.compile_hip(graphs; root=[id(g) for g in graphs], backend=:isa)
+#         -> (f::GraphFunc, leafmap::Dict{Int,G})
+#
+# with the *same* `leafmap` (index of `leafVal` -> leaf graph object) that
+# `Compilers.compile` / `to_julia_str` return (static.jl:98-133), so
+# `FrontEnds.leafstates(leaf_maps, ...)` (frontends.jl:115-232) works unchanged.
+#
+#     f(root::AbstractVector, leafVal::AbstractVector)   one sample; mutates root,
+#                                                        returns the last root written
+#     f(root::AbstractMatrix, leafVal::AbstractMatrix)   B samples: leafVal is B x L,
+#                                                        root is B x R (column-major
+#                                                        Julia matrices = the "leaf
+#                                                        major" layout of the C ABI)
+#
+# STATUS: UNVERIFIED.  Julia is not installed in the build environment or on the
+# GPU box, so this file has never been executed.  The C ABI it binds
+# (include/fdg.h) is exercised by the Python/ctypes twin (capi.py) in tests/.
+#
+# The traversal below restates to_julia_str's loop over the arrays of the node
+# table instead of over text; it must stay in lock step with static.jl:98-133.
+
+const _libfdg = get(ENV, "FDG_LIB", "libfdg.so")
+
+struct _FdgGraphDesc
+    n_leaf::UInt32
+    n_node::UInt32
+    n_root::UInt32
+    n_edge::UInt32
+    op::Ptr{UInt8}
+    power::Ptr{Int32}
+    child_off::Ptr{UInt32}
+    child_idx::Ptr{UInt32}
+    child_fac::Ptr{Float64}
+    root_slot::Ptr{UInt32}
+end
+
+const FDG_NO_ROOT = 0xffffffff
+const FDG_SPEC_ISA = Cuint(4)
+
+_fdg_check(rc) = rc == 0 ? nothing :
+    error("fdg error $rc: " * unsafe_string(ccall((:fdg_last_error, _libfdg), Cstring, ())))
+
+mutable struct GraphFunc
+    handle::Ptr{Cvoid}
+    n_leaf::Int
+    n_root::Int
+    last_root::Int          # 1-based index of the root written last, 0 if none
+    function GraphFunc(h, L, R, last)
+        f = new(h, L, R, last)
+        finalizer(x -> ccall((:fdg_graph_destroy, _libfdg), Cint, (Ptr{Cvoid},), x.handle), f)
+        return f
+    end
+end
+
+_opcode(::Type{ComputationalGraphs.Sum}) = (0x00, Int32(0))
+_opcode(::Type{ComputationalGraphs.Prod}) = (0x01, Int32(0))
+_opcode(::Type{ComputationalGraphs.Power{N}}) where {N} = (0x02, Int32(N))
+_opcode(op::Type) = error(                       # same failure as static.jl:6-11
+    "Static representation for computational graph nodes with operator $(op) not yet implemented! ")
+
+"""
+    lower_to_table(graphs; root) -> (arrays..., leafmap)
+
+Statement order, leaf numbering and root mapping of `to_julia_str` (static.jl:98-133).
+"""
+function lower_to_table(graphs::AbstractVector{G}; root::AbstractVector{Int}=[id(g) for g in graphs]) where {G<:AbstractGraph}
+    leaf_index = Dict{Int,Int}()      # id -> 0-based leaf index
+    node_index = Dict{Int,Int}()      # id -> 0-based internal index
+    leafmap = Dict{Int,G}()
+    order = G[]
+    for graph in graphs
+        for g in PostOrderDFS(graph)
+            g_id = id(g)
+            if isempty(subgraphs(g))
+                haskey(leaf_index, g_id) && continue
+                leaf_index[g_id] = length(leaf_index)
+                leafmap[length(leaf_index)] = g
+            else
+                haskey(node_index, g_id) && continue
+                _opcode(operator(g))
+                node_index[g_id] = length(order)
+                push!(order, g)
+            end
+        end
+    end
+    L = length(leaf_index)
+    vidx(gid) = haskey(leaf_index, gid) ? leaf_index[gid] : L + node_index[gid]
+    op = UInt8[]; power = Int32[]; off = UInt32[0]; idx = UInt32[]; fac = Float64[]
+    for g in order
+        o, p = _opcode(operator(g))
+        push!(op, o); push!(power, p)
+        for (sg, f) in zip(subgraphs(g), subgraph_factors(g))
+            push!(idx, UInt32(vidx(id(sg)))); push!(fac, Float64(f))
+        end
+        push!(off, UInt32(length(idx)))
+    end
+    root_slot = fill(UInt32(FDG_NO_ROOT), length(root))
+    last_root, last_rank = 0, -1
+    for (k, rid) in enumerate(root)
+        findfirst(==(rid), root) == k || continue             # findfirst (static.jl:112)
+        (haskey(leaf_index, rid) || haskey(node_index, rid)) || continue
+        root_slot[k] = UInt32(vidx(rid))
+        rank = haskey(node_index, rid) ? node_index[rid] + L : leaf_index[rid] - L   # internal nodes are emitted after the leaves they need
+        if rank > last_rank
+            last_rank, last_root = rank, k
+        end
+    end
+    return L, op, power, off, idx, fac, root_slot, leafmap, last_root
+end
+
+function compile_hip(graphs::AbstractVector{<:AbstractGraph};
+    root::AbstractVector{Int}=[id(g) for g in graphs], backend::Symbol=:isa, cache_dir::Union{Nothing,String}=nothing)
+    L, op, power, off, idx, fac, root_slot, leafmap, last_root = lower_to_table(graphs; root=root)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve op power off idx fac root_slot begin
+        desc = Ref(_FdgGraphDesc(UInt32(L), UInt32(length(op)), UInt32(length(root_slot)), UInt32(length(idx)),
+            pointer(op), pointer(power), pointer(off), pointer(idx), pointer(fac), pointer(root_slot)))
+        _fdg_check(ccall((:fdg_graph_create, _libfdg), Cint, (Ref{_FdgGraphDesc}, Ref{Ptr{Cvoid}}), desc, h))
+    end
+    if backend != :interp
+        flags = backend == :isa ? FDG_SPEC_ISA : Cuint(0)
+        cdir = isnothing(cache_dir) ? C_NULL : cache_dir
+        rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, flags)
+        if rc == -2 && backend == :isa      # FDG_E_UNSUPPORTED: e.g. Power{N}, N > 3 -> HIP-source JIT
+            rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, Cuint(0))
+        end
+        _fdg_check(rc)
+    end
+    return GraphFunc(h[], L, length(root_slot), last_root), leafmap
+end
+
+# one sample: the calling convention of the generated eval_graph!(root, leafVal)
+function (f::GraphFunc)(root::AbstractVector{Float64}, leafVal::AbstractVector{Float64})
+    length(leafVal) >= f.n_leaf || throw(BoundsError(leafVal, f.n_leaf))
+    length(root) >= f.n_root || throw(BoundsError(root, f.n_root))
+    lv = Vector{Float64}(leafVal[1:f.n_leaf]); rt = Vector{Float64}(root[1:f.n_root])
+    _fdg_check(ccall((:fdg_eval, _libfdg), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), f.handle, lv, rt, 1))
+    root[1:f.n_root] .= rt
+    return f.last_root == 0 ? nothing : root[f.last_root]
+end
+
+# B samples, host matrices (B x L in, B x R out, column-major): H2D, eval, D2H
+function (f::GraphFunc)(root::Matrix{Float64}, leafVal::Matrix{Float64})
+    B = size(leafVal, 1)
+    size(leafVal, 2) >= f.n_leaf || throw(BoundsError(leafVal, (1, f.n_leaf)))
+    size(root) == (B, f.n_root) || throw(DimensionMismatch("root must be B x R"))
+    # fdg_eval takes row-major [B,L]; a Julia (L x B) matrix is exactly that
+    lt = permutedims(leafVal[:, 1:f.n_leaf]); rt = permutedims(root)
+    _fdg_check(ccall((:fdg_eval, _libfdg), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), f.handle, lt, rt, B))
+    root .= permutedims(rt)
+    return root
+end
+
+# B samples, device pointers (e.g. from AMDGPU.jl ROCArrays of size B x L / B x R):
+# strides in elements; a column-major B x L matrix is (sample stride 1, leaf stride B)
+function eval_device!(f::GraphFunc, d_root::Ptr{Float64}, d_leaf::Ptr{Float64}, B::Integer;
+    leaf_strides=(1, B), root_strides=(1, B), stream::Ptr{Cvoid}=C_NULL)
+    _fdg_check(ccall((:fdg_eval_device, _libfdg), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64, Int64, Ptr{Cvoid}),
+        f.handle, d_leaf, leaf_strides[1], leaf_strides[2], d_root, root_strides[1], root_strides[2], B, stream))
+end
+
+# acc[k] += sum_b weight[b] * root_k(b), everything on device
+function accumulate_device!(f::GraphFunc, d_acc::Ptr{Float64}, d_leaf::Ptr{Float64}, d_weight::Ptr{Float64}, B::Integer;
+    leaf_strides=(1, B), stream::Ptr{Cvoid}=C_NULL)
+    _fdg_check(ccall((:fdg_accumulate_device, _libfdg), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Cvoid}),
+        f.handle, d_leaf, leaf_strides[1], leaf_strides[2], d_weight, d_acc, B, stream))
+end
+
+export compile_hip, GraphFunc, eval_device!, accumulate_device!
