@@ -89,6 +89,8 @@ struct fdg_graph {
   uint32_t isa_vgpr = 0, isa_lds_bytes = 0, isa_mem_slots = 0;
   void *d_ws2 = nullptr;           // roots scratch for accumulate through the ISA kernel
   size_t ws2_bytes = 0;
+  void *d_ws3 = nullptr;           // leaf-major copy of a sample-major chunk for the ISA kernel
+  size_t ws3_bytes = 0;
   int device = -1;
   int n_cu = 0;
 };

