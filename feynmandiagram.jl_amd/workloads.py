@@ -20,8 +20,9 @@ import numpy as np
 
 from .nodetable import NodeTable, OP_POWER, OP_PROD, from_program, synthetic_parquet_like
 
-PREBUILT = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma4", "gv_sigma5", "gv_sigma6")
-PREBUILT_HIP = ("sigma2", "synthetic_small", "sigma4_standin", "gv_sigma5")
+PREBUILT = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "sigma4_taylor_standin", "gv_sigma4",
+            "gv_sigma5", "gv_sigma6")
+PREBUILT_HIP = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "sigma4_taylor_standin", "gv_sigma5")
 
 
 @functools.lru_cache(maxsize=None)

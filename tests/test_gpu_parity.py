@@ -212,3 +212,36 @@ def test_full_size_properties_sigma4(libfdg, cuda):
     idx = np.random.default_rng(0).choice(B, 2000, replace=False)
     sub = leaf[torch.from_numpy(idx).to(cuda)].cpu().numpy()
     assert np.array_equal(r_spec.cpu().numpy()[idx], oracle.eval_static(t, sub))
+
+
+@pytest.mark.parametrize("spec", [False, True, "isa"], ids=["interp", "hipjit", "isa"])
+def test_config4_taylor_standin_and_special_values(libfdg, cuda, spec):
+    """BASELINE.json config 4 stand-in (3x larger graph, Power{2} nodes, 6 roots) and IEEE special
+    values: infinities, NaNs, signed zeros and subnormals must come out exactly as on the CPU."""
+    import torch
+    t = workloads.get("sigma4_taylor_standin")
+    assert t.stats()["n_power"] > 0 and t.n_root == 6
+    f = fd.compile_table(t, specialize=spec)
+    B = 700
+    leaf = dev_leaves(cuda, B, t.n_leaf, 31, 5, "leaf_major" if spec == "isa" else "sample_major")
+    got = run(f, leaf)
+    assert np.array_equal(got, oracle.eval_static(t, leaf.cpu().numpy()))
+    # special values on a small graph
+    t2 = workloads.get("synthetic_small")
+    f2 = fd.compile_table(t2, specialize=spec)
+    h = oracle.philox_uniform(256, t2.n_leaf, 3) - 0.5
+    h[0, :] = 0.0
+    h[1, ::2] = -0.0
+    h[2, 5] = np.inf
+    h[3, 7] = -np.inf
+    h[4, 9] = np.nan
+    h[5, :] = 5e-324
+    h[6, :] = 1e-310
+    h[7, :] = 1e300
+    h[8, :] = -1e300
+    got = run(f2, torch.from_numpy(h).to(cuda))
+    want = oracle.eval_static(t2, h)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    m = ~np.isnan(want)
+    assert np.array_equal(got[m], want[m])
+    assert np.array_equal(np.signbit(got[m]), np.signbit(want[m]))
