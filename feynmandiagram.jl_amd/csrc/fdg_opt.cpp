@@ -70,6 +70,44 @@ void build_uops(Builder &B) {
   std::vector<uint32_t> tops;
   for (auto &rk : rootlist) if (rk.first >= L) tops.push_back(rk.first - L);
   tops.erase(std::unique(tops.begin(), tops.end()), tops.end());
+  // Order in which the roots are evaluated (values do not depend on it): start with the root that
+  // needs the most nodes, then always continue with the root whose cone is already computed to the
+  // largest extent -- graphs that share most of their sub-expressions (Taylor coefficients of one
+  // diagram, instant/dynamic parts) are finished while the shared values are still on chip.
+  if (tops.size() > 1 && tops.size() <= 64) {
+    const size_t R = tops.size();
+    std::vector<std::vector<uint8_t>> cone(R, std::vector<uint8_t>(p.N, 0));
+    std::vector<uint64_t> csize(R, 0);
+    std::vector<uint32_t> stk;
+    for (size_t r = 0; r < R; ++r) {
+      stk.assign(1, tops[r]);
+      cone[r][tops[r]] = 1;
+      while (!stk.empty()) {
+        const uint32_t n = stk.back(); stk.pop_back();
+        csize[r]++;
+        for (uint32_t e = p.off[n]; e < p.off[n + 1]; ++e) {
+          const uint32_t c = p.idx[e];
+          if (c >= L && !cone[r][c - L]) { cone[r][c - L] = 1; stk.push_back(c - L); }
+        }
+      }
+    }
+    std::vector<uint8_t> done(p.N, 0), used(R, 0);
+    std::vector<uint32_t> ordered;
+    for (size_t k = 0; k < R; ++k) {
+      size_t best = R; double best_score = -1.0;
+      for (size_t r = 0; r < R; ++r) {
+        if (used[r]) continue;
+        uint64_t ov = 0;
+        if (k) for (uint32_t n = 0; n < p.N; ++n) ov += (cone[r][n] & done[n]);
+        const double score = k ? (double)ov / (double)csize[r] + 1e-9 * (double)csize[r] / (double)p.N : (double)csize[r];
+        if (score > best_score) { best_score = score; best = r; }
+      }
+      used[best] = 1;
+      ordered.push_back(tops[best]);
+      for (uint32_t n = 0; n < p.N; ++n) done[n] |= cone[best][n];
+    }
+    tops.swap(ordered);
+  }
   for (uint32_t top : tops) {
     if (B.ref_of[L + top] != NONE) continue;
     st.push_back(Frame{top, 0, NONE});

@@ -6,6 +6,10 @@ Each maps to a config of BASELINE.json:
                     (N ~ 10^4 nodes, L = 300, parquet-recursion sharing; the real
                     graph needs the Julia front end)
   sigma4_worstcase  same size, operands drawn uniformly at random (no locality)
+  gv_sigma4_taylor2, gv_sigma5_taylor2
+                    config 4 on real reference data: the GV 4-/5-loop self-energy with Taylor-mode
+                    AD counterterms of order 2 in the coupling (restated taylorAD + optimize!;
+                    roots = orders 0,1,2 x {instant, dynamic}); N = 7 373 / 115 588 nodes
   gv_sigma4/5/6     real reference data: GV self-energy catalogs of order 4/5/6
                     read from the reference's .diag files and run through the
                     restated optimize! (tests/golden/make_gv_tables.py)
@@ -21,7 +25,7 @@ import numpy as np
 from .nodetable import NodeTable, OP_POWER, OP_PROD, from_program, synthetic_parquet_like
 
 PREBUILT = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "sigma4_taylor_standin", "gv_sigma4",
-            "gv_sigma5", "gv_sigma6")
+            "gv_sigma5", "gv_sigma6", "gv_sigma4_taylor2", "gv_sigma5_taylor2")
 PREBUILT_HIP = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "sigma4_taylor_standin", "gv_sigma5")
 
 

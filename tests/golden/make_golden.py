@@ -48,7 +48,7 @@ def main():
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(kat, f, indent=1, ensure_ascii=False)
     for name, B, seed in (("sigma2", 257, 1234), ("synthetic_small", 64, 1234), ("sigma4_standin", 16, 1234),
-                          ("sigma4_worstcase", 8, 1234), ("gv_sigma5", 16, 1234)):
+                          ("sigma4_worstcase", 8, 1234), ("gv_sigma5", 16, 1234), ("gv_sigma4_taylor2", 32, 1234)):
         t = workloads.get(name)
         leaf = oracle.philox_uniform(B, t.n_leaf, seed)
         root = oracle.eval_static(t, leaf)
@@ -59,7 +59,9 @@ def main():
                             child_off=tn.child_off, child_idx=tn.child_idx, child_fac=tn.child_fac,
                             root_slot=tn.root_slot, name=np.array(tn.name),
                             leaf_pos=tn.leaf_positions().astype(np.uint32),
-                            seed=np.int64(seed), leaf=leaf, root_static=root, root_interp=root_interp)
+                            seed=np.int64(seed), leaf=leaf, root_static=root, root_interp=root_interp,
+                            **({k: np.load(os.path.join(HERE, f"{name}.npz"))[k] for k in ("leaf_base", "leaf_dorder")}
+                               if name.endswith("taylor2") else {}))
         print(name, t.stats(), root[0])
 
 

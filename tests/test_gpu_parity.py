@@ -40,7 +40,7 @@ def run(f, leaf):
 
 
 @pytest.mark.parametrize("spec", [False, True, "isa"], ids=["interp", "hipjit", "isa"])
-@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma5"])
+@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma5", "gv_sigma4_taylor2"])
 def test_golden_vectors_on_device(libfdg, cuda, name, spec):
     import torch
     z = np.load(os.path.join(GOLD, f"{name}.npz"))

@@ -200,7 +200,8 @@ def replay(ops, n_reg, n_lds, n_mem, n_acc, leaf, R):
     return root
 
 
-@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma4", "gv_sigma5"])
+@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma4", "gv_sigma5",
+                                  "gv_sigma4_taylor2"])
 @pytest.mark.parametrize("budget", [dict(), dict(n_reg=120, n_lds=80, n_acc=124), dict(n_reg=9, n_lds=3, n_acc=2, lookahead_leaf=40)])
 def test_allocated_program_replays_exactly(libfdg, name, budget):
     """Scheduler + Belady allocator + load hoisting move values, never change them:
@@ -236,3 +237,111 @@ def test_isa_rejects_unsupported_power(libfdg, tmp_path):
         h.specialize(str(tmp_path), capi.FDG_SPEC_ISA)
     assert e.value.code == capi.FDG_E_UNSUPPORTED
     h.specialize(str(tmp_path))              # the HIP-source JIT covers it
+
+
+# ---- Taylor-mode AD ------------------------------------------- #
+def test_taylorseries_numeric_kats():
+    # test/taylor.jl:44-63
+    from feynmandiagram_jl_amd.taylor import getcoeff, set_variables
+    a, b, c, d, e = set_variables("a b c d e", orders=[3, 3, 3, 3, 3])
+    F1 = (a + b) * (a + b) * (a + b)
+    assert [getcoeff(F1, o) for o in ([2, 1, 0, 0, 0], [1, 2, 0, 0, 0], [3, 0, 0, 0, 0], [0, 3, 0, 0, 0])] == [3.0, 3.0, 1.0, 1.0]
+    F2 = (1 + a) * (3 + 2 * c)
+    assert [getcoeff(F2, o) for o in ([0] * 5, [1, 0, 0, 0, 0], [0, 0, 1, 0, 0], [1, 0, 1, 0, 0])] == [3.0, 3.0, 2.0, 2.0]
+    F3 = (a + b) ** 3
+    assert getcoeff(F3, [2, 1, 0, 0, 0]) == 3.0 and getcoeff(F3, [0, 3, 0, 0, 0]) == 1.0
+    assert getcoeff(F3, [4, 0, 0, 0, 0]) is None           # truncated at the variable's order
+
+
+def _getdiagram(spin):
+    # test/taylor.jl:115-161 with the leaf ids the reference uses
+    import math
+    from feynmandiagram_jl_amd.gv import BareGreenId, BareInteractionId
+    gK = [[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 0.0, 1.0]]
+    gT = [(1, 2), (2, 1)]
+    g = [Graph([], properties=BareGreenId(k=gK[i], t=gT[i]), name="G") for i in range(2)]
+    vd = [Graph([], properties=BareInteractionId("ChargeCharge", k=[0.0, 0.0, 1.0, 0.0]), name="Vd") for _ in range(2)]
+    veK = [[1, 0, -1, -1], [0, 1, 0, -1]]
+    ve = [Graph([], properties=BareInteractionId("ChargeCharge", k=veK[i]), name="Ve") for i in range(2)]
+    ggn = Graph([g[0], g[1]], operator=Prod())
+    vdd = Graph.new([vd[0], vd[1]], operator=Prod(), factor=spin)
+    vde = Graph.new([vd[0], ve[1]], operator=Prod(), factor=-1.0)
+    ved = Graph.new([ve[0], vd[1]], operator=Prod(), factor=-1.0)
+    vsum = Graph([vdd, vde, ved], operator=Sum())
+    return Graph.new([vsum, ggn], operator=Prod(), factor=1 / (2 * math.pi) ** 3, name="root")
+
+
+def test_taylor_ad_of_parquet_like_graph():
+    """test/taylor.jl:181-208: every Taylor coefficient leaf set to 1/taylor_factorial(order), so all
+    derivatives equal 1: coefficient [i,j] = (spin-2)*factor * 2^(#differentiated kinds) / i!j!."""
+    import math
+    from feynmandiagram_jl_amd import taylor
+    from feynmandiagram_jl_amd.gv import BareGreenId, BareInteractionId
+    spin = 0.5
+    factor = 1 / (2 * math.pi) ** 3
+    root = _getdiagram(spin)
+    optimize.optimize_([root])
+    taylor.set_variables("x y", orders=[2, 2])
+    dep = {}
+    for n in optimize._all_nodes_postorder([root]):
+        if not n.subgraphs:
+            dep[n.id] = [isinstance(n.properties, BareGreenId), isinstance(n.properties, BareInteractionId)]
+    t, tmap = taylor.taylorexpansion(root, dep)
+    expect = {(0, 0): 1, (0, 1): 2, (1, 0): 2, (1, 1): 4, (2, 0): 4, (0, 2): 4}
+    for order, mult in expect.items():
+        coeff = t.coeffs[order]
+        tab, leafmap, _ = lower([coeff])
+        leaf = np.array([[1.0 / taylor.taylor_factorial([o for o in leafmap[i + 1].orders[:2]]) for i in range(tab.n_leaf)]])
+        got = oracle.eval_interp(tab, leaf)[0, 0]
+        want = (-2 + spin) * mult * factor / taylor.taylor_factorial(order)
+        assert math.isclose(got, want, rel_tol=1.5e-8), (order, got, want)
+        assert math.isclose(oracle.eval_static(tab, leaf)[0, 0], want, rel_tol=1.5e-8)
+
+
+def test_taylorAD_groups_by_order_and_evaluates_on_any_backend(libfdg):
+    """taylorAD (utility.jl:48-93) on the real GV sigma_3 graphs, order 2 in the interaction: the
+    enlarged graph set lowers through the same pipeline (config 4's shape: Power{2} nodes appear)."""
+    if not os.path.isdir(REF_GV):
+        pytest.skip("reference checkout not present (GPU box)")
+    from feynmandiagram_jl_amd import gv, taylor
+    graphs = gv.diagsGV("sigma", 3, REF_GV)
+    optimize.optimize_(graphs)
+    d = taylor.taylorAD(graphs, [2], [lambda pr: isinstance(pr, gv.BareInteractionId)])
+    assert sorted(d) == [(0,), (1,), (2,)] and all(len(v) == 2 for v in d.values())
+    allg = [g for o in sorted(d) for g in d[o]]
+    optimize.optimize_(allg)
+    t, leafmap, _ = lower(allg)
+    assert t.n_root == 6 and t.n_node > 50
+    # order-0 coefficients are the original graphs: same value on the same leaves
+    t0, lm0, _ = lower(graphs)
+    x = oracle.philox_uniform(5, t.n_leaf, 9)
+    pos = {id(leafmap[i + 1]): i for i in range(t.n_leaf)}
+    x0 = np.stack([x[:, pos[id(lm0[i + 1])]] for i in range(t0.n_leaf)], axis=1)
+    full = oracle.eval_static(t, x)
+    assert np.allclose(full[:, :2], oracle.eval_static(t0, x0), rtol=1e-13)
+    # first-order coefficient == directional derivative w.r.t. the interaction leaves (finite differences)
+    eps = 1e-6
+    is_v0 = np.array([isinstance(lm0[i + 1].properties, gv.BareInteractionId) for i in range(t0.n_leaf)])
+    d1 = {id(leafmap[i + 1]): i for i in range(t.n_leaf) if tuple(leafmap[i + 1].orders[:1]) == (1,)}
+    assert len(d1) == int(is_v0.sum())
+
+
+def test_committed_taylor_table_satisfies_series_identity():
+    """gv_sigma4_taylor2 (BASELINE.json config 4 on real GV data): c0 + x c1 + x^2 c2 of the enlarged graph
+    equals the plain 4-loop graph evaluated at V0 + x V1 + x^2 V2, up to O(x^3) -- checked on the committed
+    tables only (no reference needed), independently of the Taylor restatement."""
+    z = np.load(os.path.join(GOLD, "gv_sigma4_taylor2.npz"))
+    t = workloads.get("gv_sigma4_taylor2")
+    t0 = workloads.get("gv_sigma4")
+    base, dord = z["leaf_base"], z["leaf_dorder"]
+    assert t.n_root == 6 and t.stats()["n_power"] > 0 and base.max() < t0.n_leaf
+    is_v = np.zeros(t0.n_leaf, dtype=bool)
+    is_v[base[dord > 0]] = True                      # leaves that own derivative leaves are the interactions
+    rng = np.random.default_rng(4)
+    v = rng.uniform(0.5, 1.5, size=(3, t0.n_leaf))
+    x = 1e-3
+    f_x = oracle.eval_static(t0, (v[0] + np.where(is_v, x * v[1] + x * x * v[2], 0.0))[None, :])[0]
+    c = oracle.eval_static(t, np.array([[v[dord[i], base[i]] for i in range(t.n_leaf)]]))[0].reshape(3, 2)
+    series = c[0] + x * c[1] + x * x * c[2]
+    assert np.all(np.abs(series - f_x) < 1e-2 * np.abs((c[0] + x * c[1]) - f_x))
+    assert np.all(np.abs(c[0] - oracle.eval_static(t0, v[0][None, :])[0]) <= 1e-12 * (1 + np.abs(c[0])))
