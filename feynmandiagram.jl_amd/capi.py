@@ -28,7 +28,7 @@ EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
     "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_graph_release_device", "fdg_powi",
-    "fdg_graph_set_opt_params", "fdg_graph_opt_program",
+    "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups",
 ]
 
 
@@ -112,6 +112,7 @@ def lib():
     L.fdg_accumulate_device.argtypes = [vp, dp, i64, i64, dp, dp, i64, vp]
     L.fdg_fill_uniform_device.argtypes = [dp, i64, u32, i64, i64, u64, u64, vp]
     L.fdg_graph_release_device.argtypes = [vp]
+    L.fdg_graph_set_schedule_groups.argtypes = [vp, C.c_void_p, u32]
     L.fdg_graph_set_opt_params.argtypes = [vp, C.POINTER(OptParams)]
     L.fdg_graph_opt_program.argtypes = [vp, C.POINTER(OptParams), C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64),
                                         C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
@@ -144,6 +145,15 @@ class GraphHandle:
         h = C.c_void_p()
         check(lib().fdg_graph_create(C.byref(d), C.byref(h)))
         self._h = h
+        if getattr(t, "sched_group", None) is not None:
+            self.set_schedule_groups(t.sched_group)
+
+    def set_schedule_groups(self, group):
+        if group is None:
+            check(lib().fdg_graph_set_schedule_groups(self._h, None, 0))
+            return
+        g = np.ascontiguousarray(group, dtype=np.uint32)
+        check(lib().fdg_graph_set_schedule_groups(self._h, g.ctypes.data, g.shape[0]))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -39,6 +39,8 @@ struct Lowered {
   std::vector<double> fac;
   std::vector<uint32_t> root_slot;
 
+  std::vector<uint32_t> sched_group;   // optional [N]: producer's grouping hint for the scheduler
+
   // analysis
   std::vector<uint8_t> live;       // [L+N] reachable from a root
   std::vector<uint32_t> order;     // live internal nodes (index into 0..N-1), evaluation order

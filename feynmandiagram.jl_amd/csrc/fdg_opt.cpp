@@ -108,39 +108,103 @@ void build_uops(Builder &B) {
     }
     tops.swap(ordered);
   }
+  // One fold step of frame f (operand already computed).  Returns true when the node is finished.
+  auto step = [&](Frame &f) -> bool {
+    const uint32_t n = f.n, a = p.off[n], k = p.off[n + 1] - a;
+    const uint32_t c = p.idx[a + f.i];
+    const uint32_t cr = B.ref_of[c];
+    const double fc = p.fac[a + f.i];
+    uint32_t acc = f.acc;
+    if (p.op[n] == FDG_OP_SUM) {
+      const uint32_t t = B.mulc(cr, fc);                       // c_i * f_i   (static.jl:18)
+      acc = (f.i == 0) ? t : B.op2(M_ADD, acc, t);
+    } else if (p.op[n] == FDG_OP_PROD) {
+      acc = (f.i == 0) ? cr : B.op2(M_MUL, acc, cr);           // ((acc * c_i) * f_i)  (static.jl:28)
+      acc = B.mulc(acc, fc);
+    } else {  // Power: exactly one child
+      const int32_t N = p.power[n];
+      if (N == 2) acc = B.op2(M_MUL, cr, cr);
+      else if (N == 3) acc = B.op2(M_MUL, B.op2(M_MUL, cr, cr), cr);
+      else { B.ok = false; B.why = "Power{N} with N outside {2,3}"; acc = cr; }
+      acc = B.mulc(acc, fc);
+    }
+    f.acc = acc;
+    f.i++;
+    if (f.i < k) return false;
+    B.ref_of[L + n] = f.acc;
+    emit_roots(L + n);
+    return true;
+  };
+
+  if (p.sched_group.size() == p.N) {
+    // Grouped lock-step schedule.  The producer may tag nodes that belong together (the Taylor
+    // coefficients of one original node): all members of a group are evaluated together, advancing
+    // one fold step each in turn, and a missing operand pulls in its whole group first.  This is a
+    // depth-first walk of the *original* graph with a small vector per node, so the operands shared
+    // by the members are consumed while they are still in registers.  Values do not depend on it.
+    std::vector<std::vector<uint32_t>> members;
+    {
+      std::vector<std::pair<uint32_t, uint32_t>> gs;
+      for (uint32_t n = 0; n < p.N; ++n) if (p.live[L + n]) gs.push_back({p.sched_group[n], n});
+      std::sort(gs.begin(), gs.end());
+      std::vector<uint32_t> dense(p.N, 0);
+      for (size_t i = 0; i < gs.size(); ++i) {
+        if (i == 0 || gs[i].first != gs[i - 1].first) members.emplace_back();
+        members.back().push_back(gs[i].second);
+        dense[gs[i].second] = (uint32_t)members.size() - 1;
+      }
+      struct GFrame { std::vector<Frame> fr; size_t cur; };
+      std::vector<GFrame> gst;
+      std::vector<uint8_t> started(p.N, 0);
+      auto push_group = [&](uint32_t node, bool whole) {
+        GFrame g; g.cur = 0;
+        if (whole) {
+          for (uint32_t m : members[dense[node]]) if (B.ref_of[L + m] == NONE && !started[m]) { g.fr.push_back(Frame{m, 0, NONE}); started[m] = 1; }
+        }
+        if (g.fr.empty() && B.ref_of[L + node] == NONE && !started[node]) { g.fr.push_back(Frame{node, 0, NONE}); started[node] = 1; }
+        gst.push_back(std::move(g));
+      };
+      for (uint32_t top : tops) {
+        if (B.ref_of[L + top] != NONE) continue;
+        push_group(top, true);
+        while (!gst.empty()) {
+          GFrame &g = gst.back();
+          // drop finished members
+          bool any = false;
+          for (auto &f : g.fr) if (B.ref_of[L + f.n] == NONE) { any = true; break; }
+          if (!any) { gst.pop_back(); continue; }
+          if (g.cur >= g.fr.size()) g.cur = 0;
+          Frame &f = g.fr[g.cur];
+          if (B.ref_of[L + f.n] != NONE) { g.cur++; continue; }
+          const uint32_t c = p.idx[p.off[f.n] + f.i];
+          if (B.ref_of[c] == NONE) {
+            const uint32_t cn = c - L;
+            if (started[cn]) {
+              // operand is a member in progress further down the stack: cannot happen in a DAG unless
+              // the group hint ties a node to its own descendant; finish it alone
+              B.ok = false; B.why = "inconsistent schedule groups"; return;
+            }
+            push_group(cn, true);
+            continue;
+          }
+          step(f);
+          g.cur++;
+        }
+      }
+    }
+    return;
+  }
+
   for (uint32_t top : tops) {
     if (B.ref_of[L + top] != NONE) continue;
     st.push_back(Frame{top, 0, NONE});
     while (!st.empty()) {
       Frame &f = st.back();
       const uint32_t n = f.n, a = p.off[n], k = p.off[n + 1] - a;
-      if (f.i < k) {
-        const uint32_t c = p.idx[a + f.i];
-        if (B.ref_of[c] == NONE) { st.push_back(Frame{c - L, 0, NONE}); continue; }
-        const uint32_t cr = B.ref_of[c];
-        const double fc = p.fac[a + f.i];
-        uint32_t acc = f.acc;
-        if (p.op[n] == FDG_OP_SUM) {
-          const uint32_t t = B.mulc(cr, fc);                       // c_i * f_i   (static.jl:18)
-          acc = (f.i == 0) ? t : B.op2(M_ADD, acc, t);
-        } else if (p.op[n] == FDG_OP_PROD) {
-          acc = (f.i == 0) ? cr : B.op2(M_MUL, acc, cr);           // ((acc * c_i) * f_i)  (static.jl:28)
-          acc = B.mulc(acc, fc);
-        } else {  // Power: exactly one child
-          const int32_t N = p.power[n];
-          if (N == 2) acc = B.op2(M_MUL, cr, cr);
-          else if (N == 3) acc = B.op2(M_MUL, B.op2(M_MUL, cr, cr), cr);
-          else { B.ok = false; B.why = "Power{N} with N outside {2,3}"; acc = cr; }
-          acc = B.mulc(acc, fc);
-        }
-        // st may have been reallocated by nothing here (no push), safe to write back
-        st.back().acc = acc;
-        st.back().i++;
-        continue;
-      }
-      B.ref_of[L + n] = f.acc;
-      emit_roots(L + n);
-      st.pop_back();
+      (void)k;
+      const uint32_t c = p.idx[a + f.i];
+      if (B.ref_of[c] == NONE) { st.push_back(Frame{c - L, 0, NONE}); continue; }
+      if (step(st.back())) st.pop_back();
     }
   }
 }
@@ -370,8 +434,14 @@ void hoist_loads(std::vector<MOp> &ops, const OptParams &prm) {
 void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) {
   out = OptProgram();
   out.params = prm;
-  Builder B(p);
-  build_uops(B);
+  Builder B0(p);
+  build_uops(B0);
+  Lowered plain;
+  const bool retry = !B0.ok && B0.why == "inconsistent schedule groups";
+  if (retry) { plain = p; plain.sched_group.clear(); }
+  Builder B1(retry ? plain : p);
+  if (retry) build_uops(B1);
+  Builder &B = retry ? B1 : B0;
   out.supported = B.ok;
   out.why = B.why;
   if (!B.ok) return;

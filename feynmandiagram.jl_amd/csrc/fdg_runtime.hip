@@ -594,6 +594,15 @@ static fdg_opt_params g_default_opt = {0, 0, 0, 0, 0, 0};
 struct OptStore { std::mutex mu; std::vector<std::pair<const fdg_graph *, fdg_opt_params>> v; };
 static OptStore &opt_store() { static OptStore s; return s; }
 
+int fdg_graph_set_schedule_groups(fdg_graph *g, const uint32_t *group, uint32_t n_node) {
+  if (!g) { set_error("null handle"); return FDG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (!group) { g->prog.sched_group.clear(); return FDG_OK; }
+  if (n_node != g->prog.N) { set_error("schedule groups: length differs from n_node"); return FDG_E_INVALID; }
+  g->prog.sched_group.assign(group, group + n_node);
+  return FDG_OK;
+}
+
 int fdg_graph_set_opt_params(fdg_graph *g, const fdg_opt_params *prm) {
   if (!g || !prm) { set_error("null argument"); return FDG_E_INVALID; }
   OptStore &s = opt_store();
@@ -650,7 +659,7 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
     // soon as A would have to spill to the HBM panel.
     fdg::OptParams A; A.n_reg = 120; A.n_lds = 40; A.n_acc = 0; A.lookahead_leaf = 300;
     fdg::build_opt_program(g->prog, A, prog);
-    if (prog.supported && (prog.n_ld_mem + prog.n_st_mem) > 0) {
+    if (prog.supported && (prog.n_ld_mem + prog.n_st_mem) * 100 > prog.n_valu) {   // > 1 % of the ops touch the HBM panel
       fdg::OptParams Bc; Bc.n_reg = 120; Bc.n_lds = 80; Bc.n_acc = 124; Bc.lookahead_leaf = 100; Bc.lookahead_mem = 64;
       fdg::OptProgram pb;
       fdg::build_opt_program(g->prog, Bc, pb);

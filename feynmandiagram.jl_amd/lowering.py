@@ -40,8 +40,9 @@ def _opcode(g: Graph) -> Tuple[int, int]:
 
 
 def lower(graphs: Sequence[Graph], root: Optional[Sequence[int]] = None,
-          name: str = "") -> Tuple[NodeTable, Dict[int, Graph], Dict[int, int]]:
-    """Returns ``(table, leafmap, value_index_of_id)``.
+          name: str = "", groups: Optional[Dict[int, int]] = None) -> Tuple[NodeTable, Dict[int, Graph], Dict[int, int]]:
+    """Returns ``(table, leafmap, value_index_of_id)``.  ``groups`` (node id -> tag) becomes the
+    table's scheduling hint; untagged nodes are their own group.
 
     ``leafmap`` maps the 1-based ``leafVal`` index to the leaf graph object,
     exactly the second return value of ``to_julia_str`` (static.jl:104,117-119).
@@ -105,6 +106,10 @@ def lower(graphs: Sequence[Graph], root: Optional[Sequence[int]] = None,
     table = NodeTable(L, op, power, off, np.array(idx, dtype=np.uint32),
                       np.array(fac, dtype=np.float64), root_slot, name,
                       np.array(leaf_pos, dtype=np.uint32))
+    if groups:
+        tags = {}
+        table.sched_group = np.array([tags.setdefault(("g", groups[g.id]) if g.id in groups else ("n", g.id), len(tags))
+                                      for g in order], dtype=np.uint32)
     table.validate()
     ids = {gid: i for gid, i in leaf_index.items()}
     ids.update({gid: L + i for gid, i in node_index.items()})

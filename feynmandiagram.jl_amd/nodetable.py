@@ -41,6 +41,8 @@ class NodeTable:
     # text-emitter detail only (no effect on arithmetic): number of internal-node
     # statements that precede leaf k's load statement in the reference's output.
     leaf_pos: Optional[np.ndarray] = None   # uint32 [L], non-decreasing
+    # optional scheduling hint (fdg_graph_set_schedule_groups): nodes with equal tags are evaluated together
+    sched_group: Optional[np.ndarray] = None   # uint32 [N]
 
     # ------------------------------------------------------------------ #
     @property
@@ -67,6 +69,7 @@ class NodeTable:
             np.ascontiguousarray(self.root_slot, dtype=np.uint32),
             self.name,
             None if self.leaf_pos is None else np.ascontiguousarray(self.leaf_pos, dtype=np.uint32),
+            None if self.sched_group is None else np.ascontiguousarray(self.sched_group, dtype=np.uint32),
         )
 
     def leaf_positions(self) -> np.ndarray:
@@ -134,14 +137,16 @@ class NodeTable:
         np.savez_compressed(path, n_leaf=np.int64(t.n_leaf), op=t.op, power=t.power,
                             child_off=t.child_off, child_idx=t.child_idx,
                             child_fac=t.child_fac, root_slot=t.root_slot,
-                            name=np.array(t.name), leaf_pos=t.leaf_positions().astype(np.uint32))
+                            name=np.array(t.name), leaf_pos=t.leaf_positions().astype(np.uint32),
+                            **({} if t.sched_group is None else {"sched_group": t.sched_group}))
 
     @staticmethod
     def load(path) -> "NodeTable":
         z = np.load(path, allow_pickle=False)
         return NodeTable(int(z["n_leaf"]), z["op"], z["power"], z["child_off"], z["child_idx"],
                          z["child_fac"], z["root_slot"], str(z["name"]),
-                         z["leaf_pos"] if "leaf_pos" in z.files else None).normalized()
+                         z["leaf_pos"] if "leaf_pos" in z.files else None,
+                         z["sched_group"] if "sched_group" in z.files else None).normalized()
 
     def children(self, n: int) -> List[Tuple[int, float]]:
         a, b = int(self.child_off[n]), int(self.child_off[n + 1])

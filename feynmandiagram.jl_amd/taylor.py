@@ -26,7 +26,7 @@ T = TypeVar("T")
 Order = Tuple[int, ...]
 
 __all__ = ["TaylorSeries", "set_variables", "get_orders", "get_numvars", "taylor_factorial", "taylor_binomial",
-           "taylorexpansion", "taylorAD", "getcoeff"]
+           "taylorexpansion", "taylorAD", "getcoeff", "coefficient_groups"]
 
 _params = {"orders": [2, 2], "names": ["x1", "x2"]}       # parameter.jl:26
 
@@ -208,9 +208,20 @@ def taylorexpansion(graph, var_dependence: Optional[Dict[int, List[bool]]] = Non
     return m[graph.id], m
 
 
+def coefficient_groups(to_coeff_map: Dict[int, TaylorSeries]) -> Dict[int, int]:
+    """node id of every Taylor coefficient graph -> id of the original node it was derived from
+    (the scheduling hint of fdg_graph_set_schedule_groups)."""
+    out: Dict[int, int] = {}
+    for oid, ts in to_coeff_map.items():
+        for c in ts.coeffs.values():
+            out.setdefault(c.id, oid)
+    return out
+
+
 def taylorAD(graphs: Sequence[Graph], deriv_orders: Sequence[int], leaf_dep_funcs: Sequence[Callable],
-             dict_graphs: Optional[Dict[Order, List[Graph]]] = None) -> Dict[Order, List[Graph]]:
-    """utility.jl:48-93."""
+             dict_graphs: Optional[Dict[Order, List[Graph]]] = None, groups: Optional[Dict[int, int]] = None
+             ) -> Dict[Order, List[Graph]]:
+    """utility.jl:48-93.  ``groups`` (optional, filled in place) receives ``coefficient_groups``."""
     if len(deriv_orders) != len(leaf_dep_funcs):
         raise AssertionError("Lengths of deriv_orders and properties_deps must be equal.")
     names = []
@@ -230,7 +241,9 @@ def taylorAD(graphs: Sequence[Graph], deriv_orders: Sequence[int], leaf_dep_func
                 dep.setdefault(n.id, [bool(f(n.properties)) for f in leaf_dep_funcs])
             else:
                 stack.extend(n.subgraphs)
-    series, _ = taylorexpansion(list(graphs), dep)
+    series, cmap = taylorexpansion(list(graphs), dep)
+    if groups is not None:
+        groups.update(coefficient_groups(cmap))
     out = dict_graphs if dict_graphs is not None else {}
     for ts in series:
         for o, g in ts.coeffs.items():

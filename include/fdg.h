@@ -153,6 +153,12 @@ typedef struct fdg_mop {
   double imm;
 } fdg_mop;
 
+/* Optional scheduling hint for FDG_SPEC_ISA: group[n] (n < n_node) tags internal nodes that belong
+ * together -- e.g. the Taylor coefficients that taylorexpansion! (src/utility.jl:105-135) derives from
+ * one original node share that node's id.  Members of a group are evaluated together.  Only the order
+ * of evaluation changes, never a value.  Pass NULL to clear. */
+int fdg_graph_set_schedule_groups(fdg_graph *g, const uint32_t *group, uint32_t n_node);
+
 /* Sets the parameters used by the next fdg_graph_specialize(..., FDG_SPEC_ISA). */
 int fdg_graph_set_opt_params(fdg_graph *g, const fdg_opt_params *prm);
 /* Runs scheduler + allocator and returns the op list (malloc'ed; fdg_free).  Host-only. */

@@ -60,7 +60,7 @@ def main():
                             root_slot=tn.root_slot, name=np.array(tn.name),
                             leaf_pos=tn.leaf_positions().astype(np.uint32),
                             seed=np.int64(seed), leaf=leaf, root_static=root, root_interp=root_interp,
-                            **({k: np.load(os.path.join(HERE, f"{name}.npz"))[k] for k in ("leaf_base", "leaf_dorder")}
+                            **({k: np.load(os.path.join(HERE, f"{name}.npz"))[k] for k in ("leaf_base", "leaf_dorder", "sched_group")}
                                if name.endswith("taylor2") else {}))
         print(name, t.stats(), root[0])
 

@@ -77,10 +77,11 @@ def taylor_tables():
         graphs = gv.diagsGV("sigma", order, RD)
         optimize.optimize_(graphs)
         t0, lm0, _ = lower(graphs)
-        d = taylor.taylorAD(graphs, [2], [lambda pr: isinstance(pr, gv.BareInteractionId)])
+        groups = {}
+        d = taylor.taylorAD(graphs, [2], [lambda pr: isinstance(pr, gv.BareInteractionId)], groups=groups)
         allg = [g for o in sorted(d) for g in d[o]]          # roots: (c0_ins, c0_dyn, c1_ins, c1_dyn, c2_ins, c2_dyn)
         optimize.optimize_(allg)
-        t, lm, _ = lower(allg, name=f"gv_sigma{order}_taylor2_optimized")
+        t, lm, _ = lower(allg, name=f"gv_sigma{order}_taylor2_optimized", groups=groups)
         # leaf bookkeeping: which original leaf and which derivative order each leaf of the enlarged graph is
         key0 = {}
         for i in range(t0.n_leaf):
@@ -103,7 +104,7 @@ def taylor_tables():
         np.savez_compressed(os.path.join(HERE, f"gv_sigma{order}_taylor2.npz"), n_leaf=np.int64(tn.n_leaf), op=tn.op,
                             power=tn.power, child_off=tn.child_off, child_idx=tn.child_idx, child_fac=tn.child_fac,
                             root_slot=tn.root_slot, name=np.array(tn.name), leaf_pos=tn.leaf_positions().astype(np.uint32),
-                            leaf_base=base, leaf_dorder=dord)
+                            sched_group=tn.sched_group, leaf_base=base, leaf_dorder=dord)
         print("taylor2", order, t.stats(), "series err", np.abs(series - f_x), "first-order err", np.abs((c[0] + x * c[1]) - f_x))
 
 
