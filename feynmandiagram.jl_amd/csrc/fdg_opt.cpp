@@ -7,6 +7,7 @@
 #include <cstring>
 #include <deque>
 #include <limits>
+#include <unordered_map>
 
 #include "fdg_opt.h"
 
@@ -32,19 +33,65 @@ struct Builder {
 
   explicit Builder(const Lowered &p_) : p(p_), next_vid(p_.L), ref_of((size_t)p_.L + p_.N, NONE) {
     for (uint32_t i = 0; i < p.L; ++i) ref_of[i] = i << 1;
+    born.assign(p.L, 0);
   }
-  uint32_t fresh() { return next_vid++; }
+  // Value numbering: the reference's straight-line code repeats identical fold steps (products that
+  // share a prefix, `g * -1.0` of the same g, ...).  An op with the same kind and the same operands
+  // yields the same bits, so it is computed once.  Exact identities used, nothing else:
+  //   x*y == y*x, x+y == y+x (IEEE, any zero/inf), (-x)*y == -(x*y), (-x)*c == -(x*c).
+  // Sums are NOT canonicalised across negation ((-x)+y vs -(x-y) differ in the sign of an exact zero).
+  std::unordered_map<uint64_t, uint32_t> vn_mul, vn_add;
+  std::unordered_map<uint64_t, std::vector<std::pair<double, uint32_t>>> vn_mulc;
+  bool value_numbering = true;
+  uint64_t vn_window = 0;        // reuse only results computed at most this many ops ago (0 = no limit)
+  std::vector<uint32_t> born;    // vid -> index of the op that produced it
+  bool fresh_enough(uint32_t ref) const {
+    if (!vn_window) return true;
+    const uint32_t v = ref >> 1;
+    return v < born.size() && (uint64_t)u.size() - born[v] <= vn_window;
+  }
+  uint32_t fresh() { born.resize(next_vid + 1, 0); born[next_vid] = (uint32_t)u.size(); return next_vid++; }
   uint32_t op2(uint8_t k, uint32_t a, uint32_t b) {
+    if (!value_numbering) { uint32_t d = fresh(); u.push_back(UOp{k, d, a, b, 0.0}); return d << 1; }
+    if (k == M_MUL) {
+      const uint32_t sign = (a ^ b) & 1u;
+      uint32_t x = a & ~1u, y = b & ~1u;
+      if (x > y) std::swap(x, y);
+      const uint64_t key = ((uint64_t)x << 32) | y;
+      auto it = vn_mul.find(key);
+      if (it != vn_mul.end() && fresh_enough(it->second)) return it->second | sign;
+      uint32_t d = fresh();
+      u.push_back(UOp{M_MUL, d, x, y, 0.0});
+      vn_mul[key] = d << 1;
+      return (d << 1) | sign;
+    }
+    uint32_t x = a, y = b;
+    if (x > y) std::swap(x, y);
+    const uint64_t key = ((uint64_t)x << 32) | y;
+    auto it = vn_add.find(key);
+    if (it != vn_add.end() && fresh_enough(it->second)) return it->second;
     uint32_t d = fresh();
-    u.push_back(UOp{k, d, a, b, 0.0});
+    u.push_back(UOp{M_ADD, d, x, y, 0.0});
+    vn_add[key] = d << 1;
     return d << 1;
   }
   uint32_t mulc(uint32_t a, double f) {
     if (f == 1.0) return a;
     if (f == -1.0) return a ^ 1u;
+    if (!value_numbering) { uint32_t d = fresh(); u.push_back(UOp{M_MULC, d, a, 0, f}); return d << 1; }
+    const uint32_t sign = a & 1u, x = a & ~1u;
+    auto &lst = vn_mulc[x];
+    for (auto &e : lst) if (std::memcmp(&e.first, &f, 8) == 0) {
+      if (fresh_enough(e.second)) return e.second | sign;
+      uint32_t d = fresh();
+      u.push_back(UOp{M_MULC, d, x, 0, f});
+      e.second = d << 1;
+      return (d << 1) | sign;
+    }
     uint32_t d = fresh();
-    u.push_back(UOp{M_MULC, d, a, 0, f});
-    return d << 1;
+    u.push_back(UOp{M_MULC, d, x, 0, f});
+    lst.push_back({f, d << 1});
+    return (d << 1) | sign;
   }
 };
 
@@ -435,11 +482,14 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   out = OptProgram();
   out.params = prm;
   Builder B0(p);
+  B0.value_numbering = prm.vn_window != 1;     // 1 = off, 0 = unlimited, else window in ops
+  B0.vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
   build_uops(B0);
   Lowered plain;
   const bool retry = !B0.ok && B0.why == "inconsistent schedule groups";
   if (retry) { plain = p; plain.sched_group.clear(); }
   Builder B1(retry ? plain : p);
+  B1.value_numbering = B0.value_numbering; B1.vn_window = B0.vn_window;
   if (retry) build_uops(B1);
   Builder &B = retry ? B1 : B0;
   out.supported = B.ok;

@@ -46,6 +46,7 @@ struct OptParams {
   uint32_t n_acc = 0;       // AGPR pairs per lane used as a spill level (needs 1 wave/SIMD)
   uint32_t lookahead_lds = 32;    // micro-ops of prefetch distance for LDS loads
   uint32_t lookahead_mem = 128;   // ... for loads from the workspace panel (L2 / HBM)
+  uint32_t vn_window = 200;       // value numbering: 1 = off, 0 = reuse any earlier identical op, n > 1 = only results at most n ops old
   uint32_t lookahead_leaf = 300;  // ... for first-use loads of leaves (HBM)
 };
 

@@ -586,11 +586,12 @@ static fdg::OptParams to_params(const fdg_opt_params *q) {
     if (q->lookahead_mem) prm.lookahead_mem = q->lookahead_mem;
     if (q->lookahead_leaf) prm.lookahead_leaf = q->lookahead_leaf;
     if (q->n_acc) prm.n_acc = std::min<uint32_t>(q->n_acc, 124);
+    if (q->vn_window) prm.vn_window = q->vn_window;
   }
   return prm;
 }
 
-static fdg_opt_params g_default_opt = {0, 0, 0, 0, 0, 0};
+static fdg_opt_params g_default_opt = {0, 0, 0, 0, 0, 0, 0};
 struct OptStore { std::mutex mu; std::vector<std::pair<const fdg_graph *, fdg_opt_params>> v; };
 static OptStore &opt_store() { static OptStore s; return s; }
 
@@ -657,10 +658,10 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
     // prefetcher cannot.  B: one wave per SIMD with the idle half of the register
     // file (124 AGPR pairs) and 80 LDS slots as on-chip spill levels -- taken as
     // soon as A would have to spill to the HBM panel.
-    fdg::OptParams A; A.n_reg = 120; A.n_lds = 40; A.n_acc = 0; A.lookahead_leaf = 300;
+    fdg::OptParams A; A.n_reg = 120; A.n_lds = 40; A.n_acc = 0; A.lookahead_leaf = 300; A.vn_window = 200;
     fdg::build_opt_program(g->prog, A, prog);
     if (prog.supported && (prog.n_ld_mem + prog.n_st_mem) * 100 > prog.n_valu) {   // > 1 % of the ops touch the HBM panel
-      fdg::OptParams Bc; Bc.n_reg = 120; Bc.n_lds = 80; Bc.n_acc = 124; Bc.lookahead_leaf = 100; Bc.lookahead_mem = 64;
+      fdg::OptParams Bc; Bc.n_reg = 120; Bc.n_lds = 80; Bc.n_acc = 124; Bc.lookahead_leaf = 100; Bc.lookahead_mem = 64; Bc.vn_window = 1000;
       fdg::OptProgram pb;
       fdg::build_opt_program(g->prog, Bc, pb);
       if (pb.supported) prog = std::move(pb);

@@ -140,6 +140,7 @@ typedef struct fdg_opt_params {
   uint32_t lookahead_mem;  /* prefetch distance, in ops, of workspace-panel (L2/HBM) loads */
   uint32_t lookahead_leaf; /* prefetch distance, in ops, of first-use leaf loads (HBM) */
   uint32_t n_acc;          /* AGPR pairs per lane used as a spill level (<= 124; 0 with two waves per SIMD) */
+  uint32_t vn_window;      /* value numbering of identical fold steps: 0 default, 1 off, n > 1 window in ops */
 } fdg_opt_params;
 
 /* One op of the register-allocated program (for inspection and for host-side
