@@ -658,9 +658,16 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
     // prefetcher cannot.  B: one wave per SIMD with the idle half of the register
     // file (124 AGPR pairs) and 80 LDS slots as on-chip spill levels -- taken as
     // soon as A would have to spill to the HBM panel.
+    // S: tiny graphs whose whole live set fits 28 register pairs run 8 waves per SIMD (64 VGPRs):
+    // they are HBM-bound and want bytes in flight, not registers.
+    fdg::OptParams S; S.n_reg = 28; S.n_lds = 1; S.n_acc = 0; S.lookahead_leaf = 300; S.vn_window = 200;
+    fdg::OptProgram ps;
+    fdg::build_opt_program(g->prog, S, ps);
+    const bool small_ok = ps.supported && ps.n_ld_leaf <= g->prog.n_live_leaf && ps.n_ld_lds + ps.n_st_lds + ps.n_ld_mem + ps.n_st_mem == 0;
     fdg::OptParams A; A.n_reg = 120; A.n_lds = 40; A.n_acc = 0; A.lookahead_leaf = 300; A.vn_window = 200;
-    fdg::build_opt_program(g->prog, A, prog);
-    if (prog.supported && (prog.n_ld_mem + prog.n_st_mem) * 100 > prog.n_valu) {   // > 1 % of the ops touch the HBM panel
+    if (small_ok) prog = std::move(ps);
+    else fdg::build_opt_program(g->prog, A, prog);
+    if (!small_ok && prog.supported && (prog.n_ld_mem + prog.n_st_mem) * 100 > prog.n_valu) {   // > 1 % of the ops touch the HBM panel
       fdg::OptParams Bc; Bc.n_reg = 120; Bc.n_lds = 80; Bc.n_acc = 124; Bc.lookahead_leaf = 100; Bc.lookahead_mem = 64; Bc.vn_window = 1000;
       fdg::OptProgram pb;
       fdg::build_opt_program(g->prog, Bc, pb);
