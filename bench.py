@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--layout", default="leaf_major", choices=["sample_major", "leaf_major"],
                     help="leaf_major = a Julia column-major B x L matrix (the host language's native layout); "
                          "sample_major = compile_Python's row-major [B, L]")
-    ap.add_argument("--backend", default="isa", choices=["isa", "hip", "interp"],
+    ap.add_argument("--backend", default="isa", choices=["isa", "isa-autotune", "hip", "interp"],
                     help="isa: optimizing back end, gfx950 assembly; hip: straight-line HIP source via hiprtc; interp: table interpreter")
     ap.add_argument("--interp", action="store_true", help="same as --backend interp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -68,7 +68,9 @@ def main():
     B = args.samples or default_B
     if args.interp:
         args.backend = "interp"
-    f = fd.compile_table(t, specialize={"isa": "isa", "hip": True, "interp": False}[args.backend])
+    f = fd.compile_table(t, specialize={"isa": "isa", "isa-autotune": "isa-autotune", "hip": True, "interp": False}[args.backend])
+    if args.backend == "isa-autotune":
+        args.backend = "isa"
 
     if args.layout == "sample_major":
         leaf = torch.empty((B, L), dtype=torch.float64, device=dev)

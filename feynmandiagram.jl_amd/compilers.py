@@ -47,9 +47,11 @@ class GraphFunc:
         self.table = table.normalized()
         self.handle = capi.GraphHandle(self.table)
         self.n_leaf, self.n_root = self.table.n_leaf, self.table.n_root
-        if specialize == "isa":
+        if specialize in ("isa", "isa-autotune"):
             if opt:
                 self.handle.set_opt_params(**opt)
+            if specialize == "isa-autotune":
+                flags |= capi.FDG_SPEC_AUTOTUNE
             self.handle.specialize(cache_dir, flags | capi.FDG_SPEC_ISA)
         elif specialize:
             self.handle.specialize(cache_dir, flags)

@@ -308,6 +308,9 @@ static int ensure_module(fdg_graph *g) {
 }
 
 // mode 0: roots -> d_root; mode 1: partial sums -> d_acc
+static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
+                      int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st);
+
 static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
                int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st) {
   if (!g) { set_error("null handle"); return FDG_E_INVALID; }
@@ -317,6 +320,11 @@ static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t
     set_error("null device buffer"); return FDG_E_INVALID;
   }
   std::lock_guard<std::mutex> lk(g->mu);
+  return run_locked(g, mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st);
+}
+
+static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
+                      int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st) {
   int rc = ensure_device(g);
   if (rc) return rc;
   const Lowered &p = g->prog;
@@ -647,39 +655,13 @@ static bool has_opt_params(const fdg_graph *g) {
   return false;
 }
 
-static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
-  fdg::OptProgram prog;
-  if (has_opt_params(g)) {
-    const fdg_opt_params q = get_opt_params(g);
-    fdg::build_opt_program(g->prog, to_params(&q), prog);
-  } else {
-    // automatic configuration.  A: two waves per SIMD (120 VGPR pairs + 40 LDS
-    // slots each) -- best when the live set fits, the second wave hides what the
-    // prefetcher cannot.  B: one wave per SIMD with the idle half of the register
-    // file (124 AGPR pairs) and 80 LDS slots as on-chip spill levels -- taken as
-    // soon as A would have to spill to the HBM panel.
-    // S: tiny graphs whose whole live set fits 28 register pairs run 8 waves per SIMD (64 VGPRs):
-    // they are HBM-bound and want bytes in flight, not registers.
-    fdg::OptParams S; S.n_reg = 28; S.n_lds = 1; S.n_acc = 0; S.lookahead_leaf = 300; S.vn_window = 200;
-    fdg::OptProgram ps;
-    fdg::build_opt_program(g->prog, S, ps);
-    const bool small_ok = ps.supported && ps.n_ld_leaf <= g->prog.n_live_leaf && ps.n_ld_lds + ps.n_st_lds + ps.n_ld_mem + ps.n_st_mem == 0;
-    fdg::OptParams A; A.n_reg = 120; A.n_lds = 40; A.n_acc = 0; A.lookahead_leaf = 300; A.vn_window = 200;
-    if (small_ok) prog = std::move(ps);
-    else fdg::build_opt_program(g->prog, A, prog);
-    if (!small_ok && prog.supported && (prog.n_ld_mem + prog.n_st_mem) * 100 > prog.n_valu) {   // > 1 % of the ops touch the HBM panel
-      fdg::OptParams Bc; Bc.n_reg = 120; Bc.n_lds = 80; Bc.n_acc = 124; Bc.lookahead_leaf = 100; Bc.lookahead_mem = 64; Bc.vn_window = 1000;
-      fdg::OptProgram pb;
-      fdg::build_opt_program(g->prog, Bc, pb);
-      if (pb.supported) prog = std::move(pb);
-    }
-  }
-  if (!prog.supported) { set_error("optimizing back end does not cover this graph: " + prog.why); return FDG_E_UNSUPPORTED; }
+static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags,
+                        std::vector<char> &co, std::string &hash) {
   const std::string src = fdg::emit_isa(g->prog, prog, "fdg_isa_eval");
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
+  hash = hbuf;
   const std::string base = dir + "/fdg_isa_" + hbuf;
-  std::vector<char> co;
   if (!read_file(base + ".hsaco", co)) {
     if (!write_file(base + ".s", src.c_str(), src.size())) { set_error("cannot write " + base + ".s"); return FDG_E_JIT; }
     const char *llvm = std::getenv("FDG_LLVM_BIN");
@@ -698,6 +680,10 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
   } else if (flags & FDG_SPEC_KEEP_SOURCE) {
     write_file(base + ".s", src.c_str(), src.size());
   }
+  return FDG_OK;
+}
+
+static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<char> &co, const std::string &hash, unsigned flags) {
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
   g->code_object.swap(co);
   g->isa = true;
@@ -706,8 +692,156 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
   g->isa_lds_bytes = prog.n_lds_used * 512u;
   g->isa_mem_slots = prog.n_mem_used;
   g->spec_vgpr = g->isa_vgpr; g->spec_lds = g->isa_lds_bytes; g->spec_scratch = 0;
-  g->spec_source_hash = hbuf;
+  g->spec_source_hash = hash;
   g->spec_flags = flags;
+}
+
+// the automatic configurations: S tiny graphs, A two waves/SIMD, B one wave/SIMD + AGPR level
+static fdg::OptParams cfg_S() { fdg::OptParams S; S.n_reg = 28; S.n_lds = 1; S.n_acc = 0; S.lookahead_leaf = 300; S.vn_window = 200; return S; }
+static fdg::OptParams cfg_A() { fdg::OptParams A; A.n_reg = 120; A.n_lds = 40; A.n_acc = 0; A.lookahead_leaf = 300; A.vn_window = 200; return A; }
+static fdg::OptParams cfg_B() {
+  fdg::OptParams B; B.n_reg = 120; B.n_lds = 80; B.n_acc = 124; B.lookahead_leaf = 100; B.lookahead_mem = 64; B.vn_window = 1000; return B;
+}
+
+static void auto_program(const fdg_graph *g, fdg::OptProgram &prog) {
+  fdg::OptProgram ps;
+  fdg::build_opt_program(g->prog, cfg_S(), ps);
+  const bool small_ok = ps.supported && ps.n_ld_leaf <= g->prog.n_live_leaf && ps.n_ld_lds + ps.n_st_lds + ps.n_ld_mem + ps.n_st_mem == 0;
+  if (small_ok) { prog = std::move(ps); return; }
+  fdg::build_opt_program(g->prog, cfg_A(), prog);
+  if (prog.supported && (prog.n_ld_mem + prog.n_st_mem) * 100 > prog.n_valu) {   // > 1 % of the ops touch the HBM panel
+    fdg::OptProgram pb;
+    fdg::build_opt_program(g->prog, cfg_B(), pb);
+    if (pb.supported) prog = std::move(pb);
+  }
+}
+
+// On-device selection among a handful of configurations: each candidate is assembled, run on a
+// synthetic batch that fills the chip twice, and the fastest is kept; the choice is remembered in
+// the cache directory (keyed by the table), so tuning happens once per graph.
+static std::string tuned_path(const fdg_graph *g, const std::string &dir) {
+  const fdg::Lowered &p = g->prog;
+  uint64_t th = fnv1a("tuned-v1");
+  auto mix = [&](const void *d, size_t n) { th = fnv1a(std::string((const char *)d, n), th); };
+  mix(&p.L, 4); mix(&p.N, 4); mix(&p.R, 4);
+  if (p.N) { mix(p.op.data(), p.op.size()); mix(p.power.data(), p.power.size() * 4); mix(p.off.data(), p.off.size() * 4); }
+  if (p.E) { mix(p.idx.data(), p.idx.size() * 4); mix(p.fac.data(), p.fac.size() * 8); }
+  if (p.R) mix(p.root_slot.data(), p.root_slot.size() * 4);
+  if (!p.sched_group.empty()) mix(p.sched_group.data(), p.sched_group.size() * 4);
+  char hb[40];
+  std::snprintf(hb, sizeof hb, "%016llx", (unsigned long long)th);
+  return dir + "/fdg_tuned_" + hb + ".txt";
+}
+
+// returns 1 when a remembered choice was installed, 0 when there is none, < 0 on error
+static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
+  const fdg::Lowered &p = g->prog;
+  const std::string tuned = tuned_path(g, dir);
+  std::vector<char> buf;
+  if (!read_file(tuned, buf)) return 0;
+  fdg::OptParams q;
+  buf.push_back(0);
+  if (std::sscanf(buf.data(), "%u %u %u %u %u %u %u", &q.n_reg, &q.n_lds, &q.n_acc, &q.lookahead_lds, &q.lookahead_mem, &q.lookahead_leaf, &q.vn_window) != 7) return 0;
+  fdg::OptProgram prog;
+  fdg::build_opt_program(p, q, prog);
+  if (!prog.supported) return 0;
+  std::vector<char> co; std::string hash;
+  int rc = assemble_isa(g, prog, dir, flags, co, hash);
+  if (rc) return rc;
+  install_isa(g, prog, co, hash, flags);
+  return 1;
+}
+
+static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
+  int rc = ensure_device(g);
+  if (rc) return rc;
+  const fdg::Lowered &p = g->prog;
+  const std::string tuned = tuned_path(g, dir);
+  auto to_line = [](const fdg::OptParams &q) {
+    char b[160];
+    std::snprintf(b, sizeof b, "%u %u %u %u %u %u %u", q.n_reg, q.n_lds, q.n_acc, q.lookahead_lds, q.lookahead_mem, q.lookahead_leaf, q.vn_window);
+    return std::string(b);
+  };
+  std::vector<fdg::OptParams> cand;
+  cand.push_back(cfg_S());
+  cand.push_back(cfg_A());
+  { fdg::OptParams q = cfg_A(); q.vn_window = 1000; cand.push_back(q); }
+  { fdg::OptParams q = cfg_A(); q.vn_window = 60; cand.push_back(q); }
+  cand.push_back(cfg_B());
+  { fdg::OptParams q = cfg_B(); q.vn_window = 0; cand.push_back(q); }
+  { fdg::OptParams q = cfg_B(); q.vn_window = 200; cand.push_back(q); }
+  { fdg::OptParams q = cfg_A(); q.n_reg = 80; q.n_lds = 26; cand.push_back(q); }     // three waves per SIMD
+  { fdg::OptParams q = cfg_A(); q.n_reg = 56; q.n_lds = 20; cand.push_back(q); }     // four waves per SIMD
+  // batch: at least two tiles per resident wave, and enough bytes (about 0.4 GB of leaves) that a run
+  // is not dominated by launch overhead on tiny graphs
+  long Bt = std::max<long>((long)g->n_cu * 8 * 64 * 2, (long)(4e8 / (8.0 * std::max<uint32_t>(p.L + p.R, 1))));
+  Bt = std::min<long>((Bt + 63) & ~63l, 1l << 24);
+  double *d_leaf = nullptr, *d_root = nullptr;
+  HIP_TRY(hipMalloc(&d_leaf, std::max<size_t>(1, (size_t)Bt * p.L) * 8));
+  if (hipMalloc(&d_root, std::max<size_t>(1, (size_t)Bt * p.R) * 8) != hipSuccess) { hipFree(d_leaf); set_error("hipMalloc failed"); return FDG_E_NOMEM; }
+  if (p.L) {
+    hipLaunchKernelGGL(fdg_fill_uniform, dim3(4096), dim3(256), 0, 0, d_leaf, Bt, p.L, 1L, Bt, (uint64_t)1234, (uint64_t)0, 0);
+  }
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  double best_ms = 1e300;
+  int best = -1;
+  std::string seen;
+  for (size_t c = 0; c < cand.size(); ++c) {
+    fdg::OptProgram prog;
+    fdg::build_opt_program(p, cand[c], prog);
+    if (!prog.supported) continue;
+    if (c == 0 && !(prog.n_ld_leaf <= p.n_live_leaf && prog.n_ld_lds + prog.n_st_lds + prog.n_ld_mem + prog.n_st_mem == 0)) continue;
+    std::vector<char> co; std::string hash;
+    if (assemble_isa(g, prog, dir, flags, co, hash) != FDG_OK) continue;
+    if (seen.find(hash) != std::string::npos) continue;
+    seen += hash + ";";
+    install_isa(g, prog, co, hash, flags);
+    if (run_locked(g, 0, d_leaf, 1, Bt, d_root, p.R, 1, nullptr, nullptr, Bt, nullptr) != FDG_OK) continue;
+    float ms_min = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0, nullptr);
+      if (run_locked(g, 0, d_leaf, 1, Bt, d_root, p.R, 1, nullptr, nullptr, Bt, nullptr) != FDG_OK) { ms_min = 1e30f; break; }
+      hipEventRecord(e1, nullptr);
+      hipEventSynchronize(e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      ms_min = std::min(ms_min, ms);
+    }
+    if (ms_min < best_ms) { best_ms = ms_min; best = (int)c; }
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipFree(d_leaf); hipFree(d_root);
+  if (best < 0) { set_error("autotune: no candidate configuration ran"); return FDG_E_JIT; }
+  fdg::OptProgram prog;
+  fdg::build_opt_program(p, cand[best], prog);
+  std::vector<char> co; std::string hash;
+  rc = assemble_isa(g, prog, dir, flags, co, hash);
+  if (rc) return rc;
+  install_isa(g, prog, co, hash, flags);
+  const std::string line = to_line(cand[best]) + "\n";
+  write_file(tuned, line.c_str(), line.size());
+  return FDG_OK;
+}
+
+static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
+  if (!has_opt_params(g) && !std::getenv("FDG_IGNORE_TUNED")) {
+    const int t = use_tuned(g, dir, flags);        // a remembered on-device choice wins (no device needed to use it)
+    if (t != 0) return t < 0 ? t : FDG_OK;
+    if (flags & FDG_SPEC_AUTOTUNE) return autotune_isa(g, dir, flags);
+  }
+  fdg::OptProgram prog;
+  if (has_opt_params(g)) {
+    const fdg_opt_params q = get_opt_params(g);
+    fdg::build_opt_program(g->prog, to_params(&q), prog);
+  } else {
+    auto_program(g, prog);
+  }
+  if (!prog.supported) { set_error("optimizing back end does not cover this graph: " + prog.why); return FDG_E_UNSUPPORTED; }
+  std::vector<char> co; std::string hash;
+  int rc = assemble_isa(g, prog, dir, flags, co, hash);
+  if (rc) return rc;
+  install_isa(g, prog, co, hash, flags);
   return FDG_OK;
 }
 

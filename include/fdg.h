@@ -108,6 +108,8 @@ typedef struct fdg_graph_info {
 #define FDG_SPEC_DEFAULT 0u
 #define FDG_SPEC_KEEP_SOURCE 1u   /* leave the generated source next to the code object */
 #define FDG_SPEC_FAST_MATH 2u     /* allow FMA contraction: NOT parity-exact, reported separately */
+#define FDG_SPEC_AUTOTUNE 8u      /* with FDG_SPEC_ISA: pick the configuration by timing a few candidates on
+                                     the device (needs one); the choice is remembered in the cache directory */
 #define FDG_SPEC_ISA 4u           /* optimizing back end: own scheduler + register allocator, gfx950
                                      assembly printed directly (one VALU instruction per fold step) */
 
