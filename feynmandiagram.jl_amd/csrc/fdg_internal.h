@@ -93,6 +93,8 @@ struct fdg_graph {
   size_t ws2_bytes = 0;
   void *d_ws3 = nullptr;           // leaf-major copy of a sample-major chunk for the ISA kernel
   size_t ws3_bytes = 0;
+  void *s2 = nullptr;              // internal stream: transposition of the next chunk overlaps the evaluator
+  void *ev_t[2] = {nullptr, nullptr}, *ev_k[2] = {nullptr, nullptr}, *ev_in = nullptr;
   int device = -1;
   int n_cu = 0;
 };

@@ -362,25 +362,53 @@ static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, 
       // sample-major input (compile_Python's [B, L]): the ISA kernel wants a wave's 64 samples of
       // one leaf contiguous, so chunks of the batch are transposed to leaf-major first
       // (2 extra HBM passes over the leaves; in-kernel LDS staging would avoid them -- DESIGN.md 8)
-      long Bc = std::max<long>(65536, (long)((1ull << 30) / (8ull * p.L)));
+      // Chunks are double-buffered: the transposition of chunk c+1 (HBM-bound) runs on an internal
+      // stream while the evaluator works on chunk c (fp64-bound for all but tiny graphs).
+      long Bc = std::max<long>((long)g->n_cu * 8 * 64 * 2, (long)((1ull << 29) / (8ull * p.L)));
       Bc = std::min<long>((Bc + 63) & ~63l, (B + 63) & ~63l);
-      const size_t need3 = (size_t)Bc * p.L * sizeof(double);
+      const size_t one = (size_t)Bc * p.L * sizeof(double);
+      const size_t need3 = 2 * one;
       if (g->ws3_bytes < need3) {
         if (g->d_ws3) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws3)); g->d_ws3 = nullptr; g->ws3_bytes = 0; }
         if (hipMalloc(&g->d_ws3, need3) != hipSuccess) { set_error("hipMalloc(transposed leaves) failed"); return FDG_E_NOMEM; }
         g->ws3_bytes = need3;
       }
-      for (long c0 = 0; c0 < B; c0 += Bc) {
+      if (!g->s2) {
+        hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); g->s2 = s;
+        for (int i = 0; i < 2; ++i) {
+          hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->ev_t[i] = e;
+          HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->ev_k[i] = e;
+        }
+        hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->ev_in = e;
+      }
+      hipStream_t s2 = (hipStream_t)g->s2;
+      HIP_TRY(hipEventRecord((hipEvent_t)g->ev_in, st));              // the caller's leaves are ready on st
+      HIP_TRY(hipStreamWaitEvent(s2, (hipEvent_t)g->ev_in, 0));
+      auto transpose = [&](long c0, int buf) {
         const long n = std::min<long>(Bc, B - c0);
         const long ntile = ((n + 63) / 64) * ((p.L + 31) / 32);
-        hipLaunchKernelGGL(fdg_transpose_to_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, st,
-                           d_leaf + c0 * ss, (long)ss, (double *)g->d_ws3, Bc, n, p.L);
-        const double *c_leaf = (const double *)g->d_ws3;
+        hipLaunchKernelGGL(fdg_transpose_to_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, s2,
+                           d_leaf + c0 * ss, (long)ss, (double *)((char *)g->d_ws3 + (size_t)buf * one), Bc, n, p.L);
+        return hipEventRecord((hipEvent_t)g->ev_t[buf], s2);
+      };
+      HIP_TRY(transpose(0, 0));
+      int c = 0;
+      for (long c0 = 0; c0 < B; c0 += Bc, ++c) {
+        const int buf = c & 1;
+        const long n = std::min<long>(Bc, B - c0);
+        if (c0 + Bc < B) {
+          // buffer buf^1 was last read by the evaluator of chunk c-1
+          if (c >= 1) HIP_TRY(hipStreamWaitEvent(s2, (hipEvent_t)g->ev_k[buf ^ 1], 0));
+          HIP_TRY(transpose(c0 + Bc, buf ^ 1));
+        }
+        HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)g->ev_t[buf], 0));
+        const double *c_leaf = (const double *)((char *)g->d_ws3 + (size_t)buf * one);
         double *c_root = roots + c0 * a_rs;
         long c_ss = 1, c_ls = Bc, c_B = n;
         long c_nwg = std::min<long>((n + 63) / 64, grid);
         void *args[] = {(void *)&c_leaf, &c_ss, &c_ls, (void *)&c_root, &a_rs, &a_rk, &a_ws, &c_B, &c_nwg};
         HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa, (unsigned)c_nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+        HIP_TRY(hipEventRecord((hipEvent_t)g->ev_k[buf], st));
       }
     } else {
       long a_ss = ss, a_ls = ls, a_B = B, a_nwg = grid;
@@ -551,6 +579,12 @@ int fdg_graph_release_device(fdg_graph *g) {
   if (g->d_ws) { hipFree(g->d_ws); g->d_ws = nullptr; g->ws_bytes = 0; }
   if (g->d_ws2) { hipFree(g->d_ws2); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
   if (g->d_ws3) { hipFree(g->d_ws3); g->d_ws3 = nullptr; g->ws3_bytes = 0; }
+  if (g->s2) {
+    hipStreamSynchronize((hipStream_t)g->s2);
+    hipStreamDestroy((hipStream_t)g->s2); g->s2 = nullptr;
+    for (int i = 0; i < 2; ++i) { hipEventDestroy((hipEvent_t)g->ev_t[i]); hipEventDestroy((hipEvent_t)g->ev_k[i]); }
+    hipEventDestroy((hipEvent_t)g->ev_in);
+  }
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; g->fn_eval_sm = g->fn_eval_gen = nullptr; g->fn_isa = nullptr; }
   return FDG_OK;
 }
