@@ -42,6 +42,7 @@ end
 
 const FDG_NO_ROOT = 0xffffffff
 const FDG_SPEC_ISA = Cuint(4)
+const FDG_SPEC_AUTOTUNE = Cuint(8)
 
 _fdg_check(rc) = rc == 0 ? nothing :
     error("fdg error $rc: " * unsafe_string(ccall((:fdg_last_error, _libfdg), Cstring, ())))
@@ -114,8 +115,17 @@ function lower_to_table(graphs::AbstractVector{G}; root::AbstractVector{Int}=[id
     return L, op, power, off, idx, fac, root_slot, leafmap, last_root
 end
 
+"""
+    compile_hip(graphs; root, backend=:isa, autotune=false, groups=nothing, cache_dir=nothing)
+
+`groups` (optional `Dict{Int,Int}`: node id => tag) is the scheduling hint of
+`fdg_graph_set_schedule_groups`: pass the coefficient -> original-node map of `taylorexpansion!`
+(`to_coeff_map`, src/utility.jl:105-135) so that all Taylor coefficients of one node are evaluated
+together.  It never changes a value.
+"""
 function compile_hip(graphs::AbstractVector{<:AbstractGraph};
-    root::AbstractVector{Int}=[id(g) for g in graphs], backend::Symbol=:isa, cache_dir::Union{Nothing,String}=nothing)
+    root::AbstractVector{Int}=[id(g) for g in graphs], backend::Symbol=:isa, autotune::Bool=false,
+    groups::Union{Nothing,Dict{Int,Int}}=nothing, cache_dir::Union{Nothing,String}=nothing)
     L, op, power, off, idx, fac, root_slot, leafmap, last_root = lower_to_table(graphs; root=root)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve op power off idx fac root_slot begin
@@ -123,8 +133,19 @@ function compile_hip(graphs::AbstractVector{<:AbstractGraph};
             pointer(op), pointer(power), pointer(off), pointer(idx), pointer(fac), pointer(root_slot)))
         _fdg_check(ccall((:fdg_graph_create, _libfdg), Cint, (Ref{_FdgGraphDesc}, Ref{Ptr{Cvoid}}), desc, h))
     end
+    if !isnothing(groups)
+        # internal nodes in statement order, exactly the order lower_to_table numbered them
+        seen = Set{Int}(); tags = Dict{Int,UInt32}(); grp = UInt32[]
+        for graph in graphs, g in PostOrderDFS(graph)
+            (isempty(subgraphs(g)) || id(g) in seen) && continue
+            push!(seen, id(g))
+            key = get(groups, id(g), -id(g))
+            push!(grp, get!(tags, key, UInt32(length(tags))))
+        end
+        _fdg_check(ccall((:fdg_graph_set_schedule_groups, _libfdg), Cint, (Ptr{Cvoid}, Ptr{UInt32}, UInt32), h[], grp, UInt32(length(grp))))
+    end
     if backend != :interp
-        flags = backend == :isa ? FDG_SPEC_ISA : Cuint(0)
+        flags = backend == :isa ? (FDG_SPEC_ISA | (autotune ? FDG_SPEC_AUTOTUNE : Cuint(0))) : Cuint(0)
         cdir = isnothing(cache_dir) ? C_NULL : cache_dir
         rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, flags)
         if rc == -2 && backend == :isa      # FDG_E_UNSUPPORTED: e.g. Power{N}, N > 3 -> HIP-source JIT
