@@ -28,7 +28,7 @@ EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
     "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_graph_release_device", "fdg_powi",
-    "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups",
+    "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
 ]
 
 
@@ -59,6 +59,13 @@ class GraphInfo(C.Structure):
 
     def asdict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class LeafTables(C.Structure):
+    _fields_ = [("n_leaf", C.c_uint32), ("n_basis", C.c_uint32), ("n_loop", C.c_uint32), ("dim", C.c_uint32),
+                ("n_tau", C.c_uint32), ("leaf_type", C.c_void_p), ("leaf_order", C.c_void_p), ("tau_in", C.c_void_p),
+                ("tau_out", C.c_void_p), ("loop_index", C.c_void_p), ("basis", C.c_void_p),
+                ("kF", C.c_double), ("beta", C.c_double), ("lambda_", C.c_double)]
 
 
 class OptParams(C.Structure):
@@ -113,6 +120,7 @@ def lib():
     L.fdg_accumulate_device.argtypes = [vp, dp, i64, i64, dp, dp, i64, vp]
     L.fdg_fill_uniform_device.argtypes = [dp, i64, u32, i64, i64, u64, u64, vp]
     L.fdg_graph_release_device.argtypes = [vp]
+    L.fdg_leaf_eval_device.argtypes = [C.POINTER(LeafTables), dp, i64, i64, dp, i64, i64, dp, i64, i64, i64, vp]
     L.fdg_graph_set_schedule_groups.argtypes = [vp, C.c_void_p, u32]
     L.fdg_graph_set_opt_params.argtypes = [vp, C.POINTER(OptParams)]
     L.fdg_graph_opt_program.argtypes = [vp, C.POINTER(OptParams), C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64),
@@ -241,3 +249,17 @@ def fill_uniform_device(d_leaf: int, B: int, L: int, ss: int, ls: int, seed: int
 
 def powi(x: float, n: int) -> float:
     return float(lib().fdg_powi(x, n))
+
+
+def leaf_eval_device(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, dim, n_tau, kF, beta, lam,
+                     d_K: int, ks: int, kc: int, d_T: int, ts: int, tc: int, d_leaf: int, ss: int, ls: int, B: int,
+                     stream: int = 0):
+    """fdg_leaf_eval_device with the tables of ``FrontEnds.leafstates`` (1-based indices)."""
+    a = [np.ascontiguousarray(x, dtype=np.int32) for x in (leaf_type, leaf_order, tau_in, tau_out, loop_index)]
+    bs = np.ascontiguousarray(basis, dtype=np.float64)
+    t = LeafTables()
+    t.n_leaf, t.n_basis, t.n_loop, t.dim, t.n_tau = a[0].shape[0], bs.shape[0], bs.shape[1], dim, n_tau
+    t.leaf_type, t.leaf_order, t.tau_in, t.tau_out, t.loop_index = [x.ctypes.data for x in a]
+    t.basis = bs.ctypes.data
+    t.kF, t.beta, t.lambda_ = kF, beta, lam
+    check(lib().fdg_leaf_eval_device(C.byref(t), d_K, ks, kc, d_T, ts, tc, d_leaf, ss, ls, B, stream))

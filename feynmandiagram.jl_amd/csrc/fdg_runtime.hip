@@ -244,6 +244,56 @@ fdg_fill_uniform(double *__restrict__ leaf, long B, uint32_t L, long ss, long ls
   }
 }
 
+// Leaf values from (K, T): one lane = one sample; the tables are wave-uniform (scalar loads); the
+// sample's momenta and times are staged once in LDS columns and re-read per leaf.
+__device__ __forceinline__ double fdg_green0(double tau, double w, double beta) {
+  // example/benchmark.jl:113-127
+  if (tau == 0.0) tau = -1e-10;
+  if (tau > 0.0)
+    return w > 0.0 ? exp(-w * tau) / (1.0 + exp(-w * beta)) : exp(w * (beta - tau)) / (1.0 + exp(w * beta));
+  return w > 0.0 ? -exp(-w * (tau + beta)) / (1.0 + exp(-w * beta)) : -exp(-w * tau) / (1.0 + exp(w * beta));
+}
+
+__global__ void __launch_bounds__(64)
+fdg_leaf_kernel(const int32_t *__restrict__ ltype, const int32_t *__restrict__ lorder, const int32_t *__restrict__ tin,
+                const int32_t *__restrict__ tout, const int32_t *__restrict__ lidx, const double *__restrict__ basis,
+                uint32_t L, uint32_t n_loop, uint32_t dim, uint32_t n_tau, double kF, double beta, double lambda,
+                const double *__restrict__ K, long ks, long kc, const double *__restrict__ T, long ts, long tc,
+                double *__restrict__ leaf, long ss, long ls, long B) {
+  extern __shared__ double sh[];                 // [(n_loop*dim + n_tau)][64]
+  const int t = threadIdx.x;
+  double *kk = sh + t;
+  double *tt = sh + (size_t)n_loop * dim * 64 + t;
+  const long ntile = (B + 63) / 64;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long b0 = tile * 64 + t;
+    const bool valid = b0 < B;
+    const long b = valid ? b0 : B - 1;
+    for (uint32_t c = 0; c < n_loop * dim; ++c) kk[(size_t)c * 64] = K[b * ks + (long)c * kc];
+    for (uint32_t i = 0; i < n_tau; ++i) tt[(size_t)i * 64] = T[b * ts + (long)i * tc];
+    for (uint32_t i = 0; i < L; ++i) {
+      const int32_t ty = ltype[i];
+      if (ty == 0) continue;
+      const double *bv = basis + (size_t)(lidx[i] - 1) * n_loop;
+      double q2 = 0.0;
+      for (uint32_t d = 0; d < dim; ++d) {
+        double q = 0.0;
+        for (uint32_t j = 0; j < n_loop; ++j) q += kk[(size_t)(j * dim + d) * 64] * bv[j];
+        q2 += q * q;
+      }
+      double v;
+      if (ty == 1) {
+        const double tau = tt[(size_t)(tout[i] - 1) * 64] - tt[(size_t)(tin[i] - 1) * 64];
+        v = fdg_green0(tau, q2 - kF * kF, beta);
+      } else {
+        const double invK = 1.0 / (q2 + lambda);
+        v = 8.0 * 3.141592653589793 / invK * fdg_powi_impl(lambda * invK, lorder[i] == 0 ? 0 : lorder[i]);
+      }
+      if (valid) leaf[b * ss + (long)i * ls] = v;
+    }
+  }
+}
+
 // ============================================================================
 // host side
 // ============================================================================
@@ -954,6 +1004,54 @@ int fdg_eval(fdg_graph *g, const double *leaf, double *root, int64_t B) {
   } while (0);
   hipFree(dl); hipFree(dr);
   return rc;
+}
+
+int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t ks, int64_t kc, const double *d_T,
+                         int64_t ts, int64_t tc, double *d_leaf, int64_t ss, int64_t ls, int64_t B, void *stream) {
+  if (!tab || !tab->leaf_type || !tab->leaf_order || !tab->tau_in || !tab->tau_out || !tab->loop_index || !tab->basis) {
+    set_error("null leaf table"); return FDG_E_INVALID;
+  }
+  if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
+  if (B == 0 || tab->n_leaf == 0) return FDG_OK;
+  if (!d_K || !d_T || !d_leaf) { set_error("null device buffer"); return FDG_E_INVALID; }
+  const uint32_t L = tab->n_leaf;
+  for (uint32_t i = 0; i < L; ++i) {
+    const int32_t ty = tab->leaf_type[i];
+    if (ty < 0 || ty > 2) { set_error("this leaftype " + std::to_string(ty) + " not implemented!"); return FDG_E_UNSUPPORTED; }  // benchmark.jl:79
+    if (ty == 0) continue;
+    if (tab->loop_index[i] < 1 || (uint32_t)tab->loop_index[i] > tab->n_basis) { set_error("loop_index out of range"); return FDG_E_INVALID; }
+    if (ty == 1) {
+      if (tab->leaf_order[i] != 0) { set_error("fermionic leaf of derivative order > 0 needs Lehmann.jl's kernelFermiT_dw* (not part of the reference)"); return FDG_E_UNSUPPORTED; }
+      if (tab->tau_in[i] < 1 || tab->tau_out[i] < 1 || (uint32_t)tab->tau_in[i] > tab->n_tau || (uint32_t)tab->tau_out[i] > tab->n_tau) { set_error("tau index out of range"); return FDG_E_INVALID; }
+    } else if (tab->leaf_order[i] < 0) { set_error("negative derivative order"); return FDG_E_INVALID; }
+  }
+  const size_t lds = ((size_t)tab->n_loop * tab->dim + tab->n_tau) * 64 * sizeof(double);
+  if (lds > 160 * 1024) { set_error("too many momentum/time components for the LDS staging"); return FDG_E_INVALID; }
+  int n = 0, dev = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device available (no CPU fallback)"); return FDG_E_NO_DEVICE; }
+  HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  // tables -> device (small; freed after the launch has been enqueued on the same stream order)
+  const size_t ib = (size_t)L * sizeof(int32_t), bb = (size_t)tab->n_basis * tab->n_loop * sizeof(double);
+  char *d_tab = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMallocAsync((void **)&d_tab, 5 * ib + bb + 64, st));
+  const int32_t *src[5] = {tab->leaf_type, tab->leaf_order, tab->tau_in, tab->tau_out, tab->loop_index};
+  for (int k = 0; k < 5; ++k) HIP_TRY(hipMemcpyAsync(d_tab + k * ib, src[k], ib, hipMemcpyHostToDevice, st));
+  const size_t boff = (5 * ib + 7) & ~(size_t)7;
+  HIP_TRY(hipMemcpyAsync(d_tab + boff, tab->basis, bb, hipMemcpyHostToDevice, st));
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)fdg_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long ntile = (long)((B + 63) / 64);
+  const long per_cu = std::max<long>(1, std::min<long>(32, (160 * 1024) / std::max<size_t>(lds, 1)));
+  const long grid = std::min<long>(ntile, (long)prop.multiProcessorCount * per_cu);
+  hipLaunchKernelGGL(fdg_leaf_kernel, dim3((unsigned)grid), dim3(64), lds, st, (const int32_t *)d_tab, (const int32_t *)(d_tab + ib),
+                     (const int32_t *)(d_tab + 2 * ib), (const int32_t *)(d_tab + 3 * ib), (const int32_t *)(d_tab + 4 * ib),
+                     (const double *)(d_tab + boff), L, tab->n_loop, tab->dim, tab->n_tau, tab->kF, tab->beta, tab->lambda, d_K,
+                     (long)ks, (long)kc, d_T, (long)ts, (long)tc, d_leaf, (long)ss, (long)ls, (long)B);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipFreeAsync(d_tab, st));
+  return FDG_OK;
 }
 
 int fdg_fill_uniform_device(double *d_leaf, int64_t B, uint32_t L, int64_t ss, int64_t ls, uint64_t seed,

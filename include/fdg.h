@@ -196,6 +196,36 @@ int fdg_fill_uniform_device(double *d_leaf, int64_t n_sample, uint32_t n_leaf,
                             int64_t leaf_sample_stride, int64_t leaf_leaf_stride, uint64_t seed,
                             uint64_t sample_offset, void *stream);
 
+/* ---- leaf values on device (the caller's side of the path) ----------------
+ * The per-sample leaf loop of the reference's example integrand (example/benchmark.jl:58-81):
+ *   loops = K[:, 1:n_loop] * basis                       (FrontEnds.update, src/frontend/pool.jl:69-76)
+ *   type 1 (fermionic G): tau = T[tau_out] - T[tau_in];  eps = |loops[:, loop_index]|^2 - kF^2;
+ *                         leaf = green(tau, eps, beta)   (example/benchmark.jl:113-127; order 0 only --
+ *                         higher orders call Lehmann.jl, which is not part of the reference)
+ *   type 2 (bosonic V):   invK = 1/(|q|^2 + lambda);     leaf = 8*pi/invK * (lambda*invK)^order
+ *   type 0:               leaf left untouched
+ * with the tables FrontEnds.leafstates returns (src/frontend/frontends.jl:178-232; indices 1-based as
+ * in the reference).  Writes the leaf matrix the evaluator reads, so the Monte-Carlo loop
+ * (K, T) -> leaves -> graph -> accumulate never leaves the device.  Transcendentals differ from the
+ * host libm in the last ulp: parity for this entry point is 1e-13 relative, not bit-exact. */
+typedef struct fdg_leaf_tables {
+  uint32_t n_leaf, n_basis, n_loop, dim, n_tau;
+  const int32_t *leaf_type;    /* [n_leaf] 0 / 1 / 2 */
+  const int32_t *leaf_order;   /* [n_leaf] derivative order of that leaf's own kind */
+  const int32_t *tau_in;       /* [n_leaf] 1-based index into T */
+  const int32_t *tau_out;      /* [n_leaf] */
+  const int32_t *loop_index;   /* [n_leaf] 1-based index into the loop basis */
+  const double *basis;         /* [n_basis][n_loop] */
+  double kF, beta, lambda;
+} fdg_leaf_tables;
+
+/* K element (sample b, loop j, component d): d_K[b*k_sample_stride + (j*dim + d)*k_comp_stride];
+ * T element (b, i): d_T[b*t_sample_stride + i*t_comp_stride]; leaves as in fdg_eval_device. */
+int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t k_sample_stride,
+                         int64_t k_comp_stride, const double *d_T, int64_t t_sample_stride,
+                         int64_t t_comp_stride, double *d_leaf, int64_t leaf_sample_stride,
+                         int64_t leaf_leaf_stride, int64_t n_sample, void *stream);
+
 /* Device workspace control: the interpreter keeps per-sample overflow slots in
  * an HBM panel owned by the handle; it is sized on first use for the number of
  * resident waves.  This releases it (and any loaded module). */

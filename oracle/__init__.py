@@ -194,6 +194,43 @@ def philox_uniform(B: int, L: int, seed: int, sample_offset: int = 0) -> np.ndar
 
 
 # --------------------------------------------------------------------------- #
+# leaf values from (K, T): numpy restatement of example/benchmark.jl:58-81,113-127
+# (FrontEnds.update = one matrix product, src/frontend/pool.jl:69-76)
+# --------------------------------------------------------------------------- #
+def leaf_values(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, K, T, kF, beta, lam):
+    """K: [B, n_loop, dim], T: [B, n_tau]; tables 1-based like FrontEnds.leafstates.  Returns [B, L]
+    (entries of type-0 leaves are NaN: the reference leaves them untouched)."""
+    K = np.asarray(K, dtype=np.float64)
+    T = np.asarray(T, dtype=np.float64)
+    basis = np.asarray(basis, dtype=np.float64)                   # [n_basis, n_loop]
+    loops = np.einsum("bjd,nj->bnd", K, basis)                    # loops[:, n] = K[:, 1:n_loop] * basis[:, n]
+    q2 = (loops * loops).sum(axis=2)                              # [B, n_basis]
+    B, L = K.shape[0], len(leaf_type)
+    out = np.full((B, L), np.nan)
+    for i in range(L):
+        ty = int(leaf_type[i])
+        if ty == 0:
+            continue
+        qq = q2[:, int(loop_index[i]) - 1]
+        if ty == 1:
+            if int(leaf_order[i]) != 0:
+                raise NotImplementedError("green_derive order > 0 needs Lehmann.jl")
+            tau = T[:, int(tau_out[i]) - 1] - T[:, int(tau_in[i]) - 1]
+            tau = np.where(tau == 0.0, -1e-10, tau)
+            w = qq - kF * kF
+            with np.errstate(over="ignore"):
+                pos = np.where(w > 0, np.exp(-w * tau) / (1 + np.exp(-w * beta)), np.exp(w * (beta - tau)) / (1 + np.exp(w * beta)))
+                neg = np.where(w > 0, -np.exp(-w * (tau + beta)) / (1 + np.exp(-w * beta)), -np.exp(-w * tau) / (1 + np.exp(w * beta)))
+            out[:, i] = np.where(tau > 0, pos, neg)
+        elif ty == 2:
+            invK = 1.0 / (qq + lam)
+            out[:, i] = 8 * np.pi / invK * (lam * invK) ** int(leaf_order[i])
+        else:
+            raise NotImplementedError(f"this leaftype {ty} not implemented!")
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # CPU baseline: the reference's C back-end text compiled by gcc
 # --------------------------------------------------------------------------- #
 _DRIVER = r"""

@@ -245,3 +245,48 @@ def test_config4_taylor_standin_and_special_values(libfdg, cuda, spec):
     m = ~np.isnan(want)
     assert np.array_equal(got[m], want[m])
     assert np.array_equal(np.signbit(got[m]), np.signbit(want[m]))
+
+
+def test_leaf_values_on_device_and_full_mc_step(libfdg, cuda):
+    """SURVEY.md 8f row 3 (not fused): (K, T) -> leaves on device with the leafstates tables, then the
+    evaluator, then the weighted accumulation -- the loop of example/benchmark.jl:58-87 without leaving the
+    GPU.  exp() differs from libm in the last ulp, so this entry point is compared at 1e-13 relative."""
+    import torch
+    z = np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz"))
+    t = workloads.get("gv_sigma4")
+    L = t.n_leaf
+    assert z["leaf_type"].shape[0] == L
+    B, dim, n_loop, n_tau = 5000, 3, int(z["basis"].shape[1]), int(z["n_tau"])
+    kF, beta, lam = 1.919, 3.0, 1.2
+    rng = np.random.default_rng(1)
+    K = rng.uniform(-2.0, 2.0, size=(B, n_loop, dim))
+    T = rng.uniform(0.0, beta, size=(B, n_tau))
+    T[:, 0] = 0.0
+    want = oracle.leaf_values(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], K, T, kF, beta, lam)
+    dK = torch.from_numpy(np.ascontiguousarray(K.reshape(B, n_loop * dim).T)).to(cuda)       # component-major [n_loop*dim, B]
+    dT = torch.from_numpy(np.ascontiguousarray(T.T)).to(cuda)                                 # [n_tau, B]
+    leaf = torch.zeros((L, B), dtype=torch.float64, device=cuda).t()                          # leaf-major
+    st = torch.cuda.current_stream().cuda_stream
+    capi.leaf_eval_device(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau,
+                          kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf.data_ptr(), leaf.stride(0), leaf.stride(1), B, st)
+    torch.cuda.synchronize()
+    got = leaf.cpu().numpy()
+    assert np.isfinite(want).all()
+    assert np.all(np.abs(got - want) <= 1e-13 * np.abs(want))
+    # graph on the device-made leaves == oracle on the same (device-made) leaves, bit for bit
+    f = fd.compile_table(t, specialize="isa")
+    roots = f(None, leaf)
+    w = torch.rand(B, dtype=torch.float64, device=cuda)
+    acc = f.accumulate(leaf, w)
+    torch.cuda.synchronize()
+    ref = oracle.eval_static(t, got)
+    assert np.array_equal(roots.cpu().numpy(), ref)
+    wn = w.cpu().numpy()[:, None]
+    assert np.all(np.abs(acc.cpu().numpy() - (ref * wn).sum(0)) <= TOL * np.maximum(1.0, np.abs(ref * wn).sum(0)))
+    # unsupported: fermionic derivative order > 0 (Lehmann), unknown leaf type
+    bad = z["leaf_order"].copy()
+    bad[np.argmax(z["leaf_type"] == 1)] = 1
+    with pytest.raises(capi.FdgError) as e:
+        capi.leaf_eval_device(z["leaf_type"], bad, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau, kF, beta, lam,
+                              dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf.data_ptr(), leaf.stride(0), leaf.stride(1), B, st)
+    assert e.value.code == capi.FDG_E_UNSUPPORTED
