@@ -1,0 +1,33 @@
+"""Whole integrand step on device: (K, T) -> leaves -> graph -> weighted accumulation (dev tool)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import feynmandiagram_jl_amd as fd
+from feynmandiagram_jl_amd import capi, workloads
+dev = torch.device("cuda:0")
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+z = np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz"))
+t = workloads.get("gv_sigma4"); L = t.n_leaf
+B, dim, n_loop, n_tau = 1 << 22, 3, int(z["basis"].shape[1]), int(z["n_tau"])
+kF, beta, lam = 1.919, 3.0, 1.2
+dK = (torch.rand((n_loop * dim, B), dtype=torch.float64, device=dev) * 4 - 2)
+dT = torch.rand((n_tau, B), dtype=torch.float64, device=dev) * beta
+leaf = torch.zeros((L, B), dtype=torch.float64, device=dev).t()
+w = torch.rand(B, dtype=torch.float64, device=dev)
+f = fd.compile_table(t, specialize="isa")
+st = torch.cuda.current_stream().cuda_stream
+def leaves():
+    capi.leaf_eval_device(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau, kF, beta, lam,
+                          dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf.data_ptr(), leaf.stride(0), leaf.stride(1), B, st)
+acc = torch.zeros(t.n_root, dtype=torch.float64, device=dev)
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+tl = timeit(leaves); te = timeit(lambda: f.accumulate(leaf, w, acc))
+def both(): leaves(); f.accumulate(leaf, w, acc)
+tb = timeit(both)
+print(f"gv_sigma4 B={B}: leaves {tl:.3f} ms ({B/tl*1e3:.3e}/s, {B*L*8/tl/1e6:.0f} GB/s written), eval+accumulate {te:.3f} ms ({B/te*1e3:.3e}/s), whole step {tb:.3f} ms = {B/tb*1e3:.3e} samples/s")
