@@ -42,12 +42,22 @@ class GraphFunc:
 
     def __init__(self, table: NodeTable, specialize=False, cache_dir: Optional[str] = None,
                  flags: int = 0, opt: Optional[dict] = None):
-        """``specialize``: False (table interpreter), True / "hip" (straight-line HIP
-        source through hiprtc) or "isa" (optimizing back end, gfx950 assembly)."""
+        """``specialize``: "auto" (ISA, else HIP source), "isa" / "isa-autotune" (optimizing back end,
+        gfx950 assembly), True / "hip" (straight-line HIP source through hiprtc), False (table
+        interpreter, no JIT)."""
         self.table = table.normalized()
         self.handle = capi.GraphHandle(self.table)
         self.n_leaf, self.n_root = self.table.n_leaf, self.table.n_root
-        if specialize in ("isa", "isa-autotune"):
+        if specialize == "auto":
+            # best available: gfx950 assembly; graphs it does not cover (Power{N}, N not in {2,3}) go
+            # through the HIP-source JIT.  Both are JIT back ends of the same ABI, not fallbacks to a CPU.
+            try:
+                self.handle.specialize(cache_dir, flags | capi.FDG_SPEC_ISA)
+            except capi.FdgError as e:
+                if e.code != capi.FDG_E_UNSUPPORTED:
+                    raise
+                self.handle.specialize(cache_dir, flags)
+        elif specialize in ("isa", "isa-autotune"):
             if opt:
                 self.handle.set_opt_params(**opt)
             if specialize == "isa-autotune":
@@ -150,7 +160,7 @@ def compile_table(table: NodeTable, specialize: bool = False, **kw) -> GraphFunc
     return GraphFunc(table, specialize=specialize, **kw)
 
 
-def compile(graphs: Sequence[Graph], root: Optional[Sequence[int]] = None, specialize: bool = False,
+def compile(graphs: Sequence[Graph], root: Optional[Sequence[int]] = None, specialize="auto",
             **kw) -> Tuple[GraphFunc, Dict[int, Graph]]:
     """``Compilers.compile`` (static.jl:221-227): returns ``(f, leafmap)``."""
     table, leafmap, _ = lower(graphs, root)
