@@ -90,9 +90,13 @@ fdg_interp(const uint32_t *code_, const double *__restrict__ leaf, long ss, long
 
     auto fetch = [&](uint32_t loc) -> double {
       const uint32_t sp = loc >> 30, ix = loc & LOC_IDX_MASK;
-      if (sp == SP_LDS) return ldsl[(size_t)ix * 256u];
-      if (sp == SP_MEM) return mem[(size_t)ix * 256u];
-      return STAGED ? lpanel[(size_t)ix * 256u] : lp[(long)ix * ls];
+      double v;
+      // three explicit branches (the empty asm keeps the compiler from merging them into one flat load
+      // through a selected generic pointer: LDS reads stay ds_read, panel reads stay global_load)
+      if (sp == SP_LDS) { v = ldsl[(size_t)ix * 256u]; asm volatile("" : "+v"(v)); }
+      else if (sp == SP_MEM) { v = mem[(size_t)ix * 256u]; asm volatile("" : "+v"(v)); }
+      else { v = STAGED ? lpanel[(size_t)ix * 256u] : lp[(long)ix * ls]; asm volatile("" : "+v"(v)); }
+      return v;
     };
     auto factor = [&](uint32_t pc) -> double {
       const uint64_t u = (uint64_t)code[pc] | ((uint64_t)code[pc + 1] << 32);
