@@ -89,6 +89,10 @@ struct fdg_graph {
   bool isa = false;
   void *fn_isa = nullptr;
   uint32_t isa_vgpr = 0, isa_lds_bytes = 0, isa_mem_slots = 0;
+  // optional two-samples-per-lane variant in the same code object (sample stride 1, full 128-sample tiles)
+  bool has_w2 = false;
+  void *fn_isa_w2 = nullptr;
+  uint32_t isa2_vgpr = 0, isa2_lds_bytes = 0, isa2_mem_slots = 0;
   void *d_ws2 = nullptr;           // roots scratch for accumulate through the ISA kernel
   size_t ws2_bytes = 0;
   void *d_ws3 = nullptr;           // leaf-major copy of a sample-major chunk for the ISA kernel

@@ -104,76 +104,77 @@ void emit_scaled_addr(Emit &E, int dst, int base, int mul8, uint32_t k) {
   E.ins("s_addc_u32 s" + std::to_string(dst + 1) + ", s" + std::to_string(base + 1) + ", s" + std::to_string(S_X + 1));
 }
 
-// panel slot address: returns "s[a:b] offset:imm" operand text after emitting the SALU that forms the base
-std::string panel_operand(Emit &E, uint32_t slot) {
-  const uint64_t byte = (uint64_t)slot * 512u;
-  const uint64_t hi = byte & ~4095ull, lo = byte & 4095ull;
-  if (hi == 0) return "s[" + std::to_string(S_PANEL) + ":" + std::to_string(S_PANEL + 1) + "] offset:" + std::to_string(lo);
-  E.ins("s_add_u32 s" + std::to_string(S_A) + ", s" + std::to_string(S_PANEL) + ", " + hex32((uint32_t)hi));
-  E.ins("s_addc_u32 s" + std::to_string(S_A + 1) + ", s" + std::to_string(S_PANEL + 1) + ", " + hex32((uint32_t)(hi >> 32)));
-  return "s[" + std::to_string(S_A) + ":" + std::to_string(S_A + 1) + "] offset:" + std::to_string(lo);
-}
+struct KernelMeta { std::string name; uint32_t lds_bytes, accum, n_agpr; };
 
-}  // namespace
-
-std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname) {
-  Emit E;
+// Prints one kernel.  W = samples per lane: 1 (64-sample tiles, 8-byte accesses) or 2 (128-sample
+// tiles: a value is two doubles in four VGPRs, every memory access is 16 bytes per lane -- the
+// wide-access form HBM-bound graphs want; needs sample stride 1 and full tiles, the host runs the
+// remainder through the W = 1 kernel).
+static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog, const std::string &kname, int W) {
+  E.vm_issued = E.lg_issued = E.vm_done = E.lg_done = 0;
   E.pend.assign(std::max<uint32_t>(prog.n_reg_used, 1), {0, 0});
-  const uint32_t lds_bytes = prog.n_lds_used * 512u;
-  const uint32_t panel_bytes_per_wave = std::max<uint32_t>(prog.n_mem_used, 1) * 512u;
+  const uint32_t SLOT = 512u * W;                 // bytes of one LDS / panel slot of a wave
+  const uint32_t lds_bytes = prog.n_lds_used * SLOT;
+  const uint32_t panel_bytes_per_wave = std::max<uint32_t>(prog.n_mem_used, 1) * SLOT;
+  const int RW = 2 * W;                           // VGPRs per value
+  const int TSH = W == 2 ? 7 : 6;                 // log2(samples per tile)
+  const std::string sfx = "_" + kname;
   std::ostringstream &os = E.os;
-  os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n\t.text\n";
-  os << "\t.protected\t" << kname << "\n\t.globl\t" << kname << "\n\t.p2align\t8\n\t.type\t" << kname << ",@function\n";
+  os << "\t.text\n\t.protected\t" << kname << "\n\t.globl\t" << kname << "\n\t.p2align\t8\n\t.type\t" << kname << ",@function\n";
   os << kname << ":\n";
   auto S = [](int r) { return "s" + std::to_string(r); };
   auto S2 = [](int r) { return "s[" + std::to_string(r) + ":" + std::to_string(r + 1) + "]"; };
   auto V = [](int r) { return "v" + std::to_string(r); };
+  auto vlo = [&](uint32_t r) { const int b = V_BASE + RW * r; return "v[" + std::to_string(b) + ":" + std::to_string(b + 1) + "]"; };
+  auto vhi = [&](uint32_t r) { const int b = V_BASE + RW * r + 2; return "v[" + std::to_string(b) + ":" + std::to_string(b + 1) + "]"; };
+  auto vall = [&](uint32_t r) { const int b = V_BASE + RW * r; return "v[" + std::to_string(b) + ":" + std::to_string(b + RW - 1) + "]"; };
+  const std::string LD = W == 2 ? "global_load_dwordx4 " : "global_load_dwordx2 ";
+  const std::string ST = W == 2 ? "global_store_dwordx4 " : "global_store_dwordx2 ";
+  const std::string DSR = W == 2 ? "ds_read_b128 " : "ds_read_b64 ";
+  const std::string DSW = W == 2 ? "ds_write_b128 " : "ds_write_b64 ";
 
   const char *dbg = std::getenv("FDG_ISA_DEBUG");
   const bool dbg_noleaf = dbg && std::strstr(dbg, "noleaf");
   const bool dbg_nolds = dbg && std::strstr(dbg, "nolds");
-  const bool dbg_panelin = dbg && std::strstr(dbg, "panelin");   // timing only: read leaves as [tile][L][64]
   // ---- prologue ------------------------------------------------------------
   E.ins("s_load_dwordx8 s[4:11], s[0:1], 0x0");
   E.ins("s_load_dwordx8 s[12:19], s[0:1], 0x20");
   E.ins("s_load_dwordx2 s[20:21], s[0:1], 0x40");
-  for (uint32_t r = 0; r < E.pend.size(); ++r) E.wait_reg(r);   // loads never consumed (evicted prefetches): no WAW into the next tile
   E.ins("s_waitcnt lgkmcnt(0)");
-  E.ins("v_lshlrev_b32_e32 " + V(V_LANE8) + ", 3, v0");
-  E.ins("v_mul_lo_u32 " + V(V_LEAFOFF) + ", v0, " + S(S_SS));          // lane*ss (low 32 bits)
-  E.ins("v_lshlrev_b32_e32 " + V(V_LEAFOFF) + ", 3, " + V(V_LEAFOFF));
+  E.ins("v_lshlrev_b32_e32 " + V(V_LANE8) + ", " + std::to_string(W == 2 ? 4 : 3) + ", v0");      // lane * 8W
+  E.ins("v_mul_lo_u32 " + V(V_LEAFOFF) + ", v0, " + S(S_SS));                                    // lane*ss (low 32 bits)
+  E.ins("v_lshlrev_b32_e32 " + V(V_LEAFOFF) + ", " + std::to_string(W == 2 ? 4 : 3) + ", " + V(V_LEAFOFF));
   E.ins("v_mul_lo_u32 " + V(V_ROOTOFF) + ", v0, " + S(S_RS));
-  E.ins("v_lshlrev_b32_e32 " + V(V_ROOTOFF) + ", 3, " + V(V_ROOTOFF));
+  E.ins("v_lshlrev_b32_e32 " + V(V_ROOTOFF) + ", " + std::to_string(W == 2 ? 4 : 3) + ", " + V(V_ROOTOFF));
   E.ins("s_lshl_b64 " + S2(S_LS8) + ", " + S2(S_LS) + ", 3");
   E.ins("s_lshl_b64 " + S2(S_RK8) + ", " + S2(S_RK) + ", 3");
-  // ntiles = (B + 63) >> 6 (B < 2^37 so that ntiles fits 32 bits)
-  E.ins("s_add_u32 " + S(S_X) + ", " + S(S_B) + ", 63");
+  // ntiles = ceil(B / tile)   (W = 2 is only launched on a multiple of 128 samples)
+  E.ins("s_add_u32 " + S(S_X) + ", " + S(S_B) + ", " + std::to_string((1 << TSH) - 1));
   E.ins("s_addc_u32 " + S(S_X + 1) + ", " + S(S_B + 1) + ", 0");
-  E.ins("s_lshr_b64 " + S2(S_X) + ", " + S2(S_X) + ", 6");
+  E.ins("s_lshr_b64 " + S2(S_X) + ", " + S2(S_X) + ", " + std::to_string(TSH));
   E.ins("s_mov_b32 " + S(S_NTILES) + ", " + S(S_X));
   E.ins("s_mov_b32 " + S(S_TILE) + ", s2");
-  // panel base = ws + wg * panel_bytes_per_wave
   E.ins("s_mul_i32 " + S(S_X) + ", s2, " + hex32(panel_bytes_per_wave));
   E.ins("s_mul_hi_u32 " + S(S_X + 1) + ", s2, " + hex32(panel_bytes_per_wave));
   E.ins("s_add_u32 " + S(S_PANEL) + ", " + S(S_WS) + ", " + S(S_X));
   E.ins("s_addc_u32 " + S(S_PANEL + 1) + ", " + S(S_WS + 1) + ", " + S(S_X + 1));
   E.ins("s_cmp_ge_u32 " + S(S_TILE) + ", " + S(S_NTILES));
-  E.ins("s_cbranch_scc0 .Ltile");
+  E.ins("s_cbranch_scc0 .Ltile" + sfx);
   E.ins("s_endpgm");
-  os << ".Ltile:\n";
-  // b0 = tile*64 (64-bit in S_X:S_X+1); valid lanes; exec
+  os << ".Ltile" << sfx << ":\n";
   E.ins("s_mov_b32 " + S(S_X + 1) + ", 0");
   E.ins("s_mov_b32 " + S(S_X) + ", " + S(S_TILE));
-  E.ins("s_lshl_b64 " + S2(S_X) + ", " + S2(S_X) + ", 6");
-  E.ins("s_sub_u32 " + S(S_T) + ", " + S(S_B) + ", " + S(S_X));           // B - b0 (low); high decides >= 64
-  E.ins("s_subb_u32 " + S(S_T + 1) + ", " + S(S_B + 1) + ", " + S(S_X + 1));
-  E.ins("s_cmp_lg_u32 " + S(S_T + 1) + ", 0");
-  E.ins("s_cselect_b32 " + S(S_T) + ", 64, " + S(S_T));
-  E.ins("s_min_u32 " + S(S_T) + ", " + S(S_T) + ", 64");
-  E.ins("s_bfm_b64 " + S2(S_A) + ", " + S(S_T) + ", 0");
-  E.ins("s_cmp_ge_u32 " + S(S_T) + ", 64");
-  E.ins("s_cselect_b64 exec, -1, " + S2(S_A));
-  // leaf tile base = leaf + b0*ss*8 ; root tile base = root + b0*rs*8   (b0 < 2^32 assumed hi part folded)
+  E.ins("s_lshl_b64 " + S2(S_X) + ", " + S2(S_X) + ", " + std::to_string(TSH));                 // b0
+  if (W == 1) {
+    E.ins("s_sub_u32 " + S(S_T) + ", " + S(S_B) + ", " + S(S_X));           // B - b0 (low); high decides >= 64
+    E.ins("s_subb_u32 " + S(S_T + 1) + ", " + S(S_B + 1) + ", " + S(S_X + 1));
+    E.ins("s_cmp_lg_u32 " + S(S_T + 1) + ", 0");
+    E.ins("s_cselect_b32 " + S(S_T) + ", 64, " + S(S_T));
+    E.ins("s_min_u32 " + S(S_T) + ", " + S(S_T) + ", 64");
+    E.ins("s_bfm_b64 " + S2(S_A) + ", " + S(S_T) + ", 0");
+    E.ins("s_cmp_ge_u32 " + S(S_T) + ", 64");
+    E.ins("s_cselect_b64 exec, -1, " + S2(S_A));
+  }
   auto tile_base = [&](int dst, int base, int stride) {
     E.ins("s_mul_i32 " + S(S_A) + ", " + S(S_X) + ", " + S(stride));
     E.ins("s_mul_hi_u32 " + S(S_A + 1) + ", " + S(S_X) + ", " + S(stride));
@@ -187,67 +188,63 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   };
   tile_base(S_LT, S_LEAF, S_SS);
   tile_base(S_RT, S_ROOT, S_RS);
-  if (dbg_panelin) {
-    E.ins("s_mul_i32 " + S(S_A) + ", " + S(S_TILE) + ", " + hex32(p.L * 512u));
-    E.ins("s_mul_hi_u32 " + S(S_A + 1) + ", " + S(S_TILE) + ", " + hex32(p.L * 512u));
-    E.ins("s_add_u32 " + S(S_LT) + ", " + S(S_LEAF) + ", " + S(S_A));
-    E.ins("s_addc_u32 " + S(S_LT + 1) + ", " + S(S_LEAF + 1) + ", " + S(S_A + 1));
-  }
+
+  auto panel_operand = [&](uint32_t slot) -> std::string {
+    const uint64_t byte = (uint64_t)slot * SLOT;
+    const uint64_t hi = byte & ~4095ull, lo = byte & 4095ull;
+    if (hi == 0) return S2(S_PANEL) + " offset:" + std::to_string(lo);
+    E.ins("s_add_u32 " + S(S_A) + ", " + S(S_PANEL) + ", " + hex32((uint32_t)hi));
+    E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_PANEL + 1) + ", " + hex32((uint32_t)(hi >> 32)));
+    return S2(S_A) + " offset:" + std::to_string(lo);
+  };
+  auto valu2 = [&](const std::string &opc, const MOp &o, const std::string &second_lo, const std::string &second_hi) {
+    E.ins(opc + vlo(o.d) + ", " + (o.nega ? "-" : "") + vlo(o.a) + ", " + second_lo);
+    if (W == 2) E.ins(opc + vhi(o.d) + ", " + (o.nega ? "-" : "") + vhi(o.a) + ", " + second_hi);
+  };
 
   // ---- body ------------------------------------------------------------------
   for (const MOp &o : prog.ops) {
     switch (o.kind) {
-      case M_LD_LEAF: {
+      case M_LD_LEAF:
         if (dbg_noleaf) break;   // timing experiments only (results are garbage)
         E.wait_reg(o.d);
-        if (dbg_panelin) {
-          const uint64_t byte = (uint64_t)o.a * 512u;
-          E.ins("s_add_u32 " + S(S_A) + ", " + S(S_LT) + ", " + hex32((uint32_t)(byte & ~4095ull)));
-          E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_LT + 1) + ", 0");
-          E.ins("global_load_dwordx2 " + E.vr(o.d) + ", " + V(V_LANE8) + ", " + S2(S_A) + " offset:" + std::to_string(byte & 4095ull));
-          E.pend[o.d] = {1, ++E.vm_issued};
-          break;
-        }
         emit_scaled_addr(E, S_A, S_LT, S_LS8, o.a);
-        E.ins("global_load_dwordx2 " + E.vr(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_A));
+        E.ins(LD + vall(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_A));
         E.pend[o.d] = {1, ++E.vm_issued};
         break;
-      }
       case M_LD_MEM: {
         E.wait_reg(o.d);
-        const std::string opnd = panel_operand(E, o.a);
-        E.ins("global_load_dwordx2 " + E.vr(o.d) + ", " + V(V_LANE8) + ", " + opnd);
+        const std::string opnd = panel_operand(o.a);
+        E.ins(LD + vall(o.d) + ", " + V(V_LANE8) + ", " + opnd);
         E.pend[o.d] = {1, ++E.vm_issued};
         break;
       }
       case M_ST_MEM: {
         E.wait_reg(o.a);
-        const std::string opnd = panel_operand(E, o.d);
-        E.ins("global_store_dwordx2 " + V(V_LANE8) + ", " + E.vr(o.a) + ", " + opnd);
+        const std::string opnd = panel_operand(o.d);
+        E.ins(ST + V(V_LANE8) + ", " + vall(o.a) + ", " + opnd);
         ++E.vm_issued;
         break;
       }
       case M_LD_LDS:
         if (dbg_nolds) break;
         E.wait_reg(o.d);
-        E.ins("ds_read_b64 " + E.vr(o.d) + ", " + V(V_LANE8) + " offset:" + std::to_string(o.a * 512u));
+        E.ins(DSR + vall(o.d) + ", " + V(V_LANE8) + " offset:" + std::to_string(o.a * SLOT));
         E.pend[o.d] = {2, ++E.lg_issued};
         break;
       case M_ST_LDS:
         if (dbg_nolds) break;
         E.wait_reg(o.a);
-        E.ins("ds_write_b64 " + V(V_LANE8) + ", " + E.vr(o.a) + " offset:" + std::to_string(o.d * 512u));
+        E.ins(DSW + V(V_LANE8) + ", " + vall(o.a) + " offset:" + std::to_string(o.d * SLOT));
         ++E.lg_issued;
         break;
       case M_MUL:
-      case M_ADD: {
+      case M_ADD:
         E.wait_reg(o.a);
         E.wait_reg(o.b);
         E.wait_reg(o.d);
-        E.ins(std::string(o.kind == M_MUL ? "v_mul_f64 " : "v_add_f64 ") + E.vr(o.d) + ", " + (o.nega ? "-" : "") +
-              E.vr(o.a) + ", " + (o.negb ? "-" : "") + E.vr(o.b));
+        valu2(o.kind == M_MUL ? "v_mul_f64 " : "v_add_f64 ", o, (o.negb ? "-" : "") + vlo(o.b), (o.negb ? "-" : "") + vhi(o.b));
         break;
-      }
       case M_MULC: {
         E.wait_reg(o.a);
         E.wait_reg(o.d);
@@ -260,31 +257,38 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
           E.ins("s_mov_b32 " + S(S_C + 1) + ", " + hex32((uint32_t)(u >> 32)));
           c = S2(S_C);
         }
-        E.ins("v_mul_f64 " + E.vr(o.d) + ", " + (o.nega ? "-" : "") + E.vr(o.a) + ", " + c);
+        valu2("v_mul_f64 ", o, c, c);
         break;
       }
       case M_LD_ACC:
         E.wait_reg(o.d);
-        E.ins("v_accvgpr_read_b32 v" + std::to_string(V_BASE + 2 * o.d) + ", a" + std::to_string(2 * o.a));
-        E.ins("v_accvgpr_read_b32 v" + std::to_string(V_BASE + 2 * o.d + 1) + ", a" + std::to_string(2 * o.a + 1));
+        for (int k = 0; k < RW; ++k)
+          E.ins("v_accvgpr_read_b32 v" + std::to_string(V_BASE + RW * o.d + k) + ", a" + std::to_string(RW * o.a + k));
         break;
       case M_ST_ACC:
         E.wait_reg(o.a);
-        E.ins("v_accvgpr_write_b32 a" + std::to_string(2 * o.d) + ", v" + std::to_string(V_BASE + 2 * o.a));
-        E.ins("v_accvgpr_write_b32 a" + std::to_string(2 * o.d + 1) + ", v" + std::to_string(V_BASE + 2 * o.a + 1));
+        for (int k = 0; k < RW; ++k)
+          E.ins("v_accvgpr_write_b32 a" + std::to_string(RW * o.d + k) + ", v" + std::to_string(V_BASE + RW * o.a + k));
         break;
       case M_ROOT: {
         E.wait_reg(o.a);
         emit_scaled_addr(E, S_A, S_RT, S_RK8, o.d);
-        if (o.nega) {
-          E.ins("v_mov_b32_e32 " + V(V_TMP) + ", v" + std::to_string(V_BASE + 2 * o.a));
-          E.ins("v_xor_b32_e32 " + V(V_TMP + 1) + ", 0x80000000, v" + std::to_string(V_BASE + 2 * o.a + 1));
-          E.ins("global_store_dwordx2 " + V(V_ROOTOFF) + ", v[" + std::to_string(V_TMP) + ":" + std::to_string(V_TMP + 1) +
-                "], " + S2(S_A));
-        } else {
-          E.ins("global_store_dwordx2 " + V(V_ROOTOFF) + ", " + E.vr(o.a) + ", " + S2(S_A));
+        for (int h = 0; h < W; ++h) {
+          const int src = V_BASE + RW * o.a + 2 * h;
+          if (h == 1) {   // second sample of the lane: one row further
+            E.ins("s_lshl_b64 " + S2(S_T) + ", " + S2(S_RS) + ", 3");
+            E.ins("s_add_u32 " + S(S_A) + ", " + S(S_A) + ", " + S(S_T));
+            E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_A + 1) + ", " + S(S_T + 1));
+          }
+          if (o.nega) {
+            E.ins("v_mov_b32_e32 " + V(V_TMP) + ", v" + std::to_string(src));
+            E.ins("v_xor_b32_e32 " + V(V_TMP + 1) + ", 0x80000000, v" + std::to_string(src + 1));
+            E.ins("global_store_dwordx2 " + V(V_ROOTOFF) + ", v[" + std::to_string(V_TMP) + ":" + std::to_string(V_TMP + 1) + "], " + S2(S_A));
+          } else {
+            E.ins("global_store_dwordx2 " + V(V_ROOTOFF) + ", v[" + std::to_string(src) + ":" + std::to_string(src + 1) + "], " + S2(S_A));
+          }
+          ++E.vm_issued;
         }
-        ++E.vm_issued;
         break;
       }
       default:
@@ -299,46 +303,63 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   E.ins("s_waitcnt lgkmcnt(0)");
   E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", " + S(S_NWG));
   E.ins("s_cmp_ge_u32 " + S(S_TILE) + ", " + S(S_NTILES));
-  E.ins("s_cbranch_scc0 .Lback");
+  E.ins("s_cbranch_scc0 .Lback" + sfx);
   E.ins("s_endpgm");
   // long backward jump (the body may exceed the 16-bit branch range)
-  os << ".Lback:\n";
+  os << ".Lback" << sfx << ":\n";
   E.ins("s_getpc_b64 " + S2(S_A));
-  os << ".Lpc:\n";
-  E.ins("s_add_u32 " + S(S_A) + ", " + S(S_A) + ", (.Ltile-.Lpc)&0xffffffff");
-  E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_A + 1) + ", (.Ltile-.Lpc)>>32");
+  os << ".Lpc" << sfx << ":\n";
+  E.ins("s_add_u32 " + S(S_A) + ", " + S(S_A) + ", (.Ltile" + sfx + "-.Lpc" + sfx + ")&0xffffffff");
+  E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_A + 1) + ", (.Ltile" + sfx + "-.Lpc" + sfx + ")>>32");
   E.ins("s_setpc_b64 " + S2(S_A));
   E.ins("s_endpgm");
 
-  // ---- kernel descriptor + metadata ------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + 2 * std::max<uint32_t>(prog.n_reg_used, 1), 8);
+  // ---- kernel descriptor -------------------------------------------------------
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
+  const uint32_t n_agpr = RW * prog.n_acc_used;
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
   os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";
   os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size 72\n\t\t.amdhsa_user_sgpr_count 2\n";
   os << "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1\n\t\t.amdhsa_system_sgpr_workgroup_id_x 1\n";
   os << "\t\t.amdhsa_system_vgpr_workitem_id 0\n";
-  const uint32_t n_agpr = 2 * prog.n_acc_used;
   os << "\t\t.amdhsa_next_free_vgpr " << (accum + n_agpr) << "\n\t\t.amdhsa_next_free_sgpr " << S_END << "\n";
   os << "\t\t.amdhsa_accum_offset " << accum << "\n\t\t.amdhsa_reserve_vcc 1\n";
   os << "\t\t.amdhsa_float_round_mode_32 0\n\t\t.amdhsa_float_round_mode_16_64 0\n";
   os << "\t\t.amdhsa_float_denorm_mode_32 3\n\t\t.amdhsa_float_denorm_mode_16_64 3\n";
   os << "\t\t.amdhsa_dx10_clamp 1\n\t\t.amdhsa_ieee_mode 1\n";
-  os << "\t.end_amdhsa_kernel\n\t.text\n";
-  os << "\t.amdgpu_metadata\n---\namdhsa.kernels:\n  - .agpr_count: " << n_agpr << "\n    .args:\n";
+  os << "\t.end_amdhsa_kernel\n";
+  (void)p;
+  return KernelMeta{kname, lds_bytes, accum, n_agpr};
+}
+
+}  // namespace
+
+// One code object: the W = 1 kernel `kname`, and, when prog2 is given, the two-samples-per-lane kernel
+// `kname`_w2 next to it.
+std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2) {
+  Emit E;
+  E.os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n";
+  std::vector<KernelMeta> ks;
+  ks.push_back(emit_kernel(E, p, prog, kname, 1));
+  if (prog2) ks.push_back(emit_kernel(E, p, *prog2, kname + "_w2", 2));
+  std::ostringstream &os = E.os;
+  os << "\t.text\n\t.amdgpu_metadata\n---\namdhsa.kernels:\n";
   const char *kinds[9] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",
                           "global_buffer", "by_value", "by_value"};
-  for (int i = 0; i < 9; ++i) {
-    os << "      - .offset: " << i * 8 << "\n        .size: 8\n        .value_kind: " << kinds[i] << "\n";
-    if (std::strcmp(kinds[i], "global_buffer") == 0) os << "        .address_space: global\n";
+  for (const KernelMeta &k : ks) {
+    os << "  - .agpr_count: " << k.n_agpr << "\n    .args:\n";
+    for (int i = 0; i < 9; ++i) {
+      os << "      - .offset: " << i * 8 << "\n        .size: 8\n        .value_kind: " << kinds[i] << "\n";
+      if (std::strcmp(kinds[i], "global_buffer") == 0) os << "        .address_space: global\n";
+    }
+    os << "    .group_segment_fixed_size: " << k.lds_bytes << "\n    .kernarg_segment_align: 8\n    .kernarg_segment_size: 72\n";
+    os << "    .max_flat_workgroup_size: 64\n    .name: " << k.name << "\n    .private_segment_fixed_size: 0\n";
+    os << "    .sgpr_count: " << (S_END + 6) << "\n    .sgpr_spill_count: 0\n    .symbol: " << k.name << ".kd\n";
+    os << "    .uniform_work_group_size: 1\n    .uses_dynamic_stack: false\n    .vgpr_count: " << (k.accum + k.n_agpr)
+       << "\n    .vgpr_spill_count: 0\n    .wavefront_size: 64\n";
   }
-  os << "    .group_segment_fixed_size: " << lds_bytes << "\n    .kernarg_segment_align: 8\n    .kernarg_segment_size: 72\n";
-  os << "    .max_flat_workgroup_size: 64\n    .name: " << kname << "\n    .private_segment_fixed_size: 0\n";
-  os << "    .sgpr_count: " << (S_END + 6) << "\n    .sgpr_spill_count: 0\n    .symbol: " << kname << ".kd\n";
-  os << "    .uniform_work_group_size: 1\n    .uses_dynamic_stack: false\n    .vgpr_count: " << (accum + n_agpr)
-     << "\n    .vgpr_spill_count: 0\n    .wavefront_size: 64\n";
   os << "amdhsa.target: amdgcn-amd-amdhsa--gfx950\namdhsa.version:\n  - 1\n  - 2\n...\n\t.end_amdgpu_metadata\n";
-  (void)p;
   return os.str();
 }
 

@@ -348,6 +348,7 @@ static int ensure_module(fdg_graph *g) {
     hipFunction_t f;
     HIP_TRY(hipModuleGetFunction(&f, m, "fdg_isa_eval"));
     g->module = m; g->fn_isa = f;
+    if (g->has_w2) { hipFunction_t f2; HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_isa_eval_w2")); g->fn_isa_w2 = f2; }
     return FDG_OK;
   }
   hipFunction_t f1, f2;
@@ -389,17 +390,44 @@ static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, 
     rc = ensure_module(g);
     if (rc) return rc;
     // resident waves: one wave per workgroup; bounded by VGPRs, LDS and 32 waves/CU
-    const uint32_t valloc = std::max<uint32_t>(8, (g->isa_vgpr + 7) & ~7u);
-    uint32_t per_cu = std::min<uint32_t>(8, 512 / valloc) * 4;
-    if (g->isa_lds_bytes) per_cu = std::min<uint32_t>(per_cu, (160u * 1024u) / g->isa_lds_bytes);
-    per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32));
-    const char *env = std::getenv("FDG_ISA_WAVES_PER_CU");
-    if (env) per_cu = (uint32_t)std::max(1, std::atoi(env));
+    auto waves_per_cu = [&](uint32_t vgpr, uint32_t lds_bytes) {
+      const uint32_t valloc = std::max<uint32_t>(8, (vgpr + 7) & ~7u);
+      uint32_t per_cu = std::min<uint32_t>(8, 512 / valloc) * 4;
+      if (lds_bytes) per_cu = std::min<uint32_t>(per_cu, (160u * 1024u) / lds_bytes);
+      per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32));
+      const char *env = std::getenv("FDG_ISA_WAVES_PER_CU");
+      if (env) per_cu = (uint32_t)std::max(1, std::atoi(env));
+      return per_cu;
+    };
     const long ntiles = (long)((B + 63) / 64);
-    const long grid = std::min<long>(ntiles, (long)g->n_cu * per_cu);
-    const size_t panel = (size_t)std::max<uint32_t>(g->isa_mem_slots, 1) * 512u;
-    rc = ensure_ws(g, (size_t)grid * panel + 4096);
+    const long grid = std::min<long>(ntiles, (long)g->n_cu * waves_per_cu(g->isa_vgpr, g->isa_lds_bytes));
+    const long grid2 = g->has_w2 ? (long)g->n_cu * waves_per_cu(g->isa2_vgpr, g->isa2_lds_bytes) : 0;
+    const size_t panel = std::max((size_t)std::max<uint32_t>(g->isa_mem_slots, 1) * 512u * (size_t)grid,
+                                  (size_t)std::max<uint32_t>(g->isa2_mem_slots, 1) * 1024u * (size_t)grid2);
+    rc = ensure_ws(g, panel + 4096);
     if (rc) return rc;
+    // one batch with sample stride `lss`: full 128-sample tiles through the two-samples-per-lane kernel
+    // when there is one and the samples of a leaf are contiguous, the rest through the W = 1 kernel
+    auto launch_isa = [&](const double *lf, long lss, long lls, double *rt, long rrs, long rrk, long n) -> int {
+      void *a_wsp = g->d_ws;
+      long done = 0;
+      if (g->has_w2 && lss == 1 && n >= 128 && !std::getenv("FDG_ISA_NO_W2")) {
+        long n2 = n & ~127l;
+        long nwg = std::min<long>(n2 / 128, grid2);
+        void *args[] = {(void *)&lf, &lss, &lls, (void *)&rt, &rrs, &rrk, &a_wsp, &n2, &nwg};
+        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_w2, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+        done = n2;
+      }
+      if (done < n) {
+        const double *lf1 = lf + done * lss;
+        double *rt1 = rt + done * rrs;
+        long n1 = n - done;
+        long nwg = std::min<long>((n1 + 63) / 64, grid);
+        void *args[] = {(void *)&lf1, &lss, &lls, (void *)&rt1, &rrs, &rrk, &a_wsp, &n1, &nwg};
+        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+      }
+      return FDG_OK;
+    };
     double *roots = d_root;
     long a_rs = rs, a_rk = rk;
     if (mode == 1) {
@@ -411,7 +439,6 @@ static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, 
       }
       roots = (double *)g->d_ws2; a_rs = R; a_rk = 1;
     }
-    void *a_ws = g->d_ws;
     if (ls == 1 && ss != 1 && p.L > 1) {
       // sample-major input (compile_Python's [B, L]): the ISA kernel wants a wave's 64 samples of
       // one leaf contiguous, so chunks of the batch are transposed to leaf-major first
@@ -457,17 +484,13 @@ static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, 
         }
         HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)g->ev_t[buf], 0));
         const double *c_leaf = (const double *)((char *)g->d_ws3 + (size_t)buf * one);
-        double *c_root = roots + c0 * a_rs;
-        long c_ss = 1, c_ls = Bc, c_B = n;
-        long c_nwg = std::min<long>((n + 63) / 64, grid);
-        void *args[] = {(void *)&c_leaf, &c_ss, &c_ls, (void *)&c_root, &a_rs, &a_rk, &a_ws, &c_B, &c_nwg};
-        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa, (unsigned)c_nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+        rc = launch_isa(c_leaf, 1, Bc, roots + c0 * a_rs, a_rs, a_rk, n);
+        if (rc) return rc;
         HIP_TRY(hipEventRecord((hipEvent_t)g->ev_k[buf], st));
       }
     } else {
-      long a_ss = ss, a_ls = ls, a_B = B, a_nwg = grid;
-      void *args[] = {(void *)&d_leaf, &a_ss, &a_ls, (void *)&roots, &a_rs, &a_rk, &a_ws, &a_B, &a_nwg};
-      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa, (unsigned)grid, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+      rc = launch_isa(d_leaf, (long)ss, (long)ls, roots, a_rs, a_rk, (long)B);
+      if (rc) return rc;
     }
     if (mode == 1) {
       double *partial = roots + (size_t)B * R;
@@ -744,8 +767,8 @@ static bool has_opt_params(const fdg_graph *g) {
 }
 
 static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags,
-                        std::vector<char> &co, std::string &hash) {
-  const std::string src = fdg::emit_isa(g->prog, prog, "fdg_isa_eval");
+                        std::vector<char> &co, std::string &hash, const fdg::OptProgram *prog2 = nullptr) {
+  const std::string src = fdg::emit_isa(g->prog, prog, "fdg_isa_eval", prog2);
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
   hash = hbuf;
@@ -771,11 +794,19 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
   return FDG_OK;
 }
 
-static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<char> &co, const std::string &hash, unsigned flags) {
+static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<char> &co, const std::string &hash, unsigned flags,
+                        const fdg::OptProgram *prog2 = nullptr) {
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
   g->code_object.swap(co);
   g->isa = true;
   g->fn_isa = nullptr;
+  g->fn_isa_w2 = nullptr;
+  g->has_w2 = prog2 != nullptr;
+  if (prog2) {
+    g->isa2_vgpr = ((6 + 4 * std::max<uint32_t>(prog2->n_reg_used, 1) + 3) & ~3u) + 4 * prog2->n_acc_used;
+    g->isa2_lds_bytes = prog2->n_lds_used * 1024u;
+    g->isa2_mem_slots = prog2->n_mem_used;
+  }
   g->isa_vgpr = ((6 + 2 * std::max<uint32_t>(prog.n_reg_used, 1) + 3) & ~3u) + 2 * prog.n_acc_used;
   g->isa_lds_bytes = prog.n_lds_used * 512u;
   g->isa_mem_slots = prog.n_mem_used;
@@ -821,6 +852,28 @@ static std::string tuned_path(const fdg_graph *g, const std::string &dir) {
   return dir + "/fdg_tuned_" + hb + ".txt";
 }
 
+// two samples per lane: a value is four VGPRs, so 60 of them fill the 2-waves-per-SIMD budget; T = tiny graphs
+static fdg::OptParams cfg_W2() { fdg::OptParams q; q.n_reg = 60; q.n_lds = 20; q.n_acc = 0; q.lookahead_leaf = 300; q.vn_window = 200; return q; }
+static fdg::OptParams cfg_W2T() { fdg::OptParams q; q.n_reg = 14; q.n_lds = 1; q.n_acc = 0; q.lookahead_leaf = 300; q.vn_window = 200; return q; }
+
+// The wide variant pays when the graph is HBM-bound: 16-byte accesses stream faster than 8-byte ones.
+// Static estimate: 8(L+R) bytes at 5 TB/s against the executed fold steps at 15 T op/s.
+static bool auto_program_w2(const fdg_graph *g, fdg::OptProgram &p2) {
+  // Measured on MI355X: the wide variant is SLOWER (sigma2 58 % vs 64 % of HBM peak, gv_sigma4 63 % vs
+  // 66 %), so it is opt-in (FDG_ISA_W2=1) and kept only as an experiment.
+  if (!std::getenv("FDG_ISA_W2")) return false;
+  const fdg::Lowered &p = g->prog;
+  fdg::build_opt_program(p, cfg_W2T(), p2);
+  bool ok = p2.supported && p2.n_ld_leaf <= p.n_live_leaf && p2.n_ld_lds + p2.n_st_lds + p2.n_ld_mem + p2.n_st_mem == 0;
+  if (!ok) {
+    fdg::build_opt_program(p, cfg_W2(), p2);
+    ok = p2.supported && p2.n_ld_mem + p2.n_st_mem == 0;
+  }
+  if (!ok) return false;
+  const double t_hbm = 8.0 * ((double)p.L + p.R) / 5e12, t_valu = (double)p2.n_valu / 15e12;
+  return t_hbm > 1.2 * t_valu;
+}
+
 // returns 1 when a remembered choice was installed, 0 when there is none, < 0 on error
 static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   const fdg::Lowered &p = g->prog;
@@ -833,10 +886,12 @@ static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   fdg::OptProgram prog;
   fdg::build_opt_program(p, q, prog);
   if (!prog.supported) return 0;
+  fdg::OptProgram p2;
+  const bool w2 = !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, p2);
   std::vector<char> co; std::string hash;
-  int rc = assemble_isa(g, prog, dir, flags, co, hash);
+  int rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr);
   if (rc) return rc;
-  install_isa(g, prog, co, hash, flags);
+  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr);
   return 1;
 }
 
@@ -903,10 +958,12 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   if (best < 0) { set_error("autotune: no candidate configuration ran"); return FDG_E_JIT; }
   fdg::OptProgram prog;
   fdg::build_opt_program(p, cand[best], prog);
+  fdg::OptProgram p2;
+  const bool w2 = !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, p2);
   std::vector<char> co; std::string hash;
-  rc = assemble_isa(g, prog, dir, flags, co, hash);
+  rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr);
   if (rc) return rc;
-  install_isa(g, prog, co, hash, flags);
+  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr);
   const std::string line = to_line(cand[best]) + "\n";
   write_file(tuned, line.c_str(), line.size());
   return FDG_OK;
@@ -926,10 +983,12 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
     auto_program(g, prog);
   }
   if (!prog.supported) { set_error("optimizing back end does not cover this graph: " + prog.why); return FDG_E_UNSUPPORTED; }
+  fdg::OptProgram p2;
+  const bool w2 = !has_opt_params(g) && !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, p2);
   std::vector<char> co; std::string hash;
-  int rc = assemble_isa(g, prog, dir, flags, co, hash);
+  int rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr);
   if (rc) return rc;
-  install_isa(g, prog, co, hash, flags);
+  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr);
   return FDG_OK;
 }
 
