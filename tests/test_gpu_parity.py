@@ -290,3 +290,17 @@ def test_leaf_values_on_device_and_full_mc_step(libfdg, cuda):
         capi.leaf_eval_device(z["leaf_type"], bad, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau, kF, beta, lam,
                               dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf.data_ptr(), leaf.stride(0), leaf.stride(1), B, st)
     assert e.value.code == capi.FDG_E_UNSUPPORTED
+
+
+def test_two_samples_per_lane_variant(libfdg, cuda, monkeypatch, tmp_path):
+    """The opt-in wide variant of the ISA kernel (FDG_ISA_W2=1; slower on MI355X): full
+    128-sample tiles through fdg_isa_eval_w2, the remainder through the 64-sample kernel."""
+    monkeypatch.setenv("FDG_ISA_W2", "1")
+    monkeypatch.setenv("FDG_IGNORE_TUNED", "1")
+    for name in ("sigma2", "gv_sigma4"):
+        t = workloads.get(name)
+        f = fd.compile_table(t, specialize="isa", cache_dir=str(tmp_path), flags=capi.FDG_SPEC_KEEP_SOURCE)
+        assert any("fdg_isa_eval_w2" in open(os.path.join(tmp_path, s)).read() for s in os.listdir(tmp_path) if s.endswith(".s"))
+        for B in (127, 128, 129, 1000, 70001):
+            leaf = dev_leaves(cuda, B, t.n_leaf, 8, 3, "leaf_major")
+            assert np.array_equal(run(f, leaf), oracle.eval_static(t, leaf.cpu().numpy())), (name, B)
