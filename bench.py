@@ -200,9 +200,17 @@ def cpu_baseline(t, leaf, root, budget_s):
         ref = cb(h, cores)
     dt = time.perf_counter() - t0
     got = root[:n].cpu().numpy()
+    # the interpreter the reference's examples actually call (IR.eval!, example/benchmark.jl:84-86):
+    # its arithmetic restated in oracle/fdg_oracle.c, one thread
+    ni = int(min(n, 2048))
+    t0 = time.perf_counter()
+    ri = oracle.eval_interp(t, h[:ni])
+    dti = max(time.perf_counter() - t0, 1e-9)
     return {"value": n * reps / dt, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": f"{reps} pass(es) over {n} samples of the same leaf batch, {dt:.2f} s on {cores} threads; reference's to_Cstr text compiled by gcc {opt} -ffp-contract=off (the Julia evaluator cannot run here)",
             "single_core_evals_per_s": rate1, "gcc_compile_s": cb.compile_seconds,
+            "eval_interp_single_core_evals_per_s": ni / dti,
+            "eval_interp_max_rel_dev_vs_compiled": float(np.max(np.abs(ri - ref[:ni]) / np.maximum(np.abs(ref[:ni]), 1e-300))),
             "gpu_matches_cpu_bitwise": bool(np.array_equal(got, ref)),
             "max_abs_dev": float(np.abs(got - ref).max())}
 
