@@ -304,3 +304,31 @@ def test_two_samples_per_lane_variant(libfdg, cuda, monkeypatch, tmp_path):
         for B in (127, 128, 129, 1000, 70001):
             leaf = dev_leaves(cuda, B, t.n_leaf, 8, 3, "leaf_major")
             assert np.array_equal(run(f, leaf), oracle.eval_static(t, leaf.cpu().numpy())), (name, B)
+
+
+def test_hip_graph_capture_and_replay(libfdg, cuda):
+    """After one warm-up call (workspace + module are allocated lazily) fdg_eval_device enqueues kernels
+    only, so a Monte-Carlo step (fill leaves -> evaluate) can be captured in a HIP graph and replayed:
+    what launch-bound inner loops with small batches want."""
+    import torch
+    t = workloads.get("gv_sigma4")
+    f = fd.compile_table(t, specialize="isa")
+    B = 4096
+    leaf = torch.zeros((t.n_leaf, B), dtype=torch.float64, device=cuda).t()
+    root = torch.zeros((B, t.n_root), dtype=torch.float64, device=cuda)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        capi.fill_uniform_device(leaf.data_ptr(), B, t.n_leaf, leaf.stride(0), leaf.stride(1), 1, 0, s.cuda_stream)
+        f(root, leaf)                                   # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    seed_offsets = [0]
+    with torch.cuda.graph(g, stream=s):
+        capi.fill_uniform_device(leaf.data_ptr(), B, t.n_leaf, leaf.stride(0), leaf.stride(1), 7, 1000, torch.cuda.current_stream().cuda_stream)
+        f(root, leaf)
+    for _ in range(3):
+        root.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        want = oracle.eval_static(t, oracle.philox_uniform(B, t.n_leaf, 7, 1000))
+        assert np.array_equal(root.cpu().numpy(), want)
