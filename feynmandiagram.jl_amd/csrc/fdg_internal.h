@@ -93,6 +93,10 @@ struct fdg_graph {
   bool has_w2 = false;
   void *fn_isa_w2 = nullptr;
   uint32_t isa2_vgpr = 0, isa2_lds_bytes = 0, isa2_mem_slots = 0;
+  // fused accumulate variant (per-lane accumulators in VGPRs, roots never written)
+  bool has_acc = false;
+  void *fn_isa_acc = nullptr;
+  uint32_t isa3_vgpr = 0, isa3_lds_bytes = 0, isa3_mem_slots = 0;
   void *d_ws2 = nullptr;           // roots scratch for accumulate through the ISA kernel
   size_t ws2_bytes = 0;
   void *d_ws3 = nullptr;           // leaf-major copy of a sample-major chunk for the ISA kernel

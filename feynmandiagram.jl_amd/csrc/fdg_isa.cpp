@@ -29,6 +29,7 @@ constexpr int V_LANE8 = 1, V_LEAFOFF = 2, V_ROOTOFF = 3, V_TMP = 4, V_BASE = 6;
 constexpr int S_LEAF = 4, S_SS = 6, S_LS = 8, S_ROOT = 10, S_RS = 12, S_RK = 14, S_WS = 16, S_B = 18, S_NWG = 20;
 constexpr int S_TILE = 22, S_NTILES = 23, S_LT = 24, S_RT = 26, S_PANEL = 28, S_LS8 = 30, S_RK8 = 32, S_A = 34,
               S_T = 36, S_C = 38, S_X = 40;  // S_X.. : scratch (4)
+constexpr int S_WGT = 44;
 constexpr int S_END = 48;
 
 struct Emit {
@@ -110,7 +111,7 @@ struct KernelMeta { std::string name; uint32_t lds_bytes, accum, n_agpr; };
 // tiles: a value is two doubles in four VGPRs, every memory access is 16 bytes per lane -- the
 // wide-access form HBM-bound graphs want; needs sample stride 1 and full tiles, the host runs the
 // remainder through the W = 1 kernel).
-static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog, const std::string &kname, int W) {
+static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog, const std::string &kname, int W, bool accumulate = false) {
   E.vm_issued = E.lg_issued = E.vm_done = E.lg_done = 0;
   E.pend.assign(std::max<uint32_t>(prog.n_reg_used, 1), {0, 0});
   const uint32_t SLOT = 512u * W;                 // bytes of one LDS / panel slot of a wave
@@ -140,7 +141,18 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_load_dwordx8 s[4:11], s[0:1], 0x0");
   E.ins("s_load_dwordx8 s[12:19], s[0:1], 0x20");
   E.ins("s_load_dwordx2 s[20:21], s[0:1], 0x40");
+  if (accumulate) E.ins("s_load_dwordx2 " + S2(S_WGT) + ", s[0:1], 0x48");
   E.ins("s_waitcnt lgkmcnt(0)");
+  // accumulate mode: R per-lane accumulators, the lane's weight and one temporary live above the value registers
+  uint64_t w_seq = 0;
+  const uint32_t acc0 = V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1);
+  auto vacc = [&](uint32_t k) { const uint32_t b = acc0 + 2 * k; return "v[" + std::to_string(b) + ":" + std::to_string(b + 1) + "]"; };
+  const std::string vwgt = vacc(p.R), vtmp = vacc(p.R + 1);
+  if (accumulate)
+    for (uint32_t k = 0; k < p.R; ++k) {
+      E.ins("v_mov_b32_e32 v" + std::to_string(acc0 + 2 * k) + ", 0");
+      E.ins("v_mov_b32_e32 v" + std::to_string(acc0 + 2 * k + 1) + ", 0");
+    }
   E.ins("v_lshlrev_b32_e32 " + V(V_LANE8) + ", " + std::to_string(W == 2 ? 4 : 3) + ", v0");      // lane * 8W
   E.ins("v_mul_lo_u32 " + V(V_LEAFOFF) + ", v0, " + S(S_SS));                                    // lane*ss (low 32 bits)
   E.ins("v_lshlrev_b32_e32 " + V(V_LEAFOFF) + ", " + std::to_string(W == 2 ? 4 : 3) + ", " + V(V_LEAFOFF));
@@ -160,7 +172,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_addc_u32 " + S(S_PANEL + 1) + ", " + S(S_WS + 1) + ", " + S(S_X + 1));
   E.ins("s_cmp_ge_u32 " + S(S_TILE) + ", " + S(S_NTILES));
   E.ins("s_cbranch_scc0 .Ltile" + sfx);
-  E.ins("s_endpgm");
+  E.ins("s_endpgm");   // (the host never launches more waves than tiles)
   os << ".Ltile" << sfx << ":\n";
   E.ins("s_mov_b32 " + S(S_X + 1) + ", 0");
   E.ins("s_mov_b32 " + S(S_X) + ", " + S(S_TILE));
@@ -187,7 +199,20 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("s_addc_u32 " + S(dst + 1) + ", " + S(base + 1) + ", " + S(S_A + 1));
   };
   tile_base(S_LT, S_LEAF, S_SS);
-  tile_base(S_RT, S_ROOT, S_RS);
+  if (!accumulate) tile_base(S_RT, S_ROOT, S_RS);
+  if (accumulate) {
+    // w = weight ? weight[b0 + lane] : 1.0   (consumed at the first root, long after this load)
+    E.ins("v_mov_b32_e32 v" + std::to_string(acc0 + 2 * p.R) + ", 0");
+    E.ins("v_mov_b32_e32 v" + std::to_string(acc0 + 2 * p.R + 1) + ", 0x3ff00000");
+    E.ins("s_cmp_eq_u64 " + S2(S_WGT) + ", 0");
+    E.ins("s_cbranch_scc1 .Lnow" + sfx);
+    E.ins("s_lshl_b64 " + S2(S_A) + ", " + S2(S_X) + ", 3");
+    E.ins("s_add_u32 " + S(S_A) + ", " + S(S_A) + ", " + S(S_WGT));
+    E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_A + 1) + ", " + S(S_WGT + 1));
+    E.ins("global_load_dwordx2 " + vwgt + ", " + V(V_LANE8) + ", " + S2(S_A));
+    os << ".Lnow" << sfx << ":\n";
+    w_seq = ++E.vm_issued;     // counted on both paths: a phantom older op only makes later waits conservative
+  }
 
   auto panel_operand = [&](uint32_t slot) -> std::string {
     const uint64_t byte = (uint64_t)slot * SLOT;
@@ -272,6 +297,16 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         break;
       case M_ROOT: {
         E.wait_reg(o.a);
+        if (accumulate) {   // acc_k = acc_k + w * root_k
+          if (w_seq > E.vm_done) {
+            const uint64_t n = std::min<uint64_t>(E.vm_issued - w_seq, 63);
+            E.ins("s_waitcnt vmcnt(" + std::to_string(n) + ")");
+            E.vm_done = std::max(E.vm_done, std::max(E.vm_issued - n, w_seq));
+          }
+          E.ins("v_mul_f64 " + vtmp + ", " + vwgt + ", " + (o.nega ? "-" : "") + vlo(o.a));
+          E.ins("v_add_f64 " + vacc(o.d) + ", " + vacc(o.d) + ", " + vtmp);
+          break;
+        }
         emit_scaled_addr(E, S_A, S_RT, S_RK8, o.d);
         for (int h = 0; h < W; ++h) {
           const int src = V_BASE + RW * o.a + 2 * h;
@@ -304,6 +339,33 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", " + S(S_NWG));
   E.ins("s_cmp_ge_u32 " + S(S_TILE) + ", " + S(S_NTILES));
   E.ins("s_cbranch_scc0 .Lback" + sfx);
+  if (accumulate) {
+    // butterfly sum over the 64 lanes (IEEE addition commutes, so every lane ends with the same bits),
+    // then partial[k][wg] = lane 0's value; fdg_reduce_lane_partials adds the waves in fixed order
+    E.ins("s_mov_b64 exec, -1");
+    E.ins("v_lshlrev_b32_e32 " + V(V_TMP) + ", 2, v0");
+    for (int off = 32; off >= 1; off >>= 1) {
+      E.ins("v_xor_b32_e32 " + V(V_TMP + 1) + ", " + std::to_string(off * 4) + ", " + V(V_TMP));
+      for (uint32_t k = 0; k < p.R; ++k) {
+        const uint32_t a = acc0 + 2 * k, t = acc0 + 2 * (p.R + 1);
+        E.ins("ds_bpermute_b32 v" + std::to_string(t) + ", " + V(V_TMP + 1) + ", v" + std::to_string(a));
+        E.ins("ds_bpermute_b32 v" + std::to_string(t + 1) + ", " + V(V_TMP + 1) + ", v" + std::to_string(a + 1));
+        E.ins("s_waitcnt lgkmcnt(0)");
+        E.ins("v_add_f64 " + vacc(k) + ", " + vacc(k) + ", " + vtmp);
+      }
+    }
+    E.ins("s_mov_b64 exec, 1");
+    E.ins("v_mov_b32_e32 " + V(V_TMP) + ", 0");
+    E.ins("s_lshl_b32 " + S(S_X) + ", s2, 3");
+    E.ins("s_add_u32 " + S(S_A) + ", " + S(S_ROOT) + ", " + S(S_X));
+    E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_ROOT + 1) + ", 0");
+    E.ins("s_lshl_b32 " + S(S_T) + ", " + S(S_NWG) + ", 3");
+    for (uint32_t k = 0; k < p.R; ++k) {
+      E.ins("global_store_dwordx2 " + V(V_TMP) + ", " + vacc(k) + ", " + S2(S_A));
+      E.ins("s_add_u32 " + S(S_A) + ", " + S(S_A) + ", " + S(S_T));
+      E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_A + 1) + ", 0");
+    }
+  }
   E.ins("s_endpgm");
   // long backward jump (the body may exceed the 16-bit branch range)
   os << ".Lback" << sfx << ":\n";
@@ -315,12 +377,12 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_endpgm");
 
   // ---- kernel descriptor -------------------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1), 8);
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
   const uint32_t n_agpr = RW * prog.n_acc_used;
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
   os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";
-  os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size 72\n\t\t.amdhsa_user_sgpr_count 2\n";
+  os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size 80\n\t\t.amdhsa_user_sgpr_count 2\n";
   os << "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1\n\t\t.amdhsa_system_sgpr_workgroup_id_x 1\n";
   os << "\t\t.amdhsa_system_vgpr_workitem_id 0\n";
   os << "\t\t.amdhsa_next_free_vgpr " << (accum + n_agpr) << "\n\t\t.amdhsa_next_free_sgpr " << S_END << "\n";
@@ -337,23 +399,25 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
 
 // One code object: the W = 1 kernel `kname`, and, when prog2 is given, the two-samples-per-lane kernel
 // `kname`_w2 next to it.
-std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2) {
+std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2,
+                     const OptProgram *prog_acc) {
   Emit E;
   E.os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n";
   std::vector<KernelMeta> ks;
   ks.push_back(emit_kernel(E, p, prog, kname, 1));
   if (prog2) ks.push_back(emit_kernel(E, p, *prog2, kname + "_w2", 2));
+  if (prog_acc) ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc", 1, true));
   std::ostringstream &os = E.os;
   os << "\t.text\n\t.amdgpu_metadata\n---\namdhsa.kernels:\n";
-  const char *kinds[9] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",
-                          "global_buffer", "by_value", "by_value"};
+  const char *kinds[10] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",
+                           "global_buffer", "by_value", "by_value", "global_buffer"};
   for (const KernelMeta &k : ks) {
     os << "  - .agpr_count: " << k.n_agpr << "\n    .args:\n";
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < 10; ++i) {
       os << "      - .offset: " << i * 8 << "\n        .size: 8\n        .value_kind: " << kinds[i] << "\n";
       if (std::strcmp(kinds[i], "global_buffer") == 0) os << "        .address_space: global\n";
     }
-    os << "    .group_segment_fixed_size: " << k.lds_bytes << "\n    .kernarg_segment_align: 8\n    .kernarg_segment_size: 72\n";
+    os << "    .group_segment_fixed_size: " << k.lds_bytes << "\n    .kernarg_segment_align: 8\n    .kernarg_segment_size: 80\n";
     os << "    .max_flat_workgroup_size: 64\n    .name: " << k.name << "\n    .private_segment_fixed_size: 0\n";
     os << "    .sgpr_count: " << (S_END + 6) << "\n    .sgpr_spill_count: 0\n    .symbol: " << k.name << ".kd\n";
     os << "    .uniform_work_group_size: 1\n    .uses_dynamic_stack: false\n    .vgpr_count: " << (k.accum + k.n_agpr)

@@ -62,6 +62,7 @@ struct OptProgram {
 };
 
 void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out);
-std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2 = nullptr);
+std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2 = nullptr,
+                     const OptProgram *prog_acc = nullptr);
 
 }  // namespace fdg

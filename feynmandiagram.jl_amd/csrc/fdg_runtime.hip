@@ -176,6 +176,18 @@ __global__ void fdg_reduce_partials(const double *__restrict__ partial, uint32_t
   }
 }
 
+// acc[k] += sum over waves of partial[k][wave], fixed order (one block per root)
+__global__ void __launch_bounds__(256)
+fdg_reduce_lane_partials(const double *__restrict__ partial, uint32_t nwave, uint32_t R, double *__restrict__ acc) {
+  __shared__ double sh[256];
+  for (uint32_t k = blockIdx.x; k < R; k += gridDim.x) {
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < nwave; i += 256) s = s + partial[(size_t)k * nwave + i];
+    s = fdg_block_sum256(s, sh);
+    if (threadIdx.x == 0) acc[k] = acc[k] + s;
+  }
+}
+
 // partial[blk][k] = sum over the block's samples of w[b] * root[b][k]  (row-major roots)
 __global__ void __launch_bounds__(256)
 fdg_weighted_partials(const double *__restrict__ root, const double *__restrict__ weight, long B, uint32_t R,
@@ -349,6 +361,7 @@ static int ensure_module(fdg_graph *g) {
     HIP_TRY(hipModuleGetFunction(&f, m, "fdg_isa_eval"));
     g->module = m; g->fn_isa = f;
     if (g->has_w2) { hipFunction_t f2; HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_isa_eval_w2")); g->fn_isa_w2 = f2; }
+    if (g->has_acc) { hipFunction_t f3; HIP_TRY(hipModuleGetFunction(&f3, m, "fdg_isa_eval_acc")); g->fn_isa_acc = f3; }
     return FDG_OK;
   }
   hipFunction_t f1, f2;
@@ -404,8 +417,23 @@ static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, 
     const long grid2 = g->has_w2 ? (long)g->n_cu * waves_per_cu(g->isa2_vgpr, g->isa2_lds_bytes) : 0;
     const size_t panel = std::max((size_t)std::max<uint32_t>(g->isa_mem_slots, 1) * 512u * (size_t)grid,
                                   (size_t)std::max<uint32_t>(g->isa2_mem_slots, 1) * 1024u * (size_t)grid2);
-    rc = ensure_ws(g, panel + 4096);
+    const bool fused_acc = mode == 1 && g->has_acc && !std::getenv("FDG_ISA_NO_FUSED_ACC");
+    const long grid3 = g->has_acc ? (long)g->n_cu * waves_per_cu(g->isa3_vgpr, g->isa3_lds_bytes) : 0;
+    const size_t panel3 = (size_t)std::max<uint32_t>(g->isa3_mem_slots, 1) * 512u * (size_t)grid3;
+    const size_t panel_all = (std::max(panel, panel3) + 4095) & ~(size_t)4095;
+    rc = ensure_ws(g, panel_all + (size_t)grid3 * R * 512u + 4096);
     if (rc) return rc;
+    // fused accumulation: acc[k] += sum_b w_b root_k(b) with per-lane accumulators inside the evaluator
+    auto launch_acc = [&](const double *lf, long lss, long lls, const double *wt, long n) -> int {
+      void *a_wsp = g->d_ws;
+      double *part = (double *)((char *)g->d_ws + panel_all);
+      long nwg = std::min<long>((n + 63) / 64, grid3), zero = 0;
+      void *args[] = {(void *)&lf, &lss, &lls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+      hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
+      HIP_TRY(hipGetLastError());
+      return FDG_OK;
+    };
     // one batch with sample stride `lss`: full 128-sample tiles through the two-samples-per-lane kernel
     // when there is one and the samples of a leaf are contiguous, the rest through the W = 1 kernel
     auto launch_isa = [&](const double *lf, long lss, long lls, double *rt, long rrs, long rrk, long n) -> int {
@@ -414,7 +442,8 @@ static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, 
       if (g->has_w2 && lss == 1 && n >= 128 && !std::getenv("FDG_ISA_NO_W2")) {
         long n2 = n & ~127l;
         long nwg = std::min<long>(n2 / 128, grid2);
-        void *args[] = {(void *)&lf, &lss, &lls, (void *)&rt, &rrs, &rrk, &a_wsp, &n2, &nwg};
+        const double *nowt = nullptr;
+        void *args[] = {(void *)&lf, &lss, &lls, (void *)&rt, &rrs, &rrk, &a_wsp, &n2, &nwg, (void *)&nowt};
         HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_w2, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
         done = n2;
       }
@@ -423,14 +452,15 @@ static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, 
         double *rt1 = rt + done * rrs;
         long n1 = n - done;
         long nwg = std::min<long>((n1 + 63) / 64, grid);
-        void *args[] = {(void *)&lf1, &lss, &lls, (void *)&rt1, &rrs, &rrk, &a_wsp, &n1, &nwg};
+        const double *nowt = nullptr;
+        void *args[] = {(void *)&lf1, &lss, &lls, (void *)&rt1, &rrs, &rrk, &a_wsp, &n1, &nwg, (void *)&nowt};
         HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
       }
       return FDG_OK;
     };
     double *roots = d_root;
     long a_rs = rs, a_rk = rk;
-    if (mode == 1) {
+    if (mode == 1 && !fused_acc) {
       const size_t need = (size_t)B * std::max<uint32_t>(R, 1) * sizeof(double) + (size_t)2048 * R * sizeof(double);
       if (g->ws2_bytes < need) {
         if (g->d_ws2) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws2)); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
@@ -484,15 +514,17 @@ static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, 
         }
         HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)g->ev_t[buf], 0));
         const double *c_leaf = (const double *)((char *)g->d_ws3 + (size_t)buf * one);
-        rc = launch_isa(c_leaf, 1, Bc, roots + c0 * a_rs, a_rs, a_rk, n);
+        rc = fused_acc ? launch_acc(c_leaf, 1, Bc, d_weight ? d_weight + c0 : nullptr, n)
+                       : launch_isa(c_leaf, 1, Bc, roots + c0 * a_rs, a_rs, a_rk, n);
         if (rc) return rc;
         HIP_TRY(hipEventRecord((hipEvent_t)g->ev_k[buf], st));
       }
     } else {
-      rc = launch_isa(d_leaf, (long)ss, (long)ls, roots, a_rs, a_rk, (long)B);
+      rc = fused_acc ? launch_acc(d_leaf, (long)ss, (long)ls, d_weight, (long)B)
+                     : launch_isa(d_leaf, (long)ss, (long)ls, roots, a_rs, a_rk, (long)B);
       if (rc) return rc;
     }
-    if (mode == 1) {
+    if (mode == 1 && !fused_acc) {
       double *partial = roots + (size_t)B * R;
       const uint32_t pb = (uint32_t)std::min<long>(2048, nblk);
       hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb), dim3(256), 0, st, roots, d_weight, (long)B, R, partial);
@@ -767,8 +799,9 @@ static bool has_opt_params(const fdg_graph *g) {
 }
 
 static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags,
-                        std::vector<char> &co, std::string &hash, const fdg::OptProgram *prog2 = nullptr) {
-  const std::string src = fdg::emit_isa(g->prog, prog, "fdg_isa_eval", prog2);
+                        std::vector<char> &co, std::string &hash, const fdg::OptProgram *prog2 = nullptr,
+                        const fdg::OptProgram *prog_acc = nullptr) {
+  const std::string src = fdg::emit_isa(g->prog, prog, "fdg_isa_eval", prog2, prog_acc);
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
   hash = hbuf;
@@ -795,12 +828,19 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
 }
 
 static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<char> &co, const std::string &hash, unsigned flags,
-                        const fdg::OptProgram *prog2 = nullptr) {
+                        const fdg::OptProgram *prog2 = nullptr, const fdg::OptProgram *prog_acc = nullptr) {
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
   g->code_object.swap(co);
   g->isa = true;
   g->fn_isa = nullptr;
   g->fn_isa_w2 = nullptr;
+  g->fn_isa_acc = nullptr;
+  g->has_acc = prog_acc != nullptr;
+  if (prog_acc) {
+    g->isa3_vgpr = ((6 + 2 * std::max<uint32_t>(prog_acc->n_reg_used, 1) + 2 * (g->prog.R + 2) + 3) & ~3u) + 2 * prog_acc->n_acc_used;
+    g->isa3_lds_bytes = prog_acc->n_lds_used * 512u;
+    g->isa3_mem_slots = prog_acc->n_mem_used;
+  }
   g->has_w2 = prog2 != nullptr;
   if (prog2) {
     g->isa2_vgpr = ((6 + 4 * std::max<uint32_t>(prog2->n_reg_used, 1) + 3) & ~3u) + 4 * prog2->n_acc_used;
@@ -822,17 +862,18 @@ static fdg::OptParams cfg_B() {
   fdg::OptParams B; B.n_reg = 120; B.n_lds = 80; B.n_acc = 124; B.lookahead_leaf = 100; B.lookahead_mem = 64; B.vn_window = 1000; return B;
 }
 
-static void auto_program(const fdg_graph *g, fdg::OptProgram &prog) {
+static fdg::OptParams auto_program(const fdg_graph *g, fdg::OptProgram &prog) {
   fdg::OptProgram ps;
   fdg::build_opt_program(g->prog, cfg_S(), ps);
   const bool small_ok = ps.supported && ps.n_ld_leaf <= g->prog.n_live_leaf && ps.n_ld_lds + ps.n_st_lds + ps.n_ld_mem + ps.n_st_mem == 0;
-  if (small_ok) { prog = std::move(ps); return; }
+  if (small_ok) { prog = std::move(ps); return cfg_S(); }
   fdg::build_opt_program(g->prog, cfg_A(), prog);
   if (prog.supported && (prog.n_ld_mem + prog.n_st_mem) * 100 > prog.n_valu) {   // > 1 % of the ops touch the HBM panel
     fdg::OptProgram pb;
     fdg::build_opt_program(g->prog, cfg_B(), pb);
-    if (pb.supported) prog = std::move(pb);
+    if (pb.supported) { prog = std::move(pb); return cfg_B(); }
   }
+  return cfg_A();
 }
 
 // On-device selection among a handful of configurations: each candidate is assembled, run on a
@@ -874,6 +915,24 @@ static bool auto_program_w2(const fdg_graph *g, fdg::OptProgram &p2) {
   return t_hbm > 1.2 * t_valu;
 }
 
+// The fused-accumulate kernel keeps R accumulators, the weight and a temporary in VGPR pairs above
+// the values, so its program is allocated with that many fewer registers (same configuration otherwise).
+static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, fdg::OptProgram &pa) {
+  const uint32_t extra = g->prog.R + 2;
+  if (g->prog.R == 0 || g->prog.R > 16 || chosen.n_reg < extra + 8 || std::getenv("FDG_ISA_NO_FUSED_ACC")) return false;
+  fdg::OptParams q = chosen;
+  // stay inside the occupancy step of the eval kernel (VGPRs per wave: 64 -> 8 waves/SIMD ... 256 -> 2, 512 -> 1)
+  static const uint32_t steps[] = {64, 72, 80, 96, 128, 168, 256, 512};
+  const uint32_t v0 = ((6 + 2 * chosen.n_reg + 3) & ~3u) + 2 * chosen.n_acc;
+  uint32_t budget = 512;
+  for (uint32_t st : steps) if (st >= v0) { budget = st; break; }
+  const uint32_t arch = std::min<uint32_t>(budget - 2 * chosen.n_acc, 256);   // architectural VGPRs end at v255
+  if (arch < 6 + 2 * extra + 16) return false;
+  q.n_reg = std::min<uint32_t>(chosen.n_reg, (arch - 6 - 2 * extra) / 2);
+  fdg::build_opt_program(g->prog, q, pa);
+  return pa.supported;
+}
+
 // returns 1 when a remembered choice was installed, 0 when there is none, < 0 on error
 static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   const fdg::Lowered &p = g->prog;
@@ -886,12 +945,13 @@ static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   fdg::OptProgram prog;
   fdg::build_opt_program(p, q, prog);
   if (!prog.supported) return 0;
-  fdg::OptProgram p2;
+  fdg::OptProgram p2, pa;
   const bool w2 = !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, p2);
+  const bool acc = build_acc_program(g, q, pa);
   std::vector<char> co; std::string hash;
-  int rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr);
+  int rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
   if (rc) return rc;
-  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr);
+  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
   return 1;
 }
 
@@ -958,12 +1018,13 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   if (best < 0) { set_error("autotune: no candidate configuration ran"); return FDG_E_JIT; }
   fdg::OptProgram prog;
   fdg::build_opt_program(p, cand[best], prog);
-  fdg::OptProgram p2;
+  fdg::OptProgram p2, pa;
   const bool w2 = !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, p2);
+  const bool acc = build_acc_program(g, cand[best], pa);
   std::vector<char> co; std::string hash;
-  rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr);
+  rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
   if (rc) return rc;
-  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr);
+  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
   const std::string line = to_line(cand[best]) + "\n";
   write_file(tuned, line.c_str(), line.size());
   return FDG_OK;
@@ -976,19 +1037,22 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
     if (flags & FDG_SPEC_AUTOTUNE) return autotune_isa(g, dir, flags);
   }
   fdg::OptProgram prog;
+  fdg::OptParams chosen;
   if (has_opt_params(g)) {
     const fdg_opt_params q = get_opt_params(g);
-    fdg::build_opt_program(g->prog, to_params(&q), prog);
+    chosen = to_params(&q);
+    fdg::build_opt_program(g->prog, chosen, prog);
   } else {
-    auto_program(g, prog);
+    chosen = auto_program(g, prog);
   }
   if (!prog.supported) { set_error("optimizing back end does not cover this graph: " + prog.why); return FDG_E_UNSUPPORTED; }
-  fdg::OptProgram p2;
+  fdg::OptProgram p2, pa;
   const bool w2 = !has_opt_params(g) && !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, p2);
+  const bool acc = build_acc_program(g, chosen, pa);
   std::vector<char> co; std::string hash;
-  int rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr);
+  int rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
   if (rc) return rc;
-  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr);
+  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
   return FDG_OK;
 }
 

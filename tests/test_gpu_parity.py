@@ -162,6 +162,34 @@ def test_accumulate(libfdg, cuda, spec):
         assert np.all(np.abs(acc2.cpu().numpy() - 2 * want) <= 2 * TOL * np.maximum(1.0, scale))
 
 
+@pytest.mark.parametrize("name,B,layout", [("gv_sigma4_taylor2", 300_007, "leaf_major"), ("gv_sigma4", 100_000, "sample_major"),
+                                           ("sigma4_standin", 20_011, "leaf_major")])
+def test_fused_accumulate_isa(libfdg, cuda, name, B, layout, monkeypatch):
+    """The optimizing back end sums w_b * root_k(b) in registers (per-lane partials, one store per wave at the
+    end) instead of writing roots.  Same roots bit for bit; only the order of the sum over samples differs from
+    the oracle, hence 1e-12 * sum|w root|.  Compared too with the unfused path (roots -> weighted partials)."""
+    import torch
+    t = workloads.get(name)
+    f = fd.compile_table(t, specialize="isa")
+    leaf = dev_leaves(cuda, B, t.n_leaf, 5, 0, layout)
+    w = torch.rand(B, dtype=torch.float64, device=cuda) - 0.25
+    acc = f.accumulate(leaf, w)
+    acc_again = f.accumulate(leaf, w)
+    acc1 = f.accumulate(leaf, None)
+    torch.cuda.synchronize()
+    assert torch.equal(acc, acc_again)
+    ref = oracle.eval_static(t, leaf.cpu().numpy())
+    wn = w.cpu().numpy()[:, None]
+    scale = np.maximum(1.0, np.abs(ref * wn).sum(0))
+    assert np.all(np.abs(acc.cpu().numpy() - (ref * wn).sum(0)) <= TOL * scale)
+    assert np.all(np.abs(acc1.cpu().numpy() - ref.sum(0)) <= TOL * np.maximum(1.0, np.abs(ref).sum(0)))
+    monkeypatch.setenv("FDG_ISA_NO_FUSED_ACC", "1")
+    f2 = fd.compile_table(t, specialize="isa")
+    acc_unfused = f2.accumulate(leaf, w)
+    torch.cuda.synchronize()
+    assert np.all(np.abs((acc - acc_unfused).cpu().numpy()) <= TOL * scale)
+
+
 def test_config2_sigma2_ten_million_samples(libfdg, cuda):
     """BASELINE.json config 2: 2-loop sigma, fp64, 10^7 samples, compared with the
     CPU reference within 1e-12 (scaled); we additionally require 0 ulp."""
