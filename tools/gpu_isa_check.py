@@ -29,7 +29,7 @@ for name in names:
     t = table(name)
     st = t.stats()
     for layout in (() if timeonly else ("leaf_major", "sample_major")):
-        for B in (1, 63, 64, 1000, 20000):
+        for B in (1, 63, 64, 1000, 20000) + ((600_007,) if layout == 'leaf_major' else ()):   # the last: several tiles per persistent wave
             f = fd.compile_table(t, **spec_kw)
             leaf = leaves(B, t.n_leaf, layout)
             root = torch.full((B, t.n_root), -3.0, dtype=torch.float64, device=dev)
