@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--backend", default="isa", choices=["isa", "isa-autotune", "hip", "interp"],
                     help="isa: optimizing back end, gfx950 assembly; hip: straight-line HIP source via hiprtc; interp: table interpreter")
     ap.add_argument("--interp", action="store_true", help="same as --backend interp")
+    ap.add_argument("--comm", default="torch", choices=["torch", "fdg"],
+                    help="who runs the one reduction of the observable: torch.distributed (nccl == RCCL) or libfdg's fdg_comm_* (RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
@@ -44,7 +46,7 @@ def main():
     import torch
     import feynmandiagram_jl_amd as fd
     from feynmandiagram_jl_amd import capi, workloads
-    from feynmandiagram_jl_amd.sharding import reduce_observable, shard_range
+    from feynmandiagram_jl_amd.sharding import make_comm, reduce_observable, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -58,6 +60,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm = make_comm(rank, world) if (dist and args.comm == "fdg") else None
 
     t = workloads.get(args.workload)
     st = t.stats()
@@ -100,7 +103,7 @@ def main():
         step()
         ev[i + 1].record(stream)          # same stream the kernel is launched on
     acc = root.sum(dim=0)                 # final observable accumulation
-    reduce_observable(acc)                # the one collective: R doubles over xGMI (RCCL)
+    reduce_observable(acc, comm=comm)     # the one collective: R doubles over xGMI (RCCL)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

@@ -29,7 +29,9 @@ EXPORTS = [
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
     "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_graph_release_device", "fdg_powi",
     "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
+    "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
 ]
+COMM_ID_BYTES = 128
 
 
 class FdgLibraryMissing(ImportError):
@@ -125,6 +127,10 @@ def lib():
     L.fdg_graph_set_opt_params.argtypes = [vp, C.POINTER(OptParams)]
     L.fdg_graph_opt_program.argtypes = [vp, C.POINTER(OptParams), C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64),
                                         C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.fdg_comm_unique_id.argtypes = [C.c_void_p, C.c_size_t]
+    L.fdg_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(vp)]
+    L.fdg_comm_destroy.argtypes = [vp]
+    L.fdg_reduce_device.argtypes = [vp, dp, u32, C.c_int, vp]
     L.fdg_powi.argtypes = [C.c_double, C.c_int32]
     L.fdg_powi.restype = C.c_double
     _lib = L
@@ -249,6 +255,40 @@ def fill_uniform_device(d_leaf: int, B: int, L: int, ss: int, ls: int, seed: int
 
 def powi(x: float, n: int) -> float:
     return float(lib().fdg_powi(x, n))
+
+
+class Comm:
+    """One RCCL communicator per process/GPU for the single reduction of the observable (fdg.h, multi-GPU).
+    ``Comm.unique_id()`` on rank 0, ship the 128 bytes to the other ranks, ``Comm(id, rank, world)`` everywhere
+    (with the rank's device current), then ``reduce(d_acc_ptr, n)``."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % COMM_ID_BYTES)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        check(lib().fdg_comm_create(buf, rank, world, C.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        check(lib().fdg_comm_unique_id(buf, COMM_ID_BYTES))
+        return buf.raw
+
+    def reduce(self, d_acc: int, n: int, root: int = -1, stream: int = 0):
+        check(lib().fdg_reduce_device(self._h, d_acc, n, root, stream))
+
+    def close(self):
+        if self._h:
+            lib().fdg_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def leaf_eval_device(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, dim, n_tau, kF, beta, lam,

@@ -24,10 +24,27 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return start, base + (1 if rank < rem else 0)
 
 
-def reduce_observable(acc, group=None):
-    """In-place sum of the per-rank accumulators over all ranks (no-op when
-    torch.distributed is not initialised)."""
+def make_comm(rank: int, world: int, group=None):
+    """The C-ABI communicator (``fdg_comm_*``: RCCL bound inside libfdg.so) for callers that want the
+    reduction without torch in the data path.  The 128-byte id travels over the already initialised
+    ``torch.distributed`` group (any backend); a Julia or C host would use MPI or a file instead."""
     import torch.distributed as dist
+    from . import capi
+    box = [capi.Comm.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    return capi.Comm(box[0], rank, world)
+
+
+def reduce_observable(acc, group=None, comm=None):
+    """In-place sum of the per-rank accumulators over all ranks (no-op when
+    torch.distributed is not initialised).  With ``comm`` (see make_comm) the sum
+    goes through ``fdg_reduce_device`` on the current stream instead."""
+    import torch.distributed as dist
+    if comm is not None:
+        import torch
+        comm.reduce(acc.data_ptr(), acc.numel(), -1, torch.cuda.current_stream(acc.device).cuda_stream)
+        return acc
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     return acc

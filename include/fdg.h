@@ -231,6 +231,26 @@ int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t 
  * resident waves.  This releases it (and any loaded module). */
 int fdg_graph_release_device(fdg_graph *g);
 
+/* ---- multi-GPU -------------------------------------------------
+ * Samples are sharded over one process per GPU (rank r of G evaluates the r-th
+ * contiguous range, Philox counters = global sample index); each rank runs
+ * fdg_accumulate_device into its own acc[R]; ONE collective of R doubles -- RCCL
+ * over xGMI -- adds the ranks' partial sums.  No data-path collective exists.
+ * The reference has no counterpart (example/benchmark*.jl are single-process).
+ * RCCL is bound at run time; without it these calls return FDG_E_NO_DEVICE and
+ * everything else keeps working.
+ *   rank 0: fdg_comm_unique_id(id) -> ship the 128 bytes to the other ranks by any
+ *   means (MPI, a file, torch.distributed) -> every rank, with its device current:
+ *   fdg_comm_create(id, rank, world, &c) -> ... fdg_reduce_device(c, d_acc, R, -1, stream). */
+#define FDG_COMM_ID_BYTES 128
+typedef struct fdg_comm fdg_comm;
+int fdg_comm_unique_id(void *id, size_t bytes);
+int fdg_comm_create(const void *id, int rank, int world, fdg_comm **out);
+int fdg_comm_destroy(fdg_comm *c);
+/* d_acc[0..n) <- sum over ranks, in place, on `stream`.  root < 0: every rank gets
+ * the sum (all-reduce); else only rank `root` (reduce). */
+int fdg_reduce_device(fdg_comm *c, double *d_acc, uint32_t n, int root, void *stream);
+
 /* Integer power used for Power{N}, |N| >= 4 (and N < 0): exposed so host-side
  * checkers can call the very same routine.  Pure host function. */
 double fdg_powi(double x, int32_t n);

@@ -360,3 +360,29 @@ def test_hip_graph_capture_and_replay(libfdg, cuda):
         torch.cuda.synchronize()
         want = oracle.eval_static(t, oracle.philox_uniform(B, t.n_leaf, 7, 1000))
         assert np.array_equal(root.cpu().numpy(), want)
+
+
+def test_c_abi_communicator_world_one(libfdg, cuda):
+    """fdg_comm_* / fdg_reduce_device (RCCL bound at run time inside libfdg.so): with one rank the sum over
+    ranks is the identity, for the all-reduce and the rooted form; the N > 1 logic is the gloo test's."""
+    import torch
+    from feynmandiagram_jl_amd.sharding import make_comm, reduce_observable
+    ident = capi.Comm.unique_id()
+    assert len(ident) == capi.COMM_ID_BYTES
+    with torch.cuda.device(cuda):
+        c = capi.Comm(ident, 0, 1)
+        acc = torch.arange(6, dtype=torch.float64, device=cuda) * 0.37 - 1.0
+        want = acc.clone()
+        st = torch.cuda.current_stream().cuda_stream
+        c.reduce(acc.data_ptr(), acc.numel(), -1, st)
+        c.reduce(acc.data_ptr(), acc.numel(), 0, st)
+        torch.cuda.synchronize()
+        assert torch.equal(acc, want)
+        with pytest.raises(capi.FdgError):
+            c.reduce(acc.data_ptr(), acc.numel(), 3, st)
+        c.close()
+        c2 = make_comm(0, 1)
+        reduce_observable(acc, comm=c2)
+        torch.cuda.synchronize()
+        assert torch.equal(acc, want)
+        c2.close()
