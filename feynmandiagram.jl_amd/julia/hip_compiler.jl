@@ -196,3 +196,34 @@ function accumulate_device!(f::GraphFunc, d_acc::Ptr{Float64}, d_leaf::Ptr{Float
 end
 
 export compile_hip, GraphFunc, eval_device!, accumulate_device!
+
+# ---- multi-GPU: one Julia process per GPU, ONE reduction of the accumulated observable ------------ #
+# (include/fdg.h, "multi-GPU").  Rank 0 calls `comm_unique_id()` and ships the 128 bytes to the other
+# ranks (MPI.jl `MPI.bcast`, a shared file, ...); every rank then builds its communicator with its own
+# device current and, after its share of `accumulate_device!` calls, reduces `d_acc` in place.
+const FDG_COMM_ID_BYTES = 128
+
+function comm_unique_id()
+    id = Vector{UInt8}(undef, FDG_COMM_ID_BYTES)
+    _fdg_check(ccall((:fdg_comm_unique_id, _libfdg), Cint, (Ptr{UInt8}, Csize_t), id, FDG_COMM_ID_BYTES))
+    return id
+end
+
+mutable struct Comm
+    handle::Ptr{Cvoid}
+    function Comm(id::Vector{UInt8}, rank::Integer, world::Integer)
+        length(id) == FDG_COMM_ID_BYTES || error("unique id must be $FDG_COMM_ID_BYTES bytes")
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        _fdg_check(ccall((:fdg_comm_create, _libfdg), Cint, (Ptr{UInt8}, Cint, Cint, Ref{Ptr{Cvoid}}), id, rank, world, h))
+        c = new(h[])
+        finalizer(x -> ccall((:fdg_comm_destroy, _libfdg), Cint, (Ptr{Cvoid},), x.handle), c)
+        return c
+    end
+end
+
+"""`d_acc[1:n]` <- sum over ranks (all ranks get it; `root >= 0`: only that rank), on `stream`."""
+function reduce_device!(c::Comm, d_acc::Ptr{Float64}, n::Integer; root::Integer=-1, stream::Ptr{Cvoid}=C_NULL)
+    _fdg_check(ccall((:fdg_reduce_device, _libfdg), Cint, (Ptr{Cvoid}, Ptr{Float64}, UInt32, Cint, Ptr{Cvoid}),
+                     c.handle, d_acc, UInt32(n), Cint(root), stream))
+    return nothing
+end
