@@ -261,18 +261,15 @@ fdg_fill_uniform(double *__restrict__ leaf, long B, uint32_t L, long ss, long ls
 }
 
 // Leaf values from (K, T): one lane = one sample; the tables are wave-uniform (scalar loads); the
-// sample's momenta and times are staged once in LDS columns and re-read per leaf.
-__device__ __forceinline__ double fdg_green0(double tau, double w, double beta) {
-  // example/benchmark.jl:113-127
-  if (tau == 0.0) tau = -1e-10;
-  if (tau > 0.0)
-    return w > 0.0 ? exp(-w * tau) / (1.0 + exp(-w * beta)) : exp(w * (beta - tau)) / (1.0 + exp(w * beta));
-  return w > 0.0 ? -exp(-w * (tau + beta)) / (1.0 + exp(-w * beta)) : -exp(-w * tau) / (1.0 + exp(w * beta));
-}
-
+// sample's momenta and times are staged once in LDS columns.  The host hands the leaves over sorted by
+// (type, loop-basis index): many propagators carry the same momentum (GV 4-loop self-energy: 89 fermionic
+// leaves, 23 distinct momenta), so q^2, the dispersion and the Fermi denominator are computed once per
+// distinct momentum and only the tau-dependent exponential per leaf.  Same expressions, same order of
+// operations as example/benchmark.jl:113-127 -- evaluated once instead of once per leaf.
 __global__ void __launch_bounds__(64)
 fdg_leaf_kernel(const int32_t *__restrict__ ltype, const int32_t *__restrict__ lorder, const int32_t *__restrict__ tin,
-                const int32_t *__restrict__ tout, const int32_t *__restrict__ lidx, const double *__restrict__ basis,
+                const int32_t *__restrict__ tout, const int32_t *__restrict__ lidx, const int32_t *__restrict__ oidx,
+                const double *__restrict__ basis,
                 uint32_t L, uint32_t n_loop, uint32_t dim, uint32_t n_tau, double kF, double beta, double lambda,
                 const double *__restrict__ K, long ks, long kc, const double *__restrict__ T, long ts, long tc,
                 double *__restrict__ leaf, long ss, long ls, long B) {
@@ -287,25 +284,38 @@ fdg_leaf_kernel(const int32_t *__restrict__ ltype, const int32_t *__restrict__ l
     const long b = valid ? b0 : B - 1;
     for (uint32_t c = 0; c < n_loop * dim; ++c) kk[(size_t)c * 64] = K[b * ks + (long)c * kc];
     for (uint32_t i = 0; i < n_tau; ++i) tt[(size_t)i * 64] = T[b * ts + (long)i * tc];
+    int32_t cur = -1;
+    double q2 = 0.0, w = 0.0, den = 1.0;
     for (uint32_t i = 0; i < L; ++i) {
       const int32_t ty = ltype[i];
       if (ty == 0) continue;
-      const double *bv = basis + (size_t)(lidx[i] - 1) * n_loop;
-      double q2 = 0.0;
-      for (uint32_t d = 0; d < dim; ++d) {
-        double q = 0.0;
-        for (uint32_t j = 0; j < n_loop; ++j) q += kk[(size_t)(j * dim + d) * 64] * bv[j];
-        q2 += q * q;
+      if (lidx[i] != cur) {                      // wave-uniform: a new momentum
+        cur = lidx[i];
+        const double *bv = basis + (size_t)(cur - 1) * n_loop;
+        q2 = 0.0;
+        for (uint32_t d = 0; d < dim; ++d) {
+          double q = 0.0;
+          for (uint32_t j = 0; j < n_loop; ++j) q += kk[(size_t)(j * dim + d) * 64] * bv[j];
+          q2 += q * q;
+        }
+        w = q2 - kF * kF;
+        den = 1.0 + exp(-fabs(w) * beta);        // 1 + exp(-w beta) for w > 0, 1 + exp(w beta) otherwise
       }
       double v;
       if (ty == 1) {
-        const double tau = tt[(size_t)(tout[i] - 1) * 64] - tt[(size_t)(tin[i] - 1) * 64];
-        v = fdg_green0(tau, q2 - kF * kF, beta);
+        double tau = tt[(size_t)(tout[i] - 1) * 64] - tt[(size_t)(tin[i] - 1) * 64];
+        if (tau == 0.0) tau = -1e-10;
+        // one exponential per lane: the four cases of green() differ in the argument and the sign only
+        // (lanes of a wave fall into different cases; branching would evaluate exp() once per case)
+        const double a_pos = w > 0.0 ? -w * tau : w * (beta - tau);
+        const double a_neg = w > 0.0 ? -w * (tau + beta) : -w * tau;
+        const double e = exp(tau > 0.0 ? a_pos : a_neg);
+        v = (tau > 0.0 ? e : -e) / den;
       } else {
         const double invK = 1.0 / (q2 + lambda);
         v = 8.0 * 3.141592653589793 / invK * fdg_powi_impl(lambda * invK, lorder[i] == 0 ? 0 : lorder[i]);
       }
-      if (valid) leaf[b * ss + (long)i * ls] = v;
+      if (valid) leaf[b * ss + (long)oidx[i] * ls] = v;
     }
   }
 }
@@ -1159,25 +1169,48 @@ int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t 
   HIP_TRY(hipGetDevice(&dev));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  // leaves in (type, loop-basis index) order, so that a momentum shared by several leaves is worked out once
+  std::vector<int32_t> perm(L);
+  for (uint32_t i = 0; i < L; ++i) perm[i] = (int32_t)i;
+  std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) {
+    if (tab->leaf_type[a] != tab->leaf_type[b]) return tab->leaf_type[a] < tab->leaf_type[b];
+    return tab->loop_index[a] < tab->loop_index[b];
+  });
   // tables -> device (small; freed after the launch has been enqueued on the same stream order)
   const size_t ib = (size_t)L * sizeof(int32_t), bb = (size_t)tab->n_basis * tab->n_loop * sizeof(double);
-  char *d_tab = nullptr;
-  hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMallocAsync((void **)&d_tab, 5 * ib + bb + 64, st));
+  const size_t boff = (6 * ib + 7) & ~(size_t)7;
+  std::vector<char> h_tab(boff + bb);
   const int32_t *src[5] = {tab->leaf_type, tab->leaf_order, tab->tau_in, tab->tau_out, tab->loop_index};
-  for (int k = 0; k < 5; ++k) HIP_TRY(hipMemcpyAsync(d_tab + k * ib, src[k], ib, hipMemcpyHostToDevice, st));
-  const size_t boff = (5 * ib + 7) & ~(size_t)7;
-  HIP_TRY(hipMemcpyAsync(d_tab + boff, tab->basis, bb, hipMemcpyHostToDevice, st));
+  for (int k = 0; k < 5; ++k)
+    for (uint32_t i = 0; i < L; ++i) ((int32_t *)(h_tab.data() + k * ib))[i] = src[k][perm[i]];
+  std::memcpy(h_tab.data() + 5 * ib, perm.data(), ib);
+  std::memcpy(h_tab.data() + boff, tab->basis, bb);
+  // the sorted tables live on the device for the life of the process, keyed by their content (a caller
+  // evaluates the same few partitions millions of times): no allocation, copy or synchronisation per call
+  hipStream_t st = (hipStream_t)stream;
+  char *d_tab = nullptr;
+  {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, std::vector<char>>, char *>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : cache) if (e.first.first == dev && e.first.second == h_tab) { d_tab = e.second; break; }
+    if (!d_tab) {
+      HIP_TRY(hipMalloc((void **)&d_tab, h_tab.size() + 64));
+      HIP_TRY(hipMemcpy(d_tab, h_tab.data(), h_tab.size(), hipMemcpyHostToDevice));
+      if (cache.size() >= 64) { hipFree(cache.front().second); cache.erase(cache.begin()); }
+      cache.push_back({{dev, h_tab}, d_tab});
+    }
+  }
   if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)fdg_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long ntile = (long)((B + 63) / 64);
   const long per_cu = std::max<long>(1, std::min<long>(32, (160 * 1024) / std::max<size_t>(lds, 1)));
   const long grid = std::min<long>(ntile, (long)prop.multiProcessorCount * per_cu);
   hipLaunchKernelGGL(fdg_leaf_kernel, dim3((unsigned)grid), dim3(64), lds, st, (const int32_t *)d_tab, (const int32_t *)(d_tab + ib),
                      (const int32_t *)(d_tab + 2 * ib), (const int32_t *)(d_tab + 3 * ib), (const int32_t *)(d_tab + 4 * ib),
+                     (const int32_t *)(d_tab + 5 * ib),
                      (const double *)(d_tab + boff), L, tab->n_loop, tab->dim, tab->n_tau, tab->kF, tab->beta, tab->lambda, d_K,
                      (long)ks, (long)kc, d_T, (long)ts, (long)tc, d_leaf, (long)ss, (long)ls, (long)B);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipFreeAsync(d_tab, st));
   return FDG_OK;
 }
 
