@@ -656,6 +656,110 @@ static int compile_hipcc(const std::string &src_path, const std::string &out_pat
   return rc == 0 ? 0 : -1;
 }
 
+// ---------------------------------------------------------------------------
+// Leaf kernel specialised to one set of leafstates tables (the same JIT route as the graph kernels):
+// indices, the loop basis (almost all entries 0 / +-1) and the leaf order are compile-time constants, so
+// the sample's momenta and times stay in registers, zero coefficients vanish and the compiler schedules the
+// whole straight-line body.  Same expressions in the same order as fdg_leaf_kernel, hence the same bits:
+// skipping q += k * 0.0 and writing k for k * 1.0 cannot change q (only the sign of a zero that is squared).
+// ---------------------------------------------------------------------------
+static std::string emit_leaf_source(const fdg_leaf_tables *tab, const std::vector<int32_t> &perm) {
+  std::ostringstream os;
+  auto dbl = [&](double f) { char b[64]; std::snprintf(b, sizeof b, "%a", f); return std::string(b); };
+  const uint32_t L = tab->n_leaf, nl = tab->n_loop, dim = tab->dim;
+  os << "#include <hip/hip_runtime.h>\n";
+  os << "extern \"C\" __global__ void __launch_bounds__(64) fdg_leaf_spec(const double *__restrict__ K, long ks, long kc,\n"
+        "    const double *__restrict__ T, long ts, long tc, double *__restrict__ leaf, long ss, long ls, long B,\n"
+        "    double kF, double beta, double lambda) {\n"
+        "  const long ntile = (B + 63) / 64;\n"
+        "  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {\n"
+        "    const long b0 = tile * 64 + threadIdx.x;\n    const bool valid = b0 < B;\n    const long b = valid ? b0 : B - 1;\n";
+  std::vector<uint8_t> k_used(nl * dim, 0), t_used(tab->n_tau + 1, 0);
+  for (uint32_t i = 0; i < L; ++i) {
+    if (tab->leaf_type[i] == 0) continue;
+    for (uint32_t j = 0; j < nl; ++j)
+      if (tab->basis[(size_t)(tab->loop_index[i] - 1) * nl + j] != 0.0) for (uint32_t d = 0; d < dim; ++d) k_used[j * dim + d] = 1;
+    if (tab->leaf_type[i] == 1) { t_used[tab->tau_in[i]] = 1; t_used[tab->tau_out[i]] = 1; }
+  }
+  for (uint32_t c = 0; c < nl * dim; ++c) if (k_used[c]) os << "    const double k" << c << " = K[b * ks + " << c << "L * kc];\n";
+  for (uint32_t i = 1; i <= tab->n_tau; ++i) if (t_used[i]) os << "    const double t" << i << " = T[b * ts + " << (i - 1) << "L * tc];\n";
+  os << "    double q, q2, w, den, tau, ap, an, e, invK, x, v;\n";
+  int32_t cur = -1;
+  for (uint32_t s = 0; s < L; ++s) {
+    const int32_t i = perm[s];
+    const int32_t ty = tab->leaf_type[i];
+    if (ty == 0) continue;
+    if (tab->loop_index[i] != cur) {
+      cur = tab->loop_index[i];
+      const double *bv = tab->basis + (size_t)(cur - 1) * nl;
+      os << "    q2 = 0.0;\n";
+      for (uint32_t d = 0; d < dim; ++d) {
+        os << "    q = 0.0;";
+        for (uint32_t j = 0; j < nl; ++j) {
+          if (bv[j] == 0.0) continue;
+          if (bv[j] == 1.0) os << " q += k" << (j * dim + d) << ";";
+          else os << " q += k" << (j * dim + d) << " * " << dbl(bv[j]) << ";";
+        }
+        os << " q2 += q * q;\n";
+      }
+      os << "    w = q2 - kF * kF; den = 1.0 + exp(-fabs(w) * beta);\n";
+    }
+    if (ty == 1) {
+      os << "    tau = t" << tab->tau_out[i] << " - t" << tab->tau_in[i] << "; if (tau == 0.0) tau = -1e-10;\n"
+            "    ap = w > 0.0 ? -w * tau : w * (beta - tau); an = w > 0.0 ? -w * (tau + beta) : -w * tau;\n"
+            "    e = exp(tau > 0.0 ? ap : an); v = (tau > 0.0 ? e : -e) / den;\n";
+    } else {
+      os << "    invK = 1.0 / (q2 + lambda); x = lambda * invK; v = 8.0 * 3.141592653589793 / invK";
+      const int32_t n = tab->leaf_order[i];
+      if (n == 0) os << " * 1.0";
+      else if (n == 1) os << " * x";
+      else if (n == 2) os << " * (x * x)";
+      else os << " * (x * x * x)";
+      os << ";\n";
+    }
+    os << "    if (valid) leaf[b * ss + " << i << "L * ls] = v;\n";
+  }
+  os << "  }\n}\n";
+  return os.str();
+}
+
+struct LeafModule { int dev; std::string key; hipModule_t mod; hipFunction_t fn; };
+
+// returns the specialised kernel for these tables on the current device, or nullptr (caller uses the generic one)
+static hipFunction_t leaf_spec_function(const fdg_leaf_tables *tab, const std::vector<int32_t> &perm, int dev) {
+  if (std::getenv("FDG_LEAF_GENERIC")) return nullptr;
+  for (uint32_t i = 0; i < tab->n_leaf; ++i)
+    if (tab->leaf_type[i] == 2 && (tab->leaf_order[i] < 0 || tab->leaf_order[i] > 3)) return nullptr;   // pow_body lives in the generic kernel
+  const std::string src = emit_leaf_source(tab, perm);
+  char hbuf[40];
+  std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("leaf-v1")));
+  static std::mutex mu;
+  static std::vector<LeafModule> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto &m : cache) if (m.dev == dev && m.key == hbuf) return m.fn;
+  const std::string dir = std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache";
+  mkdir(dir.c_str(), 0777);
+  const std::string base = dir + "/fdg_leaf_" + hbuf;
+  std::vector<char> co;
+  if (!read_file(base + ".hsaco", co)) {
+    std::string log;
+    if (compile_hiprtc(src, false, co, log) != 0) {
+      cache.push_back(LeafModule{dev, hbuf, nullptr, nullptr});   // do not retry on every call
+      return nullptr;
+    }
+    write_file(base + ".hsaco", co.data(), co.size());
+  }
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  if (hipModuleLoadData(&mod, co.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "fdg_leaf_spec") != hipSuccess) {
+    (void)hipGetLastError();
+    cache.push_back(LeafModule{dev, hbuf, nullptr, nullptr});
+    return nullptr;
+  }
+  cache.push_back(LeafModule{dev, hbuf, mod, fn});
+  return fn;
+}
+
 extern "C" {
 
 const char *fdg_last_error(void) { return fdg::last_error_cstr(); }
@@ -1176,6 +1280,15 @@ int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t 
     if (tab->leaf_type[a] != tab->leaf_type[b]) return tab->leaf_type[a] < tab->leaf_type[b];
     return tab->loop_index[a] < tab->loop_index[b];
   });
+  const long ntile = (long)((B + 63) / 64);
+  if (hipFunction_t fn = leaf_spec_function(tab, perm, dev)) {
+    long a_ks = ks, a_kc = kc, a_ts = ts, a_tc = tc, a_ss = ss, a_ls = ls, a_B = B;
+    double a_kF = tab->kF, a_beta = tab->beta, a_lambda = tab->lambda;
+    void *args[] = {(void *)&d_K, &a_ks, &a_kc, (void *)&d_T, &a_ts, &a_tc, (void *)&d_leaf, &a_ss, &a_ls, &a_B, &a_kF, &a_beta, &a_lambda};
+    const long grid = std::min<long>(ntile, (long)prop.multiProcessorCount * 32);
+    HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+    return FDG_OK;
+  }
   // tables -> device (small; freed after the launch has been enqueued on the same stream order)
   const size_t ib = (size_t)L * sizeof(int32_t), bb = (size_t)tab->n_basis * tab->n_loop * sizeof(double);
   const size_t boff = (6 * ib + 7) & ~(size_t)7;
@@ -1202,7 +1315,6 @@ int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t 
     }
   }
   if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)fdg_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const long ntile = (long)((B + 63) / 64);
   const long per_cu = std::max<long>(1, std::min<long>(32, (160 * 1024) / std::max<size_t>(lds, 1)));
   const long grid = std::min<long>(ntile, (long)prop.multiProcessorCount * per_cu);
   hipLaunchKernelGGL(fdg_leaf_kernel, dim3((unsigned)grid), dim3(64), lds, st, (const int32_t *)d_tab, (const int32_t *)(d_tab + ib),

@@ -301,6 +301,16 @@ def test_leaf_values_on_device_and_full_mc_step(libfdg, cuda):
     got = leaf.cpu().numpy()
     assert np.isfinite(want).all()
     assert np.all(np.abs(got - want) <= 1e-13 * np.abs(want))
+    # the kernel specialised to these tables (default) and the table-driven one give the same bits
+    os.environ["FDG_LEAF_GENERIC"] = "1"
+    try:
+        leaf_g = torch.zeros((L, B), dtype=torch.float64, device=cuda).t()
+        capi.leaf_eval_device(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau,
+                              kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf_g.data_ptr(), leaf_g.stride(0), leaf_g.stride(1), B, st)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["FDG_LEAF_GENERIC"]
+    assert torch.equal(leaf_g, leaf)
     # graph on the device-made leaves == oracle on the same (device-made) leaves, bit for bit
     f = fd.compile_table(t, specialize="isa")
     roots = f(None, leaf)

@@ -27,6 +27,10 @@ def timeit(fn, n=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
+os.environ["FDG_LEAF_GENERIC"] = "1"
+tg = timeit(leaves)
+del os.environ["FDG_LEAF_GENERIC"]
+print(f"table-driven leaf kernel: {tg:.3f} ms")
 tl = timeit(leaves); te = timeit(lambda: f.accumulate(leaf, w, acc))
 def both(): leaves(); f.accumulate(leaf, w, acc)
 tb = timeit(both)
