@@ -418,3 +418,23 @@ def test_large_real_graphs(libfdg, cuda, name, B):
         torch.cuda.synchronize()
         wn = w.cpu().numpy()[:, None]
         assert np.all(np.abs(acc.cpu().numpy() - (want * wn).sum(0)) <= TOL * np.maximum(1.0, np.abs(want * wn).sum(0)))
+
+
+def test_many_roots_accumulate_and_eval(libfdg, cuda):
+    """More roots than the fused accumulation keeps in registers (R = 24 > 16): the optimizing back end writes
+    roots to its scratch buffer and reduces them with the separate kernels; values still the oracle's bits."""
+    import torch
+    from feynmandiagram_jl_amd.nodetable import synthetic_parquet_like
+    t = synthetic_parquet_like(n_node=600, n_leaf=40, n_root=24, seed=5)
+    assert t.n_root == 24
+    B = 70_001
+    for spec in ("isa", True, False):
+        f = fd.compile_table(t, specialize=spec)
+        leaf = dev_leaves(cuda, B, t.n_leaf, 3, 0, "leaf_major" if spec == "isa" else "sample_major")
+        want = oracle.eval_static(t, leaf.cpu().numpy())
+        assert np.array_equal(run(f, leaf), want)
+        w = torch.rand(B, dtype=torch.float64, device=cuda)
+        acc = f.accumulate(leaf, w)
+        torch.cuda.synchronize()
+        wn = w.cpu().numpy()[:, None]
+        assert np.all(np.abs(acc.cpu().numpy() - (want * wn).sum(0)) <= TOL * np.maximum(1.0, np.abs(want * wn).sum(0)))
