@@ -38,10 +38,52 @@ def _isapprox_vec(a: Sequence[float], b: Sequence[float]) -> bool:
     return d <= 1.4901161193847656e-08 * max(na, nb)
 
 
-def leafstates(leaf_maps: Sequence[Dict[int, Graph]], maxloopNum: int):
-    """frontends.jl:178-232.  Returns
+def _leafstates_labelprod(leaf_maps: Sequence[Dict[int, Graph]], labelProd):
+    """frontends.jl:115-160: the ``FeynmanGraph`` method.  A leaf is an Interaction vertex (type 0, loop
+    index 1, both times from its first operator's label) or a Propagator (type 1 fermionic / 2 bosonic; in
+    = second vertex, out = first; loop index = last component of the in-label's index into ``labelProd``).
+    Returns ``(leafValue, leafType, leafOrders, leafInTau, leafOutTau, leafLoopIndex)``."""
+    from .graph import diagram_type
+    from .quantum_operators import isfermionic
+    num_g = len(leaf_maps)
+    leafType: List[List[int]] = [[] for _ in range(num_g)]
+    leafOrders: List[List[List[int]]] = [[] for _ in range(num_g)]
+    leafInTau: List[List[int]] = [[] for _ in range(num_g)]
+    leafOutTau: List[List[int]] = [[] for _ in range(num_g)]
+    leafLoopIndex: List[List[int]] = [[] for _ in range(num_g)]
+    leafValue: List[List[float]] = [[] for _ in range(num_g)]
+    for ikey, leafmap in enumerate(leaf_maps):
+        n = len(leafmap)
+        leafValue[ikey] = [1.0] * n
+        for idx in range(1, n + 1):
+            g = leafmap[idx]
+            vertices = g.properties.vertices
+            kind = diagram_type(g)
+            if kind == "Interaction":
+                In = Out = vertices[0][0].label
+                leafType[ikey].append(0)
+                leafLoopIndex[ikey].append(1)
+            elif kind == "Propagator":
+                In, Out = vertices[1][0].label, vertices[0][0].label
+                leafType[ikey].append(1 if isfermionic(vertices[0]) else 2)
+                leafLoopIndex[ikey].append(labelProd.linear_to_index(In)[-1])
+            else:
+                # the reference falls through both branches and then reads the undefined `In` (UndefVarError)
+                raise NameError("In not defined: leaf is neither an Interaction nor a Propagator")
+            leafOrders[ikey].append(list(g.orders))
+            leafInTau[ikey].append(labelProd[In][0])
+            leafOutTau[ikey].append(labelProd[Out][0])
+    return leafValue, leafType, leafOrders, leafInTau, leafOutTau, leafLoopIndex
+
+
+def leafstates(leaf_maps: Sequence[Dict[int, Graph]], maxloopNum):
+    """frontends.jl:178-232 (``maxloopNum::Int``; with a ``LabelProduct`` as second argument the
+    ``FeynmanGraph`` method of :115-160 is dispatched instead).  Returns
     ``((leafValue, leafType, leafOrders, leafInTau, leafOutTau, leafLoopIndex), loopbasis)``;
     every element of the first tuple is a list with one entry per graph partition."""
+    from .labelproduct import LabelProduct
+    if isinstance(maxloopNum, LabelProduct):
+        return _leafstates_labelprod(leaf_maps, maxloopNum)
     num_g = len(leaf_maps)
     leafType: List[List[int]] = [[] for _ in range(num_g)]
     leafOrders: List[List[List[int]]] = [[] for _ in range(num_g)]

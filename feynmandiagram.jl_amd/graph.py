@@ -374,13 +374,35 @@ def external_vertex(ops, name: str = "") -> FeynmanGraph:
 
 
 def propagator(ops, name: str = "", factor: float = 1.0, orders=None) -> FeynmanGraph:
-    """Leaf of diagram type Propagator (feynmangraph.jl:232-252, sign handling
-    of the operator algebra omitted: pass the sign in ``factor``)."""
+    """Leaf of diagram type Propagator (feynmangraph.jl:581-593).  With QuantumOperators (see
+    quantum_operators.py) the two operators must be conjugate and the fermionic sign of bringing them to
+    correlator order multiplies ``factor``; opaque labels are accepted too (sign then rides in ``factor``)."""
+    from .quantum_operators import OperatorProduct, QuantumOperator, correlator_order
+    ops = list(ops)
+    if ops and all(isinstance(o, QuantumOperator) for o in ops):
+        assert len(ops) == 2
+        assert ops[0].adjoint.operator == ops[1].operator
+        sign, perm = correlator_order(ops)
+        props = _FeynProps("Propagator", [OperatorProduct([o]) for o in ops], topology=[[1, 2]],
+                           external_indices=perm, external_legs=[True, True])
+        return FeynmanGraph.new([], operator=Unitary(), name=name, factor=factor * sign, orders=orders, properties=props)
     return FeynmanGraph.new([], operator=Unitary(), name=name, factor=factor, orders=orders,
-                            properties=_FeynProps("Propagator", list(ops)))
+                            properties=_FeynProps("Propagator", ops))
 
 
 def interaction(ops, name: str = "", factor: float = 1.0, orders=None) -> FeynmanGraph:
-    """Leaf of diagram type Interaction (feynmangraph.jl:254-268)."""
+    """Leaf of diagram type Interaction (feynmangraph.jl:602-613): one bosonic vertex."""
+    from .quantum_operators import OperatorProduct, QuantumOperator, isfermionic
+    if isinstance(ops, (list, tuple)) and ops and all(isinstance(o, QuantumOperator) for o in ops):
+        ops = OperatorProduct(ops)
+        assert not isfermionic(ops), "interaction OperatorProduct must be bosonic."
+        props = _FeynProps("Interaction", [ops], external_indices=list(range(1, len(ops) + 1)),
+                           external_legs=[False] * len(ops))
+        return FeynmanGraph.new([], operator=Unitary(), name=name, factor=factor, orders=orders, properties=props)
     return FeynmanGraph.new([], operator=Unitary(), name=name, factor=factor, orders=orders,
                             properties=_FeynProps("Interaction", [ops]))
+
+
+def diagram_type(g: FeynmanGraph) -> str:
+    """feynmangraph.jl:233."""
+    return g.properties.diagtype
