@@ -4,6 +4,7 @@
 // (src/backend/static.jl:13-31), and a factor of -1 is carried as a sign on the
 // operand (x * -1.0 == -x exactly).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <limits>
@@ -44,12 +45,14 @@ struct Builder {
   std::unordered_map<uint64_t, std::vector<std::pair<double, uint32_t>>> vn_mulc;
   bool value_numbering = true;
   uint64_t vn_window = 0;        // reuse only results computed at most this many ops ago (0 = no limit)
-  std::vector<uint32_t> born;    // vid -> index of the op that produced it
+  std::vector<uint32_t> born;    // vid -> index of the op that produced it or (vn_touch) last read it
+  bool vn_touch = true;          // a value stays reusable while it keeps being read (it is live anyway)
   bool fresh_enough(uint32_t ref) const {
     if (!vn_window) return true;
     const uint32_t v = ref >> 1;
     return v < born.size() && (uint64_t)u.size() - born[v] <= vn_window;
   }
+  void touch(uint32_t ref) { if (vn_touch) { const uint32_t v = ref >> 1; if (v < born.size()) born[v] = (uint32_t)u.size(); } }
   uint32_t fresh() { born.resize(next_vid + 1, 0); born[next_vid] = (uint32_t)u.size(); return next_vid++; }
   uint32_t op2(uint8_t k, uint32_t a, uint32_t b) {
     if (!value_numbering) { uint32_t d = fresh(); u.push_back(UOp{k, d, a, b, 0.0}); return d << 1; }
@@ -59,7 +62,8 @@ struct Builder {
       if (x > y) std::swap(x, y);
       const uint64_t key = ((uint64_t)x << 32) | y;
       auto it = vn_mul.find(key);
-      if (it != vn_mul.end() && fresh_enough(it->second)) return it->second | sign;
+      if (it != vn_mul.end() && fresh_enough(it->second)) { touch(it->second); return it->second | sign; }
+      touch(x); touch(y);
       uint32_t d = fresh();
       u.push_back(UOp{M_MUL, d, x, y, 0.0});
       vn_mul[key] = d << 1;
@@ -69,7 +73,8 @@ struct Builder {
     if (x > y) std::swap(x, y);
     const uint64_t key = ((uint64_t)x << 32) | y;
     auto it = vn_add.find(key);
-    if (it != vn_add.end() && fresh_enough(it->second)) return it->second;
+    if (it != vn_add.end() && fresh_enough(it->second)) { touch(it->second); return it->second; }
+    touch(x); touch(y);
     uint32_t d = fresh();
     u.push_back(UOp{M_ADD, d, x, y, 0.0});
     vn_add[key] = d << 1;
@@ -81,8 +86,9 @@ struct Builder {
     if (!value_numbering) { uint32_t d = fresh(); u.push_back(UOp{M_MULC, d, a, 0, f}); return d << 1; }
     const uint32_t sign = a & 1u, x = a & ~1u;
     auto &lst = vn_mulc[x];
+    touch(x);
     for (auto &e : lst) if (std::memcmp(&e.first, &f, 8) == 0) {
-      if (fresh_enough(e.second)) return e.second | sign;
+      if (fresh_enough(e.second)) { touch(e.second); return e.second | sign; }
       uint32_t d = fresh();
       u.push_back(UOp{M_MULC, d, x, 0, f});
       e.second = d << 1;
@@ -484,12 +490,13 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   Builder B0(p);
   B0.value_numbering = prm.vn_window != 1;     // 1 = off, 0 = unlimited, else window in ops
   B0.vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
+  B0.vn_touch = std::getenv("FDG_VN_BIRTH_WINDOW") == nullptr;   // default: the window counts from the last read
   build_uops(B0);
   Lowered plain;
   const bool retry = !B0.ok && B0.why == "inconsistent schedule groups";
   if (retry) { plain = p; plain.sched_group.clear(); }
   Builder B1(retry ? plain : p);
-  B1.value_numbering = B0.value_numbering; B1.vn_window = B0.vn_window;
+  B1.value_numbering = B0.value_numbering; B1.vn_window = B0.vn_window; B1.vn_touch = B0.vn_touch;
   if (retry) build_uops(B1);
   Builder &B = retry ? B1 : B0;
   out.supported = B.ok;

@@ -995,7 +995,7 @@ static fdg::OptParams auto_program(const fdg_graph *g, fdg::OptProgram &prog) {
 // the cache directory (keyed by the table), so tuning happens once per graph.
 static std::string tuned_path(const fdg_graph *g, const std::string &dir) {
   const fdg::Lowered &p = g->prog;
-  uint64_t th = fnv1a("tuned-v1");
+  uint64_t th = fnv1a("tuned-v2");
   auto mix = [&](const void *d, size_t n) { th = fnv1a(std::string((const char *)d, n), th); };
   mix(&p.L, 4); mix(&p.N, 4); mix(&p.R, 4);
   if (p.N) { mix(p.op.data(), p.op.size()); mix(p.power.data(), p.power.size() * 4); mix(p.off.data(), p.off.size() * 4); }

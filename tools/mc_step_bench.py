@@ -35,3 +35,14 @@ tl = timeit(leaves); te = timeit(lambda: f.accumulate(leaf, w, acc))
 def both(): leaves(); f.accumulate(leaf, w, acc)
 tb = timeit(both)
 print(f"gv_sigma4 B={B}: leaves {tl:.3f} ms ({B/tl*1e3:.3e}/s, {B*L*8/tl/1e6:.0f} GB/s written), eval+accumulate {te:.3f} ms ({B/te*1e3:.3e}/s), whole step {tb:.3f} ms = {B/tb*1e3:.3e} samples/s")
+
+# chunked: leaves of one chunk are consumed by the evaluator while still in L2 / MALL
+for Bc in (1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20):
+    lc = torch.zeros((L, Bc), dtype=torch.float64, device=dev).t()
+    def chunked():
+        for c0 in range(0, B, Bc):
+            capi.leaf_eval_device(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau, kF, beta, lam,
+                                  dK.data_ptr() + 8 * c0, 1, B, dT.data_ptr() + 8 * c0, 1, B, lc.data_ptr(), lc.stride(0), lc.stride(1), Bc, st)
+            f.handle.accumulate_device(lc.data_ptr(), lc.stride(0), lc.stride(1), w.data_ptr() + 8 * c0, acc.data_ptr(), Bc, st)
+    tc = timeit(chunked, 3)
+    print(f"chunks of {Bc}: whole step {tc:.3f} ms = {B/tc*1e3:.3e} samples/s")
