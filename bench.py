@@ -161,7 +161,7 @@ def main():
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(args.workload)
             if tr and tr["layout"] == args.layout and args.backend == "isa":
                 out["roofline"]["traffic"] = tr["bytes_per_eval"] * B
-                out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_b_isa_*.txt (per evaluation, scaled to this batch)"
+                out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " + tr.get("source", "profiles/") + " (per evaluation, scaled to this batch)"
         except (OSError, ValueError):
             pass
         out["valu_fp64"] = {"achieved_tflops": st["flops_alg"] * B / avg_kernel_s / 1e12,
