@@ -26,8 +26,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6    # AMD spec, FMA counted as 2 (not in the local g
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=25)   # 25 steps x 4e6 samples = config 3's 1e8 samples
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="gv_sigma4_taylor2")
     ap.add_argument("--samples", type=int, default=0, help="samples per step per GPU (0 = workload default)")
     ap.add_argument("--layout", default="leaf_major", choices=["sample_major", "leaf_major"],
