@@ -30,6 +30,7 @@ EXPORTS = [
     "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_graph_release_device", "fdg_powi",
     "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
+    "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device",
 ]
 COMM_ID_BYTES = 128
 
@@ -127,6 +128,9 @@ def lib():
     L.fdg_graph_set_opt_params.argtypes = [vp, C.POINTER(OptParams)]
     L.fdg_graph_opt_program.argtypes = [vp, C.POINTER(OptParams), C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64),
                                         C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.fdg_graph_specialize_fused.argtypes = [vp, C.POINTER(LeafTables), C.c_char_p, C.c_uint]
+    L.fdg_mc_eval_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, C.c_double, C.c_double, C.c_double, dp, i64, i64, i64, vp]
+    L.fdg_mc_accumulate_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, C.c_double, C.c_double, C.c_double, dp, dp, i64, vp]
     L.fdg_comm_unique_id.argtypes = [C.c_void_p, C.c_size_t]
     L.fdg_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(vp)]
     L.fdg_comm_destroy.argtypes = [vp]
@@ -230,6 +234,19 @@ class GraphHandle:
     def accumulate_device(self, d_leaf: int, ss: int, ls: int, d_weight: int, d_acc: int, B: int, stream: int = 0):
         check(lib().fdg_accumulate_device(self._h, d_leaf, ss, ls, d_weight or None, d_acc, B, stream))
 
+    # fused Monte-Carlo step: leaves from (K, T) in registers, then the graph --------------------- #
+    def specialize_fused(self, tables, cache_dir: Optional[str] = None, flags: int = 0):
+        """``tables`` = the struct returned by make_leaf_tables."""
+        cd = cache_dir if cache_dir is not None else os.environ.get("FDG_CACHE_DIR", KERNEL_CACHE)
+        os.makedirs(cd, exist_ok=True)
+        check(lib().fdg_graph_specialize_fused(self._h, C.byref(tables), cd.encode(), flags))
+
+    def mc_eval_device(self, d_K, ks, kc, d_T, ts, tc, kF, beta, lam, d_root, rs, rk, B, stream=0):
+        check(lib().fdg_mc_eval_device(self._h, d_K, ks, kc, d_T, ts, tc, kF, beta, lam, d_root, rs, rk, B, stream))
+
+    def mc_accumulate_device(self, d_K, ks, kc, d_T, ts, tc, kF, beta, lam, d_weight, d_acc, B, stream=0):
+        check(lib().fdg_mc_accumulate_device(self._h, d_K, ks, kc, d_T, ts, tc, kF, beta, lam, d_weight or None, d_acc, B, stream))
+
     def eval_host(self, leaf: np.ndarray, root: Optional[np.ndarray] = None) -> np.ndarray:
         leaf = np.ascontiguousarray(leaf, dtype=np.float64)
         if leaf.ndim != 2 or leaf.shape[1] < self.table.n_leaf:
@@ -291,10 +308,9 @@ class Comm:
             pass
 
 
-def leaf_eval_device(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, dim, n_tau, kF, beta, lam,
-                     d_K: int, ks: int, kc: int, d_T: int, ts: int, tc: int, d_leaf: int, ss: int, ls: int, B: int,
-                     stream: int = 0):
-    """fdg_leaf_eval_device with the tables of ``FrontEnds.leafstates`` (1-based indices)."""
+def make_leaf_tables(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, dim, n_tau, kF=0.0, beta=0.0, lam=0.0):
+    """``fdg_leaf_tables`` from the vectors of ``FrontEnds.leafstates`` (1-based indices); returns the
+    struct and the arrays it points into (keep them alive)."""
     a = [np.ascontiguousarray(x, dtype=np.int32) for x in (leaf_type, leaf_order, tau_in, tau_out, loop_index)]
     bs = np.ascontiguousarray(basis, dtype=np.float64)
     t = LeafTables()
@@ -302,4 +318,12 @@ def leaf_eval_device(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, 
     t.leaf_type, t.leaf_order, t.tau_in, t.tau_out, t.loop_index = [x.ctypes.data for x in a]
     t.basis = bs.ctypes.data
     t.kF, t.beta, t.lambda_ = kF, beta, lam
+    return t, (a, bs)
+
+
+def leaf_eval_device(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, dim, n_tau, kF, beta, lam,
+                     d_K: int, ks: int, kc: int, d_T: int, ts: int, tc: int, d_leaf: int, ss: int, ls: int, B: int,
+                     stream: int = 0):
+    """fdg_leaf_eval_device with the tables of ``FrontEnds.leafstates`` (1-based indices)."""
+    t, _keep = make_leaf_tables(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, dim, n_tau, kF, beta, lam)
     check(lib().fdg_leaf_eval_device(C.byref(t), d_K, ks, kc, d_T, ts, tc, d_leaf, ss, ls, B, stream))

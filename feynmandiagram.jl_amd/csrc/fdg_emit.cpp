@@ -104,6 +104,44 @@ static void emit_node_expr(std::ostringstream &os, const Lowered &p, uint32_t n)
   for (size_t i = 1; i < terms.size(); ++i) os << sep << terms[i] << ")";
 }
 
+static void emit_nodes(std::ostringstream &os, const Lowered &p) {
+  for (uint32_t n : p.order) {
+    os << "    const double g" << (p.L + n) << " = ";
+    emit_node_expr(os, p, n);
+    os << ";\n";
+  }
+}
+
+// mode 0: roots of the block's samples; mode 1: w * root accumulated per lane, block sums at the end of the kernel
+static void emit_outputs(std::ostringstream &os, const Lowered &p, bool sample_major) {
+  os << "    if (mode == 0) {\n      if (valid) {\n";
+  os << "        double *rp = root + b * rs;\n";
+  bool pair_ok = sample_major;
+  for (uint32_t k = 0; k < p.R; ++k) {
+    if (p.root_slot[k] == FDG_NO_ROOT) continue;
+    if (pair_ok && k % 2 == 0 && k + 1 < p.R && p.root_slot[k + 1] != FDG_NO_ROOT) {
+      os << "        if (rk == 1 && ((rs & 1l) == 0l) && ((((unsigned long)root) & 15ul) == 0ul)) { fdg_d2 t; t.x = g"
+         << p.root_slot[k] << "; t.y = g" << p.root_slot[k + 1] << "; __builtin_nontemporal_store(t, (fdg_d2 *)(rp + " << k
+         << ")); } else { rp[" << k << "l * rk] = g" << p.root_slot[k] << "; rp[" << (k + 1) << "l * rk] = g"
+         << p.root_slot[k + 1] << "; }\n";
+      ++k;
+    } else {
+      os << "        rp[" << k << "l * rk] = g" << p.root_slot[k] << ";\n";
+    }
+  }
+  os << "      }\n    } else {\n";
+  os << "      const double w = valid ? (weight ? weight[b] : 1.0) : 0.0;\n";
+  for (uint32_t k = 0; k < p.R; ++k)
+    if (p.root_slot[k] != FDG_NO_ROOT) os << "      acc" << k << " = acc" << k << " + w * g" << p.root_slot[k] << ";\n";
+  os << "    }\n";
+  os << "  }\n";
+  os << "  if (mode != 0) {\n";
+  for (uint32_t k = 0; k < p.R; ++k) {
+    os << "    { double s = fdg_block_sum(acc" << k << ", fdg_sh); if (threadIdx.x == 0) partial[(long)blockIdx.x * "
+       << p.R << " + " << k << "] = s; }\n";
+  }
+}
+
 static void emit_kernel(std::ostringstream &os, const Lowered &p, bool sample_major) {
   const uint32_t L = p.L;
   os << "extern \"C\" __global__ void __launch_bounds__(256) " << (sample_major ? "fdg_spec_sm" : "fdg_spec_gen")
@@ -139,38 +177,9 @@ static void emit_kernel(std::ostringstream &os, const Lowered &p, bool sample_ma
     for (uint32_t i = 0; i < L; ++i)
       if (p.live[i]) os << "    const double g" << i << " = __builtin_nontemporal_load(lp + " << i << "l * ls);\n";
   }
-  for (uint32_t n : p.order) {
-    os << "    const double g" << (L + n) << " = ";
-    emit_node_expr(os, p, n);
-    os << ";\n";
-  }
+  emit_nodes(os, p);
   // outputs
-  os << "    if (mode == 0) {\n      if (valid) {\n";
-  os << "        double *rp = root + b * rs;\n";
-  bool pair_ok = sample_major;
-  for (uint32_t k = 0; k < p.R; ++k) {
-    if (p.root_slot[k] == FDG_NO_ROOT) continue;
-    if (pair_ok && k % 2 == 0 && k + 1 < p.R && p.root_slot[k + 1] != FDG_NO_ROOT) {
-      os << "        if (rk == 1 && ((rs & 1l) == 0l) && ((((unsigned long)root) & 15ul) == 0ul)) { fdg_d2 t; t.x = g"
-         << p.root_slot[k] << "; t.y = g" << p.root_slot[k + 1] << "; __builtin_nontemporal_store(t, (fdg_d2 *)(rp + " << k
-         << ")); } else { rp[" << k << "l * rk] = g" << p.root_slot[k] << "; rp[" << (k + 1) << "l * rk] = g"
-         << p.root_slot[k + 1] << "; }\n";
-      ++k;
-    } else {
-      os << "        rp[" << k << "l * rk] = g" << p.root_slot[k] << ";\n";
-    }
-  }
-  os << "      }\n    } else {\n";
-  os << "      const double w = valid ? (weight ? weight[b] : 1.0) : 0.0;\n";
-  for (uint32_t k = 0; k < p.R; ++k)
-    if (p.root_slot[k] != FDG_NO_ROOT) os << "      acc" << k << " = acc" << k << " + w * g" << p.root_slot[k] << ";\n";
-  os << "    }\n";
-  os << "  }\n";
-  os << "  if (mode != 0) {\n";
-  for (uint32_t k = 0; k < p.R; ++k) {
-    os << "    { double s = fdg_block_sum(acc" << k << ", fdg_sh); if (threadIdx.x == 0) partial[(long)blockIdx.x * "
-       << p.R << " + " << k << "] = s; }\n";
-  }
+  emit_outputs(os, p, sample_major);
   os << "  }\n}\n\n";
 }
 
@@ -183,6 +192,32 @@ std::string emit_hip_source(const Lowered &p, unsigned flags) {
   os << kPrelude;
   emit_kernel(os, p, true);
   emit_kernel(os, p, false);
+  return os.str();
+}
+
+// Fused Monte-Carlo step: the leaves are not read from memory but worked out in
+// registers from the sample's momenta and times (`leaf_stmts`, produced by the runtime from the leafstates
+// tables: it declares and assigns g0 .. g{L-1}); the graph body and the outputs are those of fdg_spec_gen.
+std::string emit_fused_source(const Lowered &p, const std::string &leaf_stmts) {
+  std::ostringstream os;
+  os << "// generated: fused leaves + graph, L=" << p.L << " N=" << p.N << " R=" << p.R << "\n";
+  os << "#include <hip/hip_runtime.h>\n";
+  os << kPrelude;
+  os << "extern \"C\" __global__ void __launch_bounds__(256) fdg_spec_fused(const double *__restrict__ K, long ks, long kc,\n"
+        "    const double *__restrict__ T, long ts, long tc, double kF, double beta, double lambda,\n"
+        "    double *__restrict__ root, long rs, long rk, const double *__restrict__ weight, double *__restrict__ partial, long B, int mode) {\n";
+  os << "  __shared__ double fdg_sh[256];\n";
+  for (uint32_t k = 0; k < p.R; ++k) os << "  double acc" << k << " = 0.0;\n";
+  os << "  const long nblk = (B + 255) / 256;\n";
+  os << "  _Pragma(\"unroll 1\")\n";
+  os << "  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {\n";
+  os << "    const long b0 = blk * 256 + threadIdx.x;\n";
+  os << "    const bool valid = b0 < B;\n";
+  os << "    const long b = valid ? b0 : (B - 1);\n";
+  os << leaf_stmts;
+  emit_nodes(os, p);
+  emit_outputs(os, p, false);
+  os << "  }\n}\n\n";
   return os.str();
 }
 

@@ -63,6 +63,7 @@ void build_interpreter_program(Lowered &p, uint32_t lds_slot_budget);
 
 // source emitter (fdg_emit.cpp)
 std::string emit_hip_source(const Lowered &p, unsigned flags);
+std::string emit_fused_source(const Lowered &p, const std::string &leaf_stmts);
 
 // thread-local error
 void set_error(const std::string &s);
@@ -97,6 +98,9 @@ struct fdg_graph {
   bool has_acc = false;
   void *fn_isa_acc = nullptr;
   uint32_t isa3_vgpr = 0, isa3_lds_bytes = 0, isa3_mem_slots = 0;
+  // fused Monte-Carlo step: leaves computed in registers from (K, T), then the graph (HIP-source JIT)
+  std::vector<char> fused_code;
+  void *fused_module = nullptr, *fn_fused = nullptr;
   void *d_ws2 = nullptr;           // roots scratch for accumulate through the ISA kernel
   size_t ws2_bytes = 0;
   void *d_ws3 = nullptr;           // leaf-major copy of a sample-major chunk for the ISA kernel

@@ -663,17 +663,12 @@ static int compile_hipcc(const std::string &src_path, const std::string &out_pat
 // whole straight-line body.  Same expressions in the same order as fdg_leaf_kernel, hence the same bits:
 // skipping q += k * 0.0 and writing k for k * 1.0 cannot change q (only the sign of a zero that is squared).
 // ---------------------------------------------------------------------------
-static std::string emit_leaf_source(const fdg_leaf_tables *tab, const std::vector<int32_t> &perm) {
+// `fused` = false: statements store each leaf to leaf[b*ss + i*ls]; true: they assign g<i> (declared here, 1.0 for
+// leaves without a formula: leafstates' initial leafValue) for the graph body that follows.
+static std::string emit_leaf_statements(const fdg_leaf_tables *tab, const std::vector<int32_t> &perm, bool fused) {
   std::ostringstream os;
   auto dbl = [&](double f) { char b[64]; std::snprintf(b, sizeof b, "%a", f); return std::string(b); };
   const uint32_t L = tab->n_leaf, nl = tab->n_loop, dim = tab->dim;
-  os << "#include <hip/hip_runtime.h>\n";
-  os << "extern \"C\" __global__ void __launch_bounds__(64) fdg_leaf_spec(const double *__restrict__ K, long ks, long kc,\n"
-        "    const double *__restrict__ T, long ts, long tc, double *__restrict__ leaf, long ss, long ls, long B,\n"
-        "    double kF, double beta, double lambda) {\n"
-        "  const long ntile = (B + 63) / 64;\n"
-        "  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {\n"
-        "    const long b0 = tile * 64 + threadIdx.x;\n    const bool valid = b0 < B;\n    const long b = valid ? b0 : B - 1;\n";
   std::vector<uint8_t> k_used(nl * dim, 0), t_used(tab->n_tau + 1, 0);
   for (uint32_t i = 0; i < L; ++i) {
     if (tab->leaf_type[i] == 0) continue;
@@ -684,6 +679,7 @@ static std::string emit_leaf_source(const fdg_leaf_tables *tab, const std::vecto
   for (uint32_t c = 0; c < nl * dim; ++c) if (k_used[c]) os << "    const double k" << c << " = K[b * ks + " << c << "L * kc];\n";
   for (uint32_t i = 1; i <= tab->n_tau; ++i) if (t_used[i]) os << "    const double t" << i << " = T[b * ts + " << (i - 1) << "L * tc];\n";
   os << "    double q, q2, w, den, tau, ap, an, e, invK, x, v;\n";
+  if (fused) for (uint32_t i = 0; i < L; ++i) os << "    double g" << i << " = 1.0;\n";
   int32_t cur = -1;
   for (uint32_t s = 0; s < L; ++s) {
     const int32_t i = perm[s];
@@ -717,10 +713,51 @@ static std::string emit_leaf_source(const fdg_leaf_tables *tab, const std::vecto
       else os << " * (x * x * x)";
       os << ";\n";
     }
-    os << "    if (valid) leaf[b * ss + " << i << "L * ls] = v;\n";
+    if (fused) os << "    g" << i << " = v;\n";
+    else os << "    if (valid) leaf[b * ss + " << i << "L * ls] = v;\n";
   }
+  return os.str();
+}
+
+static std::string emit_leaf_source(const fdg_leaf_tables *tab, const std::vector<int32_t> &perm) {
+  std::ostringstream os;
+  os << "#include <hip/hip_runtime.h>\n";
+  os << "extern \"C\" __global__ void __launch_bounds__(64) fdg_leaf_spec(const double *__restrict__ K, long ks, long kc,\n"
+        "    const double *__restrict__ T, long ts, long tc, double *__restrict__ leaf, long ss, long ls, long B,\n"
+        "    double kF, double beta, double lambda) {\n"
+        "  const long ntile = (B + 63) / 64;\n"
+        "  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {\n"
+        "    const long b0 = tile * 64 + threadIdx.x;\n    const bool valid = b0 < B;\n    const long b = valid ? b0 : B - 1;\n";
+  os << emit_leaf_statements(tab, perm, false);
   os << "  }\n}\n";
   return os.str();
+}
+
+static std::vector<int32_t> leaf_order_by_momentum(const fdg_leaf_tables *tab) {
+  std::vector<int32_t> perm(tab->n_leaf);
+  for (uint32_t i = 0; i < tab->n_leaf; ++i) perm[i] = (int32_t)i;
+  std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) {
+    if (tab->leaf_type[a] != tab->leaf_type[b]) return tab->leaf_type[a] < tab->leaf_type[b];
+    return tab->loop_index[a] < tab->loop_index[b];
+  });
+  return perm;
+}
+
+static int check_leaf_tables(const fdg_leaf_tables *tab) {
+  if (!tab || !tab->leaf_type || !tab->leaf_order || !tab->tau_in || !tab->tau_out || !tab->loop_index || !tab->basis) {
+    set_error("null leaf table"); return FDG_E_INVALID;
+  }
+  for (uint32_t i = 0; i < tab->n_leaf; ++i) {
+    const int32_t ty = tab->leaf_type[i];
+    if (ty < 0 || ty > 2) { set_error("this leaftype " + std::to_string(ty) + " not implemented!"); return FDG_E_UNSUPPORTED; }  // benchmark.jl:79
+    if (ty == 0) continue;
+    if (tab->loop_index[i] < 1 || (uint32_t)tab->loop_index[i] > tab->n_basis) { set_error("loop_index out of range"); return FDG_E_INVALID; }
+    if (ty == 1) {
+      if (tab->leaf_order[i] != 0) { set_error("fermionic leaf of derivative order > 0 needs Lehmann.jl's kernelFermiT_dw* (not part of the reference)"); return FDG_E_UNSUPPORTED; }
+      if (tab->tau_in[i] < 1 || tab->tau_out[i] < 1 || (uint32_t)tab->tau_in[i] > tab->n_tau || (uint32_t)tab->tau_out[i] > tab->n_tau) { set_error("tau index out of range"); return FDG_E_INVALID; }
+    } else if (tab->leaf_order[i] < 0) { set_error("negative derivative order"); return FDG_E_INVALID; }
+  }
+  return FDG_OK;
 }
 
 struct LeafModule { int dev; std::string key; hipModule_t mod; hipFunction_t fn; };
@@ -809,6 +846,7 @@ int fdg_graph_release_device(fdg_graph *g) {
     hipEventDestroy((hipEvent_t)g->ev_in);
   }
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; g->fn_eval_sm = g->fn_eval_gen = nullptr; g->fn_isa = nullptr; }
+  if (g->fused_module) { hipModuleUnload((hipModule_t)g->fused_module); g->fused_module = nullptr; g->fn_fused = nullptr; }
   return FDG_OK;
 }
 
@@ -1249,23 +1287,11 @@ int fdg_eval(fdg_graph *g, const double *leaf, double *root, int64_t B) {
 
 int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t ks, int64_t kc, const double *d_T,
                          int64_t ts, int64_t tc, double *d_leaf, int64_t ss, int64_t ls, int64_t B, void *stream) {
-  if (!tab || !tab->leaf_type || !tab->leaf_order || !tab->tau_in || !tab->tau_out || !tab->loop_index || !tab->basis) {
-    set_error("null leaf table"); return FDG_E_INVALID;
-  }
+  { const int rc0 = check_leaf_tables(tab); if (rc0) return rc0; }
   if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
   if (B == 0 || tab->n_leaf == 0) return FDG_OK;
   if (!d_K || !d_T || !d_leaf) { set_error("null device buffer"); return FDG_E_INVALID; }
   const uint32_t L = tab->n_leaf;
-  for (uint32_t i = 0; i < L; ++i) {
-    const int32_t ty = tab->leaf_type[i];
-    if (ty < 0 || ty > 2) { set_error("this leaftype " + std::to_string(ty) + " not implemented!"); return FDG_E_UNSUPPORTED; }  // benchmark.jl:79
-    if (ty == 0) continue;
-    if (tab->loop_index[i] < 1 || (uint32_t)tab->loop_index[i] > tab->n_basis) { set_error("loop_index out of range"); return FDG_E_INVALID; }
-    if (ty == 1) {
-      if (tab->leaf_order[i] != 0) { set_error("fermionic leaf of derivative order > 0 needs Lehmann.jl's kernelFermiT_dw* (not part of the reference)"); return FDG_E_UNSUPPORTED; }
-      if (tab->tau_in[i] < 1 || tab->tau_out[i] < 1 || (uint32_t)tab->tau_in[i] > tab->n_tau || (uint32_t)tab->tau_out[i] > tab->n_tau) { set_error("tau index out of range"); return FDG_E_INVALID; }
-    } else if (tab->leaf_order[i] < 0) { set_error("negative derivative order"); return FDG_E_INVALID; }
-  }
   const size_t lds = ((size_t)tab->n_loop * tab->dim + tab->n_tau) * 64 * sizeof(double);
   if (lds > 160 * 1024) { set_error("too many momentum/time components for the LDS staging"); return FDG_E_INVALID; }
   int n = 0, dev = 0;
@@ -1274,12 +1300,7 @@ int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t 
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
   // leaves in (type, loop-basis index) order, so that a momentum shared by several leaves is worked out once
-  std::vector<int32_t> perm(L);
-  for (uint32_t i = 0; i < L; ++i) perm[i] = (int32_t)i;
-  std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) {
-    if (tab->leaf_type[a] != tab->leaf_type[b]) return tab->leaf_type[a] < tab->leaf_type[b];
-    return tab->loop_index[a] < tab->loop_index[b];
-  });
+  const std::vector<int32_t> perm = leaf_order_by_momentum(tab);
   const long ntile = (long)((B + 63) / 64);
   if (hipFunction_t fn = leaf_spec_function(tab, perm, dev)) {
     long a_ks = ks, a_kc = kc, a_ts = ts, a_tc = tc, a_ss = ss, a_ls = ls, a_B = B;
@@ -1324,6 +1345,89 @@ int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t 
                      (long)ks, (long)kc, d_T, (long)ts, (long)tc, d_leaf, (long)ss, (long)ls, (long)B);
   HIP_TRY(hipGetLastError());
   return FDG_OK;
+}
+
+// ---- fused Monte-Carlo step --------------------------------------------------------------------
+int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const char *cache_dir, unsigned flags) {
+  if (!g) { set_error("null handle"); return FDG_E_INVALID; }
+  { const int rc0 = check_leaf_tables(tab); if (rc0) return rc0; }
+  if (tab->n_leaf != g->prog.L) { set_error("leaf tables describe " + std::to_string(tab->n_leaf) + " leaves, the graph has " + std::to_string(g->prog.L)); return FDG_E_INVALID; }
+  for (uint32_t i = 0; i < tab->n_leaf; ++i)
+    if (tab->leaf_type[i] == 2 && tab->leaf_order[i] > 3) { set_error("fused step: interaction order > 3 not covered (use fdg_leaf_eval_device + fdg_accumulate_device)"); return FDG_E_UNSUPPORTED; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  const std::string src = emit_fused_source(g->prog, emit_leaf_statements(tab, leaf_order_by_momentum(tab), true));
+  char hbuf[40];
+  std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("fused-v1")));
+  const std::string dir = cache_dir ? cache_dir : (std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache");
+  mkdir(dir.c_str(), 0777);
+  const std::string base = dir + "/fdg_fused_" + hbuf;
+  std::vector<char> co;
+  if (!read_file(base + ".hsaco", co)) {
+    std::string log;
+    if (compile_hiprtc(src, false, co, log) != 0) {
+      std::string log2;
+      if (!write_file(base + ".hip", src.c_str(), src.size())) { set_error("cannot write " + base + ".hip"); return FDG_E_JIT; }
+      const int rc = compile_hipcc(base + ".hip", base + ".hsaco", false, log2);
+      if (!(flags & FDG_SPEC_KEEP_SOURCE)) std::remove((base + ".hip").c_str());
+      if (rc != 0 || !read_file(base + ".hsaco", co)) { set_error("fused kernel specialization failed.\nhiprtc: " + log + "\nhipcc: " + log2); return FDG_E_JIT; }
+    } else {
+      write_file(base + ".hsaco", co.data(), co.size());
+    }
+  }
+  if (flags & FDG_SPEC_KEEP_SOURCE) write_file(base + ".hip", src.c_str(), src.size());
+  if (g->fused_module) { hipModuleUnload((hipModule_t)g->fused_module); g->fused_module = nullptr; g->fn_fused = nullptr; }
+  g->fused_code.swap(co);
+  return FDG_OK;
+}
+
+static int run_fused(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_t kc, const double *d_T, int64_t ts, int64_t tc,
+                     double kF, double beta, double lambda, double *d_root, int64_t rs, int64_t rk, const double *d_weight,
+                     double *d_acc, int64_t B, void *stream) {
+  if (!g) { set_error("null handle"); return FDG_E_INVALID; }
+  if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
+  if (B == 0) return FDG_OK;
+  if (!d_K || !d_T || (mode == 0 && !d_root) || (mode == 1 && !d_acc)) { set_error("null device buffer"); return FDG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->fused_code.empty()) { set_error("fdg_graph_specialize_fused has not been called on this handle"); return FDG_E_INVALID; }
+  int rc = ensure_device(g);
+  if (rc) return rc;
+  if (!g->fn_fused) {
+    hipModule_t m; hipFunction_t f;
+    hipError_t e = hipModuleLoadData(&m, g->fused_code.data());
+    if (e != hipSuccess) { set_error("hipModuleLoadData failed: " + std::string(hipGetErrorString(e))); return FDG_E_JIT; }
+    HIP_TRY(hipModuleGetFunction(&f, m, "fdg_spec_fused"));
+    g->fused_module = m; g->fn_fused = f;
+  }
+  const uint32_t R = g->prog.R;
+  const long nblk = (long)((B + 255) / 256);
+  const long grid = std::min<long>(nblk, (long)g->n_cu * 8);
+  double *partial = nullptr;
+  if (mode == 1) {
+    rc = ensure_ws(g, (size_t)grid * std::max<uint32_t>(R, 1) * sizeof(double));
+    if (rc) return rc;
+    partial = (double *)g->d_ws;
+  }
+  long a_ks = ks, a_kc = kc, a_ts = ts, a_tc = tc, a_rs = rs, a_rk = rk, a_B = B;
+  int a_mode = mode;
+  void *args[] = {(void *)&d_K, &a_ks, &a_kc, (void *)&d_T, &a_ts, &a_tc, &kF, &beta, &lambda, (void *)&d_root, &a_rs, &a_rk,
+                  (void *)&d_weight, (void *)&partial, &a_B, &a_mode};
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_fused, (unsigned)grid, 1, 1, 256, 1, 1, 0, st, args, nullptr));
+  if (mode == 1 && R) {
+    hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, (uint32_t)grid, R, d_acc);
+    HIP_TRY(hipGetLastError());
+  }
+  return FDG_OK;
+}
+
+int fdg_mc_eval_device(fdg_graph *g, const double *d_K, int64_t ks, int64_t kc, const double *d_T, int64_t ts, int64_t tc,
+                       double kF, double beta, double lambda, double *d_root, int64_t rs, int64_t rk, int64_t B, void *stream) {
+  return run_fused(g, 0, d_K, ks, kc, d_T, ts, tc, kF, beta, lambda, d_root, rs, rk, nullptr, nullptr, B, stream);
+}
+
+int fdg_mc_accumulate_device(fdg_graph *g, const double *d_K, int64_t ks, int64_t kc, const double *d_T, int64_t ts, int64_t tc,
+                             double kF, double beta, double lambda, const double *d_weight, double *d_acc, int64_t B, void *stream) {
+  return run_fused(g, 1, d_K, ks, kc, d_T, ts, tc, kF, beta, lambda, nullptr, 0, 0, d_weight, d_acc, B, stream);
 }
 
 int fdg_fill_uniform_device(double *d_leaf, int64_t B, uint32_t L, int64_t ss, int64_t ls, uint64_t seed,

@@ -226,6 +226,25 @@ int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t 
                          int64_t t_comp_stride, double *d_leaf, int64_t leaf_sample_stride,
                          int64_t leaf_leaf_stride, int64_t n_sample, void *stream);
 
+/* Fused Monte-Carlo step (the integrand of example/benchmark.jl:58-87 in one kernel):
+ * the leaves are worked out in registers from the sample's loop momenta K and times T with the formulas
+ * of fdg_leaf_eval_device and fed straight into the graph, so the 8*L bytes per evaluation of the leaf
+ * matrix never exist.  fdg_graph_specialize_fused JIT-compiles the kernel for (graph, tables) -- tables as
+ * for fdg_leaf_eval_device, n_leaf equal to the graph's, leaves without a formula (type 0) are 1.0 like
+ * leafstates' initial leafValue; needs no device -- then
+ *   fdg_mc_eval_device       root[b][k]           (strides as in fdg_eval_device)
+ *   fdg_mc_accumulate_device acc[k] += sum_b weight[b] * root_k(b)   (weight NULL = 1)
+ * with K, T laid out as in fdg_leaf_eval_device.  Compiler-scheduled (HIP source through hiprtc): meant
+ * for graphs of up to a few thousand nodes; larger ones run faster as fdg_leaf_eval_device +
+ * fdg_accumulate_device on the FDG_SPEC_ISA back end. */
+int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const char *cache_dir, unsigned flags);
+int fdg_mc_eval_device(fdg_graph *g, const double *d_K, int64_t k_sample_stride, int64_t k_comp_stride, const double *d_T,
+                       int64_t t_sample_stride, int64_t t_comp_stride, double kF, double beta, double lambda,
+                       double *d_root, int64_t root_sample_stride, int64_t root_root_stride, int64_t n_sample, void *stream);
+int fdg_mc_accumulate_device(fdg_graph *g, const double *d_K, int64_t k_sample_stride, int64_t k_comp_stride, const double *d_T,
+                             int64_t t_sample_stride, int64_t t_comp_stride, double kF, double beta, double lambda,
+                             const double *d_weight, double *d_acc, int64_t n_sample, void *stream);
+
 /* Device workspace control: the interpreter keeps per-sample overflow slots in
  * an HBM panel owned by the handle; it is sized on first use for the number of
  * resident waves.  This releases it (and any loaded module). */

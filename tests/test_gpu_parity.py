@@ -438,3 +438,49 @@ def test_many_roots_accumulate_and_eval(libfdg, cuda):
         torch.cuda.synchronize()
         wn = w.cpu().numpy()[:, None]
         assert np.all(np.abs(acc.cpu().numpy() - (want * wn).sum(0)) <= TOL * np.maximum(1.0, np.abs(want * wn).sum(0)))
+
+
+def test_fused_mc_step(libfdg, cuda):
+    """SURVEY.md 8f row 3, fused: leaves worked out in registers from (K, T) and fed to the graph in one kernel.
+    Roots equal, bit for bit, those of the unfused route (fdg_leaf_eval_device -> evaluator) and agree with the
+    oracle chain (numpy leaves -> oracle graph) to 1e-12 of the roots' term scale; accumulate likewise."""
+    import torch
+    z = np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz"))
+    t = workloads.get("gv_sigma4")
+    L, R = t.n_leaf, t.n_root
+    B, dim, n_loop, n_tau = 70_001, 3, int(z["basis"].shape[1]), int(z["n_tau"])
+    kF, beta, lam = 1.919, 3.0, 1.2
+    rng = np.random.default_rng(7)
+    K = rng.uniform(-2.0, 2.0, size=(B, n_loop, dim))
+    T = rng.uniform(0.0, beta, size=(B, n_tau))
+    T[:, 0] = 0.0
+    dK = torch.from_numpy(np.ascontiguousarray(K.reshape(B, n_loop * dim).T)).to(cuda)
+    dT = torch.from_numpy(np.ascontiguousarray(T.T)).to(cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
+    # unfused route
+    leaf = torch.ones((L, B), dtype=torch.float64, device=cuda).t()
+    capi.leaf_eval_device(*args, kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf.data_ptr(), leaf.stride(0), leaf.stride(1), B, st)
+    f = fd.compile_table(t, specialize="isa")
+    want_dev = f(None, leaf)
+    # fused
+    tab, _keep = capi.make_leaf_tables(*args)
+    h = capi.GraphHandle(t)
+    h.specialize_fused(tab)
+    root = torch.full((B, R), -5.0, dtype=torch.float64, device=cuda)
+    h.mc_eval_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, root.data_ptr(), R, 1, B, st)
+    torch.cuda.synchronize()
+    assert torch.equal(root, want_dev)
+    h_leaf = oracle.leaf_values(*args[:6], K, T, kF, beta, lam)
+    want = oracle.eval_static(t, h_leaf)
+    scale = oracle.root_scale(t, h_leaf)
+    assert np.all(np.abs(root.cpu().numpy() - want) <= 1e-12 * np.maximum(1.0, scale))
+    w = torch.rand(B, dtype=torch.float64, device=cuda)
+    acc = torch.zeros(R, dtype=torch.float64, device=cuda)
+    h.mc_accumulate_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, w.data_ptr(), acc.data_ptr(), B, st)
+    torch.cuda.synchronize()
+    wr = (want_dev * w[:, None]).cpu().numpy()
+    assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0)))
+    # a handle without the fused kernel says so
+    with pytest.raises(capi.FdgError):
+        capi.GraphHandle(t).mc_eval_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, root.data_ptr(), R, 1, B, st)
