@@ -227,3 +227,48 @@ function reduce_device!(c::Comm, d_acc::Ptr{Float64}, n::Integer; root::Integer=
                      c.handle, d_acc, UInt32(n), Cint(root), stream))
     return nothing
 end
+
+# ---- fused Monte-Carlo step: leaves from (K, T) in registers, then the graph (include/fdg.h) --------- #
+struct _FdgLeafTables
+    n_leaf::UInt32
+    n_basis::UInt32
+    n_loop::UInt32
+    dim::UInt32
+    n_tau::UInt32
+    leaf_type::Ptr{Int32}
+    leaf_order::Ptr{Int32}
+    tau_in::Ptr{Int32}
+    tau_out::Ptr{Int32}
+    loop_index::Ptr{Int32}
+    basis::Ptr{Float64}
+    kF::Float64
+    beta::Float64
+    lambda::Float64
+end
+
+"""
+    specialize_fused!(f, leafType, leafOrder, leafInTau, leafOutTau, leafLoopIndex, loopbasis; dim=3, n_tau)
+
+`leaf*` are one partition of `FrontEnds.leafstates` (1-based indices, `leafOrder` the order of the leaf's own kind),
+`loopbasis` its deduplicated basis (`n_loop × n_basis`, columns as returned).  After this,
+`mc_accumulate_device!(f, d_K, d_T, d_weight, d_acc, B; kF, beta, lambda)` runs leaves + graph + weighted sum in one kernel.
+"""
+function specialize_fused!(f::GraphFunc, leafType::Vector{Int}, leafOrder::Vector{Int}, leafInTau::Vector{Int}, leafOutTau::Vector{Int},
+    leafLoopIndex::Vector{Int}, loopbasis::Matrix{Float64}; dim::Int=3, n_tau::Int, cache_dir::String=get(ENV, "FDG_CACHE_DIR", "/tmp/fdg-cache"))
+    a = [Int32.(v) for v in (leafType, leafOrder, leafInTau, leafOutTau, leafLoopIndex)]
+    bs = Matrix{Float64}(loopbasis)      # column-major n_loop × n_basis == row-major [n_basis][n_loop]
+    GC.@preserve a bs begin
+        tab = _FdgLeafTables(length(a[1]), size(bs, 2), size(bs, 1), dim, n_tau, pointer(a[1]), pointer(a[2]), pointer(a[3]),
+            pointer(a[4]), pointer(a[5]), pointer(bs), 0.0, 0.0, 0.0)
+        _fdg_check(ccall((:fdg_graph_specialize_fused, _libfdg), Cint, (Ptr{Cvoid}, Ref{_FdgLeafTables}, Cstring, Cuint), f.handle, tab, cache_dir, Cuint(0)))
+    end
+    return f
+end
+
+function mc_accumulate_device!(f::GraphFunc, d_K::Ptr{Float64}, d_T::Ptr{Float64}, d_weight::Ptr{Float64}, d_acc::Ptr{Float64}, B::Integer;
+    kF::Float64, beta::Float64, lambda::Float64, k_strides=(1, B), t_strides=(1, B), stream::Ptr{Cvoid}=C_NULL)
+    _fdg_check(ccall((:fdg_mc_accumulate_device, _libfdg), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64, Float64, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Cvoid}),
+        f.handle, d_K, k_strides[1], k_strides[2], d_T, t_strides[1], t_strides[2], kF, beta, lambda, d_weight, d_acc, B, stream))
+    return nothing
+end
