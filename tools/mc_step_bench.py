@@ -6,9 +6,18 @@ import feynmandiagram_jl_amd as fd
 from feynmandiagram_jl_amd import capi, workloads
 dev = torch.device("cuda:0")
 GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-z = np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz"))
-t = workloads.get("gv_sigma4"); L = t.n_leaf
-B, dim, n_loop, n_tau = 1 << 22, 3, int(z["basis"].shape[1]), int(z["n_tau"])
+z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
+name = sys.argv[1] if len(sys.argv) > 1 else "gv_sigma4"
+t = workloads.get(name); L = t.n_leaf
+if name == "gv_sigma4_taylor2":
+    # leaves of the Taylor-expanded graph = (leaf of the 4-loop graph, derivative order in the coupling)
+    zt = np.load(os.path.join(GOLD, "gv_sigma4_taylor2.npz"))
+    base, dord = zt["leaf_base"], zt["leaf_dorder"]
+    for k in ("leaf_type", "tau_in", "tau_out", "loop_index"):
+        z[k] = z[k][base]
+    z["leaf_order"] = np.where(z["leaf_type"] == 2, dord, 0).astype(np.int32)
+    assert np.all(dord[z["leaf_type"] == 1] == 0)
+B, dim, n_loop, n_tau = (1 << 22) if name == "gv_sigma4" else 2_000_000, 3, int(z["basis"].shape[1]), int(z["n_tau"])
 kF, beta, lam = 1.919, 3.0, 1.2
 dK = (torch.rand((n_loop * dim, B), dtype=torch.float64, device=dev) * 4 - 2)
 dT = torch.rand((n_tau, B), dtype=torch.float64, device=dev) * beta
@@ -34,7 +43,7 @@ print(f"table-driven leaf kernel: {tg:.3f} ms")
 tl = timeit(leaves); te = timeit(lambda: f.accumulate(leaf, w, acc))
 def both(): leaves(); f.accumulate(leaf, w, acc)
 tb = timeit(both)
-print(f"gv_sigma4 B={B}: leaves {tl:.3f} ms ({B/tl*1e3:.3e}/s, {B*L*8/tl/1e6:.0f} GB/s written), eval+accumulate {te:.3f} ms ({B/te*1e3:.3e}/s), whole step {tb:.3f} ms = {B/tb*1e3:.3e} samples/s")
+print(f"{name} B={B}: leaves {tl:.3f} ms ({B/tl*1e3:.3e}/s, {B*L*8/tl/1e6:.0f} GB/s written), eval+accumulate {te:.3f} ms ({B/te*1e3:.3e}/s), whole step {tb:.3f} ms = {B/tb*1e3:.3e} samples/s")
 
 # fused kernel (leaves in registers)
 tab, _keep = capi.make_leaf_tables(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
