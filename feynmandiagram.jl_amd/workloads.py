@@ -26,7 +26,7 @@ from .nodetable import NodeTable, OP_POWER, OP_PROD, from_program, synthetic_par
 
 PREBUILT = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "sigma4_taylor_standin", "gv_sigma4",
             "gv_sigma5", "gv_sigma6", "gv_sigma4_taylor2", "gv_sigma5_taylor2")
-PREBUILT_HIP = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "sigma4_taylor_standin", "gv_sigma5")
+PREBUILT_HIP = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma5", "gv_sigma4_taylor2")
 
 
 @functools.lru_cache(maxsize=None)
