@@ -243,3 +243,32 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(capi.FdgLibraryMissing, match="no CPU fallback"):
         capi.lib()
+
+
+def test_fused_step_specializes_without_device(libfdg, tmp_path):
+    """fdg_graph_specialize_fused is host-only (hiprtc cross-compiles): the generated source carries the leaf
+    formulas of example/benchmark.jl and the graph body; table/graph mismatches are rejected; the run entry
+    points refuse a handle that was not specialised."""
+    import numpy as np
+    from feynmandiagram_jl_amd import workloads
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(gold, "gv_sigma4_leafstates.npz"))
+    t = workloads.get("gv_sigma4")
+    h = capi.GraphHandle(t)
+    tab, keep = capi.make_leaf_tables(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]))
+    h.specialize_fused(tab, str(tmp_path), capi.FDG_SPEC_KEEP_SOURCE)
+    files = os.listdir(tmp_path)
+    assert any(f.startswith("fdg_fused_") and f.endswith(".hsaco") for f in files)
+    src = open(os.path.join(tmp_path, [f for f in files if f.endswith(".hip")][0])).read()
+    assert "fdg_spec_fused" in src and src.count("exp(") >= 89 and "den = 1.0 + exp(-fabs(w) * beta)" in src
+    assert f"const double g{t.n_leaf} = " in src                       # first internal node follows the leaves
+    small = capi.GraphHandle(workloads.get("sigma2"))
+    with pytest.raises(capi.FdgError) as e:
+        small.specialize_fused(tab, str(tmp_path))
+    assert e.value.code == capi.FDG_E_INVALID
+    bad = z["leaf_type"].copy()
+    bad[0] = 7
+    tab2, keep2 = capi.make_leaf_tables(bad, z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]))
+    with pytest.raises(capi.FdgError) as e:
+        h.specialize_fused(tab2, str(tmp_path))
+    assert e.value.code == capi.FDG_E_UNSUPPORTED                     # "this leaftype ... not implemented!" (benchmark.jl:79)
