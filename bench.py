@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--layout", default="leaf_major", choices=["sample_major", "leaf_major"],
                     help="leaf_major = a Julia column-major B x L matrix (the host language's native layout); "
                          "sample_major = compile_Python's row-major [B, L]")
-    ap.add_argument("--backend", default="isa", choices=["isa", "isa-autotune", "hip", "interp"],
+    ap.add_argument("--backend", default="isa", choices=["isa", "isa-autotune", "auto", "hip", "interp"],
                     help="isa: optimizing back end, gfx950 assembly; hip: straight-line HIP source via hiprtc; interp: table interpreter")
     ap.add_argument("--interp", action="store_true", help="same as --backend interp")
     ap.add_argument("--comm", default="torch", choices=["torch", "fdg"],
@@ -74,7 +74,7 @@ def main():
     B = args.samples or default_B
     if args.interp:
         args.backend = "interp"
-    f = fd.compile_table(t, specialize={"isa": "isa", "isa-autotune": "isa-autotune", "hip": True, "interp": False}[args.backend])
+    f = fd.compile_table(t, specialize={"isa": "isa", "isa-autotune": "isa-autotune", "auto": "auto", "hip": True, "interp": False}[args.backend])
     if args.backend == "isa-autotune":
         args.backend = "isa"
 
@@ -143,6 +143,7 @@ def main():
                    "flops_per_eval": st["flops_alg"], "bytes_per_eval": st["bytes_alg"],
                    "samples_per_step_per_gpu": B, "layout": args.layout,
                    "kernel": {"isa": "fdg_isa_eval (per-graph gfx950 assembly)", "hip": "fdg_spec (per-graph HIP source, hiprtc)",
+                              "auto": "fdg_isa_eval, or its HIP-source companion fdg_spec_sm for row-major input of small graphs",
                               "interp": "fdg_interp (table interpreter)"}[args.backend],
                    "parallelism": f"samples sharded x{world}, one all-reduce of {R} doubles"},
     }
@@ -151,7 +152,7 @@ def main():
         achieved = bytes_per_launch / avg_kernel_s / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                           "kernel": {"isa": "fdg_isa_eval", "interp": "fdg_interp",
+                           "kernel": {"isa": "fdg_isa_eval", "interp": "fdg_interp", "auto": "fdg_isa_eval / fdg_spec_sm",
                                       "hip": "fdg_spec_sm" if args.layout == "sample_major" else "fdg_spec_gen"}[args.backend],
                            "avg_kernel_ms": avg_kernel_s * 1e3,
                            "algorithmic_bytes_per_launch": bytes_per_launch}

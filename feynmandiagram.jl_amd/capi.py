@@ -23,6 +23,7 @@ KERNEL_CACHE = os.path.join(_HERE, "kernel_cache")
 FDG_OK = 0
 FDG_E_INVALID, FDG_E_UNSUPPORTED, FDG_E_NO_DEVICE, FDG_E_NOMEM, FDG_E_JIT, FDG_E_INTERNAL = -1, -2, -3, -4, -5, -6
 FDG_SPEC_DEFAULT, FDG_SPEC_KEEP_SOURCE, FDG_SPEC_FAST_MATH, FDG_SPEC_ISA, FDG_SPEC_AUTOTUNE = 0, 1, 2, 4, 8
+FDG_SPEC_ROW_MAJOR_COMPANION = 16
 
 EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",

@@ -98,6 +98,9 @@ struct fdg_graph {
   bool has_acc = false;
   void *fn_isa_acc = nullptr;
   uint32_t isa3_vgpr = 0, isa3_lds_bytes = 0, isa3_mem_slots = 0;
+  // companion HIP-source kernels of an ISA-specialised handle, used for sample-major input (FDG_SPEC_ROW_MAJOR_COMPANION)
+  std::vector<char> alt_code;
+  void *alt_module = nullptr, *fn_alt_sm = nullptr, *fn_alt_gen = nullptr;
   // fused Monte-Carlo step: leaves computed in registers from (K, T), then the graph (HIP-source JIT)
   std::vector<char> fused_code;
   void *fused_module = nullptr, *fn_fused = nullptr;

@@ -401,6 +401,31 @@ static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t
   return run_locked(g, mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st);
 }
 
+// launch of the compiler-scheduled per-graph kernels (fdg_spec_sm / fdg_spec_gen)
+static int launch_hip_source(fdg_graph *g, hipFunction_t fn, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
+                             int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st) {
+  const uint32_t R = g->prog.R;
+  const long nblk = (long)((B + 255) / 256);
+  const long grid = std::min<long>(nblk, (long)g->n_cu * 8);
+  double *partial = nullptr;
+  if (mode == 1) {
+    int rc = ensure_ws(g, (size_t)grid * R * sizeof(double));
+    if (rc) return rc;
+    partial = (double *)g->d_ws;
+  }
+  long a_ss = ss, a_ls = ls, a_rs = rs, a_rk = rk, a_B = B;
+  int a_mode = mode;
+  void *args[] = {(void *)&d_leaf, &a_ss, &a_ls, (void *)&d_root, &a_rs, &a_rk, (void *)&d_weight,
+                  (void *)&partial, &a_B, &a_mode};
+  HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, st, args, nullptr));
+  if (mode == 1) {
+    hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial,
+                       (uint32_t)grid, R, d_acc);
+    HIP_TRY(hipGetLastError());
+  }
+  return FDG_OK;
+}
+
 static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
                       int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st) {
   int rc = ensure_device(g);
@@ -409,6 +434,18 @@ static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, 
   const long nblk = (long)((B + 255) / 256);
   const uint32_t R = p.R;
 
+  if (!g->code_object.empty() && g->isa && !g->alt_code.empty() && ls == 1 && ss != 1 && p.L > 1) {
+    // sample-major input and a companion: its lanes read their own rows; no transposition pass
+    if (!g->alt_module) {
+      hipModule_t m; hipFunction_t f1, f2;
+      hipError_t e = hipModuleLoadData(&m, g->alt_code.data());
+      if (e != hipSuccess) { set_error("hipModuleLoadData failed: " + std::string(hipGetErrorString(e))); return FDG_E_JIT; }
+      HIP_TRY(hipModuleGetFunction(&f1, m, "fdg_spec_sm"));
+      HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_spec_gen"));
+      g->alt_module = m; g->fn_alt_sm = f1; g->fn_alt_gen = f2;
+    }
+    return launch_hip_source(g, (hipFunction_t)g->fn_alt_sm, mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st);
+  }
   if (!g->code_object.empty() && g->isa) {
     rc = ensure_module(g);
     if (rc) return rc;
@@ -547,25 +584,8 @@ static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, 
   if (!g->code_object.empty()) {
     rc = ensure_module(g);
     if (rc) return rc;
-    const long grid = std::min<long>(nblk, (long)g->n_cu * 8);
-    double *partial = nullptr;
-    if (mode == 1) {
-      rc = ensure_ws(g, (size_t)grid * R * sizeof(double));
-      if (rc) return rc;
-      partial = (double *)g->d_ws;
-    }
-    hipFunction_t fn = (hipFunction_t)((ls == 1) ? g->fn_eval_sm : g->fn_eval_gen);
-    long a_ss = ss, a_ls = ls, a_rs = rs, a_rk = rk, a_B = B;
-    int a_mode = mode;
-    void *args[] = {(void *)&d_leaf, &a_ss, &a_ls, (void *)&d_root, &a_rs, &a_rk, (void *)&d_weight,
-                    (void *)&partial, &a_B, &a_mode};
-    HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, st, args, nullptr));
-    if (mode == 1) {
-      hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial,
-                         (uint32_t)grid, R, d_acc);
-      HIP_TRY(hipGetLastError());
-    }
-    return FDG_OK;
+    return launch_hip_source(g, (hipFunction_t)((ls == 1) ? g->fn_eval_sm : g->fn_eval_gen), mode, d_leaf, ss, ls, d_root, rs, rk,
+                             d_weight, d_acc, B, st);
   }
 
   // interpreter
@@ -847,6 +867,7 @@ int fdg_graph_release_device(fdg_graph *g) {
   }
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; g->fn_eval_sm = g->fn_eval_gen = nullptr; g->fn_isa = nullptr; }
   if (g->fused_module) { hipModuleUnload((hipModule_t)g->fused_module); g->fused_module = nullptr; g->fn_fused = nullptr; }
+  if (g->alt_module) { hipModuleUnload((hipModule_t)g->alt_module); g->alt_module = nullptr; g->fn_alt_sm = g->fn_alt_gen = nullptr; }
   return FDG_OK;
 }
 
@@ -1216,7 +1237,9 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
     mkdir(dir0.c_str(), 0777);
     return specialize_isa(g, dir0, flags);
   }
-  g->isa = false;
+  const bool companion = (flags & FDG_SPEC_ROW_MAJOR_COMPANION) != 0;
+  if (companion && !(g->isa && !g->code_object.empty())) { set_error("FDG_SPEC_ROW_MAJOR_COMPANION needs a handle already specialised with FDG_SPEC_ISA"); return FDG_E_INVALID; }
+  if (!companion) g->isa = false;
   const bool fast = (flags & FDG_SPEC_FAST_MATH) != 0;
   const std::string src = emit_hip_source(g->prog, flags);
   char hbuf[40];
@@ -1244,6 +1267,13 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
     }
   }
   if ((flags & FDG_SPEC_KEEP_SOURCE)) write_file(base + ".hip", src.c_str(), src.size());
+  if (companion) {
+    if (g->alt_module) { hipModuleUnload((hipModule_t)g->alt_module); g->alt_module = nullptr; }
+    g->alt_code.swap(co);
+    return FDG_OK;
+  }
+  g->alt_code.clear();
+  if (g->alt_module) { hipModuleUnload((hipModule_t)g->alt_module); g->alt_module = nullptr; }
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
   g->code_object.swap(co);
   g->spec_source_hash = hbuf;

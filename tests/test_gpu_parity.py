@@ -486,3 +486,27 @@ def test_fused_mc_step(libfdg, cuda):
     # a handle without the fused kernel says so
     with pytest.raises(capi.FdgError):
         capi.GraphHandle(t).mc_eval_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, root.data_ptr(), R, 1, B, st)
+
+
+def test_auto_backend_row_major_companion(libfdg, cuda):
+    """compile(..., "auto") on a small graph keeps the HIP-source kernels next to the ISA ones and evaluates
+    row-major [B, L] input (compile_Python's layout) with them; both layouts and accumulate give the oracle's bits."""
+    import torch
+    for name in ("sigma2", "gv_sigma4"):
+        t = workloads.get(name)
+        f = fd.compile_table(t, specialize="auto")
+        B = 100_003
+        for layout in ("sample_major", "leaf_major", "padded"):
+            leaf = dev_leaves(cuda, B, t.n_leaf, 21, 0, layout)
+            want = oracle.eval_static(t, leaf.cpu().numpy())
+            assert np.array_equal(run(f, leaf), want), (name, layout)
+        leaf = dev_leaves(cuda, B, t.n_leaf, 21, 0, "sample_major")
+        w = torch.rand(B, dtype=torch.float64, device=cuda)
+        acc = f.accumulate(leaf, w)
+        torch.cuda.synchronize()
+        wr = want * w.cpu().numpy()[:, None]
+        assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0)))
+    # the flag needs an ISA-specialised handle
+    h = capi.GraphHandle(workloads.get("sigma2"))
+    with pytest.raises(capi.FdgError):
+        h.specialize(None, capi.FDG_SPEC_ROW_MAJOR_COMPANION)
