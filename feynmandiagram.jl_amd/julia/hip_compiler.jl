@@ -150,7 +150,7 @@ function compile_hip(graphs::AbstractVector{<:AbstractGraph};
         rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, flags)
         if rc == -2 && backend == :isa      # FDG_E_UNSUPPORTED: e.g. Power{N}, N > 3 -> HIP-source JIT
             rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, Cuint(0))
-        elseif rc == 0 && backend == :isa && length(child_idx) <= 4000
+        elseif rc == 0 && backend == :isa && length(idx) <= 4000 && L <= 256
             # small graph: HIP-source companion for row-major [B, L] input (FDG_SPEC_ROW_MAJOR_COMPANION = 16)
             rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, Cuint(16))
         end
