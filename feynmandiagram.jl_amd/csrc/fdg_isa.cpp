@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <sstream>
 
 #include "fdg_opt.h"
@@ -30,7 +31,10 @@ constexpr int S_LEAF = 4, S_SS = 6, S_LS = 8, S_ROOT = 10, S_RS = 12, S_RK = 14,
 constexpr int S_TILE = 22, S_NTILES = 23, S_LT = 24, S_RT = 26, S_PANEL = 28, S_LS8 = 30, S_RK8 = 32, S_A = 34,
               S_T = 36, S_C = 38, S_X = 40;  // S_X.. : scratch (4)
 constexpr int S_WGT = 44;
-constexpr int S_END = 48;
+constexpr int S_LP = 48;     // running pointer: column of the most recently loaded leaf in this tile
+constexpr int S_DELTA = 50;  // up to N_DELTA pairs: (leaf stride in bytes) x the most frequent index steps between consecutive loads
+constexpr int N_DELTA = 6;
+constexpr int S_END = S_DELTA + 2 * N_DELTA;
 
 struct Emit {
   std::ostringstream os;
@@ -160,6 +164,28 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("v_lshlrev_b32_e32 " + V(V_ROOTOFF) + ", " + std::to_string(W == 2 ? 4 : 3) + ", " + V(V_ROOTOFF));
   E.ins("s_lshl_b64 " + S2(S_LS8) + ", " + S2(S_LS) + ", 3");
   E.ins("s_lshl_b64 " + S2(S_RK8) + ", " + S2(S_RK) + ", 3");
+  // Leaf addresses: consecutive loads mostly step by +1 leaf (leaves are numbered in first-visit order and
+  // the schedule visits them nearly in that order), so the column pointer is advanced by an add of the
+  // stride (2 scalar ops) instead of being rebuilt from the leaf index (6); the next most frequent positive
+  // steps get their stride multiple precomputed once per wave.
+  std::vector<int64_t> delta_tab;
+  {
+    std::map<int64_t, int> hist;
+    int64_t last = -1;
+    for (const MOp &o : prog.ops) if (o.kind == M_LD_LEAF) { if (last >= 0 && (int64_t)o.a - last > 1) hist[(int64_t)o.a - last]++; last = o.a; }
+    std::vector<std::pair<int, int64_t>> v;
+    for (auto &kv : hist) if (kv.second >= 2) v.push_back({kv.second, kv.first});
+    std::sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
+    for (size_t i = 0; i < v.size() && i < (size_t)N_DELTA; ++i) delta_tab.push_back(v[i].second);
+  }
+  for (size_t k = 0; k < delta_tab.size(); ++k) {
+    const int d = S_DELTA + 2 * (int)k;
+    const std::string ks = hex32((uint32_t)delta_tab[k]);
+    E.ins("s_mul_i32 " + S(d) + ", " + S(S_LS8) + ", " + ks);
+    E.ins("s_mul_hi_u32 " + S(d + 1) + ", " + S(S_LS8) + ", " + ks);
+    E.ins("s_mul_i32 " + S(S_X) + ", " + S(S_LS8 + 1) + ", " + ks);
+    E.ins("s_add_u32 " + S(d + 1) + ", " + S(d + 1) + ", " + S(S_X));
+  }
   // ntiles = ceil(B / tile)   (W = 2 is only launched on a multiple of 128 samples)
   E.ins("s_add_u32 " + S(S_X) + ", " + S(S_B) + ", " + std::to_string((1 << TSH) - 1));
   E.ins("s_addc_u32 " + S(S_X + 1) + ", " + S(S_B + 1) + ", 0");
@@ -228,13 +254,28 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   };
 
   // ---- body ------------------------------------------------------------------
+  int64_t last_leaf = -1;
   for (const MOp &o : prog.ops) {
     switch (o.kind) {
       case M_LD_LEAF:
         if (dbg_noleaf) break;   // timing experiments only (results are garbage)
         E.wait_reg(o.d);
-        emit_scaled_addr(E, S_A, S_LT, S_LS8, o.a);
-        E.ins(LD + vall(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_A));
+        {
+          const int64_t step = last_leaf >= 0 ? (int64_t)o.a - last_leaf : 0;
+          int dreg = -1;
+          if (last_leaf >= 0 && step == 1) dreg = S_LS8;
+          for (size_t k = 0; k < delta_tab.size() && last_leaf >= 0; ++k) if (delta_tab[k] == step) dreg = S_DELTA + 2 * (int)k;
+          if (last_leaf >= 0 && step == 0) {
+            // same column again: pointer already there
+          } else if (dreg >= 0) {
+            E.ins("s_add_u32 " + S(S_LP) + ", " + S(S_LP) + ", " + S(dreg));
+            E.ins("s_addc_u32 " + S(S_LP + 1) + ", " + S(S_LP + 1) + ", " + S(dreg + 1));
+          } else {
+            emit_scaled_addr(E, S_LP, S_LT, S_LS8, o.a);
+          }
+          last_leaf = o.a;
+        }
+        E.ins(LD + vall(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_LP));
         E.pend[o.d] = {1, ++E.vm_issued};
         break;
       case M_LD_MEM: {

@@ -482,6 +482,25 @@ void hoist_loads(std::vector<MOp> &ops, const OptParams &prm) {
   ops.swap(r);
 }
 
+// Runs of back-to-back leaf loads (the burst at the start of a tile, groups hoisted to the same point) are
+// independent of each other: issue them in ascending leaf order, so that the kernel's column pointer mostly
+// advances by one stride (two scalar ops) instead of being rebuilt (six).
+void sort_load_runs(std::vector<MOp> &ops) {
+  size_t i = 0;
+  while (i < ops.size()) {
+    if (ops[i].kind != M_LD_LEAF) { ++i; continue; }
+    size_t j = i;
+    while (j < ops.size() && ops[j].kind == M_LD_LEAF) ++j;
+    if (j - i >= 2) {
+      bool distinct = true;
+      for (size_t a = i; a < j && distinct; ++a)
+        for (size_t b = a + 1; b < j; ++b) if (ops[a].d == ops[b].d) { distinct = false; break; }
+      if (distinct) std::stable_sort(ops.begin() + i, ops.begin() + j, [](const MOp &x, const MOp &y) { return x.a < y.a; });
+    }
+    i = j;
+  }
+}
+
 }  // namespace
 
 void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) {
@@ -507,6 +526,7 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   A.run();
   out.ops.swap(A.out);
   hoist_loads(out.ops, prm);
+  sort_load_runs(out.ops);
 }
 
 }  // namespace fdg
