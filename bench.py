@@ -156,6 +156,25 @@ def main():
                                       "hip": "fdg_spec_sm" if args.layout == "sample_major" else "fdg_spec_gen"}[args.backend],
                            "avg_kernel_ms": avg_kernel_s * 1e3,
                            "algorithmic_bytes_per_launch": bytes_per_launch}
+        # the box's own streaming ceiling next to the 8 TB/s spec: a 2 GiB device-to-device copy,
+        # read + write counted, outside the timed region
+        try:
+            a = torch.empty(1 << 28, dtype=torch.float64, device=dev)
+            b = torch.empty_like(a)
+            for _ in range(2):
+                b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            out["roofline"]["measured_copy_gbs"] = copy_gbs
+            out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+            del a, b
+        except RuntimeError:
+            pass
         # HBM traffic per launch: measured separately with rocprofv3 --pmc (bench.py cannot collect
         # counters on itself); profiles/r01_traffic.json holds bytes per evaluation for the default configs
         try:
