@@ -34,7 +34,9 @@ constexpr int S_WGT = 44;
 constexpr int S_LP = 48;     // running pointer: column of the most recently loaded leaf in this tile
 constexpr int S_DELTA = 50;  // up to N_DELTA pairs: (leaf stride in bytes) x the most frequent index steps between consecutive loads
 constexpr int N_DELTA = 6;
-constexpr int S_END = S_DELTA + 2 * N_DELTA;
+constexpr int S_POOL = S_DELTA + 2 * N_DELTA;   // constants of the graph (edge factors without an inline encoding), loaded once per wave
+constexpr int N_POOL = 16;
+constexpr int S_END = S_POOL + 2 * N_POOL;
 
 struct Emit {
   std::ostringstream os;
@@ -64,6 +66,12 @@ struct Emit {
       if (lg_done < p.second) lg_done = p.second;
     }
     p.first = 0;
+  }
+  void wait_vm(uint64_t seq) {
+    if (seq <= vm_done) return;
+    uint64_t n = std::min<uint64_t>(vm_issued - seq, 63);
+    ins("s_waitcnt vmcnt(" + std::to_string(n) + ")");
+    vm_done = std::max(std::max(vm_done, vm_issued - n), seq);
   }
   void drain() {
     ins("s_waitcnt vmcnt(0) lgkmcnt(0)");
@@ -186,6 +194,24 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("s_mul_i32 " + S(S_X) + ", " + S(S_LS8 + 1) + ", " + ks);
     E.ins("s_add_u32 " + S(d + 1) + ", " + S(d + 1) + ", " + S(S_X));
   }
+  // Edge factors that have no inline encoding: a graph uses a handful of distinct ones (spin / symmetry
+  // factors), so they live in SGPR pairs for the whole kernel instead of being moved in before every use.
+  std::vector<uint64_t> pool;
+  {
+    std::map<uint64_t, int> hist;
+    for (const MOp &o : prog.ops) if (o.kind == M_MULC) {
+      bool inl; f64_inline(o.imm, inl);
+      if (!inl) { uint64_t u; std::memcpy(&u, &o.imm, 8); hist[u]++; }
+    }
+    std::vector<std::pair<int, uint64_t>> v;
+    for (auto &kv : hist) v.push_back({kv.second, kv.first});
+    std::sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
+    for (size_t i = 0; i < v.size() && i < (size_t)N_POOL; ++i) pool.push_back(v[i].second);
+  }
+  for (size_t k = 0; k < pool.size(); ++k) {
+    E.ins("s_mov_b32 " + S(S_POOL + 2 * (int)k) + ", " + hex32((uint32_t)pool[k]));
+    E.ins("s_mov_b32 " + S(S_POOL + 2 * (int)k + 1) + ", " + hex32((uint32_t)(pool[k] >> 32)));
+  }
   // ntiles = ceil(B / tile)   (W = 2 is only launched on a multiple of 128 samples)
   E.ins("s_add_u32 " + S(S_X) + ", " + S(S_B) + ", " + std::to_string((1 << TSH) - 1));
   E.ins("s_addc_u32 " + S(S_X + 1) + ", " + S(S_B + 1) + ", 0");
@@ -255,7 +281,33 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
 
   // ---- body ------------------------------------------------------------------
   int64_t last_leaf = -1;
+  // One s_waitcnt can serve several consumers: when an op has to wait for a load, the wait also covers what
+  // the next few ops need of the loads issued so far (they complete in order and were issued long before,
+  // so this costs nothing and saves issue slots).
+  const char *wl_env = std::getenv("FDG_ISA_WAIT_LOOKAHEAD");
+  const size_t wait_look = wl_env ? (size_t)std::max(0, std::atoi(wl_env)) : 6;
+  auto vm_seq_needed = [&](const MOp &q) -> uint64_t {
+    uint64_t sq = 0;
+    auto use = [&](uint32_t r) { if (r < E.pend.size() && E.pend[r].first == 1) sq = std::max(sq, E.pend[r].second); };
+    switch (q.kind) {
+      case M_LD_LEAF: case M_LD_LDS: case M_LD_MEM: case M_LD_ACC: use(q.d); break;
+      case M_ST_LDS: case M_ST_MEM: case M_ST_ACC: case M_ROOT: use(q.a); break;
+      case M_MUL: case M_ADD: use(q.a); use(q.b); use(q.d); break;
+      case M_MULC: case M_MOV: use(q.a); use(q.d); break;
+      default: break;
+    }
+    return sq;
+  };
+  size_t op_index = 0;
   for (const MOp &o : prog.ops) {
+    {
+      const size_t i = op_index++;
+      uint64_t need = vm_seq_needed(o);
+      if (need > E.vm_done && wait_look) {
+        for (size_t j = i + 1; j < prog.ops.size() && j <= i + wait_look; ++j) need = std::max(need, vm_seq_needed(prog.ops[j]));
+        E.wait_vm(need);
+      }
+    }
     switch (o.kind) {
       case M_LD_LEAF:
         if (dbg_noleaf) break;   // timing experiments only (results are garbage)
@@ -319,9 +371,15 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         if (!inl) {
           uint64_t u;
           std::memcpy(&u, &o.imm, 8);
-          E.ins("s_mov_b32 " + S(S_C) + ", " + hex32((uint32_t)u));
-          E.ins("s_mov_b32 " + S(S_C + 1) + ", " + hex32((uint32_t)(u >> 32)));
-          c = S2(S_C);
+          int slot = -1;
+          for (size_t k = 0; k < pool.size(); ++k) if (pool[k] == u) slot = (int)k;
+          if (slot >= 0) {
+            c = S2(S_POOL + 2 * slot);
+          } else {
+            E.ins("s_mov_b32 " + S(S_C) + ", " + hex32((uint32_t)u));
+            E.ins("s_mov_b32 " + S(S_C + 1) + ", " + hex32((uint32_t)(u >> 32)));
+            c = S2(S_C);
+          }
         }
         valu2("v_mul_f64 ", o, c, c);
         break;
