@@ -26,8 +26,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6    # AMD spec, FMA counted as 2 (not in the local g
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=25)   # 25 steps x 4e6 samples = config 3's 1e8 samples
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)   # 100 steps x 4e6 samples = 4e8 samples (config 3 names 1e8)
+    ap.add_argument("--warmup", type=int, default=60)   # power management needs ~40 launches (50 ms) to settle: 1.4 -> 1.04 ms per launch
     ap.add_argument("--workload", default="gv_sigma4_taylor2")
     ap.add_argument("--samples", type=int, default=0, help="samples per step per GPU (0 = workload default)")
     ap.add_argument("--layout", default="leaf_major", choices=["sample_major", "leaf_major"],
@@ -82,7 +82,8 @@ def main():
         leaf = torch.empty((B, L), dtype=torch.float64, device=dev)
     else:
         leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
-    root = torch.empty((B, R), dtype=torch.float64, device=dev)
+    root = torch.empty((B, R), dtype=torch.float64, device=dev)   # row-major roots (compile_Python's [B, R]): measured faster than
+    #                                                                  R more column streams for the HBM-bound graphs, equal for the others
     stream = torch.cuda.current_stream()
     # per-rank Philox offset: results do not depend on how samples are sharded
     start, count = shard_range(B * world, rank, world)          # weak scaling: B samples per GPU
@@ -92,9 +93,11 @@ def main():
     def step():
         f(root, leaf)
 
+    step()
+    _ = root.sum(dim=0)                   # load the reduction used for the final observable now: a pause between the
+    torch.cuda.synchronize()              # warm-up and the timed steps would let the clocks fall back
     for _ in range(args.warmup):
         step()
-    _ = root.sum(dim=0)                   # warm the reduction used for the final observable
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
