@@ -113,3 +113,26 @@ struct fdg_graph {
   int device = -1;
   int n_cu = 0;
 };
+
+// ---- shared by the runtime translation units (fdg_runtime.hip, fdg_leaf.hip) -------------------------
+#ifdef FDG_RUNTIME_TU
+#include <hip/hip_runtime.h>
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      fdg::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+      return FDG_E_NO_DEVICE;                                                           \
+    }                                                                                   \
+  } while (0)
+
+int ensure_device(fdg_graph *g);                 // binds the handle to the current gfx950 device
+int ensure_ws(fdg_graph *g, size_t bytes);       // grows the handle's device workspace
+int launch_reduce_partials(const double *partial, uint32_t nblk, uint32_t R, double *acc, hipStream_t st);
+#endif
+namespace fdg { const char *last_error_cstr(); }
+uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull);
+bool read_file(const std::string &path, std::vector<char> &out);
+bool write_file(const std::string &path, const char *data, size_t n);
+int compile_hiprtc(const std::string &src, bool fast, std::vector<char> &co, std::string &log);
+int compile_hipcc(const std::string &src_path, const std::string &out_path, bool fast, std::string &log);

@@ -1,0 +1,368 @@
+// Leaves of the integrand on the device: fdg_leaf_eval_device -- the leaf loop of
+// example/benchmark.jl:58-81,113-127 over the FrontEnds.leafstates tables, table-driven or JIT-specialised to
+// the tables -- and the fused Monte-Carlo step (fdg_graph_specialize_fused, fdg_mc_*_device), where the same
+// leaf code runs in registers in front of the graph body.  gfx950 only; no CPU path.
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <sstream>
+
+#define FDG_RUNTIME_TU 1   // fdg_internal.h then also declares the helpers that need the HIP runtime types
+#include "fdg_internal.h"
+#include "fdg_powi.h"
+
+using namespace fdg;
+
+// Leaf values from (K, T): one lane = one sample; the tables are wave-uniform (scalar loads); the
+// sample's momenta and times are staged once in LDS columns.  The host hands the leaves over sorted by
+// (type, loop-basis index): many propagators carry the same momentum (GV 4-loop self-energy: 89 fermionic
+// leaves, 23 distinct momenta), so q^2, the dispersion and the Fermi denominator are computed once per
+// distinct momentum and only the tau-dependent exponential per leaf.  Same expressions, same order of
+// operations as example/benchmark.jl:113-127 -- evaluated once instead of once per leaf.
+__global__ void __launch_bounds__(64)
+fdg_leaf_kernel(const int32_t *__restrict__ ltype, const int32_t *__restrict__ lorder, const int32_t *__restrict__ tin,
+                const int32_t *__restrict__ tout, const int32_t *__restrict__ lidx, const int32_t *__restrict__ oidx,
+                const double *__restrict__ basis,
+                uint32_t L, uint32_t n_loop, uint32_t dim, uint32_t n_tau, double kF, double beta, double lambda,
+                const double *__restrict__ K, long ks, long kc, const double *__restrict__ T, long ts, long tc,
+                double *__restrict__ leaf, long ss, long ls, long B) {
+  extern __shared__ double sh[];                 // [(n_loop*dim + n_tau)][64]
+  const int t = threadIdx.x;
+  double *kk = sh + t;
+  double *tt = sh + (size_t)n_loop * dim * 64 + t;
+  const long ntile = (B + 63) / 64;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long b0 = tile * 64 + t;
+    const bool valid = b0 < B;
+    const long b = valid ? b0 : B - 1;
+    for (uint32_t c = 0; c < n_loop * dim; ++c) kk[(size_t)c * 64] = K[b * ks + (long)c * kc];
+    for (uint32_t i = 0; i < n_tau; ++i) tt[(size_t)i * 64] = T[b * ts + (long)i * tc];
+    int32_t cur = -1;
+    double q2 = 0.0, w = 0.0, den = 1.0;
+    for (uint32_t i = 0; i < L; ++i) {
+      const int32_t ty = ltype[i];
+      if (ty == 0) continue;
+      if (lidx[i] != cur) {                      // wave-uniform: a new momentum
+        cur = lidx[i];
+        const double *bv = basis + (size_t)(cur - 1) * n_loop;
+        q2 = 0.0;
+        for (uint32_t d = 0; d < dim; ++d) {
+          double q = 0.0;
+          for (uint32_t j = 0; j < n_loop; ++j) q += kk[(size_t)(j * dim + d) * 64] * bv[j];
+          q2 += q * q;
+        }
+        w = q2 - kF * kF;
+        den = 1.0 + exp(-fabs(w) * beta);        // 1 + exp(-w beta) for w > 0, 1 + exp(w beta) otherwise
+      }
+      double v;
+      if (ty == 1) {
+        double tau = tt[(size_t)(tout[i] - 1) * 64] - tt[(size_t)(tin[i] - 1) * 64];
+        if (tau == 0.0) tau = -1e-10;
+        // one exponential per lane: the four cases of green() differ in the argument and the sign only
+        // (lanes of a wave fall into different cases; branching would evaluate exp() once per case)
+        const double a_pos = w > 0.0 ? -w * tau : w * (beta - tau);
+        const double a_neg = w > 0.0 ? -w * (tau + beta) : -w * tau;
+        const double e = exp(tau > 0.0 ? a_pos : a_neg);
+        v = (tau > 0.0 ? e : -e) / den;
+      } else {
+        const double invK = 1.0 / (q2 + lambda);
+        v = 8.0 * 3.141592653589793 / invK * fdg_powi_impl(lambda * invK, lorder[i] == 0 ? 0 : lorder[i]);
+      }
+      if (valid) leaf[b * ss + (long)oidx[i] * ls] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Leaf kernel specialised to one set of leafstates tables (the same JIT route as the graph kernels):
+// indices, the loop basis (almost all entries 0 / +-1) and the leaf order are compile-time constants, so
+// the sample's momenta and times stay in registers, zero coefficients vanish and the compiler schedules the
+// whole straight-line body.  Same expressions in the same order as fdg_leaf_kernel, hence the same bits:
+// skipping q += k * 0.0 and writing k for k * 1.0 cannot change q (only the sign of a zero that is squared).
+// ---------------------------------------------------------------------------
+// `fused` = false: statements store each leaf to leaf[b*ss + i*ls]; true: they assign g<i> (declared here, 1.0 for
+// leaves without a formula: leafstates' initial leafValue) for the graph body that follows.
+static std::string emit_leaf_statements(const fdg_leaf_tables *tab, const std::vector<int32_t> &perm, bool fused) {
+  std::ostringstream os;
+  auto dbl = [&](double f) { char b[64]; std::snprintf(b, sizeof b, "%a", f); return std::string(b); };
+  const uint32_t L = tab->n_leaf, nl = tab->n_loop, dim = tab->dim;
+  std::vector<uint8_t> k_used(nl * dim, 0), t_used(tab->n_tau + 1, 0);
+  for (uint32_t i = 0; i < L; ++i) {
+    if (tab->leaf_type[i] == 0) continue;
+    for (uint32_t j = 0; j < nl; ++j)
+      if (tab->basis[(size_t)(tab->loop_index[i] - 1) * nl + j] != 0.0) for (uint32_t d = 0; d < dim; ++d) k_used[j * dim + d] = 1;
+    if (tab->leaf_type[i] == 1) { t_used[tab->tau_in[i]] = 1; t_used[tab->tau_out[i]] = 1; }
+  }
+  for (uint32_t c = 0; c < nl * dim; ++c) if (k_used[c]) os << "    const double k" << c << " = K[b * ks + " << c << "L * kc];\n";
+  for (uint32_t i = 1; i <= tab->n_tau; ++i) if (t_used[i]) os << "    const double t" << i << " = T[b * ts + " << (i - 1) << "L * tc];\n";
+  os << "    double q, q2, w, den, tau, ap, an, e, invK, x, v;\n";
+  if (fused) for (uint32_t i = 0; i < L; ++i) os << "    double g" << i << " = 1.0;\n";
+  int32_t cur = -1;
+  for (uint32_t s = 0; s < L; ++s) {
+    const int32_t i = perm[s];
+    const int32_t ty = tab->leaf_type[i];
+    if (ty == 0) continue;
+    if (tab->loop_index[i] != cur) {
+      cur = tab->loop_index[i];
+      const double *bv = tab->basis + (size_t)(cur - 1) * nl;
+      os << "    q2 = 0.0;\n";
+      for (uint32_t d = 0; d < dim; ++d) {
+        os << "    q = 0.0;";
+        for (uint32_t j = 0; j < nl; ++j) {
+          if (bv[j] == 0.0) continue;
+          if (bv[j] == 1.0) os << " q += k" << (j * dim + d) << ";";
+          else os << " q += k" << (j * dim + d) << " * " << dbl(bv[j]) << ";";
+        }
+        os << " q2 += q * q;\n";
+      }
+      os << "    w = q2 - kF * kF; den = 1.0 + exp(-fabs(w) * beta);\n";
+    }
+    if (ty == 1) {
+      os << "    tau = t" << tab->tau_out[i] << " - t" << tab->tau_in[i] << "; if (tau == 0.0) tau = -1e-10;\n"
+            "    ap = w > 0.0 ? -w * tau : w * (beta - tau); an = w > 0.0 ? -w * (tau + beta) : -w * tau;\n"
+            "    e = exp(tau > 0.0 ? ap : an); v = (tau > 0.0 ? e : -e) / den;\n";
+    } else {
+      os << "    invK = 1.0 / (q2 + lambda); x = lambda * invK; v = 8.0 * 3.141592653589793 / invK";
+      const int32_t n = tab->leaf_order[i];
+      if (n == 0) os << " * 1.0";
+      else if (n == 1) os << " * x";
+      else if (n == 2) os << " * (x * x)";
+      else os << " * (x * x * x)";
+      os << ";\n";
+    }
+    if (fused) os << "    g" << i << " = v;\n";
+    else os << "    if (valid) leaf[b * ss + " << i << "L * ls] = v;\n";
+  }
+  return os.str();
+}
+
+static std::string emit_leaf_source(const fdg_leaf_tables *tab, const std::vector<int32_t> &perm) {
+  std::ostringstream os;
+  os << "#include <hip/hip_runtime.h>\n";
+  os << "extern \"C\" __global__ void __launch_bounds__(64) fdg_leaf_spec(const double *__restrict__ K, long ks, long kc,\n"
+        "    const double *__restrict__ T, long ts, long tc, double *__restrict__ leaf, long ss, long ls, long B,\n"
+        "    double kF, double beta, double lambda) {\n"
+        "  const long ntile = (B + 63) / 64;\n"
+        "  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {\n"
+        "    const long b0 = tile * 64 + threadIdx.x;\n    const bool valid = b0 < B;\n    const long b = valid ? b0 : B - 1;\n";
+  os << emit_leaf_statements(tab, perm, false);
+  os << "  }\n}\n";
+  return os.str();
+}
+
+static std::vector<int32_t> leaf_order_by_momentum(const fdg_leaf_tables *tab) {
+  std::vector<int32_t> perm(tab->n_leaf);
+  for (uint32_t i = 0; i < tab->n_leaf; ++i) perm[i] = (int32_t)i;
+  std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) {
+    if (tab->leaf_type[a] != tab->leaf_type[b]) return tab->leaf_type[a] < tab->leaf_type[b];
+    return tab->loop_index[a] < tab->loop_index[b];
+  });
+  return perm;
+}
+
+static int check_leaf_tables(const fdg_leaf_tables *tab) {
+  if (!tab || !tab->leaf_type || !tab->leaf_order || !tab->tau_in || !tab->tau_out || !tab->loop_index || !tab->basis) {
+    set_error("null leaf table"); return FDG_E_INVALID;
+  }
+  for (uint32_t i = 0; i < tab->n_leaf; ++i) {
+    const int32_t ty = tab->leaf_type[i];
+    if (ty < 0 || ty > 2) { set_error("this leaftype " + std::to_string(ty) + " not implemented!"); return FDG_E_UNSUPPORTED; }  // benchmark.jl:79
+    if (ty == 0) continue;
+    if (tab->loop_index[i] < 1 || (uint32_t)tab->loop_index[i] > tab->n_basis) { set_error("loop_index out of range"); return FDG_E_INVALID; }
+    if (ty == 1) {
+      if (tab->leaf_order[i] != 0) { set_error("fermionic leaf of derivative order > 0 needs Lehmann.jl's kernelFermiT_dw* (not part of the reference)"); return FDG_E_UNSUPPORTED; }
+      if (tab->tau_in[i] < 1 || tab->tau_out[i] < 1 || (uint32_t)tab->tau_in[i] > tab->n_tau || (uint32_t)tab->tau_out[i] > tab->n_tau) { set_error("tau index out of range"); return FDG_E_INVALID; }
+    } else if (tab->leaf_order[i] < 0) { set_error("negative derivative order"); return FDG_E_INVALID; }
+  }
+  return FDG_OK;
+}
+
+struct LeafModule { int dev; std::string key; hipModule_t mod; hipFunction_t fn; };
+
+// returns the specialised kernel for these tables on the current device, or nullptr (caller uses the generic one)
+static hipFunction_t leaf_spec_function(const fdg_leaf_tables *tab, const std::vector<int32_t> &perm, int dev) {
+  if (std::getenv("FDG_LEAF_GENERIC")) return nullptr;
+  for (uint32_t i = 0; i < tab->n_leaf; ++i)
+    if (tab->leaf_type[i] == 2 && (tab->leaf_order[i] < 0 || tab->leaf_order[i] > 3)) return nullptr;   // pow_body lives in the generic kernel
+  const std::string src = emit_leaf_source(tab, perm);
+  char hbuf[40];
+  std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("leaf-v1")));
+  static std::mutex mu;
+  static std::vector<LeafModule> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto &m : cache) if (m.dev == dev && m.key == hbuf) return m.fn;
+  const std::string dir = std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache";
+  mkdir(dir.c_str(), 0777);
+  const std::string base = dir + "/fdg_leaf_" + hbuf;
+  std::vector<char> co;
+  if (!read_file(base + ".hsaco", co)) {
+    std::string log;
+    if (compile_hiprtc(src, false, co, log) != 0) {
+      cache.push_back(LeafModule{dev, hbuf, nullptr, nullptr});   // do not retry on every call
+      return nullptr;
+    }
+    write_file(base + ".hsaco", co.data(), co.size());
+  }
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  if (hipModuleLoadData(&mod, co.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "fdg_leaf_spec") != hipSuccess) {
+    (void)hipGetLastError();
+    cache.push_back(LeafModule{dev, hbuf, nullptr, nullptr});
+    return nullptr;
+  }
+  cache.push_back(LeafModule{dev, hbuf, mod, fn});
+  return fn;
+}
+
+extern "C" {
+
+int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t ks, int64_t kc, const double *d_T,
+                         int64_t ts, int64_t tc, double *d_leaf, int64_t ss, int64_t ls, int64_t B, void *stream) {
+  { const int rc0 = check_leaf_tables(tab); if (rc0) return rc0; }
+  if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
+  if (B == 0 || tab->n_leaf == 0) return FDG_OK;
+  if (!d_K || !d_T || !d_leaf) { set_error("null device buffer"); return FDG_E_INVALID; }
+  const uint32_t L = tab->n_leaf;
+  const size_t lds = ((size_t)tab->n_loop * tab->dim + tab->n_tau) * 64 * sizeof(double);
+  if (lds > 160 * 1024) { set_error("too many momentum/time components for the LDS staging"); return FDG_E_INVALID; }
+  int n = 0, dev = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device available (no CPU fallback)"); return FDG_E_NO_DEVICE; }
+  HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  // leaves in (type, loop-basis index) order, so that a momentum shared by several leaves is worked out once
+  const std::vector<int32_t> perm = leaf_order_by_momentum(tab);
+  const long ntile = (long)((B + 63) / 64);
+  if (hipFunction_t fn = leaf_spec_function(tab, perm, dev)) {
+    long a_ks = ks, a_kc = kc, a_ts = ts, a_tc = tc, a_ss = ss, a_ls = ls, a_B = B;
+    double a_kF = tab->kF, a_beta = tab->beta, a_lambda = tab->lambda;
+    void *args[] = {(void *)&d_K, &a_ks, &a_kc, (void *)&d_T, &a_ts, &a_tc, (void *)&d_leaf, &a_ss, &a_ls, &a_B, &a_kF, &a_beta, &a_lambda};
+    const long grid = std::min<long>(ntile, (long)prop.multiProcessorCount * 32);
+    HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+    return FDG_OK;
+  }
+  // tables -> device (small; freed after the launch has been enqueued on the same stream order)
+  const size_t ib = (size_t)L * sizeof(int32_t), bb = (size_t)tab->n_basis * tab->n_loop * sizeof(double);
+  const size_t boff = (6 * ib + 7) & ~(size_t)7;
+  std::vector<char> h_tab(boff + bb);
+  const int32_t *src[5] = {tab->leaf_type, tab->leaf_order, tab->tau_in, tab->tau_out, tab->loop_index};
+  for (int k = 0; k < 5; ++k)
+    for (uint32_t i = 0; i < L; ++i) ((int32_t *)(h_tab.data() + k * ib))[i] = src[k][perm[i]];
+  std::memcpy(h_tab.data() + 5 * ib, perm.data(), ib);
+  std::memcpy(h_tab.data() + boff, tab->basis, bb);
+  // the sorted tables live on the device for the life of the process, keyed by their content (a caller
+  // evaluates the same few partitions millions of times): no allocation, copy or synchronisation per call
+  hipStream_t st = (hipStream_t)stream;
+  char *d_tab = nullptr;
+  {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, std::vector<char>>, char *>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : cache) if (e.first.first == dev && e.first.second == h_tab) { d_tab = e.second; break; }
+    if (!d_tab) {
+      HIP_TRY(hipMalloc((void **)&d_tab, h_tab.size() + 64));
+      HIP_TRY(hipMemcpy(d_tab, h_tab.data(), h_tab.size(), hipMemcpyHostToDevice));
+      if (cache.size() >= 64) { hipFree(cache.front().second); cache.erase(cache.begin()); }
+      cache.push_back({{dev, h_tab}, d_tab});
+    }
+  }
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)fdg_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long per_cu = std::max<long>(1, std::min<long>(32, (160 * 1024) / std::max<size_t>(lds, 1)));
+  const long grid = std::min<long>(ntile, (long)prop.multiProcessorCount * per_cu);
+  hipLaunchKernelGGL(fdg_leaf_kernel, dim3((unsigned)grid), dim3(64), lds, st, (const int32_t *)d_tab, (const int32_t *)(d_tab + ib),
+                     (const int32_t *)(d_tab + 2 * ib), (const int32_t *)(d_tab + 3 * ib), (const int32_t *)(d_tab + 4 * ib),
+                     (const int32_t *)(d_tab + 5 * ib),
+                     (const double *)(d_tab + boff), L, tab->n_loop, tab->dim, tab->n_tau, tab->kF, tab->beta, tab->lambda, d_K,
+                     (long)ks, (long)kc, d_T, (long)ts, (long)tc, d_leaf, (long)ss, (long)ls, (long)B);
+  HIP_TRY(hipGetLastError());
+  return FDG_OK;
+}
+
+// ---- fused Monte-Carlo step --------------------------------------------------------------------
+int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const char *cache_dir, unsigned flags) {
+  if (!g) { set_error("null handle"); return FDG_E_INVALID; }
+  { const int rc0 = check_leaf_tables(tab); if (rc0) return rc0; }
+  if (tab->n_leaf != g->prog.L) { set_error("leaf tables describe " + std::to_string(tab->n_leaf) + " leaves, the graph has " + std::to_string(g->prog.L)); return FDG_E_INVALID; }
+  for (uint32_t i = 0; i < tab->n_leaf; ++i)
+    if (tab->leaf_type[i] == 2 && tab->leaf_order[i] > 3) { set_error("fused step: interaction order > 3 not covered (use fdg_leaf_eval_device + fdg_accumulate_device)"); return FDG_E_UNSUPPORTED; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  const std::string src = emit_fused_source(g->prog, emit_leaf_statements(tab, leaf_order_by_momentum(tab), true));
+  char hbuf[40];
+  std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("fused-v1")));
+  const std::string dir = cache_dir ? cache_dir : (std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache");
+  mkdir(dir.c_str(), 0777);
+  const std::string base = dir + "/fdg_fused_" + hbuf;
+  std::vector<char> co;
+  if (!read_file(base + ".hsaco", co)) {
+    std::string log;
+    if (compile_hiprtc(src, false, co, log) != 0) {
+      std::string log2;
+      if (!write_file(base + ".hip", src.c_str(), src.size())) { set_error("cannot write " + base + ".hip"); return FDG_E_JIT; }
+      const int rc = compile_hipcc(base + ".hip", base + ".hsaco", false, log2);
+      if (!(flags & FDG_SPEC_KEEP_SOURCE)) std::remove((base + ".hip").c_str());
+      if (rc != 0 || !read_file(base + ".hsaco", co)) { set_error("fused kernel specialization failed.\nhiprtc: " + log + "\nhipcc: " + log2); return FDG_E_JIT; }
+    } else {
+      write_file(base + ".hsaco", co.data(), co.size());
+    }
+  }
+  if (flags & FDG_SPEC_KEEP_SOURCE) write_file(base + ".hip", src.c_str(), src.size());
+  if (g->fused_module) { hipModuleUnload((hipModule_t)g->fused_module); g->fused_module = nullptr; g->fn_fused = nullptr; }
+  g->fused_code.swap(co);
+  return FDG_OK;
+}
+
+static int run_fused(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_t kc, const double *d_T, int64_t ts, int64_t tc,
+                     double kF, double beta, double lambda, double *d_root, int64_t rs, int64_t rk, const double *d_weight,
+                     double *d_acc, int64_t B, void *stream) {
+  if (!g) { set_error("null handle"); return FDG_E_INVALID; }
+  if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
+  if (B == 0) return FDG_OK;
+  if (!d_K || !d_T || (mode == 0 && !d_root) || (mode == 1 && !d_acc)) { set_error("null device buffer"); return FDG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->fused_code.empty()) { set_error("fdg_graph_specialize_fused has not been called on this handle"); return FDG_E_INVALID; }
+  int rc = ensure_device(g);
+  if (rc) return rc;
+  if (!g->fn_fused) {
+    hipModule_t m; hipFunction_t f;
+    hipError_t e = hipModuleLoadData(&m, g->fused_code.data());
+    if (e != hipSuccess) { set_error("hipModuleLoadData failed: " + std::string(hipGetErrorString(e))); return FDG_E_JIT; }
+    HIP_TRY(hipModuleGetFunction(&f, m, "fdg_spec_fused"));
+    g->fused_module = m; g->fn_fused = f;
+  }
+  const uint32_t R = g->prog.R;
+  const long nblk = (long)((B + 255) / 256);
+  const long grid = std::min<long>(nblk, (long)g->n_cu * 8);
+  double *partial = nullptr;
+  if (mode == 1) {
+    rc = ensure_ws(g, (size_t)grid * std::max<uint32_t>(R, 1) * sizeof(double));
+    if (rc) return rc;
+    partial = (double *)g->d_ws;
+  }
+  long a_ks = ks, a_kc = kc, a_ts = ts, a_tc = tc, a_rs = rs, a_rk = rk, a_B = B;
+  int a_mode = mode;
+  void *args[] = {(void *)&d_K, &a_ks, &a_kc, (void *)&d_T, &a_ts, &a_tc, &kF, &beta, &lambda, (void *)&d_root, &a_rs, &a_rk,
+                  (void *)&d_weight, (void *)&partial, &a_B, &a_mode};
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_fused, (unsigned)grid, 1, 1, 256, 1, 1, 0, st, args, nullptr));
+  if (mode == 1 && R) {
+    { const int rr = launch_reduce_partials(partial, (uint32_t)grid, R, d_acc, st); if (rr) return rr; }
+  }
+  return FDG_OK;
+}
+
+int fdg_mc_eval_device(fdg_graph *g, const double *d_K, int64_t ks, int64_t kc, const double *d_T, int64_t ts, int64_t tc,
+                       double kF, double beta, double lambda, double *d_root, int64_t rs, int64_t rk, int64_t B, void *stream) {
+  return run_fused(g, 0, d_K, ks, kc, d_T, ts, tc, kF, beta, lambda, d_root, rs, rk, nullptr, nullptr, B, stream);
+}
+
+int fdg_mc_accumulate_device(fdg_graph *g, const double *d_K, int64_t ks, int64_t kc, const double *d_T, int64_t ts, int64_t tc,
+                             double kF, double beta, double lambda, const double *d_weight, double *d_acc, int64_t B, void *stream) {
+  return run_fused(g, 1, d_K, ks, kc, d_T, ts, tc, kF, beta, lambda, nullptr, 0, 0, d_weight, d_acc, B, stream);
+}
+
+}  // extern "C"
