@@ -1097,19 +1097,25 @@ int fdg_eval(fdg_graph *g, const double *leaf, double *root, int64_t B) {
   const size_t L = g->prog.L, R = g->prog.R;
   if ((L && !leaf) || (R && !root)) { set_error("null host buffer"); return FDG_E_INVALID; }
   { std::lock_guard<std::mutex> lk(g->mu); int rc = ensure_device(g); if (rc) return rc; }
+  // host buffers of any size: the batch goes through the device in chunks of at most ~2 GiB (FDG_EVAL_CHUNK
+  // samples overrides, for tests), so device memory bounds nothing
+  int64_t chunk = std::max<int64_t>(65536, (int64_t)((2ull << 30) / (8ull * std::max<size_t>(L + R, 1))));
+  if (const char *e = std::getenv("FDG_EVAL_CHUNK")) chunk = std::max<int64_t>(1, std::atoll(e));
+  chunk = std::min<int64_t>(chunk, B);
   double *dl = nullptr, *dr = nullptr;
-  HIP_TRY(hipMalloc(&dl, std::max<size_t>(1, (size_t)B * L) * 8));
-  if (hipMalloc(&dr, std::max<size_t>(1, (size_t)B * R) * 8) != hipSuccess) { hipFree(dl); set_error("hipMalloc failed"); return FDG_E_NOMEM; }
+  HIP_TRY(hipMalloc(&dl, std::max<size_t>(1, (size_t)chunk * L) * 8));
+  if (hipMalloc(&dr, std::max<size_t>(1, (size_t)chunk * R) * 8) != hipSuccess) { hipFree(dl); set_error("hipMalloc failed"); return FDG_E_NOMEM; }
   int rc = FDG_OK;
-  do {
-    if (L && hipMemcpy(dl, leaf, (size_t)B * L * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = FDG_E_NO_DEVICE; break; }
+  for (int64_t c0 = 0; c0 < B && rc == FDG_OK; c0 += chunk) {
+    const int64_t n = std::min<int64_t>(chunk, B - c0);
+    if (L && hipMemcpy(dl, leaf + (size_t)c0 * L, (size_t)n * L * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = FDG_E_NO_DEVICE; break; }
     // eval_graph! leaves root entries it does not assign untouched: start from the caller's values
-    if (R && hipMemcpy(dr, root, (size_t)B * R * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = FDG_E_NO_DEVICE; break; }
-    rc = run(g, 0, dl, (int64_t)L, 1, dr, (int64_t)R, 1, nullptr, nullptr, B, nullptr);
+    if (R && hipMemcpy(dr, root + (size_t)c0 * R, (size_t)n * R * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = FDG_E_NO_DEVICE; break; }
+    rc = run(g, 0, dl, (int64_t)L, 1, dr, (int64_t)R, 1, nullptr, nullptr, n, nullptr);
     if (rc) break;
     if (hipDeviceSynchronize() != hipSuccess) { set_error("kernel execution failed"); rc = FDG_E_NO_DEVICE; break; }
-    if (R && hipMemcpy(root, dr, (size_t)B * R * 8, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H copy failed"); rc = FDG_E_NO_DEVICE; break; }
-  } while (0);
+    if (R && hipMemcpy(root + (size_t)c0 * R, dr, (size_t)n * R * 8, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H copy failed"); rc = FDG_E_NO_DEVICE; break; }
+  }
   hipFree(dl); hipFree(dr);
   return rc;
 }

@@ -510,3 +510,18 @@ def test_auto_backend_row_major_companion(libfdg, cuda):
     h = capi.GraphHandle(workloads.get("sigma2"))
     with pytest.raises(capi.FdgError):
         h.specialize(None, capi.FDG_SPEC_ROW_MAJOR_COMPANION)
+
+
+def test_host_buffers_in_chunks(libfdg, cuda, monkeypatch):
+    """fdg_eval (host arrays in, host arrays out) streams the batch through the device in chunks; a tiny chunk
+    size must give the same bits, including root entries the graph does not assign."""
+    t = workloads.get("synthetic_small")
+    h_leaf = oracle.philox_uniform(10_007, t.n_leaf, 3)
+    want = oracle.eval_static(t, h_leaf, np.full((10_007, t.n_root), -2.5))
+    for spec in ("isa", False):
+        f = fd.compile_table(t, specialize=spec)
+        monkeypatch.setenv("FDG_EVAL_CHUNK", "999")
+        got = f(np.full((10_007, t.n_root), -2.5), h_leaf)
+        monkeypatch.delenv("FDG_EVAL_CHUNK")
+        assert np.array_equal(got, want)
+        assert np.array_equal(f(np.full((10_007, t.n_root), -2.5), h_leaf), want)
