@@ -104,6 +104,13 @@ struct fdg_graph {
   // fused Monte-Carlo step: leaves computed in registers from (K, T), then the graph (HIP-source JIT)
   std::vector<char> fused_code;
   void *fused_module = nullptr, *fn_fused = nullptr;
+  // ... or, for graphs too large for a compiler-scheduled kernel, leaf kernel -> chunk of leaves -> this handle's evaluator
+  int mc_route = 0;                // 0 none, 1 fused kernel, 2 leaf kernel + evaluator
+  std::vector<int32_t> lt_i32[5];  // copy of the leafstates tables (type, order, tau_in, tau_out, loop_index)
+  std::vector<double> lt_basis;
+  uint32_t lt_hdr[5] = {0, 0, 0, 0, 0};   // n_leaf, n_basis, n_loop, dim, n_tau
+  void *d_ws4 = nullptr;           // leaf-major chunk of leaves for route 2
+  size_t ws4_bytes = 0;
   void *d_ws2 = nullptr;           // roots scratch for accumulate through the ISA kernel
   size_t ws2_bytes = 0;
   void *d_ws3 = nullptr;           // leaf-major copy of a sample-major chunk for the ISA kernel
@@ -128,6 +135,8 @@ struct fdg_graph {
 
 int ensure_device(fdg_graph *g);                 // binds the handle to the current gfx950 device
 int ensure_ws(fdg_graph *g, size_t bytes);       // grows the handle's device workspace
+int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root, int64_t rs, int64_t rk,
+                   const double *d_weight, double *d_acc, int64_t B, hipStream_t st);   // caller holds g->mu
 int launch_reduce_partials(const double *partial, uint32_t nblk, uint32_t R, double *acc, hipStream_t st);
 #endif
 namespace fdg { const char *last_error_cstr(); }

@@ -221,66 +221,99 @@ static hipFunction_t leaf_spec_function(const fdg_leaf_tables *tab, const std::v
 
 extern "C" {
 
+// Everything that depends only on the tables, built once per (device, table contents): the specialised
+// kernel (or, for the table-driven one, the sorted tables on the device).  A Monte-Carlo loop calls with
+// the same few partitions millions of times; per call nothing is generated, hashed, allocated or copied.
+struct LeafPlan {
+  int dev = 0, n_cu = 0;
+  std::vector<char> key;
+  hipFunction_t fn = nullptr;      // specialised kernel, or nullptr: table-driven kernel with d_tab
+  char *d_tab = nullptr;
+  size_t ib = 0, boff = 0, lds = 0;
+};
+
+static int leaf_plan(const fdg_leaf_tables *tab, const LeafPlan **out) {
+  int n = 0, dev = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device available (no CPU fallback)"); return FDG_E_NO_DEVICE; }
+  HIP_TRY(hipGetDevice(&dev));
+  const uint32_t L = tab->n_leaf;
+  const size_t ib = (size_t)L * sizeof(int32_t), bb = (size_t)tab->n_basis * tab->n_loop * sizeof(double);
+  std::vector<char> key(5 * sizeof(uint32_t) + 5 * ib + bb + 1);
+  {
+    char *w = key.data();
+    const uint32_t hd[5] = {tab->n_leaf, tab->n_basis, tab->n_loop, tab->dim, tab->n_tau};
+    std::memcpy(w, hd, sizeof hd); w += sizeof hd;
+    const int32_t *src[5] = {tab->leaf_type, tab->leaf_order, tab->tau_in, tab->tau_out, tab->loop_index};
+    for (int k = 0; k < 5; ++k) { std::memcpy(w, src[k], ib); w += ib; }
+    std::memcpy(w, tab->basis, bb); w += bb;
+    *w = std::getenv("FDG_LEAF_GENERIC") ? 1 : 0;
+  }
+  static std::mutex mu;
+  static std::vector<LeafPlan *> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  for (LeafPlan *p : cache) if (p->dev == dev && p->key == key) { *out = p; return FDG_OK; }
+  LeafPlan *p = new LeafPlan;
+  p->dev = dev; p->key.swap(key); p->ib = ib;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  p->n_cu = prop.multiProcessorCount;
+  // leaves in (type, loop-basis index) order, so that a momentum shared by several leaves is worked out once
+  const std::vector<int32_t> perm = leaf_order_by_momentum(tab);
+  p->fn = leaf_spec_function(tab, perm, dev);
+  if (!p->fn) {
+    p->lds = ((size_t)tab->n_loop * tab->dim + tab->n_tau) * 64 * sizeof(double);
+    if (p->lds > 160 * 1024) { delete p; set_error("too many momentum/time components for the LDS staging"); return FDG_E_INVALID; }
+    p->boff = (6 * ib + 7) & ~(size_t)7;
+    std::vector<char> h_tab(p->boff + bb);
+    const int32_t *src[5] = {tab->leaf_type, tab->leaf_order, tab->tau_in, tab->tau_out, tab->loop_index};
+    for (int k = 0; k < 5; ++k)
+      for (uint32_t i = 0; i < L; ++i) ((int32_t *)(h_tab.data() + k * ib))[i] = src[k][perm[i]];
+    std::memcpy(h_tab.data() + 5 * ib, perm.data(), ib);
+    std::memcpy(h_tab.data() + p->boff, tab->basis, bb);
+    if (hipMalloc((void **)&p->d_tab, h_tab.size() + 64) != hipSuccess ||
+        hipMemcpy(p->d_tab, h_tab.data(), h_tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      delete p; set_error("leaf tables: device allocation / copy failed"); return FDG_E_NOMEM;
+    }
+    if (p->lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)fdg_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds));
+  }
+  cache.push_back(p);
+  *out = p;
+  return FDG_OK;
+}
+
+static int leaf_launch(const LeafPlan *p, const fdg_leaf_tables *tab, const double *d_K, int64_t ks, int64_t kc, const double *d_T,
+                       int64_t ts, int64_t tc, double *d_leaf, int64_t ss, int64_t ls, int64_t B, hipStream_t st) {
+  const long ntile = (long)((B + 63) / 64);
+  if (p->fn) {
+    long a_ks = ks, a_kc = kc, a_ts = ts, a_tc = tc, a_ss = ss, a_ls = ls, a_B = B;
+    double a_kF = tab->kF, a_beta = tab->beta, a_lambda = tab->lambda;
+    void *args[] = {(void *)&d_K, &a_ks, &a_kc, (void *)&d_T, &a_ts, &a_tc, (void *)&d_leaf, &a_ss, &a_ls, &a_B, &a_kF, &a_beta, &a_lambda};
+    const long grid = std::min<long>(ntile, (long)p->n_cu * 32);
+    HIP_TRY(hipModuleLaunchKernel(p->fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+    return FDG_OK;
+  }
+  const size_t ib = p->ib;
+  const char *d_tab = p->d_tab;
+  const long per_cu = std::max<long>(1, std::min<long>(32, (160 * 1024) / std::max<size_t>(p->lds, 1)));
+  const long grid = std::min<long>(ntile, (long)p->n_cu * per_cu);
+  hipLaunchKernelGGL(fdg_leaf_kernel, dim3((unsigned)grid), dim3(64), p->lds, st, (const int32_t *)d_tab, (const int32_t *)(d_tab + ib),
+                     (const int32_t *)(d_tab + 2 * ib), (const int32_t *)(d_tab + 3 * ib), (const int32_t *)(d_tab + 4 * ib),
+                     (const int32_t *)(d_tab + 5 * ib),
+                     (const double *)(d_tab + p->boff), tab->n_leaf, tab->n_loop, tab->dim, tab->n_tau, tab->kF, tab->beta, tab->lambda, d_K,
+                     (long)ks, (long)kc, d_T, (long)ts, (long)tc, d_leaf, (long)ss, (long)ls, (long)B);
+  HIP_TRY(hipGetLastError());
+  return FDG_OK;
+}
+
 int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t ks, int64_t kc, const double *d_T,
                          int64_t ts, int64_t tc, double *d_leaf, int64_t ss, int64_t ls, int64_t B, void *stream) {
   { const int rc0 = check_leaf_tables(tab); if (rc0) return rc0; }
   if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
   if (B == 0 || tab->n_leaf == 0) return FDG_OK;
   if (!d_K || !d_T || !d_leaf) { set_error("null device buffer"); return FDG_E_INVALID; }
-  const uint32_t L = tab->n_leaf;
-  const size_t lds = ((size_t)tab->n_loop * tab->dim + tab->n_tau) * 64 * sizeof(double);
-  if (lds > 160 * 1024) { set_error("too many momentum/time components for the LDS staging"); return FDG_E_INVALID; }
-  int n = 0, dev = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device available (no CPU fallback)"); return FDG_E_NO_DEVICE; }
-  HIP_TRY(hipGetDevice(&dev));
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, dev));
-  // leaves in (type, loop-basis index) order, so that a momentum shared by several leaves is worked out once
-  const std::vector<int32_t> perm = leaf_order_by_momentum(tab);
-  const long ntile = (long)((B + 63) / 64);
-  if (hipFunction_t fn = leaf_spec_function(tab, perm, dev)) {
-    long a_ks = ks, a_kc = kc, a_ts = ts, a_tc = tc, a_ss = ss, a_ls = ls, a_B = B;
-    double a_kF = tab->kF, a_beta = tab->beta, a_lambda = tab->lambda;
-    void *args[] = {(void *)&d_K, &a_ks, &a_kc, (void *)&d_T, &a_ts, &a_tc, (void *)&d_leaf, &a_ss, &a_ls, &a_B, &a_kF, &a_beta, &a_lambda};
-    const long grid = std::min<long>(ntile, (long)prop.multiProcessorCount * 32);
-    HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr));
-    return FDG_OK;
-  }
-  // tables -> device (small; freed after the launch has been enqueued on the same stream order)
-  const size_t ib = (size_t)L * sizeof(int32_t), bb = (size_t)tab->n_basis * tab->n_loop * sizeof(double);
-  const size_t boff = (6 * ib + 7) & ~(size_t)7;
-  std::vector<char> h_tab(boff + bb);
-  const int32_t *src[5] = {tab->leaf_type, tab->leaf_order, tab->tau_in, tab->tau_out, tab->loop_index};
-  for (int k = 0; k < 5; ++k)
-    for (uint32_t i = 0; i < L; ++i) ((int32_t *)(h_tab.data() + k * ib))[i] = src[k][perm[i]];
-  std::memcpy(h_tab.data() + 5 * ib, perm.data(), ib);
-  std::memcpy(h_tab.data() + boff, tab->basis, bb);
-  // the sorted tables live on the device for the life of the process, keyed by their content (a caller
-  // evaluates the same few partitions millions of times): no allocation, copy or synchronisation per call
-  hipStream_t st = (hipStream_t)stream;
-  char *d_tab = nullptr;
-  {
-    static std::mutex mu;
-    static std::vector<std::pair<std::pair<int, std::vector<char>>, char *>> cache;
-    std::lock_guard<std::mutex> lk(mu);
-    for (auto &e : cache) if (e.first.first == dev && e.first.second == h_tab) { d_tab = e.second; break; }
-    if (!d_tab) {
-      HIP_TRY(hipMalloc((void **)&d_tab, h_tab.size() + 64));
-      HIP_TRY(hipMemcpy(d_tab, h_tab.data(), h_tab.size(), hipMemcpyHostToDevice));
-      if (cache.size() >= 64) { hipFree(cache.front().second); cache.erase(cache.begin()); }
-      cache.push_back({{dev, h_tab}, d_tab});
-    }
-  }
-  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)fdg_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const long per_cu = std::max<long>(1, std::min<long>(32, (160 * 1024) / std::max<size_t>(lds, 1)));
-  const long grid = std::min<long>(ntile, (long)prop.multiProcessorCount * per_cu);
-  hipLaunchKernelGGL(fdg_leaf_kernel, dim3((unsigned)grid), dim3(64), lds, st, (const int32_t *)d_tab, (const int32_t *)(d_tab + ib),
-                     (const int32_t *)(d_tab + 2 * ib), (const int32_t *)(d_tab + 3 * ib), (const int32_t *)(d_tab + 4 * ib),
-                     (const int32_t *)(d_tab + 5 * ib),
-                     (const double *)(d_tab + boff), L, tab->n_loop, tab->dim, tab->n_tau, tab->kF, tab->beta, tab->lambda, d_K,
-                     (long)ks, (long)kc, d_T, (long)ts, (long)tc, d_leaf, (long)ss, (long)ls, (long)B);
-  HIP_TRY(hipGetLastError());
-  return FDG_OK;
+  const LeafPlan *p = nullptr;
+  { const int rc = leaf_plan(tab, &p); if (rc) return rc; }
+  return leaf_launch(p, tab, d_K, ks, kc, d_T, ts, tc, d_leaf, ss, ls, B, (hipStream_t)stream);
 }
 
 // ---- fused Monte-Carlo step --------------------------------------------------------------------
@@ -291,6 +324,22 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
   for (uint32_t i = 0; i < tab->n_leaf; ++i)
     if (tab->leaf_type[i] == 2 && tab->leaf_order[i] > 3) { set_error("fused step: interaction order > 3 not covered (use fdg_leaf_eval_device + fdg_accumulate_device)"); return FDG_E_UNSUPPORTED; }
   std::lock_guard<std::mutex> lk(g->mu);
+  // Route: one compiler-scheduled kernel (leaves in registers) for graphs of up to a few thousand operations; for
+  // larger ones the specialised leaf kernel fills a chunk of leaves that this handle's own evaluator (ISA kernel
+  // if the handle was specialised with FDG_SPEC_ISA) consumes -- measured faster there.
+  // FDG_MC_ROUTE=fused|split overrides.
+  {
+    const char *env = std::getenv("FDG_MC_ROUTE");
+    bool split = g->prog.flops_alg > 6000;
+    if (env && std::strcmp(env, "fused") == 0) split = false;
+    if (env && std::strcmp(env, "split") == 0) split = true;
+    const int32_t *src5[5] = {tab->leaf_type, tab->leaf_order, tab->tau_in, tab->tau_out, tab->loop_index};
+    for (int k = 0; k < 5; ++k) g->lt_i32[k].assign(src5[k], src5[k] + tab->n_leaf);
+    g->lt_basis.assign(tab->basis, tab->basis + (size_t)tab->n_basis * tab->n_loop);
+    const uint32_t hd[5] = {tab->n_leaf, tab->n_basis, tab->n_loop, tab->dim, tab->n_tau};
+    std::memcpy(g->lt_hdr, hd, sizeof hd);
+    if (split) { g->mc_route = 2; g->fused_code.clear(); return FDG_OK; }
+  }
   const std::string src = emit_fused_source(g->prog, emit_leaf_statements(tab, leaf_order_by_momentum(tab), true));
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("fused-v1")));
@@ -313,6 +362,7 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
   if (flags & FDG_SPEC_KEEP_SOURCE) write_file(base + ".hip", src.c_str(), src.size());
   if (g->fused_module) { hipModuleUnload((hipModule_t)g->fused_module); g->fused_module = nullptr; g->fn_fused = nullptr; }
   g->fused_code.swap(co);
+  g->mc_route = 1;
   return FDG_OK;
 }
 
@@ -324,9 +374,42 @@ static int run_fused(fdg_graph *g, int mode, const double *d_K, int64_t ks, int6
   if (B == 0) return FDG_OK;
   if (!d_K || !d_T || (mode == 0 && !d_root) || (mode == 1 && !d_acc)) { set_error("null device buffer"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
-  if (g->fused_code.empty()) { set_error("fdg_graph_specialize_fused has not been called on this handle"); return FDG_E_INVALID; }
+  if (g->mc_route == 0) { set_error("fdg_graph_specialize_fused has not been called on this handle"); return FDG_E_INVALID; }
   int rc = ensure_device(g);
   if (rc) return rc;
+  if (g->mc_route == 2) {
+    fdg_leaf_tables tab;
+    tab.n_leaf = g->lt_hdr[0]; tab.n_basis = g->lt_hdr[1]; tab.n_loop = g->lt_hdr[2]; tab.dim = g->lt_hdr[3]; tab.n_tau = g->lt_hdr[4];
+    tab.leaf_type = g->lt_i32[0].data(); tab.leaf_order = g->lt_i32[1].data(); tab.tau_in = g->lt_i32[2].data();
+    tab.tau_out = g->lt_i32[3].data(); tab.loop_index = g->lt_i32[4].data(); tab.basis = g->lt_basis.data();
+    tab.kF = kF; tab.beta = beta; tab.lambda = lambda;
+    const LeafPlan *plan = nullptr;
+    rc = leaf_plan(&tab, &plan);
+    if (rc) return rc;
+    const size_t L = std::max<uint32_t>(g->prog.L, 1);
+    int64_t Bc = std::max<int64_t>(1 << 16, (int64_t)((4ull << 30) / (8ull * L)));     // about 4 GiB of leaves per chunk
+    Bc = std::min<int64_t>((Bc + 63) & ~63ll, (B + 63) & ~63ll);
+    const size_t need = (size_t)Bc * L * sizeof(double);
+    if (g->ws4_bytes < need) {
+      if (g->d_ws4) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws4)); g->d_ws4 = nullptr; g->ws4_bytes = 0; }
+      if (hipMalloc(&g->d_ws4, need) != hipSuccess) { set_error("hipMalloc(leaf chunk) failed"); return FDG_E_NOMEM; }
+      g->ws4_bytes = need;
+      // leaves without a formula keep leafstates' initial value 1.0
+      std::vector<double> ones((size_t)Bc, 1.0);
+      for (uint32_t i = 0; i < g->prog.L; ++i)
+        if (tab.leaf_type[i] == 0) HIP_TRY(hipMemcpy((double *)g->d_ws4 + (size_t)i * Bc, ones.data(), (size_t)Bc * 8, hipMemcpyHostToDevice));
+    }
+    hipStream_t st = (hipStream_t)stream;
+    double *d_leaf = (double *)g->d_ws4;
+    for (int64_t c0 = 0; c0 < B; c0 += Bc) {
+      const int64_t n = std::min<int64_t>(Bc, B - c0);
+      rc = leaf_launch(plan, &tab, d_K + c0 * ks, ks, kc, d_T + c0 * ts, ts, tc, d_leaf, 1, Bc, n, st);
+      if (rc) return rc;
+      rc = fdg_run_locked(g, mode, d_leaf, 1, Bc, mode == 0 ? d_root + c0 * rs : nullptr, rs, rk, d_weight ? d_weight + c0 : nullptr, d_acc, n, st);
+      if (rc) return rc;
+    }
+    return FDG_OK;
+  }
   if (!g->fn_fused) {
     hipModule_t m; hipFunction_t f;
     hipError_t e = hipModuleLoadData(&m, g->fused_code.data());

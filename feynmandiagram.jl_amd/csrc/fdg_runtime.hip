@@ -322,8 +322,8 @@ static int ensure_module(fdg_graph *g) {
 }
 
 // mode 0: roots -> d_root; mode 1: partial sums -> d_acc
-static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
-                      int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st);
+int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
+                   int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st);
 
 static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
                int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st) {
@@ -334,7 +334,7 @@ static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t
     set_error("null device buffer"); return FDG_E_INVALID;
   }
   std::lock_guard<std::mutex> lk(g->mu);
-  return run_locked(g, mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st);
+  return fdg_run_locked(g, mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st);
 }
 
 // launch of the compiler-scheduled per-graph kernels (fdg_spec_sm / fdg_spec_gen)
@@ -362,8 +362,8 @@ static int launch_hip_source(fdg_graph *g, hipFunction_t fn, int mode, const dou
   return FDG_OK;
 }
 
-static int run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
-                      int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st) {
+int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
+                   int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st) {
   int rc = ensure_device(g);
   if (rc) return rc;
   const Lowered &p = g->prog;
@@ -654,6 +654,7 @@ int fdg_graph_release_device(fdg_graph *g) {
   if (g->d_ws) { hipFree(g->d_ws); g->d_ws = nullptr; g->ws_bytes = 0; }
   if (g->d_ws2) { hipFree(g->d_ws2); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
   if (g->d_ws3) { hipFree(g->d_ws3); g->d_ws3 = nullptr; g->ws3_bytes = 0; }
+  if (g->d_ws4) { hipFree(g->d_ws4); g->d_ws4 = nullptr; g->ws4_bytes = 0; }
   if (g->s2) {
     hipStreamSynchronize((hipStream_t)g->s2);
     hipStreamDestroy((hipStream_t)g->s2); g->s2 = nullptr;
@@ -971,12 +972,12 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
     // warm-up: the first launches after a change of load run at transient clocks (power management settles
     // within a few tens of milliseconds); candidates are compared in the settled state
     bool ok_run = true;
-    for (int w = 0; w < 12 && ok_run; ++w) ok_run = run_locked(g, 0, d_leaf, 1, Bt, d_root, p.R, 1, nullptr, nullptr, Bt, nullptr) == FDG_OK;
+    for (int w = 0; w < 12 && ok_run; ++w) ok_run = fdg_run_locked(g, 0, d_leaf, 1, Bt, d_root, p.R, 1, nullptr, nullptr, Bt, nullptr) == FDG_OK;
     if (!ok_run) continue;
     float ms_min = 1e30f;
     for (int rep = 0; rep < 6; ++rep) {
       hipEventRecord(e0, nullptr);
-      if (run_locked(g, 0, d_leaf, 1, Bt, d_root, p.R, 1, nullptr, nullptr, Bt, nullptr) != FDG_OK) { ms_min = 1e30f; break; }
+      if (fdg_run_locked(g, 0, d_leaf, 1, Bt, d_root, p.R, 1, nullptr, nullptr, Bt, nullptr) != FDG_OK) { ms_min = 1e30f; break; }
       hipEventRecord(e1, nullptr);
       hipEventSynchronize(e1);
       float ms = 0;

@@ -238,9 +238,11 @@ int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t 
  * leafstates' initial leafValue; needs no device -- then
  *   fdg_mc_eval_device       root[b][k]           (strides as in fdg_eval_device)
  *   fdg_mc_accumulate_device acc[k] += sum_b weight[b] * root_k(b)   (weight NULL = 1)
- * with K, T laid out as in fdg_leaf_eval_device.  Compiler-scheduled (HIP source through hiprtc): meant
- * for graphs of up to a few thousand nodes; larger ones run faster as fdg_leaf_eval_device +
- * fdg_accumulate_device on the FDG_SPEC_ISA back end. */
+ * with K, T laid out as in fdg_leaf_eval_device.  The single kernel is compiler-scheduled (HIP source through
+ * hiprtc) and right for graphs of up to a few thousand operations.  For larger graphs the same calls run the
+ * specialised leaf kernel into a chunk of leaves owned by the handle and then the handle's own evaluator
+ * (specialise it with FDG_SPEC_ISA first): fdg_graph_specialize_fused picks the route by graph size
+ * (FDG_MC_ROUTE=fused|split overrides); the roots are the same bits on either route. */
 int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const char *cache_dir, unsigned flags);
 int fdg_mc_eval_device(fdg_graph *g, const double *d_K, int64_t k_sample_stride, int64_t k_comp_stride, const double *d_T,
                        int64_t t_sample_stride, int64_t t_comp_stride, double kF, double beta, double lambda,

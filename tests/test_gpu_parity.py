@@ -525,3 +525,46 @@ def test_host_buffers_in_chunks(libfdg, cuda, monkeypatch):
         monkeypatch.delenv("FDG_EVAL_CHUNK")
         assert np.array_equal(got, want)
         assert np.array_equal(f(np.full((10_007, t.n_root), -2.5), h_leaf), want)
+
+
+def test_mc_step_routes_on_large_graph(libfdg, cuda, monkeypatch):
+    """fdg_graph_specialize_fused on a graph too large for one compiler-scheduled kernel takes the split route
+    (specialised leaf kernel -> chunk of leaves -> the handle's ISA evaluator) behind the same fdg_mc_* calls;
+    FDG_MC_ROUTE=fused forces the single kernel.  Both give the bits of the hand-written unfused sequence."""
+    import torch
+    z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
+    zt = np.load(os.path.join(GOLD, "gv_sigma4_taylor2.npz"))
+    base, dord = zt["leaf_base"], zt["leaf_dorder"]
+    for k in ("leaf_type", "tau_in", "tau_out", "loop_index"):
+        z[k] = z[k][base]
+    z["leaf_order"] = np.where(z["leaf_type"] == 2, dord, 0).astype(np.int32)
+    t = workloads.get("gv_sigma4_taylor2")
+    L, R = t.n_leaf, t.n_root
+    B, dim, n_loop, n_tau = 50_001, 3, int(z["basis"].shape[1]), int(z["n_tau"])
+    kF, beta, lam = 1.919, 3.0, 1.2
+    rng = np.random.default_rng(11)
+    dK = torch.from_numpy(rng.uniform(-2.0, 2.0, size=(n_loop * dim, B))).to(cuda)
+    dT = torch.from_numpy(rng.uniform(0.0, beta, size=(n_tau, B))).to(cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
+    leaf = torch.ones((L, B), dtype=torch.float64, device=cuda).t()
+    capi.leaf_eval_device(*args, kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf.data_ptr(), leaf.stride(0), leaf.stride(1), B, st)
+    f = fd.compile_table(t, specialize="isa")
+    want = f(None, leaf)
+    assert np.array_equal(want.cpu().numpy(), oracle.eval_static(t, leaf.cpu().numpy()))
+    tab, _keep = capi.make_leaf_tables(*args)
+    for route in (None, "fused"):
+        if route:
+            monkeypatch.setenv("FDG_MC_ROUTE", route)
+        g = fd.compile_table(t, specialize="isa")
+        g.handle.specialize_fused(tab)
+        root = torch.zeros((B, R), dtype=torch.float64, device=cuda)
+        g.handle.mc_eval_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, root.data_ptr(), R, 1, B, st)
+        torch.cuda.synchronize()
+        assert torch.equal(root, want), route
+        w = torch.rand(B, dtype=torch.float64, device=cuda)
+        acc = torch.zeros(R, dtype=torch.float64, device=cuda)
+        g.handle.mc_accumulate_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, w.data_ptr(), acc.data_ptr(), B, st)
+        torch.cuda.synchronize()
+        wr = (want * w[:, None]).cpu().numpy()
+        assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0))), route

@@ -47,9 +47,9 @@ print(f"{name} B={B}: leaves {tl:.3f} ms ({B/tl*1e3:.3e}/s, {B*L*8/tl/1e6:.0f} G
 
 # fused kernel (leaves in registers)
 tab, _keep = capi.make_leaf_tables(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
-hf = capi.GraphHandle(t); hf.specialize_fused(tab)
+hf = fd.compile_table(t, specialize="isa").handle; hf.specialize_fused(tab)
 tf = timeit(lambda: hf.mc_accumulate_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, w.data_ptr(), acc.data_ptr(), B, st))
-print(f"fused step (one kernel): {tf:.3f} ms = {B/tf*1e3:.3e} samples/s")
+print(f"fdg_mc_accumulate_device, route chosen by the library: {tf:.3f} ms = {B/tf*1e3:.3e} samples/s")
 sys.exit(0)
 # chunked: leaves of one chunk are consumed by the evaluator while still in L2 / MALL
 for Bc in (1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20):
