@@ -272,3 +272,25 @@ def test_fused_step_specializes_without_device(libfdg, tmp_path):
     with pytest.raises(capi.FdgError) as e:
         h.specialize_fused(tab2, str(tmp_path))
     assert e.value.code == capi.FDG_E_UNSUPPORTED                     # "this leaftype ... not implemented!" (benchmark.jl:79)
+
+
+def test_argument_checks_of_the_newer_entry_points(libfdg):
+    """Bad arguments are rejected before any device or RCCL work (so this runs without a GPU)."""
+    import ctypes as C
+    L = capi.lib()
+    out = C.c_void_p()
+    buf = C.create_string_buffer(capi.COMM_ID_BYTES)
+    assert L.fdg_comm_create(None, 0, 1, C.byref(out)) == capi.FDG_E_INVALID
+    assert L.fdg_comm_create(buf, 2, 2, C.byref(out)) == capi.FDG_E_INVALID          # rank out of range
+    assert L.fdg_comm_create(buf, 0, 0, C.byref(out)) == capi.FDG_E_INVALID
+    assert L.fdg_comm_unique_id(buf, 16) == capi.FDG_E_INVALID                       # buffer too small
+    assert L.fdg_comm_destroy(None) == 0
+    h = capi.GraphHandle(workloads.get("sigma2"))
+    with pytest.raises(capi.FdgError) as e:                                          # companion without an ISA kernel
+        h.specialize(None, capi.FDG_SPEC_ROW_MAJOR_COMPANION)
+    assert e.value.code == capi.FDG_E_INVALID
+    with pytest.raises(capi.FdgError) as e:                                          # fused step never specialised
+        h.mc_eval_device(8, 1, 1, 8, 1, 1, 1.0, 1.0, 1.0, 8, 1, 1, 4)
+    assert e.value.code == capi.FDG_E_INVALID
+    with pytest.raises(capi.FdgError):
+        h.mc_accumulate_device(8, 1, 1, 8, 1, 1, 1.0, 1.0, 1.0, 0, 0, 4)            # null accumulator
