@@ -24,6 +24,12 @@ FP64_VALU_PEAK_TFLOPS = 78.6    # AMD spec, FMA counted as 2 (not in the local g
 
 
 def main():
+    # The result line must be the only thing on stdout.  RCCL writes a version banner to the C-level stdout
+    # (buffered, so it would land AFTER our line at exit); everything else this process or its libraries print
+    # goes to stderr, and the JSON line is written to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)   # 100 steps x 4e6 samples = 4e8 samples (config 3 names 1e8)
@@ -193,7 +199,7 @@ def main():
         out["kernel_info"] = {k: info[k] for k in ("max_live", "spec_vgpr", "spec_lds_bytes", "spec_scratch_bytes")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(t, leaf, root, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
         dist.destroy_process_group()
 
