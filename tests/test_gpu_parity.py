@@ -568,3 +568,28 @@ def test_mc_step_routes_on_large_graph(libfdg, cuda, monkeypatch):
         torch.cuda.synchronize()
         wr = (want * w[:, None]).cpu().numpy()
         assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0))), route
+
+
+def test_strides_beyond_four_gibibytes(libfdg, cuda):
+    """Leaf and root strides whose byte value does not fit 32 bits (a leaf-major matrix of more than 2^29 samples
+    per column): the kernels' 64-bit address arithmetic, on every back end."""
+    import torch
+    t = from_program(3, [(OP_PROD, 0, [(0, 1.0), (1, -2.0)]), (OP_SUM, 0, [(3, 1.0), (2, 0.5), (0, -1.0)]), (OP_POWER, 2, [(4, 1.0)])],
+                     [4, 5], "wide_stride")
+    ld = (1 << 29) + 192                       # column stride in elements: 4 GiB + 1.5 KiB
+    B = 1000
+    buf = torch.empty(3 * ld, dtype=torch.float64, device=cuda)
+    leaf = torch.as_strided(buf, (B, 3), (1, ld))
+    h = oracle.philox_uniform(B, 3, 5) - 0.4
+    leaf.copy_(torch.from_numpy(h).to(cuda))
+    rbuf = torch.full((2 * ld,), -1.0, dtype=torch.float64, device=cuda)
+    root = torch.as_strided(rbuf, (B, 2), (1, ld))
+    want = oracle.eval_static(t, h)
+    for spec in ("isa", True, False):
+        root.fill_(-1.0)
+        f = fd.compile_table(t, specialize=spec)
+        f(root, leaf)
+        torch.cuda.synchronize()
+        assert np.array_equal(root.cpu().numpy(), want), spec
+    del buf, rbuf
+    torch.cuda.empty_cache()
