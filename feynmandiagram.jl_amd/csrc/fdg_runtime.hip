@@ -198,11 +198,11 @@ fdg_weighted_partials(const double *__restrict__ root, const double *__restrict_
   }
 }
 
-// dst[l * ld + b] = src[b * ss + l]  for b < n, l < L: sample-major rows -> leaf-major columns,
+// dst[l * ld + b] = src[b * ss + l * ls]  for b < n, l < L: (usually sample-major, ls = 1) rows -> leaf-major columns,
 // 64 x 32 tiles through LDS so that both the reads (256 B runs along a row) and the writes
 // (512 B runs along a column) are coalesced.
 __global__ void __launch_bounds__(256)
-fdg_transpose_to_leaf_major(const double *__restrict__ src, long ss, double *__restrict__ dst, long ld, long n,
+fdg_transpose_to_leaf_major(const double *__restrict__ src, long ss, long ls, double *__restrict__ dst, long ld, long n,
                             uint32_t L) {
   __shared__ double tile[32][65];
   const int t = threadIdx.x;
@@ -212,7 +212,7 @@ fdg_transpose_to_leaf_major(const double *__restrict__ src, long ss, double *__r
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const long row = s0 + k * 8 + t / 32, col = l0 + t % 32;
-      if (row < n && col < L) tile[t % 32][k * 8 + t / 32] = __builtin_nontemporal_load(src + row * ss + col);
+      if (row < n && col < L) tile[t % 32][k * 8 + t / 32] = __builtin_nontemporal_load(src + row * ss + col * ls);
     }
     __syncthreads();
 #pragma unroll
@@ -452,7 +452,11 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       }
       roots = (double *)g->d_ws2; a_rs = R; a_rk = 1;
     }
-    if (ls == 1 && ss != 1 && p.L > 1) {
+    // the kernel forms a lane's offset (lane * stride * 8) in 32 bits: strides that large are brought into the
+    // leaf-major workspace first (leaves) or refused (roots); neither occurs with the layouts of DESIGN.md 2
+    const bool wide_ss = (ss < 0 ? -ss : ss) >= (1ll << 23);
+    if (mode == 0 && (rs < 0 ? -rs : rs) >= (1ll << 23)) { set_error("root sample stride of 2^23 elements or more is not supported by the ISA kernel"); return FDG_E_UNSUPPORTED; }
+    if ((ls == 1 && ss != 1 && p.L > 1) || (wide_ss && p.L > 0)) {
       // sample-major input (compile_Python's [B, L]): the ISA kernel wants a wave's 64 samples of
       // one leaf contiguous, so chunks of the batch are transposed to leaf-major first
       // (2 extra HBM passes over the leaves; in-kernel LDS staging would avoid them -- DESIGN.md 8)
@@ -482,7 +486,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
         const long n = std::min<long>(Bc, B - c0);
         const long ntile = ((n + 63) / 64) * ((p.L + 31) / 32);
         hipLaunchKernelGGL(fdg_transpose_to_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, s2,
-                           d_leaf + c0 * ss, (long)ss, (double *)((char *)g->d_ws3 + (size_t)buf * one), Bc, n, p.L);
+                           d_leaf + c0 * ss, (long)ss, (long)ls, (double *)((char *)g->d_ws3 + (size_t)buf * one), Bc, n, p.L);
         return hipEventRecord((hipEvent_t)g->ev_t[buf], s2);
       };
       HIP_TRY(transpose(0, 0));

@@ -592,4 +592,12 @@ def test_strides_beyond_four_gibibytes(libfdg, cuda):
         torch.cuda.synchronize()
         assert np.array_equal(root.cpu().numpy(), want), spec
     del buf, rbuf
+    # a sample stride too large for the kernel's 32-bit lane offsets goes through the leaf-major workspace
+    ss = (1 << 23) + 8
+    buf = torch.empty(200 * ss, dtype=torch.float64, device=cuda)
+    leaf = torch.as_strided(buf, (200, 3), (ss, 2))
+    leaf.copy_(torch.from_numpy(h[:200]).to(cuda))
+    f = fd.compile_table(t, specialize="isa")
+    assert np.array_equal(run(f, leaf), want[:200])
+    del buf
     torch.cuda.empty_cache()
