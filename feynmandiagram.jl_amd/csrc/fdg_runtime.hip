@@ -454,8 +454,8 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     }
     // the kernel forms a lane's offset (lane * stride * 8) in 32 bits: strides that large are brought into the
     // leaf-major workspace first (leaves) or refused (roots); neither occurs with the layouts of DESIGN.md 2
-    const bool wide_ss = (ss < 0 ? -ss : ss) >= (1ll << 23);
-    if (mode == 0 && (rs < 0 ? -rs : rs) >= (1ll << 23)) { set_error("root sample stride of 2^23 elements or more is not supported by the ISA kernel"); return FDG_E_UNSUPPORTED; }
+    const bool wide_ss = ss < 0 || ss >= (1ll << 23);           // (the offset is unsigned: negative strides too)
+    if (mode == 0 && (rs < 0 || rs >= (1ll << 23))) { set_error("root sample stride negative or of 2^23 elements or more is not supported by the ISA kernel"); return FDG_E_UNSUPPORTED; }
     if ((ls == 1 && ss != 1 && p.L > 1) || (wide_ss && p.L > 0)) {
       // sample-major input (compile_Python's [B, L]): the ISA kernel wants a wave's 64 samples of
       // one leaf contiguous, so chunks of the batch are transposed to leaf-major first
