@@ -12,7 +12,8 @@
 // barriers, no cross-wave traffic.  s_waitcnt is placed by an exact model of the
 // in-order vmcnt / lgkmcnt counters.
 //
-// Kernel arguments (all 8 bytes): leaf, ss, ls, root, rs, rk, ws, B, nwg
+// Kernel arguments (all 8 bytes): leaf, ss, ls, root, rs, rk, ws, B, nwg, weight
+//   (the _acc variant keeps acc_k += w * root_k in registers and writes one partial per wave and root to `root`)
 //   leaf value i of sample b: leaf[b*ss + i*ls]; root k: root[b*rs + k*rk]
 #include <cinttypes>
 #include <cstdio>

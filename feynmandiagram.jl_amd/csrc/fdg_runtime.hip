@@ -1,6 +1,8 @@
 // Device runtime behind include/fdg.h: the table-walking interpreter kernel,
-// the Philox leaf generator, the partial-sum reducer, the hiprtc/hipcc JIT for
-// per-graph straight-line kernels, and the C ABI entry points.
+// the Philox leaf generator, the partial-sum reducers, the transposition kernel,
+// the launch logic of the three back ends (ISA, HIP source, interpreter), the
+// hiprtc/hipcc/assembler JIT with its on-device autotuner, and most C ABI entry
+// points (leaf kernels and the fused step: fdg_leaf.hip; communicator: fdg_comm.cpp).
 //
 // Written for gfx950 only (wave64, 256 CUs, 160 KiB LDS per CU).  There is no
 // CPU path here: every evaluation entry point needs a device.
