@@ -198,11 +198,12 @@ std::string emit_hip_source(const Lowered &p, unsigned flags) {
 // Fused Monte-Carlo step: the leaves are not read from memory but worked out in
 // registers from the sample's momenta and times (`leaf_stmts`, produced by the runtime from the leafstates
 // tables: it declares and assigns g0 .. g{L-1}); the graph body and the outputs are those of fdg_spec_gen.
-std::string emit_fused_source(const Lowered &p, const std::string &leaf_stmts) {
+std::string emit_fused_source(const Lowered &p, const std::string &leaf_stmts, const std::string &device_functions) {
   std::ostringstream os;
   os << "// generated: fused leaves + graph, L=" << p.L << " N=" << p.N << " R=" << p.R << "\n";
   os << "#include <hip/hip_runtime.h>\n";
   os << kPrelude;
+  os << device_functions << "\n";
   os << "extern \"C\" __global__ void __launch_bounds__(256) fdg_spec_fused(const double *__restrict__ K, long ks, long kc,\n"
         "    const double *__restrict__ T, long ts, long tc, double kF, double beta, double lambda,\n"
         "    double *__restrict__ root, long rs, long rk, const double *__restrict__ weight, double *__restrict__ partial, long B, int mode) {\n";

@@ -63,7 +63,7 @@ void build_interpreter_program(Lowered &p, uint32_t lds_slot_budget);
 
 // source emitter (fdg_emit.cpp)
 std::string emit_hip_source(const Lowered &p, unsigned flags);
-std::string emit_fused_source(const Lowered &p, const std::string &leaf_stmts);
+std::string emit_fused_source(const Lowered &p, const std::string &leaf_stmts, const std::string &device_functions);
 
 // thread-local error
 void set_error(const std::string &s);

@@ -18,6 +18,41 @@
 
 using namespace fdg;
 
+// green_derive of example/benchmark.jl:93-111 for orders 1..5: (-1)^n / n! d^n/dw^n of the fermionic kernel
+// K(tau, w) = exp(-w tau) / (1 + exp(-w beta)), antiperiodic in tau.  The derivative lives in Lehmann.jl
+// (Spectral.kernelFermiT_dw*), which is not part of the reference checkout; this is the published definition in
+// an overflow-safe form, the twin of oracle.green_derive (pinned by 60-digit mpmath vectors, tests/golden/
+// green_derive.npz): on each of green()'s four branches K = sgn A g with A = exp(w a), g = 1/(1+exp(-|w| beta)),
+// d^j A = a^j A, d^k g = b^k Q_k(g) (b = +-beta, Q_0 = g, Q_{k+1} = Q_k' g (1-g)), summed by Leibniz.
+// One definition, compiled here for the table-driven kernel and pasted as text into the JIT sources.
+#define FDG_STRINGIFY(...) #__VA_ARGS__
+#define FDG_SHARED_DEVICE_CODE(...) __VA_ARGS__ static const char *kFermiDnSource = FDG_STRINGIFY(__VA_ARGS__);
+FDG_SHARED_DEVICE_CODE(
+__device__ __forceinline__ double fdg_fermi_dn(double tau, double w, double beta, int n) {
+  const double QC[6][7] = {{0, 1, 0, 0, 0, 0, 0}, {0, 1, -1, 0, 0, 0, 0}, {0, 1, -3, 2, 0, 0, 0}, {0, 1, -7, 12, -6, 0, 0},
+                           {0, 1, -15, 50, -60, 24, 0}, {0, 1, -31, 180, -390, 360, -120}};
+  const double BC[6][6] = {{1, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0}, {1, 3, 3, 1, 0, 0}, {1, 4, 6, 4, 1, 0}, {1, 5, 10, 10, 5, 1}};
+  const double NF[6] = {1.0, -1.0, 0.5, -1.0 / 6.0, 1.0 / 24.0, -1.0 / 120.0};
+  if (tau == 0.0) tau = -1e-10;
+  const bool neg = tau < 0.0;
+  const bool pos = w >= 0.0;
+  const double a = pos ? (neg ? -(tau + beta) : -tau) : (neg ? -tau : beta - tau);
+  const double A = exp(w * a);
+  const double g = 1.0 / (1.0 + exp(-fabs(w) * beta));
+  const double b = pos ? beta : -beta;
+  double total = 0.0;
+  for (int k = 0; k <= n; ++k) {
+    double q = 0.0;
+    for (int c = k + 1; c >= 0; --c) q = q * g + QC[k][c];
+    double term = BC[n][k] * q;
+    for (int j = 0; j < n - k; ++j) term = term * a;
+    for (int j = 0; j < k; ++j) term = term * b;
+    total = total + term;
+  }
+  return (neg ? -1.0 : 1.0) * A * total * NF[n];
+}
+)
+
 // Leaf values from (K, T): one lane = one sample; the tables are wave-uniform (scalar loads); the
 // sample's momenta and times are staged once in LDS columns.  The host hands the leaves over sorted by
 // (type, loop-basis index): many propagators carry the same momentum (GV 4-loop self-energy: 89 fermionic
@@ -62,6 +97,11 @@ fdg_leaf_kernel(const int32_t *__restrict__ ltype, const int32_t *__restrict__ l
       double v;
       if (ty == 1) {
         double tau = tt[(size_t)(tout[i] - 1) * 64] - tt[(size_t)(tin[i] - 1) * 64];
+        if (lorder[i] != 0) {                    // wave-uniform
+          v = fdg_fermi_dn(tau, w, beta, lorder[i]);
+          if (valid) leaf[b * ss + (long)oidx[i] * ls] = v;
+          continue;
+        }
         if (tau == 0.0) tau = -1e-10;
         // one exponential per lane: the four cases of green() differ in the argument and the sign only
         // (lanes of a wave fall into different cases; branching would evaluate exp() once per case)
@@ -122,7 +162,9 @@ static std::string emit_leaf_statements(const fdg_leaf_tables *tab, const std::v
       }
       os << "    w = q2 - kF * kF; den = 1.0 + exp(-fabs(w) * beta);\n";
     }
-    if (ty == 1) {
+    if (ty == 1 && tab->leaf_order[i] != 0) {
+      os << "    v = fdg_fermi_dn(t" << tab->tau_out[i] << " - t" << tab->tau_in[i] << ", w, beta, " << tab->leaf_order[i] << ");\n";
+    } else if (ty == 1) {
       os << "    tau = t" << tab->tau_out[i] << " - t" << tab->tau_in[i] << "; if (tau == 0.0) tau = -1e-10;\n"
             "    ap = w > 0.0 ? -w * tau : w * (beta - tau); an = w > 0.0 ? -w * (tau + beta) : -w * tau;\n"
             "    e = exp(tau > 0.0 ? ap : an); v = (tau > 0.0 ? e : -e) / den;\n";
@@ -141,9 +183,15 @@ static std::string emit_leaf_statements(const fdg_leaf_tables *tab, const std::v
   return os.str();
 }
 
+static bool needs_fermi_dn(const fdg_leaf_tables *tab) {
+  for (uint32_t i = 0; i < tab->n_leaf; ++i) if (tab->leaf_type[i] == 1 && tab->leaf_order[i] != 0) return true;
+  return false;
+}
+
 static std::string emit_leaf_source(const fdg_leaf_tables *tab, const std::vector<int32_t> &perm) {
   std::ostringstream os;
   os << "#include <hip/hip_runtime.h>\n";
+  if (needs_fermi_dn(tab)) os << kFermiDnSource << "\n";
   os << "extern \"C\" __global__ void __launch_bounds__(64) fdg_leaf_spec(const double *__restrict__ K, long ks, long kc,\n"
         "    const double *__restrict__ T, long ts, long tc, double *__restrict__ leaf, long ss, long ls, long B,\n"
         "    double kF, double beta, double lambda) {\n"
@@ -175,7 +223,7 @@ static int check_leaf_tables(const fdg_leaf_tables *tab) {
     if (ty == 0) continue;
     if (tab->loop_index[i] < 1 || (uint32_t)tab->loop_index[i] > tab->n_basis) { set_error("loop_index out of range"); return FDG_E_INVALID; }
     if (ty == 1) {
-      if (tab->leaf_order[i] != 0) { set_error("fermionic leaf of derivative order > 0 needs Lehmann.jl's kernelFermiT_dw* (not part of the reference)"); return FDG_E_UNSUPPORTED; }
+      if (tab->leaf_order[i] < 0 || tab->leaf_order[i] > 5) { set_error("not implemented!"); return FDG_E_UNSUPPORTED; }   // green_derive, benchmark.jl:108
       if (tab->tau_in[i] < 1 || tab->tau_out[i] < 1 || (uint32_t)tab->tau_in[i] > tab->n_tau || (uint32_t)tab->tau_out[i] > tab->n_tau) { set_error("tau index out of range"); return FDG_E_INVALID; }
     } else if (tab->leaf_order[i] < 0) { set_error("negative derivative order"); return FDG_E_INVALID; }
   }
@@ -340,7 +388,7 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
     std::memcpy(g->lt_hdr, hd, sizeof hd);
     if (split) { g->mc_route = 2; g->fused_code.clear(); return FDG_OK; }
   }
-  const std::string src = emit_fused_source(g->prog, emit_leaf_statements(tab, leaf_order_by_momentum(tab), true));
+  const std::string src = emit_fused_source(g->prog, emit_leaf_statements(tab, leaf_order_by_momentum(tab), true), needs_fermi_dn(tab) ? kFermiDnSource : "");
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("fused-v1")));
   const std::string dir = cache_dir ? cache_dir : (std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache");

@@ -204,8 +204,12 @@ int fdg_fill_uniform_device(double *d_leaf, int64_t n_sample, uint32_t n_leaf,
  * The per-sample leaf loop of the reference's example integrand (example/benchmark.jl:58-81):
  *   loops = K[:, 1:n_loop] * basis                       (FrontEnds.update, src/frontend/pool.jl:69-76)
  *   type 1 (fermionic G): tau = T[tau_out] - T[tau_in];  eps = |loops[:, loop_index]|^2 - kF^2;
- *                         leaf = green(tau, eps, beta)   (example/benchmark.jl:113-127; order 0 only --
- *                         higher orders call Lehmann.jl, which is not part of the reference)
+ *                         leaf = green(tau, eps, beta)   (example/benchmark.jl:113-127) for order 0;
+ *                         orders 1..5: green_derive (benchmark.jl:93-111) = (-1)^n/n! d^n/d eps^n of the
+ *                         fermionic kernel.  The reference calls Lehmann.jl's kernelFermiT_dw* for these;
+ *                         Lehmann.jl is not part of the reference checkout, so the definition is restated
+ *                         (overflow-safe closed form) and pinned by high-precision vectors, not by
+ *                         Lehmann.jl output.  Other orders: "not implemented!" like benchmark.jl:108
  *   type 2 (bosonic V):   invK = 1/(|q|^2 + lambda);     leaf = 8*pi/invK * (lambda*invK)^order
  *   type 0:               leaf left untouched
  * with the tables FrontEnds.leafstates returns (src/frontend/frontends.jl:178-232; indices 1-based as

@@ -213,9 +213,10 @@ def leaf_values(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, K, T,
             continue
         qq = q2[:, int(loop_index[i]) - 1]
         if ty == 1:
-            if int(leaf_order[i]) != 0:
-                raise NotImplementedError("green_derive order > 0 needs Lehmann.jl")
             tau = T[:, int(tau_out[i]) - 1] - T[:, int(tau_in[i]) - 1]
+            if int(leaf_order[i]) != 0:
+                out[:, i] = green_derive(tau, qq - kF * kF, beta, int(leaf_order[i]))
+                continue
             tau = np.where(tau == 0.0, -1e-10, tau)
             w = qq - kF * kF
             with np.errstate(over="ignore"):
@@ -228,6 +229,63 @@ def leaf_values(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, K, T,
         else:
             raise NotImplementedError(f"this leaftype {ty} not implemented!")
     return out
+
+
+# Polynomials Q_k with d^k/dw^k [1/(1+exp(-b w))] = b^k Q_k(g), g = 1/(1+exp(-b w)):  Q_0 = g, Q_{k+1} = Q_k'(g) g (1-g)
+_Q = [[0, 1], [0, 1, -1], [0, 1, -3, 2], [0, 1, -7, 12, -6], [0, 1, -15, 50, -60, 24], [0, 1, -31, 180, -390, 360, -120]]
+_BINOM = [[1], [1, 1], [1, 2, 1], [1, 3, 3, 1], [1, 4, 6, 4, 1], [1, 5, 10, 10, 5, 1]]
+_FACT = [1.0, 1.0, 2.0, 6.0, 24.0, 120.0]
+
+
+def green_derive(tau, w, beta, order):
+    """``green_derive`` of example/benchmark.jl:93-111 for order 1..5: (-1)^n / n! * d^n/dw^n of the fermionic
+    kernel K(tau, w) = exp(-w tau) / (1 + exp(-w beta)) on 0 < tau <= beta, antiperiodic in tau (tau == 0 is taken
+    as 0^- like ``green``, benchmark.jl:115-117).  The derivative itself lives in Lehmann.jl
+    (``Spectral.kernelFermiT_dw*``), a dependency that is not part of the reference checkout: this restates the
+    published definition in an overflow-safe form -- K = sgn A g with A = exp(w a), g = 1/(1+exp(-|w| beta)), where
+    a = -tau, beta - tau, -(tau + beta), -tau on green()'s four branches; d^j A = a^j A, d^k g = b^k Q_k(g), b = +-beta
+    -- and is pinned
+    by 50-digit mpmath derivatives (tests/golden/green_derive.npz), not by Lehmann.jl output."""
+    n = int(order)
+    if not 1 <= n <= 5:
+        raise NotImplementedError("not implemented!")        # benchmark.jl:108
+    tau = np.asarray(tau, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    tau = np.where(tau == 0.0, -1e-10, tau)
+    neg = tau < 0.0
+    sgn = np.where(neg, -1.0, 1.0)
+    pos = w >= 0.0
+    # the four branches of green() (benchmark.jl:113-127), each in its overflow-safe form K = sgn * A * g
+    a = np.where(pos, np.where(neg, -(tau + beta), -tau), np.where(neg, -tau, beta - tau))
+    with np.errstate(over="ignore"):
+        A = np.exp(w * a)
+        g = 1.0 / (1.0 + np.exp(-np.abs(w) * beta))
+    b = np.where(pos, beta, -beta)
+    total = np.zeros_like(A)
+    for k in range(n + 1):
+        q = np.zeros_like(g)
+        for c in reversed(_Q[k]):                 # Horner in g
+            q = q * g + c
+        term = _BINOM[n][k] * q
+        for _ in range(n - k):
+            term = term * a
+        for _ in range(k):
+            term = term * b
+        total = total + term
+    return sgn * A * total * ((-1.0) ** n / _FACT[n])
+
+
+def green_derive_scale(tau, w, beta, order):
+    """Magnitude of the largest Leibniz term of green_derive: the scale against which its rounding error (and
+    the cancellation between terms) is to be judged."""
+    n = int(order)
+    tau = np.asarray(tau, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    tau = np.where(tau == 0.0, -1e-10, tau)
+    neg, pos = tau < 0.0, w >= 0.0
+    a = np.where(pos, np.where(neg, -(tau + beta), -tau), np.where(neg, -tau, beta - tau))
+    with np.errstate(over="ignore"):
+        return np.exp(w * a) * (np.abs(a) + beta) ** n / _FACT[n]
 
 
 # --------------------------------------------------------------------------- #

@@ -323,9 +323,9 @@ def test_leaf_values_on_device_and_full_mc_step(libfdg, cuda):
     assert np.array_equal(roots.cpu().numpy(), ref)
     wn = w.cpu().numpy()[:, None]
     assert np.all(np.abs(acc.cpu().numpy() - (ref * wn).sum(0)) <= TOL * np.maximum(1.0, np.abs(ref * wn).sum(0)))
-    # unsupported: fermionic derivative order > 0 (Lehmann), unknown leaf type
+    # unsupported: fermionic derivative order > 5 ("not implemented!", benchmark.jl:108)
     bad = z["leaf_order"].copy()
-    bad[np.argmax(z["leaf_type"] == 1)] = 1
+    bad[np.argmax(z["leaf_type"] == 1)] = 6
     with pytest.raises(capi.FdgError) as e:
         capi.leaf_eval_device(z["leaf_type"], bad, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau, kF, beta, lam,
                               dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf.data_ptr(), leaf.stride(0), leaf.stride(1), B, st)
@@ -601,3 +601,59 @@ def test_strides_beyond_four_gibibytes(libfdg, cuda):
     assert np.array_equal(run(f, leaf), want[:200])
     del buf
     torch.cuda.empty_cache()
+
+
+def test_leaf_kernels_with_green_function_derivatives(libfdg, cuda, monkeypatch):
+    """Fermionic leaves of derivative order 1..5 (green_derive, example/benchmark.jl:93-111; the kernels of
+    Lehmann.jl restated from their definition and pinned by mpmath vectors in the CPU suite): specialised and
+    table-driven leaf kernels agree bit for bit, match the oracle within 1e-12 of the largest Leibniz term, and
+    the fused step gives the bits of the unfused route."""
+    import torch
+    z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
+    t = workloads.get("gv_sigma4")
+    L, R = t.n_leaf, t.n_root
+    fermi = np.nonzero(z["leaf_type"] == 1)[0]
+    order = z["leaf_order"].copy()
+    for n in range(1, 6):
+        order[fermi[n::6]] = n
+    B, dim, n_loop, n_tau = 20_003, 3, int(z["basis"].shape[1]), int(z["n_tau"])
+    kF, beta, lam = 1.919, 3.0, 1.2
+    rng = np.random.default_rng(3)
+    K = rng.uniform(-2.0, 2.0, size=(B, n_loop, dim))
+    T = rng.uniform(0.0, beta, size=(B, n_tau))
+    T[:, 0] = 0.0
+    T[:50, 1] = T[:50, 0]                                  # tau == 0 exactly on some samples
+    dK = torch.from_numpy(np.ascontiguousarray(K.reshape(B, n_loop * dim).T)).to(cuda)
+    dT = torch.from_numpy(np.ascontiguousarray(T.T)).to(cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (z["leaf_type"], order, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
+    out = {}
+    for mode in ("spec", "generic"):
+        if mode == "generic":
+            monkeypatch.setenv("FDG_LEAF_GENERIC", "1")
+        leaf = torch.ones((L, B), dtype=torch.float64, device=cuda).t()
+        capi.leaf_eval_device(*args, kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf.data_ptr(), leaf.stride(0), leaf.stride(1), B, st)
+        torch.cuda.synchronize()
+        out[mode] = leaf
+    monkeypatch.delenv("FDG_LEAF_GENERIC")
+    assert torch.equal(out["spec"], out["generic"])
+    got = out["spec"].cpu().numpy()
+    want = oracle.leaf_values(*args[:6], K, T, kF, beta, lam)
+    q2 = (np.einsum("bjd,nj->bnd", K, z["basis"]) ** 2).sum(axis=2)
+    for i in range(L):
+        if z["leaf_type"][i] == 1 and order[i] > 0:
+            tau = T[:, z["tau_out"][i] - 1] - T[:, z["tau_in"][i] - 1]
+            scale = oracle.green_derive_scale(tau, q2[:, z["loop_index"][i] - 1] - kF * kF, beta, int(order[i]))
+            assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-12 * scale), (i, int(order[i]))
+        elif z["leaf_type"][i] != 0:
+            assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-13 * np.abs(want[:, i])), i
+    # fused step == leaf kernel -> evaluator, bit for bit
+    f = fd.compile_table(t, specialize="isa")
+    want_root = f(None, out["spec"])
+    tab, _keep = capi.make_leaf_tables(*args)
+    h = capi.GraphHandle(t)
+    h.specialize_fused(tab)
+    root = torch.zeros((B, R), dtype=torch.float64, device=cuda)
+    h.mc_eval_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, root.data_ptr(), R, 1, B, st)
+    torch.cuda.synchronize()
+    assert torch.equal(root, want_root)

@@ -134,3 +134,21 @@ def test_root_edge_cases():
     root = np.full((1, 4), -7.0)
     out = oracle.eval_static(t, np.array([[2.0, 3.0]]), root)
     assert out[0].tolist() == [2.0, 5.0, -7.0, -7.0]
+
+
+def test_green_derive_against_high_precision_vectors():
+    """Derivative orders 1..5 of the fermionic Green's function (example/benchmark.jl:93-111).  The derivative
+    kernels belong to Lehmann.jl, which is not in the reference checkout, so the oracle restates the definition
+    and is pinned by 60-digit mpmath derivatives (tests/golden/make_green_derive.py), not by Lehmann.jl output:
+    4 845 points over tau in [-beta, beta] (incl. 0, +-beta), w up to +-700/beta, beta in {1, 3, 25}."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "green_derive.npz"))
+    for n in range(1, 6):
+        for beta in np.unique(z["beta"]):
+            m = (z["order"] == n) & (z["beta"] == beta)
+            got = oracle.green_derive(z["tau"][m], z["w"][m], beta, n)
+            scale = oracle.green_derive_scale(z["tau"][m], z["w"][m], beta, n)
+            assert np.all(np.abs(got - z["value"][m]) <= 1e-12 * np.maximum(scale, 1e-300)), (n, beta)
+    # order 1 at tau -> 0+, w = 0: -d/dw [e^{-w tau}/(1+e^{-w beta})] = tau/2 - beta/4
+    assert abs(oracle.green_derive(np.array([1e-3]), np.array([0.0]), 2.0, 1)[0] - (1e-3 / 2 - 2.0 / 4)) < 1e-15
+    with pytest.raises(NotImplementedError):
+        oracle.green_derive(np.array([0.1]), np.array([0.0]), 1.0, 6)
