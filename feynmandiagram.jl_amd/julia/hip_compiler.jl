@@ -275,3 +275,25 @@ function mc_accumulate_device!(f::GraphFunc, d_K::Ptr{Float64}, d_T::Ptr{Float64
         f.handle, d_K, k_strides[1], k_strides[2], d_T, t_strides[1], t_strides[2], kF, beta, lambda, d_weight, d_acc, B, stream))
     return nothing
 end
+
+"""
+    leaf_eval_device!(d_leaf, leafType, leafOrder, leafInTau, leafOutTau, leafLoopIndex, loopbasis, d_K, d_T, B; dim, n_tau, kF, beta, lambda)
+
+The leaf loop of `example/benchmark.jl:58-81` on the device (`fdg_leaf_eval_device`): fills the `B × L`
+column-major leaf matrix at `d_leaf` from the loop momenta `d_K` (`B × (n_loop*dim)`, column-major) and times `d_T`
+(`B × n_tau`).  Fermionic leaves of derivative order 0..5, interaction leaves of any order; type-0 leaves untouched.
+"""
+function leaf_eval_device!(d_leaf::Ptr{Float64}, leafType::Vector{Int}, leafOrder::Vector{Int}, leafInTau::Vector{Int}, leafOutTau::Vector{Int},
+    leafLoopIndex::Vector{Int}, loopbasis::Matrix{Float64}, d_K::Ptr{Float64}, d_T::Ptr{Float64}, B::Integer;
+    dim::Int=3, n_tau::Int, kF::Float64, beta::Float64, lambda::Float64, stream::Ptr{Cvoid}=C_NULL)
+    a = [Int32.(v) for v in (leafType, leafOrder, leafInTau, leafOutTau, leafLoopIndex)]
+    bs = Matrix{Float64}(loopbasis)
+    GC.@preserve a bs begin
+        tab = _FdgLeafTables(length(a[1]), size(bs, 2), size(bs, 1), dim, n_tau, pointer(a[1]), pointer(a[2]), pointer(a[3]),
+            pointer(a[4]), pointer(a[5]), pointer(bs), kF, beta, lambda)
+        _fdg_check(ccall((:fdg_leaf_eval_device, _libfdg), Cint,
+            (Ref{_FdgLeafTables}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64, Int64, Ptr{Cvoid}),
+            tab, d_K, 1, B, d_T, 1, B, d_leaf, 1, B, B, stream))
+    end
+    return nothing
+end
