@@ -15,9 +15,11 @@
 #include <cinttypes>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <sstream>
 
 #include "fdg_internal.h"
+#include "fdg_opt.h"
 
 namespace fdg {
 
@@ -104,12 +106,58 @@ static void emit_node_expr(std::ostringstream &os, const Lowered &p, uint32_t n)
   for (size_t i = 1; i < terms.size(); ++i) os << sep << terms[i] << ")";
 }
 
-static void emit_nodes(std::ostringstream &os, const Lowered &p) {
+// The graph body in the order of the optimizing back end's schedule (fdg_opt.cpp: depth-first streaming folds,
+// grouped Taylor coefficients, value numbering) instead of the reference's statement order: same fold steps, same
+// bits, but values die soon after they are born, so the compiler keeps them in registers instead of scratch.
+// Leaves are g<i>, computed values v<id>; roots are collected in r<k>.  False: the schedule does not cover the
+// graph (Power{N}, N not 2 or 3) and the caller falls back to statement order.
+static bool emit_nodes_scheduled(std::ostringstream &os, const Lowered &p, const std::function<void(std::ostringstream &, uint32_t)> &load_leaf) {
+  if (std::getenv("FDG_HIP_TABLE_ORDER")) return false;
+  std::vector<SchedOp> ops;
+  uint32_t nv = 0;
+  std::string why;
+  OptParams prm;
+  prm.vn_window = 200;
+  if (!build_schedule(p, prm, ops, nv, why)) return false;
+  auto ref = [&](uint32_t r) {
+    const uint32_t v = r >> 1;
+    std::string n = (v < p.L ? "g" : "v") + std::to_string(v);
+    return (r & 1u) ? "(-" + n + ")" : n;
+  };
+  // leaf loads are written where the schedule first needs the leaf (the compiler may still move them, but it
+  // no longer starts from "everything live at the top"); load_leaf emits nothing for a leaf it has done
+  auto need = [&](uint32_t r) { if ((r >> 1) < p.L && load_leaf) load_leaf(os, r >> 1); };
+  for (const SchedOp &o : ops) {
+    need(o.a);
+    if (o.kind == M_MUL || o.kind == M_ADD) need(o.b);
+    switch (o.kind) {
+      case M_MUL: os << "    const double v" << o.d << " = " << ref(o.a) << " * " << ref(o.b) << ";\n"; break;
+      case M_ADD: os << "    const double v" << o.d << " = " << ref(o.a) << " + " << ref(o.b) << ";\n"; break;
+      case M_MULC: os << "    const double v" << o.d << " = " << ref(o.a) << " * "; put_double(os, o.imm); os << ";\n"; break;
+      case M_ROOT: os << "    const double r" << o.d << " = " << ref(o.a) << ";\n"; break;   // (need(o.a) above covers leaf roots)
+      default: return false;
+    }
+  }
+  return true;
+}
+
+// load_all: statements that define every live leaf g<i> up front (statement order needs them; the fused kernel
+// computes them anyway); load_leaf: on-demand definition of one leaf (may be empty when load_all is used).
+static void emit_nodes(std::ostringstream &os, const Lowered &p, const std::string &load_all,
+                       const std::function<void(std::ostringstream &, uint32_t)> &load_leaf) {
+  {
+    std::ostringstream body;
+    if (!load_leaf) body << load_all;
+    if (emit_nodes_scheduled(body, p, load_leaf)) { os << body.str(); return; }
+  }
+  os << load_all;
   for (uint32_t n : p.order) {
     os << "    const double g" << (p.L + n) << " = ";
     emit_node_expr(os, p, n);
     os << ";\n";
   }
+  for (uint32_t k = 0; k < p.R; ++k)
+    if (p.root_slot[k] != FDG_NO_ROOT) os << "    const double r" << k << " = g" << p.root_slot[k] << ";\n";
 }
 
 // mode 0: roots of the block's samples; mode 1: w * root accumulated per lane, block sums at the end of the kernel
@@ -120,19 +168,19 @@ static void emit_outputs(std::ostringstream &os, const Lowered &p, bool sample_m
   for (uint32_t k = 0; k < p.R; ++k) {
     if (p.root_slot[k] == FDG_NO_ROOT) continue;
     if (pair_ok && k % 2 == 0 && k + 1 < p.R && p.root_slot[k + 1] != FDG_NO_ROOT) {
-      os << "        if (rk == 1 && ((rs & 1l) == 0l) && ((((unsigned long)root) & 15ul) == 0ul)) { fdg_d2 t; t.x = g"
-         << p.root_slot[k] << "; t.y = g" << p.root_slot[k + 1] << "; __builtin_nontemporal_store(t, (fdg_d2 *)(rp + " << k
-         << ")); } else { rp[" << k << "l * rk] = g" << p.root_slot[k] << "; rp[" << (k + 1) << "l * rk] = g"
-         << p.root_slot[k + 1] << "; }\n";
+      os << "        if (rk == 1 && ((rs & 1l) == 0l) && ((((unsigned long)root) & 15ul) == 0ul)) { fdg_d2 t; t.x = r"
+         << k << "; t.y = r" << (k + 1) << "; __builtin_nontemporal_store(t, (fdg_d2 *)(rp + " << k
+         << ")); } else { rp[" << k << "l * rk] = r" << k << "; rp[" << (k + 1) << "l * rk] = r"
+         << (k + 1) << "; }\n";
       ++k;
     } else {
-      os << "        rp[" << k << "l * rk] = g" << p.root_slot[k] << ";\n";
+      os << "        rp[" << k << "l * rk] = r" << k << ";\n";
     }
   }
   os << "      }\n    } else {\n";
   os << "      const double w = valid ? (weight ? weight[b] : 1.0) : 0.0;\n";
   for (uint32_t k = 0; k < p.R; ++k)
-    if (p.root_slot[k] != FDG_NO_ROOT) os << "      acc" << k << " = acc" << k << " + w * g" << p.root_slot[k] << ";\n";
+    if (p.root_slot[k] != FDG_NO_ROOT) os << "      acc" << k << " = acc" << k << " + w * r" << k << ";\n";
   os << "    }\n";
   os << "  }\n";
   os << "  if (mode != 0) {\n";
@@ -156,28 +204,35 @@ static void emit_kernel(std::ostringstream &os, const Lowered &p, bool sample_ma
   os << "    const bool valid = b0 < B;\n";
   os << "    const long b = valid ? b0 : (B - 1);\n";
   // body
-  if (sample_major) {
-    os << "    const double *lp = leaf + b * ss;\n";
-    os << "    const bool al = ((((unsigned long)leaf) & 15ul) == 0ul) && ((ss & 1l) == 0l);\n";
-    uint32_t i = 0;
-    while (i < L) {
-      if (i + 1 < L && p.live[i] && p.live[i + 1] && (i % 2 == 0)) {
-        os << "    double g" << i << ", g" << (i + 1) << ";\n";
-        os << "    if (al) { fdg_d2 t = __builtin_nontemporal_load((const fdg_d2 *)(lp + " << i << ")); g" << i
-           << " = t.x; g" << (i + 1) << " = t.y; } else { g" << i << " = __builtin_nontemporal_load(lp + " << i
-           << "); g" << (i + 1) << " = __builtin_nontemporal_load(lp + " << (i + 1) << "); }\n";
-        i += 2;
-      } else {
-        if (p.live[i]) os << "    const double g" << i << " = __builtin_nontemporal_load(lp + " << i << ");\n";
-        i += 1;
+  os << "    const double *lp = leaf + b * ss;\n";
+  if (sample_major) os << "    const bool al = ((((unsigned long)leaf) & 15ul) == 0ul) && ((ss & 1l) == 0l);\n";
+  std::vector<uint8_t> done(L, 0);
+  // one leaf (or, sample-major, the aligned pair it belongs to: one 16-byte load)
+  auto load_leaf = [&](std::ostringstream &o, uint32_t i) {
+    if (done[i] || !p.live[i]) return;
+    if (sample_major) {
+      const uint32_t e = i & ~1u;
+      if (e + 1 < L && p.live[e] && p.live[e + 1]) {
+        o << "    double g" << e << ", g" << (e + 1) << ";\n";
+        o << "    if (al) { fdg_d2 t = __builtin_nontemporal_load((const fdg_d2 *)(lp + " << e << ")); g" << e
+          << " = t.x; g" << (e + 1) << " = t.y; } else { g" << e << " = __builtin_nontemporal_load(lp + " << e
+          << "); g" << (e + 1) << " = __builtin_nontemporal_load(lp + " << (e + 1) << "); }\n";
+        done[e] = done[e + 1] = 1;
+        return;
       }
+      o << "    const double g" << i << " = __builtin_nontemporal_load(lp + " << i << ");\n";
+    } else {
+      o << "    const double g" << i << " = __builtin_nontemporal_load(lp + " << i << "l * ls);\n";
     }
-  } else {
-    os << "    const double *lp = leaf + b * ss;\n";
-    for (uint32_t i = 0; i < L; ++i)
-      if (p.live[i]) os << "    const double g" << i << " = __builtin_nontemporal_load(lp + " << i << "l * ls);\n";
+    done[i] = 1;
+  };
+  std::ostringstream all;
+  {
+    std::vector<uint8_t> keep = done;
+    for (uint32_t i = 0; i < L; ++i) load_leaf(all, i);
+    done = keep;                                   // (the string is only used when the lazy form is not)
   }
-  emit_nodes(os, p);
+  emit_nodes(os, p, all.str(), load_leaf);
   // outputs
   emit_outputs(os, p, sample_major);
   os << "  }\n}\n\n";
@@ -215,8 +270,7 @@ std::string emit_fused_source(const Lowered &p, const std::string &leaf_stmts, c
   os << "    const long b0 = blk * 256 + threadIdx.x;\n";
   os << "    const bool valid = b0 < B;\n";
   os << "    const long b = valid ? b0 : (B - 1);\n";
-  os << leaf_stmts;
-  emit_nodes(os, p);
+  emit_nodes(os, p, leaf_stmts, nullptr);
   emit_outputs(os, p, false);
   os << "  }\n}\n\n";
   return os.str();

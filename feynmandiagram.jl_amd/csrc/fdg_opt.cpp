@@ -529,4 +529,26 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   sort_load_runs(out.ops);
 }
 
+bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp> &ops, uint32_t &n_value, std::string &why) {
+  Builder B0(p);
+  B0.value_numbering = prm.vn_window != 1;
+  B0.vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
+  B0.vn_touch = std::getenv("FDG_VN_BIRTH_WINDOW") == nullptr;
+  build_uops(B0);
+  Lowered plain;
+  const bool retry = !B0.ok && B0.why == "inconsistent schedule groups";
+  if (retry) { plain = p; plain.sched_group.clear(); }
+  Builder B1(retry ? plain : p);
+  B1.value_numbering = B0.value_numbering; B1.vn_window = B0.vn_window; B1.vn_touch = B0.vn_touch;
+  if (retry) build_uops(B1);
+  Builder &B = retry ? B1 : B0;
+  why = B.why;
+  if (!B.ok) return false;
+  ops.clear();
+  ops.reserve(B.u.size());
+  for (const UOp &o : B.u) ops.push_back(SchedOp{o.kind, o.d, o.a, o.b, o.imm});
+  n_value = B.next_vid;
+  return true;
+}
+
 }  // namespace fdg

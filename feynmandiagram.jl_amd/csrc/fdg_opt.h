@@ -62,6 +62,12 @@ struct OptProgram {
 };
 
 void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out);
+
+// The scheduled, value-numbered fold steps before register allocation, for back ends that leave registers to a
+// compiler: values are numbered 0..n_value-1 (leaves first, in leaf order); an operand reference is
+// (value << 1) | negate.  kind: M_MUL d = a*b, M_ADD d = a+b, M_MULC d = a*imm, M_ROOT root[d] = a.
+struct SchedOp { uint8_t kind; uint32_t d, a, b; double imm; };
+bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp> &ops, uint32_t &n_value, std::string &why);
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2 = nullptr,
                      const OptProgram *prog_acc = nullptr);
 

@@ -261,7 +261,7 @@ def test_fused_step_specializes_without_device(libfdg, tmp_path):
     assert any(f.startswith("fdg_fused_") and f.endswith(".hsaco") for f in files)
     src = open(os.path.join(tmp_path, [f for f in files if f.endswith(".hip")][0])).read()
     assert "fdg_spec_fused" in src and src.count("exp(") >= 89 and "den = 1.0 + exp(-fabs(w) * beta)" in src
-    assert f"const double g{t.n_leaf} = " in src                       # first internal node follows the leaves
+    assert "const double r0 = " in src and "const double v" in src      # graph body (scheduled order) follows the leaves
     small = capi.GraphHandle(workloads.get("sigma2"))
     with pytest.raises(capi.FdgError) as e:
         small.specialize_fused(tab, str(tmp_path))
