@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--interp", action="store_true", help="same as --backend interp")
     ap.add_argument("--comm", default="torch", choices=["torch", "fdg"],
                     help="who runs the one reduction of the observable: torch.distributed (nccl == RCCL) or libfdg's fdg_comm_* (RCCL)")
+    ap.add_argument("--fast-math", action="store_true",
+                    help="FDG_SPEC_FAST_MATH: fused multiply-adds; within 1e-12 of the term scale but NOT bit-identical to the reference "
+                         "(reported separately, never the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
@@ -80,7 +83,8 @@ def main():
     B = args.samples or default_B
     if args.interp:
         args.backend = "interp"
-    f = fd.compile_table(t, specialize={"isa": "isa", "isa-autotune": "isa-autotune", "auto": "auto", "hip": True, "interp": False}[args.backend])
+    f = fd.compile_table(t, specialize={"isa": "isa", "isa-autotune": "isa-autotune", "auto": "auto", "hip": True, "interp": False}[args.backend],
+                         flags=capi.FDG_SPEC_FAST_MATH if args.fast_math else 0)
     if args.backend == "isa-autotune":
         args.backend = "isa"
 
@@ -142,7 +146,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": "f64" if not args.fast_math else "f64 (fused multiply-add: within 1e-12, not bit-identical)",
         "data": "synthetic",
         "config": {"workload": args.workload + {"sigma4_standin": " (seeded parquet-recursion stand-in for the 4-loop Parquet self-energy, ~10^4 nodes; the real graph needs the Julia front end)",
                                                 "gv_sigma4_taylor2": " (4-loop self-energy with Taylor-mode AD counterterms of order 2 in the coupling: reference GV catalog Sigma4_0_0.diag through the restated reader, taylorAD and optimize!; 7373 nodes; the 4-loop Parquet graph itself needs the Julia front end)",

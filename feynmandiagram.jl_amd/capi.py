@@ -75,16 +75,17 @@ class LeafTables(C.Structure):
 class OptParams(C.Structure):
     _fields_ = [("n_reg", C.c_uint32), ("n_lds", C.c_uint32), ("lookahead_lds", C.c_uint32),
                 ("lookahead_mem", C.c_uint32), ("lookahead_leaf", C.c_uint32), ("n_acc", C.c_uint32),
-                ("vn_window", C.c_uint32)]
+                ("vn_window", C.c_uint32), ("fma", C.c_uint32)]
 
 
 class MOp(C.Structure):
-    _fields_ = [("kind", C.c_uint8), ("nega", C.c_uint8), ("negb", C.c_uint8), ("pad", C.c_uint8),
-                ("d", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("imm", C.c_double)]
+    _fields_ = [("kind", C.c_uint8), ("nega", C.c_uint8), ("negb", C.c_uint8), ("negc", C.c_uint8),
+                ("d", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("imm", C.c_double),
+                ("c", C.c_uint32), ("pad", C.c_uint32)]
 
 
-MOP_DTYPE = np.dtype([("kind", "u1"), ("nega", "u1"), ("negb", "u1"), ("pad", "u1"),
-                      ("d", "<u4"), ("a", "<u4"), ("b", "<u4"), ("imm", "<f8")])
+MOP_DTYPE = np.dtype([("kind", "u1"), ("nega", "u1"), ("negb", "u1"), ("negc", "u1"),
+                      ("d", "<u4"), ("a", "<u4"), ("b", "<u4"), ("imm", "<f8"), ("c", "<u4"), ("pad", "<u4")])
 
 _lib = None
 
@@ -203,13 +204,13 @@ class GraphHandle:
         finally:
             lib().fdg_free(s)
 
-    def set_opt_params(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0, vn_window=0):
-        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc, vn_window)
+    def set_opt_params(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0, vn_window=0, fma=0):
+        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc, vn_window, fma)
         check(lib().fdg_graph_set_opt_params(self._h, C.byref(q)))
 
-    def opt_program(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0, vn_window=0):
+    def opt_program(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0, vn_window=0, fma=0):
         """Returns ``(ops, n_reg_used, n_lds_used, n_mem_used)``; ops is a numpy record array (MOP_DTYPE)."""
-        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc, vn_window)
+        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc, vn_window, fma)
         ops = C.POINTER(MOp)()
         n = C.c_uint64()
         nr, nl, nm, na = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()

@@ -96,6 +96,7 @@ struct fdg_graph {
   uint32_t isa2_vgpr = 0, isa2_lds_bytes = 0, isa2_mem_slots = 0;
   // fused accumulate variant (per-lane accumulators in VGPRs, roots never written)
   bool has_acc = false;
+  bool isa_fma = false;            // FDG_SPEC_FAST_MATH with FDG_SPEC_ISA: fused multiply-adds (not parity-exact)
   void *fn_isa_acc = nullptr;
   uint32_t isa3_vgpr = 0, isa3_lds_bytes = 0, isa3_mem_slots = 0;
   // companion HIP-source kernels of an ISA-specialised handle, used for sample-major input (FDG_SPEC_ROW_MAJOR_COMPANION)

@@ -15,6 +15,7 @@
 // Kernel arguments (all 8 bytes): leaf, ss, ls, root, rs, rk, ws, B, nwg, weight
 //   (the _acc variant keeps acc_k += w * root_k in registers and writes one partial per wave and root to `root`)
 //   leaf value i of sample b: leaf[b*ss + i*ls]; root k: root[b*rs + k*rk]
+#include <algorithm>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -200,7 +201,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   std::vector<uint64_t> pool;
   {
     std::map<uint64_t, int> hist;
-    for (const MOp &o : prog.ops) if (o.kind == M_MULC) {
+    for (const MOp &o : prog.ops) if (o.kind == M_MULC || o.kind == M_FMAC) {
       bool inl; f64_inline(o.imm, inl);
       if (!inl) { uint64_t u; std::memcpy(&u, &o.imm, 8); hist[u]++; }
     }
@@ -280,6 +281,18 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     if (W == 2) E.ins(opc + vhi(o.d) + ", " + (o.nega ? "-" : "") + vhi(o.a) + ", " + second_hi);
   };
 
+  // a constant multiplier as an instruction operand: inline encoding, resident SGPR pair, or moved in just now
+  auto const_operand = [&](double imm) -> std::string {
+    bool inl;
+    std::string c = f64_inline(imm, inl);
+    if (inl) return c;
+    uint64_t u;
+    std::memcpy(&u, &imm, 8);
+    for (size_t k = 0; k < pool.size(); ++k) if (pool[k] == u) return S2(S_POOL + 2 * (int)k);
+    E.ins("s_mov_b32 " + S(S_C) + ", " + hex32((uint32_t)u));
+    E.ins("s_mov_b32 " + S(S_C + 1) + ", " + hex32((uint32_t)(u >> 32)));
+    return S2(S_C);
+  };
   // ---- body ------------------------------------------------------------------
   int64_t last_leaf = -1;
   // One s_waitcnt can serve several consumers: when an op has to wait for a load, the wait also covers what
@@ -294,6 +307,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       case M_LD_LEAF: case M_LD_LDS: case M_LD_MEM: case M_LD_ACC: use(q.d); break;
       case M_ST_LDS: case M_ST_MEM: case M_ST_ACC: case M_ROOT: use(q.a); break;
       case M_MUL: case M_ADD: use(q.a); use(q.b); use(q.d); break;
+      case M_FMA: use(q.a); use(q.b); use(q.c); use(q.d); break;
+      case M_FMAC: use(q.a); use(q.c); use(q.d); break;
       case M_MULC: case M_MOV: use(q.a); use(q.d); break;
       default: break;
     }
@@ -367,22 +382,22 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       case M_MULC: {
         E.wait_reg(o.a);
         E.wait_reg(o.d);
-        bool inl;
-        std::string c = f64_inline(o.imm, inl);
-        if (!inl) {
-          uint64_t u;
-          std::memcpy(&u, &o.imm, 8);
-          int slot = -1;
-          for (size_t k = 0; k < pool.size(); ++k) if (pool[k] == u) slot = (int)k;
-          if (slot >= 0) {
-            c = S2(S_POOL + 2 * slot);
-          } else {
-            E.ins("s_mov_b32 " + S(S_C) + ", " + hex32((uint32_t)u));
-            E.ins("s_mov_b32 " + S(S_C + 1) + ", " + hex32((uint32_t)(u >> 32)));
-            c = S2(S_C);
-          }
-        }
+        const std::string c = const_operand(o.imm);
         valu2("v_mul_f64 ", o, c, c);
+        break;
+      }
+      case M_FMA:     // FDG_SPEC_FAST_MATH only
+      case M_FMAC: {
+        E.wait_reg(o.a);
+        if (o.kind == M_FMA) E.wait_reg(o.b);
+        E.wait_reg(o.c);
+        E.wait_reg(o.d);
+        const std::string k = o.kind == M_FMAC ? const_operand(o.imm) : std::string();
+        for (int h = 0; h < W; ++h) {
+          auto part = [&](uint32_t r) { return h ? vhi(r) : vlo(r); };
+          E.ins("v_fma_f64 " + part(o.d) + ", " + (o.nega ? "-" : "") + part(o.a) + ", " +
+                (o.kind == M_FMA ? (o.negb ? "-" : "") + part(o.b) : k) + ", " + (o.negc ? "-" : "") + part(o.c));
+        }
         break;
       }
       case M_LD_ACC:

@@ -22,6 +22,7 @@ struct UOp {      // micro-op over virtual values; refs are (vid << 1) | neg
   uint32_t d;     // destination vid (root index for M_ROOT)
   uint32_t a, b;  // operand refs (b unused for MULC / ROOT)
   double imm;
+  uint32_t c = 0; // addend ref of M_FMA / M_FMAC
 };
 
 struct Builder {
@@ -262,6 +263,53 @@ void build_uops(Builder &B) {
   }
 }
 
+// FDG_SPEC_FAST_MATH: a product (MUL / MULC) whose only use is as a term of an ADD is folded into that ADD as
+// a fused multiply-add at the ADD's position.  One rounding instead of two: results differ from the reference's
+// in the last bits (within 1e-12 of the sum's term scale), so this is off unless asked for.
+void fuse_fma(std::vector<UOp> &u, uint32_t n_value) {
+  std::vector<uint32_t> n_use(n_value, 0), prod(n_value, NONE);
+  auto two = [](uint8_t k) { return k == M_MUL || k == M_ADD; };
+  for (uint32_t j = 0; j < u.size(); ++j) {
+    const UOp &o = u[j];
+    n_use[o.a >> 1]++;
+    if (two(o.kind)) n_use[o.b >> 1]++;
+    if (o.kind != M_ROOT) prod[o.d] = j;
+  }
+  std::vector<uint8_t> dead(u.size(), 0);
+  for (uint32_t j = 0; j < u.size(); ++j) {
+    UOp &o = u[j];
+    if (o.kind != M_ADD) continue;
+    auto fusable = [&](uint32_t ref) -> int64_t {
+      const uint32_t v = ref >> 1;
+      if (n_use[v] != 1 || prod[v] == NONE || dead[prod[v]]) return -1;
+      const uint8_t k = u[prod[v]].kind;
+      // only a product computed just before: fusing moves the multiplication to the sum's position, and the
+      // factors of an older product would have to stay in registers until then
+      static const uint32_t reach = std::getenv("FDG_FMA_REACH") ? (uint32_t)std::atoi(std::getenv("FDG_FMA_REACH")) : 6u;
+      if (j - prod[v] > reach) return -1;
+      return (k == M_MUL || k == M_MULC) ? (int64_t)prod[v] : -1;
+    };
+    const int64_t pa = fusable(o.a), pb = (o.b >> 1) != (o.a >> 1) ? fusable(o.b) : -1;
+    if (pa < 0 && pb < 0) continue;
+    const bool take_b = pb > pa;                    // the product computed last (nearest): its operands are still around
+    const UOp m = u[take_b ? pb : pa];
+    const uint32_t term = take_b ? o.b : o.a, other = take_b ? o.a : o.b;
+    dead[take_b ? pb : pa] = 1;
+    UOp f;
+    f.kind = m.kind == M_MUL ? M_FMA : M_FMAC;
+    f.d = o.d;
+    f.a = m.a ^ (term & 1u);                        // -(x*y) == (-x)*y
+    f.b = m.kind == M_MUL ? m.b : 0;
+    f.imm = m.imm;
+    f.c = other;
+    o = f;
+  }
+  std::vector<UOp> r;
+  r.reserve(u.size());
+  for (uint32_t j = 0; j < u.size(); ++j) if (!dead[j]) r.push_back(u[j]);
+  u.swap(r);
+}
+
 // ---------------------------------------------------------------------------
 struct Alloc {
   const Lowered &p;
@@ -382,9 +430,13 @@ struct Alloc {
       const UOp &o = u[pf];
       const uint32_t va = o.a >> 1;
       if (home_kind[va] == kind) prefetch(va, j, pf);
-      if (o.kind == M_MUL || o.kind == M_ADD) {
+      if (o.kind == M_MUL || o.kind == M_ADD || o.kind == M_FMA) {
         const uint32_t vb = o.b >> 1;
         if (home_kind[vb] == kind) prefetch(vb, j, pf);
+      }
+      if (o.kind == M_FMA || o.kind == M_FMAC) {
+        const uint32_t vc = o.c >> 1;
+        if (home_kind[vc] == kind) prefetch(vc, j, pf);
       }
     }
   }
@@ -393,7 +445,8 @@ struct Alloc {
     for (uint32_t j = 0; j < u.size(); ++j) {
       const UOp &o = u[j];
       uses[o.a >> 1].push_back(j);
-      if (o.kind == M_MUL || o.kind == M_ADD) uses[o.b >> 1].push_back(j);
+      if (o.kind == M_MUL || o.kind == M_ADD || o.kind == M_FMA) uses[o.b >> 1].push_back(j);
+      if (o.kind == M_FMA || o.kind == M_FMAC) uses[o.c >> 1].push_back(j);
     }
     up.assign(nv, 0);
     reg_of.assign(nv, NONE);
@@ -410,15 +463,19 @@ struct Alloc {
       if (prm.lookahead_leaf) prefetch_window(pf_leaf, j, prm.lookahead_leaf, 3);
       if (prm.lookahead_mem) prefetch_window(pf_mem, j, prm.lookahead_mem, 2);
       if (prm.lookahead_lds) prefetch_window(pf_lds, j, prm.lookahead_lds, 1);
-      const bool two = (o.kind == M_MUL || o.kind == M_ADD);
-      const uint32_t va = o.a >> 1, vb = two ? (o.b >> 1) : NONE;
+      const bool two = (o.kind == M_MUL || o.kind == M_ADD || o.kind == M_FMA);
+      const bool three = (o.kind == M_FMA || o.kind == M_FMAC);
+      const uint32_t va = o.a >> 1, vb = two ? (o.b >> 1) : NONE, vc = three ? (o.c >> 1) : NONE;
       const uint32_t ra = ensure_in_reg(va, j);
       const uint32_t rb = two ? ensure_in_reg(vb, j) : 0;
+      const uint32_t rc = three ? ensure_in_reg(vc, j) : 0;
       // advance use cursors, free dead operands (so the destination may reuse a register)
       up[va]++;
       if (two) up[vb]++;     // (a == b: two entries at position j)
+      if (three) up[vc]++;
       if (next_use(va) == std::numeric_limits<uint32_t>::max()) kill(va);
       if (two && vb != va && next_use(vb) == std::numeric_limits<uint32_t>::max()) kill(vb);
+      if (three && vc != va && vc != vb && next_use(vc) == std::numeric_limits<uint32_t>::max()) kill(vc);
       if (o.kind == M_ROOT) {
         out.push_back(MOp{M_ROOT, (uint8_t)(o.a & 1), 0, o.d, ra, 0, 0.0});
         continue;
@@ -426,6 +483,7 @@ struct Alloc {
       const uint32_t rd = take_reg(j);
       reg_of[o.d] = rd; owner[rd] = o.d; lock[rd] = j;
       if (o.kind == M_MULC) out.push_back(MOp{M_MULC, (uint8_t)(o.a & 1), 0, rd, ra, 0, o.imm});
+      else if (three) out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), (uint8_t)(two ? (o.b & 1) : 0), rd, ra, rb, o.imm, (uint8_t)(o.c & 1), rc});
       else out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), (uint8_t)(o.b & 1), rd, ra, rb, 0.0});
       prog.n_valu++;
       if (uses[o.d].empty()) kill(o.d);   // cannot happen for reachable values; keeps the state sane
@@ -468,6 +526,8 @@ void hoist_loads(std::vector<MOp> &ops, const OptParams &prm) {
         if (last_st_mem.size() <= o.d) last_st_mem.resize(o.d + 1, -1);
         last_st_mem[o.d] = (int64_t)q; touch(o.a); break;
       case M_MUL: case M_ADD: touch(o.a); touch(o.b); touch(o.d); break;
+      case M_FMA: touch(o.a); touch(o.b); touch(o.c); touch(o.d); break;
+      case M_FMAC: touch(o.a); touch(o.c); touch(o.d); break;
       case M_MULC: case M_MOV: touch(o.a); touch(o.d); break;
       case M_ROOT: touch(o.a); break;
       case M_LD_ACC: touch(o.d); break;
@@ -522,6 +582,7 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   out.why = B.why;
   if (!B.ok) return;
   if (prm.n_reg < 4) { out.supported = false; out.why = "too few registers"; return; }
+  if (prm.fma) fuse_fma(B.u, B.next_vid);
   Alloc A(p, prm, B.u, B.next_vid, out);
   A.run();
   out.ops.swap(A.out);

@@ -31,6 +31,8 @@ enum MKind : uint8_t {
   M_MOV,          // r[d] = +-r[a]        (only for a root that aliases a negated value)
   M_LD_ACC,       // r[d] = acc[a]        (AGPR pair -> VGPR pair, two v_accvgpr_read_b32)
   M_ST_ACC,       // acc[d] = r[a]
+  M_FMA = 14,     // r[d] = (+-r[a]) * (+-r[b]) + (+-r[c])   one rounding: only with OptParams::fma (not parity-exact)
+  M_FMAC = 15,    // r[d] = (+-r[a]) * imm + (+-r[c])
 };
 
 struct MOp {
@@ -38,6 +40,8 @@ struct MOp {
   uint8_t nega, negb;
   uint32_t d, a, b;
   double imm;
+  uint8_t negc = 0;     // M_FMA / M_FMAC only
+  uint32_t c = 0;
 };
 
 struct OptParams {
@@ -48,6 +52,7 @@ struct OptParams {
   uint32_t lookahead_mem = 128;   // ... for loads from the workspace panel (L2 / HBM)
   uint32_t vn_window = 200;       // value numbering: 1 = off, 0 = reuse any earlier identical op, n > 1 = only results at most n ops old
   uint32_t lookahead_leaf = 300;  // ... for first-use loads of leaves (HBM)
+  bool fma = false;               // FDG_SPEC_FAST_MATH: a product used once, by a sum, is fused into it (v_fma_f64)
 };
 
 struct OptProgram {

@@ -713,11 +713,12 @@ static fdg::OptParams to_params(const fdg_opt_params *q) {
     if (q->lookahead_leaf) prm.lookahead_leaf = q->lookahead_leaf;
     if (q->n_acc) prm.n_acc = std::min<uint32_t>(q->n_acc, 124);
     if (q->vn_window) prm.vn_window = q->vn_window;
+    prm.fma = q->fma != 0;
   }
   return prm;
 }
 
-static fdg_opt_params g_default_opt = {0, 0, 0, 0, 0, 0, 0};
+static fdg_opt_params g_default_opt = {0, 0, 0, 0, 0, 0, 0, 0};
 struct OptStore { std::mutex mu; std::vector<std::pair<const fdg_graph *, fdg_opt_params>> v; };
 static OptStore &opt_store() { static OptStore s; return s; }
 
@@ -756,7 +757,7 @@ int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop *
   if (!m) { set_error("out of memory"); return FDG_E_NOMEM; }
   for (size_t i = 0; i < prog.ops.size(); ++i) {
     const fdg::MOp &o = prog.ops[i];
-    m[i] = fdg_mop{o.kind, o.nega, o.negb, 0, o.d, o.a, o.b, o.imm};
+    m[i] = fdg_mop{o.kind, o.nega, o.negb, o.negc, o.d, o.a, o.b, o.imm, o.c, 0};
   }
   *ops = m; *n_ops = prog.ops.size();
   if (n_reg_used) *n_reg_used = prog.n_reg_used;
@@ -830,6 +831,12 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
   g->spec_flags = flags;
 }
 
+// every program of a handle specialised with FDG_SPEC_FAST_MATH fuses products into sums (v_fma_f64)
+static void build_prog(const fdg_graph *g, fdg::OptParams prm, fdg::OptProgram &out) {
+  prm.fma = prm.fma || g->isa_fma;
+  fdg::build_opt_program(g->prog, prm, out);
+}
+
 // the automatic configurations: S tiny graphs, A two waves/SIMD, B one wave/SIMD + AGPR level
 static fdg::OptParams cfg_S() { fdg::OptParams S; S.n_reg = 28; S.n_lds = 1; S.n_acc = 0; S.lookahead_leaf = 300; S.vn_window = 200; return S; }
 static fdg::OptParams cfg_A() { fdg::OptParams A; A.n_reg = 120; A.n_lds = 40; A.n_acc = 0; A.lookahead_leaf = 300; A.vn_window = 200; return A; }
@@ -839,13 +846,13 @@ static fdg::OptParams cfg_B() {
 
 static fdg::OptParams auto_program(const fdg_graph *g, fdg::OptProgram &prog) {
   fdg::OptProgram ps;
-  fdg::build_opt_program(g->prog, cfg_S(), ps);
+  build_prog(g, cfg_S(), ps);
   const bool small_ok = ps.supported && ps.n_ld_leaf <= g->prog.n_live_leaf && ps.n_ld_lds + ps.n_st_lds + ps.n_ld_mem + ps.n_st_mem == 0;
   if (small_ok) { prog = std::move(ps); return cfg_S(); }
-  fdg::build_opt_program(g->prog, cfg_A(), prog);
+  build_prog(g, cfg_A(), prog);
   if (prog.supported && (prog.n_ld_mem + prog.n_st_mem) * 100 > prog.n_valu) {   // > 1 % of the ops touch the HBM panel
     fdg::OptProgram pb;
-    fdg::build_opt_program(g->prog, cfg_B(), pb);
+    build_prog(g, cfg_B(), pb);
     if (pb.supported) { prog = std::move(pb); return cfg_B(); }
   }
   return cfg_A();
@@ -879,10 +886,10 @@ static bool auto_program_w2(const fdg_graph *g, fdg::OptProgram &p2) {
   // 66 %), so it is opt-in (FDG_ISA_W2=1) and kept only as an experiment.
   if (!std::getenv("FDG_ISA_W2")) return false;
   const fdg::Lowered &p = g->prog;
-  fdg::build_opt_program(p, cfg_W2T(), p2);
+  build_prog(g, cfg_W2T(), p2);
   bool ok = p2.supported && p2.n_ld_leaf <= p.n_live_leaf && p2.n_ld_lds + p2.n_st_lds + p2.n_ld_mem + p2.n_st_mem == 0;
   if (!ok) {
-    fdg::build_opt_program(p, cfg_W2(), p2);
+    build_prog(g, cfg_W2(), p2);
     ok = p2.supported && p2.n_ld_mem + p2.n_st_mem == 0;
   }
   if (!ok) return false;
@@ -904,7 +911,7 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
   const uint32_t arch = std::min<uint32_t>(budget - 2 * chosen.n_acc, 256);   // architectural VGPRs end at v255
   if (arch < 6 + 2 * extra + 16) return false;
   q.n_reg = std::min<uint32_t>(chosen.n_reg, (arch - 6 - 2 * extra) / 2);
-  fdg::build_opt_program(g->prog, q, pa);
+  build_prog(g, q, pa);
   return pa.supported;
 }
 
@@ -918,7 +925,7 @@ static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   buf.push_back(0);
   if (std::sscanf(buf.data(), "%u %u %u %u %u %u %u", &q.n_reg, &q.n_lds, &q.n_acc, &q.lookahead_lds, &q.lookahead_mem, &q.lookahead_leaf, &q.vn_window) != 7) return 0;
   fdg::OptProgram prog;
-  fdg::build_opt_program(p, q, prog);
+  build_prog(g, q, prog);
   if (!prog.supported) return 0;
   fdg::OptProgram p2, pa;
   const bool w2 = !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, p2);
@@ -967,7 +974,7 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   std::string seen;
   for (size_t c = 0; c < cand.size(); ++c) {
     fdg::OptProgram prog;
-    fdg::build_opt_program(p, cand[c], prog);
+    build_prog(g, cand[c], prog);
     if (!prog.supported) continue;
     if (c == 0 && !(prog.n_ld_leaf <= p.n_live_leaf && prog.n_ld_lds + prog.n_st_lds + prog.n_ld_mem + prog.n_st_mem == 0)) continue;
     std::vector<char> co; std::string hash;
@@ -996,7 +1003,7 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   hipFree(d_leaf); hipFree(d_root);
   if (best < 0) { set_error("autotune: no candidate configuration ran"); return FDG_E_JIT; }
   fdg::OptProgram prog;
-  fdg::build_opt_program(p, cand[best], prog);
+  build_prog(g, cand[best], prog);
   fdg::OptProgram p2, pa;
   const bool w2 = !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, p2);
   const bool acc = build_acc_program(g, cand[best], pa);
@@ -1020,7 +1027,7 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
   if (has_opt_params(g)) {
     const fdg_opt_params q = get_opt_params(g);
     chosen = to_params(&q);
-    fdg::build_opt_program(g->prog, chosen, prog);
+    build_prog(g, chosen, prog);
   } else {
     chosen = auto_program(g, prog);
   }
@@ -1039,6 +1046,7 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
   if (!g) { set_error("null handle"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
   if (flags & FDG_SPEC_ISA) {
+    g->isa_fma = (flags & FDG_SPEC_FAST_MATH) != 0;
     std::string dir0 = cache_dir ? cache_dir : (std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache");
     mkdir(dir0.c_str(), 0777);
     return specialize_isa(g, dir0, flags);

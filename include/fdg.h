@@ -107,7 +107,9 @@ typedef struct fdg_graph_info {
 /* flags for fdg_graph_specialize */
 #define FDG_SPEC_DEFAULT 0u
 #define FDG_SPEC_KEEP_SOURCE 1u   /* leave the generated source next to the code object */
-#define FDG_SPEC_FAST_MATH 2u     /* allow FMA contraction: NOT parity-exact, reported separately */
+#define FDG_SPEC_FAST_MATH 2u     /* allow FMA contraction (compiler flag for HIP source; with FDG_SPEC_ISA a product used
+                                   * once by a sum becomes v_fma_f64): NOT bit-exact -- within 1e-12 of the sums' term
+                                   * scale -- and reported separately */
 #define FDG_SPEC_AUTOTUNE 8u      /* with FDG_SPEC_ISA: pick the configuration by timing a few candidates on
                                      the device (needs one); the choice is remembered in the cache directory */
 #define FDG_SPEC_ROW_MAJOR_COMPANION 16u /* keep the handle's current (FDG_SPEC_ISA) kernels and add the HIP-source ones next to
@@ -147,6 +149,7 @@ typedef struct fdg_opt_params {
   uint32_t lookahead_leaf; /* prefetch distance, in ops, of first-use leaf loads (HBM) */
   uint32_t n_acc;          /* AGPR pairs per lane used as a spill level (<= 124; 0 with two waves per SIMD) */
   uint32_t vn_window;      /* value numbering of identical fold steps: 0 default, 1 off, n > 1 window in ops */
+  uint32_t fma;            /* fdg_graph_opt_program only: 1 = fuse products into sums like FDG_SPEC_FAST_MATH does */
 } fdg_opt_params;
 
 /* One op of the register-allocated program (for inspection and for host-side
@@ -155,9 +158,11 @@ typedef struct fdg_opt_params {
  * 5 MUL r[d]=(+-r[a])*(+-r[b]), 6 ADD, 7 MULC r[d]=(+-r[a])*imm, 8 ROOT root[d]=+-r[a],
  * 10 LD_ACC r[d]=acc[a], 11 ST_ACC acc[d]=r[a]. */
 typedef struct fdg_mop {
-  uint8_t kind, nega, negb, pad;
+  uint8_t kind, nega, negb, negc;
   uint32_t d, a, b;
   double imm;
+  uint32_t c, pad;     /* third source of kinds 14 FMA r[d]=(+-r[a])*(+-r[b])+(+-r[c]) and 15 FMAC r[d]=(+-r[a])*imm+(+-r[c]),
+                        * which only FDG_SPEC_FAST_MATH programs contain */
 } fdg_mop;
 
 /* Optional scheduling hint for FDG_SPEC_ISA: group[n] (n < n_node) tags internal nodes that belong

@@ -657,3 +657,26 @@ def test_leaf_kernels_with_green_function_derivatives(libfdg, cuda, monkeypatch)
     h.mc_eval_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, root.data_ptr(), R, 1, B, st)
     torch.cuda.synchronize()
     assert torch.equal(root, want_root)
+
+
+@pytest.mark.parametrize("name", ["sigma2", "gv_sigma4", "gv_sigma4_taylor2", "gv_sigma5"])
+def test_fast_math_isa_within_stated_tolerance(libfdg, cuda, name):
+    """FDG_SPEC_ISA | FDG_SPEC_FAST_MATH: products used once by a sum are fused (v_fma_f64, one rounding instead
+    of two).  Not bit-exact by construction; BASELINE.json's tolerance -- 1e-12 of the root's term scale -- holds
+    with room to spare, for evaluation and for the fused accumulation.  (The default mode stays bit-exact.)"""
+    import torch
+    t = workloads.get(name)
+    f = fd.compile_table(t, specialize="isa", flags=capi.FDG_SPEC_FAST_MATH)
+    B = 30_011
+    leaf = dev_leaves(cuda, B, t.n_leaf, 17, 0, "leaf_major")
+    h_leaf = leaf.cpu().numpy()
+    got = run(f, leaf)
+    want = oracle.eval_static(t, h_leaf)
+    scale = np.maximum(1.0, oracle.root_scale(t, h_leaf))
+    assert np.all(np.abs(got - want) <= TOL * scale)
+    assert not np.array_equal(got, want) or name == "sigma2"          # it really is a different rounding
+    w = torch.rand(B, dtype=torch.float64, device=cuda)
+    acc = f.accumulate(leaf, w)
+    torch.cuda.synchronize()
+    wr = want * w.cpu().numpy()[:, None]
+    assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0)) <= 2 * TOL * np.maximum(1.0, (scale * w.cpu().numpy()[:, None]).sum(0)))

@@ -196,6 +196,8 @@ def replay(ops, n_reg, n_lds, n_mem, n_acc, leaf, R):
         elif k == 8: root[:, d] = sa * reg[a]
         elif k == 10: reg[d] = acc[a]
         elif k == 11: acc[d] = reg[a]
+        elif k == 14: reg[d] = (sa * reg[a]) * (sb * reg[b]) + (-1.0 if o["negc"] else 1.0) * reg[int(o["c"])]     # FMA (two roundings here)
+        elif k == 15: reg[d] = (sa * reg[a]) * o["imm"] + (-1.0 if o["negc"] else 1.0) * reg[int(o["c"])]
         else: raise AssertionError(k)
     return root
 
@@ -345,3 +347,21 @@ def test_committed_taylor_table_satisfies_series_identity():
     series = c[0] + x * c[1] + x * x * c[2]
     assert np.all(np.abs(series - f_x) < 1e-2 * np.abs((c[0] + x * c[1]) - f_x))
     assert np.all(np.abs(c[0] - oracle.eval_static(t0, v[0][None, :])[0]) <= 1e-12 * (1 + np.abs(c[0])))
+
+
+@pytest.mark.parametrize("name", ["sigma2", "gv_sigma4", "gv_sigma5", "gv_sigma4_taylor2"])
+def test_fast_math_program_fuses_products_into_sums(libfdg, name):
+    """FDG_SPEC_FAST_MATH for the optimizing back end: products used once by a sum become fused multiply-adds.
+    Fewer ops, same values up to the one rounding saved per fusion: within 1e-12 of the roots' term scale."""
+    t = workloads.get(name)
+    h = capi.GraphHandle(t)
+    strict, *_ = h.opt_program()
+    ops, nr, nl, nm = h.opt_program(fma=1)
+    valu = lambda o: int(np.isin(o["kind"], (5, 6, 7, 14, 15)).sum())
+    assert not np.isin(strict["kind"], (14, 15)).any()
+    n_fma = int(np.isin(ops["kind"], (14, 15)).sum())
+    assert n_fma > 0 and valu(ops) == valu(strict) - n_fma
+    leaf = oracle.philox_uniform(9, t.n_leaf, 5)
+    got = replay(ops, nr, nl, nm, h.last_n_acc, leaf, t.n_root)
+    want = oracle.eval_static(t, leaf)
+    assert np.all(np.abs(got - want) <= 1e-12 * np.maximum(1.0, oracle.root_scale(t, leaf)))
