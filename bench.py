@@ -194,6 +194,9 @@ def main():
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(args.workload)
             if tr and tr["layout"] == args.layout and args.backend == "isa":
                 out["roofline"]["traffic"] = tr["bytes_per_eval"] * B
+                # the same launch time against the bytes the PMC counters saw move (re-read leaves, partial-line root writes)
+                out["roofline"]["traffic_gbs"] = tr["bytes_per_eval"] * B / avg_kernel_s / 1e9
+                out["roofline"]["traffic_frac"] = out["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
                 out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " + tr.get("source", "profiles/") + " (per evaluation, scaled to this batch)"
         except (OSError, ValueError):
             pass
