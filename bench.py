@@ -92,8 +92,12 @@ def main():
         leaf = torch.empty((B, L), dtype=torch.float64, device=dev)
     else:
         leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
-    root = torch.empty((B, R), dtype=torch.float64, device=dev)   # row-major roots (compile_Python's [B, R]): measured faster than
-    #                                                                  R more column streams for the HBM-bound graphs, equal for the others
+    if args.layout == "sample_major":
+        root = torch.empty((B, R), dtype=torch.float64, device=dev)          # compile_Python's row-major [B, R]
+    else:
+        # a Julia column-major B x R matrix, like the leaves: a wave's 64 values of one root are one 512-byte line-aligned
+        # store (row-major roots leave L2 as partial lines: 2.5x the bytes for R = 6; tools/gpu_root_layout.py)
+        root = torch.empty((R, B), dtype=torch.float64, device=dev).t()
     stream = torch.cuda.current_stream()
     # per-rank Philox offset: results do not depend on how samples are sharded
     start, count = shard_range(B * world, rank, world)          # weak scaling: B samples per GPU
