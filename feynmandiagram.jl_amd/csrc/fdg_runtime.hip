@@ -955,6 +955,8 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   cand.push_back(cfg_B());
   { fdg::OptParams q = cfg_B(); q.vn_window = 0; cand.push_back(q); }
   { fdg::OptParams q = cfg_B(); q.vn_window = 200; cand.push_back(q); }
+  { fdg::OptParams q = cfg_B(); q.vn_window = 400; q.lookahead_leaf = 300; q.lookahead_mem = 128; cand.push_back(q); }
+  { fdg::OptParams q = cfg_A(); q.vn_window = 300; cand.push_back(q); }
   { fdg::OptParams q = cfg_A(); q.n_reg = 80; q.n_lds = 26; cand.push_back(q); }     // three waves per SIMD
   { fdg::OptParams q = cfg_A(); q.n_reg = 56; q.n_lds = 20; cand.push_back(q); }     // four waves per SIMD
   // batch: at least two tiles per resident wave, and enough bytes (about 0.4 GB of leaves) that a run

@@ -11,7 +11,7 @@ B = {"sigma2": 64_000_000, "gv_sigma4": 8_000_000, "gv_sigma5": 2_000_000, "gv_s
 dev = torch.device("cuda:0")
 leaf = torch.empty((t.n_leaf, B), dtype=torch.float64, device=dev).t()
 capi.fill_uniform_device(leaf.data_ptr(), B, t.n_leaf, leaf.stride(0), leaf.stride(1), 1234, 0, torch.cuda.current_stream().cuda_stream)
-root = torch.empty((B, t.n_root), dtype=torch.float64, device=dev)
+root = torch.empty((t.n_root, B), dtype=torch.float64, device=dev).t()
 for spec in sys.argv[2:]:
     opt = {k: int(v) for k, v in (kv.split("=") for kv in spec.split(","))} if spec != "tuned" else None
     f = fd.compile_table(t, specialize="isa", opt=opt, cache_dir="/tmp/kc_sweep" if opt else None)
