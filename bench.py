@@ -110,7 +110,12 @@ def main():
     step()
     _ = root.sum(dim=0)                   # load the reduction used for the final observable now: a pause between the
     torch.cuda.synchronize()              # warm-up and the timed steps would let the clocks fall back
-    for _ in range(args.warmup):
+    # Clock settling: after idle the first ~50 launches run at transient clocks (boost, then throttle, then the
+    # sustained state: 1.10 -> 1.40 -> 1.05-1.15 ms per launch on the default workload).  The timed steps are meant to
+    # show the sustained rate, so at least 60 untimed launches precede them whatever --warmup says (disclosed in the
+    # JSON line as config.settle_steps; they are the same step as the warm-up and the timed ones).
+    settle = max(0, 60 - args.warmup)
+    for _ in range(settle + args.warmup):
         step()
     torch.cuda.synchronize()
     if dist:
@@ -158,7 +163,7 @@ def main():
                                                 "gv_sigma6": " (reference GV catalog Sigma6_0_0.diag through the restated reader + optimize!)"}.get(args.workload, ""),
                    "graph": t.name, "n_leaf": L, "n_node": t.n_node, "n_edge": t.n_edge, "n_root": R,
                    "flops_per_eval": st["flops_alg"], "bytes_per_eval": st["bytes_alg"],
-                   "samples_per_step_per_gpu": B, "layout": args.layout,
+                   "samples_per_step_per_gpu": B, "layout": args.layout, "settle_steps": settle,
                    "kernel": {"isa": "fdg_isa_eval (per-graph gfx950 assembly)", "hip": "fdg_spec (per-graph HIP source, hiprtc)",
                               "auto": "fdg_isa_eval, or its HIP-source companion fdg_spec_sm for row-major input of small graphs",
                               "interp": "fdg_interp (table interpreter)"}[args.backend],
