@@ -31,7 +31,7 @@ EXPORTS = [
     "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_graph_release_device", "fdg_powi",
     "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
-    "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device",
+    "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
 ]
 COMM_ID_BYTES = 128
 
@@ -130,6 +130,8 @@ def lib():
     L.fdg_graph_set_opt_params.argtypes = [vp, C.POINTER(OptParams)]
     L.fdg_graph_opt_program.argtypes = [vp, C.POINTER(OptParams), C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64),
                                         C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.fdg_graph_mc_program.argtypes = [vp, C.POINTER(LeafTables), C.POINTER(OptParams), C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64),
+                                       C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.fdg_graph_specialize_fused.argtypes = [vp, C.POINTER(LeafTables), C.c_char_p, C.c_uint]
     L.fdg_mc_eval_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, C.c_double, C.c_double, C.c_double, dp, i64, i64, i64, vp]
     L.fdg_mc_accumulate_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, C.c_double, C.c_double, C.c_double, dp, dp, i64, vp]
@@ -222,6 +224,21 @@ class GraphHandle:
         finally:
             lib().fdg_free(ops)
         self.last_n_acc = na.value
+        return arr, nr.value, nl.value, nm.value
+
+    def mc_program(self, tables, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0, vn_window=0, fma=0):
+        """The program of the fused ISA step (leaves computed from the input columns K components, then times;
+        ``tables`` from make_leaf_tables with kF, beta, lam set).  Returns like :meth:`opt_program`."""
+        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc, vn_window, fma)
+        ops = C.POINTER(MOp)()
+        n = C.c_uint64()
+        nr, nl, nm, na = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().fdg_graph_mc_program(self._h, C.byref(tables), C.byref(q), C.byref(ops), C.byref(n), C.byref(nr),
+                                         C.byref(nl), C.byref(nm), C.byref(na)))
+        try:
+            arr = np.frombuffer(C.string_at(ops, n.value * C.sizeof(MOp)), dtype=MOP_DTYPE).copy()
+        finally:
+            lib().fdg_free(ops)
         return arr, nr.value, nl.value, nm.value
 
     def specialize(self, cache_dir: Optional[str] = None, flags: int = 0):

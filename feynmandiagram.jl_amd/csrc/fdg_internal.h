@@ -106,11 +106,19 @@ struct fdg_graph {
   std::vector<char> fused_code;
   void *fused_module = nullptr, *fn_fused = nullptr;
   // ... or, for graphs too large for a compiler-scheduled kernel, leaf kernel -> chunk of leaves -> this handle's evaluator
-  int mc_route = 0;                // 0 none, 1 fused kernel, 2 leaf kernel + evaluator
+  int mc_route = 0;                // 0 none, 1 fused HIP kernel, 2 leaf kernel + evaluator, 3 fused ISA kernel
   std::vector<int32_t> lt_i32[5];  // copy of the leafstates tables (type, order, tau_in, tau_out, loop_index)
   std::vector<double> lt_basis;
   uint32_t lt_hdr[5] = {0, 0, 0, 0, 0};   // n_leaf, n_basis, n_loop, dim, n_tau
-  void *d_ws4 = nullptr;           // leaf-major chunk of leaves for route 2
+  // ... or (route 3) ONE kernel of the optimizing back end whose leaves are computed in registers from (K, T)
+  std::vector<char> mc_code;
+  void *mc_module = nullptr, *fn_mc = nullptr, *fn_mc_acc = nullptr;
+  bool mc_has_acc = false, mc_built = false;
+  uint32_t mc_vgpr[2] = {0, 0}, mc_lds[2] = {0, 0}, mc_mem[2] = {0, 0};   // [0] eval kernel, [1] accumulate kernel
+  double mc_const[3] = {0, 0, 0};  // kF, beta, lambda the kernel was built for (they are constants of its code)
+  std::string mc_dir;
+  unsigned mc_flags = 0;
+  void *d_ws4 = nullptr;           // leaf-major chunk of leaves for route 2 / packed (K, T) columns for route 3
   size_t ws4_bytes = 0;
   void *d_ws2 = nullptr;           // roots scratch for accumulate through the ISA kernel
   size_t ws2_bytes = 0;
@@ -139,6 +147,12 @@ int ensure_ws(fdg_graph *g, size_t bytes);       // grows the handle's device wo
 int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root, int64_t rs, int64_t rk,
                    const double *d_weight, double *d_acc, int64_t B, hipStream_t st);   // caller holds g->mu
 int launch_reduce_partials(const double *partial, uint32_t nblk, uint32_t R, double *acc, hipStream_t st);
+// Monte-Carlo step through one ISA kernel (fdg_runtime.hip); callers hold g->mu
+bool fdg_mc_isa_supported(fdg_graph *g, const fdg_leaf_tables *tab, std::string &why);
+int fdg_mc_isa_build(fdg_graph *g, double kF, double beta, double lambda);   // host-only (assembler); no-op when current
+int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_t kc, const double *d_T, int64_t ts, int64_t tc,
+                   double kF, double beta, double lambda, double *d_root, int64_t rs, int64_t rk, const double *d_weight,
+                   double *d_acc, int64_t B, hipStream_t st);
 #endif
 namespace fdg { const char *last_error_cstr(); }
 uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull);

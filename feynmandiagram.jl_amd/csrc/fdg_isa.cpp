@@ -37,8 +37,14 @@ constexpr int S_LP = 48;     // running pointer: column of the most recently loa
 constexpr int S_DELTA = 50;  // up to N_DELTA pairs: (leaf stride in bytes) x the most frequent index steps between consecutive loads
 constexpr int N_DELTA = 6;
 constexpr int S_POOL = S_DELTA + 2 * N_DELTA;   // constants of the graph (edge factors without an inline encoding), loaded once per wave
-constexpr int N_POOL = 16;
+constexpr int N_POOL = 20;   // (16 are used by programs without leaf formulas)
 constexpr int S_END = S_POOL + 2 * N_POOL;
+
+// exp(x), x <= 0 in practice: n = rint(x log2 e), r = x - n ln2 (two-part), exp(r) by its Taylor polynomial of degree 13
+// (|r| <= 0.347: truncation 4e-18), scaled by 2^n with v_ldexp_f64 (flushes to 0 / denormals correctly far below)
+const double kLog2e = 0x1.71547652b82fep+0, kLn2Hi = 0x1.62e42fefa39efp-1, kLn2Lo = 0x1.abc9e3b39803fp-56;
+const double kExpC[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                          1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
 
 struct Emit {
   std::ostringstream os;
@@ -162,6 +168,12 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const uint32_t acc0 = V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1);
   auto vacc = [&](uint32_t k) { const uint32_t b = acc0 + 2 * k; return "v[" + std::to_string(b) + ":" + std::to_string(b + 1) + "]"; };
   const std::string vwgt = vacc(p.R), vtmp = vacc(p.R + 1);
+  // programs with leaf formulas: two more temporaries (register pairs) above those
+  bool has_macro = false;
+  for (const MOp &o : prog.ops) if (mop_is_macro(o.kind)) { has_macro = true; break; }
+  const uint32_t tmp0 = acc0 + (accumulate ? 2 * (p.R + 2) : 0);
+  const std::string tA = "v[" + std::to_string(tmp0) + ":" + std::to_string(tmp0 + 1) + "]", tB = "v[" + std::to_string(tmp0 + 2) + ":" + std::to_string(tmp0 + 3) + "]";
+  auto tAd = [&](int h) { return "v" + std::to_string(tmp0 + h); };
   if (accumulate)
     for (uint32_t k = 0; k < p.R; ++k) {
       E.ins("v_mov_b32_e32 v" + std::to_string(acc0 + 2 * k) + ", 0");
@@ -201,14 +213,15 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   std::vector<uint64_t> pool;
   {
     std::map<uint64_t, int> hist;
-    for (const MOp &o : prog.ops) if (o.kind == M_MULC || o.kind == M_FMAC) {
-      bool inl; f64_inline(o.imm, inl);
-      if (!inl) { uint64_t u; std::memcpy(&u, &o.imm, 8); hist[u]++; }
+    auto count = [&](double f) { bool inl; f64_inline(f, inl); if (!inl) { uint64_t u; std::memcpy(&u, &f, 8); hist[u]++; } };
+    for (const MOp &o : prog.ops) {
+      if (o.kind == M_MULC || o.kind == M_FMAC || o.kind == M_ADDC || o.kind == M_FIXZ || o.kind == M_SELC) count(o.imm);
+      if (o.kind == M_EXP) { count(kLog2e); count(-kLn2Hi); count(-kLn2Lo); for (int k = 3; k < 14; ++k) count(kExpC[k]); }
     }
     std::vector<std::pair<int, uint64_t>> v;
     for (auto &kv : hist) v.push_back({kv.second, kv.first});
     std::sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
-    for (size_t i = 0; i < v.size() && i < (size_t)N_POOL; ++i) pool.push_back(v[i].second);
+    for (size_t i = 0; i < v.size() && i < (size_t)(has_macro ? N_POOL : 16); ++i) pool.push_back(v[i].second);
   }
   for (size_t k = 0; k < pool.size(); ++k) {
     E.ins("s_mov_b32 " + S(S_POOL + 2 * (int)k) + ", " + hex32((uint32_t)pool[k]));
@@ -293,6 +306,16 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("s_mov_b32 " + S(S_C + 1) + ", " + hex32((uint32_t)(u >> 32)));
     return S2(S_C);
   };
+  // the same constant as an SGPR pair (first register), for v_mov_b32 of its halves
+  auto const_sgpr = [&](double imm) -> int {
+    uint64_t u;
+    std::memcpy(&u, &imm, 8);
+    for (size_t k = 0; k < pool.size(); ++k) if (pool[k] == u) return S_POOL + 2 * (int)k;
+    E.ins("s_mov_b32 " + S(S_C) + ", " + hex32((uint32_t)u));
+    E.ins("s_mov_b32 " + S(S_C + 1) + ", " + hex32((uint32_t)(u >> 32)));
+    return S_C;
+  };
+  auto vd = [&](uint32_t r, int h) { return "v" + std::to_string(V_BASE + RW * r + h); };   // one dword of a value register
   // ---- body ------------------------------------------------------------------
   int64_t last_leaf = -1;
   // One s_waitcnt can serve several consumers: when an op has to wait for a load, the wait also covers what
@@ -309,7 +332,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       case M_MUL: case M_ADD: use(q.a); use(q.b); use(q.d); break;
       case M_FMA: use(q.a); use(q.b); use(q.c); use(q.d); break;
       case M_FMAC: use(q.a); use(q.c); use(q.d); break;
-      case M_MULC: case M_MOV: use(q.a); use(q.d); break;
+      case M_MULC: case M_MOV: case M_ADDC: case M_EXP: case M_RCP: case M_FIXZ: case M_SELC: use(q.a); use(q.d); break;
+      case M_SEL: use(q.a); use(q.b); use(q.c); use(q.d); break;
       default: break;
     }
     return sq;
@@ -384,6 +408,78 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         E.wait_reg(o.d);
         const std::string c = const_operand(o.imm);
         valu2("v_mul_f64 ", o, c, c);
+        break;
+      }
+      case M_ADDC: {
+        E.wait_reg(o.a);
+        E.wait_reg(o.d);
+        const std::string c = const_operand(o.imm);
+        valu2("v_add_f64 ", o, c, c);
+        break;
+      }
+      case M_EXP: {
+        E.wait_reg(o.a);
+        E.wait_reg(o.d);
+        const std::string x = (o.nega ? "-" : "") + vlo(o.a);
+        E.ins("v_mul_f64 " + tA + ", " + x + ", " + const_operand(kLog2e));
+        E.ins("v_rndne_f64_e32 " + tA + ", " + tA);
+        E.ins("v_fma_f64 " + tB + ", " + tA + ", " + const_operand(-kLn2Hi) + ", " + x);
+        E.ins("v_fma_f64 " + tB + ", " + tA + ", " + const_operand(-kLn2Lo) + ", " + tB);
+        {
+          const int c = const_sgpr(kExpC[13]);                       // (the argument register is dead from here: d may be it)
+          E.ins("v_mov_b32_e32 " + vd(o.d, 0) + ", " + S(c));
+          E.ins("v_mov_b32_e32 " + vd(o.d, 1) + ", " + S(c + 1));
+        }
+        for (int k = 12; k >= 0; --k) E.ins("v_fma_f64 " + vlo(o.d) + ", " + vlo(o.d) + ", " + tB + ", " + const_operand(kExpC[k]));
+        E.ins("v_cvt_i32_f64_e32 " + tAd(0) + ", " + tA);
+        E.ins("v_ldexp_f64 " + vlo(o.d) + ", " + vlo(o.d) + ", " + tAd(0));
+        break;
+      }
+      case M_RCP: {
+        E.wait_reg(o.a);
+        E.wait_reg(o.d);
+        const std::string x = (o.nega ? "-" : "") + vlo(o.a), mx = (o.nega ? "" : "-") + vlo(o.a);
+        E.ins("v_rcp_f64_e64 " + tA + ", " + x);
+        E.ins("s_nop 1");   // gfx940+: the result of a transcendental op is not forwarded to the next VALU op (measured: stale read)
+        E.ins("v_fma_f64 " + tB + ", " + mx + ", " + tA + ", 1.0");
+        E.ins("v_fma_f64 " + tA + ", " + tA + ", " + tB + ", " + tA);
+        E.ins("v_fma_f64 " + tB + ", " + mx + ", " + tA + ", 1.0");
+        E.ins("v_fma_f64 " + vlo(o.d) + ", " + tA + ", " + tB + ", " + tA);
+        break;
+      }
+      case M_SEL: {   // d = cond(c) ? a : b
+        E.wait_reg(o.a);
+        E.wait_reg(o.b);
+        E.wait_reg(o.c);
+        E.wait_reg(o.d);
+        E.ins(std::string(o.imm != 0.0 ? "v_cmp_ge_f64_e64" : "v_cmp_gt_f64_e64") + " vcc, " + (o.negc ? "-" : "") + vlo(o.c) + ", 0");
+        std::string ahi = vd(o.a, 1), bhi = vd(o.b, 1);
+        if (o.nega) { E.ins("v_xor_b32_e32 " + tAd(0) + ", 0x80000000, " + ahi); ahi = tAd(0); }
+        if (o.negb) { E.ins("v_xor_b32_e32 " + tAd(1) + ", 0x80000000, " + bhi); bhi = tAd(1); }
+        E.ins("v_cndmask_b32_e32 " + vd(o.d, 0) + ", " + vd(o.b, 0) + ", " + vd(o.a, 0) + ", vcc");
+        E.ins("v_cndmask_b32_e32 " + vd(o.d, 1) + ", " + bhi + ", " + ahi + ", vcc");
+        break;
+      }
+      case M_FIXZ: {  // d = a == 0 ? imm : a
+        E.wait_reg(o.a);
+        E.wait_reg(o.d);
+        const int c = const_sgpr(o.imm);
+        E.ins("v_cmp_eq_f64_e64 vcc, " + vlo(o.a) + ", 0");
+        E.ins("v_mov_b32_e32 " + tAd(0) + ", " + S(c));
+        E.ins("v_mov_b32_e32 " + tAd(1) + ", " + S(c + 1));
+        E.ins("v_cndmask_b32_e32 " + vd(o.d, 0) + ", " + vd(o.a, 0) + ", " + tAd(0) + ", vcc");
+        E.ins("v_cndmask_b32_e32 " + vd(o.d, 1) + ", " + vd(o.a, 1) + ", " + tAd(1) + ", vcc");
+        break;
+      }
+      case M_SELC: {  // d = cond(a) ? imm : -imm
+        E.wait_reg(o.a);
+        E.wait_reg(o.d);
+        const int c = const_sgpr(o.imm);
+        E.ins(std::string(o.negb ? "v_cmp_ge_f64_e64" : "v_cmp_gt_f64_e64") + " vcc, " + (o.nega ? "-" : "") + vlo(o.a) + ", 0");
+        E.ins("v_mov_b32_e32 " + vd(o.d, 0) + ", " + S(c));
+        E.ins("v_mov_b32_e32 " + tAd(0) + ", " + S(c + 1));
+        E.ins("v_xor_b32_e32 " + tAd(1) + ", 0x80000000, " + tAd(0));
+        E.ins("v_cndmask_b32_e32 " + vd(o.d, 1) + ", " + tAd(1) + ", " + tAd(0) + ", vcc");
         break;
       }
       case M_FMA:     // FDG_SPEC_FAST_MATH only
@@ -492,7 +588,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_endpgm");
 
   // ---- kernel descriptor -------------------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0), 8);
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + (has_macro ? 4 : 0), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
   const uint32_t n_agpr = RW * prog.n_acc_used;
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";

@@ -372,21 +372,37 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
   for (uint32_t i = 0; i < tab->n_leaf; ++i)
     if (tab->leaf_type[i] == 2 && tab->leaf_order[i] > 3) { set_error("fused step: interaction order > 3 not covered (use fdg_leaf_eval_device + fdg_accumulate_device)"); return FDG_E_UNSUPPORTED; }
   std::lock_guard<std::mutex> lk(g->mu);
-  // Route: one compiler-scheduled kernel (leaves in registers) for graphs of up to a few thousand operations; for
-  // larger ones the specialised leaf kernel fills a chunk of leaves that this handle's own evaluator (ISA kernel
-  // if the handle was specialised with FDG_SPEC_ISA) consumes -- measured faster there.
-  // FDG_MC_ROUTE=fused|split overrides.
+  // Route.  1: one compiler-scheduled kernel (leaves in registers, HIP source through hiprtc) -- graphs of up to a few
+  // thousand operations.  2: the specialised leaf kernel fills a chunk of leaves that this handle's own evaluator
+  // consumes -- larger graphs.  3: a handle specialised with FDG_SPEC_ISA whose leaves the optimizing back end's
+  // formulas cover: ONE kernel of that back end with the leaves computed in registers (fdg_runtime.hip) -- measured
+  // faster than either, taken for everything but tiny graphs.  FDG_MC_ROUTE=fused|split|isa overrides.
   {
     const char *env = std::getenv("FDG_MC_ROUTE");
-    bool split = g->prog.flops_alg > 6000;
-    if (env && std::strcmp(env, "fused") == 0) split = false;
-    if (env && std::strcmp(env, "split") == 0) split = true;
+    const bool env_fused = env && std::strcmp(env, "fused") == 0, env_split = env && std::strcmp(env, "split") == 0,
+               env_isa = env && std::strcmp(env, "isa") == 0;
+    const bool big = (g->prog.flops_alg > 6000 || env_split) && !env_fused;
+    const bool try_isa = env_isa || (g->isa && g->prog.flops_alg > 300 && !env_fused && !env_split);
     const int32_t *src5[5] = {tab->leaf_type, tab->leaf_order, tab->tau_in, tab->tau_out, tab->loop_index};
     for (int k = 0; k < 5; ++k) g->lt_i32[k].assign(src5[k], src5[k] + tab->n_leaf);
     g->lt_basis.assign(tab->basis, tab->basis + (size_t)tab->n_basis * tab->n_loop);
     const uint32_t hd[5] = {tab->n_leaf, tab->n_basis, tab->n_loop, tab->dim, tab->n_tau};
     std::memcpy(g->lt_hdr, hd, sizeof hd);
-    if (split) { g->mc_route = 2; g->fused_code.clear(); return FDG_OK; }
+    g->mc_built = false;
+    g->mc_dir = cache_dir ? cache_dir : (std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache");
+    mkdir(g->mc_dir.c_str(), 0777);
+    g->mc_flags = flags;
+    if (try_isa) {
+      std::string why;
+      if (fdg_mc_isa_supported(g, tab, why)) {
+        g->mc_route = 3; g->fused_code.clear();
+        // parameters known already (the tables carry them): assemble now rather than at the first call
+        if (tab->beta != 0.0) { const int rb = fdg_mc_isa_build(g, tab->kF, tab->beta, tab->lambda); if (rb) return rb; }
+        return FDG_OK;
+      }
+      if (env_isa) { set_error("fused ISA step does not cover this graph / these leaves: " + why); return FDG_E_UNSUPPORTED; }
+    }
+    if (big) { g->mc_route = 2; g->fused_code.clear(); return FDG_OK; }
   }
   const std::string src = emit_fused_source(g->prog, emit_leaf_statements(tab, leaf_order_by_momentum(tab), true), needs_fermi_dn(tab) ? kFermiDnSource : "");
   char hbuf[40];
@@ -425,6 +441,8 @@ static int run_fused(fdg_graph *g, int mode, const double *d_K, int64_t ks, int6
   if (g->mc_route == 0) { set_error("fdg_graph_specialize_fused has not been called on this handle"); return FDG_E_INVALID; }
   int rc = ensure_device(g);
   if (rc) return rc;
+  if (g->mc_route == 3)
+    return fdg_mc_isa_run(g, mode, d_K, ks, kc, d_T, ts, tc, kF, beta, lambda, d_root, rs, rk, d_weight, d_acc, B, (hipStream_t)stream);
   if (g->mc_route == 2) {
     fdg_leaf_tables tab;
     tab.n_leaf = g->lt_hdr[0]; tab.n_basis = g->lt_hdr[1]; tab.n_loop = g->lt_hdr[2]; tab.dim = g->lt_hdr[3]; tab.n_tau = g->lt_hdr[4];
@@ -436,6 +454,7 @@ static int run_fused(fdg_graph *g, int mode, const double *d_K, int64_t ks, int6
     if (rc) return rc;
     const size_t L = std::max<uint32_t>(g->prog.L, 1);
     int64_t Bc = std::max<int64_t>(1 << 16, (int64_t)((4ull << 30) / (8ull * L)));     // about 4 GiB of leaves per chunk
+    if (const char *env = std::getenv("FDG_MC_CHUNK")) { const long long v = std::atoll(env); if (v >= 64) Bc = v; }   // samples per chunk (tuning)
     Bc = std::min<int64_t>((Bc + 63) & ~63ll, (B + 63) & ~63ll);
     const size_t need = (size_t)Bc * L * sizeof(double);
     if (g->ws4_bytes < need) {

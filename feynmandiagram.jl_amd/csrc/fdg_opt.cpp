@@ -4,10 +4,12 @@
 // (src/backend/static.jl:13-31), and a factor of -1 is carried as a sign on the
 // operand (x * -1.0 == -x exactly).
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <limits>
+#include <map>
 #include <unordered_map>
 
 #include "fdg_opt.h"
@@ -33,7 +35,20 @@ struct Builder {
   bool ok = true;
   std::string why;
 
-  explicit Builder(const Lowered &p_) : p(p_), next_vid(p_.L), ref_of((size_t)p_.L + p_.N, NONE) {
+  // Monte-Carlo program (build_mc_program): values in_base .. in_base+n_in-1 are the kernel's input columns
+  // (momentum components, then times); the graph's leaves are computed values, built at their first use
+  const LeafSpec *mc = nullptr;
+  uint32_t in_base = 0, n_in = 0, n_k = 0;
+
+  explicit Builder(const Lowered &p_, const LeafSpec *mc_ = nullptr) : p(p_), next_vid(p_.L), ref_of((size_t)p_.L + p_.N, NONE), mc(mc_) {
+    if (mc) {
+      in_base = p.L;
+      n_k = mc->tab->n_loop * mc->tab->dim;
+      n_in = n_k + mc->tab->n_tau;
+      next_vid = p.L + n_in;
+      born.assign(next_vid, 0);
+      return;
+    }
     for (uint32_t i = 0; i < p.L; ++i) ref_of[i] = i << 1;
     born.assign(p.L, 0);
   }
@@ -100,6 +115,136 @@ struct Builder {
     lst.push_back({f, d << 1});
     return (d << 1) | sign;
   }
+
+  // ---- leaf formulas (Monte-Carlo program) ---------------------------------------------------------------
+  // Any other op kind, computed once per distinct operand tuple (these values are few and costly: no window).
+  std::map<std::array<uint64_t, 3>, uint32_t> vn_x;
+  uint32_t opx(uint8_t k, uint32_t a, uint32_t b, uint32_t c, double imm) {
+    uint64_t ib; std::memcpy(&ib, &imm, 8);
+    const std::array<uint64_t, 3> key = {((uint64_t)k << 32) | a, ((uint64_t)b << 32) | c, ib};
+    auto it = vn_x.find(key);
+    if (it != vn_x.end()) { touch(it->second); return it->second; }
+    touch(a); if (mop_has_b(k)) touch(b); if (mop_has_c(k)) touch(c);
+    const uint32_t d = fresh();
+    UOp o{k, d, a, b, imm}; o.c = c;
+    u.push_back(o);
+    vn_x[key] = d << 1;
+    return d << 1;
+  }
+  uint32_t addc(uint32_t a, double f) { return opx(M_ADDC, a, 0, 0, f); }
+  uint32_t rcp(uint32_t a) { return opx(M_RCP, a & ~1u, 0, 0, 0.0) | (a & 1u); }          // 1/(-x) == -(1/x)
+  // cond(c) ? a : b, cond = c > 0 (ge false) or c >= 0
+  uint32_t sel(uint32_t c, uint32_t a, uint32_t b, bool ge) {
+    if (a == b) return a;
+    if ((a & 1u) && (b & 1u)) return opx(M_SEL, a ^ 1u, b ^ 1u, c, ge ? 1.0 : 0.0) ^ 1u;
+    return opx(M_SEL, a, b, c, ge ? 1.0 : 0.0);
+  }
+  uint32_t mul(uint32_t a, uint32_t b) { return op2(M_MUL, a, b); }
+  uint32_t add(uint32_t a, uint32_t b) { return op2(M_ADD, a, b); }
+  uint32_t in_k(uint32_t c) const { return (in_base + c) << 1; }
+  uint32_t in_t(int32_t i) const { return (in_base + n_k + (uint32_t)(i - 1)) << 1; }
+
+  struct Mom { uint32_t q2 = NONE, w = NONE, g = NONE, bsel = NONE; };
+  struct Tau { uint32_t tf = NONE, u = NONE, v = NONE; };
+  std::map<int32_t, Mom> moms;
+  std::map<std::pair<int32_t, int32_t>, Tau> taus;
+
+  Mom &momentum(int32_t li) {
+    Mom &m = moms[li];
+    if (m.q2 != NONE) return m;
+    const fdg_leaf_tables *t = mc->tab;
+    const double *bv = t->basis + (size_t)(li - 1) * t->n_loop;
+    uint32_t q2 = NONE;
+    for (uint32_t d = 0; d < t->dim; ++d) {                       // q2 = sum_d (sum_j k[j][d] * basis[j])^2   (benchmark.jl:113-117)
+      uint32_t q = NONE;
+      for (uint32_t j = 0; j < t->n_loop; ++j) {
+        if (bv[j] == 0.0) continue;
+        const uint32_t term = mulc(in_k(j * t->dim + d), bv[j]);
+        q = q == NONE ? term : add(q, term);
+      }
+      if (q == NONE) { ok = false; why = "a leaf with zero momentum"; m.q2 = in_k(0); return m; }
+      const uint32_t sq = mul(q, q);
+      q2 = q2 == NONE ? sq : add(q2, sq);
+    }
+    m.q2 = q2;
+    return m;
+  }
+  // dispersion and the Fermi factor of a momentum: w = q2 - kF^2, g = 1 / (1 + exp(-|w| beta))
+  Mom &fermi(int32_t li) {
+    Mom &m = momentum(li);
+    if (m.w != NONE || !ok) return m;
+    m.w = addc(m.q2, -(mc->kF * mc->kF));
+    const uint32_t wb = mulc(m.w, mc->beta);
+    const uint32_t e = opx(M_EXP, sel(m.w, wb ^ 1u, wb, false), 0, 0, 0.0);
+    m.g = rcp(addc(e, 1.0));
+    return m;
+  }
+  Tau &tau_pair(int32_t tin, int32_t tout) {
+    Tau &t = taus[{tin, tout}];
+    if (t.tf != NONE) return t;
+    const uint32_t tau = add(in_t(tout), in_t(tin) ^ 1u);
+    t.tf = opx(M_FIXZ, tau, 0, 0, -1e-10);                           // benchmark.jl:98 / green(): tau == 0 -> -1e-10
+    t.u = sel(t.tf, t.tf, addc(t.tf, mc->beta), false);             // w >= 0 branch: a = -(tau > 0 ? tau : tau + beta)
+    t.v = sel(t.tf, addc(t.tf, -mc->beta), t.tf, false);            // w <  0 branch: a = -(tau > 0 ? tau - beta : tau)
+    return t;
+  }
+  // value of table leaf i (the expressions of fdg_leaf.hip, every exponential with a non-positive argument)
+  uint32_t leaf_formula(uint32_t i) {
+    const fdg_leaf_tables *t = mc->tab;
+    const int32_t ty = t->leaf_type[i], n = t->leaf_order[i], li = t->loop_index[i];
+    if (ty == 2) {                                                  // 8 pi / invK * (lambda invK)^n, invK = 1 / (q2 + lambda)
+      if (n < 0 || n > 3) { ok = false; why = "interaction counter-term of order above 3"; return in_k(0); }
+      Mom &m = momentum(li);
+      if (!ok) return in_k(0);
+      const uint32_t s = addc(m.q2, mc->lambda);
+      uint32_t v = mulc(s, 8.0 * 3.141592653589793);
+      if (n) {
+        const uint32_t x = mulc(rcp(s), mc->lambda);
+        v = mul(v, n == 1 ? x : (n == 2 ? mul(x, x) : mul(mul(x, x), x)));
+      }
+      return v;
+    }
+    if (ty != 1) { ok = false; why = "a leaf without a formula"; return in_k(0); }
+    if (n < 0 || n > 5) { ok = false; why = "green_derive order above 5"; return in_k(0); }
+    Mom &m = fermi(li);
+    if (!ok) return in_k(0);
+    Tau &tp = tau_pair(t->tau_in[i], t->tau_out[i]);
+    const uint32_t a = sel(m.w, tp.u, tp.v, n != 0) ^ 1u;           // green() tests w > 0, green_derive's twin w >= 0
+    const uint32_t A = opx(M_EXP, mul(m.w, a), 0, 0, 0.0);
+    if (const char *dbg = std::getenv("FDG_MC_DEBUG_STAGE")) {   // development only: a leaf's intermediate instead of its value
+      const std::string st = dbg;
+      if (st == "w") return m.w; if (st == "g") return m.g; if (st == "tau") return tp.tf; if (st == "a") return a; if (st == "A") return A;
+      if (st == "wa") return mul(m.w, a); if (st == "u") return tp.u; if (st == "v") return tp.v;
+    }
+    uint32_t x;
+    if (n == 0) {
+      x = mul(A, m.g);
+    } else {
+      // fdg_fermi_dn: sum_k C(n,k) Q_k(g) a^(n-k) b^k, b = +-beta, Q_k by Horner
+      static const double QC[6][7] = {{0, 1, 0, 0, 0, 0, 0}, {0, 1, -1, 0, 0, 0, 0}, {0, 1, -3, 2, 0, 0, 0}, {0, 1, -7, 12, -6, 0, 0},
+                                      {0, 1, -15, 50, -60, 24, 0}, {0, 1, -31, 180, -390, 360, -120}};
+      static const double BC[6][6] = {{1, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0}, {1, 3, 3, 1, 0, 0}, {1, 4, 6, 4, 1, 0}, {1, 5, 10, 10, 5, 1}};
+      static const double NF[6] = {1.0, -1.0, 0.5, -1.0 / 6.0, 1.0 / 24.0, -1.0 / 120.0};
+      if (m.bsel == NONE) m.bsel = opx(M_SELC, m.w, 1, 0, mc->beta);     // b = w >= 0 ? beta : -beta  (operand b = 1: the >= form)
+      uint32_t total = NONE;
+      for (int k = 0; k <= n; ++k) {
+        uint32_t q = mulc(m.g, QC[k][k + 1]);
+        if (QC[k][k] != 0.0) q = addc(q, QC[k][k]);
+        for (int c = k - 1; c >= 0; --c) { q = mul(q, m.g); if (QC[k][c] != 0.0) q = addc(q, QC[k][c]); }
+        uint32_t term = mulc(q, BC[n][k]);
+        for (int j = 0; j < n - k; ++j) term = mul(term, a);
+        for (int j = 0; j < k; ++j) term = mul(term, m.bsel);
+        total = total == NONE ? term : add(total, term);
+      }
+      x = mulc(mul(A, total), NF[n]);
+    }
+    return mul(x, opx(M_SELC, tp.tf, 0, 0, 1.0));                   // antiperiodicity: times the sign of tau (+-1.0, exact)
+  }
+  // operand `c` of the table is about to be read
+  void need(uint32_t c) {
+    if (!mc || c >= p.L || ref_of[c] != NONE) return;
+    ref_of[c] = leaf_formula(c);
+  }
 };
 
 struct Frame { uint32_t n, i, acc; };
@@ -117,7 +262,7 @@ void build_uops(Builder &B) {
     for (; it != rootlist.end() && it->first == v; ++it) B.u.push_back(UOp{M_ROOT, it->second, B.ref_of[v], 0, 0.0});
   };
   for (auto &rk : rootlist)
-    if (rk.first < L) B.u.push_back(UOp{M_ROOT, rk.second, rk.first << 1, 0, 0.0});
+    if (rk.first < L) { B.need(rk.first); B.u.push_back(UOp{M_ROOT, rk.second, B.ref_of[rk.first], 0, 0.0}); }
 
   std::vector<Frame> st;
   // roots in statement order of the reference (increasing node index)
@@ -231,6 +376,7 @@ void build_uops(Builder &B) {
           Frame &f = g.fr[g.cur];
           if (B.ref_of[L + f.n] != NONE) { g.cur++; continue; }
           const uint32_t c = p.idx[p.off[f.n] + f.i];
+          B.need(c);
           if (B.ref_of[c] == NONE) {
             const uint32_t cn = c - L;
             if (started[cn]) {
@@ -257,6 +403,7 @@ void build_uops(Builder &B) {
       const uint32_t n = f.n, a = p.off[n], k = p.off[n + 1] - a;
       (void)k;
       const uint32_t c = p.idx[a + f.i];
+      B.need(c);
       if (B.ref_of[c] == NONE) { st.push_back(Frame{c - L, 0, NONE}); continue; }
       if (step(st.back())) st.pop_back();
     }
@@ -268,11 +415,11 @@ void build_uops(Builder &B) {
 // in the last bits (within 1e-12 of the sum's term scale), so this is off unless asked for.
 void fuse_fma(std::vector<UOp> &u, uint32_t n_value) {
   std::vector<uint32_t> n_use(n_value, 0), prod(n_value, NONE);
-  auto two = [](uint8_t k) { return k == M_MUL || k == M_ADD; };
   for (uint32_t j = 0; j < u.size(); ++j) {
     const UOp &o = u[j];
     n_use[o.a >> 1]++;
-    if (two(o.kind)) n_use[o.b >> 1]++;
+    if (mop_has_b(o.kind)) n_use[o.b >> 1]++;
+    if (mop_has_c(o.kind)) n_use[o.c >> 1]++;
     if (o.kind != M_ROOT) prod[o.d] = j;
   }
   std::vector<uint8_t> dead(u.size(), 0);
@@ -329,8 +476,10 @@ struct Alloc {
   std::vector<MOp> out;
   OptProgram &prog;
 
+  uint32_t leaf_lo = 0, leaf_n = 0;          // values leaf_lo .. leaf_lo+leaf_n-1 are input columns (re-loadable)
+
   Alloc(const Lowered &p_, const OptParams &prm_, const std::vector<UOp> &u_, uint32_t nv_, OptProgram &pr)
-      : p(p_), prm(prm_), u(u_), nv(nv_), prog(pr) {}
+      : p(p_), prm(prm_), u(u_), nv(nv_), prog(pr) { leaf_n = p.L; }
 
   uint32_t next_use(uint32_t v) const {
     return up[v] < uses[v].size() ? uses[v][up[v]] : std::numeric_limits<uint32_t>::max();
@@ -405,7 +554,7 @@ struct Alloc {
       case 1: out.push_back(MOp{M_LD_LDS, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_lds++; break;
       case 2: out.push_back(MOp{M_LD_MEM, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_mem++; break;
       case 4: out.push_back(MOp{M_LD_ACC, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_acc++; break;
-      default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v, 0, 0.0}); prog.n_ld_leaf++; break;   // leaves only
+      default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v - leaf_lo, 0, 0.0}); prog.n_ld_leaf++; break;   // leaves only
     }
     reg_of[v] = r; owner[r] = v; lock[r] = pos;
     return r;
@@ -418,7 +567,7 @@ struct Alloc {
     switch (home_kind[v]) {
       case 1: out.push_back(MOp{M_LD_LDS, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_lds++; break;
       case 2: out.push_back(MOp{M_LD_MEM, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_mem++; break;
-      default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v, 0, 0.0}); prog.n_ld_leaf++; break;
+      default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v - leaf_lo, 0, 0.0}); prog.n_ld_leaf++; break;
     }
     reg_of[v] = r; owner[r] = v;
   }
@@ -430,11 +579,11 @@ struct Alloc {
       const UOp &o = u[pf];
       const uint32_t va = o.a >> 1;
       if (home_kind[va] == kind) prefetch(va, j, pf);
-      if (o.kind == M_MUL || o.kind == M_ADD || o.kind == M_FMA) {
+      if (mop_has_b(o.kind)) {
         const uint32_t vb = o.b >> 1;
         if (home_kind[vb] == kind) prefetch(vb, j, pf);
       }
-      if (o.kind == M_FMA || o.kind == M_FMAC) {
+      if (mop_has_c(o.kind)) {
         const uint32_t vc = o.c >> 1;
         if (home_kind[vc] == kind) prefetch(vc, j, pf);
       }
@@ -445,14 +594,14 @@ struct Alloc {
     for (uint32_t j = 0; j < u.size(); ++j) {
       const UOp &o = u[j];
       uses[o.a >> 1].push_back(j);
-      if (o.kind == M_MUL || o.kind == M_ADD || o.kind == M_FMA) uses[o.b >> 1].push_back(j);
-      if (o.kind == M_FMA || o.kind == M_FMAC) uses[o.c >> 1].push_back(j);
+      if (mop_has_b(o.kind)) uses[o.b >> 1].push_back(j);
+      if (mop_has_c(o.kind)) uses[o.c >> 1].push_back(j);
     }
     up.assign(nv, 0);
     reg_of.assign(nv, NONE);
     home_kind.assign(nv, 0);
     home_slot.assign(nv, 0);
-    for (uint32_t i = 0; i < p.L; ++i) home_kind[i] = 3;
+    for (uint32_t i = 0; i < leaf_n; ++i) home_kind[leaf_lo + i] = 3;
     owner.assign(prm.n_reg, NONE);
     lock.assign(prm.n_reg, NONE);
     for (uint32_t r = 0; r < prm.n_reg; ++r) free_regs.push_back(r);
@@ -463,8 +612,8 @@ struct Alloc {
       if (prm.lookahead_leaf) prefetch_window(pf_leaf, j, prm.lookahead_leaf, 3);
       if (prm.lookahead_mem) prefetch_window(pf_mem, j, prm.lookahead_mem, 2);
       if (prm.lookahead_lds) prefetch_window(pf_lds, j, prm.lookahead_lds, 1);
-      const bool two = (o.kind == M_MUL || o.kind == M_ADD || o.kind == M_FMA);
-      const bool three = (o.kind == M_FMA || o.kind == M_FMAC);
+      const bool two = mop_has_b(o.kind);
+      const bool three = mop_has_c(o.kind);
       const uint32_t va = o.a >> 1, vb = two ? (o.b >> 1) : NONE, vc = three ? (o.c >> 1) : NONE;
       const uint32_t ra = ensure_in_reg(va, j);
       const uint32_t rb = two ? ensure_in_reg(vb, j) : 0;
@@ -483,6 +632,8 @@ struct Alloc {
       const uint32_t rd = take_reg(j);
       reg_of[o.d] = rd; owner[rd] = o.d; lock[rd] = j;
       if (o.kind == M_MULC) out.push_back(MOp{M_MULC, (uint8_t)(o.a & 1), 0, rd, ra, 0, o.imm});
+      else if (o.kind == M_SELC) out.push_back(MOp{M_SELC, (uint8_t)(o.a & 1), (uint8_t)(o.b ? 1 : 0), rd, ra, 0, o.imm});
+      else if (o.kind == M_ADDC || o.kind == M_EXP || o.kind == M_RCP || o.kind == M_FIXZ) out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), 0, rd, ra, 0, o.imm});
       else if (three) out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), (uint8_t)(two ? (o.b & 1) : 0), rd, ra, rb, o.imm, (uint8_t)(o.c & 1), rc});
       else out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), (uint8_t)(o.b & 1), rd, ra, rb, 0.0});
       prog.n_valu++;
@@ -528,7 +679,8 @@ void hoist_loads(std::vector<MOp> &ops, const OptParams &prm) {
       case M_MUL: case M_ADD: touch(o.a); touch(o.b); touch(o.d); break;
       case M_FMA: touch(o.a); touch(o.b); touch(o.c); touch(o.d); break;
       case M_FMAC: touch(o.a); touch(o.c); touch(o.d); break;
-      case M_MULC: case M_MOV: touch(o.a); touch(o.d); break;
+      case M_MULC: case M_MOV: case M_ADDC: case M_EXP: case M_RCP: case M_FIXZ: case M_SELC: touch(o.a); touch(o.d); break;
+      case M_SEL: touch(o.a); touch(o.b); touch(o.c); touch(o.d); break;
       case M_ROOT: touch(o.a); break;
       case M_LD_ACC: touch(o.d); break;
       case M_ST_ACC: touch(o.a); break;
@@ -588,6 +740,32 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   out.ops.swap(A.out);
   hoist_loads(out.ops, prm);
   sort_load_runs(out.ops);
+}
+
+void build_mc_program(const Lowered &p, const LeafSpec &ls, const OptParams &prm, OptProgram &out) {
+  out = OptProgram();
+  out.params = prm;
+  Lowered plain;
+  bool retry = false;
+  for (int pass = 0; pass < 2; ++pass) {
+    Builder B(retry ? plain : p, &ls);
+    B.value_numbering = true;
+    B.vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
+    build_uops(B);
+    if (!B.ok && !retry && B.why == "inconsistent schedule groups") { plain = p; plain.sched_group.clear(); retry = true; continue; }
+    out.supported = B.ok;
+    out.why = B.why;
+    if (!B.ok) return;
+    if (prm.n_reg < 4) { out.supported = false; out.why = "too few registers"; return; }
+    if (prm.fma) fuse_fma(B.u, B.next_vid);
+    Alloc A(p, prm, B.u, B.next_vid, out);
+    A.leaf_lo = B.in_base; A.leaf_n = B.n_in;
+    A.run();
+    out.ops.swap(A.out);
+    hoist_loads(out.ops, prm);
+    sort_load_runs(out.ops);
+    return;
+  }
 }
 
 bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp> &ops, uint32_t &n_value, std::string &why) {

@@ -33,7 +33,17 @@ enum MKind : uint8_t {
   M_ST_ACC,       // acc[d] = r[a]
   M_FMA = 14,     // r[d] = (+-r[a]) * (+-r[b]) + (+-r[c])   one rounding: only with OptParams::fma (not parity-exact)
   M_FMAC = 15,    // r[d] = (+-r[a]) * imm + (+-r[c])
+  // ---- leaf formulas inside the kernel (build_mc_program; results within the leaf kernels' tolerance, not bit-pinned) ----
+  M_ADDC = 16,    // r[d] = (+-r[a]) + imm
+  M_EXP = 17,     // r[d] = exp(+-r[a])                       range reduction + degree-13 polynomial + v_ldexp_f64
+  M_RCP = 18,     // r[d] = 1 / (+-r[a])                      v_rcp_f64 + two Newton steps
+  M_SEL = 19,     // r[d] = cond(+-r[c]) ? +-r[a] : +-r[b]    cond: x > 0 (imm = 0) or x >= 0 (imm = 1)
+  M_FIXZ = 20,    // r[d] = r[a] == 0 ? imm : r[a]
+  M_SELC = 21,    // r[d] = cond(+-r[a]) ? imm : -imm         cond as M_SEL, selected by negb
 };
+inline bool mop_has_b(uint8_t k) { return k == M_MUL || k == M_ADD || k == M_FMA || k == M_SEL; }
+inline bool mop_has_c(uint8_t k) { return k == M_FMA || k == M_FMAC || k == M_SEL; }
+inline bool mop_is_macro(uint8_t k) { return k >= M_EXP && k <= M_SELC; }   // needs the emitter's two temporaries
 
 struct MOp {
   uint8_t kind;
@@ -67,6 +77,16 @@ struct OptProgram {
 };
 
 void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out);
+
+// The Monte-Carlo step as ONE program: the kernel's inputs are the sample's momentum components and times
+// (input column c < n_k: K component c; n_k + i: time i+1), and every leaf of the graph is a value computed from
+// them by the formulas of example/benchmark.jl:58-127 (green / green_derive / the Yukawa interaction and its
+// counter-terms) at its first use.  kF, beta, lambda are constants of the program.
+struct LeafSpec {
+  const fdg_leaf_tables *tab = nullptr;
+  double kF = 0, beta = 0, lambda = 0;
+};
+void build_mc_program(const Lowered &p, const LeafSpec &ls, const OptParams &prm, OptProgram &out);
 
 // The scheduled, value-numbered fold steps before register allocation, for back ends that leave registers to a
 // compiler: values are numbered 0..n_value-1 (leaves first, in leaf order); an operand reference is

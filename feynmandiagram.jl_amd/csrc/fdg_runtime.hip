@@ -767,6 +767,28 @@ int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop *
   return FDG_OK;
 }
 
+int fdg_graph_mc_program(const fdg_graph *g, const fdg_leaf_tables *tab, const fdg_opt_params *q, fdg_mop **ops, uint64_t *n_ops,
+                         uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used) {
+  if (!g || !tab || !ops || !n_ops) { set_error("null argument"); return FDG_E_INVALID; }
+  if (tab->n_leaf != g->prog.L) { set_error("leaf tables: n_leaf differs from the graph's"); return FDG_E_INVALID; }
+  fdg::LeafSpec ls; ls.tab = tab; ls.kF = tab->kF; ls.beta = tab->beta; ls.lambda = tab->lambda;
+  fdg::OptProgram prog;
+  fdg::build_mc_program(g->prog, ls, to_params(q), prog);
+  if (!prog.supported) { set_error("the fused ISA step does not cover this graph / these leaves: " + prog.why); return FDG_E_UNSUPPORTED; }
+  fdg_mop *m = (fdg_mop *)std::malloc(std::max<size_t>(1, prog.ops.size()) * sizeof(fdg_mop));
+  if (!m) { set_error("out of memory"); return FDG_E_NOMEM; }
+  for (size_t i = 0; i < prog.ops.size(); ++i) {
+    const fdg::MOp &o = prog.ops[i];
+    m[i] = fdg_mop{o.kind, o.nega, o.negb, o.negc, o.d, o.a, o.b, o.imm, o.c, 0};
+  }
+  *ops = m; *n_ops = prog.ops.size();
+  if (n_reg_used) *n_reg_used = prog.n_reg_used;
+  if (n_lds_used) *n_lds_used = prog.n_lds_used;
+  if (n_mem_used) *n_mem_used = prog.n_mem_used;
+  if (n_acc_used) *n_acc_used = prog.n_acc_used;
+  return FDG_OK;
+}
+
 static bool has_opt_params(const fdg_graph *g) {
   OptStore &s = opt_store();
   std::lock_guard<std::mutex> lk(s.mu);
@@ -776,8 +798,8 @@ static bool has_opt_params(const fdg_graph *g) {
 
 static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags,
                         std::vector<char> &co, std::string &hash, const fdg::OptProgram *prog2 = nullptr,
-                        const fdg::OptProgram *prog_acc = nullptr) {
-  const std::string src = fdg::emit_isa(g->prog, prog, "fdg_isa_eval", prog2, prog_acc);
+                        const fdg::OptProgram *prog_acc = nullptr, const char *kname = "fdg_isa_eval") {
+  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc);
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
   hash = hbuf;
@@ -1043,6 +1065,174 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
   install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
   return FDG_OK;
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Monte-Carlo step as one kernel of the optimizing back end (route 3 of fdg_graph_specialize_fused): the
+// program of fdg::build_mc_program, whose inputs are the n_loop*dim momentum components and n_tau times of a
+// sample (168 bytes for the 4-loop self-energy) instead of its L leaf values (1240 bytes).  kF, beta, lambda
+// are constants of the code: the kernels are assembled at the first call and again when a call brings others.
+// ---------------------------------------------------------------------------
+static fdg_leaf_tables handle_tables(const fdg_graph *g, double kF, double beta, double lambda) {
+  fdg_leaf_tables tab;
+  tab.n_leaf = g->lt_hdr[0]; tab.n_basis = g->lt_hdr[1]; tab.n_loop = g->lt_hdr[2]; tab.dim = g->lt_hdr[3]; tab.n_tau = g->lt_hdr[4];
+  tab.leaf_type = g->lt_i32[0].data(); tab.leaf_order = g->lt_i32[1].data(); tab.tau_in = g->lt_i32[2].data();
+  tab.tau_out = g->lt_i32[3].data(); tab.loop_index = g->lt_i32[4].data(); tab.basis = g->lt_basis.data();
+  tab.kF = kF; tab.beta = beta; tab.lambda = lambda;
+  return tab;
+}
+
+static fdg::OptParams mc_params(const fdg_graph *g) {
+  fdg::OptParams q = cfg_A();
+  if (has_opt_params(g)) { const fdg_opt_params o = get_opt_params(g); q = to_params(&o); }
+  q.n_reg = std::min<uint32_t>(q.n_reg, 123);      // two temporaries (4 VGPRs) above the values
+  q.fma = q.fma || g->isa_fma;
+  return q;
+}
+
+bool fdg_mc_isa_supported(fdg_graph *g, const fdg_leaf_tables *tab, std::string &why) {
+  fdg::LeafSpec ls; ls.tab = tab; ls.kF = 1.0; ls.beta = 1.0; ls.lambda = 1.0;
+  fdg::OptProgram prog;
+  fdg::build_mc_program(g->prog, ls, mc_params(g), prog);
+  why = prog.why;
+  return prog.supported;
+}
+
+static uint32_t isa_waves_per_cu(uint32_t vgpr, uint32_t lds_bytes) {
+  const uint32_t valloc = std::max<uint32_t>(8, (vgpr + 7) & ~7u);
+  uint32_t per_cu = std::min<uint32_t>(8, 512 / valloc) * 4;
+  if (lds_bytes) per_cu = std::min<uint32_t>(per_cu, (160u * 1024u) / lds_bytes);
+  return std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32));
+}
+
+int fdg_mc_isa_build(fdg_graph *g, double kF, double beta, double lambda) {
+  if (g->mc_built && g->mc_const[0] == kF && g->mc_const[1] == beta && g->mc_const[2] == lambda) return FDG_OK;
+  const fdg_leaf_tables tab = handle_tables(g, kF, beta, lambda);
+  fdg::LeafSpec ls; ls.tab = &tab; ls.kF = kF; ls.beta = beta; ls.lambda = lambda;
+  fdg::OptParams q = mc_params(g);
+  fdg::OptProgram pe, pa;
+  fdg::build_mc_program(g->prog, ls, q, pe);
+  if (pe.supported && !has_opt_params(g) && (pe.n_ld_mem + pe.n_st_mem) * 100 > pe.n_valu) {
+    // values computed from (K, T) cannot be re-read from the input like leaves: what does not fit on chip goes through
+    // the HBM panel (16 bytes per spill).  One wave per SIMD with the AGPR level keeps it all on chip (measured on the
+    // Taylor-expanded 4-loop self-energy: 2.1e9 -> 2.8e9 samples/s)
+    fdg::OptParams qb = cfg_B();
+    qb.n_reg = std::min<uint32_t>(qb.n_reg, 123);
+    qb.fma = q.fma;
+    fdg::OptProgram pb;
+    fdg::build_mc_program(g->prog, ls, qb, pb);
+    if (pb.supported) { pe = std::move(pb); q = qb; }
+  }
+  if (!pe.supported) { set_error("the fused ISA step does not cover this graph / these leaves: " + pe.why); return FDG_E_UNSUPPORTED; }
+  const uint32_t R = g->prog.R;
+  bool has_acc = R >= 1 && R <= 16;
+  if (has_acc) {
+    fdg::OptParams qa = q;
+    qa.n_reg = std::min<uint32_t>(q.n_reg, (256 - 6 - 2 * (R + 2) - 4) / 2);
+    fdg::build_mc_program(g->prog, ls, qa, pa);
+    has_acc = pa.supported;
+  }
+  std::vector<char> co;
+  std::string hash;
+  const int rc = assemble_isa(g, pe, g->mc_dir, g->mc_flags, co, hash, nullptr, has_acc ? &pa : nullptr, "fdg_isa_mc");
+  if (rc) return rc;
+  if (g->mc_module) { HIP_TRY(hipDeviceSynchronize()); hipModuleUnload((hipModule_t)g->mc_module); g->mc_module = nullptr; }
+  g->fn_mc = g->fn_mc_acc = nullptr;
+  g->mc_code.swap(co);
+  g->mc_has_acc = has_acc;
+  g->mc_vgpr[0] = ((6 + 2 * std::max<uint32_t>(pe.n_reg_used, 1) + 4 + 3) & ~3u) + 2 * pe.n_acc_used;
+  g->mc_lds[0] = pe.n_lds_used * 512u; g->mc_mem[0] = pe.n_mem_used;
+  if (has_acc) {
+    g->mc_vgpr[1] = ((6 + 2 * std::max<uint32_t>(pa.n_reg_used, 1) + 2 * (R + 2) + 4 + 3) & ~3u) + 2 * pa.n_acc_used;
+    g->mc_lds[1] = pa.n_lds_used * 512u; g->mc_mem[1] = pa.n_mem_used;
+  }
+  g->mc_const[0] = kF; g->mc_const[1] = beta; g->mc_const[2] = lambda;
+  g->mc_built = true;
+  return FDG_OK;
+}
+
+int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_t kc, const double *d_T, int64_t ts, int64_t tc,
+                   double kF, double beta, double lambda, double *d_root, int64_t rs, int64_t rk, const double *d_weight,
+                   double *d_acc, int64_t B, hipStream_t st) {
+  int rc = fdg_mc_isa_build(g, kF, beta, lambda);
+  if (rc) return rc;
+  if (!g->mc_module) {
+    hipModule_t m; hipFunction_t f;
+    hipError_t e = hipModuleLoadData(&m, g->mc_code.data());
+    if (e != hipSuccess) { set_error("hipModuleLoadData failed: " + std::string(hipGetErrorString(e))); return FDG_E_JIT; }
+    HIP_TRY(hipModuleGetFunction(&f, m, "fdg_isa_mc"));
+    g->mc_module = m; g->fn_mc = f;
+    if (g->mc_has_acc) { HIP_TRY(hipModuleGetFunction(&f, m, "fdg_isa_mc_acc")); g->fn_mc_acc = f; }
+  }
+  const uint32_t R = g->prog.R;
+  const uint32_t n_k = g->lt_hdr[2] * g->lt_hdr[3], n_tau = g->lt_hdr[4], n_in = n_k + n_tau;
+  const bool use_acc = mode == 1 && g->mc_has_acc;
+  if (mode == 1 && !use_acc) { set_error("fused ISA step: accumulation needs 1..16 roots"); return FDG_E_UNSUPPORTED; }
+  if (mode == 0 && (rs < 0 || rs >= (1ll << 23))) { set_error("root sample stride negative or of 2^23 elements or more is not supported by the ISA kernel"); return FDG_E_UNSUPPORTED; }
+  const int v = use_acc ? 1 : 0;
+  const long grid = (long)g->n_cu * isa_waves_per_cu(g->mc_vgpr[v], g->mc_lds[v]);
+  const size_t panel = (((size_t)std::max<uint32_t>(g->mc_mem[v], 1) * 512u * (size_t)grid) + 4095) & ~(size_t)4095;
+  rc = ensure_ws(g, panel + (size_t)grid * std::max<uint32_t>(R, 1) * 512u + 4096);
+  if (rc) return rc;
+  // The kernel reads its inputs as columns of ONE leaf-major matrix.  K and T handed over as such a matrix
+  // (component-major, the times right behind the momenta, one column stride) are read in place; anything else
+  // is packed into a chunk owned by the handle first (8 (n_k + n_tau) bytes per sample each way).
+  const bool in_place = ks == 1 && ts == 1 && kc == tc && kc >= 0 && d_T == d_K + (int64_t)n_k * kc;
+  int64_t Bc = std::min<int64_t>((B + 63) & ~63ll, 1ll << 22);
+  if (const char *env = std::getenv("FDG_MC_CHUNK")) { const long long c = std::atoll(env); if (c >= 64) Bc = std::min<int64_t>((c + 63) & ~63ll, (B + 63) & ~63ll); }
+  if (!in_place) {
+    const size_t need = (size_t)Bc * n_in * sizeof(double);
+    if (g->ws4_bytes < need) {
+      if (g->d_ws4) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws4)); g->d_ws4 = nullptr; g->ws4_bytes = 0; }
+      if (hipMalloc(&g->d_ws4, need) != hipSuccess) { set_error("hipMalloc(packed inputs) failed"); return FDG_E_NOMEM; }
+      g->ws4_bytes = need;
+    }
+  }
+  auto pack = [&](const double *src, int64_t ss, int64_t cs, uint32_t ncol, double *dst, int64_t n) -> int {
+    if (ss == 1 && cs >= n) {
+      HIP_TRY(hipMemcpy2DAsync(dst, (size_t)Bc * 8, src, (size_t)cs * 8, (size_t)n * 8, ncol, hipMemcpyDeviceToDevice, st));
+    } else {
+      const long ntile = ((n + 63) / 64) * ((ncol + 31) / 32);
+      hipLaunchKernelGGL(fdg_transpose_to_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, st,
+                         src, (long)ss, (long)cs, dst, (long)Bc, (long)n, ncol);
+      HIP_TRY(hipGetLastError());
+    }
+    return FDG_OK;
+  };
+  for (int64_t c0 = 0; c0 < B; c0 += (in_place ? B : Bc)) {
+    long n = (long)(in_place ? B : std::min<int64_t>(Bc, B - c0));
+    const double *x = d_K;
+    long xls = (long)kc;
+    if (!in_place) {
+      double *X = (double *)g->d_ws4;
+      rc = pack(d_K + c0 * ks, ks, kc, n_k, X, n);
+      if (rc) return rc;
+      rc = pack(d_T + c0 * ts, ts, tc, n_tau, X + (size_t)n_k * Bc, n);
+      if (rc) return rc;
+      x = X; xls = (long)Bc;
+    }
+    void *a_wsp = g->d_ws;
+    long one = 1, nwg = std::min<long>((n + 63) / 64, grid), zero = 0;
+    if (use_acc) {
+      double *part = (double *)((char *)g->d_ws + panel);
+      const double *wt = d_weight ? d_weight + c0 : nullptr;
+      void *args[] = {(void *)&x, &one, &xls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_mc_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+      hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
+      HIP_TRY(hipGetLastError());
+    } else {
+      double *rt = d_root + c0 * rs;
+      long a_rs = (long)rs, a_rk = (long)rk;
+      const double *nowt = nullptr;
+      void *args[] = {(void *)&x, &one, &xls, (void *)&rt, &a_rs, &a_rk, &a_wsp, &n, &nwg, (void *)&nowt};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_mc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+    }
+  }
+  return FDG_OK;
+}
+
+extern "C" {
 
 int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
   if (!g) { set_error("null handle"); return FDG_E_INVALID; }

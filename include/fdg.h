@@ -253,6 +253,17 @@ int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t 
  * (specialise it with FDG_SPEC_ISA first): fdg_graph_specialize_fused picks the route by graph size
  * (FDG_MC_ROUTE=fused|split overrides); the roots are the same bits on either route. */
 int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const char *cache_dir, unsigned flags);
+/* The third route, taken for large graphs on a handle specialised with FDG_SPEC_ISA: ONE kernel of the optimizing
+ * back end whose inputs are the sample's n_loop*dim momentum components and n_tau times; every leaf is a value
+ * computed in registers from them at its first use (ops 16..21 of fdg_mop: add-constant, exp, reciprocal, selects),
+ * scheduled and register-allocated together with the graph.  kF, beta, lambda are constants of that kernel's code: it is
+ * assembled at the first fdg_mc_*_device call and again when a call brings other values (about a second).  K and T
+ * are read in place when they are ONE component-major matrix (sample stride 1, T right behind K, one column stride);
+ * otherwise they are packed into such a matrix first.  Leaves agree with fdg_leaf_eval_device within its stated
+ * tolerance (own exp: range reduction + degree-13 polynomial), not bit for bit.  FDG_MC_ROUTE=isa|split overrides.
+ * fdg_graph_mc_program returns that program for inspection / host-side replay (tab->kF, beta, lambda are used). */
+int fdg_graph_mc_program(const fdg_graph *g, const fdg_leaf_tables *tab, const fdg_opt_params *prm, fdg_mop **ops, uint64_t *n_ops,
+                         uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used);
 int fdg_mc_eval_device(fdg_graph *g, const double *d_K, int64_t k_sample_stride, int64_t k_comp_stride, const double *d_T,
                        int64_t t_sample_stride, int64_t t_comp_stride, double kF, double beta, double lambda,
                        double *d_root, int64_t root_sample_stride, int64_t root_root_stride, int64_t n_sample, void *stream);

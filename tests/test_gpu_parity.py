@@ -528,9 +528,9 @@ def test_host_buffers_in_chunks(libfdg, cuda, monkeypatch):
 
 
 def test_mc_step_routes_on_large_graph(libfdg, cuda, monkeypatch):
-    """fdg_graph_specialize_fused on a graph too large for one compiler-scheduled kernel takes the split route
-    (specialised leaf kernel -> chunk of leaves -> the handle's ISA evaluator) behind the same fdg_mc_* calls;
-    FDG_MC_ROUTE=fused forces the single kernel.  Both give the bits of the hand-written unfused sequence."""
+    """The split route of fdg_graph_specialize_fused (specialised leaf kernel -> chunk of leaves -> the handle's ISA
+    evaluator, what a large graph gets when the one-kernel ISA route does not apply) and FDG_MC_ROUTE=fused (the single
+    compiler-scheduled kernel): both give the bits of the hand-written unfused sequence."""
     import torch
     z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
     zt = np.load(os.path.join(GOLD, "gv_sigma4_taylor2.npz"))
@@ -553,9 +553,8 @@ def test_mc_step_routes_on_large_graph(libfdg, cuda, monkeypatch):
     want = f(None, leaf)
     assert np.array_equal(want.cpu().numpy(), oracle.eval_static(t, leaf.cpu().numpy()))
     tab, _keep = capi.make_leaf_tables(*args)
-    for route in (None, "fused"):
-        if route:
-            monkeypatch.setenv("FDG_MC_ROUTE", route)
+    for route in ("split", "fused"):       # (the default on an ISA-specialised handle is the one-kernel route: test below)
+        monkeypatch.setenv("FDG_MC_ROUTE", route)
         g = fd.compile_table(t, specialize="isa")
         g.handle.specialize_fused(tab)
         root = torch.zeros((B, R), dtype=torch.float64, device=cuda)
@@ -568,6 +567,122 @@ def test_mc_step_routes_on_large_graph(libfdg, cuda, monkeypatch):
         torch.cuda.synchronize()
         wr = (want * w[:, None]).cpu().numpy()
         assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0))), route
+
+
+def _taylor2_tables():
+    z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
+    zt = np.load(os.path.join(GOLD, "gv_sigma4_taylor2.npz"))
+    for k in ("leaf_type", "tau_in", "tau_out", "loop_index"):
+        z[k] = z[k][zt["leaf_base"]]
+    z["leaf_order"] = np.where(z["leaf_type"] == 2, zt["leaf_dorder"], 0).astype(np.int32)
+    return z
+
+
+def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch):
+    """Route 3 of the Monte-Carlo step: on a handle specialised with FDG_SPEC_ISA the leaves are computed inside the
+    optimizing back end's kernel from the sample's momenta and times (own exp / reciprocal / selects in gfx950
+    assembly).  Two statements.  (1) The graph part is exact: the roots are, bit for bit, the oracle's graph applied to
+    the leaves this kernel computes (read out through a second kernel whose roots ARE the leaves -- same formulas, same
+    IEEE operations, hence the same bits; those leaves are checked against the oracle in the test below).  (2) Against
+    the pure oracle chain (numpy leaves -> oracle graph) the roots agree to 1e-12 of their term scale on the 4-loop
+    graph and to 1e-10 on its Taylor expansion, whose cancellations amplify a last-bit difference of a leaf (the
+    leaf-kernel route is 2e-12 off on the same samples).  Eval and accumulate; K and T as one matrix (read in place),
+    as separate component-major arrays and sample-major (packed first); a ragged last tile; and again after the
+    physical parameters change (the kernel is re-assembled)."""
+    import torch
+    from feynmandiagram_jl_amd.nodetable import NodeTable
+    for name, z in (("gv_sigma4", dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))), ("gv_sigma4_taylor2", _taylor2_tables())):
+        t = workloads.get(name)
+        L, R = t.n_leaf, t.n_root
+        B, dim, n_loop, n_tau = 30_011, 3, int(z["basis"].shape[1]), int(z["n_tau"])
+        n_k = n_loop * dim
+        rng = np.random.default_rng(23)
+        K = rng.uniform(-2.0, 2.0, size=(B, n_loop, dim))
+        args = (z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
+        tab, _keep = capi.make_leaf_tables(*args)
+        monkeypatch.setenv("FDG_MC_ROUTE", "isa")            # insist: an unsupported table would raise instead of falling back
+        g = fd.compile_table(t, specialize="isa")
+        g.handle.specialize_fused(tab)
+        t_leaves = NodeTable(L, np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(1, np.uint32), np.zeros(0, np.uint32),
+                             np.zeros(0), np.arange(L, dtype=np.uint32), "leaves")
+        gl = fd.compile_table(t_leaves, specialize="isa")
+        gl.handle.specialize_fused(tab)
+        monkeypatch.delenv("FDG_MC_ROUTE")
+        st = torch.cuda.current_stream().cuda_stream
+        for kF, beta, lam in ((1.919, 3.0, 1.2), (1.5, 8.0, 0.7)):
+            T = rng.uniform(0.0, beta, size=(B, n_tau))
+            T[:, 0] = 0.0
+            T[:40, 1] = T[:40, 0]                           # tau == 0 exactly
+            h_leaf = oracle.leaf_values(*args[:6], K, T, kF, beta, lam)
+            want = oracle.eval_static(t, h_leaf)
+            scale = np.maximum(1.0, oracle.root_scale(t, h_leaf))
+            X = torch.from_numpy(np.concatenate([K.reshape(B, n_k).T, T.T], axis=0).copy()).to(cuda)   # [n_k + n_tau, B]
+            dKs = torch.from_numpy(K.reshape(B, n_k).copy()).to(cuda)                                  # sample-major [B, n_k]
+            dT2 = X[n_k:].clone()
+            layouts = {"one matrix": (X.data_ptr(), 1, B, X[n_k:].data_ptr(), 1, B),
+                       "two arrays": (X.data_ptr(), 1, B, dT2.data_ptr(), 1, B),
+                       "sample-major K": (dKs.data_ptr(), n_k, 1, dT2.data_ptr(), 1, B)}
+            d_leaves = torch.zeros((B, L), dtype=torch.float64, device=cuda)
+            gl.handle.mc_eval_device(X.data_ptr(), 1, B, X[n_k:].data_ptr(), 1, B, kF, beta, lam, d_leaves.data_ptr(), L, 1, B, st)
+            torch.cuda.synchronize()
+            want_exact = oracle.eval_static(t, d_leaves.cpu().numpy())
+            first = None
+            for lay, (pk, ks, kc, pt, ts, tc) in layouts.items():
+                root = torch.full((B, R), -7.0, dtype=torch.float64, device=cuda)
+                g.handle.mc_eval_device(pk, ks, kc, pt, ts, tc, kF, beta, lam, root.data_ptr(), R, 1, B, st)
+                torch.cuda.synchronize()
+                got = root.cpu().numpy()
+                assert np.array_equal(got, want_exact), (name, beta, lay)
+                err = np.abs(got - want) / scale
+                assert np.all(err <= (1e-12 if name == "gv_sigma4" else 1e-10)), (name, beta, lay, float(np.nanmax(err)))
+                first = got if first is None else first
+                assert np.array_equal(got, first), (name, lay)      # the layout changes addresses, never a value
+                w = torch.rand(B, dtype=torch.float64, device=cuda)
+                acc = torch.zeros(R, dtype=torch.float64, device=cuda)
+                g.handle.mc_accumulate_device(pk, ks, kc, pt, ts, tc, kF, beta, lam, w.data_ptr(), acc.data_ptr(), B, st)
+                torch.cuda.synchronize()
+                wr = got * w.cpu().numpy()[:, None]
+                assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0))), (name, lay)
+
+
+def test_isa_leaf_formulas_one_by_one(libfdg, cuda, monkeypatch):
+    """The formulas of the one-kernel route leaf by leaf -- a graph whose roots ARE its leaves -- with green_derive
+    orders 0..5 and interaction counter-terms 0..3 on the 4-loop self-energy's leaves: against the oracle within 1e-12
+    of the largest Leibniz term (derivatives) / 1e-13 relative (everything else), like the leaf kernels' own test."""
+    import torch
+    from feynmandiagram_jl_amd.nodetable import NodeTable
+    z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
+    L = len(z["leaf_type"])
+    order = np.where(z["leaf_type"] == 1, np.arange(L) % 6, np.arange(L) % 4).astype(np.int32)
+    t = NodeTable(L, np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0),
+                  np.arange(L, dtype=np.uint32), "leaves")
+    B, dim, n_loop, n_tau = 10_007, 3, int(z["basis"].shape[1]), int(z["n_tau"])
+    n_k = n_loop * dim
+    kF, beta, lam = 1.919, 3.0, 1.2
+    rng = np.random.default_rng(29)
+    K = rng.uniform(-2.0, 2.0, size=(B, n_loop, dim))
+    T = rng.uniform(0.0, beta, size=(B, n_tau))
+    T[:30, 1] = T[:30, 0]
+    args = (z["leaf_type"], order, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
+    tab, _keep = capi.make_leaf_tables(*args)
+    monkeypatch.setenv("FDG_MC_ROUTE", "isa")
+    g = fd.compile_table(t, specialize="isa")
+    g.handle.specialize_fused(tab)
+    X = torch.from_numpy(np.concatenate([K.reshape(B, n_k).T, T.T], axis=0).copy()).to(cuda)
+    root = torch.zeros((L, B), dtype=torch.float64, device=cuda)
+    g.handle.mc_eval_device(X.data_ptr(), 1, B, X[n_k:].data_ptr(), 1, B, kF, beta, lam, root.data_ptr(), 1, B, B,
+                            torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = root.cpu().numpy().T
+    want = oracle.leaf_values(*args[:6], K, T, kF, beta, lam)
+    q2 = (np.einsum("bjd,nj->bnd", K, z["basis"]) ** 2).sum(axis=2)
+    for i in range(L):
+        if z["leaf_type"][i] == 1 and order[i] > 0:
+            tau = T[:, z["tau_out"][i] - 1] - T[:, z["tau_in"][i] - 1]
+            scale = oracle.green_derive_scale(tau, q2[:, z["loop_index"][i] - 1] - kF * kF, beta, int(order[i]))
+            assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-12 * scale), (i, int(order[i]))
+        else:
+            assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-13 * np.abs(want[:, i])), (i, int(z["leaf_type"][i]), int(order[i]))
 
 
 def test_strides_beyond_four_gibibytes(libfdg, cuda):

@@ -274,6 +274,43 @@ def test_fused_step_specializes_without_device(libfdg, tmp_path):
     assert e.value.code == capi.FDG_E_UNSUPPORTED                     # "this leaftype ... not implemented!" (benchmark.jl:79)
 
 
+def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypatch):
+    """Route 3 of fdg_graph_specialize_fused (handle specialised with FDG_SPEC_ISA): with kF, beta, lambda in the
+    tables the kernels -- eval and accumulate -- are assembled right away, host-only; the assembly carries the exp /
+    reciprocal sequences (v_rndne_f64, v_ldexp_f64, v_rcp_f64 followed by the wait state gfx950 needs) and loads only
+    the n_loop*dim + n_tau input columns."""
+    import numpy as np
+    import re
+    import feynmandiagram_jl_amd as fd
+    from feynmandiagram_jl_amd import workloads
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(gold, "gv_sigma4_leafstates.npz"))
+    t = workloads.get("gv_sigma4")
+    f = fd.compile_table(t, specialize="isa")
+    tab, keep = capi.make_leaf_tables(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]),
+                                      1.919, 3.0, 1.2)
+    f.handle.specialize_fused(tab, str(tmp_path), capi.FDG_SPEC_KEEP_SOURCE)
+    asm = [x for x in os.listdir(tmp_path) if x.startswith("fdg_isa_") and x.endswith(".s")]
+    assert len(asm) == 1 and os.path.exists(os.path.join(tmp_path, asm[0][:-2] + ".hsaco"))
+    src = open(os.path.join(tmp_path, asm[0])).read()
+    assert "fdg_isa_mc:" in src and "fdg_isa_mc_acc:" in src
+    body = src.split("fdg_isa_mc_acc:")[0]
+    n_exp = body.count("v_ldexp_f64")
+    assert n_exp == body.count("v_rndne_f64") and n_exp >= 89          # one exponential per fermionic leaf + one per momentum
+    assert len(re.findall(r"v_rcp_f64_e64 [^\n]*\n\ts_nop 1", body)) == body.count("v_rcp_f64") > 0
+    assert body.count("global_load_dwordx2") <= 3 * (int(z["basis"].shape[1]) * 3 + int(z["n_tau"]))   # inputs (a few re-loads), no leaf matrix
+    # FDG_MC_ROUTE=isa insists on this route and says why it cannot be taken
+    bad_order = z["leaf_order"].copy()
+    bad_order[np.nonzero(z["leaf_type"] == 1)[0][0]] = 0
+    ty = z["leaf_type"].copy(); ty[0] = 0
+    tab0, keep0 = capi.make_leaf_tables(ty, z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]))
+    monkeypatch.setenv("FDG_MC_ROUTE", "isa")
+    with pytest.raises(capi.FdgError, match="without a formula"):
+        fd.compile_table(t, specialize="isa").handle.specialize_fused(tab0, str(tmp_path))
+    monkeypatch.delenv("FDG_MC_ROUTE")
+    fd.compile_table(t, specialize="isa").handle.specialize_fused(tab0, str(tmp_path))    # ... otherwise falls back to the other routes
+
+
 def test_argument_checks_of_the_newer_entry_points(libfdg):
     """Bad arguments are rejected before any device or RCCL work (so this runs without a GPU)."""
     import ctypes as C

@@ -14,6 +14,7 @@ import feynmandiagram_jl_amd as fd
 from feynmandiagram_jl_amd import capi, optimize, workloads
 from feynmandiagram_jl_amd.graph import AbstractOperator, Graph, Power, Prod, Sum
 from feynmandiagram_jl_amd.lowering import lower
+from feynmandiagram_jl_amd.nodetable import NodeTable
 from feynmandiagram_jl_amd.optimize import isequiv
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -365,3 +366,108 @@ def test_fast_math_program_fuses_products_into_sums(libfdg, name):
     got = replay(ops, nr, nl, nm, h.last_n_acc, leaf, t.n_root)
     want = oracle.eval_static(t, leaf)
     assert np.all(np.abs(got - want) <= 1e-12 * np.maximum(1.0, oracle.root_scale(t, leaf)))
+
+
+# --------------------------------------------------------------------------- #
+# Monte-Carlo step as one program: leaves computed from (K, T) inside the optimizing back end
+# --------------------------------------------------------------------------- #
+def replay_mc(ops, n_reg, n_lds, n_mem, n_acc, X, R):
+    """numpy replay of fdg_graph_mc_program's op list (kinds 16..21 with numpy's exp / division)."""
+    B = X.shape[0]
+    reg = np.full((max(n_reg, 1), B), np.nan); lds = np.full((max(n_lds, 1), B), np.nan)
+    mem = np.full((max(n_mem, 1), B), np.nan); acc = np.full((max(n_acc, 1), B), np.nan)
+    root = np.zeros((B, R))
+    cond = lambda x, ge: (x >= 0) if ge else (x > 0)
+    for o in ops:
+        k, d, a, b, c = int(o["kind"]), int(o["d"]), int(o["a"]), int(o["b"]), int(o["c"])
+        sa = -1.0 if o["nega"] else 1.0; sb = -1.0 if o["negb"] else 1.0; sc = -1.0 if o["negc"] else 1.0
+        if k == 0: reg[d] = X[:, a]
+        elif k == 1: reg[d] = lds[a]
+        elif k == 2: reg[d] = mem[a]
+        elif k == 3: lds[d] = reg[a]
+        elif k == 4: mem[d] = reg[a]
+        elif k == 5: reg[d] = (sa * reg[a]) * (sb * reg[b])
+        elif k == 6: reg[d] = (sa * reg[a]) + (sb * reg[b])
+        elif k == 7: reg[d] = (sa * reg[a]) * o["imm"]
+        elif k == 8: root[:, d] = sa * reg[a]
+        elif k == 10: reg[d] = acc[a]
+        elif k == 11: acc[d] = reg[a]
+        elif k == 16: reg[d] = (sa * reg[a]) + o["imm"]
+        elif k == 17: reg[d] = np.exp(sa * reg[a])
+        elif k == 18: reg[d] = 1.0 / (sa * reg[a])
+        elif k == 19: reg[d] = np.where(cond(sc * reg[c], o["imm"] != 0), sa * reg[a], sb * reg[b])
+        elif k == 20: reg[d] = np.where(reg[a] == 0, o["imm"], reg[a])
+        elif k == 21: reg[d] = np.where(cond(sa * reg[a], bool(o["negb"])), o["imm"], -o["imm"])
+        else: raise AssertionError(k)
+    return root
+
+
+def _mc_tables(name):
+    z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
+    if name == "gv_sigma4_taylor2":
+        zt = np.load(os.path.join(GOLD, "gv_sigma4_taylor2.npz"))
+        for k in ("leaf_type", "tau_in", "tau_out", "loop_index"):
+            z[k] = z[k][zt["leaf_base"]]
+        z["leaf_order"] = np.where(z["leaf_type"] == 2, zt["leaf_dorder"], 0).astype(np.int32)
+    elif name == "orders":      # green_derive orders 0..5 and interaction counter-terms 0..3 on the 4-loop leaves
+        L = len(z["leaf_type"])
+        z["leaf_order"] = np.where(z["leaf_type"] == 1, np.arange(L) % 6, np.arange(L) % 4).astype(np.int32)
+    return z
+
+
+@pytest.mark.parametrize("name,budget", [("gv_sigma4", dict(n_reg=120, n_lds=40)), ("gv_sigma4_taylor2", dict(n_reg=120, n_lds=40)),
+                                         ("gv_sigma4_taylor2", dict(n_reg=120, n_lds=80, n_acc=124, vn_window=1000)),
+                                         ("orders", dict(n_reg=40, n_lds=8))])
+def test_mc_program_replays_to_the_oracle_chain(libfdg, name, budget):
+    """The program of the one-kernel Monte-Carlo step (fdg_graph_mc_program: inputs = momentum components and times,
+    leaves = values computed by micro-ops 16..21 at their first use) replayed with numpy against the oracle chain
+    leaf_values -> eval_static.  The formulas, the value numbering and the allocation are what is checked here; the
+    kernel's own exp / reciprocal run in the GPU suite."""
+    z = _mc_tables(name)
+    if name == "orders":
+        L = len(z["leaf_type"])
+        t = NodeTable(L, np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0),
+                      np.arange(L, dtype=np.uint32), "leaves")
+    else:
+        t = workloads.get(name)
+    kF, beta, lam = 1.919, 3.0, 1.2
+    dim, n_tau, n_loop = 3, int(z["n_tau"]), int(z["basis"].shape[1])
+    args = (z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"])
+    tab, _keep = capi.make_leaf_tables(*args, dim, n_tau, kF, beta, lam)
+    h = capi.GraphHandle(t)
+    ops, nr, nl, nm = h.mc_program(tab, **budget)
+    assert nr <= budget["n_reg"] and nl <= budget["n_lds"]
+    assert int((ops["kind"] == 0).max()) == 1 and int(ops["a"][ops["kind"] == 0].max()) < n_loop * dim + n_tau   # loads are input columns only
+    rng = np.random.default_rng(5)
+    B = 48
+    K = rng.uniform(-2, 2, (B, n_loop, dim)); T = rng.uniform(0, beta, (B, n_tau))
+    T[:4, 1] = T[:4, 0]                                   # tau == 0
+    got = replay_mc(ops, nr, nl, nm, budget.get("n_acc", 0), np.concatenate([K.reshape(B, -1), T], axis=1), t.n_root)
+    leaf = oracle.leaf_values(*args, K, T, kF, beta, lam)
+    want = oracle.eval_static(t, leaf)
+    if name == "orders":
+        q2 = (np.einsum("bjd,nj->bnd", K, z["basis"]) ** 2).sum(axis=2)
+        for i in range(t.n_leaf):
+            if z["leaf_type"][i] == 1 and z["leaf_order"][i] > 0:
+                tau = T[:, z["tau_out"][i] - 1] - T[:, z["tau_in"][i] - 1]
+                scale = oracle.green_derive_scale(tau, q2[:, z["loop_index"][i] - 1] - kF * kF, beta, int(z["leaf_order"][i]))
+                assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-12 * scale), i
+            else:
+                assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-13 * np.abs(want[:, i])), i
+    else:
+        scale = np.maximum(1.0, oracle.root_scale(t, leaf))
+        assert np.all(np.abs(got - want) <= (1e-12 if name == "gv_sigma4" else 1e-10) * scale)
+
+
+def test_mc_program_refuses_what_its_formulas_do_not_cover(libfdg):
+    z = _mc_tables("gv_sigma4")
+    t = workloads.get("gv_sigma4")
+    order = z["leaf_order"].copy()
+    order[np.nonzero(z["leaf_type"] == 2)[0][0]] = 4          # interaction counter-term beyond x^3
+    tab, _keep = capi.make_leaf_tables(z["leaf_type"], order, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]), 1.9, 3.0, 1.2)
+    with pytest.raises(capi.FdgError, match="order above 3"):
+        capi.GraphHandle(t).mc_program(tab)
+    ty = z["leaf_type"].copy(); ty[0] = 0                       # a leaf without a formula
+    tab, _keep = capi.make_leaf_tables(ty, z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]), 1.9, 3.0, 1.2)
+    with pytest.raises(capi.FdgError, match="without a formula"):
+        capi.GraphHandle(t).mc_program(tab)
