@@ -12,7 +12,8 @@
 // barriers, no cross-wave traffic.  s_waitcnt is placed by an exact model of the
 // in-order vmcnt / lgkmcnt counters.
 //
-// Kernel arguments (all 8 bytes): leaf, ss, ls, root, rs, rk, ws, B, nwg, weight
+// Kernel arguments (all 8 bytes): leaf, ss, ls, root, rs, rk, ws, B, nwg, weight [, leaf2, ls2: Monte-Carlo kernels,
+//   whose input columns n_k.. (the times) are leaf2[b*ss + (i - n_k)*ls2]]
 //   (the _acc variant keeps acc_k += w * root_k in registers and writes one partial per wave and root to `root`)
 //   leaf value i of sample b: leaf[b*ss + i*ls]; root k: root[b*rs + k*rk]
 #include <algorithm>
@@ -37,8 +38,12 @@ constexpr int S_LP = 48;     // running pointer: column of the most recently loa
 constexpr int S_DELTA = 50;  // up to N_DELTA pairs: (leaf stride in bytes) x the most frequent index steps between consecutive loads
 constexpr int N_DELTA = 6;
 constexpr int S_POOL = S_DELTA + 2 * N_DELTA;   // constants of the graph (edge factors without an inline encoding), loaded once per wave
-constexpr int N_POOL = 20;   // (16 are used by programs without leaf formulas)
+constexpr int N_POOL = 20;   // (16 are used by programs without leaf formulas, 17 by those with)
 constexpr int S_END = S_POOL + 2 * N_POOL;
+// Monte-Carlo kernels (two more arguments: the times' base and column stride) keep these in the pool's last three pairs
+constexpr int N_POOL_MC = 17;
+constexpr int S_LEAF2 = S_POOL + 2 * N_POOL_MC, S_LS82 = S_LEAF2 + 2, S_LT2 = S_LEAF2 + 4;
+static_assert(S_LT2 + 2 == S_END, "SGPR map");
 
 // exp(x), x <= 0 in practice: n = rint(x log2 e), r = x - n ln2 (two-part), exp(r) by its Taylor polynomial of degree 13
 // (|r| <= 0.347: truncation 4e-18), scaled by 2^n with v_ldexp_f64 (flushes to 0 / denormals correctly far below)
@@ -125,7 +130,7 @@ void emit_scaled_addr(Emit &E, int dst, int base, int mul8, uint32_t k) {
   E.ins("s_addc_u32 s" + std::to_string(dst + 1) + ", s" + std::to_string(base + 1) + ", s" + std::to_string(S_X + 1));
 }
 
-struct KernelMeta { std::string name; uint32_t lds_bytes, accum, n_agpr; };
+struct KernelMeta { std::string name; uint32_t lds_bytes, accum, n_agpr; int n_args; };
 
 // Prints one kernel.  W = samples per lane: 1 (64-sample tiles, 8-byte accesses) or 2 (128-sample
 // tiles: a value is two doubles in four VGPRs, every memory access is 16 bytes per lane -- the
@@ -162,6 +167,9 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_load_dwordx8 s[12:19], s[0:1], 0x20");
   E.ins("s_load_dwordx2 s[20:21], s[0:1], 0x40");
   if (accumulate) E.ins("s_load_dwordx2 " + S2(S_WGT) + ", s[0:1], 0x48");
+  const uint32_t n_k = prog.mc_n_k;               // > 0: Monte-Carlo kernel; input columns >= n_k come from the second base
+  const bool mc = n_k > 0 || prog.mc_n_t > 0;
+  if (mc) E.ins("s_load_dwordx4 s[" + std::to_string(S_LEAF2) + ":" + std::to_string(S_LEAF2 + 3) + "], s[0:1], 0x50");
   E.ins("s_waitcnt lgkmcnt(0)");
   // accumulate mode: R per-lane accumulators, the lane's weight and one temporary live above the value registers
   uint64_t w_seq = 0;
@@ -186,6 +194,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("v_lshlrev_b32_e32 " + V(V_ROOTOFF) + ", " + std::to_string(W == 2 ? 4 : 3) + ", " + V(V_ROOTOFF));
   E.ins("s_lshl_b64 " + S2(S_LS8) + ", " + S2(S_LS) + ", 3");
   E.ins("s_lshl_b64 " + S2(S_RK8) + ", " + S2(S_RK) + ", 3");
+  if (mc) E.ins("s_lshl_b64 " + S2(S_LS82) + ", " + S2(S_LS82) + ", 3");
   // Leaf addresses: consecutive loads mostly step by +1 leaf (leaves are numbered in first-visit order and
   // the schedule visits them nearly in that order), so the column pointer is advanced by an add of the
   // stride (2 scalar ops) instead of being rebuilt from the leaf index (6); the next most frequent positive
@@ -194,7 +203,11 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   {
     std::map<int64_t, int> hist;
     int64_t last = -1;
-    for (const MOp &o : prog.ops) if (o.kind == M_LD_LEAF) { if (last >= 0 && (int64_t)o.a - last > 1) hist[(int64_t)o.a - last]++; last = o.a; }
+    for (const MOp &o : prog.ops) if (o.kind == M_LD_LEAF) {
+      const bool same_space = !mc || (o.a < n_k && last < (int64_t)n_k);     // only steps inside the first column space use the table
+      if (last >= 0 && same_space && (int64_t)o.a - last > 1) hist[(int64_t)o.a - last]++;
+      last = o.a;
+    }
     std::vector<std::pair<int, int64_t>> v;
     for (auto &kv : hist) if (kv.second >= 2) v.push_back({kv.second, kv.first});
     std::sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
@@ -221,7 +234,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     std::vector<std::pair<int, uint64_t>> v;
     for (auto &kv : hist) v.push_back({kv.second, kv.first});
     std::sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
-    for (size_t i = 0; i < v.size() && i < (size_t)(has_macro ? N_POOL : 16); ++i) pool.push_back(v[i].second);
+    for (size_t i = 0; i < v.size() && i < (size_t)(mc ? N_POOL_MC : (has_macro ? N_POOL : 16)); ++i) pool.push_back(v[i].second);
   }
   for (size_t k = 0; k < pool.size(); ++k) {
     E.ins("s_mov_b32 " + S(S_POOL + 2 * (int)k) + ", " + hex32((uint32_t)pool[k]));
@@ -266,6 +279,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("s_addc_u32 " + S(dst + 1) + ", " + S(base + 1) + ", " + S(S_A + 1));
   };
   tile_base(S_LT, S_LEAF, S_SS);
+  if (mc) tile_base(S_LT2, S_LEAF2, S_SS);
   if (!accumulate) tile_base(S_RT, S_ROOT, S_RS);
   if (accumulate) {
     // w = weight ? weight[b0 + lane] : 1.0   (consumed at the first root, long after this load)
@@ -354,14 +368,18 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         E.wait_reg(o.d);
         {
           const int64_t step = last_leaf >= 0 ? (int64_t)o.a - last_leaf : 0;
+          const bool second = mc && o.a >= n_k;                      // a time: second base, its own column stride
+          const bool same_space = !mc || last_leaf < 0 || (second == (last_leaf >= (int64_t)n_k));
           int dreg = -1;
-          if (last_leaf >= 0 && step == 1) dreg = S_LS8;
-          for (size_t k = 0; k < delta_tab.size() && last_leaf >= 0; ++k) if (delta_tab[k] == step) dreg = S_DELTA + 2 * (int)k;
+          if (last_leaf >= 0 && same_space && step == 1) dreg = second ? S_LS82 : S_LS8;
+          for (size_t k = 0; k < delta_tab.size() && last_leaf >= 0 && same_space && !second; ++k) if (delta_tab[k] == step) dreg = S_DELTA + 2 * (int)k;
           if (last_leaf >= 0 && step == 0) {
             // same column again: pointer already there
           } else if (dreg >= 0) {
             E.ins("s_add_u32 " + S(S_LP) + ", " + S(S_LP) + ", " + S(dreg));
             E.ins("s_addc_u32 " + S(S_LP + 1) + ", " + S(S_LP + 1) + ", " + S(dreg + 1));
+          } else if (second) {
+            emit_scaled_addr(E, S_LP, S_LT2, S_LS82, o.a - n_k);
           } else {
             emit_scaled_addr(E, S_LP, S_LT, S_LS8, o.a);
           }
@@ -593,7 +611,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const uint32_t n_agpr = RW * prog.n_acc_used;
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
   os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";
-  os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size 80\n\t\t.amdhsa_user_sgpr_count 2\n";
+  os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size " << (mc ? 96 : 80) << "\n\t\t.amdhsa_user_sgpr_count 2\n";
   os << "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1\n\t\t.amdhsa_system_sgpr_workgroup_id_x 1\n";
   os << "\t\t.amdhsa_system_vgpr_workitem_id 0\n";
   os << "\t\t.amdhsa_next_free_vgpr " << (accum + n_agpr) << "\n\t\t.amdhsa_next_free_sgpr " << S_END << "\n";
@@ -603,7 +621,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   os << "\t\t.amdhsa_dx10_clamp 1\n\t\t.amdhsa_ieee_mode 1\n";
   os << "\t.end_amdhsa_kernel\n";
   (void)p;
-  return KernelMeta{kname, lds_bytes, accum, n_agpr};
+  return KernelMeta{kname, lds_bytes, accum, n_agpr, mc ? 12 : 10};
 }
 
 }  // namespace
@@ -620,15 +638,15 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   if (prog_acc) ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc", 1, true));
   std::ostringstream &os = E.os;
   os << "\t.text\n\t.amdgpu_metadata\n---\namdhsa.kernels:\n";
-  const char *kinds[10] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",
-                           "global_buffer", "by_value", "by_value", "global_buffer"};
+  const char *kinds[12] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",
+                           "global_buffer", "by_value", "by_value", "global_buffer", "global_buffer", "by_value"};
   for (const KernelMeta &k : ks) {
     os << "  - .agpr_count: " << k.n_agpr << "\n    .args:\n";
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < k.n_args; ++i) {
       os << "      - .offset: " << i * 8 << "\n        .size: 8\n        .value_kind: " << kinds[i] << "\n";
       if (std::strcmp(kinds[i], "global_buffer") == 0) os << "        .address_space: global\n";
     }
-    os << "    .group_segment_fixed_size: " << k.lds_bytes << "\n    .kernarg_segment_align: 8\n    .kernarg_segment_size: 80\n";
+    os << "    .group_segment_fixed_size: " << k.lds_bytes << "\n    .kernarg_segment_align: 8\n    .kernarg_segment_size: " << 8 * k.n_args << "\n";
     os << "    .max_flat_workgroup_size: 64\n    .name: " << k.name << "\n    .private_segment_fixed_size: 0\n";
     os << "    .sgpr_count: " << (S_END + 6) << "\n    .sgpr_spill_count: 0\n    .symbol: " << k.name << ".kd\n";
     os << "    .uniform_work_group_size: 1\n    .uses_dynamic_stack: false\n    .vgpr_count: " << (k.accum + k.n_agpr)

@@ -760,6 +760,7 @@ void build_mc_program(const Lowered &p, const LeafSpec &ls, const OptParams &prm
     if (prm.fma) fuse_fma(B.u, B.next_vid);
     Alloc A(p, prm, B.u, B.next_vid, out);
     A.leaf_lo = B.in_base; A.leaf_n = B.n_in;
+    out.mc_n_k = B.n_k; out.mc_n_t = B.n_in - B.n_k;
     A.run();
     out.ops.swap(A.out);
     hoist_loads(out.ops, prm);

@@ -72,6 +72,7 @@ struct OptProgram {
   // statistics
   uint64_t n_valu = 0, n_ld_leaf = 0, n_ld_lds = 0, n_ld_mem = 0, n_st_lds = 0, n_st_mem = 0, n_ld_acc = 0, n_st_acc = 0;
   uint32_t max_live = 0;
+  uint32_t mc_n_k = 0, mc_n_t = 0;   // build_mc_program: input columns 0..mc_n_k-1 are momentum components, the next mc_n_t are times
   bool supported = true;    // false: graph uses something the ISA path does not cover
   std::string why;
 };

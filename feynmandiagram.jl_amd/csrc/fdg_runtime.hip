@@ -1175,10 +1175,11 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
   const size_t panel = (((size_t)std::max<uint32_t>(g->mc_mem[v], 1) * 512u * (size_t)grid) + 4095) & ~(size_t)4095;
   rc = ensure_ws(g, panel + (size_t)grid * std::max<uint32_t>(R, 1) * 512u + 4096);
   if (rc) return rc;
-  // The kernel reads its inputs as columns of ONE leaf-major matrix.  K and T handed over as such a matrix
-  // (component-major, the times right behind the momenta, one column stride) are read in place; anything else
-  // is packed into a chunk owned by the handle first (8 (n_k + n_tau) bytes per sample each way).
-  const bool in_place = ks == 1 && ts == 1 && kc == tc && kc >= 0 && d_T == d_K + (int64_t)n_k * kc;
+  // The kernel reads its inputs as columns: momentum component c at K[b*ss + c*kc], time i at T[b*ss + i*tc] (two
+  // bases, two column strides, one sample stride).  Component-major K and T (sample stride 1: a wave's 64 samples of a
+  // column are one 512-byte access) are read in place; anything else is packed into such a pair owned by the handle
+  // first (8 (n_k + n_tau) bytes per sample each way).
+  const bool in_place = ks == ts && ks >= 1 && ks < (1ll << 23) && (ks == 1 || std::getenv("FDG_MC_IN_PLACE"));
   int64_t Bc = std::min<int64_t>((B + 63) & ~63ll, 1ll << 22);
   if (const char *env = std::getenv("FDG_MC_CHUNK")) { const long long c = std::atoll(env); if (c >= 64) Bc = std::min<int64_t>((c + 63) & ~63ll, (B + 63) & ~63ll); }
   if (!in_place) {
@@ -1202,22 +1203,22 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
   };
   for (int64_t c0 = 0; c0 < B; c0 += (in_place ? B : Bc)) {
     long n = (long)(in_place ? B : std::min<int64_t>(Bc, B - c0));
-    const double *x = d_K;
-    long xls = (long)kc;
+    const double *x = d_K, *x2 = d_T;
+    long xls = (long)kc, xls2 = (long)tc, xss = (long)ks;
     if (!in_place) {
       double *X = (double *)g->d_ws4;
       rc = pack(d_K + c0 * ks, ks, kc, n_k, X, n);
       if (rc) return rc;
       rc = pack(d_T + c0 * ts, ts, tc, n_tau, X + (size_t)n_k * Bc, n);
       if (rc) return rc;
-      x = X; xls = (long)Bc;
+      x = X; x2 = X + (size_t)n_k * Bc; xls = xls2 = (long)Bc; xss = 1;
     }
     void *a_wsp = g->d_ws;
-    long one = 1, nwg = std::min<long>((n + 63) / 64, grid), zero = 0;
+    long nwg = std::min<long>((n + 63) / 64, grid), zero = 0;
     if (use_acc) {
       double *part = (double *)((char *)g->d_ws + panel);
       const double *wt = d_weight ? d_weight + c0 : nullptr;
-      void *args[] = {(void *)&x, &one, &xls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt};
+      void *args[] = {(void *)&x, &xss, &xls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt, (void *)&x2, &xls2};
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_mc_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
       hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
       HIP_TRY(hipGetLastError());
@@ -1225,7 +1226,7 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
       double *rt = d_root + c0 * rs;
       long a_rs = (long)rs, a_rk = (long)rk;
       const double *nowt = nullptr;
-      void *args[] = {(void *)&x, &one, &xls, (void *)&rt, &a_rs, &a_rk, &a_wsp, &n, &nwg, (void *)&nowt};
+      void *args[] = {(void *)&x, &xss, &xls, (void *)&rt, &a_rs, &a_rk, &a_wsp, &n, &nwg, (void *)&nowt, (void *)&x2, &xls2};
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_mc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
     }
   }
