@@ -156,7 +156,11 @@ typedef struct fdg_opt_params {
  * checkers that replay it): kind 0 LD_LEAF r[d]=leaf[a], 1 LD_LDS r[d]=lds[a],
  * 2 LD_MEM r[d]=ws[a], 3 ST_LDS lds[d]=r[a], 4 ST_MEM ws[d]=r[a],
  * 5 MUL r[d]=(+-r[a])*(+-r[b]), 6 ADD, 7 MULC r[d]=(+-r[a])*imm, 8 ROOT root[d]=+-r[a],
- * 10 LD_ACC r[d]=acc[a], 11 ST_ACC acc[d]=r[a]. */
+ * 10 LD_ACC r[d]=acc[a], 11 ST_ACC acc[d]=r[a].  Programs of fdg_graph_mc_program also contain the leaf formulas'
+ * 16 ADDC r[d]=(+-r[a])+imm, 17 EXP r[d]=exp(+-r[a]), 18 RCP r[d]=1/(+-r[a]),
+ * 19 SEL r[d]= cond(+-r[c]) ? +-r[a] : +-r[b] (cond: x>0 if imm==0, x>=0 otherwise), 20 FIXZ r[d]= r[a]==0 ? imm : r[a],
+ * 21 SELC r[d]= cond(+-r[a]) ? imm : -imm (x>0 if negb==0, x>=0 otherwise); their LD_LEAF reads input column a
+ * (momentum components first, then times). */
 typedef struct fdg_mop {
   uint8_t kind, nega, negb, negc;
   uint32_t d, a, b;

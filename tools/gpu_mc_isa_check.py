@@ -27,7 +27,7 @@ st = torch.cuda.current_stream().cuda_stream
 tab, _keep = capi.make_leaf_tables(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
 def handle(route):
     os.environ["FDG_MC_ROUTE"] = route
-    h = fd.compile_table(t, specialize="isa").handle
+    h = fd.compile_table(t, specialize="isa", flags=capi.FDG_SPEC_FAST_MATH if os.environ.get("FAST") else 0).handle
     if len(sys.argv) > 3: h.set_opt_params(*[int(v) for v in sys.argv[3].split(",")])
     h.specialize_fused(tab)
     return h
