@@ -1168,7 +1168,25 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
   const uint32_t R = g->prog.R;
   const uint32_t n_k = g->lt_hdr[2] * g->lt_hdr[3], n_tau = g->lt_hdr[4], n_in = n_k + n_tau;
   const bool use_acc = mode == 1 && g->mc_has_acc;
-  if (mode == 1 && !use_acc) { set_error("fused ISA step: accumulation needs 1..16 roots"); return FDG_E_UNSUPPORTED; }
+  if (mode == 1 && !use_acc) {
+    // more than 16 roots: no room for the accumulators next to the values -- roots to a scratch matrix, then the
+    // deterministic weighted reduction the other back ends use
+    if (R == 0) return FDG_OK;
+    const size_t need = (size_t)B * R * sizeof(double) + (size_t)2048 * R * sizeof(double);
+    if (g->ws2_bytes < need) {
+      if (g->d_ws2) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws2)); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
+      if (hipMalloc(&g->d_ws2, need) != hipSuccess) { set_error("hipMalloc(root scratch) failed"); return FDG_E_NOMEM; }
+      g->ws2_bytes = need;
+    }
+    double *roots = (double *)g->d_ws2, *partial = roots + (size_t)B * R;
+    rc = fdg_mc_isa_run(g, 0, d_K, ks, kc, d_T, ts, tc, kF, beta, lambda, roots, (int64_t)R, 1, nullptr, nullptr, B, st);
+    if (rc) return rc;
+    const uint32_t pb = (uint32_t)std::min<long>(2048, (long)((B + 255) / 256));
+    hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb), dim3(256), 0, st, roots, d_weight, (long)B, R, partial);
+    hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, pb, R, d_acc);
+    HIP_TRY(hipGetLastError());
+    return FDG_OK;
+  }
   if (mode == 0 && (rs < 0 || rs >= (1ll << 23))) { set_error("root sample stride negative or of 2^23 elements or more is not supported by the ISA kernel"); return FDG_E_UNSUPPORTED; }
   const int v = use_acc ? 1 : 0;
   const long grid = (long)g->n_cu * isa_waves_per_cu(g->mc_vgpr[v], g->mc_lds[v]);

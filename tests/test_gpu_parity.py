@@ -683,6 +683,14 @@ def test_isa_leaf_formulas_one_by_one(libfdg, cuda, monkeypatch):
             assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-12 * scale), (i, int(order[i]))
         else:
             assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-13 * np.abs(want[:, i])), (i, int(z["leaf_type"][i]), int(order[i]))
+    # 111 roots: accumulation goes through the roots' scratch matrix and the deterministic weighted reduction
+    w = torch.rand(B, dtype=torch.float64, device=cuda)
+    acc = torch.zeros(L, dtype=torch.float64, device=cuda)
+    g.handle.mc_accumulate_device(X.data_ptr(), 1, B, X[n_k:].data_ptr(), 1, B, kF, beta, lam, w.data_ptr(), acc.data_ptr(), B,
+                                  torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    wr = got * w.cpu().numpy()[:, None]
+    assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0)))
 
 
 def test_strides_beyond_four_gibibytes(libfdg, cuda):
