@@ -130,7 +130,7 @@ void emit_scaled_addr(Emit &E, int dst, int base, int mul8, uint32_t k) {
   E.ins("s_addc_u32 s" + std::to_string(dst + 1) + ", s" + std::to_string(base + 1) + ", s" + std::to_string(S_X + 1));
 }
 
-struct KernelMeta { std::string name; uint32_t lds_bytes, accum, n_agpr; int n_args; };
+struct KernelMeta { std::string name; uint32_t lds_bytes, accum, n_agpr; int n_args, n_sgpr; };
 
 // Prints one kernel.  W = samples per lane: 1 (64-sample tiles, 8-byte accesses) or 2 (128-sample
 // tiles: a value is two doubles in four VGPRs, every memory access is 16 bytes per lane -- the
@@ -614,14 +614,15 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size " << (mc ? 96 : 80) << "\n\t\t.amdhsa_user_sgpr_count 2\n";
   os << "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1\n\t\t.amdhsa_system_sgpr_workgroup_id_x 1\n";
   os << "\t\t.amdhsa_system_vgpr_workitem_id 0\n";
-  os << "\t\t.amdhsa_next_free_vgpr " << (accum + n_agpr) << "\n\t\t.amdhsa_next_free_sgpr " << S_END << "\n";
+  const int n_sgpr = (mc || has_macro) ? S_END : S_POOL + 2 * 16;   // programs without leaf formulas: the 16-entry pool ends the map
+  os << "\t\t.amdhsa_next_free_vgpr " << (accum + n_agpr) << "\n\t\t.amdhsa_next_free_sgpr " << n_sgpr << "\n";
   os << "\t\t.amdhsa_accum_offset " << accum << "\n\t\t.amdhsa_reserve_vcc 1\n";
   os << "\t\t.amdhsa_float_round_mode_32 0\n\t\t.amdhsa_float_round_mode_16_64 0\n";
   os << "\t\t.amdhsa_float_denorm_mode_32 3\n\t\t.amdhsa_float_denorm_mode_16_64 3\n";
   os << "\t\t.amdhsa_dx10_clamp 1\n\t\t.amdhsa_ieee_mode 1\n";
   os << "\t.end_amdhsa_kernel\n";
   (void)p;
-  return KernelMeta{kname, lds_bytes, accum, n_agpr, mc ? 12 : 10};
+  return KernelMeta{kname, lds_bytes, accum, n_agpr, mc ? 12 : 10, n_sgpr};
 }
 
 }  // namespace
@@ -648,7 +649,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
     }
     os << "    .group_segment_fixed_size: " << k.lds_bytes << "\n    .kernarg_segment_align: 8\n    .kernarg_segment_size: " << 8 * k.n_args << "\n";
     os << "    .max_flat_workgroup_size: 64\n    .name: " << k.name << "\n    .private_segment_fixed_size: 0\n";
-    os << "    .sgpr_count: " << (S_END + 6) << "\n    .sgpr_spill_count: 0\n    .symbol: " << k.name << ".kd\n";
+    os << "    .sgpr_count: " << (k.n_sgpr + 6) << "\n    .sgpr_spill_count: 0\n    .symbol: " << k.name << ".kd\n";
     os << "    .uniform_work_group_size: 1\n    .uses_dynamic_stack: false\n    .vgpr_count: " << (k.accum + k.n_agpr)
        << "\n    .vgpr_spill_count: 0\n    .wavefront_size: 64\n";
   }
