@@ -670,6 +670,7 @@ int fdg_graph_release_device(fdg_graph *g) {
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; g->fn_eval_sm = g->fn_eval_gen = nullptr; g->fn_isa = nullptr; }
   if (g->fused_module) { hipModuleUnload((hipModule_t)g->fused_module); g->fused_module = nullptr; g->fn_fused = nullptr; }
   if (g->alt_module) { hipModuleUnload((hipModule_t)g->alt_module); g->alt_module = nullptr; g->fn_alt_sm = g->fn_alt_gen = nullptr; }
+  if (g->mc_module) { hipModuleUnload((hipModule_t)g->mc_module); g->mc_module = nullptr; g->fn_mc = g->fn_mc_acc = nullptr; }
   return FDG_OK;
 }
 
