@@ -148,7 +148,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
                    const double *d_weight, double *d_acc, int64_t B, hipStream_t st);   // caller holds g->mu
 int launch_reduce_partials(const double *partial, uint32_t nblk, uint32_t R, double *acc, hipStream_t st);
 // Monte-Carlo step through one ISA kernel (fdg_runtime.hip); callers hold g->mu
-bool fdg_mc_isa_supported(fdg_graph *g, const fdg_leaf_tables *tab, std::string &why);
+bool fdg_mc_isa_supported(fdg_graph *g, const fdg_leaf_tables *tab, std::string &why, bool *recommended);
 int fdg_mc_isa_build(fdg_graph *g, double kF, double beta, double lambda);   // host-only (assembler); no-op when current
 int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_t kc, const double *d_T, int64_t ts, int64_t tc,
                    double kF, double beta, double lambda, double *d_root, int64_t rs, int64_t rk, const double *d_weight,

@@ -394,7 +394,8 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
     g->mc_flags = flags;
     if (try_isa) {
       std::string why;
-      if (fdg_mc_isa_supported(g, tab, why)) {
+      bool recommended = false;
+      if (fdg_mc_isa_supported(g, tab, why, &recommended) && (recommended || env_isa)) {
         g->mc_route = 3; g->fused_code.clear();
         // parameters known already (the tables carry them): assemble now rather than at the first call
         if (tab->beta != 0.0) { const int rb = fdg_mc_isa_build(g, tab->kF, tab->beta, tab->lambda); if (rb) return rb; }

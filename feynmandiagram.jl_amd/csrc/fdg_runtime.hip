@@ -1092,11 +1092,15 @@ static fdg::OptParams mc_params(const fdg_graph *g) {
   return q;
 }
 
-bool fdg_mc_isa_supported(fdg_graph *g, const fdg_leaf_tables *tab, std::string &why) {
+bool fdg_mc_isa_supported(fdg_graph *g, const fdg_leaf_tables *tab, std::string &why, bool *recommended) {
   fdg::LeafSpec ls; ls.tab = tab; ls.kF = 1.0; ls.beta = 1.0; ls.lambda = 1.0;
   fdg::OptProgram prog;
   fdg::build_mc_program(g->prog, ls, mc_params(g), prog);
   why = prog.why;
+  // Very large graphs keep leaf kernel + evaluator: a leaf that is a computed value must be spilled where a leaf that is
+  // input is simply read again, and beyond the on-chip levels that traffic outweighs the leaf matrix it saves
+  // (measured: 5-loop self-energy, 13 000 ops, one kernel 1.33x faster; its Taylor expansion, 67 000 ops, 0.88x)
+  if (recommended) *recommended = prog.supported && prog.n_valu <= 40000;
   return prog.supported;
 }
 

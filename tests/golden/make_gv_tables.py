@@ -108,25 +108,26 @@ def taylor_tables():
         print("taylor2", order, t.stats(), "series err", np.abs(series - f_x), "first-order err", np.abs((c[0] + x * c[1]) - f_x))
 
 
-def leafstates_fixture():
-    """FrontEnds.leafstates(leaf_maps, maxloopNum) (frontends.jl:178-232) of the optimized 4-loop GV
-    self-energy, in leafVal index order: what the device leaf kernel consumes."""
+def leafstates_fixture(order=4):
+    """FrontEnds.leafstates(leaf_maps, maxloopNum) (frontends.jl:178-232) of the optimized GV self-energy of that
+    order, in leafVal index order: what the device leaf kernels and the one-kernel Monte-Carlo step consume."""
     from feynmandiagram_jl_amd import FrontEnds
-    graphs = gv.diagsGV("sigma", 4, RD)
+    graphs = gv.diagsGV("sigma", order, RD)
     optimize.optimize_(graphs)
     t, leafmap, _ = lower(graphs)
-    w = np.load(os.path.join(HERE, "gv_sigma4.npz"))
+    w = np.load(os.path.join(HERE, f"gv_sigma{order}.npz"))
     assert np.array_equal(t.normalized().child_idx, w["child_idx"])
-    (val, typ, orders, tin, tout, loopidx), basis = FrontEnds.leafstates([leafmap], 5)
+    (val, typ, orders, tin, tout, loopidx), basis = FrontEnds.leafstates([leafmap], order + 1)
     lorder = [orders[0][i][0] if typ[0][i] == 1 else orders[0][i][1] for i in range(t.n_leaf)]
     n_tau = max(max(tin[0]), max(tout[0]))
-    np.savez_compressed(os.path.join(HERE, "gv_sigma4_leafstates.npz"), leaf_type=np.array(typ[0], np.int32),
+    np.savez_compressed(os.path.join(HERE, f"gv_sigma{order}_leafstates.npz"), leaf_type=np.array(typ[0], np.int32),
                         leaf_order=np.array(lorder, np.int32), tau_in=np.array(tin[0], np.int32), tau_out=np.array(tout[0], np.int32),
                         loop_index=np.array(loopidx[0], np.int32), basis=np.array(basis, np.float64), n_tau=np.int64(n_tau))
-    print("leafstates sigma4: L", t.n_leaf, "types", np.bincount(typ[0]).tolist(), "n_basis", len(basis), "n_loop", len(basis[0]), "n_tau", n_tau)
+    print(f"leafstates sigma{order}: L", t.n_leaf, "types", np.bincount(typ[0]).tolist(), "n_basis", len(basis), "n_loop", len(basis[0]), "n_tau", n_tau)
 
 
 if __name__ == "__main__":
     main()
     taylor_tables()
-    leafstates_fixture()
+    leafstates_fixture(4)
+    leafstates_fixture(5)

@@ -584,17 +584,18 @@ def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch):
     assembly).  Two statements.  (1) The graph part is exact: the roots are, bit for bit, the oracle's graph applied to
     the leaves this kernel computes (read out through a second kernel whose roots ARE the leaves -- same formulas, same
     IEEE operations, hence the same bits; those leaves are checked against the oracle in the test below).  (2) Against
-    the pure oracle chain (numpy leaves -> oracle graph) the roots agree to 1e-12 of their term scale on the 4-loop
-    graph and to 1e-10 on its Taylor expansion, whose cancellations amplify a last-bit difference of a leaf (the
+    the pure oracle chain (numpy leaves -> oracle graph) the roots agree to 1e-12 of their term scale on the 4- and
+    5-loop graphs and to 1e-10 on the Taylor expansion, whose cancellations amplify a last-bit difference of a leaf (the
     leaf-kernel route is 2e-12 off on the same samples).  Eval and accumulate; K and T as one matrix (read in place),
     as separate component-major arrays and sample-major (packed first); a ragged last tile; and again after the
     physical parameters change (the kernel is re-assembled)."""
     import torch
     from feynmandiagram_jl_amd.nodetable import NodeTable
-    for name, z in (("gv_sigma4", dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))), ("gv_sigma4_taylor2", _taylor2_tables())):
+    for name, z in (("gv_sigma4", dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))), ("gv_sigma4_taylor2", _taylor2_tables()),
+                    ("gv_sigma5", dict(np.load(os.path.join(GOLD, "gv_sigma5_leafstates.npz"))))):
         t = workloads.get(name)
         L, R = t.n_leaf, t.n_root
-        B, dim, n_loop, n_tau = 30_011, 3, int(z["basis"].shape[1]), int(z["n_tau"])
+        B, dim, n_loop, n_tau = (8_011 if name == "gv_sigma5" else 30_011), 3, int(z["basis"].shape[1]), int(z["n_tau"])
         n_k = n_loop * dim
         rng = np.random.default_rng(23)
         K = rng.uniform(-2.0, 2.0, size=(B, n_loop, dim))
@@ -634,7 +635,7 @@ def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch):
                 got = root.cpu().numpy()
                 assert np.array_equal(got, want_exact), (name, beta, lay)
                 err = np.abs(got - want) / scale
-                assert np.all(err <= (1e-12 if name == "gv_sigma4" else 1e-10)), (name, beta, lay, float(np.nanmax(err)))
+                assert np.all(err <= (1e-10 if name == "gv_sigma4_taylor2" else 1e-12)), (name, beta, lay, float(np.nanmax(err)))
                 first = got if first is None else first
                 assert np.array_equal(got, first), (name, lay)      # the layout changes addresses, never a value
                 w = torch.rand(B, dtype=torch.float64, device=cuda)

@@ -403,7 +403,7 @@ def replay_mc(ops, n_reg, n_lds, n_mem, n_acc, X, R):
 
 
 def _mc_tables(name):
-    z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
+    z = dict(np.load(os.path.join(GOLD, ("gv_sigma5" if name == "gv_sigma5" else "gv_sigma4") + "_leafstates.npz")))
     if name == "gv_sigma4_taylor2":
         zt = np.load(os.path.join(GOLD, "gv_sigma4_taylor2.npz"))
         for k in ("leaf_type", "tau_in", "tau_out", "loop_index"):
@@ -417,6 +417,7 @@ def _mc_tables(name):
 
 @pytest.mark.parametrize("name,budget", [("gv_sigma4", dict(n_reg=120, n_lds=40)), ("gv_sigma4_taylor2", dict(n_reg=120, n_lds=40)),
                                          ("gv_sigma4_taylor2", dict(n_reg=120, n_lds=80, n_acc=124, vn_window=1000)),
+                                         ("gv_sigma5", dict(n_reg=120, n_lds=80, n_acc=124, vn_window=1000)),
                                          ("orders", dict(n_reg=40, n_lds=8))])
 def test_mc_program_replays_to_the_oracle_chain(libfdg, name, budget):
     """The program of the one-kernel Monte-Carlo step (fdg_graph_mc_program: inputs = momentum components and times,
@@ -456,7 +457,7 @@ def test_mc_program_replays_to_the_oracle_chain(libfdg, name, budget):
                 assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-13 * np.abs(want[:, i])), i
     else:
         scale = np.maximum(1.0, oracle.root_scale(t, leaf))
-        assert np.all(np.abs(got - want) <= (1e-12 if name == "gv_sigma4" else 1e-10) * scale)
+        assert np.all(np.abs(got - want) <= (1e-10 if name == "gv_sigma4_taylor2" else 1e-12) * scale)
 
 
 def test_mc_program_refuses_what_its_formulas_do_not_cover(libfdg):

@@ -9,7 +9,11 @@ dev = torch.device("cuda:0")
 GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 name = sys.argv[1] if len(sys.argv) > 1 else "gv_sigma4_taylor2"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
-z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
+z = dict(np.load(os.path.join(GOLD, ("gv_sigma5" if name.startswith("gv_sigma5") else "gv_sigma4") + "_leafstates.npz")))
+if name == "gv_sigma5_taylor2":
+    zt = np.load(os.path.join(GOLD, "gv_sigma5_taylor2.npz"))
+    for k in ("leaf_type", "tau_in", "tau_out", "loop_index"): z[k] = z[k][zt["leaf_base"]]
+    z["leaf_order"] = np.where(z["leaf_type"] == 2, zt["leaf_dorder"], 0).astype(np.int32)
 if name == "gv_sigma4_taylor2":
     zt = np.load(os.path.join(GOLD, "gv_sigma4_taylor2.npz"))
     for k in ("leaf_type", "tau_in", "tau_out", "loop_index"): z[k] = z[k][zt["leaf_base"]]
