@@ -18,10 +18,11 @@ L = len(z["leaf_type"])
 sub = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(L))
 t = NodeTable(L, np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0), np.array(sub, np.uint32), "leaves")
 dim, n_loop, n_tau = 3, int(z["basis"].shape[1]), int(z["n_tau"]); n_k = n_loop * dim
-kF, beta, lam = 1.919, 3.0, 1.2
+kF, beta, lam = 1.919, float(os.environ.get("BETA", 3.0)), 1.2
+KMAX = float(os.environ.get("KMAX", 2.0))
 B = 64 * 300 + 17
 X = torch.empty((n_k + n_tau, B), dtype=torch.float64, device=dev)
-X[:n_k] = torch.rand((n_k, B), dtype=torch.float64, device=dev) * 4 - 2
+X[:n_k] = (torch.rand((n_k, B), dtype=torch.float64, device=dev) * 2 - 1) * KMAX
 X[n_k:] = torch.rand((n_tau, B), dtype=torch.float64, device=dev) * beta
 X[n_k + 1, :5] = X[n_k, :5]     # tau == 0
 st = torch.cuda.current_stream().cuda_stream
@@ -40,7 +41,7 @@ h.mc_eval_device(X.data_ptr(), 1, B, X[n_k:].data_ptr(), 1, B, kF, beta, lam, ro
 torch.cuda.synchronize()
 print("deterministic:", bool(torch.equal(r1, root)))
 want = leaf[sub]
-err = ((root - want).abs() / (want.abs() + 1e-300)).amax(dim=1).cpu().numpy()
+err = ((root - want).abs() / (want.abs() + 1e-290)).amax(dim=1).cpu().numpy()     # (results below 1e-290 count as zero)
 for j, i in enumerate(sub):
     if err[j] > 1e-12 or len(sub) <= 8:
         print(f"leaf {i}: type {z['leaf_type'][i]} order {z['leaf_order'][i]} loop {z['loop_index'][i]} tau {z['tau_in'][i]}->{z['tau_out'][i]}  max rel err {err[j]:.3e}  e.g. got {float(root[j,7]):.6e} want {float(want[j,7]):.6e}")
