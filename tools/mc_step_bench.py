@@ -50,14 +50,4 @@ tab, _keep = capi.make_leaf_tables(z["leaf_type"], z["leaf_order"], z["tau_in"],
 hf = fd.compile_table(t, specialize="isa").handle; hf.specialize_fused(tab)
 tf = timeit(lambda: hf.mc_accumulate_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, w.data_ptr(), acc.data_ptr(), B, st))
 print(f"fdg_mc_accumulate_device, route chosen by the library: {tf:.3f} ms = {B/tf*1e3:.3e} samples/s")
-sys.exit(0)
-# chunked: leaves of one chunk are consumed by the evaluator while still in L2 / MALL
-for Bc in (1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20):
-    lc = torch.zeros((L, Bc), dtype=torch.float64, device=dev).t()
-    def chunked():
-        for c0 in range(0, B, Bc):
-            capi.leaf_eval_device(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau, kF, beta, lam,
-                                  dK.data_ptr() + 8 * c0, 1, B, dT.data_ptr() + 8 * c0, 1, B, lc.data_ptr(), lc.stride(0), lc.stride(1), Bc, st)
-            f.handle.accumulate_device(lc.data_ptr(), lc.stride(0), lc.stride(1), w.data_ptr() + 8 * c0, acc.data_ptr(), Bc, st)
-    tc = timeit(chunked, 3)
-    print(f"chunks of {Bc}: whole step {tc:.3f} ms = {B/tc*1e3:.3e} samples/s")
+# (all three routes of fdg_graph_specialize_fused side by side, with value checks: tools/gpu_mc_isa_check.py)
