@@ -45,11 +45,14 @@ constexpr int N_POOL_MC = 17;
 constexpr int S_LEAF2 = S_POOL + 2 * N_POOL_MC, S_LS82 = S_LEAF2 + 2, S_LT2 = S_LEAF2 + 4;
 static_assert(S_LT2 + 2 == S_END, "SGPR map");
 
-// exp(x), x <= 0 in practice: n = rint(x log2 e), r = x - n ln2 (two-part), exp(r) by its Taylor polynomial of degree 13
-// (|r| <= 0.347: truncation 4e-18), scaled by 2^n with v_ldexp_f64 (flushes to 0 / denormals correctly far below)
+// exp(x), x <= 0 in practice: n = rint(x log2 e), r = x - n ln2 (two-part), exp(r) by a degree-11 polynomial
+// (Chebyshev-node interpolant of exp on |r| <= 0.3467, coefficients rounded to double: 1.6e-17 relative, computed with
+// 60-digit arithmetic), scaled by 2^n with v_ldexp_f64 (flushes to 0 / denormals correctly far below)
 const double kLog2e = 0x1.71547652b82fep+0, kLn2Hi = 0x1.62e42fefa39efp-1, kLn2Lo = 0x1.abc9e3b39803fp-56;
-const double kExpC[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
-                          1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+constexpr int kExpDeg = 11;
+const double kExpC[kExpDeg + 1] = {0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000011p-1, 0x1.555555555555ap-3,
+                                   0x1.555555554f0a5p-5, 0x1.111111110f218p-7, 0x1.6c16c18804745p-10, 0x1.a01a01b148c00p-13,
+                                   0x1.a019919593233p-16, 0x1.71ddf5667e394p-19, 0x1.28b41ab9f014bp-22, 0x1.af63371ef88d9p-26};
 
 struct Emit {
   std::ostringstream os;
@@ -229,7 +232,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     auto count = [&](double f) { bool inl; f64_inline(f, inl); if (!inl) { uint64_t u; std::memcpy(&u, &f, 8); hist[u]++; } };
     for (const MOp &o : prog.ops) {
       if (o.kind == M_MULC || o.kind == M_FMAC || o.kind == M_ADDC || o.kind == M_FIXZ || o.kind == M_SELC) count(o.imm);
-      if (o.kind == M_EXP) { count(kLog2e); count(-kLn2Hi); count(-kLn2Lo); for (int k = 3; k < 14; ++k) count(kExpC[k]); }
+      if (o.kind == M_EXP) { count(kLog2e); count(-kLn2Hi); count(-kLn2Lo); for (int k = 0; k <= kExpDeg; ++k) count(kExpC[k]); }
     }
     std::vector<std::pair<int, uint64_t>> v;
     for (auto &kv : hist) v.push_back({kv.second, kv.first});
@@ -443,12 +446,10 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         E.ins("v_rndne_f64_e32 " + tA + ", " + tA);
         E.ins("v_fma_f64 " + tB + ", " + tA + ", " + const_operand(-kLn2Hi) + ", " + x);
         E.ins("v_fma_f64 " + tB + ", " + tA + ", " + const_operand(-kLn2Lo) + ", " + tB);
-        {
-          const int c = const_sgpr(kExpC[13]);                       // (the argument register is dead from here: d may be it)
-          E.ins("v_mov_b32_e32 " + vd(o.d, 0) + ", " + S(c));
-          E.ins("v_mov_b32_e32 " + vd(o.d, 1) + ", " + S(c + 1));
-        }
-        for (int k = 12; k >= 0; --k) E.ins("v_fma_f64 " + vlo(o.d) + ", " + vlo(o.d) + ", " + tB + ", " + const_operand(kExpC[k]));
+        // (the argument register is dead from here: d may be it)
+        E.ins("v_mul_f64 " + vlo(o.d) + ", " + tB + ", " + const_operand(kExpC[kExpDeg]));
+        E.ins("v_add_f64 " + vlo(o.d) + ", " + vlo(o.d) + ", " + const_operand(kExpC[kExpDeg - 1]));
+        for (int k = kExpDeg - 2; k >= 0; --k) E.ins("v_fma_f64 " + vlo(o.d) + ", " + vlo(o.d) + ", " + tB + ", " + const_operand(kExpC[k]));
         E.ins("v_cvt_i32_f64_e32 " + tAd(0) + ", " + tA);
         E.ins("v_ldexp_f64 " + vlo(o.d) + ", " + vlo(o.d) + ", " + tAd(0));
         break;

@@ -35,7 +35,7 @@ enum MKind : uint8_t {
   M_FMAC = 15,    // r[d] = (+-r[a]) * imm + (+-r[c])
   // ---- leaf formulas inside the kernel (build_mc_program; results within the leaf kernels' tolerance, not bit-pinned) ----
   M_ADDC = 16,    // r[d] = (+-r[a]) + imm
-  M_EXP = 17,     // r[d] = exp(+-r[a])                       range reduction + degree-13 polynomial + v_ldexp_f64
+  M_EXP = 17,     // r[d] = exp(+-r[a])                       range reduction + degree-11 polynomial + v_ldexp_f64
   M_RCP = 18,     // r[d] = 1 / (+-r[a])                      v_rcp_f64 + two Newton steps
   M_SEL = 19,     // r[d] = cond(+-r[c]) ? +-r[a] : +-r[b]    cond: x > 0 (imm = 0) or x >= 0 (imm = 1)
   M_FIXZ = 20,    // r[d] = r[a] == 0 ? imm : r[a]

@@ -264,7 +264,7 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
  * assembled at the first fdg_mc_*_device call and again when a call brings other values (about a second).  K and T
  * are read in place when they are ONE component-major matrix (sample stride 1, T right behind K, one column stride);
  * otherwise they are packed into such a matrix first.  Leaves agree with fdg_leaf_eval_device within its stated
- * tolerance (own exp: range reduction + degree-13 polynomial), not bit for bit.  FDG_MC_ROUTE=isa|split overrides.
+ * tolerance (own exp: range reduction + degree-11 polynomial), not bit for bit.  FDG_MC_ROUTE=isa|split overrides.
  * fdg_graph_mc_program returns that program for inspection / host-side replay (tab->kF, beta, lambda are used). */
 int fdg_graph_mc_program(const fdg_graph *g, const fdg_leaf_tables *tab, const fdg_opt_params *prm, fdg_mop **ops, uint64_t *n_ops,
                          uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used);
