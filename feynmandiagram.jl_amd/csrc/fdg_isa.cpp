@@ -475,6 +475,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         std::string ahi = vd(o.a, 1), bhi = vd(o.b, 1);
         if (o.nega) { E.ins("v_xor_b32_e32 " + tAd(0) + ", 0x80000000, " + ahi); ahi = tAd(0); }
         if (o.negb) { E.ins("v_xor_b32_e32 " + tAd(1) + ", 0x80000000, " + bhi); bhi = tAd(1); }
+        // gfx940+: two wait states between a VALU write of VCC and a VALU read of it (FIXZ / SELC have two VALU ops in between)
+        if (!(o.nega && o.negb)) E.ins("s_nop " + std::string(o.nega || o.negb ? "0" : "1"));
         E.ins("v_cndmask_b32_e32 " + vd(o.d, 0) + ", " + vd(o.b, 0) + ", " + vd(o.a, 0) + ", vcc");
         E.ins("v_cndmask_b32_e32 " + vd(o.d, 1) + ", " + bhi + ", " + ahi + ", vcc");
         break;
