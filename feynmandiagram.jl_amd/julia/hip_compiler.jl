@@ -255,14 +255,20 @@ end
 `leaf*` are one partition of `FrontEnds.leafstates` (1-based indices, `leafOrder` the order of the leaf's own kind),
 `loopbasis` its deduplicated basis (`n_loop × n_basis`, columns as returned).  After this,
 `mc_accumulate_device!(f, d_K, d_T, d_weight, d_acc, B; kF, beta, lambda)` runs leaves + graph + weighted sum in one kernel.
+On a handle compiled with the optimizing back end (`compile(...; backend=:isa)`) that kernel is the back end's own: the
+leaves are values of its program, computed in registers from the momenta and times.  It reads `d_K` (`B × n_loop*dim`)
+and `d_T` (`B × n_tau`) in place when they are Julia column-major matrices -- the default `k_strides = t_strides = (1, B)`.
+`kF`, `beta`, `lambda` are constants of its code (assembled at the first call, again when they change), or pass them
+here to have it assembled now.
 """
 function specialize_fused!(f::GraphFunc, leafType::Vector{Int}, leafOrder::Vector{Int}, leafInTau::Vector{Int}, leafOutTau::Vector{Int},
-    leafLoopIndex::Vector{Int}, loopbasis::Matrix{Float64}; dim::Int=3, n_tau::Int, cache_dir::String=get(ENV, "FDG_CACHE_DIR", "/tmp/fdg-cache"))
+    leafLoopIndex::Vector{Int}, loopbasis::Matrix{Float64}; dim::Int=3, n_tau::Int, cache_dir::String=get(ENV, "FDG_CACHE_DIR", "/tmp/fdg-cache"),
+    kF::Float64=0.0, beta::Float64=0.0, lambda::Float64=0.0)
     a = [Int32.(v) for v in (leafType, leafOrder, leafInTau, leafOutTau, leafLoopIndex)]
     bs = Matrix{Float64}(loopbasis)      # column-major n_loop × n_basis == row-major [n_basis][n_loop]
     GC.@preserve a bs begin
         tab = _FdgLeafTables(length(a[1]), size(bs, 2), size(bs, 1), dim, n_tau, pointer(a[1]), pointer(a[2]), pointer(a[3]),
-            pointer(a[4]), pointer(a[5]), pointer(bs), 0.0, 0.0, 0.0)
+            pointer(a[4]), pointer(a[5]), pointer(bs), kF, beta, lambda)
         _fdg_check(ccall((:fdg_graph_specialize_fused, _libfdg), Cint, (Ptr{Cvoid}, Ref{_FdgLeafTables}, Cstring, Cuint), f.handle, tab, cache_dir, Cuint(0)))
     end
     return f
