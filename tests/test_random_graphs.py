@@ -85,3 +85,113 @@ def test_random_graphs_on_device(libfdg, cuda):
                 torch.cuda.synchronize()
                 got = root.cpu().numpy()
                 assert same(got, want), (seed, spec, layout)
+
+
+# --------------------------------------------------------------------------- #
+# one-kernel Monte-Carlo step on random graphs over random leaf tables
+# --------------------------------------------------------------------------- #
+def random_leaf_tables(seed: int, L: int):
+    """A random partition in the shape FrontEnds.leafstates produces (frontends.jl:178-232): fermionic leaves with
+    green_derive orders 0..5 and interaction leaves with counter-term orders 0..3 over a random loop basis."""
+    rng = np.random.default_rng(1000 + seed)
+    n_loop, n_tau, n_basis = int(rng.integers(1, 5)), int(rng.integers(1, 6)), int(rng.integers(1, 9))
+    basis = rng.choice([-1.0, 0.0, 0.0, 1.0, 1.0, 0.5], size=(n_basis, n_loop))
+    for r in range(n_basis):
+        if not basis[r].any():
+            basis[r, int(rng.integers(0, n_loop))] = 1.0
+    ty = rng.choice([1, 1, 2], size=L).astype(np.int32)
+    order = np.where(ty == 1, rng.integers(0, 6, size=L), rng.integers(0, 4, size=L)).astype(np.int32)
+    order[rng.random(L) < 0.5] = 0
+    return dict(leaf_type=ty, leaf_order=order, tau_in=rng.integers(1, n_tau + 1, size=L).astype(np.int32),
+                tau_out=rng.integers(1, n_tau + 1, size=L).astype(np.int32), loop_index=rng.integers(1, n_basis + 1, size=L).astype(np.int32),
+                basis=basis, n_tau=n_tau, n_loop=n_loop)
+
+
+def leaves_table(L):
+    from feynmandiagram_jl_amd.nodetable import NodeTable
+    return NodeTable(L, np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0),
+                     np.arange(L, dtype=np.uint32), "leaves")
+
+
+def check_leaves(z, got, K, T, kF, beta, lam):
+    """leaf values against the oracle: 1e-12 of the largest Leibniz term for derivatives, 1e-13 relative otherwise"""
+    args = (z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"])
+    want = oracle.leaf_values(*args, K, T, kF, beta, lam)
+    q2 = (np.einsum("bjd,nj->bnd", K, z["basis"]) ** 2).sum(axis=2)
+    for i in range(len(z["leaf_type"])):
+        if z["leaf_type"][i] == 1 and z["leaf_order"][i] > 0:
+            tau = T[:, z["tau_out"][i] - 1] - T[:, z["tau_in"][i] - 1]
+            scale = oracle.green_derive_scale(tau, q2[:, z["loop_index"][i] - 1] - kF * kF, beta, int(z["leaf_order"][i]))
+            assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-12 * scale), (i, int(z["leaf_order"][i]))
+        else:
+            assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-13 * np.abs(want[:, i])), (i, int(z["leaf_type"][i]), int(z["leaf_order"][i]))
+
+
+MC_SEEDS = list(range(16))
+
+
+@pytest.mark.parametrize("seed", MC_SEEDS)
+def test_random_mc_program_replays(libfdg, seed):
+    """fdg_graph_mc_program on random graphs over random leaf tables, replayed in numpy: the graph part is exact (the
+    roots are the oracle's graph applied to the leaves of the same formulas, read out through the leaves-as-roots
+    program), the leaves agree with the oracle's within the leaf kernels' tolerance."""
+    from test_next_rows import replay_mc
+    t = random_table(seed)
+    z = random_leaf_tables(seed, t.n_leaf)
+    kF, beta, lam = 1.3, float(np.random.default_rng(seed).choice([0.7, 3.0, 25.0])), 0.9
+    dim = 3
+    tab, _keep = capi.make_leaf_tables(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, z["n_tau"], kF, beta, lam)
+    rng = np.random.default_rng(seed)
+    B = 24
+    K = rng.uniform(-2, 2, (B, z["n_loop"], dim)); T = rng.uniform(0, beta, (B, z["n_tau"]))
+    X = np.concatenate([K.reshape(B, -1), T], axis=1)
+    budget = dict(n_reg=int(rng.integers(6, 14)), n_lds=int(rng.integers(1, 4)), n_acc=int(rng.integers(0, 3)), vn_window=int(rng.choice([0, 5, 200])))
+    ops, nr, nl, nm = capi.GraphHandle(leaves_table(t.n_leaf)).mc_program(tab, **budget)
+    leaves = replay_mc(ops, nr, nl, nm, budget["n_acc"], X, t.n_leaf)
+    check_leaves(z, leaves, K, T, kF, beta, lam)
+    ops, nr, nl, nm = capi.GraphHandle(t).mc_program(tab, **budget)
+    got = replay_mc(ops, nr, nl, nm, budget["n_acc"], X, t.n_root)
+    want = oracle.eval_static(t, leaves)
+    live = t.root_slot != FDG_NO_ROOT
+    assert same(got[:, live], want[:, live]), (seed, budget)
+
+
+@pytest.mark.gpu
+def test_random_mc_step_on_device(libfdg, cuda, monkeypatch):
+    """The same statements for the kernels: eval and accumulate of the one-kernel route on random graphs and tables."""
+    import torch
+    monkeypatch.setenv("FDG_MC_ROUTE", "isa")
+    st = torch.cuda.current_stream().cuda_stream
+    for seed in MC_SEEDS:
+        t = random_table(seed)
+        L, R = t.n_leaf, t.n_root
+        z = random_leaf_tables(seed, L)
+        rng = np.random.default_rng(seed)
+        kF, beta, lam = 1.3, float(rng.choice([0.7, 3.0, 25.0])), 0.9
+        dim, n_k, n_tau = 3, z["n_loop"] * 3, z["n_tau"]
+        tab, _keep = capi.make_leaf_tables(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
+        B = int(rng.choice([1, 65, 1000]))
+        K = rng.uniform(-2, 2, (B, z["n_loop"], dim)); T = rng.uniform(0, beta, (B, n_tau))
+        dK = torch.from_numpy(np.ascontiguousarray(K.reshape(B, n_k).T)).to(cuda)
+        dT = torch.from_numpy(np.ascontiguousarray(T.T)).to(cuda)
+        gl = fd.compile_table(leaves_table(L), specialize="isa"); gl.handle.specialize_fused(tab)
+        d_leaves = torch.zeros((B, L), dtype=torch.float64, device=cuda)
+        gl.handle.mc_eval_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, d_leaves.data_ptr(), L, 1, B, st)
+        torch.cuda.synchronize()
+        leaves = d_leaves.cpu().numpy()
+        check_leaves(z, leaves, K, T, kF, beta, lam)
+        g = fd.compile_table(t, specialize="isa"); g.handle.specialize_fused(tab)
+        root = torch.full((B, R), 9.0, dtype=torch.float64, device=cuda)
+        g.handle.mc_eval_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, root.data_ptr(), R, 1, B, st)
+        torch.cuda.synchronize()
+        want = oracle.eval_static(t, leaves, np.full((B, R), 9.0))
+        got = root.cpu().numpy()
+        assert same(got, want), seed
+        live = t.root_slot != FDG_NO_ROOT
+        w = torch.rand(B, dtype=torch.float64, device=cuda)
+        acc = torch.zeros(R, dtype=torch.float64, device=cuda)
+        g.handle.mc_accumulate_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, w.data_ptr(), acc.data_ptr(), B, st)
+        torch.cuda.synchronize()
+        wr = np.where(live[None, :], got, 0.0) * w.cpu().numpy()[:, None]
+        fin = np.isfinite(wr).all(axis=0) & live
+        assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0))[fin] <= 1e-12 * np.maximum(1.0, np.abs(wr).sum(0))[fin]), seed
