@@ -1202,7 +1202,7 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
   // bases, two column strides, one sample stride).  Component-major K and T (sample stride 1: a wave's 64 samples of a
   // column are one 512-byte access) are read in place; anything else is packed into such a pair owned by the handle
   // first (8 (n_k + n_tau) bytes per sample each way).
-  const bool in_place = ks == ts && ks >= 1 && ks < (1ll << 23) && (ks == 1 || std::getenv("FDG_MC_IN_PLACE"));
+  const bool in_place = ks == 1 && ts == 1;
   int64_t Bc = std::min<int64_t>((B + 63) & ~63ll, 1ll << 22);
   if (const char *env = std::getenv("FDG_MC_CHUNK")) { const long long c = std::atoll(env); if (c >= 64) Bc = std::min<int64_t>((c + 63) & ~63ll, (B + 63) & ~63ll); }
   if (!in_place) {
