@@ -1099,7 +1099,7 @@ bool fdg_mc_isa_supported(fdg_graph *g, const fdg_leaf_tables *tab, std::string 
   why = prog.why;
   // Very large graphs keep leaf kernel + evaluator: a leaf that is a computed value must be spilled where a leaf that is
   // input is simply read again, and beyond the on-chip levels that traffic outweighs the leaf matrix it saves
-  // (measured: 5-loop self-energy, 13 000 ops, one kernel 1.33x faster; its Taylor expansion, 67 000 ops, 0.88x)
+  // (measured: 5-loop self-energy, 13 000 ops, one kernel 1.67x faster; its Taylor expansion, 67 000 ops, 0.9x)
   if (recommended) *recommended = prog.supported && prog.n_valu <= 40000;
   return prog.supported;
 }
@@ -1125,9 +1125,21 @@ int fdg_mc_isa_build(fdg_graph *g, double kF, double beta, double lambda) {
     fdg::OptParams qb = cfg_B();
     qb.n_reg = std::min<uint32_t>(qb.n_reg, 123);
     qb.fma = q.fma;
-    fdg::OptProgram pb;
-    fdg::build_mc_program(g->prog, ls, qb, pb);
-    if (pb.supported) { pe = std::move(pb); q = qb; }
+    // ... and when even that overflows, a shorter value-numbering window trades re-computed fold steps for live values:
+    // the candidate with the least (instructions + 40 per panel access) wins -- 8 bytes per sample at the panel's
+    // ~4.7 TB/s cost what ~40 instructions do at 27e12 lane-op/s (5-loop self-energy: window 1000 -> 400, 7.8e8 -> 9.6e8)
+    fdg::OptProgram best;
+    uint64_t best_cost = ~0ull;
+    for (uint32_t vn : {1000u, 400u, 200u}) {
+      qb.vn_window = vn;
+      fdg::OptProgram pb;
+      fdg::build_mc_program(g->prog, ls, qb, pb);
+      if (!pb.supported) break;
+      const uint64_t cost = pb.n_valu + 40 * (pb.n_ld_mem + pb.n_st_mem);
+      if (cost < best_cost) { best_cost = cost; best = std::move(pb); q = qb; }
+      if (best.n_ld_mem + best.n_st_mem == 0) break;
+    }
+    if (best_cost != ~0ull) pe = std::move(best);
   }
   if (!pe.supported) { set_error("the fused ISA step does not cover this graph / these leaves: " + pe.why); return FDG_E_UNSUPPORTED; }
   const uint32_t R = g->prog.R;
