@@ -940,7 +940,6 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
 
 // returns 1 when a remembered choice was installed, 0 when there is none, < 0 on error
 static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
-  const fdg::Lowered &p = g->prog;
   const std::string tuned = tuned_path(g, dir);
   std::vector<char> buf;
   if (!read_file(tuned, buf)) return 0;
