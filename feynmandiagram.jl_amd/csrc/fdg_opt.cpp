@@ -204,7 +204,7 @@ struct Builder {
       }
       return v;
     }
-    if (ty != 1) { ok = false; why = "a leaf without a formula"; return in_k(0); }
+    if (ty != 1) return addc(mulc(in_k(0), 0.0), 1.0);             // no formula: leafstates' initial leafValue 1.0  ((+-0) + 1.0 == 1.0)
     if (n < 0 || n > 5) { ok = false; why = "green_derive order above 5"; return in_k(0); }
     Mom &m = fermi(li);
     if (!ok) return in_k(0);

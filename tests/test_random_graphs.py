@@ -99,7 +99,7 @@ def random_leaf_tables(seed: int, L: int):
     for r in range(n_basis):
         if not basis[r].any():
             basis[r, int(rng.integers(0, n_loop))] = 1.0
-    ty = rng.choice([1, 1, 2], size=L).astype(np.int32)
+    ty = rng.choice([1, 1, 1, 2, 2, 0], size=L).astype(np.int32)     # 0: a leaf without a formula (value 1.0)
     order = np.where(ty == 1, rng.integers(0, 6, size=L), rng.integers(0, 4, size=L)).astype(np.int32)
     order[rng.random(L) < 0.5] = 0
     return dict(leaf_type=ty, leaf_order=order, tau_in=rng.integers(1, n_tau + 1, size=L).astype(np.int32),
@@ -123,6 +123,8 @@ def check_leaves(z, got, K, T, kF, beta, lam):
             tau = T[:, z["tau_out"][i] - 1] - T[:, z["tau_in"][i] - 1]
             scale = oracle.green_derive_scale(tau, q2[:, z["loop_index"][i] - 1] - kF * kF, beta, int(z["leaf_order"][i]))
             assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-12 * scale), (i, int(z["leaf_order"][i]))
+        elif z["leaf_type"][i] == 0:
+            assert np.all(got[:, i] == 1.0), i
         else:
             assert np.all(np.abs(got[:, i] - want[:, i]) <= 1e-13 * np.abs(want[:, i])), (i, int(z["leaf_type"][i]), int(z["leaf_order"][i]))
 
