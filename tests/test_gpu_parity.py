@@ -569,6 +569,37 @@ def test_mc_step_routes_on_large_graph(libfdg, cuda, monkeypatch):
         assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0))), route
 
 
+def test_mc_step_with_high_interaction_orders(libfdg, cuda):
+    """Interaction counter-terms above order 3 (pow_body, only in the table-driven leaf kernel): the Monte-Carlo calls
+    take the leaf kernel + evaluator route for such tables, on any handle, and give the bits of the hand-written sequence."""
+    import torch
+    z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
+    order = z["leaf_order"].copy()
+    inter = np.nonzero(z["leaf_type"] == 2)[0]
+    order[inter[::3]] = 4
+    order[inter[1::3]] = 7
+    t = workloads.get("gv_sigma4")
+    L, R = t.n_leaf, t.n_root
+    B, dim, n_loop, n_tau = 5_003, 3, int(z["basis"].shape[1]), int(z["n_tau"])
+    kF, beta, lam = 1.919, 3.0, 1.2
+    rng = np.random.default_rng(41)
+    dK = torch.from_numpy(rng.uniform(-2.0, 2.0, size=(n_loop * dim, B))).to(cuda)
+    dT = torch.from_numpy(rng.uniform(0.0, beta, size=(n_tau, B))).to(cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (z["leaf_type"], order, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
+    leaf = torch.ones((L, B), dtype=torch.float64, device=cuda).t()
+    capi.leaf_eval_device(*args, kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf.data_ptr(), leaf.stride(0), leaf.stride(1), B, st)
+    tab, _keep = capi.make_leaf_tables(*args)
+    for spec in ("isa", True):
+        f = fd.compile_table(t, specialize=spec)
+        want = f(None, leaf)
+        f.handle.specialize_fused(tab)
+        root = torch.zeros((B, R), dtype=torch.float64, device=cuda)
+        f.handle.mc_eval_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, root.data_ptr(), R, 1, B, st)
+        torch.cuda.synchronize()
+        assert torch.equal(root, want), spec
+
+
 def _taylor2_tables():
     z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
     zt = np.load(os.path.join(GOLD, "gv_sigma4_taylor2.npz"))

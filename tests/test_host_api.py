@@ -304,8 +304,10 @@ def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypa
     order4[np.nonzero(z["leaf_type"] == 2)[0][0]] = 4         # interaction counter-term beyond x^3: the table-driven leaf kernel's pow_body only
     tab0, keep0 = capi.make_leaf_tables(z["leaf_type"], order4, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]))
     monkeypatch.setenv("FDG_MC_ROUTE", "isa")
-    with pytest.raises(capi.FdgError):
+    with pytest.raises(capi.FdgError, match="order > 3"):
         fd.compile_table(t, specialize="isa").handle.specialize_fused(tab0, str(tmp_path))
+    monkeypatch.delenv("FDG_MC_ROUTE")
+    fd.compile_table(t, specialize="isa").handle.specialize_fused(tab0, str(tmp_path))    # ... leaf kernel + evaluator otherwise
 
 
 def test_argument_checks_of_the_newer_entry_points(libfdg):
