@@ -81,11 +81,11 @@ class OptParams(C.Structure):
 class MOp(C.Structure):
     _fields_ = [("kind", C.c_uint8), ("nega", C.c_uint8), ("negb", C.c_uint8), ("negc", C.c_uint8),
                 ("d", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("imm", C.c_double),
-                ("c", C.c_uint32), ("pad", C.c_uint32)]
+                ("c", C.c_uint32), ("param", C.c_uint32)]
 
 
 MOP_DTYPE = np.dtype([("kind", "u1"), ("nega", "u1"), ("negb", "u1"), ("negc", "u1"),
-                      ("d", "<u4"), ("a", "<u4"), ("b", "<u4"), ("imm", "<f8"), ("c", "<u4"), ("pad", "<u4")])
+                      ("d", "<u4"), ("a", "<u4"), ("b", "<u4"), ("imm", "<f8"), ("c", "<u4"), ("param", "<u4")])
 
 _lib = None
 

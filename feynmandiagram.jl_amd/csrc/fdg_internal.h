@@ -115,7 +115,6 @@ struct fdg_graph {
   void *mc_module = nullptr, *fn_mc = nullptr, *fn_mc_acc = nullptr;
   bool mc_has_acc = false, mc_built = false;
   uint32_t mc_vgpr[2] = {0, 0}, mc_lds[2] = {0, 0}, mc_mem[2] = {0, 0};   // [0] eval kernel, [1] accumulate kernel
-  double mc_const[3] = {0, 0, 0};  // kF, beta, lambda the kernel was built for (they are constants of its code)
   std::string mc_dir;
   unsigned mc_flags = 0;
   void *d_ws4 = nullptr;           // leaf-major chunk of leaves for route 2 / packed (K, T) columns for route 3
@@ -149,7 +148,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
 int launch_reduce_partials(const double *partial, uint32_t nblk, uint32_t R, double *acc, hipStream_t st);
 // Monte-Carlo step through one ISA kernel (fdg_runtime.hip); callers hold g->mu
 bool fdg_mc_isa_supported(fdg_graph *g, const fdg_leaf_tables *tab, std::string &why, bool *recommended);
-int fdg_mc_isa_build(fdg_graph *g, double kF, double beta, double lambda);   // host-only (assembler); no-op when current
+int fdg_mc_isa_build(fdg_graph *g);   // host-only (assembler); no-op when built
 int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_t kc, const double *d_T, int64_t ts, int64_t tc,
                    double kF, double beta, double lambda, double *d_root, int64_t rs, int64_t rk, const double *d_weight,
                    double *d_acc, int64_t B, hipStream_t st);

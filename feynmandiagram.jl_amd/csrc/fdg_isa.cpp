@@ -12,8 +12,9 @@
 // barriers, no cross-wave traffic.  s_waitcnt is placed by an exact model of the
 // in-order vmcnt / lgkmcnt counters.
 //
-// Kernel arguments (all 8 bytes): leaf, ss, ls, root, rs, rk, ws, B, nwg, weight [, leaf2, ls2: Monte-Carlo kernels,
-//   whose input columns n_k.. (the times) are leaf2[b*ss + (i - n_k)*ls2]]
+// Kernel arguments (all 8 bytes): leaf, ss, ls, root, rs, rk, ws, B, nwg, weight [, leaf2, ls2, -kF^2, beta, -beta, lambda:
+//   Monte-Carlo kernels, whose input columns n_k.. (the times) are leaf2[b*ss + (i - n_k)*ls2] and whose formulas read the
+//   four physical parameters from SGPRs]
 //   (the _acc variant keeps acc_k += w * root_k in registers and writes one partial per wave and root to `root`)
 //   leaf value i of sample b: leaf[b*ss + i*ls]; root k: root[b*rs + k*rk]
 #include <algorithm>
@@ -38,12 +39,13 @@ constexpr int S_LP = 48;     // running pointer: column of the most recently loa
 constexpr int S_DELTA = 50;  // up to N_DELTA pairs: (leaf stride in bytes) x the most frequent index steps between consecutive loads
 constexpr int N_DELTA = 6;
 constexpr int S_POOL = S_DELTA + 2 * N_DELTA;   // constants of the graph (edge factors without an inline encoding), loaded once per wave
-constexpr int N_POOL = 20;   // (16 are used by programs without leaf formulas, 17 by those with)
+constexpr int N_POOL = 20;   // (16 are used by programs without leaf formulas, 13 by Monte-Carlo kernels)
 constexpr int S_END = S_POOL + 2 * N_POOL;
 // Monte-Carlo kernels (two more arguments: the times' base and column stride) keep these in the pool's last three pairs
-constexpr int N_POOL_MC = 17;
-constexpr int S_LEAF2 = S_POOL + 2 * N_POOL_MC, S_LS82 = S_LEAF2 + 2, S_LT2 = S_LEAF2 + 4;
-static_assert(S_LT2 + 2 == S_END, "SGPR map");
+constexpr int N_POOL_MC = 13;
+constexpr int S_PARAM = S_POOL + 2 * N_POOL_MC;   // the four physical parameters of MOp::param (kernel arguments 13-16)
+constexpr int S_LEAF2 = S_PARAM + 2 * MC_N_PARAM, S_LS82 = S_LEAF2 + 2, S_LT2 = S_LEAF2 + 4;
+static_assert(S_LT2 + 2 == S_END && S_PARAM % 4 == 0 && S_LEAF2 % 4 == 0, "SGPR map");
 
 // exp(x), x <= 0 in practice: n = rint(x log2 e), r = x - n ln2 (two-part), exp(r) by a degree-11 polynomial
 // (Chebyshev-node interpolant of exp on |r| <= 0.3467, coefficients rounded to double: 1.6e-17 relative, computed with
@@ -172,7 +174,10 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   if (accumulate) E.ins("s_load_dwordx2 " + S2(S_WGT) + ", s[0:1], 0x48");
   const uint32_t n_k = prog.mc_n_k;               // > 0: Monte-Carlo kernel; input columns >= n_k come from the second base
   const bool mc = n_k > 0 || prog.mc_n_t > 0;
-  if (mc) E.ins("s_load_dwordx4 s[" + std::to_string(S_LEAF2) + ":" + std::to_string(S_LEAF2 + 3) + "], s[0:1], 0x50");
+  if (mc) {
+    E.ins("s_load_dwordx4 s[" + std::to_string(S_LEAF2) + ":" + std::to_string(S_LEAF2 + 3) + "], s[0:1], 0x50");
+    E.ins("s_load_dwordx8 s[" + std::to_string(S_PARAM) + ":" + std::to_string(S_PARAM + 7) + "], s[0:1], 0x60");
+  }
   E.ins("s_waitcnt lgkmcnt(0)");
   // accumulate mode: R per-lane accumulators, the lane's weight and one temporary live above the value registers
   uint64_t w_seq = 0;
@@ -231,7 +236,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     std::map<uint64_t, int> hist;
     auto count = [&](double f) { bool inl; f64_inline(f, inl); if (!inl) { uint64_t u; std::memcpy(&u, &f, 8); hist[u]++; } };
     for (const MOp &o : prog.ops) {
-      if (o.kind == M_MULC || o.kind == M_FMAC || o.kind == M_ADDC || o.kind == M_FIXZ || o.kind == M_SELC) count(o.imm);
+      if ((o.kind == M_MULC || o.kind == M_FMAC || o.kind == M_ADDC || o.kind == M_FIXZ || o.kind == M_SELC) && !o.param) count(o.imm);
       if (o.kind == M_EXP) { count(kLog2e); count(-kLn2Hi); count(-kLn2Lo); for (int k = 0; k <= kExpDeg; ++k) count(kExpC[k]); }
     }
     std::vector<std::pair<int, uint64_t>> v;
@@ -333,6 +338,9 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     return S_C;
   };
   auto vd = [&](uint32_t r, int h) { return "v" + std::to_string(V_BASE + RW * r + h); };   // one dword of a value register
+  // the constant of a micro-op: a kernel argument when tagged, else as above
+  auto op_const = [&](const MOp &o) -> std::string { return o.param ? S2(S_PARAM + 2 * (o.param - 1)) : const_operand(o.imm); };
+  auto op_const_sgpr = [&](const MOp &o) -> int { return o.param ? S_PARAM + 2 * (o.param - 1) : const_sgpr(o.imm); };
   // ---- body ------------------------------------------------------------------
   int64_t last_leaf = -1;
   // One s_waitcnt can serve several consumers: when an op has to wait for a load, the wait also covers what
@@ -427,14 +435,14 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       case M_MULC: {
         E.wait_reg(o.a);
         E.wait_reg(o.d);
-        const std::string c = const_operand(o.imm);
+        const std::string c = op_const(o);
         valu2("v_mul_f64 ", o, c, c);
         break;
       }
       case M_ADDC: {
         E.wait_reg(o.a);
         E.wait_reg(o.d);
-        const std::string c = const_operand(o.imm);
+        const std::string c = op_const(o);
         valu2("v_add_f64 ", o, c, c);
         break;
       }
@@ -484,7 +492,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       case M_FIXZ: {  // d = a == 0 ? imm : a
         E.wait_reg(o.a);
         E.wait_reg(o.d);
-        const int c = const_sgpr(o.imm);
+        const int c = op_const_sgpr(o);
         E.ins("v_cmp_eq_f64_e64 vcc, " + vlo(o.a) + ", 0");
         E.ins("v_mov_b32_e32 " + tAd(0) + ", " + S(c));
         E.ins("v_mov_b32_e32 " + tAd(1) + ", " + S(c + 1));
@@ -495,7 +503,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       case M_SELC: {  // d = cond(a) ? imm : -imm
         E.wait_reg(o.a);
         E.wait_reg(o.d);
-        const int c = const_sgpr(o.imm);
+        const int c = op_const_sgpr(o);
         E.ins(std::string(o.negb ? "v_cmp_ge_f64_e64" : "v_cmp_gt_f64_e64") + " vcc, " + (o.nega ? "-" : "") + vlo(o.a) + ", 0");
         E.ins("v_mov_b32_e32 " + vd(o.d, 0) + ", " + S(c));
         E.ins("v_mov_b32_e32 " + tAd(0) + ", " + S(c + 1));
@@ -509,7 +517,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         if (o.kind == M_FMA) E.wait_reg(o.b);
         E.wait_reg(o.c);
         E.wait_reg(o.d);
-        const std::string k = o.kind == M_FMAC ? const_operand(o.imm) : std::string();
+        const std::string k = o.kind == M_FMAC ? op_const(o) : std::string();
         for (int h = 0; h < W; ++h) {
           auto part = [&](uint32_t r) { return h ? vhi(r) : vlo(r); };
           E.ins("v_fma_f64 " + part(o.d) + ", " + (o.nega ? "-" : "") + part(o.a) + ", " +
@@ -614,7 +622,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const uint32_t n_agpr = RW * prog.n_acc_used;
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
   os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";
-  os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size " << (mc ? 96 : 80) << "\n\t\t.amdhsa_user_sgpr_count 2\n";
+  os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size " << (mc ? 128 : 80) << "\n\t\t.amdhsa_user_sgpr_count 2\n";
   os << "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1\n\t\t.amdhsa_system_sgpr_workgroup_id_x 1\n";
   os << "\t\t.amdhsa_system_vgpr_workitem_id 0\n";
   const int n_sgpr = (mc || has_macro) ? S_END : S_POOL + 2 * 16;   // programs without leaf formulas: the 16-entry pool ends the map
@@ -625,7 +633,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   os << "\t\t.amdhsa_dx10_clamp 1\n\t\t.amdhsa_ieee_mode 1\n";
   os << "\t.end_amdhsa_kernel\n";
   (void)p;
-  return KernelMeta{kname, lds_bytes, accum, n_agpr, mc ? 12 : 10, n_sgpr};
+  return KernelMeta{kname, lds_bytes, accum, n_agpr, mc ? 16 : 10, n_sgpr};
 }
 
 }  // namespace
@@ -642,8 +650,9 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   if (prog_acc) ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc", 1, true));
   std::ostringstream &os = E.os;
   os << "\t.text\n\t.amdgpu_metadata\n---\namdhsa.kernels:\n";
-  const char *kinds[12] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",
-                           "global_buffer", "by_value", "by_value", "global_buffer", "global_buffer", "by_value"};
+  const char *kinds[16] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",
+                           "global_buffer", "by_value", "by_value", "global_buffer", "global_buffer", "by_value",
+                           "by_value", "by_value", "by_value", "by_value"};
   for (const KernelMeta &k : ks) {
     os << "  - .agpr_count: " << k.n_agpr << "\n    .args:\n";
     for (int i = 0; i < k.n_args; ++i) {

@@ -400,8 +400,7 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
       bool recommended = false;
       if (fdg_mc_isa_supported(g, tab, why, &recommended) && (recommended || env_isa)) {
         g->mc_route = 3; g->fused_code.clear();
-        // parameters known already (the tables carry them): assemble now rather than at the first call
-        if (tab->beta != 0.0) { const int rb = fdg_mc_isa_build(g, tab->kF, tab->beta, tab->lambda); if (rb) return rb; }
+        { const int rb = fdg_mc_isa_build(g); if (rb) return rb; }      // assembled here, host-only; parameters are kernel arguments
         return FDG_OK;
       }
       if (env_isa) { set_error("fused ISA step does not cover this graph / these leaves: " + why); return FDG_E_UNSUPPORTED; }

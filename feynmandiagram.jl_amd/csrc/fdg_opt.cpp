@@ -25,6 +25,7 @@ struct UOp {      // micro-op over virtual values; refs are (vid << 1) | neg
   uint32_t a, b;  // operand refs (b unused for MULC / ROOT)
   double imm;
   uint32_t c = 0; // addend ref of M_FMA / M_FMAC
+  uint8_t param = 0;   // MOp::param
 };
 
 struct Builder {
@@ -119,19 +120,21 @@ struct Builder {
   // ---- leaf formulas (Monte-Carlo program) ---------------------------------------------------------------
   // Any other op kind, computed once per distinct operand tuple (these values are few and costly: no window).
   std::map<std::array<uint64_t, 3>, uint32_t> vn_x;
-  uint32_t opx(uint8_t k, uint32_t a, uint32_t b, uint32_t c, double imm) {
+  uint32_t opx(uint8_t k, uint32_t a, uint32_t b, uint32_t c, double imm, uint8_t param = 0) {
     uint64_t ib; std::memcpy(&ib, &imm, 8);
+    if (param) ib = 0x7ff8000000000000ull | param;      // a parameter is identified by its tag, not by its present value
     const std::array<uint64_t, 3> key = {((uint64_t)k << 32) | a, ((uint64_t)b << 32) | c, ib};
     auto it = vn_x.find(key);
     if (it != vn_x.end()) { touch(it->second); return it->second; }
     touch(a); if (mop_has_b(k)) touch(b); if (mop_has_c(k)) touch(c);
     const uint32_t d = fresh();
-    UOp o{k, d, a, b, imm}; o.c = c;
+    UOp o{k, d, a, b, imm}; o.c = c; o.param = param;
     u.push_back(o);
     vn_x[key] = d << 1;
     return d << 1;
   }
-  uint32_t addc(uint32_t a, double f) { return opx(M_ADDC, a, 0, 0, f); }
+  uint32_t addc(uint32_t a, double f, uint8_t param = 0) { return opx(M_ADDC, a, 0, 0, f, param); }
+  uint32_t mulp(uint32_t a, double f, uint8_t param) { return opx(M_MULC, a & ~1u, 0, 0, f, param) | (a & 1u); }   // times a parameter
   uint32_t rcp(uint32_t a) { return opx(M_RCP, a & ~1u, 0, 0, 0.0) | (a & 1u); }          // 1/(-x) == -(1/x)
   // cond(c) ? a : b, cond = c > 0 (ge false) or c >= 0
   uint32_t sel(uint32_t c, uint32_t a, uint32_t b, bool ge) {
@@ -173,8 +176,8 @@ struct Builder {
   Mom &fermi(int32_t li) {
     Mom &m = momentum(li);
     if (m.w != NONE || !ok) return m;
-    m.w = addc(m.q2, -(mc->kF * mc->kF));
-    const uint32_t wb = mulc(m.w, mc->beta);
+    m.w = addc(m.q2, -(mc->kF * mc->kF), MC_P_NEG_KF2);
+    const uint32_t wb = mulp(m.w, mc->beta, MC_P_BETA);
     const uint32_t e = opx(M_EXP, sel(m.w, wb ^ 1u, wb, false), 0, 0, 0.0);
     m.g = rcp(addc(e, 1.0));
     return m;
@@ -184,8 +187,8 @@ struct Builder {
     if (t.tf != NONE) return t;
     const uint32_t tau = add(in_t(tout), in_t(tin) ^ 1u);
     t.tf = opx(M_FIXZ, tau, 0, 0, -1e-10);                           // benchmark.jl:98 / green(): tau == 0 -> -1e-10
-    t.u = sel(t.tf, t.tf, addc(t.tf, mc->beta), false);             // w >= 0 branch: a = -(tau > 0 ? tau : tau + beta)
-    t.v = sel(t.tf, addc(t.tf, -mc->beta), t.tf, false);            // w <  0 branch: a = -(tau > 0 ? tau - beta : tau)
+    t.u = sel(t.tf, t.tf, addc(t.tf, mc->beta, MC_P_BETA), false);             // w >= 0 branch: a = -(tau > 0 ? tau : tau + beta)
+    t.v = sel(t.tf, addc(t.tf, -mc->beta, MC_P_NEG_BETA), t.tf, false);            // w <  0 branch: a = -(tau > 0 ? tau - beta : tau)
     return t;
   }
   // value of table leaf i (the expressions of fdg_leaf.hip, every exponential with a non-positive argument)
@@ -196,10 +199,10 @@ struct Builder {
       if (n < 0 || n > 3) { ok = false; why = "interaction counter-term of order above 3"; return in_k(0); }
       Mom &m = momentum(li);
       if (!ok) return in_k(0);
-      const uint32_t s = addc(m.q2, mc->lambda);
+      const uint32_t s = addc(m.q2, mc->lambda, MC_P_LAMBDA);
       uint32_t v = mulc(s, 8.0 * 3.141592653589793);
       if (n) {
-        const uint32_t x = mulc(rcp(s), mc->lambda);
+        const uint32_t x = mulp(rcp(s), mc->lambda, MC_P_LAMBDA);
         v = mul(v, n == 1 ? x : (n == 2 ? mul(x, x) : mul(mul(x, x), x)));
       }
       return v;
@@ -225,7 +228,7 @@ struct Builder {
                                       {0, 1, -15, 50, -60, 24, 0}, {0, 1, -31, 180, -390, 360, -120}};
       static const double BC[6][6] = {{1, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0}, {1, 3, 3, 1, 0, 0}, {1, 4, 6, 4, 1, 0}, {1, 5, 10, 10, 5, 1}};
       static const double NF[6] = {1.0, -1.0, 0.5, -1.0 / 6.0, 1.0 / 24.0, -1.0 / 120.0};
-      if (m.bsel == NONE) m.bsel = opx(M_SELC, m.w, 1, 0, mc->beta);     // b = w >= 0 ? beta : -beta  (operand b = 1: the >= form)
+      if (m.bsel == NONE) m.bsel = opx(M_SELC, m.w, 1, 0, mc->beta, MC_P_BETA);     // b = w >= 0 ? beta : -beta  (operand b = 1: the >= form)
       uint32_t total = NONE;
       for (int k = 0; k <= n; ++k) {
         uint32_t q = mulc(m.g, QC[k][k + 1]);
@@ -448,6 +451,7 @@ void fuse_fma(std::vector<UOp> &u, uint32_t n_value) {
     f.a = m.a ^ (term & 1u);                        // -(x*y) == (-x)*y
     f.b = m.kind == M_MUL ? m.b : 0;
     f.imm = m.imm;
+    f.param = m.param;
     f.c = other;
     o = f;
   }
@@ -636,6 +640,7 @@ struct Alloc {
       else if (o.kind == M_ADDC || o.kind == M_EXP || o.kind == M_RCP || o.kind == M_FIXZ) out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), 0, rd, ra, 0, o.imm});
       else if (three) out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), (uint8_t)(two ? (o.b & 1) : 0), rd, ra, rb, o.imm, (uint8_t)(o.c & 1), rc});
       else out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), (uint8_t)(o.b & 1), rd, ra, rb, 0.0});
+      out.back().param = o.param;
       prog.n_valu++;
       if (uses[o.d].empty()) kill(o.d);   // cannot happen for reachable values; keeps the state sane
       (void)live;

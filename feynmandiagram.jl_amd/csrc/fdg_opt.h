@@ -52,7 +52,10 @@ struct MOp {
   double imm;
   uint8_t negc = 0;     // M_FMA / M_FMAC only
   uint32_t c = 0;
+  uint8_t param = 0;    // Monte-Carlo programs: imm is a physical parameter handed to the kernel as an argument (imm holds the value
+                        // the program was built with, for replay): 1 = -kF^2, 2 = beta, 3 = -beta, 4 = lambda
 };
+enum { MC_P_NEG_KF2 = 1, MC_P_BETA = 2, MC_P_NEG_BETA = 3, MC_P_LAMBDA = 4, MC_N_PARAM = 4 };
 
 struct OptParams {
   uint32_t n_reg = 120;     // fp64 registers available to values
@@ -82,7 +85,8 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out);
 // The Monte-Carlo step as ONE program: the kernel's inputs are the sample's momentum components and times
 // (input column c < n_k: K component c; n_k + i: time i+1), and every leaf of the graph is a value computed from
 // them by the formulas of example/benchmark.jl:58-127 (green / green_derive / the Yukawa interaction and its
-// counter-terms) at its first use.  kF, beta, lambda are constants of the program.
+// counter-terms) at its first use.  kF, beta, lambda enter through four tagged constants (MOp::param) that the
+// kernel takes as arguments; the values in LeafSpec only fill MOp::imm for host-side replay.
 struct LeafSpec {
   const fdg_leaf_tables *tab = nullptr;
   double kF = 0, beta = 0, lambda = 0;

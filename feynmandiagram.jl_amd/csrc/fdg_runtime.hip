@@ -758,7 +758,7 @@ int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop *
   if (!m) { set_error("out of memory"); return FDG_E_NOMEM; }
   for (size_t i = 0; i < prog.ops.size(); ++i) {
     const fdg::MOp &o = prog.ops[i];
-    m[i] = fdg_mop{o.kind, o.nega, o.negb, o.negc, o.d, o.a, o.b, o.imm, o.c, 0};
+    m[i] = fdg_mop{o.kind, o.nega, o.negb, o.negc, o.d, o.a, o.b, o.imm, o.c, o.param};
   }
   *ops = m; *n_ops = prog.ops.size();
   if (n_reg_used) *n_reg_used = prog.n_reg_used;
@@ -780,7 +780,7 @@ int fdg_graph_mc_program(const fdg_graph *g, const fdg_leaf_tables *tab, const f
   if (!m) { set_error("out of memory"); return FDG_E_NOMEM; }
   for (size_t i = 0; i < prog.ops.size(); ++i) {
     const fdg::MOp &o = prog.ops[i];
-    m[i] = fdg_mop{o.kind, o.nega, o.negb, o.negc, o.d, o.a, o.b, o.imm, o.c, 0};
+    m[i] = fdg_mop{o.kind, o.nega, o.negb, o.negc, o.d, o.a, o.b, o.imm, o.c, o.param};
   }
   *ops = m; *n_ops = prog.ops.size();
   if (n_reg_used) *n_reg_used = prog.n_reg_used;
@@ -1072,7 +1072,7 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
 // Monte-Carlo step as one kernel of the optimizing back end (route 3 of fdg_graph_specialize_fused): the
 // program of fdg::build_mc_program, whose inputs are the n_loop*dim momentum components and n_tau times of a
 // sample (168 bytes for the 4-loop self-energy) instead of its L leaf values (1240 bytes).  kF, beta, lambda
-// are constants of the code: the kernels are assembled at the first call and again when a call brings others.
+// reach the formulas as kernel arguments (-kF^2, beta, -beta, lambda in SGPR pairs): one code object per (graph, tables).
 // ---------------------------------------------------------------------------
 static fdg_leaf_tables handle_tables(const fdg_graph *g, double kF, double beta, double lambda) {
   fdg_leaf_tables tab;
@@ -1110,10 +1110,11 @@ static uint32_t isa_waves_per_cu(uint32_t vgpr, uint32_t lds_bytes) {
   return std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32));
 }
 
-int fdg_mc_isa_build(fdg_graph *g, double kF, double beta, double lambda) {
-  if (g->mc_built && g->mc_const[0] == kF && g->mc_const[1] == beta && g->mc_const[2] == lambda) return FDG_OK;
-  const fdg_leaf_tables tab = handle_tables(g, kF, beta, lambda);
-  fdg::LeafSpec ls; ls.tab = &tab; ls.kF = kF; ls.beta = beta; ls.lambda = lambda;
+int fdg_mc_isa_build(fdg_graph *g) {
+  if (g->mc_built) return FDG_OK;
+  // (the parameter values only fill the ops' imm fields; the kernel reads them from its arguments)
+  const fdg_leaf_tables tab = handle_tables(g, 1.0, 1.0, 1.0);
+  fdg::LeafSpec ls; ls.tab = &tab; ls.kF = 1.0; ls.beta = 1.0; ls.lambda = 1.0;
   fdg::OptParams q = mc_params(g);
   fdg::OptProgram pe, pa;
   fdg::build_mc_program(g->prog, ls, q, pe);
@@ -1163,7 +1164,6 @@ int fdg_mc_isa_build(fdg_graph *g, double kF, double beta, double lambda) {
     g->mc_vgpr[1] = ((6 + 2 * std::max<uint32_t>(pa.n_reg_used, 1) + 2 * (R + 2) + 4 + 3) & ~3u) + 2 * pa.n_acc_used;
     g->mc_lds[1] = pa.n_lds_used * 512u; g->mc_mem[1] = pa.n_mem_used;
   }
-  g->mc_const[0] = kF; g->mc_const[1] = beta; g->mc_const[2] = lambda;
   g->mc_built = true;
   return FDG_OK;
 }
@@ -1171,7 +1171,7 @@ int fdg_mc_isa_build(fdg_graph *g, double kF, double beta, double lambda) {
 int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_t kc, const double *d_T, int64_t ts, int64_t tc,
                    double kF, double beta, double lambda, double *d_root, int64_t rs, int64_t rk, const double *d_weight,
                    double *d_acc, int64_t B, hipStream_t st) {
-  int rc = fdg_mc_isa_build(g, kF, beta, lambda);
+  int rc = fdg_mc_isa_build(g);
   if (rc) return rc;
   if (!g->mc_module) {
     hipModule_t m; hipFunction_t f;
@@ -1249,10 +1249,11 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
     }
     void *a_wsp = g->d_ws;
     long nwg = std::min<long>((n + 63) / 64, grid), zero = 0;
+    double p_nkf2 = -(kF * kF), p_beta = beta, p_nbeta = -beta, p_lambda = lambda;     // MOp::param 1..4
     if (use_acc) {
       double *part = (double *)((char *)g->d_ws + panel);
       const double *wt = d_weight ? d_weight + c0 : nullptr;
-      void *args[] = {(void *)&x, &xss, &xls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt, (void *)&x2, &xls2};
+      void *args[] = {(void *)&x, &xss, &xls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt, (void *)&x2, &xls2, &p_nkf2, &p_beta, &p_nbeta, &p_lambda};
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_mc_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
       hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
       HIP_TRY(hipGetLastError());
@@ -1260,7 +1261,7 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
       double *rt = d_root + c0 * rs;
       long a_rs = (long)rs, a_rk = (long)rk;
       const double *nowt = nullptr;
-      void *args[] = {(void *)&x, &xss, &xls, (void *)&rt, &a_rs, &a_rk, &a_wsp, &n, &nwg, (void *)&nowt, (void *)&x2, &xls2};
+      void *args[] = {(void *)&x, &xss, &xls, (void *)&rt, &a_rs, &a_rk, &a_wsp, &n, &nwg, (void *)&nowt, (void *)&x2, &xls2, &p_nkf2, &p_beta, &p_nbeta, &p_lambda};
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_mc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
     }
   }

@@ -258,8 +258,7 @@ end
 On a handle compiled with the optimizing back end (`compile(...; backend=:isa)`) that kernel is the back end's own: the
 leaves are values of its program, computed in registers from the momenta and times.  It reads `d_K` (`B × n_loop*dim`)
 and `d_T` (`B × n_tau`) in place when they are Julia column-major matrices -- the default `k_strides = t_strides = (1, B)`.
-`kF`, `beta`, `lambda` are constants of its code (assembled at the first call, again when they change), or pass them
-here to have it assembled now.
+`kF`, `beta`, `lambda` are arguments of that kernel: one code object, assembled here, serves every parameter set.
 """
 function specialize_fused!(f::GraphFunc, leafType::Vector{Int}, leafOrder::Vector{Int}, leafInTau::Vector{Int}, leafOutTau::Vector{Int},
     leafLoopIndex::Vector{Int}, loopbasis::Matrix{Float64}; dim::Int=3, n_tau::Int, cache_dir::String=get(ENV, "FDG_CACHE_DIR", "/tmp/fdg-cache"),

@@ -165,7 +165,9 @@ typedef struct fdg_mop {
   uint8_t kind, nega, negb, negc;
   uint32_t d, a, b;
   double imm;
-  uint32_t c, pad;     /* third source of kinds 14 FMA r[d]=(+-r[a])*(+-r[b])+(+-r[c]) and 15 FMAC r[d]=(+-r[a])*imm+(+-r[c]),
+  uint32_t c, param;   /* param (programs of fdg_graph_mc_program): 0, or imm is a physical parameter the kernel takes as an argument
+                        * -- 1: -kF^2, 2: beta, 3: -beta, 4: lambda -- and holds the value the program was built with;
+                        * c: third source of kinds 14 FMA r[d]=(+-r[a])*(+-r[b])+(+-r[c]) and 15 FMAC r[d]=(+-r[a])*imm+(+-r[c]),
                         * which only FDG_SPEC_FAST_MATH programs contain */
 } fdg_mop;
 
@@ -260,10 +262,10 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
 /* The third route, taken for large graphs on a handle specialised with FDG_SPEC_ISA: ONE kernel of the optimizing
  * back end whose inputs are the sample's n_loop*dim momentum components and n_tau times; every leaf is a value
  * computed in registers from them at its first use (ops 16..21 of fdg_mop: add-constant, exp, reciprocal, selects),
- * scheduled and register-allocated together with the graph.  kF, beta, lambda are constants of that kernel's code: it is
- * assembled at the first fdg_mc_*_device call and again when a call brings other values (about a second).  K and T
- * are read in place when they are ONE component-major matrix (sample stride 1, T right behind K, one column stride);
- * otherwise they are packed into such a matrix first.  Leaves agree with fdg_leaf_eval_device within its stated
+ * scheduled and register-allocated together with the graph.  kF, beta, lambda are arguments of that kernel (four scalar
+ * registers: -kF^2, beta, -beta, lambda), so one code object per (graph, tables) serves every parameter set.  K and T
+ * are read in place when both are component-major (sample stride 1; any two column strides); sample-major input is
+ * packed into such arrays first.  Leaves agree with fdg_leaf_eval_device within its stated
  * tolerance (own exp: range reduction + degree-11 polynomial), not bit for bit.  FDG_MC_ROUTE=isa|split overrides.
  * fdg_graph_mc_program returns that program for inspection / host-side replay (tab->kF, beta, lambda are used). */
 int fdg_graph_mc_program(const fdg_graph *g, const fdg_leaf_tables *tab, const fdg_opt_params *prm, fdg_mop **ops, uint64_t *n_ops,

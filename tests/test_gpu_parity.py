@@ -619,7 +619,7 @@ def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch):
     5-loop graphs and to 1e-10 on the Taylor expansion, whose cancellations amplify a last-bit difference of a leaf (the
     leaf-kernel route is 2e-12 off on the same samples).  Eval and accumulate; K and T as one matrix (read in place),
     as separate component-major arrays and sample-major (packed first); a ragged last tile; and again after the
-    physical parameters change (the kernel is re-assembled)."""
+    physical parameters change (they are kernel arguments: the same code object)."""
     import torch
     from feynmandiagram_jl_amd.nodetable import NodeTable
     for name, z in (("gv_sigma4", dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))), ("gv_sigma4_taylor2", _taylor2_tables()),

@@ -275,10 +275,10 @@ def test_fused_step_specializes_without_device(libfdg, tmp_path):
 
 
 def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypatch):
-    """Route 3 of fdg_graph_specialize_fused (handle specialised with FDG_SPEC_ISA): with kF, beta, lambda in the
-    tables the kernels -- eval and accumulate -- are assembled right away, host-only; the assembly carries the exp /
-    reciprocal sequences (v_rndne_f64, v_ldexp_f64, v_rcp_f64 followed by the wait state gfx950 needs) and loads only
-    the n_loop*dim + n_tau input columns."""
+    """Route 3 of fdg_graph_specialize_fused (handle specialised with FDG_SPEC_ISA): the kernels -- eval and accumulate --
+    are assembled right away, host-only, and do not depend on kF, beta, lambda (kernel arguments); the assembly carries
+    the exp / reciprocal sequences (v_rndne_f64, v_ldexp_f64, v_rcp_f64 followed by the wait state gfx950 needs) and
+    loads only the n_loop*dim + n_tau input columns."""
     import numpy as np
     import re
     import feynmandiagram_jl_amd as fd
@@ -292,6 +292,10 @@ def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypa
     f.handle.specialize_fused(tab, str(tmp_path), capi.FDG_SPEC_KEEP_SOURCE)
     asm = [x for x in os.listdir(tmp_path) if x.startswith("fdg_isa_") and x.endswith(".s")]
     assert len(asm) == 1 and os.path.exists(os.path.join(tmp_path, asm[0][:-2] + ".hsaco"))
+    tab_b, keep_b = capi.make_leaf_tables(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]),
+                                          1.0, 40.0, 0.3)
+    fd.compile_table(t, specialize="isa").handle.specialize_fused(tab_b, str(tmp_path), capi.FDG_SPEC_KEEP_SOURCE)
+    assert [x for x in os.listdir(tmp_path) if x.startswith("fdg_isa_") and x.endswith(".s")] == asm      # other parameters, same code object
     src = open(os.path.join(tmp_path, asm[0])).read()
     assert "fdg_isa_mc:" in src and "fdg_isa_mc_acc:" in src
     body = src.split("fdg_isa_mc_acc:")[0]
