@@ -156,6 +156,17 @@ def test_random_mc_program_replays(libfdg, seed):
     want = oracle.eval_static(t, leaves)
     live = t.root_slot != FDG_NO_ROOT
     assert same(got[:, live], want[:, live]), (seed, budget)
+    # kF, beta, lambda reach the kernel as arguments: the ops that use them are tagged (param 1..4 = -kF^2, beta, -beta,
+    # lambda) -- substituting other values there gives the program of the other parameter set
+    kF2, beta2, lam2 = 0.8, 1.7 * beta, 0.4
+    T2 = T * (beta2 / beta)
+    ops, nr, nl, nm = capi.GraphHandle(leaves_table(t.n_leaf)).mc_program(tab, **budget)
+    assert set(np.unique(ops["param"])) <= {0, 1, 2, 3, 4}
+    ops2 = ops.copy()
+    for tag, val in ((1, -(kF2 * kF2)), (2, beta2), (3, -beta2), (4, lam2)):
+        ops2["imm"][ops["param"] == tag] = val
+    leaves2 = replay_mc(ops2, nr, nl, nm, budget["n_acc"], np.concatenate([K.reshape(B, -1), T2], axis=1), t.n_leaf)
+    check_leaves(z, leaves2, K, T2, kF2, beta2, lam2)
 
 
 @pytest.mark.gpu
