@@ -233,17 +233,11 @@ def mc_step(t, workload, B, dev, fast_math):
     import torch
     import feynmandiagram_jl_amd as fd
     from feynmandiagram_jl_amd import capi
-    gold = os.path.join(ROOT, "tests", "golden")
-    base = {"gv_sigma4": "gv_sigma4", "gv_sigma4_taylor2": "gv_sigma4", "gv_sigma5": "gv_sigma5", "gv_sigma5_taylor2": "gv_sigma5"}.get(workload)
-    if base is None:
-        return None
+    from feynmandiagram_jl_amd import workloads
     try:
-        z = dict(np.load(os.path.join(gold, base + "_leafstates.npz")))
-        if workload.endswith("_taylor2"):   # leaves of the Taylor-expanded graph = (leaf of the original graph, order in the coupling)
-            zt = np.load(os.path.join(gold, workload + ".npz"))
-            for k in ("leaf_type", "tau_in", "tau_out", "loop_index"):
-                z[k] = z[k][zt["leaf_base"]]
-            z["leaf_order"] = np.where(z["leaf_type"] == 2, zt["leaf_dorder"], 0).astype(np.int32)
+        z = workloads.leafstates(workload)
+        if z is None:
+            return None
         dim, n_loop, n_tau = 3, int(z["basis"].shape[1]), int(z["n_tau"])
         kF, beta, lam = 1.919, 3.0, 1.2
         dK = torch.rand((n_loop * dim, B), dtype=torch.float64, device=dev) * 4 - 2        # component-major, like a Julia B x n matrix

@@ -52,6 +52,28 @@ def get(name: str) -> NodeTable:
     raise KeyError(name)
 
 
+PREBUILT_MC = ("gv_sigma4", "gv_sigma4_taylor2", "gv_sigma5")     # one-kernel Monte-Carlo step assembled by build()
+
+
+def leafstates(name: str):
+    """The ``FrontEnds.leafstates`` tables of a GV workload, in leafVal order (``leaf_type``, ``leaf_order``, ``tau_in``,
+    ``tau_out``, ``loop_index``, ``basis``, ``n_tau``), or None.  For the Taylor-expanded graphs a leaf is (leaf of the
+    original graph, derivative order in the coupling): the fixture of the original graph re-indexed."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    base = name[:-len("_taylor2")] if name.endswith("_taylor2") else name
+    path = os.path.join(gold, base + "_leafstates.npz")
+    if not os.path.exists(path):
+        return None
+    z = dict(np.load(path))
+    if name.endswith("_taylor2"):
+        zt = np.load(os.path.join(gold, name + ".npz"))
+        for k in ("leaf_type", "tau_in", "tau_out", "loop_index"):
+            z[k] = z[k][zt["leaf_base"]]
+        z["leaf_order"] = np.where(z["leaf_type"] == 2, zt["leaf_dorder"], 0).astype(np.int32)
+    return z
+
+
 def _with_powers(t: NodeTable, frac: float, seed: int) -> NodeTable:
     """Turn a fraction of two-child Prod nodes with equal children ... into
     Power{2}: here simply re-type random single-use Prod nodes as Power{2} of
