@@ -216,8 +216,9 @@ struct Builder {
     const uint32_t A = opx(M_EXP, mul(m.w, a), 0, 0, 0.0);
     if (const char *dbg = std::getenv("FDG_MC_DEBUG_STAGE")) {   // development only: a leaf's intermediate instead of its value
       const std::string st = dbg;
-      if (st == "w") return m.w; if (st == "g") return m.g; if (st == "tau") return tp.tf; if (st == "a") return a; if (st == "A") return A;
-      if (st == "wa") return mul(m.w, a); if (st == "u") return tp.u; if (st == "v") return tp.v;
+      const std::pair<const char *, uint32_t> stages[] = {{"w", m.w}, {"g", m.g}, {"tau", tp.tf}, {"a", a}, {"A", A}, {"u", tp.u}, {"v", tp.v}};
+      for (const auto &kv : stages) if (st == kv.first) return kv.second;
+      if (st == "wa") return mul(m.w, a);
     }
     uint32_t x;
     if (n == 0) {
