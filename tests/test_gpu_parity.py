@@ -600,6 +600,49 @@ def test_mc_step_with_high_interaction_orders(libfdg, cuda):
         assert torch.equal(root, want), spec
 
 
+def test_entry_points_are_graph_capturable(libfdg, cuda):
+    """After a warm-up call the device entry points only launch kernels on the caller's stream (no allocation, no
+    synchronisation): a loop of them can be captured into a hipGraph (torch.cuda.CUDAGraph) and replayed with the bits of
+    the eager loop -- evaluator, fused accumulation and the one-kernel Monte-Carlo step."""
+    import torch
+    t, z = workloads.get("gv_sigma4"), workloads.leafstates("gv_sigma4")
+    L, R, B, dim, n_loop, n_tau = t.n_leaf, t.n_root, 4_099, 3, int(z["basis"].shape[1]), int(z["n_tau"])
+    f = fd.compile_table(t, specialize="isa")
+    tab, _keep = capi.make_leaf_tables(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
+    f.handle.specialize_fused(tab)
+    leaf = dev_leaves(cuda, B, L, 5, 0, "leaf_major")
+    K = torch.rand((n_loop * dim, B), dtype=torch.float64, device=cuda) * 4 - 2
+    T = torch.rand((n_tau, B), dtype=torch.float64, device=cuda) * 3.0
+    w = torch.rand(B, dtype=torch.float64, device=cuda)
+    root = torch.zeros((R, B), dtype=torch.float64, device=cuda).t()
+    acc = torch.zeros(R, dtype=torch.float64, device=cuda)
+    acc2 = torch.zeros(R, dtype=torch.float64, device=cuda)
+
+    def loop():
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            f.handle.eval_device(leaf.data_ptr(), leaf.stride(0), leaf.stride(1), root.data_ptr(), root.stride(0), root.stride(1), B, st)
+            f.handle.accumulate_device(leaf.data_ptr(), leaf.stride(0), leaf.stride(1), w.data_ptr(), acc.data_ptr(), B, st)
+            f.handle.mc_accumulate_device(K.data_ptr(), 1, B, T.data_ptr(), 1, B, 1.919, 3.0, 1.2, w.data_ptr(), acc2.data_ptr(), B, st)
+
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        loop()                                       # warm-up: modules loaded, workspaces allocated
+        torch.cuda.synchronize()
+        acc.zero_(); acc2.zero_(); root.zero_()
+        loop()
+        torch.cuda.synchronize()
+        eager = (root.clone(), acc.clone(), acc2.clone())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            loop()
+        acc.zero_(); acc2.zero_(); root.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(root, eager[0]) and torch.equal(acc, eager[1]) and torch.equal(acc2, eager[2])
+    assert np.array_equal(root.cpu().numpy(), oracle.eval_static(t, leaf.cpu().numpy()))
+
+
 def _taylor2_tables():
     z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
     zt = np.load(os.path.join(GOLD, "gv_sigma4_taylor2.npz"))
