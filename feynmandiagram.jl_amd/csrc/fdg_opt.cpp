@@ -71,6 +71,21 @@ struct Builder {
   }
   void touch(uint32_t ref) { if (vn_touch) { const uint32_t v = ref >> 1; if (v < born.size()) born[v] = (uint32_t)u.size(); } }
   uint32_t fresh() { born.resize(next_vid + 1, 0); born[next_vid] = (uint32_t)u.size(); return next_vid++; }
+  // Rematerialisation: the value of a cheap node (own fold of at most remat_cost steps) that has not been read for
+  // remat_window ops is forgotten; its next consumer computes it again (the same IEEE operations on the same operands:
+  // the same bits).  A widely shared value whose uses are thousands of ops apart would otherwise sit in a spill slot and
+  // come back through the HBM panel for every use; its operands -- lower-order sub-diagrams that many nodes keep reading --
+  // usually are still on chip.  Roots are exempt.
+  uint64_t remat_window = 0;
+  uint32_t remat_cost = 8;
+  std::vector<uint8_t> remat_ok;   // [N]
+  uint64_t n_remat = 0;
+  bool available(uint32_t c) const {
+    if (ref_of[c] == NONE) return false;
+    if (!remat_window || c < p.L || !remat_ok[c - p.L]) return true;
+    const uint32_t v = ref_of[c] >> 1;
+    return v >= born.size() || (uint64_t)u.size() - born[v] <= remat_window;
+  }
   uint32_t op2(uint8_t k, uint32_t a, uint32_t b) {
     if (!value_numbering) { uint32_t d = fresh(); u.push_back(UOp{k, d, a, b, 0.0}); return d << 1; }
     if (k == M_MUL) {
@@ -318,6 +333,7 @@ void build_uops(Builder &B) {
     const uint32_t cr = B.ref_of[c];
     const double fc = p.fac[a + f.i];
     uint32_t acc = f.acc;
+    B.touch(cr);
     if (p.op[n] == FDG_OP_SUM) {
       const uint32_t t = B.mulc(cr, fc);                       // c_i * f_i   (static.jl:18)
       acc = (f.i == 0) ? t : B.op2(M_ADD, acc, t);
@@ -338,6 +354,35 @@ void build_uops(Builder &B) {
     emit_roots(L + n);
     return true;
   };
+
+  // plain depth-first evaluation of one node; also how a forgotten value is computed again (see Builder::available)
+  auto dfs = [&](uint32_t top) {
+    const size_t base = st.size();
+    st.push_back(Frame{top, 0, NONE});
+    while (st.size() > base) {
+      Frame &f = st.back();
+      const uint32_t c = p.idx[p.off[f.n] + f.i];
+      B.need(c);
+      if (!B.available(c)) {
+        if (B.ref_of[c] != NONE) B.n_remat++;
+        st.push_back(Frame{c - L, 0, NONE});
+        continue;
+      }
+      if (step(st.back())) st.pop_back();
+    }
+  };
+  if (B.remat_window) {
+    B.remat_ok.assign(p.N, 0);
+    const char *ce = std::getenv("FDG_REMAT_COST");
+    const uint32_t max_cost = ce ? (uint32_t)std::atoi(ce) : B.remat_cost;
+    for (uint32_t n = 0; n < p.N; ++n) {
+      uint32_t cost = p.off[n + 1] - p.off[n] - 1;
+      for (uint32_t e = p.off[n]; e < p.off[n + 1]; ++e) if (p.fac[e] != 1.0 && p.fac[e] != -1.0) cost++;
+      if (p.op[n] == FDG_OP_POWER) cost += 2;
+      B.remat_ok[n] = cost <= max_cost;
+    }
+    for (auto &rk : rootlist) if (rk.first >= L) B.remat_ok[rk.first - L] = 0;
+  }
 
   if (p.sched_group.size() == p.N) {
     // Grouped lock-step schedule.  The producer may tag nodes that belong together (the Taylor
@@ -391,6 +436,11 @@ void build_uops(Builder &B) {
             push_group(cn, true);
             continue;
           }
+          if (!B.available(c)) {         // forgotten: computed again on its own, then this member goes on
+            B.n_remat++;
+            dfs(c - L);
+            continue;
+          }
           step(f);
           g.cur++;
         }
@@ -401,16 +451,7 @@ void build_uops(Builder &B) {
 
   for (uint32_t top : tops) {
     if (B.ref_of[L + top] != NONE) continue;
-    st.push_back(Frame{top, 0, NONE});
-    while (!st.empty()) {
-      Frame &f = st.back();
-      const uint32_t n = f.n, a = p.off[n], k = p.off[n + 1] - a;
-      (void)k;
-      const uint32_t c = p.idx[a + f.i];
-      B.need(c);
-      if (B.ref_of[c] == NONE) { st.push_back(Frame{c - L, 0, NONE}); continue; }
-      if (step(st.back())) st.pop_back();
-    }
+    dfs(top);
   }
 }
 
@@ -728,6 +769,7 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   B0.value_numbering = prm.vn_window != 1;     // 1 = off, 0 = unlimited, else window in ops
   B0.vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
   B0.vn_touch = std::getenv("FDG_VN_BIRTH_WINDOW") == nullptr;   // default: the window counts from the last read
+  if (const char *rw = std::getenv("FDG_REMAT_WINDOW")) B0.remat_window = (uint64_t)std::atoll(rw);
   build_uops(B0);
   Lowered plain;
   const bool retry = !B0.ok && B0.why == "inconsistent schedule groups";

@@ -1,0 +1,47 @@
+"""GPU dev tool: time one workload's ISA kernel under several environment settings (FDG_* knobs of the back end),
+checking each against the oracle first.  python tools/gpu_env_sweep.py WORKLOAD "A=1,B=2" "A=3" ...   ("-" = no setting)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import oracle
+import feynmandiagram_jl_amd as fd
+from feynmandiagram_jl_amd import workloads, capi
+dev = torch.device("cuda:0")
+name = sys.argv[1]
+t = workloads.get(name)
+st = t.stats()
+L, R = t.n_leaf, t.n_root
+B = int(os.environ.get("SWEEP_B", max(1 << 14, min(4_000_000, int(2.4e9 / (8 * L))))))
+leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
+capi.fill_uniform_device(leaf.data_ptr(), B, L, leaf.stride(0), leaf.stride(1), 11, 0, torch.cuda.current_stream().cuda_stream)
+root = torch.empty((R, B), dtype=torch.float64, device=dev).t()
+nchk = 4099
+want = oracle.eval_static(t, leaf[:nchk].cpu().numpy(), np.zeros((nchk, R)))
+for setting in sys.argv[2:]:
+    kv = {} if setting == "-" else dict(x.split("=") for x in setting.split(","))
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update(kv)
+    try:
+        t0 = time.time()
+        f = fd.compile_table(t, specialize="isa", cache_dir="/tmp/fdg-sweep-cache")
+        tc = time.time() - t0
+        root.zero_()
+        f(root, leaf); torch.cuda.synchronize()
+        ok = np.array_equal(root[:nchk].cpu().numpy(), want)
+        for _ in range(3): f(root, leaf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = int(os.environ.get("SWEEP_N", 10))
+        e0.record()
+        for _ in range(n): f(root, leaf)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        i = f.info()
+        print(f"{name} [{setting}] {'exact' if ok else 'MISMATCH'} B={B} {ms:.3f} ms {B / ms * 1e3:.3e} evals/s  alg {B / ms * 1e3 * st['bytes_alg'] / 1e9:.0f} GB/s "
+              f"vgpr={i['spec_vgpr']} lds={i['spec_lds_bytes']} compile {tc:.1f}s", flush=True)
+        del f
+    except Exception as e:
+        print(f"{name} [{setting}] FAILED: {e}", flush=True)
+    for k, v in old.items():
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
