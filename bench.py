@@ -23,6 +23,193 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6    # AMD spec, FMA counted as 2 (not in the local guide)
 
 
+WORKLOAD_NOTES = {
+    "sigma2": " (config 2: optimized 2-loop Parquet self-energy, transcribed from the reference's own rendering assets/sigma_o2.svg)",
+    "sigma4_standin": " (config 3 stand-in (ii): seeded parquet-recursion synthetic graph with SURVEY 8d's sizes, ~10^4 nodes; the real graph needs the Julia front end)",
+    "gv_sigma4": " (the 4-loop self-energy in the reference's GV form, catalog Sigma4_0_0.diag through the restated reader + optimize!)",
+    "gv_sigma4_taylor2": " (config 4: 4-loop self-energy with Taylor-mode AD counterterms of order 2 in the coupling: reference GV catalog Sigma4_0_0.diag through the restated reader, taylorAD and optimize!; 7373 nodes; the 4-loop Parquet graph itself needs the Julia front end)",
+    "gv_sigma5": " (config 3 stand-in (i) / config 5: reference GV catalog Sigma5_0_0.diag through the restated reader + optimize!)",
+    "gv_sigma6": " (config 3 stand-in (i): reference GV catalog Sigma6_0_0.diag through the restated reader + optimize!)",
+}
+DEFAULT_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcase": 1_000_000, "synthetic_small": 8_000_000,
+             "gv_sigma4": 8_000_000, "gv_sigma5": 2_000_000, "gv_sigma6": 500_000, "gv_sigma4_taylor2": 4_000_000,
+             "gv_sigma5_taylor2": 1_000_000}
+PARITY_NOTE = ("bit-exact vs our restatement of the Julia evaluator (oracle/); the reference's known-answer tests pin structure, "
+               "leaf numbering and factors, not the rounding of the n-ary folds")
+
+
+class Case:
+    """One workload resident on the device: handle, leaf batch (synthetic, Philox keyed by the global sample index), root buffer."""
+
+    def __init__(self, workload, layout, B, dev, backend="isa", flags=0, sample_offset=0):
+        import torch
+        import feynmandiagram_jl_amd as fd
+        from feynmandiagram_jl_amd import capi, workloads
+        self.workload, self.layout, self.B, self.dev = workload, layout, B, dev
+        self.t = t = workloads.get(workload)
+        self.st = t.stats()
+        L, R = t.n_leaf, t.n_root
+        self.f = fd.compile_table(t, specialize={"isa": "isa", "isa-autotune": "isa-autotune", "auto": "auto", "hip": True, "interp": False}[backend], flags=flags)
+        if layout == "sample_major":          # compile_Python's row-major [B, L] / [B, R]
+            self.leaf = torch.empty((B, L), dtype=torch.float64, device=dev)
+            self.root = torch.empty((B, R), dtype=torch.float64, device=dev)
+        else:                                 # Julia column-major B x L / B x R matrices
+            self.leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
+            self.root = torch.empty((R, B), dtype=torch.float64, device=dev).t()
+        self.stream = torch.cuda.current_stream()
+        capi.fill_uniform_device(self.leaf.data_ptr(), B, L, self.leaf.stride(0), self.leaf.stride(1), 1234, sample_offset, self.stream.cuda_stream)
+
+    def step(self):
+        self.f(self.root, self.leaf)
+
+    def timed(self, steps, warm):
+        """`warm` untimed launches, then `steps` launches bracketed by HIP events on the launch stream.  Returns ms per launch (list)."""
+        import torch
+        for _ in range(warm):
+            self.step()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        ev[0].record(self.stream)
+        for i in range(steps):
+            self.step()
+            ev[i + 1].record(self.stream)
+        torch.cuda.synchronize()
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+
+    def parity_sample(self, n=2048):
+        """The first n samples of the last launch against the oracle's restatement of the compiled evaluator (C, one thread)."""
+        import numpy as np
+        import oracle
+        n = int(min(n, self.B))
+        want = oracle.eval_static(self.t, np.ascontiguousarray(self.leaf[:n].cpu().numpy()), np.zeros((n, self.t.n_root)))
+        got = self.root[:n].cpu().numpy()
+        return bool(np.array_equal(got, want)), float(np.abs(got - want).max()) if n else 0.0, n
+
+
+def roofline_of(st, B, avg_kernel_s, kernel, accumulate=False):
+    bytes_per_eval = st["bytes_alg_accumulate"] if accumulate else st["bytes_alg"]
+    achieved = bytes_per_eval * B / avg_kernel_s / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_eval * B}
+
+
+def attach_traffic(roof, workload, layout, B, avg_kernel_s):
+    """HBM bytes per launch from the rocprofv3 --pmc passes of the same command (bench.py cannot collect counters on
+    itself): profiles/r02_traffic.json holds bytes per evaluation, scaled here to this batch -- a value from the named
+    profile, not a measurement of this run."""
+    for fn in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", fn))).get(workload)
+        except (OSError, ValueError):
+            continue
+        if tr and tr.get("layout", "leaf_major") == layout:
+            roof["traffic"] = tr["bytes_per_eval"] * B
+            roof["traffic_gbs"] = tr["bytes_per_eval"] * B / avg_kernel_s / 1e9
+            roof["traffic_frac"] = roof["traffic_gbs"] / HBM_PEAK_GBS
+            roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
+            roof["traffic_source"] = ("NOT measured in this run: (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes, profiles/" + fn +
+                                      " (" + tr.get("source", "") + "), per evaluation, scaled to this batch")
+            return
+
+
+def measured_copy(dev):
+    """The box's own streaming ceiling: a 2 GiB device-to-device copy by fdg_copy_device (16 bytes per lane), read + write counted."""
+    import torch
+    from feynmandiagram_jl_amd import capi
+    a = torch.empty(1 << 28, dtype=torch.float64, device=dev)
+    b = torch.empty_like(a)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        capi.copy_device(b.data_ptr(), a.data_ptr(), a.numel(), st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        capi.copy_device(b.data_ptr(), a.data_ptr(), a.numel(), st)
+    e1.record()
+    torch.cuda.synchronize()
+    return 10 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
+    """A workload outside the headline, measured in the same process: `warm` untimed + `steps` timed launches, its own
+    roofline fraction, and a bitwise check of a sample against the oracle."""
+    import torch
+    try:
+        c = Case(workload, layout, DEFAULT_B.get(workload, 1_000_000), dev)
+        ms = c.timed(steps, warm)
+        avg = sum(ms) / len(ms) / 1e3
+        ok, dev_max, n = c.parity_sample()
+        roof = roofline_of(c.st, c.B, avg, "fdg_isa_eval")
+        attach_traffic(roof, workload, layout, c.B, avg)
+        if copy_gbs:
+            roof["frac_of_measured_copy"] = roof["achieved"] / copy_gbs
+        info = c.f.info()
+        out = {"workload": workload + WORKLOAD_NOTES.get(workload, ""), "layout": layout, "value": c.B / avg, "unit": "evals/s",
+               "samples_per_launch": c.B, "timed_launches": steps, "warmup_launches": warm, "avg_kernel_ms": avg * 1e3,
+               "n_leaf": c.t.n_leaf, "n_node": c.t.n_node, "n_root": c.t.n_root, "flops_per_eval": c.st["flops_alg"], "bytes_per_eval": c.st["bytes_alg"],
+               "roofline": roof,
+               "valu_fp64_tflops": c.st["flops_alg"] * c.B / avg / 1e12,
+               "kernel_info": {k: info[k] for k in ("max_live", "spec_vgpr", "spec_lds_bytes")},
+               "gpu_matches_cpu_bitwise": ok, "max_abs_dev": dev_max, "parity_samples": n}
+        del c
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:                      # secondary: never takes the headline line down
+        return {"workload": workload, "layout": layout, "error": f"{type(e).__name__}: {e}"}
+
+
+def config5(dev, rank, world, dist, comm, steps, warm):
+    """BASELINE.json config 5 (example/benchmark_GV.jl as BASELINE.json words it: the GV 5th-order self-energy, samples
+    sharded over the GPUs, one final reduce): per step fdg_accumulate_device on this rank's shard -- weighted
+    accumulation inside the evaluator, roots never reach HBM --, after the last step ONE all-reduce of R doubles."""
+    import torch
+    from feynmandiagram_jl_amd.sharding import reduce_observable, shard_range
+    try:
+        B = DEFAULT_B["gv_sigma5"]
+        start, count = shard_range(B * world, rank, world)
+        c = Case("gv_sigma5", "leaf_major", count, dev, sample_offset=start)
+        w = torch.rand(count, dtype=torch.float64, device=dev)
+        acc = torch.zeros(c.t.n_root, dtype=torch.float64, device=dev)
+        for _ in range(warm):
+            c.f.accumulate(c.leaf, w, acc)
+        acc.zero_()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record(c.stream)
+        for i in range(steps):
+            c.f.accumulate(c.leaf, w, acc)
+            ev[i + 1].record(c.stream)
+        reduce_observable(acc, comm=comm)     # the one collective: R doubles over xGMI (RCCL)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+        avg = sum(ms) / len(ms) / 1e3
+        total = float(count) * steps * world
+        roof = roofline_of(c.st, count, avg, "fdg_isa_eval_acc + fdg_reduce_lane_partials", accumulate=True)
+        out = {"workload": "gv_sigma5" + WORKLOAD_NOTES["gv_sigma5"], "value": total / elapsed, "unit": "samples/s (whole job)", "n_gpus": world,
+               "steps": steps, "warmup": warm, "samples_per_step_per_gpu": count, "total_samples": total,
+               "samples_to_config5_total": "1e9 samples = %d steps of this size at this GPU count" % round(1e9 / (count * world)),
+               "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "roofline_rank0": roof,
+               "observable": [float(x) for x in acc.cpu()],
+               "what": "fdg_accumulate_device per step on the rank's shard; one all-reduce of R doubles after the last step, inside the timed region"}
+        del c, w
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:
+        return {"workload": "gv_sigma5", "error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     # The result line must be the only thing on stdout.  RCCL writes a version banner to the C-level stdout
     # (buffered, so it would land AFTER our line at exit); everything else this process or its libraries print
@@ -49,6 +236,7 @@ def main():
                          "(reported separately, never the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc-step", action="store_true", help="skip the secondary measurement of the whole Monte-Carlo step (leaves from momenta and times)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other workloads (config 2, 3 stand-ins, 5, row-major layout) measured after the headline")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
@@ -72,41 +260,22 @@ def main():
     dev = torch.device("cuda", local_rank)
     comm = make_comm(rank, world) if (dist and args.comm == "fdg") else None
 
-    t = workloads.get(args.workload)
-    st = t.stats()
-    L, R = t.n_leaf, t.n_root
+    if args.interp:
+        args.backend = "interp"
     # Samples resident per step.  Decimal sizes on purpose: BASELINE.json's sample counts are decimal (25 steps of the
     # default = config 3's 10^8 samples), and a leaf-major matrix whose column stride is a power of two aliases HBM
     # channels (measured: -3 % on the default workload, -14 % on sigma2).
-    default_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcase": 1_000_000, "synthetic_small": 8_000_000,
-                 "gv_sigma4": 8_000_000, "gv_sigma5": 2_000_000, "gv_sigma6": 500_000, "gv_sigma4_taylor2": 4_000_000,
-                 "gv_sigma5_taylor2": 1_000_000}.get(args.workload, 1_000_000)
-    B = args.samples or default_B
-    if args.interp:
-        args.backend = "interp"
-    f = fd.compile_table(t, specialize={"isa": "isa", "isa-autotune": "isa-autotune", "auto": "auto", "hip": True, "interp": False}[args.backend],
-                         flags=capi.FDG_SPEC_FAST_MATH if args.fast_math else 0)
-    if args.backend == "isa-autotune":
-        args.backend = "isa"
-
-    if args.layout == "sample_major":
-        leaf = torch.empty((B, L), dtype=torch.float64, device=dev)
-    else:
-        leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
-    if args.layout == "sample_major":
-        root = torch.empty((B, R), dtype=torch.float64, device=dev)          # compile_Python's row-major [B, R]
-    else:
-        # a Julia column-major B x R matrix, like the leaves: a wave's 64 values of one root are one 512-byte line-aligned
-        # store (row-major roots leave L2 as partial lines: 2.5x the bytes for R = 6; tools/gpu_root_layout.py)
-        root = torch.empty((R, B), dtype=torch.float64, device=dev).t()
-    stream = torch.cuda.current_stream()
+    B = args.samples or DEFAULT_B.get(args.workload, 1_000_000)
     # per-rank Philox offset: results do not depend on how samples are sharded
     start, count = shard_range(B * world, rank, world)          # weak scaling: B samples per GPU
     assert count == B
-    capi.fill_uniform_device(leaf.data_ptr(), B, L, leaf.stride(0), leaf.stride(1), 1234, start, stream.cuda_stream)
-
-    def step():
-        f(root, leaf)
+    case = Case(args.workload, args.layout, B, dev, backend=args.backend, flags=capi.FDG_SPEC_FAST_MATH if args.fast_math else 0,
+                sample_offset=start)
+    if args.backend == "isa-autotune":
+        args.backend = "isa"
+    t, st, f, leaf, root, stream = case.t, case.st, case.f, case.leaf, case.root, case.stream
+    L, R = t.n_leaf, t.n_root
+    step = case.step
 
     step()
     _ = root.sum(dim=0)                   # load the reduction used for the final observable now: a pause between the
@@ -158,66 +327,57 @@ def main():
         "vs_baseline": None,
         "dtype": "f64" if not args.fast_math else "f64 (fused multiply-add: within 1e-12, not bit-identical)",
         "data": "synthetic",
-        "config": {"workload": args.workload + {"sigma4_standin": " (seeded parquet-recursion stand-in for the 4-loop Parquet self-energy, ~10^4 nodes; the real graph needs the Julia front end)",
-                                                "gv_sigma4_taylor2": " (4-loop self-energy with Taylor-mode AD counterterms of order 2 in the coupling: reference GV catalog Sigma4_0_0.diag through the restated reader, taylorAD and optimize!; 7373 nodes; the 4-loop Parquet graph itself needs the Julia front end)",
-                                                "gv_sigma5": " (reference GV catalog Sigma5_0_0.diag through the restated reader + optimize!)",
-                                                "gv_sigma6": " (reference GV catalog Sigma6_0_0.diag through the restated reader + optimize!)"}.get(args.workload, ""),
+        "config": {"workload": args.workload + WORKLOAD_NOTES.get(args.workload, ""),
                    "graph": t.name, "n_leaf": L, "n_node": t.n_node, "n_edge": t.n_edge, "n_root": R,
                    "flops_per_eval": st["flops_alg"], "bytes_per_eval": st["bytes_alg"],
                    "samples_per_step_per_gpu": B, "layout": args.layout, "settle_steps": settle,
                    "kernel": {"isa": "fdg_isa_eval (per-graph gfx950 assembly)", "hip": "fdg_spec (per-graph HIP source, hiprtc)",
                               "auto": "fdg_isa_eval, or its HIP-source companion fdg_spec_sm for row-major input of small graphs",
                               "interp": "fdg_interp (table interpreter)"}[args.backend],
-                   "parallelism": f"samples sharded x{world}, one all-reduce of {R} doubles"},
+                   "parallelism": f"samples sharded x{world}, one all-reduce of {R} doubles",
+                   "parity": PARITY_NOTE},
     }
+    kname = {"isa": "fdg_isa_eval", "interp": "fdg_interp", "auto": "fdg_isa_eval / fdg_spec_sm",
+             "hip": "fdg_spec_sm" if args.layout == "sample_major" else "fdg_spec_gen"}[args.backend]
+    copy_gbs = None
     if rank == 0:
-        bytes_per_launch = st["bytes_alg"] * B
-        achieved = bytes_per_launch / avg_kernel_s / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                           "kernel": {"isa": "fdg_isa_eval", "interp": "fdg_interp", "auto": "fdg_isa_eval / fdg_spec_sm",
-                                      "hip": "fdg_spec_sm" if args.layout == "sample_major" else "fdg_spec_gen"}[args.backend],
-                           "avg_kernel_ms": avg_kernel_s * 1e3,
-                           "algorithmic_bytes_per_launch": bytes_per_launch}
-        # the box's own streaming ceiling next to the 8 TB/s spec: a 2 GiB device-to-device copy,
-        # read + write counted, outside the timed region
+        out["roofline"] = roofline_of(st, B, avg_kernel_s, kname)
+        achieved = out["roofline"]["achieved"]
         try:
-            a = torch.empty(1 << 28, dtype=torch.float64, device=dev)
-            b = torch.empty_like(a)
-            for _ in range(2):
-                b.copy_(a)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                b.copy_(a)
-            e1.record()
-            torch.cuda.synchronize()
-            copy_gbs = 5 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            copy_gbs = measured_copy(dev)
             out["roofline"]["measured_copy_gbs"] = copy_gbs
+            out["roofline"]["measured_copy_kernel"] = "fdg_copy_device (16 B per lane, 2 GiB, read + write counted)"
             out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
-            del a, b
         except RuntimeError:
             pass
-        # HBM traffic per launch: measured separately with rocprofv3 --pmc (bench.py cannot collect
-        # counters on itself); profiles/r01_traffic.json holds bytes per evaluation for the default configs
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(args.workload)
-            if tr and tr["layout"] == args.layout and args.backend == "isa":
-                out["roofline"]["traffic"] = tr["bytes_per_eval"] * B
-                # the same launch time against the bytes the PMC counters saw move (re-read leaves, partial-line root writes)
-                out["roofline"]["traffic_gbs"] = tr["bytes_per_eval"] * B / avg_kernel_s / 1e9
-                out["roofline"]["traffic_frac"] = out["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
-                out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " + tr.get("source", "profiles/") + " (per evaluation, scaled to this batch)"
-        except (OSError, ValueError):
-            pass
+        if args.backend == "isa":
+            attach_traffic(out["roofline"], args.workload, args.layout, B, avg_kernel_s)
         out["valu_fp64"] = {"achieved_tflops": st["flops_alg"] * B / avg_kernel_s / 1e12,
                             "peak_tflops_fma": FP64_VALU_PEAK_TFLOPS,
                             "note": "secondary ceiling: add/mul only (no FMA contraction allowed), so the usable peak is half"}
         out["kernel_info"] = {k: info[k] for k in ("max_live", "spec_vgpr", "spec_lds_bytes", "spec_scratch_bytes")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(t, leaf, root, args.cpu_seconds)
+    del case, leaf, root, f, step
+    torch.cuda.empty_cache()
+    # ---- after and outside the headline's timed region ---------------------------------------------------------
+    if args.backend == "isa" and not args.no_secondary and not args.fast_math:
+        # config 5 runs on every rank (its one collective needs them all); the rest on rank 0 at N = 1 only
+        c5 = config5(dev, rank, world, dist if world > 1 or os.environ.get("FDG_BENCH_FORCE_DIST") else None, comm, steps=max(20, min(args.steps, 100)), warm=30)
+        if rank == 0:
+            out["config5"] = c5
+        if rank == 0 and world == 1:
+            sec = []
+            head = (args.workload, args.layout)
+            for wl, lay in (("sigma2", "leaf_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "leaf_major"), ("gv_sigma5", "leaf_major"),
+                            ("gv_sigma6", "leaf_major"), ("gv_sigma4_taylor2", "leaf_major"), ("gv_sigma4_taylor2", "sample_major")):
+                if (wl, lay) != head:
+                    sec.append(secondary_case(wl, lay, dev, copy_gbs=copy_gbs))
+            out["secondary"] = sec
+            out["secondary_note"] = ("measured in this process after the headline's timed region (30 untimed + 20 timed launches each, HIP events on the "
+                                     "launch stream); never part of `value`.  " + PARITY_NOTE)
+    if rank == 0:
         if world == 1 and not args.no_mc_step and args.backend == "isa":
-            del leaf, root
             out["mc_step"] = mc_step(t, args.workload, B, dev, args.fast_math)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
@@ -228,7 +388,7 @@ def mc_step(t, workload, B, dev, fast_math):
     """Secondary figure, outside the timed region and not part of `value`: the whole Monte-Carlo integrand step of
     example/benchmark.jl:58-87 on the same graph -- leaves computed from the sample's loop momenta and times, graph,
     weighted accumulation -- through fdg_graph_specialize_fused / fdg_mc_accumulate_device.  Needs the
-    graph's leafstates tables (tests/golden/, derived from the reference's GV catalogs)."""
+    graph's leafstates tables (feynmandiagram.jl_amd/data/, derived from the reference's GV catalogs)."""
     import numpy as np
     import torch
     import feynmandiagram_jl_amd as fd

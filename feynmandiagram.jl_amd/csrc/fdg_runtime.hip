@@ -258,6 +258,20 @@ fdg_fill_uniform(double *__restrict__ leaf, long B, uint32_t L, long ss, long ls
   }
 }
 
+// Harness only: the box's streaming ceiling.  16 bytes per lane, each workgroup walks its own contiguous
+// 4 KB pieces with the same stride pattern for read and write; four loads in flight per lane.
+typedef double fdg_v2d __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256)
+fdg_copy16(const fdg_v2d *__restrict__ src, fdg_v2d *__restrict__ dst, long n16) {
+  const long stride = (long)gridDim.x * 256L;
+  long i = blockIdx.x * 256L + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const fdg_v2d a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
 // ============================================================================
 // host side
 // ============================================================================
@@ -1361,6 +1375,17 @@ int fdg_eval(fdg_graph *g, const double *leaf, double *root, int64_t B) {
   }
   hipFree(dl); hipFree(dr);
   return rc;
+}
+
+int fdg_copy_device(double *d_dst, const double *d_src, int64_t n, void *stream) {
+  if (n < 0 || (n & 1)) { set_error("fdg_copy_device: n must be even and >= 0"); return FDG_E_INVALID; }
+  if (n == 0) return FDG_OK;
+  if (!d_dst || !d_src || (((uintptr_t)d_dst | (uintptr_t)d_src) & 15)) { set_error("fdg_copy_device: null or not 16-byte aligned"); return FDG_E_INVALID; }
+  const long n16 = (long)(n / 2);
+  const long grid = std::min<long>((n16 + 255) / 256, 256L * 32);
+  hipLaunchKernelGGL(fdg_copy16, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const fdg_v2d *)d_src, (fdg_v2d *)d_dst, n16);
+  HIP_TRY(hipGetLastError());
+  return FDG_OK;
 }
 
 int fdg_fill_uniform_device(double *d_leaf, int64_t B, uint32_t L, int64_t ss, int64_t ls, uint64_t seed,

@@ -12,17 +12,21 @@ Each maps to a config of BASELINE.json:
                     roots = orders 0,1,2 x {instant, dynamic}); N = 7 373 / 115 588 nodes
   gv_sigma4/5/6     real reference data: GV self-energy catalogs of order 4/5/6
                     read from the reference's .diag files and run through the
-                    restated optimize! (tests/golden/make_gv_tables.py)
+                    restated optimize! (tests/golden/make_gv_tables.py; shipped in data/)
   sigma4_taylor_standin  config 4: the same enlarged x3 with 2 % Power{2} nodes
   synthetic_small   a 1000-node graph for quick parity runs
 """
 from __future__ import annotations
 
 import functools
+import os
 
 import numpy as np
 
 from .nodetable import NodeTable, OP_POWER, OP_PROD, from_program, synthetic_parquet_like
+
+# node tables derived from the reference's GV catalogs (tests/golden/make_gv_tables.py, make_package_data.py)
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 PREBUILT = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "sigma4_taylor_standin", "gv_sigma4",
             "gv_sigma5", "gv_sigma6", "gv_sigma4_taylor2", "gv_sigma5_taylor2")
@@ -44,9 +48,7 @@ def get(name: str) -> NodeTable:
     if name == "synthetic_small":
         return synthetic_parquet_like(1000, 64, 2, seed=7, structure="random")
     if name.startswith("gv_sigma"):
-        import os
-        return NodeTable.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                           "tests", "golden", name + ".npz"))
+        return NodeTable.load(os.path.join(DATA, name + ".npz"))
     if name == "sigma4_taylor_standin":
         return _with_powers(synthetic_parquet_like(30000, 300, 6, seed=20241221), 0.02, 99)
     raise KeyError(name)
@@ -59,15 +61,13 @@ def leafstates(name: str):
     """The ``FrontEnds.leafstates`` tables of a GV workload, in leafVal order (``leaf_type``, ``leaf_order``, ``tau_in``,
     ``tau_out``, ``loop_index``, ``basis``, ``n_tau``), or None.  For the Taylor-expanded graphs a leaf is (leaf of the
     original graph, derivative order in the coupling): the fixture of the original graph re-indexed."""
-    import os
-    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     base = name[:-len("_taylor2")] if name.endswith("_taylor2") else name
-    path = os.path.join(gold, base + "_leafstates.npz")
+    path = os.path.join(DATA, base + "_leafstates.npz")
     if not os.path.exists(path):
         return None
     z = dict(np.load(path))
     if name.endswith("_taylor2"):
-        zt = np.load(os.path.join(gold, name + ".npz"))
+        zt = np.load(os.path.join(DATA, name + ".npz"))
         for k in ("leaf_type", "tau_in", "tau_out", "loop_index"):
             z[k] = z[k][zt["leaf_base"]]
         z["leaf_order"] = np.where(z["leaf_type"] == 2, zt["leaf_dorder"], 0).astype(np.int32)

@@ -198,7 +198,8 @@ int fdg_eval_device(fdg_graph *g, const double *d_leaf, int64_t leaf_sample_stri
 int fdg_eval(fdg_graph *g, const double *leaf, double *root, int64_t n_sample);
 
 /* d_acc[k] += sum_b weight[b] * root_k(b)   (d_weight may be NULL: weight 1).
- * Block-level pairwise reduction, one fp64 atomicAdd per block and root.
+ * Per-lane accumulators inside the evaluator (ISA back end) or fixed-shape block trees, then one partial per
+ * wave / block and root summed in fixed order by a second kernel: deterministic for a given launch shape, no atomics.
  * d_acc must hold n_root doubles and be zeroed by the caller. */
 int fdg_accumulate_device(fdg_graph *g, const double *d_leaf, int64_t leaf_sample_stride,
                           int64_t leaf_leaf_stride, const double *d_weight, double *d_acc,
@@ -210,6 +211,11 @@ int fdg_accumulate_device(fdg_graph *g, const double *d_leaf, int64_t leaf_sampl
 int fdg_fill_uniform_device(double *d_leaf, int64_t n_sample, uint32_t n_leaf,
                             int64_t leaf_sample_stride, int64_t leaf_leaf_stride, uint64_t seed,
                             uint64_t sample_offset, void *stream);
+
+/* Harness only (bench.py's `roofline.measured_copy_gbs`): d_dst[0..n) = d_src[0..n), 16 bytes per lane,
+ * n even, both pointers 16-byte aligned.  The box's own streaming ceiling next to the 8 TB/s spec
+ * (the reference has no counterpart). */
+int fdg_copy_device(double *d_dst, const double *d_src, int64_t n, void *stream);
 
 /* ---- leaf values on device (the caller's side of the path) ----------------
  * The per-sample leaf loop of the reference's example integrand (example/benchmark.jl:58-81):
