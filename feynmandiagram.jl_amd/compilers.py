@@ -149,10 +149,18 @@ class GraphFunc:
         import torch
         if not leaf.is_cuda or leaf.dtype != torch.float64 or leaf.dim() != 2:
             raise TypeError("leaf must be a float64 [B, L] CUDA tensor")
+        if leaf.shape[1] < self.n_leaf:
+            raise IndexError("BoundsError: leafVal has fewer columns than the graph has leaves")
         if acc is None:
             acc = torch.zeros(self.n_root, dtype=torch.float64, device=leaf.device)
+        if (not acc.is_cuda or acc.device != leaf.device or acc.dtype != torch.float64 or not acc.is_contiguous()
+                or acc.numel() < self.n_root):
+            raise ValueError("acc must be a contiguous float64 tensor of at least n_root elements on the leaves' device")
         w = 0
         if weight is not None:
+            if (not weight.is_cuda or weight.device != leaf.device or weight.dtype != torch.float64 or weight.dim() != 1
+                    or weight.shape[0] < leaf.shape[0]):
+                raise ValueError("weight must be a float64 vector of at least B elements on the leaves' device")
             weight = weight.contiguous()
             w = weight.data_ptr()
         st = torch.cuda.current_stream(leaf.device).cuda_stream

@@ -72,8 +72,26 @@ double powi(double x, int32_t n);
 
 }  // namespace fdg
 
+// Device scratch of one caller stream.  The members of the same name in fdg_graph are the set bound to the stream of the
+// call in progress (fdg_bind_stream_ws, under fdg_graph::mu); the sets of other streams are parked in fdg_graph::ws_pool.
+// Kernels enqueued on different streams therefore never share a spill panel, partial sums or a staging buffer.
+struct fdg_ws_set {
+  void *key = nullptr;
+  void *d_ws = nullptr, *d_ws2 = nullptr, *d_ws3 = nullptr, *d_ws4 = nullptr;
+  size_t ws_bytes = 0, ws2_bytes = 0, ws3_bytes = 0, ws4_bytes = 0;
+  void *s2 = nullptr, *ev_t[2] = {nullptr, nullptr}, *ev_k[2] = {nullptr, nullptr}, *ev_in = nullptr;
+  uint64_t last_use = 0;
+};
+
 struct fdg_graph {
   fdg::Lowered prog;
+  // tuning knobs set by fdg_graph_set_opt_params (has_opt: the next FDG_SPEC_ISA specialisation uses them as they are)
+  fdg_opt_params opt = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool has_opt = false;
+  std::vector<fdg_ws_set> ws_pool;
+  void *ws_key = nullptr;
+  bool ws_bound = true;            // the members below start out as the set of the null stream
+  uint64_t ws_clock = 0;
   // specialization
   std::vector<char> code_object;   // gfx950 code object of the specialized kernels
   std::string spec_source_hash;
@@ -142,6 +160,7 @@ struct fdg_graph {
   } while (0)
 
 int ensure_device(fdg_graph *g);                 // binds the handle to the current gfx950 device
+int fdg_bind_stream_ws(fdg_graph *g, void *stream);   // makes the scratch set of `stream` the current one (caller holds g->mu)
 int ensure_ws(fdg_graph *g, size_t bytes);       // grows the handle's device workspace
 int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root, int64_t rs, int64_t rk,
                    const double *d_weight, double *d_acc, int64_t B, hipStream_t st);   // caller holds g->mu
@@ -155,6 +174,7 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
 #endif
 namespace fdg { const char *last_error_cstr(); }
 uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull);
+int fdg_cache_dir(const char *arg, std::string &dir);   // resolves, creates (0700) and vets the JIT cache directory
 bool read_file(const std::string &path, std::vector<char> &out);
 bool write_file(const std::string &path, const char *data, size_t n);
 int compile_hiprtc(const std::string &src, bool fast, std::vector<char> &co, std::string &log);

@@ -244,17 +244,17 @@ static hipFunction_t leaf_spec_function(const fdg_leaf_tables *tab, const std::v
   static std::vector<LeafModule> cache;
   std::lock_guard<std::mutex> lk(mu);
   for (auto &m : cache) if (m.dev == dev && m.key == hbuf) return m.fn;
-  const std::string dir = std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache";
-  mkdir(dir.c_str(), 0777);
+  std::string dir;
+  const bool have_dir = fdg_cache_dir(nullptr, dir) == FDG_OK;     // no usable cache directory: compile, do not cache
   const std::string base = dir + "/fdg_leaf_" + hbuf;
   std::vector<char> co;
-  if (!read_file(base + ".hsaco", co)) {
+  if (!have_dir || !read_file(base + ".hsaco", co)) {
     std::string log;
     if (compile_hiprtc(src, false, co, log) != 0) {
       cache.push_back(LeafModule{dev, hbuf, nullptr, nullptr});   // do not retry on every call
       return nullptr;
     }
-    write_file(base + ".hsaco", co.data(), co.size());
+    if (have_dir) write_file(base + ".hsaco", co.data(), co.size());
   }
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
@@ -392,8 +392,7 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
     const uint32_t hd[5] = {tab->n_leaf, tab->n_basis, tab->n_loop, tab->dim, tab->n_tau};
     std::memcpy(g->lt_hdr, hd, sizeof hd);
     g->mc_built = false;
-    g->mc_dir = cache_dir ? cache_dir : (std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache");
-    mkdir(g->mc_dir.c_str(), 0777);
+    { const int rcd = fdg_cache_dir(cache_dir, g->mc_dir); if (rcd) return rcd; }
     g->mc_flags = flags;
     if (try_isa) {
       std::string why;
@@ -410,8 +409,8 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
   const std::string src = emit_fused_source(g->prog, emit_leaf_statements(tab, leaf_order_by_momentum(tab), true), needs_fermi_dn(tab) ? kFermiDnSource : "");
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("fused-v1")));
-  const std::string dir = cache_dir ? cache_dir : (std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache");
-  mkdir(dir.c_str(), 0777);
+  std::string dir;
+  { const int rcd = fdg_cache_dir(cache_dir, dir); if (rcd) return rcd; }
   const std::string base = dir + "/fdg_fused_" + hbuf;
   std::vector<char> co;
   if (!read_file(base + ".hsaco", co)) {
@@ -443,6 +442,8 @@ static int run_fused(fdg_graph *g, int mode, const double *d_K, int64_t ks, int6
   std::lock_guard<std::mutex> lk(g->mu);
   if (g->mc_route == 0) { set_error("fdg_graph_specialize_fused has not been called on this handle"); return FDG_E_INVALID; }
   int rc = ensure_device(g);
+  if (rc) return rc;
+  rc = fdg_bind_stream_ws(g, stream);
   if (rc) return rc;
   if (g->mc_route == 3)
     return fdg_mc_isa_run(g, mode, d_K, ks, kc, d_T, ts, tc, kF, beta, lambda, d_root, rs, rk, d_weight, d_acc, B, (hipStream_t)stream);

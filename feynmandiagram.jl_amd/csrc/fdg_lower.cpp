@@ -43,12 +43,15 @@ int validate_desc(const fdg_graph_desc *d, std::string &err) {
     if (d->op[n] == FDG_OP_POWER) {
       if (b - a != 1) { err = "Power node must have one and only one subgraph"; return FDG_E_INVALID; }
       if (d->power[n] == 0 || d->power[n] == 1) { err = "Power{0}/Power{1} makes no sense"; return FDG_E_INVALID; }
+      // the interpreter stream stores the exponent biased by 2^27 in 28 bits
+      if (d->power[n] >= (1 << 27) || d->power[n] <= -(1 << 27)) { err = "Power{N} with |N| >= 2^27 is not supported"; return FDG_E_UNSUPPORTED; }
     }
     for (uint32_t e = a; e < b; ++e) {
       if (d->child_idx[e] >= L + n) { err = "child index not smaller than its node: table is not topologically sorted"; return FDG_E_INVALID; }
       if (!std::isfinite(d->child_fac[e])) { err = "non-finite subgraph factor"; return FDG_E_INVALID; }
     }
   }
+  if (R >= (1ull << 28)) { err = "2^28 roots or more are not supported"; return FDG_E_UNSUPPORTED; }   // 28-bit root index in the interpreter stream
   for (uint64_t k = 0; k < R; ++k)
     if (d->root_slot[k] != FDG_NO_ROOT && d->root_slot[k] >= L + N) { err = "root_slot out of range"; return FDG_E_INVALID; }
   return FDG_OK;

@@ -8,7 +8,9 @@
 // CPU path here: every evaluation entry point needs a device.
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <cstdio>
@@ -296,6 +298,63 @@ int ensure_device(fdg_graph *g) {
   return FDG_OK;
 }
 
+static void free_ws_set(fdg_ws_set &w) {
+  if (w.d_ws) hipFree(w.d_ws);
+  if (w.d_ws2) hipFree(w.d_ws2);
+  if (w.d_ws3) hipFree(w.d_ws3);
+  if (w.d_ws4) hipFree(w.d_ws4);
+  if (w.s2) {
+    hipStreamSynchronize((hipStream_t)w.s2);
+    hipStreamDestroy((hipStream_t)w.s2);
+    for (int i = 0; i < 2; ++i) { hipEventDestroy((hipEvent_t)w.ev_t[i]); hipEventDestroy((hipEvent_t)w.ev_k[i]); }
+    hipEventDestroy((hipEvent_t)w.ev_in);
+  }
+  w = fdg_ws_set();
+}
+static void park_current_ws(fdg_graph *g, fdg_ws_set &w) {
+  w.key = g->ws_key;
+  w.d_ws = g->d_ws; w.ws_bytes = g->ws_bytes; w.d_ws2 = g->d_ws2; w.ws2_bytes = g->ws2_bytes;
+  w.d_ws3 = g->d_ws3; w.ws3_bytes = g->ws3_bytes; w.d_ws4 = g->d_ws4; w.ws4_bytes = g->ws4_bytes;
+  w.s2 = g->s2; w.ev_in = g->ev_in;
+  for (int i = 0; i < 2; ++i) { w.ev_t[i] = g->ev_t[i]; w.ev_k[i] = g->ev_k[i]; }
+  w.last_use = g->ws_clock;
+}
+static void load_ws(fdg_graph *g, const fdg_ws_set &w) {
+  g->d_ws = w.d_ws; g->ws_bytes = w.ws_bytes; g->d_ws2 = w.d_ws2; g->ws2_bytes = w.ws2_bytes;
+  g->d_ws3 = w.d_ws3; g->ws3_bytes = w.ws3_bytes; g->d_ws4 = w.d_ws4; g->ws4_bytes = w.ws4_bytes;
+  g->s2 = w.s2; g->ev_in = w.ev_in;
+  for (int i = 0; i < 2; ++i) { g->ev_t[i] = w.ev_t[i]; g->ev_k[i] = w.ev_k[i]; }
+}
+// One scratch set per caller stream (include/fdg.h: the device entry points may be called concurrently on different
+// streams and from different threads; calls on one stream are ordered by the stream).  At most 8 sets are kept: the
+// least recently used one is released (after a device synchronisation) when a ninth stream shows up.
+int fdg_bind_stream_ws(fdg_graph *g, void *stream) {
+  g->ws_clock++;
+  if (g->ws_bound && g->ws_key == stream) return FDG_OK;
+  if (g->ws_bound) {
+    fdg_ws_set w;
+    park_current_ws(g, w);
+    g->ws_pool.push_back(w);
+  }
+  g->ws_bound = true;
+  g->ws_key = stream;
+  for (size_t i = 0; i < g->ws_pool.size(); ++i)
+    if (g->ws_pool[i].key == stream) {
+      load_ws(g, g->ws_pool[i]);
+      g->ws_pool.erase(g->ws_pool.begin() + (long)i);
+      return FDG_OK;
+    }
+  load_ws(g, fdg_ws_set());
+  if (g->ws_pool.size() >= 8) {
+    size_t lru = 0;
+    for (size_t i = 1; i < g->ws_pool.size(); ++i) if (g->ws_pool[i].last_use < g->ws_pool[lru].last_use) lru = i;
+    HIP_TRY(hipDeviceSynchronize());
+    free_ws_set(g->ws_pool[lru]);
+    g->ws_pool.erase(g->ws_pool.begin() + (long)lru);
+  }
+  return FDG_OK;
+}
+
 int ensure_ws(fdg_graph *g, size_t bytes) {
   if (g->ws_bytes >= bytes && g->d_ws) return FDG_OK;
   if (g->d_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws)); g->d_ws = nullptr; g->ws_bytes = 0; }
@@ -349,7 +408,9 @@ static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t
   if ((g->prog.L && !d_leaf) || (mode == 0 && g->prog.R && !d_root) || (mode == 1 && !d_acc)) {
     set_error("null device buffer"); return FDG_E_INVALID;
   }
+  if (mode == 1 && g->prog.R == 0) return FDG_OK;        // no roots: nothing to accumulate
   std::lock_guard<std::mutex> lk(g->mu);
+  { const int rcb = fdg_bind_stream_ws(g, (void *)st); if (rcb) return rcb; }
   return fdg_run_locked(g, mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st);
 }
 
@@ -588,17 +649,86 @@ uint64_t fnv1a(const std::string &s, uint64_t h) {
   return h;
 }
 
+// Cache artefacts are code that will run on the GPU and parameters that size register files: only files owned by the
+// calling user and not writable by anybody else are read back (FDG_CACHE_TRUST=1 lifts the ownership test, e.g. for a
+// read-only cache shipped by an administrator).
+static bool cache_trust() { static const bool t = std::getenv("FDG_CACHE_TRUST") != nullptr; return t; }
 bool read_file(const std::string &path, std::vector<char> &out) {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) return false;
-  out.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || (!cache_trust() && (sb.st_uid != geteuid() || (sb.st_mode & 022)))) { ::close(fd); return false; }
+  out.resize((size_t)sb.st_size);
+  size_t got = 0;
+  while (got < out.size()) {
+    const ssize_t r = ::read(fd, out.data() + got, out.size() - got);
+    if (r <= 0) break;
+    got += (size_t)r;
+  }
+  ::close(fd);
+  out.resize(got);
   return !out.empty();
 }
 
+// written under a process-unique name, then renamed: readers (other ranks JIT-ing the same graph) never see half a file
 bool write_file(const std::string &path, const char *data, size_t n) {
   const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
-  { std::ofstream f(tmp, std::ios::binary); if (!f) return false; f.write(data, (std::streamsize)n); if (!f) return false; }
-  return std::rename(tmp.c_str(), path.c_str()) == 0;
+  const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+  if (fd < 0) return false;
+  size_t put = 0;
+  while (put < n) {
+    const ssize_t r = ::write(fd, data + put, n - put);
+    if (r <= 0) { ::close(fd); std::remove(tmp.c_str()); return false; }
+    put += (size_t)r;
+  }
+  ::close(fd);
+  if (std::rename(tmp.c_str(), path.c_str()) != 0) { std::remove(tmp.c_str()); return false; }
+  return true;
+}
+
+// The directory JIT-ed code objects are cached in: the argument, else $FDG_CACHE_DIR, else a per-user directory
+// ($XDG_CACHE_HOME/fdg, $HOME/.cache/fdg, /tmp/fdg-cache-<uid>), created 0700.  It must belong to the calling user and
+// must not be writable by group or others -- another local user could otherwise plant a code object under a predictable
+// name.  Paths with a quote or a newline are refused outright.
+int fdg_cache_dir(const char *arg, std::string &dir) {
+  if (arg && *arg) dir = arg;
+  else if (const char *e = std::getenv("FDG_CACHE_DIR")) dir = e;
+  else if (const char *x = std::getenv("XDG_CACHE_HOME")) { dir = std::string(x); mkdir(dir.c_str(), 0700); dir += "/fdg"; }
+  else if (const char *h = std::getenv("HOME")) { dir = std::string(h) + "/.cache"; mkdir(dir.c_str(), 0700); dir += "/fdg"; }
+  else dir = "/tmp/fdg-cache-" + std::to_string((long)geteuid());
+  if (dir.find_first_of("'\"\n") != std::string::npos) { set_error("cache directory path contains a quote or a newline: " + dir); return FDG_E_INVALID; }
+  mkdir(dir.c_str(), 0700);
+  struct stat sb;
+  if (stat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) { set_error("cannot create the cache directory " + dir); return FDG_E_JIT; }
+  if (!cache_trust() && (sb.st_uid != geteuid() || (sb.st_mode & 022))) {
+    set_error("cache directory " + dir + " must be owned by the calling user and not be writable by group or others (FDG_CACHE_TRUST=1 overrides)");
+    return FDG_E_JIT;
+  }
+  return FDG_OK;
+}
+
+// runs argv (no shell), stdout + stderr appended to `log_path`; returns the exit status, -1 when it could not be run
+static int run_cmd(const std::vector<std::string> &argv, const std::string &log_path) {
+  std::vector<char *> av;
+  for (const std::string &a : argv) av.push_back(const_cast<char *>(a.c_str()));
+  av.push_back(nullptr);
+  const pid_t pid = fork();
+  if (pid < 0) return -1;
+  if (pid == 0) {
+    const int fd = ::open(log_path.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0600);
+    if (fd >= 0) { dup2(fd, 1); dup2(fd, 2); ::close(fd); }
+    execv(av[0], av.data());
+    _exit(127);
+  }
+  int status = 0;
+  while (waitpid(pid, &status, 0) < 0) if (errno != EINTR) return -1;
+  return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
+}
+static std::string slurp_and_remove(const std::string &path) {
+  std::string log;
+  { std::ifstream f(path, std::ios::binary); if (f) log.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>()); }
+  std::remove(path.c_str());
+  return log;
 }
 
 int compile_hiprtc(const std::string &src, bool fast, std::vector<char> &co, std::string &log) {
@@ -622,14 +752,12 @@ int compile_hiprtc(const std::string &src, bool fast, std::vector<char> &co, std
 
 int compile_hipcc(const std::string &src_path, const std::string &out_path, bool fast, std::string &log) {
   const char *hipcc = std::getenv("FDG_HIPCC");
-  std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " --genco --offload-arch=gfx950 -O3 " +
-                    (fast ? "-ffp-contract=fast" : "-ffp-contract=off") + " -o '" + out_path + "' '" + src_path +
-                    "' > '" + out_path + ".log' 2>&1";
-  int rc = std::system(cmd.c_str());
-  std::vector<char> l;
-  if (read_file(out_path + ".log", l)) log.assign(l.begin(), l.end());
-  std::remove((out_path + ".log").c_str());
-  return rc == 0 ? 0 : -1;
+  const std::string tmp = out_path + ".tmp." + std::to_string((long)getpid());
+  const int rc = run_cmd({hipcc ? hipcc : "/opt/rocm/bin/hipcc", "--genco", "--offload-arch=gfx950", "-O3",
+                          fast ? "-ffp-contract=fast" : "-ffp-contract=off", "-o", tmp, src_path}, tmp + ".log");
+  log = slurp_and_remove(tmp + ".log");
+  if (rc != 0 || std::rename(tmp.c_str(), out_path.c_str()) != 0) { std::remove(tmp.c_str()); return -1; }
+  return 0;
 }
 
 extern "C" {
@@ -671,15 +799,15 @@ int fdg_graph_release_device(fdg_graph *g) {
   if (!g) return FDG_OK;
   std::lock_guard<std::mutex> lk(g->mu);
   if (g->d_code) { hipFree(g->d_code); g->d_code = nullptr; }
-  if (g->d_ws) { hipFree(g->d_ws); g->d_ws = nullptr; g->ws_bytes = 0; }
-  if (g->d_ws2) { hipFree(g->d_ws2); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
-  if (g->d_ws3) { hipFree(g->d_ws3); g->d_ws3 = nullptr; g->ws3_bytes = 0; }
-  if (g->d_ws4) { hipFree(g->d_ws4); g->d_ws4 = nullptr; g->ws4_bytes = 0; }
-  if (g->s2) {
-    hipStreamSynchronize((hipStream_t)g->s2);
-    hipStreamDestroy((hipStream_t)g->s2); g->s2 = nullptr;
-    for (int i = 0; i < 2; ++i) { hipEventDestroy((hipEvent_t)g->ev_t[i]); hipEventDestroy((hipEvent_t)g->ev_k[i]); }
-    hipEventDestroy((hipEvent_t)g->ev_in);
+  {
+    fdg_ws_set cur;
+    park_current_ws(g, cur);
+    free_ws_set(cur);
+    load_ws(g, fdg_ws_set());
+    for (fdg_ws_set &w : g->ws_pool) free_ws_set(w);
+    g->ws_pool.clear();
+    g->ws_bound = true;
+    g->ws_key = nullptr;
   }
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; g->fn_eval_sm = g->fn_eval_gen = nullptr; g->fn_isa = nullptr; }
   if (g->fused_module) { hipModuleUnload((hipModule_t)g->fused_module); g->fused_module = nullptr; g->fn_fused = nullptr; }
@@ -733,10 +861,6 @@ static fdg::OptParams to_params(const fdg_opt_params *q) {
   return prm;
 }
 
-static fdg_opt_params g_default_opt = {0, 0, 0, 0, 0, 0, 0, 0};
-struct OptStore { std::mutex mu; std::vector<std::pair<const fdg_graph *, fdg_opt_params>> v; };
-static OptStore &opt_store() { static OptStore s; return s; }
-
 int fdg_graph_set_schedule_groups(fdg_graph *g, const uint32_t *group, uint32_t n_node) {
   if (!g) { set_error("null handle"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
@@ -748,19 +872,13 @@ int fdg_graph_set_schedule_groups(fdg_graph *g, const uint32_t *group, uint32_t 
 
 int fdg_graph_set_opt_params(fdg_graph *g, const fdg_opt_params *prm) {
   if (!g || !prm) { set_error("null argument"); return FDG_E_INVALID; }
-  OptStore &s = opt_store();
-  std::lock_guard<std::mutex> lk(s.mu);
-  for (auto &e : s.v) if (e.first == g) { e.second = *prm; return FDG_OK; }
-  s.v.push_back({g, *prm});
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->opt = *prm;
+  g->has_opt = true;
   return FDG_OK;
 }
 
-static fdg_opt_params get_opt_params(const fdg_graph *g) {
-  OptStore &s = opt_store();
-  std::lock_guard<std::mutex> lk(s.mu);
-  for (auto &e : s.v) if (e.first == g) return e.second;
-  return g_default_opt;
-}
+static fdg_opt_params get_opt_params(const fdg_graph *g) { return g->opt; }
 
 int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop **ops, uint64_t *n_ops,
                           uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used) {
@@ -804,12 +922,7 @@ int fdg_graph_mc_program(const fdg_graph *g, const fdg_leaf_tables *tab, const f
   return FDG_OK;
 }
 
-static bool has_opt_params(const fdg_graph *g) {
-  OptStore &s = opt_store();
-  std::lock_guard<std::mutex> lk(s.mu);
-  for (auto &e : s.v) if (e.first == g) return true;
-  return false;
-}
+static bool has_opt_params(const fdg_graph *g) { return g->has_opt; }
 
 static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags,
                         std::vector<char> &co, std::string &hash, const fdg::OptProgram *prog2 = nullptr,
@@ -820,20 +933,23 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
   hash = hbuf;
   const std::string base = dir + "/fdg_isa_" + hbuf;
   if (!read_file(base + ".hsaco", co)) {
-    if (!write_file(base + ".s", src.c_str(), src.size())) { set_error("cannot write " + base + ".s"); return FDG_E_JIT; }
+    // every intermediate under a process-unique name (ranks of one job assemble the same graph at the same time);
+    // the code object appears under its final name by rename
+    const std::string tmp = base + ".tmp." + std::to_string((long)getpid());
+    if (!write_file(tmp + ".s", src.c_str(), src.size())) { set_error("cannot write " + tmp + ".s"); return FDG_E_JIT; }
     const char *llvm = std::getenv("FDG_LLVM_BIN");
     const std::string bin = llvm ? llvm : "/opt/rocm/lib/llvm/bin";
-    const std::string cmd = bin + "/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c '" + base + ".s' -o '" + base +
-                            ".o' > '" + base + ".log' 2>&1 && " + bin + "/ld.lld -shared '" + base + ".o' -o '" + base +
-                            ".hsaco' >> '" + base + ".log' 2>&1";
-    const int rc = std::system(cmd.c_str());
-    std::vector<char> l;
-    std::string log;
-    if (read_file(base + ".log", l)) log.assign(l.begin(), l.end());
-    std::remove((base + ".log").c_str());
-    std::remove((base + ".o").c_str());
-    if (!(flags & FDG_SPEC_KEEP_SOURCE)) std::remove((base + ".s").c_str());
-    if (rc != 0 || !read_file(base + ".hsaco", co)) { set_error("assembling the ISA kernel failed:\n" + log.substr(0, 2000)); return FDG_E_JIT; }
+    int rc = run_cmd({bin + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", tmp + ".s", "-o", tmp + ".o"}, tmp + ".log");
+    if (rc == 0) rc = run_cmd({bin + "/ld.lld", "-shared", tmp + ".o", "-o", tmp + ".hsaco"}, tmp + ".log");
+    const std::string log = slurp_and_remove(tmp + ".log");
+    std::remove((tmp + ".o").c_str());
+    if (flags & FDG_SPEC_KEEP_SOURCE) std::rename((tmp + ".s").c_str(), (base + ".s").c_str());
+    else std::remove((tmp + ".s").c_str());
+    if (rc != 0 || std::rename((tmp + ".hsaco").c_str(), (base + ".hsaco").c_str()) != 0 || !read_file(base + ".hsaco", co)) {
+      std::remove((tmp + ".hsaco").c_str());
+      set_error("assembling the ISA kernel failed:\n" + log.substr(0, 2000));
+      return FDG_E_JIT;
+    }
   } else if (flags & FDG_SPEC_KEEP_SOURCE) {
     write_file(base + ".s", src.c_str(), src.size());
   }
@@ -959,7 +1075,14 @@ static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   if (!read_file(tuned, buf)) return 0;
   fdg::OptParams q;
   buf.push_back(0);
-  if (std::sscanf(buf.data(), "%u %u %u %u %u %u %u", &q.n_reg, &q.n_lds, &q.n_acc, &q.lookahead_lds, &q.lookahead_mem, &q.lookahead_leaf, &q.vn_window) != 7) return 0;
+  {
+    fdg_opt_params r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (std::sscanf(buf.data(), "%u %u %u %u %u %u %u", &r.n_reg, &r.n_lds, &r.n_acc, &r.lookahead_lds, &r.lookahead_mem, &r.lookahead_leaf, &r.vn_window) != 7) return 0;
+    if (r.n_reg < 4) return 0;
+    q = to_params(&r);          // the same clamps as parameters handed over through the ABI
+    if (!r.n_acc) q.n_acc = 0;
+    if (!r.n_lds) q.n_lds = 0;
+  }
   fdg::OptProgram prog;
   build_prog(g, q, prog);
   if (!prog.supported) return 0;
@@ -975,6 +1098,8 @@ static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
 
 static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   int rc = ensure_device(g);
+  if (rc) return rc;
+  rc = fdg_bind_stream_ws(g, nullptr);
   if (rc) return rc;
   const fdg::Lowered &p = g->prog;
   const std::string tuned = tuned_path(g, dir);
@@ -1289,19 +1414,18 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
   std::lock_guard<std::mutex> lk(g->mu);
   if (flags & FDG_SPEC_ISA) {
     g->isa_fma = (flags & FDG_SPEC_FAST_MATH) != 0;
-    std::string dir0 = cache_dir ? cache_dir : (std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache");
-    mkdir(dir0.c_str(), 0777);
+    std::string dir0;
+    { const int rcd = fdg_cache_dir(cache_dir, dir0); if (rcd) return rcd; }
     return specialize_isa(g, dir0, flags);
   }
   const bool companion = (flags & FDG_SPEC_ROW_MAJOR_COMPANION) != 0;
   if (companion && !(g->isa && !g->code_object.empty())) { set_error("FDG_SPEC_ROW_MAJOR_COMPANION needs a handle already specialised with FDG_SPEC_ISA"); return FDG_E_INVALID; }
-  if (!companion) g->isa = false;
   const bool fast = (flags & FDG_SPEC_FAST_MATH) != 0;
   const std::string src = emit_hip_source(g->prog, flags);
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a(fast ? "fast" : "strict")));
-  std::string dir = cache_dir ? cache_dir : (std::getenv("FDG_CACHE_DIR") ? std::getenv("FDG_CACHE_DIR") : "/tmp/fdg-cache");
-  mkdir(dir.c_str(), 0777);
+  std::string dir;
+  { const int rcd = fdg_cache_dir(cache_dir, dir); if (rcd) return rcd; }
   const std::string base = dir + "/fdg_" + hbuf;
   std::vector<char> co;
   if (!read_file(base + ".hsaco", co)) {
@@ -1328,9 +1452,14 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
     g->alt_code.swap(co);
     return FDG_OK;
   }
+  // the handle changes back end only now that the new code object exists (a failed JIT leaves it as it was)
   g->alt_code.clear();
   if (g->alt_module) { hipModuleUnload((hipModule_t)g->alt_module); g->alt_module = nullptr; }
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
+  g->isa = false;
+  g->fn_isa = g->fn_isa_w2 = g->fn_isa_acc = nullptr;
+  g->fn_eval_sm = g->fn_eval_gen = nullptr;
+  g->has_w2 = g->has_acc = false;
   g->code_object.swap(co);
   g->spec_source_hash = hbuf;
   g->spec_flags = flags;

@@ -30,8 +30,15 @@
  *
  * Conventions: every function returns 0 on success and a negative FDG_E_* code
  * on failure; fdg_last_error() returns a thread-local message.  All buffers are
- * owned by the caller.  A handle is immutable after create/specialize, so the
- * eval entry points are re-entrant across streams and threads.  There is no CPU
+ * owned by the caller.  The program of a handle is immutable after create/specialize, and its
+ * device scratch (spill panels, partial sums, staging buffers) is kept per caller stream, so the
+ * device entry points may be called on one handle from several threads and on several streams at
+ * once: calls on one stream run in stream order, calls on different streams may overlap on the
+ * device.  (Enqueueing is serialised by a mutex inside the handle; up to 8 streams keep their
+ * scratch, a ninth releases the least recently used set after a device synchronisation.  The first
+ * call on a stream allocates; later ones only launch kernels, so they can be captured in a hipGraph.)
+ * fdg_graph_specialize* and fdg_graph_release_device must not run concurrently with evaluations on
+ * the same handle.  There is no CPU
  * fallback anywhere behind this ABI: device entry points fail with
  * FDG_E_NO_DEVICE when no gfx950 device is usable.
  *

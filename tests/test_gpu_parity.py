@@ -643,6 +643,57 @@ def test_entry_points_are_graph_capturable(libfdg, cuda):
     assert np.array_equal(root.cpu().numpy(), oracle.eval_static(t, leaf.cpu().numpy()))
 
 
+def test_one_handle_two_streams_concurrently(libfdg, cuda):
+    """include/fdg.h: the device entry points may be called on ONE handle from several threads and on several streams
+    at once -- the scratch (spill panel, partial sums) is kept per caller stream.  Two streams (then two threads with a
+    stream each) run evaluations and fused accumulations of a graph that spills to its HBM panel, on batches small
+    enough that kernels of the two streams share the device; every result must be the single-stream one."""
+    import threading
+    import torch
+    t = workloads.get("sigma4_standin")
+    L, R, B = t.n_leaf, t.n_root, 20_000
+    f = fd.compile_table(t, specialize="isa")
+    leaf = [dev_leaves(cuda, B, L, 21 + i, 0, "leaf_major") for i in range(2)]
+    w = [torch.rand(B, dtype=torch.float64, device=cuda) for _ in range(2)]
+    want_root = [torch.from_numpy(oracle.eval_static(t, leaf[i].cpu().numpy())).to(cuda) for i in range(2)]
+    want_acc = []
+    for i in range(2):                                    # single stream, nothing else running
+        a = torch.zeros(R, dtype=torch.float64, device=cuda)
+        for _ in range(5):
+            f.accumulate(leaf[i], w[i], a)
+        torch.cuda.synchronize()
+        want_acc.append(a.clone())
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def work(i, root, acc):
+        with torch.cuda.stream(streams[i]):
+            for _ in range(5):
+                f(root, leaf[i])
+                f.accumulate(leaf[i], w[i], acc)
+
+    for threaded in (False, True):
+        root = [torch.zeros((R, B), dtype=torch.float64, device=cuda).t() for _ in range(2)]
+        acc = [torch.zeros(R, dtype=torch.float64, device=cuda) for _ in range(2)]
+        torch.cuda.synchronize()
+        if threaded:
+            th = [threading.Thread(target=work, args=(i, root[i], acc[i])) for i in range(2)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+        else:
+            for _rep in range(3):
+                for i in range(2):
+                    with torch.cuda.stream(streams[i]):
+                        f(root[i], leaf[i])
+            work(0, root[0], acc[0])
+            work(1, root[1], acc[1])
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert torch.equal(root[i], want_root[i]), (threaded, i)
+            assert torch.equal(acc[i], want_acc[i]), (threaded, i)
+
+
 def _taylor2_tables():
     z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
     zt = np.load(os.path.join(GOLD, "gv_sigma4_taylor2.npz"))

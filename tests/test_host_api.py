@@ -334,3 +334,67 @@ def test_argument_checks_of_the_newer_entry_points(libfdg):
     assert e.value.code == capi.FDG_E_INVALID
     with pytest.raises(capi.FdgError):
         h.mc_accumulate_device(8, 1, 1, 8, 1, 1, 1.0, 1.0, 1.0, 0, 0, 4)            # null accumulator
+
+
+def test_package_tables_equal_golden_fixtures():
+    """The node tables the product ships (feynmandiagram.jl_amd/data/, workloads.get / workloads.leafstates) are the
+    tables of the golden fixtures, without their vectors: tests/golden/make_package_data.py keeps them in step."""
+    from feynmandiagram_jl_amd import workloads
+    from feynmandiagram_jl_amd.nodetable import NodeTable
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    for name in ("gv_sigma4", "gv_sigma5", "gv_sigma6", "gv_sigma4_taylor2", "gv_sigma5_taylor2"):
+        a, b = workloads.get(name), NodeTable.load(os.path.join(gold, name + ".npz"))
+        for k in ("op", "power", "child_off", "child_idx", "child_fac", "root_slot"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), (name, k)
+        assert a.n_leaf == b.n_leaf and (a.sched_group is None) == (b.sched_group is None)
+        if a.sched_group is not None:
+            assert np.array_equal(a.sched_group, b.sched_group)
+    for name in ("gv_sigma4", "gv_sigma5"):
+        z, g = workloads.leafstates(name), np.load(os.path.join(gold, name + "_leafstates.npz"))
+        for k in g.files:
+            assert np.array_equal(z[k], g[k]), (name, k)
+    assert not os.path.commonpath([workloads.DATA, gold]) == gold
+
+
+def test_cache_directory_is_vetted(tmp_path):
+    """JIT-ed code objects are read back by predictable name, so the cache directory must belong to the caller and must
+    not be writable by anybody else; a world-writable artefact inside it is ignored and rebuilt; no shell sees the path."""
+    import stat
+    from feynmandiagram_jl_amd import capi, workloads
+    t = workloads.get("sigma2")
+    good = tmp_path / "cache"
+    good.mkdir(mode=0o700)
+    h = capi.GraphHandle(t)
+    h.specialize(str(good), capi.FDG_SPEC_ISA)
+    objs = [p for p in good.iterdir() if p.suffix == ".hsaco"]
+    assert len(objs) == 1 and not [p for p in good.iterdir() if ".tmp." in p.name]
+    blob = objs[0].read_bytes()
+    # a planted (world-writable) file of the same name is not trusted: the kernel is assembled again
+    objs[0].write_bytes(b"not a code object")
+    os.chmod(objs[0], 0o666)
+    capi.GraphHandle(t).specialize(str(good), capi.FDG_SPEC_ISA)
+    assert objs[0].read_bytes() == blob and not (objs[0].stat().st_mode & stat.S_IWOTH)
+    bad = tmp_path / "open"
+    bad.mkdir()
+    os.chmod(bad, 0o777)
+    with pytest.raises(capi.FdgError) as e:
+        capi.GraphHandle(t).specialize(str(bad), capi.FDG_SPEC_ISA)
+    assert e.value.code == capi.FDG_E_JIT and "writable" in str(e.value)
+    quoted = tmp_path / "it's"
+    quoted.mkdir(mode=0o700)
+    with pytest.raises(capi.FdgError) as e:
+        capi.GraphHandle(t).specialize(str(quoted), capi.FDG_SPEC_ISA)
+    assert e.value.code == capi.FDG_E_INVALID
+
+
+def test_exponent_and_root_count_bounds():
+    """The interpreter stream packs Power's exponent (biased) and the root index into 28 bits: larger ones are refused
+    at fdg_graph_create instead of being truncated."""
+    from feynmandiagram_jl_amd import capi
+    from feynmandiagram_jl_amd.nodetable import OP_POWER, from_program
+    ok = from_program(1, [(OP_POWER, (1 << 27) - 1, [(0, 1.0)])], [1])
+    capi.GraphHandle(ok)
+    for n in (1 << 27, -(1 << 27), 2**31 - 1):
+        with pytest.raises(capi.FdgError) as e:
+            capi.GraphHandle(from_program(1, [(OP_POWER, n, [(0, 1.0)])], [1]))
+        assert e.value.code == capi.FDG_E_UNSUPPORTED
