@@ -28,7 +28,7 @@ FDG_SPEC_ROW_MAJOR_COMPANION = 16
 EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
-    "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_graph_release_device", "fdg_powi",
+    "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
     "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
@@ -125,6 +125,7 @@ def lib():
     L.fdg_accumulate_device.argtypes = [vp, dp, i64, i64, dp, dp, i64, vp]
     L.fdg_fill_uniform_device.argtypes = [dp, i64, u32, i64, i64, u64, u64, vp]
     L.fdg_copy_device.argtypes = [dp, dp, i64, vp]
+    L.fdg_isa_check_hazards.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
     L.fdg_graph_release_device.argtypes = [vp]
     L.fdg_leaf_eval_device.argtypes = [C.POINTER(LeafTables), dp, i64, i64, dp, i64, i64, dp, i64, i64, i64, vp]
     L.fdg_graph_set_schedule_groups.argtypes = [vp, C.c_void_p, u32]
@@ -288,6 +289,19 @@ class GraphHandle:
 def fill_uniform_device(d_leaf: int, B: int, L: int, ss: int, ls: int, seed: int, sample_offset: int = 0,
                         stream: int = 0):
     check(lib().fdg_fill_uniform_device(d_leaf, B, L, ss, ls, seed, sample_offset, stream))
+
+
+def isa_check_hazards(asm_text: str):
+    """(number of violations, report) of a gfx950 listing against the emitter's wait-state table."""
+    rep = C.c_char_p()
+    n = lib().fdg_isa_check_hazards(asm_text.encode(), C.byref(rep))
+    try:
+        text = rep.value.decode() if rep.value else ""
+    finally:
+        lib().fdg_free(rep)
+    if n < 0:
+        check(n)
+    return n, text
 
 
 def copy_device(d_dst: int, d_src: int, n: int, stream: int = 0):

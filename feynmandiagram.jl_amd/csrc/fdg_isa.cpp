@@ -56,13 +56,223 @@ const double kExpC[kExpDeg + 1] = {0x1.0000000000000p+0, 0x1.0000000000000p+0, 0
                                    0x1.555555554f0a5p-5, 0x1.111111110f218p-7, 0x1.6c16c18804745p-10, 0x1.a01a01b148c00p-13,
                                    0x1.a019919593233p-16, 0x1.71ddf5667e394p-19, 0x1.28b41ab9f014bp-22, 0x1.af63371ef88d9p-26};
 
+
+// ---- gfx950 required wait states between dependent instructions ---------------------------------------------------
+// Hand-written assembly gets no help from a compiler's hazard recogniser, so the pairs this emitter can produce are
+// kept in ONE table: Emit::ins() consults it for every instruction and puts the missing `s_nop` in front, and
+// fdg_isa_check_hazards() re-parses a finished listing against the same table (tests/test_isa_hazards.py runs it over
+// every prebuilt kernel).  A wait state is one instruction issued in between; `s_nop N` counts N + 1.
+// Sources: the gfx90a/gfx940 hazard rules of LLVM's AMDGPU back end, and where noted our own measurements on MI355X
+// (a violated pair showed up as a stale register read).
+enum HzRes : uint8_t { HZ_VGPR, HZ_SGPR /* incl. vcc */ };
+enum HzProd : uint8_t {
+  HP_TRANS,        // VALU transcendental (v_rcp/v_rsq/v_sqrt/v_exp/v_log/v_sin/v_cos) writes a VGPR
+  HP_VALU_SGPR,    // VALU writes an SGPR or VCC (v_cmp*, v_div_scale, v_readfirstlane, carry-out)
+  HP_VALU_VGPR,    // any VALU writes a VGPR
+  HP_STORE_WIDE,   // VMEM / DS store whose data operand is wider than 64 bits reads a VGPR
+  HP_SALU_SGPR,    // SALU writes an SGPR
+};
+enum HzCons : uint8_t {
+  HC_VALU_READ,    // VALU reads the register as an operand (VGPR) / as mask, carry-in or constant (SGPR, VCC)
+  HC_DIV_FMAS,     // v_div_fmas_* reads VCC
+  HC_VMEM_SADDR,   // VMEM / SMEM instruction reads the SGPR (address, offset)
+  HC_LANE_READ,    // v_readlane / v_readfirstlane reads the VGPR
+  HC_VALU_WRITE,   // VALU overwrites the VGPR
+};
+struct HzRule { HzProd prod; HzCons cons; HzRes res; int wait; const char *what; };
+const HzRule kHazards[] = {
+    {HP_TRANS, HC_VALU_READ, HZ_VGPR, 2, "trans result -> VALU read (gfx940: not forwarded; measured: stale read with 0)"},
+    {HP_VALU_SGPR, HC_VALU_READ, HZ_SGPR, 2, "VALU write of SGPR/VCC -> VALU read as mask/carry/constant (gfx940; measured with v_cmp -> v_cndmask)"},
+    {HP_VALU_SGPR, HC_DIV_FMAS, HZ_SGPR, 4, "VALU write of VCC -> v_div_fmas"},
+    {HP_VALU_SGPR, HC_VMEM_SADDR, HZ_SGPR, 5, "VALU write of SGPR -> VMEM/SMEM read of it"},
+    {HP_VALU_VGPR, HC_LANE_READ, HZ_VGPR, 2, "VALU write of VGPR -> v_readlane/v_readfirstlane (measured: stale read with 0)"},
+    {HP_STORE_WIDE, HC_VALU_WRITE, HZ_VGPR, 2, "store data wider than 64 bits -> VALU overwrite of the data registers"},
+    {HP_SALU_SGPR, HC_VMEM_SADDR, HZ_SGPR, 0, "SALU write of SGPR -> VMEM read of it: interlocked by hardware (every leaf load does this back to back)"},
+};
+constexpr int HZ_MAX_WAIT = 5;
+
+// registers are numbered: VGPR v -> v, AGPR a -> 512 + a, SGPR s -> 1024 + s, vcc -> 1024 + 106/107, exec -> 1024 + 126/127
+constexpr int HR_AGPR = 512, HR_SGPR = 1024, HR_VCC = 1024 + 106, HR_EXEC = 1024 + 126;
+struct HzInst {
+  std::string op;
+  bool valu = false, salu = false, vmem = false, ds = false, smem = false, trans = false, lane_read = false, div_fmas = false, store = false;
+  int nop = 0;                  // s_nop: wait states it provides
+  std::vector<int> wr, rd;      // registers written / read (numbering above)
+  std::vector<int> store_wide;  // data registers of a wide store
+};
+static bool hz_starts(const std::string &s, const char *p) { return s.compare(0, std::strlen(p), p) == 0; }
+// "v[4:5]" "-v7" "s[10:11]" "a3" "vcc" "exec" "0x12" "1.0" "off" ...  -> register range (first, count), count 0 = not a register
+static void hz_parse_reg(std::string t, int &first, int &n) {
+  first = 0; n = 0;
+  while (!t.empty() && (t[0] == '-' || t[0] == '|' || t[0] == ' ')) t.erase(0, 1);
+  while (!t.empty() && (t.back() == '|' || t.back() == ' ')) t.pop_back();
+  if (t == "vcc") { first = HR_VCC; n = 2; return; }
+  if (t == "vcc_lo") { first = HR_VCC; n = 1; return; }
+  if (t == "vcc_hi") { first = HR_VCC + 1; n = 1; return; }
+  if (t == "exec") { first = HR_EXEC; n = 2; return; }
+  if (t.size() < 2 || (t[0] != 'v' && t[0] != 's' && t[0] != 'a')) return;
+  const int base = t[0] == 'v' ? 0 : (t[0] == 'a' ? HR_AGPR : HR_SGPR);
+  if (t[1] == '[') {
+    int a = 0, b = 0;
+    if (std::sscanf(t.c_str() + 2, "%d:%d", &a, &b) == 2 && b >= a) { first = base + a; n = b - a + 1; }
+    return;
+  }
+  if (t[1] < '0' || t[1] > '9') return;
+  first = base + std::atoi(t.c_str() + 1); n = 1;
+}
+static HzInst hz_decode(const std::string &line) {
+  HzInst I;
+  size_t p = 0;
+  while (p < line.size() && (line[p] == ' ' || line[p] == '\t')) ++p;
+  size_t q = p;
+  while (q < line.size() && line[q] != ' ' && line[q] != '\t') ++q;
+  I.op = line.substr(p, q - p);
+  std::vector<std::string> opnd;
+  {
+    std::string rest = line.substr(q), cur;
+    int depth = 0;
+    for (char c : rest) {
+      if (c == '[') depth++;
+      if (c == ']') depth--;
+      if (c == ',' && depth == 0) { opnd.push_back(cur); cur.clear(); } else cur.push_back(c);
+    }
+    if (!cur.empty()) opnd.push_back(cur);
+    for (std::string &o : opnd) {           // strip blanks and trailing modifiers ("offset:8", "glc")
+      while (!o.empty() && (o[0] == ' ' || o[0] == '\t')) o.erase(0, 1);
+      const size_t sp = o.find_first_of(" \t");
+      if (sp != std::string::npos) o.erase(sp);
+    }
+  }
+  auto add = [](std::vector<int> &v, const std::string &t) { int f, n; hz_parse_reg(t, f, n); for (int i = 0; i < n; ++i) v.push_back(f + i); };
+  const std::string &op = I.op;
+  if (op == "s_nop") { I.salu = true; I.nop = (opnd.empty() ? 0 : std::atoi(opnd[0].c_str())) + 1; return I; }
+  if (hz_starts(op, "s_waitcnt") || op == "s_endpgm" || op == "s_barrier" || hz_starts(op, "s_cbranch") || op == "s_branch") { I.salu = true; return I; }
+  if (hz_starts(op, "s_load") || hz_starts(op, "s_buffer_load")) {
+    I.smem = true;
+    if (!opnd.empty()) add(I.wr, opnd[0]);
+    for (size_t i = 1; i < opnd.size(); ++i) add(I.rd, opnd[i]);
+    return I;
+  }
+  if (hz_starts(op, "s_")) {
+    I.salu = true;
+    const bool nodst = hz_starts(op, "s_cmp") || hz_starts(op, "s_setpc") || hz_starts(op, "s_bitcmp");
+    for (size_t i = 0; i < opnd.size(); ++i) add((i == 0 && !nodst) ? I.wr : I.rd, opnd[i]);
+    if (hz_starts(op, "s_addc") || hz_starts(op, "s_subb") || hz_starts(op, "s_cselect")) {}   // SCC is not tracked (SALU only)
+    return I;
+  }
+  if (hz_starts(op, "global_load") || hz_starts(op, "global_store") || hz_starts(op, "buffer_") || hz_starts(op, "flat_")) {
+    I.vmem = true;
+    I.store = op.find("store") != std::string::npos;
+    const bool wide = op.find("dwordx3") != std::string::npos || op.find("dwordx4") != std::string::npos;
+    for (size_t i = 0; i < opnd.size(); ++i) {
+      if (!I.store && i == 0) add(I.wr, opnd[i]);
+      else { add(I.rd, opnd[i]); if (I.store && i == 1 && wide) add(I.store_wide, opnd[i]); }
+    }
+    return I;
+  }
+  if (hz_starts(op, "ds_")) {
+    I.ds = true;
+    I.store = hz_starts(op, "ds_write");
+    const bool wide = op.find("b96") != std::string::npos || op.find("b128") != std::string::npos;
+    for (size_t i = 0; i < opnd.size(); ++i) {
+      if (!I.store && i == 0) add(I.wr, opnd[i]);
+      else { add(I.rd, opnd[i]); if (I.store && i == 1 && wide) add(I.store_wide, opnd[i]); }
+    }
+    return I;
+  }
+  if (hz_starts(op, "v_")) {
+    I.valu = true;
+    static const char *trans[] = {"v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_"};
+    for (const char *t : trans) if (hz_starts(op, t)) I.trans = true;
+    I.lane_read = hz_starts(op, "v_readlane") || hz_starts(op, "v_readfirstlane");
+    I.div_fmas = hz_starts(op, "v_div_fmas");
+    size_t ndst = 1;
+    if (hz_starts(op, "v_div_scale") || ((hz_starts(op, "v_add_co") || hz_starts(op, "v_sub_co") || hz_starts(op, "v_addc_co") || hz_starts(op, "v_subb_co")) && opnd.size() >= 4)) ndst = 2;
+    if (hz_starts(op, "v_cmpx")) { ndst = 0; I.wr.push_back(HR_EXEC); I.wr.push_back(HR_EXEC + 1); }
+    for (size_t i = 0; i < opnd.size(); ++i) add(i < ndst ? I.wr : I.rd, opnd[i]);
+    if (I.div_fmas) { I.rd.push_back(HR_VCC); I.rd.push_back(HR_VCC + 1); }
+    return I;
+  }
+  return I;   // directives, labels: not instructions
+}
+static bool hz_is_inst(const std::string &line) {
+  size_t p = 0;
+  while (p < line.size() && (line[p] == ' ' || line[p] == '\t')) ++p;
+  if (p >= line.size() || line[p] == '.' || line[p] == ';' || line[p] == '/' || line[p] == '-') return false;
+  const size_t q = line.find_first_of(" \t", p);
+  const std::string w = line.substr(p, q == std::string::npos ? std::string::npos : q - p);
+  if (!w.empty() && w.back() == ':') return false;   // label
+  return hz_starts(w, "s_") || hz_starts(w, "v_") || hz_starts(w, "ds_") || hz_starts(w, "global_") || hz_starts(w, "buffer_") || hz_starts(w, "flat_");
+}
+
+// Sliding window over the last HZ_MAX_WAIT wait states.
+struct HzTracker {
+  struct Past { HzInst inst; int age; };     // age = wait states issued since (0 = the next instruction follows immediately)
+  std::vector<Past> past;
+  // wait states missing before `I` may issue; `why` names the rule
+  int missing(const HzInst &I, const char **why = nullptr) const {
+    int need = 0;
+    auto has = [](const std::vector<int> &v, int r) { return std::find(v.begin(), v.end(), r) != v.end(); };
+    for (const Past &P : past) {
+      for (const HzRule &R : kHazards) {
+        if (R.wait <= P.age) continue;
+        const std::vector<int> *pr = nullptr;
+        switch (R.prod) {
+          case HP_TRANS: if (P.inst.trans) pr = &P.inst.wr; break;
+          case HP_VALU_SGPR: if (P.inst.valu) pr = &P.inst.wr; break;
+          case HP_VALU_VGPR: if (P.inst.valu) pr = &P.inst.wr; break;
+          case HP_STORE_WIDE: if (!P.inst.store_wide.empty()) pr = &P.inst.store_wide; break;
+          case HP_SALU_SGPR: if (P.inst.salu) pr = &P.inst.wr; break;
+        }
+        if (!pr) continue;
+        const std::vector<int> *cr = nullptr;
+        switch (R.cons) {
+          case HC_VALU_READ: if (I.valu && !I.div_fmas) cr = &I.rd; break;
+          case HC_DIV_FMAS: if (I.div_fmas) cr = &I.rd; break;
+          case HC_VMEM_SADDR: if (I.vmem || I.smem) cr = &I.rd; break;
+          case HC_LANE_READ: if (I.lane_read) cr = &I.rd; break;
+          case HC_VALU_WRITE: if (I.valu) cr = &I.wr; break;
+        }
+        if (!cr) continue;
+        for (int r : *pr) {
+          const bool sg = r >= HR_SGPR;
+          if ((R.res == HZ_SGPR) != sg) continue;
+          if (has(*cr, r)) { if (R.wait - P.age > need) { need = R.wait - P.age; if (why) *why = R.what; } break; }
+        }
+      }
+    }
+    return need;
+  }
+  void issue(const HzInst &I) {
+    const int ws = I.nop ? I.nop : 1;
+    for (Past &P : past) P.age += ws;
+    past.erase(std::remove_if(past.begin(), past.end(), [](const Past &P) { return P.age >= HZ_MAX_WAIT; }), past.end());
+    if (!I.nop && (I.valu || !I.store_wide.empty())) past.push_back(Past{I, 0});
+    else if (!I.nop && I.salu && !I.wr.empty()) past.push_back(Past{I, 0});
+  }
+  void reset() { past.clear(); }
+};
+
 struct Emit {
   std::ostringstream os;
+  HzTracker hz;
+  uint64_t n_auto_nop = 0;
   uint64_t vm_issued = 0, lg_issued = 0, vm_done = 0, lg_done = 0;
   // pending[reg] = (kind 0 none / 1 vm / 2 lgkm, seq)
   std::vector<std::pair<uint8_t, uint64_t>> pend;
 
-  void ins(const std::string &s) { os << "\t" << s << "\n"; }
+  // every instruction goes through here: the wait states the hazard table demands are put in front of it
+  void ins(const std::string &s) {
+    const HzInst I = hz_decode(s);
+    const int need = hz.missing(I);
+    if (need > 0) { os << "\ts_nop " << (need - 1) << "\n"; HzInst N; N.salu = true; N.nop = need; hz.issue(N); n_auto_nop++; }
+    hz.issue(I);
+    os << "\t" << s << "\n";
+  }
+  // a label: control flow may arrive from elsewhere, but every path into our labels ends in SALU branches issued long
+  // after the last VALU/VMEM instruction of the previous block, except the tile loop's back edge (handled by the nops
+  // emitted in front of s_setpc)
+  void label(const std::string &l) { os << l << ":\n"; }
   std::string vr(uint32_t r) const {
     char b[32];
     std::snprintf(b, sizeof b, "v[%u:%u]", V_BASE + 2 * r, V_BASE + 2 * r + 1);
@@ -467,7 +677,6 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         E.wait_reg(o.d);
         const std::string x = (o.nega ? "-" : "") + vlo(o.a), mx = (o.nega ? "" : "-") + vlo(o.a);
         E.ins("v_rcp_f64_e64 " + tA + ", " + x);
-        E.ins("s_nop 1");   // gfx940+: the result of a transcendental op is not forwarded to the next VALU op (measured: stale read)
         E.ins("v_fma_f64 " + tB + ", " + mx + ", " + tA + ", 1.0");
         E.ins("v_fma_f64 " + tA + ", " + tA + ", " + tB + ", " + tA);
         E.ins("v_fma_f64 " + tB + ", " + mx + ", " + tA + ", 1.0");
@@ -483,8 +692,6 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         std::string ahi = vd(o.a, 1), bhi = vd(o.b, 1);
         if (o.nega) { E.ins("v_xor_b32_e32 " + tAd(0) + ", 0x80000000, " + ahi); ahi = tAd(0); }
         if (o.negb) { E.ins("v_xor_b32_e32 " + tAd(1) + ", 0x80000000, " + bhi); bhi = tAd(1); }
-        // gfx940+: two wait states between a VALU write of VCC and a VALU read of it (FIXZ / SELC have two VALU ops in between)
-        if (!(o.nega && o.negb)) E.ins("s_nop " + std::string(o.nega || o.negb ? "0" : "1"));
         E.ins("v_cndmask_b32_e32 " + vd(o.d, 0) + ", " + vd(o.b, 0) + ", " + vd(o.a, 0) + ", vcc");
         E.ins("v_cndmask_b32_e32 " + vd(o.d, 1) + ", " + bhi + ", " + ahi + ", vcc");
         break;
@@ -637,6 +844,42 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
 }
 
 }  // namespace
+
+// Re-parses an assembly listing against the hazard table (independent of how the listing was produced).  Returns the
+// number of violations; `report` gets one line per violation and a summary of what was checked.
+int check_isa_hazards(const std::string &text, std::string &report) {
+  HzTracker hz;
+  std::istringstream in(text);
+  std::string line;
+  std::ostringstream rep;
+  long lineno = 0, n_inst = 0, n_bad = 0, n_nop = 0, n_trans = 0, n_sgpr_w = 0;
+  while (std::getline(in, line)) {
+    ++lineno;
+    if (!hz_is_inst(line)) continue;
+    const HzInst I = hz_decode(line);
+    ++n_inst;
+    if (I.nop) n_nop++;
+    if (I.trans) n_trans++;
+    if (I.valu) for (int r : I.wr) if (r >= HR_SGPR) { n_sgpr_w++; break; }
+    const char *why = nullptr;
+    const int need = hz.missing(I, &why);
+    if (need > 0) {
+      ++n_bad;
+      if (n_bad <= 50) rep << "line " << lineno << ": " << line << "   ; " << need << " more wait state(s): " << (why ? why : "") << "\n";
+    }
+    hz.issue(I);
+  }
+  rep << "checked " << n_inst << " instructions (" << n_trans << " transcendental, " << n_sgpr_w << " VALU writes of SGPR/VCC, " << n_nop
+      << " s_nop) against " << (sizeof(kHazards) / sizeof(kHazards[0])) << " rules: " << n_bad << " violation(s)\n";
+  report = rep.str();
+  return (int)n_bad;
+}
+
+std::string isa_hazard_table() {
+  std::ostringstream os;
+  for (const HzRule &R : kHazards) os << R.wait << " wait state(s): " << R.what << "\n";
+  return os.str();
+}
 
 // One code object: the W = 1 kernel `kname`, and, when prog2 is given, the two-samples-per-lane kernel
 // `kname`_w2 next to it.

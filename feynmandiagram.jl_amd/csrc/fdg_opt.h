@@ -101,4 +101,8 @@ bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp>
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2 = nullptr,
                      const OptProgram *prog_acc = nullptr);
 
+// gfx950 wait-state table of the emitter (fdg_isa.cpp): check of a finished listing, and the table as text
+int check_isa_hazards(const std::string &text, std::string &report);
+std::string isa_hazard_table();
+
 }  // namespace fdg

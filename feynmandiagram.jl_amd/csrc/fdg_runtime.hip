@@ -1506,6 +1506,20 @@ int fdg_eval(fdg_graph *g, const double *leaf, double *root, int64_t B) {
   return rc;
 }
 
+int fdg_isa_check_hazards(const char *asm_text, char **report) {
+  if (!asm_text) { set_error("null argument"); return FDG_E_INVALID; }
+  std::string rep;
+  const int n = fdg::check_isa_hazards(asm_text, rep);
+  if (report) {
+    const std::string all = fdg::isa_hazard_table() + rep;
+    char *m = (char *)std::malloc(all.size() + 1);
+    if (!m) { set_error("out of memory"); return FDG_E_NOMEM; }
+    std::memcpy(m, all.c_str(), all.size() + 1);
+    *report = m;
+  }
+  return n;
+}
+
 int fdg_copy_device(double *d_dst, const double *d_src, int64_t n, void *stream) {
   if (n < 0 || (n & 1)) { set_error("fdg_copy_device: n must be even and >= 0"); return FDG_E_INVALID; }
   if (n == 0) return FDG_OK;

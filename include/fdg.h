@@ -219,6 +219,13 @@ int fdg_fill_uniform_device(double *d_leaf, int64_t n_sample, uint32_t n_leaf,
                             int64_t leaf_sample_stride, int64_t leaf_leaf_stride, uint64_t seed,
                             uint64_t sample_offset, void *stream);
 
+/* Checks a gfx950 assembly listing (e.g. the `.s` a FDG_SPEC_ISA | FDG_SPEC_KEEP_SOURCE specialisation leaves in the
+ * cache directory) against the wait-state table the ISA emitter itself uses (csrc/fdg_isa.cpp: trans result -> VALU,
+ * VALU write of SGPR/VCC -> VALU read / v_div_fmas / VMEM, VALU -> v_readlane, wide store data -> VALU overwrite).
+ * Returns the number of violations (0 = clean), < 0 on error; *report (optional, fdg_free) lists the rules, the
+ * violations and what was checked.  Host-only; no counterpart in the reference (its code generator emits Julia). */
+int fdg_isa_check_hazards(const char *asm_text, char **report);
+
 /* Harness only (bench.py's `roofline.measured_copy_gbs`): d_dst[0..n) = d_src[0..n), 16 bytes per lane,
  * n even, both pointers 16-byte aligned.  The box's own streaming ceiling next to the 8 TB/s spec
  * (the reference has no counterpart). */

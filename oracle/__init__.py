@@ -109,6 +109,16 @@ def root_scale(table, leaf) -> np.ndarray:
     return out
 
 
+def abs_graph_scale(table, leaf) -> np.ndarray:
+    """A_k(b): the graph evaluated on |leaf| with every factor replaced by its absolute value -- the sum of the absolute
+    values of all monomials of root k.  First-order error bound used where leaves themselves carry a rounding difference
+    (leaf formulas with another exp): a relative perturbation d of every leaf moves root k by at most deg * d * A_k."""
+    import copy
+    t = copy.copy(table)
+    t.child_fac = np.abs(np.asarray(table.child_fac, dtype=np.float64))
+    return eval_static(t, np.abs(np.asarray(leaf, dtype=np.float64)))
+
+
 def powi(x: float, n: int) -> float:
     return float(_load().oracle_powi(float(x), int(n)))
 

@@ -221,6 +221,27 @@ def test_allocated_program_replays_exactly(libfdg, name, budget):
     assert valu <= st["flops_alg"]          # factor -1 rides on source modifiers
 
 
+@pytest.mark.parametrize("name,window,cost", [("sigma4_standin", 1000, 4), ("sigma4_standin", 300, 8), ("gv_sigma4_taylor2", 200, 8),
+                                              ("synthetic_small", 40, 8), ("gv_sigma5", 100, 16)])
+def test_forget_and_recompute_replays_exactly(libfdg, monkeypatch, name, window, cost):
+    """FDG_REMAT_WINDOW: the value of a cheap node that has not been read for `window` ops is forgotten and computed
+    again by its next consumer (also inside the grouped schedule of the Taylor graphs).  Same operations on the same
+    operands: the replayed program still gives the oracle's bits, with more arithmetic and fewer spill slots."""
+    t = workloads.get(name)
+    h = capi.GraphHandle(t)
+    base_ops, _, _, base_mem = h.opt_program(n_reg=60, n_lds=10)
+    monkeypatch.setenv("FDG_REMAT_WINDOW", str(window))
+    monkeypatch.setenv("FDG_REMAT_COST", str(cost))
+    ops, nr, nl, nm = h.opt_program(n_reg=60, n_lds=10)
+    leaf = oracle.philox_uniform(9, t.n_leaf, 78)
+    got = replay(ops, nr, nl, nm, h.last_n_acc, leaf, t.n_root)
+    assert np.array_equal(got, oracle.eval_static(t, leaf))
+    valu = lambda o: int(np.isin(o["kind"], (5, 6, 7)).sum())
+    assert valu(ops) >= valu(base_ops)
+    if name == "sigma4_standin":
+        assert valu(ops) > valu(base_ops) and nm < base_mem
+
+
 def test_isa_jit_assembles_without_device(libfdg, tmp_path):
     t = workloads.get("gv_sigma4")
     h = capi.GraphHandle(t)

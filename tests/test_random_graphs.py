@@ -89,6 +89,79 @@ def test_random_graphs_on_device(libfdg, cuda):
                 assert same(got, want), (seed, spec, layout)
 
 
+def fuzz_table(seed: int):
+    """Larger random DAGs for the register-pressure fuzz: up to 200 leaves and 1500 nodes, operands near or far."""
+    rng = np.random.default_rng(seed)
+    L = int(rng.integers(1, 200))
+    N = int(rng.choice([5, 40, 300, 1500]))
+    facs = [1.0, 1.0, 1.0, -1.0, -1.0, 2.0, -0.5, 0.25, 3.0, -7.5, 1e-3, 1.0 / 3.0]
+    nodes = []
+    for n in range(N):
+        nv = L + n
+        r = rng.random()
+        if r < 0.05:
+            nodes.append((OP_POWER, int(rng.choice([2, 3])), [(int(rng.integers(0, nv)), float(rng.choice(facs)))]))
+            continue
+        op = OP_SUM if r < 0.45 else OP_PROD
+        k = int(rng.choice([1, 2, 2, 2, 3, 3, 4, 7, 30]))
+        spread = float(rng.choice([3, 20, 200]))
+        ch = [(int(nv - 1 - min(nv - 1, int(rng.exponential(spread)))) if rng.random() < 0.7 else int(rng.integers(0, nv)),
+               float(rng.choice(facs))) for _ in range(k)]
+        nodes.append((op, 0, ch))
+    R = int(rng.integers(1, 8))
+    roots = [int(rng.integers(0, L + N)) for _ in range(R)]
+    roots[0] = L + N - 1
+    return from_program(L, nodes, roots, f"fuzz_{seed}"), rng
+
+
+FUZZ_SEEDS = list(range(1000, 1056))
+
+
+@pytest.mark.gpu
+def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch):
+    """The optimizing back end under random register / LDS / AGPR budgets (spills through every level), value-numbering
+    windows, the forget-and-recompute window, and -- every fourth seed -- the two-samples-per-lane variant: evaluation in
+    both layouts bit for bit against the oracle, fused accumulation within the stated tolerance, and every listing clean
+    against the emitter's wait-state table.  (tools/gpu_fuzz.py is the open-ended version of this test.)"""
+    import glob
+    import torch
+    cache = tmp_path / "cache"
+    cache.mkdir(mode=0o700)
+    for seed in FUZZ_SEEDS:
+        t, rng = fuzz_table(seed)
+        B = int(rng.choice([1, 63, 64, 65, 700, 140_000]))
+        h_leaf = oracle.philox_uniform(B, t.n_leaf, seed) * 2 - 0.7
+        want = oracle.eval_static(t, h_leaf, np.full((B, t.n_root), 9.0))
+        opts = [dict(n_reg=int(rng.integers(6, 40)), n_lds=int(rng.integers(1, 30)), vn_window=int(rng.choice([1, 20, 200, 1000]))),
+                dict(n_reg=int(rng.integers(30, 120)), n_lds=int(rng.integers(1, 80)), n_acc=int(rng.integers(1, 124)))]
+        if seed % 4 == 0:
+            monkeypatch.setenv("FDG_ISA_W2", "1")
+            opts.append(None)
+        if seed % 3 == 0:
+            monkeypatch.setenv("FDG_REMAT_WINDOW", str(int(rng.choice([8, 60, 400]))))
+        for opt in opts:
+            f = fd.compile_table(t, specialize="isa", opt=opt, cache_dir=str(cache), flags=capi.FDG_SPEC_KEEP_SOURCE)
+            for layout in ("leaf_major", "sample_major"):
+                leaf = torch.from_numpy(np.ascontiguousarray(h_leaf.T)).to(cuda).t() if layout == "leaf_major" else torch.from_numpy(h_leaf).to(cuda)
+                root = torch.full((B, t.n_root), 9.0, dtype=torch.float64, device=cuda)
+                f(root, leaf)
+                torch.cuda.synchronize()
+                assert same(root.cpu().numpy(), want), (seed, opt, layout, B)
+            w = torch.rand(B, dtype=torch.float64, device=cuda)
+            acc = f.accumulate(leaf, w)
+            torch.cuda.synchronize()
+            if np.isfinite(want).all():
+                live = t.root_slot != FDG_NO_ROOT
+                wr = want * w.cpu().numpy()[:, None]
+                assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0))[live] <= 1e-12 * np.maximum(1.0, np.abs(wr).sum(0))[live]), (seed, opt)
+        monkeypatch.delenv("FDG_ISA_W2", raising=False)
+        monkeypatch.delenv("FDG_REMAT_WINDOW", raising=False)
+        for lst in glob.glob(str(cache / "*.s")):
+            n, rep = capi.isa_check_hazards(open(lst).read())
+            assert n == 0, (seed, rep)
+            os.remove(lst)
+
+
 # --------------------------------------------------------------------------- #
 # one-kernel Monte-Carlo step on random graphs over random leaf tables
 # --------------------------------------------------------------------------- #
