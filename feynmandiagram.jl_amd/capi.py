@@ -29,7 +29,7 @@ EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
     "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
-    "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
+    "fdg_eval_strided", "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
 ]
@@ -122,6 +122,7 @@ def lib():
     L.fdg_graph_specialize.argtypes = [vp, C.c_char_p, C.c_uint]
     L.fdg_eval_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, i64, vp]
     L.fdg_eval.argtypes = [vp, dp, dp, i64]
+    L.fdg_eval_strided.argtypes = [vp, dp, i64, i64, dp, i64, i64, i64]
     L.fdg_accumulate_device.argtypes = [vp, dp, i64, i64, dp, dp, i64, vp]
     L.fdg_fill_uniform_device.argtypes = [dp, i64, u32, i64, i64, u64, u64, vp]
     L.fdg_copy_device.argtypes = [dp, dp, i64, vp]
@@ -269,17 +270,21 @@ class GraphHandle:
         check(lib().fdg_mc_accumulate_device(self._h, d_K, ks, kc, d_T, ts, tc, kF, beta, lam, d_weight or None, d_acc, B, stream))
 
     def eval_host(self, leaf: np.ndarray, root: Optional[np.ndarray] = None) -> np.ndarray:
-        leaf = np.ascontiguousarray(leaf, dtype=np.float64)
+        """Host matrices ``leaf [B, >= L]`` -> ``root [B, R]``, each C-ordered (compile_Python's row-major layout) or
+        Fortran-ordered (what a Julia ``Matrix`` is); no transposition copy is made for either (fdg_eval_strided)."""
+        leaf = np.asarray(leaf, dtype=np.float64)
         if leaf.ndim != 2 or leaf.shape[1] < self.table.n_leaf:
             raise IndexError("BoundsError: leafVal has fewer columns than the graph has leaves")
-        if leaf.shape[1] != self.table.n_leaf:
-            leaf = np.ascontiguousarray(leaf[:, :self.table.n_leaf])
+        if not (leaf.flags.c_contiguous or leaf.flags.f_contiguous):
+            leaf = np.ascontiguousarray(leaf)
         B = leaf.shape[0]
         if root is None:
-            root = np.zeros((B, self.table.n_root), dtype=np.float64)
-        if root.dtype != np.float64 or not root.flags.c_contiguous or root.shape != (B, self.table.n_root):
-            raise ValueError("root must be a C-contiguous float64 [B, R] array")
-        check(lib().fdg_eval(self._h, leaf.ctypes.data, root.ctypes.data, B))
+            root = np.zeros((B, self.table.n_root), dtype=np.float64, order="C" if leaf.flags.c_contiguous else "F")
+        if root.dtype != np.float64 or not (root.flags.c_contiguous or root.flags.f_contiguous) or root.shape != (B, self.table.n_root):
+            raise ValueError("root must be a contiguous (C- or Fortran-ordered) float64 [B, R] array")
+        ss, ls = (leaf.shape[1], 1) if leaf.flags.c_contiguous else (1, B)
+        rs, rk = (self.table.n_root, 1) if root.flags.c_contiguous else (1, B)
+        check(lib().fdg_eval_strided(self._h, leaf.ctypes.data, ss, ls, root.ctypes.data, rs, rk, B))
         return root
 
     def release_device(self):

@@ -90,10 +90,12 @@ class GraphFunc:
         return float(root_row[k])
 
     def _emission_rank(self, v: int):
+        """Position of value v's statement in the emitted text: internal node n is the (n+1)-th internal statement; a
+        leaf's load comes after ``leaf_pos`` internal statements (and after the loads of lower-numbered leaves there)."""
         L = self.table.n_leaf
         if v >= L:
-            return (v - L + 1, 1)
-        return (int(self.table.leaf_positions()[v]), 0) if L else (0, 0)
+            return (v - L + 1, 0, 0)
+        return (int(self.table.leaf_positions()[v]), 1, v) if L else (0, 1, v)
 
     # -- the call ------------------------------------------------------------- #
     def __call__(self, root, leafVal):
@@ -115,9 +117,9 @@ class GraphFunc:
         B = leaf.shape[0]
         if root is None:
             root = np.zeros((B, self.n_root), dtype=np.float64)
-        if not (isinstance(root, np.ndarray) and root.dtype == np.float64 and root.flags.c_contiguous
+        if not (isinstance(root, np.ndarray) and root.dtype == np.float64 and (root.flags.c_contiguous or root.flags.f_contiguous)
                 and root.shape == (B, self.n_root)):
-            raise ValueError("root must be a C-contiguous float64 array of shape [B, R]")
+            raise ValueError("root must be a contiguous float64 array of shape [B, R]")
         self.handle.eval_host(leaf, root)
         return root
 

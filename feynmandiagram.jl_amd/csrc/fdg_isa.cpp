@@ -396,9 +396,11 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const std::string vwgt = vacc(p.R), vtmp = vacc(p.R + 1);
   // programs with leaf formulas: two more temporaries (register pairs) above those
   bool has_macro = false;
-  for (const MOp &o : prog.ops) if (mop_is_macro(o.kind)) { has_macro = true; break; }
+  uint32_t n_tmp_pairs = 0;
+  for (const MOp &o : prog.ops) { if (mop_is_macro(o.kind)) has_macro = true; n_tmp_pairs = std::max(n_tmp_pairs, mop_tmp_pairs(o.kind)); }
   const uint32_t tmp0 = acc0 + (accumulate ? 2 * (p.R + 2) : 0);
-  const std::string tA = "v[" + std::to_string(tmp0) + ":" + std::to_string(tmp0 + 1) + "]", tB = "v[" + std::to_string(tmp0 + 2) + ":" + std::to_string(tmp0 + 3) + "]";
+  auto tpair = [&](uint32_t k) { return "v[" + std::to_string(tmp0 + 2 * k) + ":" + std::to_string(tmp0 + 2 * k + 1) + "]"; };
+  const std::string tA = tpair(0), tB = tpair(1), tC = tpair(2), tD = tpair(3);
   auto tAd = [&](int h) { return "v" + std::to_string(tmp0 + h); };
   if (accumulate)
     for (uint32_t k = 0; k < p.R; ++k) {
@@ -446,7 +448,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     std::map<uint64_t, int> hist;
     auto count = [&](double f) { bool inl; f64_inline(f, inl); if (!inl) { uint64_t u; std::memcpy(&u, &f, 8); hist[u]++; } };
     for (const MOp &o : prog.ops) {
-      if ((o.kind == M_MULC || o.kind == M_FMAC || o.kind == M_ADDC || o.kind == M_FIXZ || o.kind == M_SELC) && !o.param) count(o.imm);
+      if ((o.kind == M_MULC || o.kind == M_FMAC || o.kind == M_ADDC || o.kind == M_FIXZ || o.kind == M_SELC || o.kind == M_FMAK) && !o.param) count(o.imm);
       if (o.kind == M_EXP) { count(kLog2e); count(-kLn2Hi); count(-kLn2Lo); for (int k = 0; k <= kExpDeg; ++k) count(kExpC[k]); }
     }
     std::vector<std::pair<int, uint64_t>> v;
@@ -567,7 +569,9 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       case M_MUL: case M_ADD: use(q.a); use(q.b); use(q.d); break;
       case M_FMA: use(q.a); use(q.b); use(q.c); use(q.d); break;
       case M_FMAC: use(q.a); use(q.c); use(q.d); break;
-      case M_MULC: case M_MOV: case M_ADDC: case M_EXP: case M_RCP: case M_FIXZ: case M_SELC: use(q.a); use(q.d); break;
+      case M_MULC: case M_MOV: case M_ADDC: case M_EXP: case M_RCP: case M_FIXZ: case M_SELC: case M_DIV1: use(q.a); use(q.d); break;
+      case M_CONST: use(q.d); break;
+      case M_FMAK: use(q.a); use(q.b); use(q.d); break;
       case M_SEL: use(q.a); use(q.b); use(q.c); use(q.d); break;
       default: break;
     }
@@ -688,12 +692,48 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         E.wait_reg(o.b);
         E.wait_reg(o.c);
         E.wait_reg(o.d);
+        if (o.imm == 2.0) {      // isfinite: classes -normal .. +normal (bits 3..8)
+          E.ins("s_mov_b32 " + S(S_C) + ", 0x1f8");
+          E.ins("v_cmp_class_f64_e64 vcc, " + vlo(o.c) + ", " + S(S_C));
+        } else
         E.ins(std::string(o.imm != 0.0 ? "v_cmp_ge_f64_e64" : "v_cmp_gt_f64_e64") + " vcc, " + (o.negc ? "-" : "") + vlo(o.c) + ", 0");
         std::string ahi = vd(o.a, 1), bhi = vd(o.b, 1);
         if (o.nega) { E.ins("v_xor_b32_e32 " + tAd(0) + ", 0x80000000, " + ahi); ahi = tAd(0); }
         if (o.negb) { E.ins("v_xor_b32_e32 " + tAd(1) + ", 0x80000000, " + bhi); bhi = tAd(1); }
         E.ins("v_cndmask_b32_e32 " + vd(o.d, 0) + ", " + vd(o.b, 0) + ", " + vd(o.a, 0) + ", vcc");
         E.ins("v_cndmask_b32_e32 " + vd(o.d, 1) + ", " + bhi + ", " + ahi + ", vcc");
+        break;
+      }
+      case M_FMAK: {  // d = a * b + imm, one rounding (pow_body's fma with a constant addend)
+        E.wait_reg(o.a);
+        E.wait_reg(o.b);
+        E.wait_reg(o.d);
+        E.ins("v_fma_f64 " + vlo(o.d) + ", " + (o.nega ? "-" : "") + vlo(o.a) + ", " + (o.negb ? "-" : "") + vlo(o.b) + ", " + op_const(o));
+        break;
+      }
+      case M_CONST: {
+        E.wait_reg(o.d);
+        uint64_t u;
+        std::memcpy(&u, &o.imm, 8);
+        E.ins("v_mov_b32_e32 " + vd(o.d, 0) + ", " + hex32((uint32_t)u));
+        E.ins("v_mov_b32_e32 " + vd(o.d, 1) + ", " + hex32((uint32_t)(u >> 32)));
+        break;
+      }
+      case M_DIV1: {  // d = 1.0 / a, correctly rounded: the sequence the compiler emits for an fp64 division
+        E.wait_reg(o.a);
+        E.wait_reg(o.d);
+        const std::string x = vlo(o.a);
+        E.ins("v_div_scale_f64 " + tA + ", " + S2(S_X) + ", " + x + ", " + x + ", 1.0");
+        E.ins("v_rcp_f64_e32 " + tB + ", " + tA);
+        E.ins("v_div_scale_f64 " + tC + ", vcc, 1.0, " + x + ", 1.0");
+        E.ins("v_fma_f64 " + tD + ", -" + tA + ", " + tB + ", 1.0");
+        E.ins("v_fma_f64 " + tB + ", " + tB + ", " + tD + ", " + tB);
+        E.ins("v_fma_f64 " + tD + ", -" + tA + ", " + tB + ", 1.0");
+        E.ins("v_fma_f64 " + tB + ", " + tB + ", " + tD + ", " + tB);
+        E.ins("v_mul_f64 " + tD + ", " + tC + ", " + tB);
+        E.ins("v_fma_f64 " + tA + ", -" + tA + ", " + tD + ", " + tC);
+        E.ins("v_div_fmas_f64 " + tA + ", " + tA + ", " + tB + ", " + tD);
+        E.ins("v_div_fixup_f64 " + vlo(o.d) + ", " + tA + ", " + x + ", 1.0");
         break;
       }
       case M_FIXZ: {  // d = a == 0 ? imm : a
@@ -824,7 +864,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_endpgm");
 
   // ---- kernel descriptor -------------------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + (has_macro ? 4 : 0), 8);
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs, 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
   const uint32_t n_agpr = RW * prog.n_acc_used;
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";

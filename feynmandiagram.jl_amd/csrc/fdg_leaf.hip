@@ -369,8 +369,8 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
   if (!g) { set_error("null handle"); return FDG_E_INVALID; }
   { const int rc0 = check_leaf_tables(tab); if (rc0) return rc0; }
   if (tab->n_leaf != g->prog.L) { set_error("leaf tables describe " + std::to_string(tab->n_leaf) + " leaves, the graph has " + std::to_string(g->prog.L)); return FDG_E_INVALID; }
-  // interaction counter-terms above order 3 need pow_body: only the table-driven leaf kernel has it, so such tables take
-  // the leaf kernel + evaluator route whatever the size of the graph
+  // interaction counter-terms above order 3 need pow_body: the table-driven leaf kernel and the one-kernel route of the
+  // optimizing back end have it, the compiler-scheduled fused kernel (route 1) does not
   bool high_order = false;
   for (uint32_t i = 0; i < tab->n_leaf; ++i) high_order = high_order || (tab->leaf_type[i] == 2 && tab->leaf_order[i] > 3);
   std::lock_guard<std::mutex> lk(g->mu);
@@ -383,9 +383,9 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
     const char *env = std::getenv("FDG_MC_ROUTE");
     const bool env_fused = env && std::strcmp(env, "fused") == 0, env_split = env && std::strcmp(env, "split") == 0,
                env_isa = env && std::strcmp(env, "isa") == 0;
-    if (high_order && (env_fused || env_isa)) { set_error("interaction order > 3 is covered by the leaf kernel + evaluator route only (FDG_MC_ROUTE=split or unset)"); return FDG_E_UNSUPPORTED; }
+    if (high_order && env_fused) { set_error("interaction order > 3 is not covered by the fused HIP kernel (FDG_MC_ROUTE=isa, split or unset)"); return FDG_E_UNSUPPORTED; }
     const bool big = (g->prog.flops_alg > 6000 || env_split || high_order) && !env_fused;
-    const bool try_isa = !high_order && (env_isa || (g->isa && g->prog.flops_alg > 300 && !env_fused && !env_split));
+    const bool try_isa = env_isa || (g->isa && g->prog.flops_alg > 300 && !env_fused && !env_split);
     const int32_t *src5[5] = {tab->leaf_type, tab->leaf_order, tab->tau_in, tab->tau_out, tab->loop_index};
     for (int k = 0; k < 5; ++k) g->lt_i32[k].assign(src5[k], src5[k] + tab->n_leaf);
     g->lt_basis.assign(tab->basis, tab->basis + (size_t)tab->n_basis * tab->n_loop);

@@ -5,6 +5,7 @@
 // operand (x * -1.0 == -x exactly).
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -80,9 +81,11 @@ struct Builder {
   uint32_t remat_cost = 8;
   std::vector<uint8_t> remat_ok;   // [N]
   uint64_t n_remat = 0;
+  uint64_t remat_limit = 0;        // recomputation can cascade (a forgotten node whose operands are forgotten too ...): once the
+                                   // program has grown to this many ops nothing is forgotten any more
   bool available(uint32_t c) const {
     if (ref_of[c] == NONE) return false;
-    if (!remat_window || c < p.L || !remat_ok[c - p.L]) return true;
+    if (!remat_window || c < p.L || !remat_ok[c - p.L] || u.size() > remat_limit) return true;
     const uint32_t v = ref_of[c] >> 1;
     return v >= born.size() || (uint64_t)u.size() - born[v] <= remat_window;
   }
@@ -150,7 +153,13 @@ struct Builder {
   }
   uint32_t addc(uint32_t a, double f, uint8_t param = 0) { return opx(M_ADDC, a, 0, 0, f, param); }
   uint32_t mulp(uint32_t a, double f, uint8_t param) { return opx(M_MULC, a & ~1u, 0, 0, f, param) | (a & 1u); }   // times a parameter
-  uint32_t rcp(uint32_t a) { return opx(M_RCP, a & ~1u, 0, 0, 0.0) | (a & 1u); }          // 1/(-x) == -(1/x)
+  // 1/(-x) == -(1/x).  A correctly rounded division (the oracle's and the leaf kernels' `1.0 / x`), not v_rcp_f64 + Newton
+  // steps: five more instructions per quotient, and the quotients are then the reference's bits (FDG_MC_RCP_NEWTON=1: the
+  // round-1 form, within an ulp)
+  uint32_t rcp(uint32_t a) {
+    static const bool newton = std::getenv("FDG_MC_RCP_NEWTON") != nullptr;
+    return opx(newton ? M_RCP : M_DIV1, a & ~1u, 0, 0, 0.0) | (a & 1u);
+  }
   // cond(c) ? a : b, cond = c > 0 (ge false) or c >= 0
   uint32_t sel(uint32_t c, uint32_t a, uint32_t b, bool ge) {
     if (a == b) return a;
@@ -161,6 +170,85 @@ struct Builder {
   uint32_t add(uint32_t a, uint32_t b) { return op2(M_ADD, a, b); }
   uint32_t in_k(uint32_t c) const { return (in_base + c) << 1; }
   uint32_t in_t(int32_t i) const { return (in_base + n_k + (uint32_t)(i - 1)) << 1; }
+
+  // ---- integer powers beyond x*x and x*x*x: Base.Math.pow_body spelled out (csrc/fdg_powi.h is the scalar form) ----
+  // A quantity is a value of the program or a constant known here (y = 1, the low words = 0 until the loop fills them);
+  // operations on constants alone are done here, in the same IEEE arithmetic the device uses.
+  struct PV { bool k; double c; uint32_t r; };
+  static PV pv(uint32_t r) { return PV{false, 0.0, r}; }
+  static PV pk(double c) { return PV{true, c, 0}; }
+  static PV pneg(PV a) { return a.k ? pk(-a.c) : pv(a.r ^ 1u); }
+  PV pmul(PV a, PV b) {
+    if (a.k && b.k) return pk(a.c * b.c);
+    if (a.k) std::swap(a, b);
+    if (b.k) return pv(mulc(a.r, b.c));                 // x * 1.0 == x, x * -1.0 == -x exactly: mulc's shortcuts are safe
+    return pv(mul(a.r, b.r));
+  }
+  PV padd(PV a, PV b) {
+    if (a.k && b.k) return pk(a.c + b.c);
+    if (a.k) std::swap(a, b);
+    if (b.k) return pv(opx(M_ADDC, a.r, 0, 0, b.c));    // never elided: (-0) + 0 is +0
+    return pv(add(a.r, b.r));
+  }
+  PV pfma(PV a, PV b, PV c) {                           // a * b + c, one rounding
+    if (a.k && b.k) {
+      const double prod = a.c * b.c;
+      if (std::fma(a.c, b.c, -prod) != 0.0 || !std::isfinite(prod)) { ok = false; why = "pow_body: inexact constant product"; return c; }
+      return padd(c, pk(prod));                          // an exact product: fma(a, b, c) == (a b) + c
+    }
+    if (a.k) std::swap(a, b);
+    if (b.k) {
+      if (c.k) {
+        if (b.c == 1.0) return padd(a, c);               // fma(x, 1, c) == x + c
+        ok = false; why = "pow_body: x * const + const"; return a;
+      }
+      return pv(opx(M_FMAC, a.r, 0, c.r, b.c));
+    }
+    if (c.k) return pv(opx(M_FMAK, a.r, b.r, 0, c.c));
+    return pv(opx(M_FMA, a.r, b.r, c.r, 0.0));
+  }
+  PV pdiv1(PV x) { return pv(opx(M_DIV1, x.r & ~1u, 0, 0, 0.0) | (x.r & 1u)); }       // 1 / (-x) == -(1 / x)
+  PV psel_finite(PV test, PV a, PV b, uint32_t anchor) {   // isfinite(test) ? a : b
+    if (a.k) a = pv(opx(M_CONST, anchor & ~1u, 0, 0, a.c));
+    if (b.k) b = pv(opx(M_CONST, anchor & ~1u, 0, 0, b.c));
+    if (a.r == b.r) return a;
+    return pv(opx(M_SEL, a.r, b.r, test.r & ~1u, 2.0));
+  }
+  // value of x^n for a literal n as the reference's generated code computes it (static.jl:45: `(g)^N`; Base.literal_pow, then
+  // pow_body for every n it has no shortcut for)
+  uint32_t powi(uint32_t xr, int32_t n) {
+    if (n == 2) return mul(xr, xr);
+    if (n == 3) return mul(mul(xr, xr), xr);
+    PV x = pv(xr), y = pk(1.0), xnlo = pk(0.0), ynlo = pk(0.0);
+    if (n == -1) return pdiv1(x).r;
+    if (n == -2) { const PV r = pdiv1(x); return pmul(r, r).r; }
+    int64_t m = n;
+    if (m < 0) {
+      const PV rx = pdiv1(x);
+      const PV lo = pmul(pneg(pfma(x, rx, pk(-1.0))), rx);
+      xnlo = psel_finite(x, lo, pk(0.0), xr);             // if (isfinite(x)) xnlo = -fma(x, rx, -1.0) * rx
+      x = rx;
+      m = -m;
+    }
+    while (m > 1) {
+      if (m & 1) {
+        const PV err = pfma(y, xnlo, pmul(x, ynlo));
+        const PV yh = pmul(x, y), yl = pfma(x, y, pneg(yh));
+        y = yh;
+        ynlo = padd(yl, err);
+      }
+      const PV err = pmul(pmul(x, pk(2.0)), xnlo);
+      const PV xh = pmul(x, x), xl = pfma(x, x, pneg(xh));
+      x = xh;
+      xnlo = padd(xl, err);
+      m >>= 1;
+    }
+    const PV err = pfma(y, xnlo, pmul(x, ynlo));
+    const PV r1 = pfma(x, y, err), r2 = pmul(x, y);
+    // (isfinite(x) && isfinite(err)) ? fma(x, y, err) : x * y
+    const PV inner = err.k ? (std::isfinite(err.c) ? r1 : r2) : psel_finite(err, r1, r2, xr);
+    return psel_finite(x, inner, r2, xr).r;
+  }
 
   struct Mom { uint32_t q2 = NONE, w = NONE, g = NONE, bsel = NONE; };
   struct Tau { uint32_t tf = NONE, u = NONE, v = NONE; };
@@ -211,14 +299,14 @@ struct Builder {
     const fdg_leaf_tables *t = mc->tab;
     const int32_t ty = t->leaf_type[i], n = t->leaf_order[i], li = t->loop_index[i];
     if (ty == 2) {                                                  // 8 pi / invK * (lambda invK)^n, invK = 1 / (q2 + lambda)
-      if (n < 0 || n > 3) { ok = false; why = "interaction counter-term of order above 3"; return in_k(0); }
+      if (n < 0) { ok = false; why = "interaction counter-term of negative order"; return in_k(0); }
       Mom &m = momentum(li);
       if (!ok) return in_k(0);
       const uint32_t s = addc(m.q2, mc->lambda, MC_P_LAMBDA);
       uint32_t v = mulc(s, 8.0 * 3.141592653589793);
       if (n) {
         const uint32_t x = mulp(rcp(s), mc->lambda, MC_P_LAMBDA);
-        v = mul(v, n == 1 ? x : (n == 2 ? mul(x, x) : mul(mul(x, x), x)));
+        v = mul(v, n == 1 ? x : powi(x, n));                        // (lambda invK)^n: literal_pow for n <= 3, pow_body above (as fdg_leaf.hip)
       }
       return v;
     }
@@ -341,10 +429,7 @@ void build_uops(Builder &B) {
       acc = (f.i == 0) ? cr : B.op2(M_MUL, acc, cr);           // ((acc * c_i) * f_i)  (static.jl:28)
       acc = B.mulc(acc, fc);
     } else {  // Power: exactly one child
-      const int32_t N = p.power[n];
-      if (N == 2) acc = B.op2(M_MUL, cr, cr);
-      else if (N == 3) acc = B.op2(M_MUL, B.op2(M_MUL, cr, cr), cr);
-      else { B.ok = false; B.why = "Power{N} with N outside {2,3}"; acc = cr; }
+      acc = B.powi(cr, p.power[n]);                            // (c)^N   (static.jl:34-46)
       acc = B.mulc(acc, fc);
     }
     f.acc = acc;
@@ -372,6 +457,7 @@ void build_uops(Builder &B) {
     }
   };
   if (B.remat_window) {
+    B.remat_limit = 4 * (p.flops_alg + p.N) + 1000;
     B.remat_ok.assign(p.N, 0);
     const char *ce = std::getenv("FDG_REMAT_COST");
     const uint32_t max_cost = ce ? (uint32_t)std::atoi(ce) : B.remat_cost;
@@ -679,7 +765,8 @@ struct Alloc {
       reg_of[o.d] = rd; owner[rd] = o.d; lock[rd] = j;
       if (o.kind == M_MULC) out.push_back(MOp{M_MULC, (uint8_t)(o.a & 1), 0, rd, ra, 0, o.imm});
       else if (o.kind == M_SELC) out.push_back(MOp{M_SELC, (uint8_t)(o.a & 1), (uint8_t)(o.b ? 1 : 0), rd, ra, 0, o.imm});
-      else if (o.kind == M_ADDC || o.kind == M_EXP || o.kind == M_RCP || o.kind == M_FIXZ) out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), 0, rd, ra, 0, o.imm});
+      else if (o.kind == M_ADDC || o.kind == M_EXP || o.kind == M_RCP || o.kind == M_FIXZ || o.kind == M_DIV1 || o.kind == M_CONST) out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), 0, rd, ra, 0, o.imm});
+      else if (o.kind == M_FMAK) out.push_back(MOp{M_FMAK, (uint8_t)(o.a & 1), (uint8_t)(o.b & 1), rd, ra, rb, o.imm});
       else if (three) out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), (uint8_t)(two ? (o.b & 1) : 0), rd, ra, rb, o.imm, (uint8_t)(o.c & 1), rc});
       else out.push_back(MOp{o.kind, (uint8_t)(o.a & 1), (uint8_t)(o.b & 1), rd, ra, rb, 0.0});
       out.back().param = o.param;
@@ -726,7 +813,8 @@ void hoist_loads(std::vector<MOp> &ops, const OptParams &prm) {
       case M_MUL: case M_ADD: touch(o.a); touch(o.b); touch(o.d); break;
       case M_FMA: touch(o.a); touch(o.b); touch(o.c); touch(o.d); break;
       case M_FMAC: touch(o.a); touch(o.c); touch(o.d); break;
-      case M_MULC: case M_MOV: case M_ADDC: case M_EXP: case M_RCP: case M_FIXZ: case M_SELC: touch(o.a); touch(o.d); break;
+      case M_MULC: case M_MOV: case M_ADDC: case M_EXP: case M_RCP: case M_FIXZ: case M_SELC: case M_DIV1: case M_CONST: touch(o.a); touch(o.d); break;
+      case M_FMAK: touch(o.a); touch(o.b); touch(o.d); break;
       case M_SEL: touch(o.a); touch(o.b); touch(o.c); touch(o.d); break;
       case M_ROOT: touch(o.a); break;
       case M_LD_ACC: touch(o.d); break;
@@ -762,6 +850,16 @@ void sort_load_runs(std::vector<MOp> &ops) {
 
 }  // namespace
 
+// architectural VGPRs end at v255: 6 fixed, the values, what the kernel variant reserves, the macro ops' temporaries
+static bool fit_registers(const std::vector<UOp> &u, const OptParams &prm, OptProgram &out) {
+  uint32_t tmp_pairs = 0;
+  for (const UOp &o : u) tmp_pairs = std::max(tmp_pairs, mop_tmp_pairs(o.kind));
+  if (tmp_pairs + prm.reserve_pairs + 8 > 125) { out.supported = false; out.why = "too few registers"; return false; }
+  out.params = prm;
+  out.params.n_reg = std::min<uint32_t>(prm.n_reg, 125 - tmp_pairs - prm.reserve_pairs);
+  return true;
+}
+
 void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) {
   out = OptProgram();
   out.params = prm;
@@ -783,10 +881,11 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   if (!B.ok) return;
   if (prm.n_reg < 4) { out.supported = false; out.why = "too few registers"; return; }
   if (prm.fma) fuse_fma(B.u, B.next_vid);
-  Alloc A(p, prm, B.u, B.next_vid, out);
+  if (!fit_registers(B.u, prm, out)) return;
+  Alloc A(p, out.params, B.u, B.next_vid, out);
   A.run();
   out.ops.swap(A.out);
-  hoist_loads(out.ops, prm);
+  hoist_loads(out.ops, out.params);
   sort_load_runs(out.ops);
 }
 
@@ -806,12 +905,13 @@ void build_mc_program(const Lowered &p, const LeafSpec &ls, const OptParams &prm
     if (!B.ok) return;
     if (prm.n_reg < 4) { out.supported = false; out.why = "too few registers"; return; }
     if (prm.fma) fuse_fma(B.u, B.next_vid);
-    Alloc A(p, prm, B.u, B.next_vid, out);
+    if (!fit_registers(B.u, prm, out)) return;
+    Alloc A(p, out.params, B.u, B.next_vid, out);
     A.leaf_lo = B.in_base; A.leaf_n = B.n_in;
     out.mc_n_k = B.n_k; out.mc_n_t = B.n_in - B.n_k;
     A.run();
     out.ops.swap(A.out);
-    hoist_loads(out.ops, prm);
+    hoist_loads(out.ops, out.params);
     sort_load_runs(out.ops);
     return;
   }

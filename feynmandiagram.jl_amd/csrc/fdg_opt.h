@@ -40,10 +40,17 @@ enum MKind : uint8_t {
   M_SEL = 19,     // r[d] = cond(+-r[c]) ? +-r[a] : +-r[b]    cond: x > 0 (imm = 0) or x >= 0 (imm = 1)
   M_FIXZ = 20,    // r[d] = r[a] == 0 ? imm : r[a]
   M_SELC = 21,    // r[d] = cond(+-r[a]) ? imm : -imm         cond as M_SEL, selected by negb
+  // ---- Power{N} with N outside {2, 3} and counter-terms above order 3: Julia's pow_body spelled out (fdg_powi.h); exact ----
+  M_FMAK = 22,    // r[d] = (+-r[a]) * (+-r[b]) + imm        one rounding, as the reference's fma / muladd
+  M_DIV1 = 23,    // r[d] = 1.0 / (+-r[a])                    correctly rounded (v_div_scale / v_div_fmas / v_div_fixup)
+  M_CONST = 24,   // r[d] = imm                               (operand a is only a scheduling anchor)
+  // M_SEL with imm == 2: cond(x) = isfinite(x)
 };
-inline bool mop_has_b(uint8_t k) { return k == M_MUL || k == M_ADD || k == M_FMA || k == M_SEL; }
+inline bool mop_has_b(uint8_t k) { return k == M_MUL || k == M_ADD || k == M_FMA || k == M_SEL || k == M_FMAK; }
 inline bool mop_has_c(uint8_t k) { return k == M_FMA || k == M_FMAC || k == M_SEL; }
-inline bool mop_is_macro(uint8_t k) { return k >= M_EXP && k <= M_SELC; }   // needs the emitter's two temporaries
+inline bool mop_is_macro(uint8_t k) { return (k >= M_EXP && k <= M_SELC) || k == M_DIV1; }   // needs the emitter's temporaries
+inline uint32_t mop_tmp_pairs(uint8_t k) { return k == M_DIV1 ? 4u : (mop_is_macro(k) ? 2u : 0u); }
+inline bool mop_exact_fma(uint8_t k) { return k == M_FMAK; }   // (M_FMA / M_FMAC are exact too when pow_body asks for them; fast-math uses them as a contraction)
 
 struct MOp {
   uint8_t kind;
@@ -66,6 +73,8 @@ struct OptParams {
   uint32_t vn_window = 200;       // value numbering: 1 = off, 0 = reuse any earlier identical op, n > 1 = only results at most n ops old
   uint32_t lookahead_leaf = 300;  // ... for first-use loads of leaves (HBM)
   bool fma = false;               // FDG_SPEC_FAST_MATH: a product used once, by a sum, is fused into it (v_fma_f64)
+  uint32_t reserve_pairs = 0;     // VGPR pairs the kernel variant keeps above the values (accumulators, weight): the value budget shrinks
+                                  // by this and by the temporaries the program's macro ops need, so that everything stays below v256
 };
 
 struct OptProgram {

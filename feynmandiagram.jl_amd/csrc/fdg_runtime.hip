@@ -539,7 +539,9 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       // (2 extra HBM passes over the leaves; in-kernel LDS staging would avoid them -- DESIGN.md 8)
       // Chunks are double-buffered: the transposition of chunk c+1 (HBM-bound) runs on an internal
       // stream while the evaluator works on chunk c (fp64-bound for all but tiny graphs).
-      long Bc = std::max<long>((long)g->n_cu * 8 * 64 * 2, (long)((1ull << 29) / (8ull * p.L)));
+      unsigned long long chunk_bytes = 1ull << 29;
+      if (const char *cb = std::getenv("FDG_SM_CHUNK_MB")) chunk_bytes = (unsigned long long)std::max(1, std::atoi(cb)) << 20;
+      long Bc = std::max<long>((long)g->n_cu * 8 * 64 * 2, (long)(chunk_bytes / (8ull * p.L)));
       Bc = std::min<long>((Bc + 63) & ~63l, (B + 63) & ~63l);
       const size_t one = (size_t)Bc * p.L * sizeof(double);
       const size_t need3 = 2 * one;
@@ -965,8 +967,9 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
   g->fn_isa_w2 = nullptr;
   g->fn_isa_acc = nullptr;
   g->has_acc = prog_acc != nullptr;
+  auto tmp_vgprs = [](const fdg::OptProgram &q) { uint32_t t = 0; for (const fdg::MOp &o : q.ops) t = std::max(t, fdg::mop_tmp_pairs(o.kind)); return 2 * t; };
   if (prog_acc) {
-    g->isa3_vgpr = ((6 + 2 * std::max<uint32_t>(prog_acc->n_reg_used, 1) + 2 * (g->prog.R + 2) + 3) & ~3u) + 2 * prog_acc->n_acc_used;
+    g->isa3_vgpr = ((6 + 2 * std::max<uint32_t>(prog_acc->n_reg_used, 1) + 2 * (g->prog.R + 2) + tmp_vgprs(*prog_acc) + 3) & ~3u) + 2 * prog_acc->n_acc_used;
     g->isa3_lds_bytes = prog_acc->n_lds_used * 512u;
     g->isa3_mem_slots = prog_acc->n_mem_used;
   }
@@ -976,7 +979,7 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
     g->isa2_lds_bytes = prog2->n_lds_used * 1024u;
     g->isa2_mem_slots = prog2->n_mem_used;
   }
-  g->isa_vgpr = ((6 + 2 * std::max<uint32_t>(prog.n_reg_used, 1) + 3) & ~3u) + 2 * prog.n_acc_used;
+  g->isa_vgpr = ((6 + 2 * std::max<uint32_t>(prog.n_reg_used, 1) + tmp_vgprs(prog) + 3) & ~3u) + 2 * prog.n_acc_used;
   g->isa_lds_bytes = prog.n_lds_used * 512u;
   g->isa_mem_slots = prog.n_mem_used;
   g->spec_vgpr = g->isa_vgpr; g->spec_lds = g->isa_lds_bytes; g->spec_scratch = 0;
@@ -1046,6 +1049,8 @@ static bool auto_program_w2(const fdg_graph *g, fdg::OptProgram &p2) {
     ok = p2.supported && p2.n_ld_mem + p2.n_st_mem == 0;
   }
   if (!ok) return false;
+  for (const fdg::MOp &o : p2.ops)      // the wide kernel prints plain fold steps only
+    if (fdg::mop_is_macro(o.kind) || o.kind == fdg::M_FMAK || o.kind == fdg::M_CONST || o.kind == fdg::M_FMA || o.kind == fdg::M_FMAC) return false;
   const double t_hbm = 8.0 * ((double)p.L + p.R) / 5e12, t_valu = (double)p2.n_valu / 15e12;
   return t_hbm > 1.2 * t_valu;
 }
@@ -1064,6 +1069,7 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
   const uint32_t arch = std::min<uint32_t>(budget - 2 * chosen.n_acc, 256);   // architectural VGPRs end at v255
   if (arch < 6 + 2 * extra + 16) return false;
   q.n_reg = std::min<uint32_t>(chosen.n_reg, (arch - 6 - 2 * extra) / 2);
+  q.reserve_pairs = extra;
   build_prog(g, q, pa);
   return pa.supported;
 }
@@ -1285,7 +1291,7 @@ int fdg_mc_isa_build(fdg_graph *g) {
   bool has_acc = R >= 1 && R <= 16;
   if (has_acc) {
     fdg::OptParams qa = q;
-    qa.n_reg = std::min<uint32_t>(q.n_reg, (256 - 6 - 2 * (R + 2) - 4) / 2);
+    qa.reserve_pairs = R + 2;        // (build_mc_program takes the macro ops' temporaries off the value budget itself)
     fdg::build_mc_program(g->prog, ls, qa, pa);
     has_acc = pa.supported;
   }
@@ -1297,10 +1303,11 @@ int fdg_mc_isa_build(fdg_graph *g) {
   g->fn_mc = g->fn_mc_acc = nullptr;
   g->mc_code.swap(co);
   g->mc_has_acc = has_acc;
-  g->mc_vgpr[0] = ((6 + 2 * std::max<uint32_t>(pe.n_reg_used, 1) + 4 + 3) & ~3u) + 2 * pe.n_acc_used;
+  auto tmp_vgprs = [](const fdg::OptProgram &q) { uint32_t t = 0; for (const fdg::MOp &o : q.ops) t = std::max(t, fdg::mop_tmp_pairs(o.kind)); return 2 * t; };
+  g->mc_vgpr[0] = ((6 + 2 * std::max<uint32_t>(pe.n_reg_used, 1) + tmp_vgprs(pe) + 3) & ~3u) + 2 * pe.n_acc_used;
   g->mc_lds[0] = pe.n_lds_used * 512u; g->mc_mem[0] = pe.n_mem_used;
   if (has_acc) {
-    g->mc_vgpr[1] = ((6 + 2 * std::max<uint32_t>(pa.n_reg_used, 1) + 2 * (R + 2) + 4 + 3) & ~3u) + 2 * pa.n_acc_used;
+    g->mc_vgpr[1] = ((6 + 2 * std::max<uint32_t>(pa.n_reg_used, 1) + 2 * (R + 2) + tmp_vgprs(pa) + 3) & ~3u) + 2 * pa.n_acc_used;
     g->mc_lds[1] = pa.n_lds_used * 512u; g->mc_mem[1] = pa.n_mem_used;
   }
   g->mc_built = true;
@@ -1476,34 +1483,61 @@ int fdg_accumulate_device(fdg_graph *g, const double *d_leaf, int64_t ss, int64_
   return run(g, 1, d_leaf, ss, ls, nullptr, 0, 0, d_weight, d_acc, B, (hipStream_t)stream);
 }
 
-int fdg_eval(fdg_graph *g, const double *leaf, double *root, int64_t B) {
+// host <-> device copy of an [n x m] block of a strided host matrix (element (b, i) at h[b*hs + i*hi]) to / from the
+// device block d[b*ds + i*di]; one of (hs, hi) and the matching one of (ds, di) is 1
+static hipError_t copy_block(double *d, int64_t ds, int64_t di, const double *h, int64_t hs, int64_t hi, int64_t n, int64_t m, bool to_device) {
+  if (n == 0 || m == 0) return hipSuccess;
+  const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+  // rows = the slow index, width = the contiguous run
+  int64_t rows, width, hp, dp;
+  if (hi == 1 && di == 1) { rows = n; width = m; hp = hs; dp = ds; }          // sample-major: a sample's values are contiguous
+  else if (hs == 1 && ds == 1) { rows = m; width = n; hp = hi; dp = di; }     // leaf-major (a Julia column-major matrix)
+  else return hipErrorInvalidValue;
+  if (to_device) return hipMemcpy2D(d, (size_t)dp * 8, h, (size_t)hp * 8, (size_t)width * 8, (size_t)rows, kind);
+  return hipMemcpy2D(const_cast<double *>(h), (size_t)hp * 8, d, (size_t)dp * 8, (size_t)width * 8, (size_t)rows, kind);
+}
+
+int fdg_eval_strided(fdg_graph *g, const double *leaf, int64_t ss, int64_t ls, double *root, int64_t rs, int64_t rk, int64_t B) {
   if (!g) { set_error("null handle"); return FDG_E_INVALID; }
   if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
   if (B == 0) return FDG_OK;
-  const size_t L = g->prog.L, R = g->prog.R;
+  const int64_t L = g->prog.L, R = g->prog.R;
   if ((L && !leaf) || (R && !root)) { set_error("null host buffer"); return FDG_E_INVALID; }
+  const bool leaf_rows = ls == 1 && ss >= L, leaf_cols = ss == 1 && ls >= B;
+  const bool root_rows = rk == 1 && rs >= R, root_cols = rs == 1 && rk >= B;
+  if ((L && !leaf_rows && !leaf_cols) || (R && !root_rows && !root_cols)) {
+    set_error("host matrices must be row-major (value stride 1, sample stride >= row length) or column-major (sample stride 1, value stride >= n_sample)");
+    return FDG_E_INVALID;
+  }
   { std::lock_guard<std::mutex> lk(g->mu); int rc = ensure_device(g); if (rc) return rc; }
   // host buffers of any size: the batch goes through the device in chunks of at most ~2 GiB (FDG_EVAL_CHUNK
-  // samples overrides, for tests), so device memory bounds nothing
-  int64_t chunk = std::max<int64_t>(65536, (int64_t)((2ull << 30) / (8ull * std::max<size_t>(L + R, 1))));
+  // samples overrides, for tests), so device memory bounds nothing.  The device copy keeps the host's layout: a
+  // column-major (Julia) matrix arrives leaf-major, the layout the ISA kernel is built around -- no transposition anywhere.
+  int64_t chunk = std::max<int64_t>(65536, (int64_t)((2ull << 30) / (8ull * (uint64_t)std::max<int64_t>(L + R, 1))));
   if (const char *e = std::getenv("FDG_EVAL_CHUNK")) chunk = std::max<int64_t>(1, std::atoll(e));
   chunk = std::min<int64_t>(chunk, B);
   double *dl = nullptr, *dr = nullptr;
-  HIP_TRY(hipMalloc(&dl, std::max<size_t>(1, (size_t)chunk * L) * 8));
-  if (hipMalloc(&dr, std::max<size_t>(1, (size_t)chunk * R) * 8) != hipSuccess) { hipFree(dl); set_error("hipMalloc failed"); return FDG_E_NOMEM; }
+  HIP_TRY(hipMalloc(&dl, (size_t)std::max<int64_t>(1, chunk * L) * 8));
+  if (hipMalloc(&dr, (size_t)std::max<int64_t>(1, chunk * R) * 8) != hipSuccess) { hipFree(dl); set_error("hipMalloc failed"); return FDG_E_NOMEM; }
   int rc = FDG_OK;
   for (int64_t c0 = 0; c0 < B && rc == FDG_OK; c0 += chunk) {
     const int64_t n = std::min<int64_t>(chunk, B - c0);
-    if (L && hipMemcpy(dl, leaf + (size_t)c0 * L, (size_t)n * L * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = FDG_E_NO_DEVICE; break; }
+    const int64_t dss = leaf_rows ? L : 1, dls = leaf_rows ? 1 : n;     // device block: compact, same orientation
+    const int64_t drs = root_rows ? R : 1, drk = root_rows ? 1 : n;
+    if (L && copy_block(dl, dss, dls, leaf + c0 * ss, ss, ls, n, L, true) != hipSuccess) { set_error("H2D copy failed"); rc = FDG_E_NO_DEVICE; break; }
     // eval_graph! leaves root entries it does not assign untouched: start from the caller's values
-    if (R && hipMemcpy(dr, root + (size_t)c0 * R, (size_t)n * R * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = FDG_E_NO_DEVICE; break; }
-    rc = run(g, 0, dl, (int64_t)L, 1, dr, (int64_t)R, 1, nullptr, nullptr, n, nullptr);
+    if (R && copy_block(dr, drs, drk, root + c0 * rs, rs, rk, n, R, true) != hipSuccess) { set_error("H2D copy failed"); rc = FDG_E_NO_DEVICE; break; }
+    rc = run(g, 0, dl, dss, dls, dr, drs, drk, nullptr, nullptr, n, nullptr);
     if (rc) break;
     if (hipDeviceSynchronize() != hipSuccess) { set_error("kernel execution failed"); rc = FDG_E_NO_DEVICE; break; }
-    if (R && hipMemcpy(root + (size_t)c0 * R, dr, (size_t)n * R * 8, hipMemcpyDeviceToHost) != hipSuccess) { set_error("D2H copy failed"); rc = FDG_E_NO_DEVICE; break; }
+    if (R && copy_block(dr, drs, drk, root + c0 * rs, rs, rk, n, R, false) != hipSuccess) { set_error("D2H copy failed"); rc = FDG_E_NO_DEVICE; break; }
   }
   hipFree(dl); hipFree(dr);
   return rc;
+}
+
+int fdg_eval(fdg_graph *g, const double *leaf, double *root, int64_t B) {
+  return fdg_eval_strided(g, leaf, g ? (int64_t)g->prog.L : 0, 1, root, g ? (int64_t)g->prog.R : 0, 1, B);
 }
 
 int fdg_isa_check_hazards(const char *asm_text, char **report) {

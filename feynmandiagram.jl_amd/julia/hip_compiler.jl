@@ -75,6 +75,7 @@ function lower_to_table(graphs::AbstractVector{G}; root::AbstractVector{Int}=[id
     node_index = Dict{Int,Int}()      # id -> 0-based internal index
     leafmap = Dict{Int,G}()
     order = G[]
+    stmt_pos = Dict{Int,Int}()        # id -> position of its statement in the text to_julia_str would emit
     for graph in graphs
         for g in PostOrderDFS(graph)
             g_id = id(g)
@@ -88,6 +89,7 @@ function lower_to_table(graphs::AbstractVector{G}; root::AbstractVector{Int}=[id
                 node_index[g_id] = length(order)
                 push!(order, g)
             end
+            stmt_pos[g_id] = length(stmt_pos)
         end
     end
     L = length(leaf_index)
@@ -107,7 +109,7 @@ function lower_to_table(graphs::AbstractVector{G}; root::AbstractVector{Int}=[id
         findfirst(==(rid), root) == k || continue             # findfirst (static.jl:112)
         (haskey(leaf_index, rid) || haskey(node_index, rid)) || continue
         root_slot[k] = UInt32(vidx(rid))
-        rank = haskey(node_index, rid) ? node_index[rid] + L : leaf_index[rid] - L   # internal nodes are emitted after the leaves they need
+        rank = stmt_pos[rid]          # `root[k] = g` follows g's own statement (static.jl:126-128): the last one is the call's value
         if rank > last_rank
             last_rank, last_root = rank, k
         end
@@ -174,10 +176,11 @@ function (f::GraphFunc)(root::Matrix{Float64}, leafVal::Matrix{Float64})
     B = size(leafVal, 1)
     size(leafVal, 2) >= f.n_leaf || throw(BoundsError(leafVal, (1, f.n_leaf)))
     size(root) == (B, f.n_root) || throw(DimensionMismatch("root must be B x R"))
-    # fdg_eval takes row-major [B,L]; a Julia (L x B) matrix is exactly that
-    lt = permutedims(leafVal[:, 1:f.n_leaf]); rt = permutedims(root)
-    _fdg_check(ccall((:fdg_eval, _libfdg), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), f.handle, lt, rt, B))
-    root .= permutedims(rt)
+    # column-major matrices as they are: sample stride 1, value stride B (no transposition copy on either side;
+    # the device sees them leaf-major, the evaluator's fast layout)
+    _fdg_check(ccall((:fdg_eval_strided, _libfdg), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64, Int64),
+        f.handle, leafVal, 1, B, root, 1, B, B))
     return root
 end
 

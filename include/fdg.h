@@ -204,6 +204,13 @@ int fdg_eval_device(fdg_graph *g, const double *d_leaf, int64_t leaf_sample_stri
  * synchronous.  Same in-place semantics as eval_graph!(root, leafVal). */
 int fdg_eval(fdg_graph *g, const double *leaf, double *root, int64_t n_sample);
 
+/* Same with strided host matrices (element strides as in fdg_eval_device): row-major [B, L] / [B, R]
+ * (value stride 1) or column-major B x L / B x R -- what a Julia Matrix is: sample stride 1, value
+ * stride >= n_sample.  The device copy keeps the host's orientation, so a Julia matrix reaches the
+ * evaluator leaf-major without any transposition pass.  Leaves and roots may differ in orientation. */
+int fdg_eval_strided(fdg_graph *g, const double *leaf, int64_t leaf_sample_stride, int64_t leaf_leaf_stride,
+                     double *root, int64_t root_sample_stride, int64_t root_root_stride, int64_t n_sample);
+
 /* d_acc[k] += sum_b weight[b] * root_k(b)   (d_weight may be NULL: weight 1).
  * Per-lane accumulators inside the evaluator (ISA back end) or fixed-shape block trees, then one partial per
  * wave / block and root summed in fixed order by a second kernel: deterministic for a given launch shape, no atomics.

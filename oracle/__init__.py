@@ -55,6 +55,7 @@ def _load():
         L.oracle_root_scale.argtypes = [u32, u32, u32, p, p, p, p, p, p, p, i64, i64, p, i64]
         L.oracle_powi.argtypes = [C.c_double, C.c_int32]
         L.oracle_powi.restype = C.c_double
+        L.oracle_fma.argtypes = [p, p, p, p, i64]
         _lib = L
     return _lib
 
@@ -121,6 +122,15 @@ def abs_graph_scale(table, leaf) -> np.ndarray:
 
 def powi(x: float, n: int) -> float:
     return float(_load().oracle_powi(float(x), int(n)))
+
+
+def fma(a, b, c) -> np.ndarray:
+    """Elementwise IEEE fused multiply-add (C's fma), broadcasting."""
+    a, b, c = np.broadcast_arrays(np.asarray(a, np.float64), np.asarray(b, np.float64), np.asarray(c, np.float64))
+    a, b, c = np.ascontiguousarray(a), np.ascontiguousarray(b), np.ascontiguousarray(c)
+    out = np.empty_like(a)
+    _load().oracle_fma(a.ctypes.data, b.ctypes.data, c.ctypes.data, out.ctypes.data, a.size)
+    return out
 
 
 def _powi_numpy(x: np.ndarray, n: int) -> np.ndarray:

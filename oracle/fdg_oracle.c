@@ -87,6 +87,11 @@ static double julia_pow_literal(double x, int32_t n) {
 
 double oracle_powi(double x, int32_t n) { return julia_pow_literal(x, n); }
 
+/* elementwise IEEE fused multiply-add, for the tests' replay of programs that contain pow_body's fma steps */
+void oracle_fma(const double *a, const double *b, const double *c, double *out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = fma(a[i], b[i], c[i]);
+}
+
 /* val: scratch of L+N doubles. Returns 0, or -1 on a malformed table. */
 static int eval_one_static(uint32_t L, uint32_t N, const uint8_t *op, const int32_t *power,
                            const uint32_t *off, const uint32_t *idx, const double *fac,

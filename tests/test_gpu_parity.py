@@ -643,6 +643,25 @@ def test_entry_points_are_graph_capturable(libfdg, cuda):
     assert np.array_equal(root.cpu().numpy(), oracle.eval_static(t, leaf.cpu().numpy()))
 
 
+def test_host_matrices_in_either_order(libfdg, cuda):
+    """fdg_eval_strided: host matrices row-major (compile_Python's layout) or column-major (a Julia Matrix), leaves and
+    roots independently, padded leaf rows, chunked through the device -- the same bits, no transposition copy."""
+    t = workloads.get("gv_sigma4")
+    f = fd.compile_table(t, specialize="isa")
+    B, L, R = 10_007, t.n_leaf, t.n_root
+    leaf = oracle.philox_uniform(B, L + 3, 31)            # three columns more than the graph reads
+    want = oracle.eval_static(t, leaf)
+    os.environ["FDG_EVAL_CHUNK"] = "4096"
+    try:
+        for lorder in ("C", "F"):
+            for rorder in ("C", "F"):
+                root = np.full((B, R), -5.0, order=rorder)
+                out = f(root, np.array(leaf, order=lorder))
+                assert out is root and np.array_equal(root, want), (lorder, rorder)
+    finally:
+        del os.environ["FDG_EVAL_CHUNK"]
+
+
 def test_one_handle_two_streams_concurrently(libfdg, cuda):
     """include/fdg.h: the device entry points may be called on ONE handle from several threads and on several streams
     at once -- the scratch (spill panel, partial sums) is kept per caller stream.  Two streams (then two threads with a
@@ -709,9 +728,10 @@ def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch):
     assembly).  Two statements.  (1) The graph part is exact: the roots are, bit for bit, the oracle's graph applied to
     the leaves this kernel computes (read out through a second kernel whose roots ARE the leaves -- same formulas, same
     IEEE operations, hence the same bits; those leaves are checked against the oracle in the test below).  (2) Against
-    the pure oracle chain (numpy leaves -> oracle graph) the roots agree to 1e-12 of their term scale on the 4- and
-    5-loop graphs and to 1e-10 on the Taylor expansion, whose cancellations amplify a last-bit difference of a leaf (the
-    leaf-kernel route is 2e-12 off on the same samples).  Eval and accumulate; K and T as one matrix (read in place),
+    the pure oracle chain (numpy leaves -> oracle graph) the roots agree to 1e-12 of their term scale S_k -- BASELINE.json's
+    stated tolerance -- on the 4- and 5-loop graphs and on the Taylor expansion, whose cancellations amplify a last-bit
+    difference of a leaf by up to 1e5 (tools/gpu_mc_err.py: every route stays below 2e-15 of the absolute-value graph A_k;
+    quotients are correctly rounded divisions, the exponential is within one ulp).  Eval and accumulate; K and T as one matrix (read in place),
     as separate component-major arrays and sample-major (packed first); a ragged last tile; and again after the
     physical parameters change (they are kernel arguments: the same code object)."""
     import torch
@@ -760,7 +780,7 @@ def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch):
                 got = root.cpu().numpy()
                 assert np.array_equal(got, want_exact), (name, beta, lay)
                 err = np.abs(got - want) / scale
-                assert np.all(err <= (1e-10 if name == "gv_sigma4_taylor2" else 1e-12)), (name, beta, lay, float(np.nanmax(err)))
+                assert np.all(err <= 1e-12), (name, beta, lay, float(np.nanmax(err)))
                 first = got if first is None else first
                 assert np.array_equal(got, first), (name, lay)      # the layout changes addresses, never a value
                 w = torch.rand(B, dtype=torch.float64, device=cuda)
@@ -773,13 +793,13 @@ def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch):
 
 def test_isa_leaf_formulas_one_by_one(libfdg, cuda, monkeypatch):
     """The formulas of the one-kernel route leaf by leaf -- a graph whose roots ARE its leaves -- with green_derive
-    orders 0..5 and interaction counter-terms 0..3 on the 4-loop self-energy's leaves: against the oracle within 1e-12
+    orders 0..5 and interaction counter-terms 0..7 on the 4-loop self-energy's leaves: against the oracle within 1e-12
     of the largest Leibniz term (derivatives) / 1e-13 relative (everything else), like the leaf kernels' own test."""
     import torch
     from feynmandiagram_jl_amd.nodetable import NodeTable
     z = dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))
     L = len(z["leaf_type"])
-    order = np.where(z["leaf_type"] == 1, np.arange(L) % 6, np.arange(L) % 4).astype(np.int32)
+    order = np.where(z["leaf_type"] == 1, np.arange(L) % 6, np.arange(L) % 8).astype(np.int32)   # counter-terms up to (lambda invK)^7: pow_body above x^3
     t = NodeTable(L, np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0),
                   np.arange(L, dtype=np.uint32), "leaves")
     B, dim, n_loop, n_tau = 10_007, 3, int(z["basis"].shape[1]), int(z["n_tau"])

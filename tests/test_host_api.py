@@ -301,17 +301,26 @@ def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypa
     body = src.split("fdg_isa_mc_acc:")[0]
     n_exp = body.count("v_ldexp_f64")
     assert n_exp == body.count("v_rndne_f64") and n_exp >= 89          # one exponential per fermionic leaf + one per momentum
-    assert len(re.findall(r"v_rcp_f64_e64 [^\n]*\n\ts_nop 1", body)) == body.count("v_rcp_f64") > 0
+    assert body.count("v_div_fixup_f64") == body.count("v_rcp_f64") > 0                # quotients: correctly rounded divisions
+    assert capi.isa_check_hazards(src)[0] == 0
     assert body.count("global_load_dwordx2") <= 3 * (int(z["basis"].shape[1]) * 3 + int(z["n_tau"]))   # inputs (a few re-loads), no leaf matrix
     # FDG_MC_ROUTE=isa insists on this route and says why it cannot be taken
-    order4 = z["leaf_order"].copy()
-    order4[np.nonzero(z["leaf_type"] == 2)[0][0]] = 4         # interaction counter-term beyond x^3: the table-driven leaf kernel's pow_body only
-    tab0, keep0 = capi.make_leaf_tables(z["leaf_type"], order4, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]))
+    order6 = z["leaf_order"].copy()
+    order6[np.nonzero(z["leaf_type"] == 1)[0][0]] = 6         # green_derive beyond order 5: example/benchmark.jl:108 "not implemented!"
+    tab0, keep0 = capi.make_leaf_tables(z["leaf_type"], order6, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]))
     monkeypatch.setenv("FDG_MC_ROUTE", "isa")
-    with pytest.raises(capi.FdgError, match="order > 3"):
+    with pytest.raises(capi.FdgError, match="not implemented"):          # the tables are refused as the reference's green_derive refuses them
         fd.compile_table(t, specialize="isa").handle.specialize_fused(tab0, str(tmp_path))
+    # interaction counter-terms of any order are covered (pow_body above x^3), except by the compiler-scheduled fused kernel
+    order4 = z["leaf_order"].copy()
+    order4[np.nonzero(z["leaf_type"] == 2)[0][0]] = 4
+    tab1, keep1 = capi.make_leaf_tables(z["leaf_type"], order4, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]))
+    fd.compile_table(t, specialize="isa").handle.specialize_fused(tab1, str(tmp_path))
+    monkeypatch.setenv("FDG_MC_ROUTE", "fused")
+    with pytest.raises(capi.FdgError, match="order > 3"):
+        fd.compile_table(t, specialize="isa").handle.specialize_fused(tab1, str(tmp_path))
     monkeypatch.delenv("FDG_MC_ROUTE")
-    fd.compile_table(t, specialize="isa").handle.specialize_fused(tab0, str(tmp_path))    # ... leaf kernel + evaluator otherwise
+    fd.compile_table(t, specialize="isa").handle.specialize_fused(tab1, str(tmp_path))
 
 
 def test_argument_checks_of_the_newer_entry_points(libfdg):
@@ -398,3 +407,19 @@ def test_exponent_and_root_count_bounds():
         with pytest.raises(capi.FdgError) as e:
             capi.GraphHandle(from_program(1, [(OP_POWER, n, [(0, 1.0)])], [1]))
         assert e.value.code == capi.FDG_E_UNSUPPORTED
+
+
+def test_call_value_is_the_last_root_statement(libfdg):
+    """The generated function returns its last statement (static.jl:126-128: `root[k] = g` follows g's own statement).
+    With graphs = [S, c], S = a + b and c a leaf visited after S, the text ends with `root[2] = gc`: the call's value
+    is root[2], although c is a leaf and S an internal node."""
+    reset_uid()
+    a, b, c = Graph([]), Graph([]), Graph([])
+    S = Graph([a, b], operator=Sum())
+    text, _ = Compilers.to_julia_str([S, c])
+    assert text.rstrip().splitlines()[-2].strip() == f"root[2] = g{c.id}"
+    f, leafmap = Compilers.compile([S, c], specialize=False)
+    assert f._last_root_value([3.0, 7.0]) == 7.0
+    # the other way round: the leaf's statement precedes the node's
+    f2, _ = Compilers.compile([c, S], specialize=False)
+    assert f2._last_root_value([7.0, 3.0]) == 3.0

@@ -167,7 +167,7 @@ def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch
 # --------------------------------------------------------------------------- #
 def random_leaf_tables(seed: int, L: int):
     """A random partition in the shape FrontEnds.leafstates produces (frontends.jl:178-232): fermionic leaves with
-    green_derive orders 0..5 and interaction leaves with counter-term orders 0..3 over a random loop basis."""
+    green_derive orders 0..5 and interaction leaves with counter-term orders 0..6 over a random loop basis."""
     rng = np.random.default_rng(1000 + seed)
     n_loop, n_tau, n_basis = int(rng.integers(1, 5)), int(rng.integers(1, 6)), int(rng.integers(1, 9))
     basis = rng.choice([-1.0, 0.0, 0.0, 1.0, 1.0, 0.5], size=(n_basis, n_loop))
@@ -175,7 +175,7 @@ def random_leaf_tables(seed: int, L: int):
         if not basis[r].any():
             basis[r, int(rng.integers(0, n_loop))] = 1.0
     ty = rng.choice([1, 1, 1, 2, 2, 0], size=L).astype(np.int32)     # 0: a leaf without a formula (value 1.0)
-    order = np.where(ty == 1, rng.integers(0, 6, size=L), rng.integers(0, 4, size=L)).astype(np.int32)
+    order = np.where(ty == 1, rng.integers(0, 6, size=L), rng.integers(0, 7, size=L)).astype(np.int32)
     order[rng.random(L) < 0.5] = 0
     return dict(leaf_type=ty, leaf_order=order, tau_in=rng.integers(1, n_tau + 1, size=L).astype(np.int32),
                 tau_out=rng.integers(1, n_tau + 1, size=L).astype(np.int32), loop_index=rng.integers(1, n_basis + 1, size=L).astype(np.int32),
