@@ -117,6 +117,10 @@ struct fdg_graph {
   bool isa_fma = false;            // FDG_SPEC_FAST_MATH with FDG_SPEC_ISA: fused multiply-adds (not parity-exact)
   void *fn_isa_acc = nullptr;
   uint32_t isa3_vgpr = 0, isa3_lds_bytes = 0, isa3_mem_slots = 0;
+  // row-major variant (leaf stride 1: compile_Python's [B, L]): chunks of rows staged through LDS inside the evaluator
+  bool has_rm = false;
+  void *fn_isa_rm = nullptr;
+  uint32_t isa4_vgpr = 0, isa4_lds_bytes = 0, isa4_mem_slots = 0;
   // companion HIP-source kernels of an ISA-specialised handle, used for sample-major input (FDG_SPEC_ROW_MAJOR_COMPANION)
   std::vector<char> alt_code;
   void *alt_module = nullptr, *fn_alt_sm = nullptr, *fn_alt_gen = nullptr;

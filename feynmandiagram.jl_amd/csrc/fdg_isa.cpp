@@ -78,6 +78,7 @@ enum HzCons : uint8_t {
   HC_VMEM_SADDR,   // VMEM / SMEM instruction reads the SGPR (address, offset)
   HC_LANE_READ,    // v_readlane / v_readfirstlane reads the VGPR
   HC_VALU_WRITE,   // VALU overwrites the VGPR
+  HC_LDS_DIRECT,   // global_load_lds_* reads M0 (its LDS base)
 };
 struct HzRule { HzProd prod; HzCons cons; HzRes res; int wait; const char *what; };
 const HzRule kHazards[] = {
@@ -88,14 +89,15 @@ const HzRule kHazards[] = {
     {HP_VALU_VGPR, HC_LANE_READ, HZ_VGPR, 2, "VALU write of VGPR -> v_readlane/v_readfirstlane (measured: stale read with 0)"},
     {HP_STORE_WIDE, HC_VALU_WRITE, HZ_VGPR, 2, "store data wider than 64 bits -> VALU overwrite of the data registers"},
     {HP_SALU_SGPR, HC_VMEM_SADDR, HZ_SGPR, 0, "SALU write of SGPR -> VMEM read of it: interlocked by hardware (every leaf load does this back to back)"},
+    {HP_SALU_SGPR, HC_LDS_DIRECT, HZ_SGPR, 1, "SALU write of M0 -> LDS-direct load (global_load_lds_*)"},
 };
 constexpr int HZ_MAX_WAIT = 5;
 
 // registers are numbered: VGPR v -> v, AGPR a -> 512 + a, SGPR s -> 1024 + s, vcc -> 1024 + 106/107, exec -> 1024 + 126/127
-constexpr int HR_AGPR = 512, HR_SGPR = 1024, HR_VCC = 1024 + 106, HR_EXEC = 1024 + 126;
+constexpr int HR_AGPR = 512, HR_SGPR = 1024, HR_VCC = 1024 + 106, HR_EXEC = 1024 + 126, HR_M0 = 1024 + 124;
 struct HzInst {
   std::string op;
-  bool valu = false, salu = false, vmem = false, ds = false, smem = false, trans = false, lane_read = false, div_fmas = false, store = false;
+  bool valu = false, salu = false, vmem = false, ds = false, smem = false, trans = false, lane_read = false, div_fmas = false, store = false, lds_direct = false;
   int nop = 0;                  // s_nop: wait states it provides
   std::vector<int> wr, rd;      // registers written / read (numbering above)
   std::vector<int> store_wide;  // data registers of a wide store
@@ -110,6 +112,7 @@ static void hz_parse_reg(std::string t, int &first, int &n) {
   if (t == "vcc_lo") { first = HR_VCC; n = 1; return; }
   if (t == "vcc_hi") { first = HR_VCC + 1; n = 1; return; }
   if (t == "exec") { first = HR_EXEC; n = 2; return; }
+  if (t == "m0") { first = HR_M0; n = 1; return; }
   if (t.size() < 2 || (t[0] != 'v' && t[0] != 's' && t[0] != 'a')) return;
   const int base = t[0] == 'v' ? 0 : (t[0] == 'a' ? HR_AGPR : HR_SGPR);
   if (t[1] == '[') {
@@ -163,6 +166,12 @@ static HzInst hz_decode(const std::string &line) {
   if (hz_starts(op, "global_load") || hz_starts(op, "global_store") || hz_starts(op, "buffer_") || hz_starts(op, "flat_")) {
     I.vmem = true;
     I.store = op.find("store") != std::string::npos;
+    if (op.find("_lds_") != std::string::npos) {      // LDS-direct: no VGPR destination, M0 is the LDS base
+      I.lds_direct = true;
+      I.rd.push_back(HR_M0);
+      for (size_t i = 0; i < opnd.size(); ++i) add(I.rd, opnd[i]);
+      return I;
+    }
     const bool wide = op.find("dwordx3") != std::string::npos || op.find("dwordx4") != std::string::npos;
     for (size_t i = 0; i < opnd.size(); ++i) {
       if (!I.store && i == 0) add(I.wr, opnd[i]);
@@ -232,11 +241,13 @@ struct HzTracker {
           case HC_VMEM_SADDR: if (I.vmem || I.smem) cr = &I.rd; break;
           case HC_LANE_READ: if (I.lane_read) cr = &I.rd; break;
           case HC_VALU_WRITE: if (I.valu) cr = &I.wr; break;
+          case HC_LDS_DIRECT: if (I.lds_direct) cr = &I.rd; break;
         }
         if (!cr) continue;
         for (int r : *pr) {
           const bool sg = r >= HR_SGPR;
           if ((R.res == HZ_SGPR) != sg) continue;
+          if (R.cons == HC_LDS_DIRECT && r != HR_M0) continue;
           if (has(*cr, r)) { if (R.wait - P.age > need) { need = R.wait - P.age; if (why) *why = R.what; } break; }
         }
       }
@@ -351,11 +362,24 @@ struct KernelMeta { std::string name; uint32_t lds_bytes, accum, n_agpr; int n_a
 // tiles: a value is two doubles in four VGPRs, every memory access is 16 bytes per lane -- the
 // wide-access form HBM-bound graphs want; needs sample stride 1 and full tiles, the host runs the
 // remainder through the W = 1 kernel).
-static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog, const std::string &kname, int W, bool accumulate = false) {
+//
+// rm_bufs > 0: the row-major variant (compile_Python's [B, L] input, leaf stride 1).  A wave's 64 samples are 64 rows of
+// the matrix; chunks of RM_CHUNK consecutive leaves of those rows (64 x 128 bytes) are brought into `rm_bufs` LDS staging
+// buffers by LDS-direct loads (global_load_lds_dwordx4: eight instructions per chunk, every 128-byte row segment one
+// coalesced line, no VGPR in between), and a leaf's first use reads lane = row from there (ds_read_b64).  The LDS image
+// of a chunk is lane-linear by construction of the instruction, so the bank swizzle sits in the SOURCE address: lane l
+// of instruction n fetches piece (l % 8) ^ (l / 8) of row 8 n + l / 8, which puts piece j of row r at
+// r * 128 + ((j ^ (r % 8)) * 16): a column read by 64 rows touches every bank pair twice instead of one pair 64 times.
+// Which chunk is resident when is planned here from the allocated program (Belady over the buffers); a leaf used again
+// long after its chunk left is gathered straight from memory (eight bytes per lane, rare).  Only full 64-row tiles.
+constexpr uint32_t RM_CHUNK = 16, RM_BUF_BYTES = 64 * RM_CHUNK * 8, RM_WINDOW = 800;
+static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog, const std::string &kname, int W, bool accumulate = false,
+                              uint32_t rm_bufs = 0) {
   E.vm_issued = E.lg_issued = E.vm_done = E.lg_done = 0;
   E.pend.assign(std::max<uint32_t>(prog.n_reg_used, 1), {0, 0});
   const uint32_t SLOT = 512u * W;                 // bytes of one LDS / panel slot of a wave
-  const uint32_t lds_bytes = prog.n_lds_used * SLOT;
+  const uint32_t stage_base = (prog.n_lds_used * SLOT + 1023u) & ~1023u;
+  const uint32_t lds_bytes = rm_bufs ? stage_base + rm_bufs * RM_BUF_BYTES : prog.n_lds_used * SLOT;
   const uint32_t panel_bytes_per_wave = std::max<uint32_t>(prog.n_mem_used, 1) * SLOT;
   const int RW = 2 * W;                           // VGPRs per value
   const int TSH = W == 2 ? 7 : 6;                 // log2(samples per tile)
@@ -415,6 +439,28 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_lshl_b64 " + S2(S_LS8) + ", " + S2(S_LS) + ", 3");
   E.ins("s_lshl_b64 " + S2(S_RK8) + ", " + S2(S_RK) + ", 3");
   if (mc) E.ins("s_lshl_b64 " + S2(S_LS82) + ", " + S2(S_LS82) + ", 3");
+  // row-major variant: per-lane source offset of the LDS-direct loads, and the eight swizzled read addresses
+  const uint32_t rm0 = tmp0 + 2 * n_tmp_pairs;                   // v[rm0] = source offset, v[rm0 + 1 + j] = read address of piece j
+  const int S_ROW8 = S_DELTA, S_FA = S_DELTA + 2;                // (the delta table is not used by this variant)
+  if (rm_bufs) {
+    const std::string vg = "v" + std::to_string(rm0);
+    auto vj = [&](int j) { return "v" + std::to_string(rm0 + 1 + j); };
+    E.ins("v_lshrrev_b32_e32 " + vj(0) + ", 3, v0");                                   // l / 8
+    E.ins("v_and_b32_e32 " + vj(1) + ", 7, v0");                                       // l % 8
+    E.ins("v_xor_b32_e32 " + vj(1) + ", " + vj(1) + ", " + vj(0));                     // piece this lane fetches
+    E.ins("v_lshlrev_b32_e32 " + vj(1) + ", 4, " + vj(1));
+    E.ins("v_mul_lo_u32 " + vj(0) + ", " + vj(0) + ", " + S(S_SS));                    // (l / 8) rows further
+    E.ins("v_lshlrev_b32_e32 " + vj(0) + ", 3, " + vj(0));
+    E.ins("v_add_u32_e32 " + vg + ", " + vj(0) + ", " + vj(1));
+    E.ins("v_lshlrev_b32_e32 " + V(V_TMP) + ", 7, v0");                                // row * 128
+    E.ins("v_and_b32_e32 " + V(V_TMP + 1) + ", 7, v0");                                // row % 8
+    for (int j = 0; j < 8; ++j) {
+      E.ins("v_xor_b32_e32 " + vj(j) + ", " + std::to_string(j) + ", " + V(V_TMP + 1));
+      E.ins("v_lshlrev_b32_e32 " + vj(j) + ", 4, " + vj(j));
+      E.ins("v_add_u32_e32 " + vj(j) + ", " + vj(j) + ", " + V(V_TMP));
+    }
+    E.ins("s_lshl_b64 " + S2(S_ROW8) + ", " + S2(S_SS) + ", 6");                       // eight rows in bytes
+  }
   // Leaf addresses: consecutive loads mostly step by +1 leaf (leaves are numbered in first-visit order and
   // the schedule visits them nearly in that order), so the column pointer is advanced by an add of the
   // stride (2 scalar ops) instead of being rebuilt from the leaf index (6); the next most frequent positive
@@ -431,7 +477,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     std::vector<std::pair<int, int64_t>> v;
     for (auto &kv : hist) if (kv.second >= 2) v.push_back({kv.second, kv.first});
     std::sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
-    for (size_t i = 0; i < v.size() && i < (size_t)N_DELTA; ++i) delta_tab.push_back(v[i].second);
+    for (size_t i = 0; i < v.size() && i < (size_t)N_DELTA && !rm_bufs; ++i) delta_tab.push_back(v[i].second);
   }
   for (size_t k = 0; k < delta_tab.size(); ++k) {
     const int d = S_DELTA + 2 * (int)k;
@@ -553,6 +599,70 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   // the constant of a micro-op: a kernel argument when tagged, else as above
   auto op_const = [&](const MOp &o) -> std::string { return o.param ? S2(S_PARAM + 2 * (o.param - 1)) : const_operand(o.imm); };
   auto op_const_sgpr = [&](const MOp &o) -> int { return o.param ? S_PARAM + 2 * (o.param - 1) : const_sgpr(o.imm); };
+  // ---- row-major variant: which chunk sits in which staging buffer when -------------------------------------------
+  // chunk c = leaves 16 c .. 16 c + 15; a last partial chunk is shifted back to end at the last leaf (never reads past a row)
+  const uint32_t rm_full = p.L / RM_CHUNK, rm_tail = (p.L % RM_CHUNK) ? 1u : 0u;
+  auto rm_chunk_of = [&](uint32_t leaf) { return leaf < rm_full * RM_CHUNK ? leaf / RM_CHUNK : rm_full; };
+  auto rm_chunk_start = [&](uint32_t c) { return c < rm_full ? c * RM_CHUNK : p.L - RM_CHUNK; };
+  struct RmFetch { uint32_t chunk, buf; };
+  std::vector<std::vector<RmFetch>> rm_fetch;       // [op index] fetches issued in front of that op
+  std::vector<int> rm_ld_buf;                       // [op index] staging buffer an LD_LEAF reads, -1 = gathered from memory
+  if (rm_bufs) {
+    const size_t n_ops = prog.ops.size();
+    rm_fetch.assign(n_ops + 1, {});
+    rm_ld_buf.assign(n_ops, -1);
+    std::vector<std::vector<size_t>> uses(rm_full + rm_tail);
+    for (size_t q = 0; q < n_ops; ++q) if (prog.ops[q].kind == M_LD_LEAF) uses[rm_chunk_of(prog.ops[q].a)].push_back(q);
+    std::vector<size_t> cursor(uses.size(), 0);
+    std::vector<int64_t> resident(rm_bufs, -1);
+    std::vector<size_t> free_from(rm_bufs, 0);      // op index from which the buffer may be filled again
+    for (size_t q = 0; q < n_ops; ++q) {
+      if (prog.ops[q].kind != M_LD_LEAF) continue;
+      const uint32_t c = rm_chunk_of(prog.ops[q].a);
+      cursor[c]++;                                   // uses[c][cursor[c]..] are the later ones
+      int b = -1;
+      for (uint32_t k = 0; k < rm_bufs; ++k) if (resident[k] == (int64_t)c) b = (int)k;
+      if (b < 0) {
+        // a chunk is worth a buffer (and eight loads) when at least three of its leaves are read within the next
+        // RM_WINDOW ops; stragglers -- a value used again long after its neighbours -- are gathered from memory
+        size_t soon = 1;
+        for (size_t k = cursor[c]; k < uses[c].size() && uses[c][k] <= q + RM_WINDOW; ++k) soon++;
+        if (soon < 3) continue;
+        // victim: an empty buffer, else the resident chunk whose next use is farthest (none at all first)
+        size_t far = 0;
+        for (uint32_t k = 0; k < rm_bufs; ++k) {
+          size_t nu;
+          if (resident[k] < 0) nu = std::numeric_limits<size_t>::max();
+          else { const auto &u = uses[(size_t)resident[k]]; const size_t cu = cursor[(size_t)resident[k]]; nu = cu < u.size() ? u[cu] : std::numeric_limits<size_t>::max() - 1; }
+          if (b < 0 || nu > far) { b = (int)k; far = nu; }
+        }
+        rm_fetch[std::min(free_from[(size_t)b], q)].push_back(RmFetch{c, (uint32_t)b});
+        resident[(size_t)b] = c;
+      }
+      rm_ld_buf[q] = b;
+      free_from[(size_t)b] = q + 1;
+    }
+  }
+  std::vector<uint64_t> rm_ready(rm_bufs, 0);        // vm sequence number of the last load of the chunk in each buffer
+  auto rm_emit_fetch = [&](const RmFetch &f) {
+    // the buffer's previous readers have been issued; their data must have left the LDS before it is overwritten
+    if (E.lg_done < E.lg_issued) { E.ins("s_waitcnt lgkmcnt(0)"); E.lg_done = E.lg_issued; for (auto &pp : E.pend) if (pp.first == 2) pp.first = 0; }
+    E.ins("s_mov_b32 m0, " + hex32(stage_base + f.buf * RM_BUF_BYTES));
+    const uint64_t off = (uint64_t)rm_chunk_start(f.chunk) * 8;
+    E.ins("s_add_u32 " + S(S_FA) + ", " + S(S_LT) + ", " + hex32((uint32_t)off));
+    E.ins("s_addc_u32 " + S(S_FA + 1) + ", " + S(S_LT + 1) + ", 0");
+    for (uint32_t n = 0; n < 8; ++n) {
+      if (n) {   // (two scalar ops between the write of M0 and the load that reads it)
+        E.ins("s_mov_b32 m0, " + hex32(stage_base + f.buf * RM_BUF_BYTES + n * 1024));
+        E.ins("s_add_u32 " + S(S_FA) + ", " + S(S_FA) + ", " + S(S_ROW8));
+        E.ins("s_addc_u32 " + S(S_FA + 1) + ", " + S(S_FA + 1) + ", " + S(S_ROW8 + 1));
+      }
+      E.ins("global_load_lds_dwordx4 v" + std::to_string(rm0) + ", " + S2(S_FA));
+      ++E.vm_issued;
+    }
+    rm_ready[f.buf] = E.vm_issued;
+  };
+
   // ---- body ------------------------------------------------------------------
   int64_t last_leaf = -1;
   // One s_waitcnt can serve several consumers: when an op has to wait for a load, the wait also covers what
@@ -579,6 +689,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   };
   size_t op_index = 0;
   for (const MOp &o : prog.ops) {
+    if (rm_bufs) for (const RmFetch &f : rm_fetch[op_index]) rm_emit_fetch(f);
+    const size_t this_op = op_index;
     {
       const size_t i = op_index++;
       uint64_t need = vm_seq_needed(o);
@@ -591,6 +703,22 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       case M_LD_LEAF:
         if (dbg_noleaf) break;   // timing experiments only (results are garbage)
         E.wait_reg(o.d);
+        if (rm_bufs) {
+          const int b = rm_ld_buf[this_op];
+          if (b >= 0) {          // from the staging buffer: lane = row, piece (leaf - chunk start) / 2, half (leaf - chunk start) % 2
+            const uint32_t c = o.a - rm_chunk_start(rm_chunk_of(o.a));
+            E.wait_vm(rm_ready[(size_t)b]);
+            E.ins("ds_read_b64 " + vall(o.d) + ", v" + std::to_string(rm0 + 1 + c / 2) + " offset:" +
+                  std::to_string(stage_base + (uint32_t)b * RM_BUF_BYTES + (c % 2) * 8));
+            E.pend[o.d] = {2, ++E.lg_issued};
+          } else {               // gathered: eight bytes of each lane's own row
+            E.ins("s_add_u32 " + S(S_LP) + ", " + S(S_LT) + ", " + hex32(o.a * 8u));
+            E.ins("s_addc_u32 " + S(S_LP + 1) + ", " + S(S_LT + 1) + ", 0");
+            E.ins(LD + vall(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_LP));
+            E.pend[o.d] = {1, ++E.vm_issued};
+          }
+          break;
+        }
         {
           const int64_t step = last_leaf >= 0 ? (int64_t)o.a - last_leaf : 0;
           const bool second = mc && o.a >= n_k;                      // a time: second base, its own column stride
@@ -864,7 +992,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_endpgm");
 
   // ---- kernel descriptor -------------------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs, 8);
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 9 : 0), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
   const uint32_t n_agpr = RW * prog.n_acc_used;
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
@@ -924,13 +1052,14 @@ std::string isa_hazard_table() {
 // One code object: the W = 1 kernel `kname`, and, when prog2 is given, the two-samples-per-lane kernel
 // `kname`_w2 next to it.
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2,
-                     const OptProgram *prog_acc) {
+                     const OptProgram *prog_acc, const OptProgram *prog_rm, uint32_t rm_bufs) {
   Emit E;
   E.os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n";
   std::vector<KernelMeta> ks;
   ks.push_back(emit_kernel(E, p, prog, kname, 1));
   if (prog2) ks.push_back(emit_kernel(E, p, *prog2, kname + "_w2", 2));
   if (prog_acc) ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc", 1, true));
+  if (prog_rm && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm, kname + "_rm", 1, false, rm_bufs));
   std::ostringstream &os = E.os;
   os << "\t.text\n\t.amdgpu_metadata\n---\namdhsa.kernels:\n";
   const char *kinds[16] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",

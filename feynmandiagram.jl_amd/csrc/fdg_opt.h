@@ -108,7 +108,7 @@ void build_mc_program(const Lowered &p, const LeafSpec &ls, const OptParams &prm
 struct SchedOp { uint8_t kind; uint32_t d, a, b; double imm; };
 bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp> &ops, uint32_t &n_value, std::string &why);
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2 = nullptr,
-                     const OptProgram *prog_acc = nullptr);
+                     const OptProgram *prog_acc = nullptr, const OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0);
 
 // gfx950 wait-state table of the emitter (fdg_isa.cpp): check of a finished listing, and the table as text
 int check_isa_hazards(const std::string &text, std::string &report);

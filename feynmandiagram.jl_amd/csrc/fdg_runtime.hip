@@ -383,6 +383,7 @@ static int ensure_module(fdg_graph *g) {
     g->module = m; g->fn_isa = f;
     if (g->has_w2) { hipFunction_t f2; HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_isa_eval_w2")); g->fn_isa_w2 = f2; }
     if (g->has_acc) { hipFunction_t f3; HIP_TRY(hipModuleGetFunction(&f3, m, "fdg_isa_eval_acc")); g->fn_isa_acc = f3; }
+    if (g->has_rm) { hipFunction_t f4; HIP_TRY(hipModuleGetFunction(&f4, m, "fdg_isa_eval_rm")); g->fn_isa_rm = f4; }
     return FDG_OK;
   }
   hipFunction_t f1, f2;
@@ -480,7 +481,9 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     const bool fused_acc = mode == 1 && g->has_acc && !std::getenv("FDG_ISA_NO_FUSED_ACC");
     const long grid3 = g->has_acc ? (long)g->n_cu * waves_per_cu(g->isa3_vgpr, g->isa3_lds_bytes) : 0;
     const size_t panel3 = (size_t)std::max<uint32_t>(g->isa3_mem_slots, 1) * 512u * (size_t)grid3;
-    const size_t panel_all = (std::max(panel, panel3) + 4095) & ~(size_t)4095;
+    const long grid4 = g->has_rm ? (long)g->n_cu * waves_per_cu(g->isa4_vgpr, g->isa4_lds_bytes) : 0;
+    const size_t panel4 = (size_t)std::max<uint32_t>(g->isa4_mem_slots, 1) * 512u * (size_t)grid4;
+    const size_t panel_all = (std::max(std::max(panel, panel3), panel4) + 4095) & ~(size_t)4095;
     rc = ensure_ws(g, panel_all + (size_t)grid3 * R * 512u + 4096);
     if (rc) return rc;
     // fused accumulation: acc[k] += sum_b w_b root_k(b) with per-lane accumulators inside the evaluator
@@ -532,6 +535,22 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // the kernel forms a lane's offset (lane * stride * 8) in 32 bits: strides that large are brought into the
     // leaf-major workspace first (leaves) or refused (roots); neither occurs with the layouts of DESIGN.md 2
     const bool wide_ss = ss < 0 || ss >= (1ll << 23);           // (the offset is unsigned: negative strides too)
+    // Row-major leaves ([B, L], leaf stride 1) and evaluation: full 64-row tiles go through the variant that stages chunks
+    // of rows in LDS itself -- the matrix is read once, in place; the last B % 64 rows take the general path below.
+    if (mode == 0 && g->has_rm && g->fn_isa_rm && ls == 1 && ss >= (int64_t)p.L && !wide_ss && p.L >= 16 && B >= 64 &&
+        !(rs < 0 || rs >= (1ll << 23)) && !std::getenv("FDG_ISA_NO_RM")) {
+      long n4 = (long)(B & ~(int64_t)63);
+      long nwg = std::min<long>(n4 / 64, grid4), lss = ss, lls = ls, rrs = rs, rrk = rk;
+      void *a_wsp = g->d_ws;
+      const double *nowt = nullptr;
+      void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &n4, &nwg, (void *)&nowt};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rm, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+      if (n4 == B) return FDG_OK;
+      d_leaf += (size_t)n4 * (size_t)ss;
+      d_root += (size_t)n4 * (size_t)rs;
+      roots = d_root;
+      B -= n4;
+    }
     if (mode == 0 && (rs < 0 || rs >= (1ll << 23))) { set_error("root sample stride negative or of 2^23 elements or more is not supported by the ISA kernel"); return FDG_E_UNSUPPORTED; }
     if ((ls == 1 && ss != 1 && p.L > 1) || (wide_ss && p.L > 0)) {
       // sample-major input (compile_Python's [B, L]): the ISA kernel wants a wave's 64 samples of
@@ -928,8 +947,9 @@ static bool has_opt_params(const fdg_graph *g) { return g->has_opt; }
 
 static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags,
                         std::vector<char> &co, std::string &hash, const fdg::OptProgram *prog2 = nullptr,
-                        const fdg::OptProgram *prog_acc = nullptr, const char *kname = "fdg_isa_eval") {
-  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc);
+                        const fdg::OptProgram *prog_acc = nullptr, const char *kname = "fdg_isa_eval",
+                        const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0) {
+  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc, prog_rm, rm_bufs);
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
   hash = hbuf;
@@ -959,7 +979,8 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
 }
 
 static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<char> &co, const std::string &hash, unsigned flags,
-                        const fdg::OptProgram *prog2 = nullptr, const fdg::OptProgram *prog_acc = nullptr) {
+                        const fdg::OptProgram *prog2 = nullptr, const fdg::OptProgram *prog_acc = nullptr,
+                        const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0) {
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
   g->code_object.swap(co);
   g->isa = true;
@@ -972,6 +993,13 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
     g->isa3_vgpr = ((6 + 2 * std::max<uint32_t>(prog_acc->n_reg_used, 1) + 2 * (g->prog.R + 2) + tmp_vgprs(*prog_acc) + 3) & ~3u) + 2 * prog_acc->n_acc_used;
     g->isa3_lds_bytes = prog_acc->n_lds_used * 512u;
     g->isa3_mem_slots = prog_acc->n_mem_used;
+  }
+  g->has_rm = prog_rm != nullptr && rm_bufs > 0;
+  g->fn_isa_rm = nullptr;
+  if (g->has_rm) {
+    g->isa4_vgpr = ((6 + 2 * std::max<uint32_t>(prog_rm->n_reg_used, 1) + tmp_vgprs(*prog_rm) + 9 + 3) & ~3u) + 2 * prog_rm->n_acc_used;
+    g->isa4_lds_bytes = ((prog_rm->n_lds_used * 512u + 1023u) & ~1023u) + rm_bufs * 8192u;
+    g->isa4_mem_slots = prog_rm->n_mem_used;
   }
   g->has_w2 = prog2 != nullptr;
   if (prog2) {
@@ -1074,6 +1102,46 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
   return pa.supported;
 }
 
+// The row-major variant (compile_Python's [B, L] input read in place, csrc/fdg_isa.cpp): the same configuration with
+// part of the LDS budget turned into staging buffers of 8 KB, nine VGPRs of addresses, and leaf loads that come from
+// LDS (short prefetch distance).  Not for the tiny-graph configuration (its waves have 5 KB of LDS each; such graphs
+// take the HIP-source companion) nor for graphs of fewer than 16 leaves.
+static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chosen, fdg::OptProgram &pr) {
+  if (g->prog.L < 16 || std::getenv("FDG_ISA_NO_RM")) return 0;
+  if (chosen.n_reg < 100) return 0;                              // tiny-graph configuration
+  // One wave per SIMD whatever the leaf-major kernel runs with: 40 KB of LDS per wave hold four staging buffers -- the
+  // stream of first uses plus the few chunks a schedule keeps coming back to -- and the AGPR level makes up for the LDS
+  // slots given away.  (Graphs that stream leaves are bound by latency, not by occupancy: DESIGN.md 6.)
+  uint32_t bufs = 4;
+  if (const char *e = std::getenv("FDG_ISA_RM_BUFS")) bufs = (uint32_t)std::max(1, std::min(4, std::atoi(e)));
+  fdg::OptParams q = cfg_B();
+  q.vn_window = chosen.vn_window;
+  q.n_lds = 80u - bufs * 16u - 2u;                               // (two slots lost to the 1 KB alignment of the buffers)
+  q.reserve_pairs = 5;
+  q.lookahead_leaf = 48;
+  build_prog(g, q, pr);
+  return pr.supported ? bufs : 0;
+}
+
+struct IsaVariants {
+  fdg::OptProgram p2, pa, pr;
+  bool w2 = false, acc = false;
+  uint32_t rm_bufs = 0;
+};
+static void build_variants(const fdg_graph *g, const fdg::OptParams &chosen, bool allow_w2, IsaVariants &V) {
+  V.w2 = allow_w2 && !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, V.p2);
+  V.acc = build_acc_program(g, chosen, V.pa);
+  V.rm_bufs = build_rm_program(g, chosen, V.pr);
+}
+static int assemble_and_install(fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags, IsaVariants &V) {
+  std::vector<char> co; std::string hash;
+  const int rc = assemble_isa(g, prog, dir, flags, co, hash, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, "fdg_isa_eval",
+                              V.rm_bufs ? &V.pr : nullptr, V.rm_bufs);
+  if (rc) return rc;
+  install_isa(g, prog, co, hash, flags, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, V.rm_bufs ? &V.pr : nullptr, V.rm_bufs);
+  return FDG_OK;
+}
+
 // returns 1 when a remembered choice was installed, 0 when there is none, < 0 on error
 static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   const std::string tuned = tuned_path(g, dir);
@@ -1092,14 +1160,10 @@ static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   fdg::OptProgram prog;
   build_prog(g, q, prog);
   if (!prog.supported) return 0;
-  fdg::OptProgram p2, pa;
-  const bool w2 = !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, p2);
-  const bool acc = build_acc_program(g, q, pa);
-  std::vector<char> co; std::string hash;
-  int rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
-  if (rc) return rc;
-  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
-  return 1;
+  IsaVariants V;
+  build_variants(g, q, true, V);
+  const int rc = assemble_and_install(g, prog, dir, flags, V);
+  return rc ? rc : 1;
 }
 
 static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
@@ -1173,13 +1237,10 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   if (best < 0) { set_error("autotune: no candidate configuration ran"); return FDG_E_JIT; }
   fdg::OptProgram prog;
   build_prog(g, cand[best], prog);
-  fdg::OptProgram p2, pa;
-  const bool w2 = !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, p2);
-  const bool acc = build_acc_program(g, cand[best], pa);
-  std::vector<char> co; std::string hash;
-  rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
+  IsaVariants V;
+  build_variants(g, cand[best], true, V);
+  rc = assemble_and_install(g, prog, dir, flags, V);
   if (rc) return rc;
-  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
   const std::string line = to_line(cand[best]) + "\n";
   write_file(tuned, line.c_str(), line.size());
   return FDG_OK;
@@ -1201,14 +1262,9 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
     chosen = auto_program(g, prog);
   }
   if (!prog.supported) { set_error("optimizing back end does not cover this graph: " + prog.why); return FDG_E_UNSUPPORTED; }
-  fdg::OptProgram p2, pa;
-  const bool w2 = !has_opt_params(g) && !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, p2);
-  const bool acc = build_acc_program(g, chosen, pa);
-  std::vector<char> co; std::string hash;
-  int rc = assemble_isa(g, prog, dir, flags, co, hash, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
-  if (rc) return rc;
-  install_isa(g, prog, co, hash, flags, w2 ? &p2 : nullptr, acc ? &pa : nullptr);
-  return FDG_OK;
+  IsaVariants V;
+  build_variants(g, chosen, !has_opt_params(g), V);
+  return assemble_and_install(g, prog, dir, flags, V);
 }
 
 }  // extern "C"
