@@ -373,6 +373,48 @@ struct KernelMeta { std::string name; uint32_t lds_bytes, accum, n_agpr; int n_a
 // Which chunk is resident when is planned here from the allocated program (Belady over the buffers); a leaf used again
 // long after its chunk left is gathered straight from memory (eight bytes per lane, rare).  Only full 64-row tiles.
 constexpr uint32_t RM_CHUNK = 16, RM_BUF_BYTES = 64 * RM_CHUNK * 8, RM_WINDOW = 800;
+// chunk c = leaves 16 c .. 16 c + 15; a last partial chunk is shifted back to end at the last leaf (never reads past a row)
+struct RmFetch { uint32_t chunk, buf; };
+static void rm_plan(const Lowered &p, const OptProgram &prog, uint32_t rm_bufs, std::vector<std::vector<RmFetch>> &rm_fetch,
+                    std::vector<int> &rm_ld_buf) {
+  const uint32_t rm_full = p.L / RM_CHUNK, rm_tail = (p.L % RM_CHUNK) ? 1u : 0u;
+  auto rm_chunk_of = [&](uint32_t leaf) { return leaf < rm_full * RM_CHUNK ? leaf / RM_CHUNK : rm_full; };
+  const size_t n_ops = prog.ops.size();
+  rm_fetch.assign(n_ops + 1, {});
+  rm_ld_buf.assign(n_ops, -1);
+  std::vector<std::vector<size_t>> uses(rm_full + rm_tail);
+  for (size_t q = 0; q < n_ops; ++q) if (prog.ops[q].kind == M_LD_LEAF) uses[rm_chunk_of(prog.ops[q].a)].push_back(q);
+  std::vector<size_t> cursor(uses.size(), 0);
+  std::vector<int64_t> resident(rm_bufs, -1);
+  std::vector<size_t> free_from(rm_bufs, 0);      // op index from which the buffer may be filled again
+  for (size_t q = 0; q < n_ops; ++q) {
+    if (prog.ops[q].kind != M_LD_LEAF) continue;
+    const uint32_t c = rm_chunk_of(prog.ops[q].a);
+    cursor[c]++;                                   // uses[c][cursor[c]..] are the later ones
+    int b = -1;
+    for (uint32_t k = 0; k < rm_bufs; ++k) if (resident[k] == (int64_t)c) b = (int)k;
+    if (b < 0) {
+      // a chunk is worth a buffer (and eight loads) when at least three of its leaves are read within the next
+      // RM_WINDOW ops; stragglers -- a value used again long after its neighbours -- are gathered from memory
+      size_t soon = 1;
+      for (size_t k = cursor[c]; k < uses[c].size() && uses[c][k] <= q + RM_WINDOW; ++k) soon++;
+      if (soon < 3) continue;
+      // victim: an empty buffer, else the resident chunk whose next use is farthest (none at all first)
+      size_t far = 0;
+      for (uint32_t k = 0; k < rm_bufs; ++k) {
+        size_t nu;
+        if (resident[k] < 0) nu = std::numeric_limits<size_t>::max();
+        else { const auto &u = uses[(size_t)resident[k]]; const size_t cu = cursor[(size_t)resident[k]]; nu = cu < u.size() ? u[cu] : std::numeric_limits<size_t>::max() - 1; }
+        if (b < 0 || nu > far) { b = (int)k; far = nu; }
+      }
+      rm_fetch[std::min(free_from[(size_t)b], q)].push_back(RmFetch{c, (uint32_t)b});
+      resident[(size_t)b] = c;
+    }
+    rm_ld_buf[q] = b;
+    free_from[(size_t)b] = q + 1;
+  }
+}
+
 static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog, const std::string &kname, int W, bool accumulate = false,
                               uint32_t rm_bufs = 0) {
   E.vm_issued = E.lg_issued = E.vm_done = E.lg_done = 0;
@@ -599,50 +641,13 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   // the constant of a micro-op: a kernel argument when tagged, else as above
   auto op_const = [&](const MOp &o) -> std::string { return o.param ? S2(S_PARAM + 2 * (o.param - 1)) : const_operand(o.imm); };
   auto op_const_sgpr = [&](const MOp &o) -> int { return o.param ? S_PARAM + 2 * (o.param - 1) : const_sgpr(o.imm); };
-  // ---- row-major variant: which chunk sits in which staging buffer when -------------------------------------------
-  // chunk c = leaves 16 c .. 16 c + 15; a last partial chunk is shifted back to end at the last leaf (never reads past a row)
-  const uint32_t rm_full = p.L / RM_CHUNK, rm_tail = (p.L % RM_CHUNK) ? 1u : 0u;
+  // ---- row-major variant: which chunk sits in which staging buffer when (rm_plan above) ---------------------------
+  const uint32_t rm_full = p.L / RM_CHUNK;
   auto rm_chunk_of = [&](uint32_t leaf) { return leaf < rm_full * RM_CHUNK ? leaf / RM_CHUNK : rm_full; };
   auto rm_chunk_start = [&](uint32_t c) { return c < rm_full ? c * RM_CHUNK : p.L - RM_CHUNK; };
-  struct RmFetch { uint32_t chunk, buf; };
   std::vector<std::vector<RmFetch>> rm_fetch;       // [op index] fetches issued in front of that op
   std::vector<int> rm_ld_buf;                       // [op index] staging buffer an LD_LEAF reads, -1 = gathered from memory
-  if (rm_bufs) {
-    const size_t n_ops = prog.ops.size();
-    rm_fetch.assign(n_ops + 1, {});
-    rm_ld_buf.assign(n_ops, -1);
-    std::vector<std::vector<size_t>> uses(rm_full + rm_tail);
-    for (size_t q = 0; q < n_ops; ++q) if (prog.ops[q].kind == M_LD_LEAF) uses[rm_chunk_of(prog.ops[q].a)].push_back(q);
-    std::vector<size_t> cursor(uses.size(), 0);
-    std::vector<int64_t> resident(rm_bufs, -1);
-    std::vector<size_t> free_from(rm_bufs, 0);      // op index from which the buffer may be filled again
-    for (size_t q = 0; q < n_ops; ++q) {
-      if (prog.ops[q].kind != M_LD_LEAF) continue;
-      const uint32_t c = rm_chunk_of(prog.ops[q].a);
-      cursor[c]++;                                   // uses[c][cursor[c]..] are the later ones
-      int b = -1;
-      for (uint32_t k = 0; k < rm_bufs; ++k) if (resident[k] == (int64_t)c) b = (int)k;
-      if (b < 0) {
-        // a chunk is worth a buffer (and eight loads) when at least three of its leaves are read within the next
-        // RM_WINDOW ops; stragglers -- a value used again long after its neighbours -- are gathered from memory
-        size_t soon = 1;
-        for (size_t k = cursor[c]; k < uses[c].size() && uses[c][k] <= q + RM_WINDOW; ++k) soon++;
-        if (soon < 3) continue;
-        // victim: an empty buffer, else the resident chunk whose next use is farthest (none at all first)
-        size_t far = 0;
-        for (uint32_t k = 0; k < rm_bufs; ++k) {
-          size_t nu;
-          if (resident[k] < 0) nu = std::numeric_limits<size_t>::max();
-          else { const auto &u = uses[(size_t)resident[k]]; const size_t cu = cursor[(size_t)resident[k]]; nu = cu < u.size() ? u[cu] : std::numeric_limits<size_t>::max() - 1; }
-          if (b < 0 || nu > far) { b = (int)k; far = nu; }
-        }
-        rm_fetch[std::min(free_from[(size_t)b], q)].push_back(RmFetch{c, (uint32_t)b});
-        resident[(size_t)b] = c;
-      }
-      rm_ld_buf[q] = b;
-      free_from[(size_t)b] = q + 1;
-    }
-  }
+  if (rm_bufs) rm_plan(p, prog, rm_bufs, rm_fetch, rm_ld_buf);
   std::vector<uint64_t> rm_ready(rm_bufs, 0);        // vm sequence number of the last load of the chunk in each buffer
   auto rm_emit_fetch = [&](const RmFetch &f) {
     // the buffer's previous readers have been issued; their data must have left the LDS before it is overwritten
@@ -1012,6 +1017,16 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
 }
 
 }  // namespace
+
+// What the row-major variant of `prog` would move with `bufs` staging buffers: chunk fetches (8 KB each) and gathered leaves.
+void rm_plan_stats(const Lowered &p, const OptProgram &prog, uint32_t bufs, uint64_t &fetches, uint64_t &gathers) {
+  std::vector<std::vector<RmFetch>> f;
+  std::vector<int> ld;
+  rm_plan(p, prog, bufs, f, ld);
+  fetches = gathers = 0;
+  for (const auto &v : f) fetches += v.size();
+  for (size_t q = 0; q < prog.ops.size(); ++q) if (prog.ops[q].kind == M_LD_LEAF && ld[q] < 0) gathers++;
+}
 
 // Re-parses an assembly listing against the hazard table (independent of how the listing was produced).  Returns the
 // number of violations; `report` gets one line per violation and a summary of what was checked.

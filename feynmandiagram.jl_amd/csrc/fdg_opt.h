@@ -110,6 +110,7 @@ bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp>
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2 = nullptr,
                      const OptProgram *prog_acc = nullptr, const OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0);
 
+void rm_plan_stats(const Lowered &p, const OptProgram &prog, uint32_t bufs, uint64_t &fetches, uint64_t &gathers);
 // gfx950 wait-state table of the emitter (fdg_isa.cpp): check of a finished listing, and the table as text
 int check_isa_hazards(const std::string &text, std::string &report);
 std::string isa_hazard_table();

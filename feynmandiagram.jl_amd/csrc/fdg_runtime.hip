@@ -1109,18 +1109,30 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
 static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chosen, fdg::OptProgram &pr) {
   if (g->prog.L < 16 || std::getenv("FDG_ISA_NO_RM")) return 0;
   if (chosen.n_reg < 100) return 0;                              // tiny-graph configuration
-  // One wave per SIMD whatever the leaf-major kernel runs with: 40 KB of LDS per wave hold four staging buffers -- the
+  // One wave per SIMD whatever the leaf-major kernel runs with: 40 KB of LDS per wave hold up to four staging buffers -- the
   // stream of first uses plus the few chunks a schedule keeps coming back to -- and the AGPR level makes up for the LDS
-  // slots given away.  (Graphs that stream leaves are bound by latency, not by occupancy: DESIGN.md 6.)
-  uint32_t bufs = 4;
-  if (const char *e = std::getenv("FDG_ISA_RM_BUFS")) bufs = (uint32_t)std::max(1, std::min(4, std::atoi(e)));
-  fdg::OptParams q = cfg_B();
-  q.vn_window = chosen.vn_window;
-  q.n_lds = 80u - bufs * 16u - 2u;                               // (two slots lost to the 1 KB alignment of the buffers)
-  q.reserve_pairs = 5;
-  q.lookahead_leaf = 48;
-  build_prog(g, q, pr);
-  return pr.supported ? bufs : 0;
+  // slots given away.  (Graphs that stream leaves are bound by latency, not by occupancy: DESIGN.md 6.)  The fewest
+  // buffers that keep re-fetching within a quarter of the chunk count are taken: a small graph then leaves room for
+  // more waves per CU.  A program that would move more than 2.5x the matrix (leaves re-read all over a huge graph)
+  // gets no such variant: the chunked transposition in front of the leaf-major kernel is cheaper there.
+  const uint32_t n_chunk = (g->prog.L + 15) / 16;
+  const char *e = std::getenv("FDG_ISA_RM_BUFS");
+  for (uint32_t bufs = e ? (uint32_t)std::max(1, std::min(4, std::atoi(e))) : 2u; bufs <= 4; ++bufs) {
+    fdg::OptParams q = cfg_B();
+    q.vn_window = chosen.vn_window;
+    q.n_lds = 80u - bufs * 16u - 2u;                             // (two slots lost to the 1 KB alignment of the buffers)
+    q.reserve_pairs = 5;
+    q.lookahead_leaf = 48;
+    build_prog(g, q, pr);
+    if (!pr.supported) return 0;
+    uint64_t fetches = 0, gathers = 0;
+    fdg::rm_plan_stats(g->prog, pr, bufs, fetches, gathers);
+    const bool cheap = fetches * 4 <= (uint64_t)n_chunk * 5 + 4;
+    if (!cheap && bufs < 4 && !e) continue;
+    if ((fetches * 8192 + gathers * 2048) * 2 > (uint64_t)g->prog.L * 512 * 5) return 0;
+    return bufs;
+  }
+  return 0;
 }
 
 struct IsaVariants {

@@ -12,9 +12,13 @@ t = workloads.get(name)
 st = t.stats()
 L, R = t.n_leaf, t.n_root
 B = int(os.environ.get("SWEEP_B", max(1 << 14, min(4_000_000, int(2.4e9 / (8 * L))))))
-leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
+if os.environ.get("SWEEP_LAYOUT") == "sample_major":      # compile_Python's row-major [B, L] / [B, R]
+    leaf = torch.empty((B, L), dtype=torch.float64, device=dev)
+    root = torch.empty((B, R), dtype=torch.float64, device=dev)
+else:
+    leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
+    root = torch.empty((R, B), dtype=torch.float64, device=dev).t()
 capi.fill_uniform_device(leaf.data_ptr(), B, L, leaf.stride(0), leaf.stride(1), 11, 0, torch.cuda.current_stream().cuda_stream)
-root = torch.empty((R, B), dtype=torch.float64, device=dev).t()
 nchk = 4099
 want = oracle.eval_static(t, leaf[:nchk].cpu().numpy(), np.zeros((nchk, R)))
 for setting in sys.argv[2:]:
