@@ -99,7 +99,7 @@ def attach_traffic(roof, workload, layout, B, avg_kernel_s):
     profile, not a measurement of this run."""
     for fn in ("r02_traffic.json", "r01_traffic.json"):
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", fn))).get(workload)
+            tr = json.load(open(os.path.join(ROOT, "profiles", fn))).get(workload if layout == "leaf_major" else workload + ":" + layout)
         except (OSError, ValueError):
             continue
         if tr and tr.get("layout", "leaf_major") == layout:

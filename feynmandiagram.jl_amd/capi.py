@@ -75,7 +75,7 @@ class LeafTables(C.Structure):
 class OptParams(C.Structure):
     _fields_ = [("n_reg", C.c_uint32), ("n_lds", C.c_uint32), ("lookahead_lds", C.c_uint32),
                 ("lookahead_mem", C.c_uint32), ("lookahead_leaf", C.c_uint32), ("n_acc", C.c_uint32),
-                ("vn_window", C.c_uint32), ("fma", C.c_uint32)]
+                ("vn_window", C.c_uint32), ("fma", C.c_uint32), ("remat_window", C.c_uint32), ("remat_cost", C.c_uint32)]
 
 
 class MOp(C.Structure):
@@ -209,13 +209,13 @@ class GraphHandle:
         finally:
             lib().fdg_free(s)
 
-    def set_opt_params(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0, vn_window=0, fma=0):
-        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc, vn_window, fma)
+    def set_opt_params(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0, vn_window=0, fma=0, remat_window=0, remat_cost=0):
+        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc, vn_window, fma, remat_window, remat_cost)
         check(lib().fdg_graph_set_opt_params(self._h, C.byref(q)))
 
-    def opt_program(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0, vn_window=0, fma=0):
+    def opt_program(self, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0, vn_window=0, fma=0, remat_window=0, remat_cost=0):
         """Returns ``(ops, n_reg_used, n_lds_used, n_mem_used)``; ops is a numpy record array (MOP_DTYPE)."""
-        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc, vn_window, fma)
+        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc, vn_window, fma, remat_window, remat_cost)
         ops = C.POINTER(MOp)()
         n = C.c_uint64()
         nr, nl, nm, na = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
@@ -229,10 +229,10 @@ class GraphHandle:
         self.last_n_acc = na.value
         return arr, nr.value, nl.value, nm.value
 
-    def mc_program(self, tables, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0, vn_window=0, fma=0):
+    def mc_program(self, tables, n_reg=0, n_lds=0, lookahead_lds=0, lookahead_mem=0, lookahead_leaf=0, n_acc=0, vn_window=0, fma=0, remat_window=0, remat_cost=0):
         """The program of the fused ISA step (leaves computed from the input columns K components, then times;
         ``tables`` from make_leaf_tables with kF, beta, lam set).  Returns like :meth:`opt_program`."""
-        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc, vn_window, fma)
+        q = OptParams(n_reg, n_lds, lookahead_lds, lookahead_mem, lookahead_leaf, n_acc, vn_window, fma, remat_window, remat_cost)
         ops = C.POINTER(MOp)()
         n = C.c_uint64()
         nr, nl, nm, na = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()

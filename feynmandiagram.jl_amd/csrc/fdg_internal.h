@@ -86,7 +86,7 @@ struct fdg_ws_set {
 struct fdg_graph {
   fdg::Lowered prog;
   // tuning knobs set by fdg_graph_set_opt_params (has_opt: the next FDG_SPEC_ISA specialisation uses them as they are)
-  fdg_opt_params opt = {0, 0, 0, 0, 0, 0, 0, 0};
+  fdg_opt_params opt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool has_opt = false;
   std::vector<fdg_ws_set> ws_pool;
   void *ws_key = nullptr;

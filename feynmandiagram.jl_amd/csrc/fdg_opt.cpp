@@ -867,13 +867,16 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   B0.value_numbering = prm.vn_window != 1;     // 1 = off, 0 = unlimited, else window in ops
   B0.vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
   B0.vn_touch = std::getenv("FDG_VN_BIRTH_WINDOW") == nullptr;   // default: the window counts from the last read
-  if (const char *rw = std::getenv("FDG_REMAT_WINDOW")) B0.remat_window = (uint64_t)std::atoll(rw);
+  B0.remat_window = prm.remat_window;
+  B0.remat_cost = prm.remat_cost;
+  if (const char *rw = std::getenv("FDG_REMAT_WINDOW")) B0.remat_window = (uint64_t)std::atoll(rw);     // experiments
   build_uops(B0);
   Lowered plain;
   const bool retry = !B0.ok && B0.why == "inconsistent schedule groups";
   if (retry) { plain = p; plain.sched_group.clear(); }
   Builder B1(retry ? plain : p);
   B1.value_numbering = B0.value_numbering; B1.vn_window = B0.vn_window; B1.vn_touch = B0.vn_touch;
+  B1.remat_window = B0.remat_window; B1.remat_cost = B0.remat_cost;
   if (retry) build_uops(B1);
   Builder &B = retry ? B1 : B0;
   out.supported = B.ok;

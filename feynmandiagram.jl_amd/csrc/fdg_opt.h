@@ -73,6 +73,8 @@ struct OptParams {
   uint32_t vn_window = 200;       // value numbering: 1 = off, 0 = reuse any earlier identical op, n > 1 = only results at most n ops old
   uint32_t lookahead_leaf = 300;  // ... for first-use loads of leaves (HBM)
   bool fma = false;               // FDG_SPEC_FAST_MATH: a product used once, by a sum, is fused into it (v_fma_f64)
+  uint32_t remat_window = 0;      // > 0: the value of a cheap node not read for this many ops is forgotten and computed again by its
+  uint32_t remat_cost = 4;        //      next consumer (nodes whose own fold has at most remat_cost steps); exact, trades arithmetic for spills
   uint32_t reserve_pairs = 0;     // VGPR pairs the kernel variant keeps above the values (accumulators, weight): the value budget shrinks
                                   // by this and by the temporaries the program's macro ops need, so that everything stays below v256
 };

@@ -878,6 +878,8 @@ static fdg::OptParams to_params(const fdg_opt_params *q) {
     if (q->n_acc) prm.n_acc = std::min<uint32_t>(q->n_acc, 124);
     if (q->vn_window) prm.vn_window = q->vn_window;
     prm.fma = q->fma != 0;
+    prm.remat_window = q->remat_window;
+    if (q->remat_cost) prm.remat_cost = std::min<uint32_t>(q->remat_cost, 64);
   }
   return prm;
 }
@@ -1162,8 +1164,10 @@ static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   fdg::OptParams q;
   buf.push_back(0);
   {
-    fdg_opt_params r = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (std::sscanf(buf.data(), "%u %u %u %u %u %u %u", &r.n_reg, &r.n_lds, &r.n_acc, &r.lookahead_lds, &r.lookahead_mem, &r.lookahead_leaf, &r.vn_window) != 7) return 0;
+    fdg_opt_params r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // seven numbers, or nine: ... recompute window and cost (files written before round 2 have seven)
+    if (std::sscanf(buf.data(), "%u %u %u %u %u %u %u %u %u", &r.n_reg, &r.n_lds, &r.n_acc, &r.lookahead_lds, &r.lookahead_mem, &r.lookahead_leaf, &r.vn_window,
+                    &r.remat_window, &r.remat_cost) < 7) return 0;
     if (r.n_reg < 4) return 0;
     q = to_params(&r);          // the same clamps as parameters handed over through the ABI
     if (!r.n_acc) q.n_acc = 0;
@@ -1186,8 +1190,9 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   const fdg::Lowered &p = g->prog;
   const std::string tuned = tuned_path(g, dir);
   auto to_line = [](const fdg::OptParams &q) {
-    char b[160];
-    std::snprintf(b, sizeof b, "%u %u %u %u %u %u %u", q.n_reg, q.n_lds, q.n_acc, q.lookahead_lds, q.lookahead_mem, q.lookahead_leaf, q.vn_window);
+    char b[200];
+    std::snprintf(b, sizeof b, "%u %u %u %u %u %u %u %u %u", q.n_reg, q.n_lds, q.n_acc, q.lookahead_lds, q.lookahead_mem, q.lookahead_leaf, q.vn_window,
+                  q.remat_window, q.remat_cost);
     return std::string(b);
   };
   std::vector<fdg::OptParams> cand;
@@ -1202,6 +1207,15 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   { fdg::OptParams q = cfg_A(); q.vn_window = 300; cand.push_back(q); }
   { fdg::OptParams q = cfg_A(); q.n_reg = 80; q.n_lds = 26; cand.push_back(q); }     // three waves per SIMD
   { fdg::OptParams q = cfg_A(); q.n_reg = 56; q.n_lds = 20; cand.push_back(q); }     // four waves per SIMD
+  // programs that spill to the HBM panel: forget-and-recompute of cheap nodes (arithmetic instead of panel traffic)
+  {
+    fdg::OptProgram pb;
+    build_prog(g, cfg_B(), pb);
+    if (pb.supported && (pb.n_ld_mem + pb.n_st_mem) * 20 > pb.n_valu) {
+      for (uint32_t w : {500u, 1000u, 2000u}) for (uint32_t c : {3u, 6u}) { fdg::OptParams q = cfg_B(); q.vn_window = 200; q.remat_window = w; q.remat_cost = c; cand.push_back(q); }
+      { fdg::OptParams q = cfg_B(); q.vn_window = 60; cand.push_back(q); }
+    }
+  }
   // batch: at least two tiles per resident wave, and enough bytes (about 0.4 GB of leaves) that a run
   // is not dominated by launch overhead on tiny graphs
   long Bt = std::max<long>((long)g->n_cu * 8 * 64 * 2, (long)(4e8 / (8.0 * std::max<uint32_t>(p.L + p.R, 1))));

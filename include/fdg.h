@@ -157,6 +157,9 @@ typedef struct fdg_opt_params {
   uint32_t n_acc;          /* AGPR pairs per lane used as a spill level (<= 124; 0 with two waves per SIMD) */
   uint32_t vn_window;      /* value numbering of identical fold steps: 0 default, 1 off, n > 1 window in ops */
   uint32_t fma;            /* fdg_graph_opt_program only: 1 = fuse products into sums like FDG_SPEC_FAST_MATH does */
+  uint32_t remat_window;   /* > 0: the value of a cheap node that has not been read for this many ops is forgotten and computed
+                            * again by its next consumer (same operations, same bits): arithmetic instead of spill traffic */
+  uint32_t remat_cost;     /* ... "cheap" = at most this many fold steps of its own (default 4) */
 } fdg_opt_params;
 
 /* One op of the register-allocated program (for inspection and for host-side

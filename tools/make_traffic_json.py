@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""profiles/r02_traffic.json from the PMC passes of tools/prof_r02.sh: per workload and layout, HBM-side bytes per
+evaluation of the evaluator kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / samples  (FETCH_SIZE / WRITE_SIZE in KiB per
+dispatch; the factor 2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md's HBM section, calibrated on sigma2 where
+the byte count is known: 64 B read + 16 B written per evaluation).  usage: make_traffic_json.py gpurun_out/prof_<tag> out.json"""
+import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root, out_path = sys.argv[1], sys.argv[2]
+SAMPLES = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "gv_sigma4": 8_000_000, "gv_sigma5": 2_000_000, "gv_sigma6": 500_000,
+           "gv_sigma4_taylor2": 4_000_000}
+out = {"_comment": "HBM-side traffic of the evaluator kernel from separate rocprofv3 --pmc passes (tools/prof_r02.sh; summaries in "
+                   "profiles/r02_pmc_*.txt): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; factor 2 = the guide's gfx950 FETCH_SIZE "
+                   "correction, calibrated on sigma2 (80 B per evaluation).  Infinity-Cache hits are included in FETCH_SIZE: this is "
+                   "L2-miss traffic, an upper bound on HBM bytes.  Keys: workload, or workload:sample_major for the row-major layout."}
+for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    name = os.path.basename(d)[4:]
+    lay = "sample_major" if name.endswith("_sample_major") else "leaf_major"
+    wl = name[: -len("_" + lay)]
+    vals = {}
+    for f in glob.glob(os.path.join(d, "pass*", "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                k = r["Kernel_Name"]
+                if k.startswith("fdg_isa_eval"):
+                    vals.setdefault((k.replace(".kd", ""), r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    kernels = sorted({k for k, _ in vals})
+    fetch = sum(sum(vals.get((k, "FETCH_SIZE"), [0])) / max(1, len(vals.get((k, "FETCH_SIZE"), [0]))) for k in kernels)
+    write = sum(sum(vals.get((k, "WRITE_SIZE"), [0])) / max(1, len(vals.get((k, "WRITE_SIZE"), [0]))) for k in kernels)
+    if not kernels:
+        continue
+    B = SAMPLES[wl]
+    key = wl if lay == "leaf_major" else wl + ":" + lay
+    out[key] = {"layout": lay, "samples": B, "kernels": kernels, "fetch_kib": fetch, "write_kib": write,
+                "bytes_per_eval": round((2 * fetch + write) * 1024 / B, 1), "source": f"profiles/r02_pmc_{wl}_{lay}.txt"}
+json.dump(out, open(out_path, "w"), indent=1)
+print(json.dumps(out, indent=1))
