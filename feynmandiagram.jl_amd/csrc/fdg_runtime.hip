@@ -1641,7 +1641,7 @@ int fdg_copy_device(double *d_dst, const double *d_src, int64_t n, void *stream)
   if (n == 0) return FDG_OK;
   if (!d_dst || !d_src || (((uintptr_t)d_dst | (uintptr_t)d_src) & 15)) { set_error("fdg_copy_device: null or not 16-byte aligned"); return FDG_E_INVALID; }
   const long n16 = (long)(n / 2);
-  const long grid = std::min<long>((n16 + 255) / 256, 256L * 32);
+  const long grid = std::min<long>((n16 + 255) / 256, 256L * 8);        // 8 workgroups per CU, grid-stride for the rest
   hipLaunchKernelGGL(fdg_copy16, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const fdg_v2d *)d_src, (fdg_v2d *)d_dst, n16);
   HIP_TRY(hipGetLastError());
   return FDG_OK;
