@@ -29,7 +29,7 @@ EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
     "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
-    "fdg_eval_strided", "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
+    "fdg_eval_strided", "fdg_graph_coop_program", "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
 ]
@@ -135,6 +135,7 @@ def lib():
                                         C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.fdg_graph_mc_program.argtypes = [vp, C.POINTER(LeafTables), C.POINTER(OptParams), C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64),
                                        C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.fdg_graph_coop_program.argtypes = [vp, C.POINTER(OptParams), u32, C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64), C.POINTER(u32)]
     L.fdg_graph_specialize_fused.argtypes = [vp, C.POINTER(LeafTables), C.c_char_p, C.c_uint]
     L.fdg_mc_eval_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, C.c_double, C.c_double, C.c_double, dp, i64, i64, i64, vp]
     L.fdg_mc_accumulate_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, C.c_double, C.c_double, C.c_double, dp, dp, i64, vp]
@@ -243,6 +244,26 @@ class GraphHandle:
         finally:
             lib().fdg_free(ops)
         return arr, nr.value, nl.value, nm.value
+
+    def coop_program(self, **kw):
+        """The four per-wave programs of the cooperative variant: ``([ops_w0, .., ops_w3], info)`` with
+        ``info = dict(n_reg, n_lds, n_mem, n_acc per wave; n_shared, n_epoch, n_transfer, n_duplicate)``."""
+        q = OptParams(kw.get("n_reg", 0), kw.get("n_lds", 0), kw.get("lookahead_lds", 0), kw.get("lookahead_mem", 0),
+                      kw.get("lookahead_leaf", 0), kw.get("n_acc", 0), kw.get("vn_window", 0), 0, 0, 0)
+        progs, per_wave = [], []
+        info = None
+        for w in range(4):
+            ops = C.POINTER(MOp)()
+            n = C.c_uint64()
+            inf = (C.c_uint32 * 8)()
+            check(lib().fdg_graph_coop_program(self._h, C.byref(q), w, C.byref(ops), C.byref(n), inf))
+            try:
+                progs.append(np.frombuffer(C.string_at(ops, n.value * C.sizeof(MOp)), dtype=MOP_DTYPE).copy())
+            finally:
+                lib().fdg_free(ops)
+            per_wave.append(dict(n_reg=inf[0], n_lds=inf[1], n_mem=inf[2], n_acc=inf[3]))
+            info = dict(n_shared=inf[4], n_epoch=inf[5], n_transfer=inf[6], n_duplicate=inf[7], waves=per_wave)
+        return progs, info
 
     def specialize(self, cache_dir: Optional[str] = None, flags: int = 0):
         cd = cache_dir if cache_dir is not None else os.environ.get("FDG_CACHE_DIR", KERNEL_CACHE)

@@ -11,6 +11,7 @@
 #include <deque>
 #include <limits>
 #include <map>
+#include <memory>
 #include <unordered_map>
 
 #include "fdg_opt.h"
@@ -686,6 +687,7 @@ struct Alloc {
       case 1: out.push_back(MOp{M_LD_LDS, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_lds++; break;
       case 2: out.push_back(MOp{M_LD_MEM, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_mem++; break;
       case 4: out.push_back(MOp{M_LD_ACC, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_acc++; break;
+      case 5: out.push_back(MOp{M_RECV, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_recv++; break;          // still in its shared slot
       default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v - leaf_lo, 0, 0.0}); prog.n_ld_leaf++; break;   // leaves only
     }
     reg_of[v] = r; owner[r] = v; lock[r] = pos;
@@ -699,6 +701,7 @@ struct Alloc {
     switch (home_kind[v]) {
       case 1: out.push_back(MOp{M_LD_LDS, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_lds++; break;
       case 2: out.push_back(MOp{M_LD_MEM, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_mem++; break;
+      case 5: out.push_back(MOp{M_RECV, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_recv++; break;
       default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v - leaf_lo, 0, 0.0}); prog.n_ld_leaf++; break;
     }
     reg_of[v] = r; owner[r] = v;
@@ -709,6 +712,7 @@ struct Alloc {
     if (pf <= j) pf = j + 1;
     for (; pf < lim; ++pf) {
       const UOp &o = u[pf];
+      if (!mop_has_a(o.kind)) continue;
       const uint32_t va = o.a >> 1;
       if (home_kind[va] == kind) prefetch(va, j, pf);
       if (mop_has_b(o.kind)) {
@@ -725,6 +729,7 @@ struct Alloc {
     uses.assign(nv, {});
     for (uint32_t j = 0; j < u.size(); ++j) {
       const UOp &o = u[j];
+      if (!mop_has_a(o.kind)) continue;
       uses[o.a >> 1].push_back(j);
       if (mop_has_b(o.kind)) uses[o.b >> 1].push_back(j);
       if (mop_has_c(o.kind)) uses[o.c >> 1].push_back(j);
@@ -744,6 +749,16 @@ struct Alloc {
       if (prm.lookahead_leaf) prefetch_window(pf_leaf, j, prm.lookahead_leaf, 3);
       if (prm.lookahead_mem) prefetch_window(pf_mem, j, prm.lookahead_mem, 2);
       if (prm.lookahead_lds) prefetch_window(pf_lds, j, prm.lookahead_lds, 1);
+      if (o.kind == M_BARRIER) { out.push_back(MOp{M_BARRIER, 0, 0, 0, 0, 0, 0.0}); prog.n_barrier++; continue; }
+      if (o.kind == M_RECV) {             // a value another wave published: it stays re-loadable from its shared slot for its whole life
+        const uint32_t rd = take_reg(j, true);
+        reg_of[o.d] = rd; owner[rd] = o.d; lock[rd] = j;
+        home_kind[o.d] = 5; home_slot[o.d] = o.a;
+        out.push_back(MOp{M_RECV, 0, 0, rd, o.a, 0, 0.0});
+        prog.n_recv++;
+        if (uses[o.d].empty()) kill(o.d);
+        continue;
+      }
       const bool two = mop_has_b(o.kind);
       const bool three = mop_has_c(o.kind);
       const uint32_t va = o.a >> 1, vb = two ? (o.b >> 1) : NONE, vc = three ? (o.c >> 1) : NONE;
@@ -759,6 +774,11 @@ struct Alloc {
       if (three && vc != va && vc != vb && next_use(vc) == std::numeric_limits<uint32_t>::max()) kill(vc);
       if (o.kind == M_ROOT) {
         out.push_back(MOp{M_ROOT, (uint8_t)(o.a & 1), 0, o.d, ra, 0, 0.0});
+        continue;
+      }
+      if (o.kind == M_SEND) {
+        out.push_back(MOp{M_SEND, 0, 0, o.d, ra, 0, 0.0});
+        prog.n_send++;
         continue;
       }
       const uint32_t rd = take_reg(j);
@@ -788,6 +808,7 @@ struct Alloc {
 void hoist_loads(std::vector<MOp> &ops, const OptParams &prm) {
   const size_t n = ops.size();
   std::vector<int64_t> last_reg(prm.n_reg, -1), last_st_lds, last_st_mem;
+  int64_t last_barrier = -1;
   std::vector<std::pair<double, uint32_t>> key(n);
   for (size_t q = 0; q < n; ++q) {
     MOp &o = ops[q];
@@ -804,6 +825,15 @@ void hoist_loads(std::vector<MOp> &ops, const OptParams &prm) {
         touch(o.d);
         break;
       }
+      case M_RECV: {       // never above the barrier that makes the slot's content visible
+        int64_t lo = std::max(last_reg[o.d] + 1, last_barrier + 1);
+        lo = std::max<int64_t>(lo, (int64_t)q - (int64_t)prm.lookahead_lds);
+        if (lo < (int64_t)q) k = (double)lo - 0.5;
+        touch(o.d);
+        break;
+      }
+      case M_SEND: touch(o.a); break;
+      case M_BARRIER: last_barrier = (int64_t)q; break;
       case M_ST_LDS:
         if (last_st_lds.size() <= o.d) last_st_lds.resize(o.d + 1, -1);
         last_st_lds[o.d] = (int64_t)q; touch(o.a); break;
@@ -940,6 +970,324 @@ bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp>
   for (const UOp &o : B.u) ops.push_back(SchedOp{o.kind, o.d, o.a, o.b, o.imm});
   n_value = B.next_vid;
   return true;
+}
+
+}  // namespace fdg
+
+// =====================================================================================================================
+// Cooperative variant (fdg_opt.h: CoopProgram).  Host-side simulation of four waves working through the graph in epochs:
+// the terms of the wide root sums are dealt to whichever wave is free, a wave that needs a shared sub-expression another
+// wave computed in an EARLIER epoch receives it through a shared LDS slot, the root's own left fold runs on its home wave as
+// the terms arrive (the association is untouched: only who computes a term changes).  Afterwards the hand-overs are grouped
+// into publication intervals, slots are assigned, the owners' programs get their M_SEND ops, and each wave's list goes
+// through the ordinary allocator.
+// =====================================================================================================================
+namespace fdg {
+namespace {
+
+struct CoopBuild {
+  const Lowered &p;
+  const uint32_t L;
+  std::vector<std::unique_ptr<Builder>> B;
+  // global knowledge about nodes
+  std::vector<int8_t> owner;          // [N] wave whose value is the published one, -1 = not computed yet
+  std::vector<uint32_t> prod_epoch;   // [N]
+  std::vector<uint32_t> pub_ref;      // [N] the owner's ref of the node's value (vid << 1 | neg)
+  std::vector<int8_t> in_progress;    // [N] wave that has the node on its stack, -1 = none
+  std::vector<uint8_t> cheap;         // [N] may be computed again by a wave that cannot wait for it
+  std::vector<uint8_t> is_wide_root;  // [N]
+  // copies: a value received by a wave (one M_RECV op each)
+  struct Copy { uint32_t node; uint8_t wave; uint32_t e_first, e_last; uint32_t uop; uint32_t interval = NONE; };
+  std::vector<Copy> copies;
+  std::vector<std::vector<uint32_t>> copy_of;   // [wave][N] index of the live copy, NONE
+  struct Wide { uint32_t node, home, next, acc; bool done; };
+  std::vector<Wide> wides;
+  std::vector<uint32_t> tasks;        // value indices (>= L) to compute, in order
+  size_t next_task = 0;
+  std::vector<std::vector<Frame>> st;
+  std::vector<std::pair<uint32_t, uint32_t>> rootlist;
+  uint32_t cur_epoch = 0;
+  uint64_t n_dup = 0;
+  uint32_t copy_window = 600;         // a received value not read for this many ops of its wave is received again when needed
+  bool ok = true;
+  std::string why;
+
+  explicit CoopBuild(const Lowered &p_) : p(p_), L(p_.L) {}
+
+  uint32_t fold_cost(uint32_t n) const {
+    uint32_t c = p.off[n + 1] - p.off[n] - 1;
+    for (uint32_t e = p.off[n]; e < p.off[n + 1]; ++e) if (p.fac[e] != 1.0 && p.fac[e] != -1.0) c++;
+    if (p.op[n] == FDG_OP_POWER) c += 4;
+    return c;
+  }
+  void emit_roots(uint32_t w, uint32_t v) {
+    auto it = std::lower_bound(rootlist.begin(), rootlist.end(), std::make_pair(v, 0u));
+    for (; it != rootlist.end() && it->first == v; ++it) B[w]->u.push_back(UOp{M_ROOT, it->second, B[w]->ref_of[v], 0, 0.0});
+  }
+  // one fold step of node n with operand ref cr (the reference's left fold, static.jl:13-46)
+  uint32_t fold(Builder &Bw, uint32_t n, uint32_t i, uint32_t acc, uint32_t cr) {
+    const uint32_t a = p.off[n];
+    const double fc = p.fac[a + i];
+    Bw.touch(cr);
+    if (p.op[n] == FDG_OP_SUM) {
+      const uint32_t t = Bw.mulc(cr, fc);
+      return i == 0 ? t : Bw.op2(M_ADD, acc, t);
+    }
+    if (p.op[n] == FDG_OP_PROD) {
+      acc = i == 0 ? cr : Bw.op2(M_MUL, acc, cr);
+      return Bw.mulc(acc, fc);
+    }
+    return Bw.mulc(Bw.powi(cr, p.power[n]), fc);
+  }
+  enum Avail { HAVE, COMPUTE, BLOCKED };
+  // operand c (value index) as seen by wave w; on HAVE `ref` is set (a receive op may have been emitted)
+  Avail operand(uint32_t w, uint32_t c, uint32_t &ref) {
+    Builder &Bw = *B[w];
+    if (c < L) { ref = Bw.ref_of[c]; return HAVE; }
+    const uint32_t n = c - L;
+    if (Bw.ref_of[c] != NONE) {
+      const uint32_t ci = copy_of[w][n];
+      if (ci == NONE) { ref = Bw.ref_of[c]; return HAVE; }                      // computed here
+      const uint32_t v = Bw.ref_of[c] >> 1;
+      if ((uint64_t)Bw.u.size() - Bw.born[v] <= copy_window) {                   // a copy still around
+        copies[ci].e_last = cur_epoch;
+        ref = Bw.ref_of[c];
+        return HAVE;
+      }
+      Bw.ref_of[c] = NONE; copy_of[w][n] = NONE;                                 // forgotten: received again below
+    }
+    if (owner[n] >= 0 && (uint32_t)owner[n] != w) {
+      if (prod_epoch[n] < cur_epoch) {
+        const uint32_t d = Bw.fresh();
+        Bw.u.push_back(UOp{M_RECV, d, 0, 0, 0.0});
+        copies.push_back(Copy{n, (uint8_t)w, cur_epoch, cur_epoch, (uint32_t)Bw.u.size() - 1});
+        copy_of[w][n] = (uint32_t)copies.size() - 1;
+        Bw.ref_of[c] = (d << 1) | (pub_ref[n] & 1u);
+        ref = Bw.ref_of[c];
+        return HAVE;
+      }
+      return (cheap[n] && !is_wide_root[n]) ? COMPUTE : BLOCKED;                 // computed by another wave in this very epoch
+    }
+    if (is_wide_root[n]) return BLOCKED;                                         // folded by its home wave as the terms arrive
+    if (in_progress[n] >= 0 && (uint32_t)in_progress[n] != w) return cheap[n] ? COMPUTE : BLOCKED;
+    return COMPUTE;
+  }
+  void finished(uint32_t w, uint32_t n, uint32_t acc) {
+    Builder &Bw = *B[w];
+    Bw.ref_of[L + n] = acc;
+    copy_of[w][n] = NONE;
+    if (in_progress[n] == (int8_t)w) in_progress[n] = -1;
+    if (owner[n] < 0) { owner[n] = (int8_t)w; prod_epoch[n] = cur_epoch; pub_ref[n] = acc; emit_roots(w, L + n); }
+    else n_dup += fold_cost(n);
+  }
+  // lets wave w do one unit of work; returns the number of ops it added, 0 = idle or blocked (blocked: `blk` set)
+  size_t advance(uint32_t w, bool &blk) {
+    Builder &Bw = *B[w];
+    const size_t before = Bw.u.size();
+    blk = false;
+    // 1. the fold of a wide root this wave is home of
+    for (Wide &W : wides) {
+      if (W.done || W.home != w) continue;
+      const uint32_t n = W.node, k = p.off[n + 1] - p.off[n];
+      const uint32_t c = p.idx[p.off[n] + W.next];
+      const bool ready = c < L || Bw.ref_of[c] != NONE || (owner[c - L] >= 0 && ((uint32_t)owner[c - L] == w || prod_epoch[c - L] < cur_epoch));
+      if (!ready) continue;
+      uint32_t cr;
+      const Avail a = operand(w, c, cr);
+      if (a != HAVE) continue;
+      W.acc = fold(Bw, n, W.next, W.acc, cr);
+      if (++W.next == k) { W.done = true; finished(w, n, W.acc); }
+      return std::max<size_t>(Bw.u.size() - before, 1);
+    }
+    // 2. a task
+    if (st[w].empty()) {
+      while (next_task < tasks.size() && (owner[tasks[next_task] - L] >= 0 || in_progress[tasks[next_task] - L] >= 0)) next_task++;
+      if (next_task >= tasks.size()) return 0;
+      const uint32_t n = tasks[next_task++] - L;
+      in_progress[n] = (int8_t)w;
+      st[w].push_back(Frame{n, 0, NONE});
+    }
+    Frame &f = st[w].back();
+    const uint32_t n = f.n, k = p.off[n + 1] - p.off[n];
+    if (owner[n] >= 0 && (uint32_t)owner[n] != w && prod_epoch[n] < cur_epoch && f.i == 0) {   // someone else finished it meanwhile
+      if (in_progress[n] == (int8_t)w) in_progress[n] = -1;
+      st[w].pop_back();
+      return 1;
+    }
+    const uint32_t c = p.idx[p.off[n] + f.i];
+    uint32_t cr;
+    const Avail a = operand(w, c, cr);
+    if (a == BLOCKED) { blk = true; return 0; }
+    if (a == COMPUTE) {
+      const uint32_t cn = c - L;
+      if (in_progress[cn] < 0) in_progress[cn] = (int8_t)w;
+      st[w].push_back(Frame{cn, 0, NONE});
+      return 1;
+    }
+    f.acc = fold(Bw, n, f.i, f.acc, cr);
+    if (++f.i == k) { const uint32_t acc = f.acc; st[w].pop_back(); finished(w, n, acc); }
+    return std::max<size_t>(Bw.u.size() - before, 1);
+  }
+};
+
+}  // namespace
+
+static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budget, uint32_t gap, CoopProgram &out);
+
+// Shorter epochs keep fewer hand-overs in flight: when the shared slots run out the schedule is rebuilt with a smaller budget.
+void build_coop_program(const Lowered &p, const OptParams &prm, CoopProgram &out) {
+  const char *te = std::getenv("FDG_COOP_EPOCH_OPS");
+  if (te) { build_coop_once(p, prm, (size_t)std::max(8, std::atoi(te)), 2, out); return; }
+  for (size_t budget : {192, 128, 96, 64, 48}) {
+    build_coop_once(p, prm, budget, budget > 64 ? 2u : 1u, out);
+    if (out.supported || out.why != "shared LDS slots exhausted") return;
+  }
+}
+
+static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budget, uint32_t gap, CoopProgram &out) {
+  out = CoopProgram();
+  constexpr uint32_t NW = CoopProgram::NW;
+  const uint32_t L = p.L;
+  CoopBuild C(p);
+  for (uint32_t k = 0; k < p.R; ++k) if (p.root_slot[k] != FDG_NO_ROOT) C.rootlist.push_back({p.root_slot[k], k});
+  std::sort(C.rootlist.begin(), C.rootlist.end());
+  for (uint32_t w = 0; w < NW; ++w) {
+    C.B.emplace_back(new Builder(p));
+    C.B[w]->value_numbering = prm.vn_window != 1;
+    C.B[w]->vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
+  }
+  C.owner.assign(p.N, -1); C.prod_epoch.assign(p.N, 0); C.pub_ref.assign(p.N, NONE); C.in_progress.assign(p.N, -1);
+  C.cheap.assign(p.N, 0); C.is_wide_root.assign(p.N, 0);
+  for (uint32_t n = 0; n < p.N; ++n) C.cheap[n] = C.fold_cost(n) <= 12;
+  C.copy_of.assign(NW, std::vector<uint32_t>(p.N, NONE));
+  C.st.assign(NW, {});
+  // roots: leaves are written by wave 0; a wide Sum / Prod root is folded by a home wave while every wave computes terms
+  std::vector<uint32_t> root_nodes;
+  for (auto &rk : C.rootlist) {
+    if (rk.first < L) { C.B[0]->u.push_back(UOp{M_ROOT, rk.second, C.B[0]->ref_of[rk.first], 0, 0.0}); continue; }
+    if (root_nodes.empty() || root_nodes.back() != rk.first - L) root_nodes.push_back(rk.first - L);
+  }
+  std::vector<std::vector<uint32_t>> term_lists;
+  for (uint32_t rn : root_nodes) {
+    const uint32_t k = p.off[rn + 1] - p.off[rn];
+    if (k >= 8 && p.op[rn] != FDG_OP_POWER) {
+      C.is_wide_root[rn] = 1;
+      C.wides.push_back(CoopBuild::Wide{rn, (uint32_t)(C.wides.size() % NW), 0, NONE, false});
+      std::vector<uint32_t> t;
+      for (uint32_t e = p.off[rn]; e < p.off[rn + 1]; ++e) if (p.idx[e] >= L) t.push_back(p.idx[e]);
+      term_lists.push_back(t);
+    } else {
+      C.tasks.push_back(L + rn);
+    }
+  }
+  if (C.wides.empty()) { out.why = "no wide root to distribute"; return; }
+  for (size_t i = 0;; ++i) {                           // the wide roots' terms, interleaved
+    bool any = false;
+    for (auto &t : term_lists) if (i < t.size()) { C.tasks.push_back(t[i]); any = true; }
+    if (!any) break;
+  }
+  // ---- epochs ---------------------------------------------------------------------------------------------------------
+  std::vector<std::vector<uint32_t>> bar_pos(NW);     // [wave][epoch] index of the barrier op ending that epoch
+  uint32_t stalled = 0;
+  for (;;) {
+    std::vector<size_t> used(NW, 0);
+    std::vector<uint8_t> stop(NW, 0);
+    size_t progress = 0;
+    for (;;) {
+      int w = -1;
+      for (uint32_t k = 0; k < NW; ++k) if (!stop[k] && used[k] < budget && (w < 0 || used[k] < used[(size_t)w])) w = (int)k;
+      if (w < 0) break;
+      bool blk;
+      const size_t did = C.advance((uint32_t)w, blk);
+      if (did == 0) stop[(size_t)w] = 1;
+      used[(size_t)w] += did;
+      progress += did;
+    }
+    for (uint32_t w = 0; w < NW; ++w) { bar_pos[w].push_back((uint32_t)C.B[w]->u.size()); C.B[w]->u.push_back(UOp{M_BARRIER, 0, 0, 0, 0.0}); }
+    C.cur_epoch++;
+    bool all_done = C.next_task >= C.tasks.size();
+    for (uint32_t w = 0; w < NW; ++w) all_done = all_done && C.st[w].empty();
+    for (auto &W : C.wides) all_done = all_done && W.done;
+    if (all_done) break;
+    stalled = progress ? 0 : stalled + 1;
+    if (stalled > 2 || C.cur_epoch > 200000) { out.why = "cooperative schedule does not make progress"; return; }
+    for (uint32_t w = 0; w < NW; ++w) if (!C.B[w]->ok) { out.why = C.B[w]->why; return; }
+  }
+  for (uint32_t w = 0; w < NW; ++w) if (!C.B[w]->ok) { out.why = C.B[w]->why; return; }
+  out.n_epoch = C.cur_epoch;
+  out.n_duplicate = C.n_dup;
+  // a copy is readable from its shared slot until the epoch of its LAST use in its wave's list (a product whose first
+  // operand is a received value keeps it as its accumulator across however many epochs its other operands take)
+  for (uint32_t w = 0; w < NW; ++w) {
+    std::unordered_map<uint32_t, uint32_t> copy_vid;
+    for (uint32_t i = 0; i < C.copies.size(); ++i) if (C.copies[i].wave == w) copy_vid[C.B[w]->u[C.copies[i].uop].d] = i;
+    uint32_t e = 0;
+    auto seen = [&](uint32_t ref) { auto it = copy_vid.find(ref >> 1); if (it != copy_vid.end()) C.copies[it->second].e_last = std::max(C.copies[it->second].e_last, e); };
+    for (const UOp &o : C.B[w]->u) {
+      if (o.kind == M_BARRIER) { e++; continue; }
+      if (!mop_has_a(o.kind)) continue;
+      seen(o.a);
+      if (mop_has_b(o.kind)) seen(o.b);
+      if (mop_has_c(o.kind)) seen(o.c);
+    }
+  }
+  // ---- publication intervals and shared slots ---------------------------------------------------------------------------
+  out.n_priv_lds = 16;
+  out.n_shared = 312 - NW * out.n_priv_lds;
+  struct Interval { uint32_t node, start, end, slot; };
+  std::vector<Interval> ivs;
+  {
+    std::vector<std::vector<uint32_t>> by_node(p.N);
+    for (uint32_t i = 0; i < C.copies.size(); ++i) by_node[C.copies[i].node].push_back(i);
+    for (uint32_t n = 0; n < p.N; ++n) {
+      auto &v = by_node[n];
+      if (v.empty()) continue;
+      std::sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return C.copies[a].e_first < C.copies[b].e_first; });
+      for (uint32_t ci : v) {
+        CoopBuild::Copy &c = C.copies[ci];
+        if (!ivs.empty() && ivs.back().node == n && c.e_first - 1 <= ivs.back().end + gap) ivs.back().end = std::max(ivs.back().end, c.e_last);
+        else ivs.push_back(Interval{n, c.e_first - 1, c.e_last, NONE});
+        c.interval = (uint32_t)ivs.size() - 1;
+      }
+    }
+    std::vector<uint32_t> order(ivs.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ivs[a].start < ivs[b].start || (ivs[a].start == ivs[b].start && a < b); });
+    std::vector<uint32_t> free_at(out.n_shared, 0);   // first epoch in which the slot may be written again
+    for (uint32_t i : order) {
+      uint32_t best = NONE;
+      for (uint32_t s = 0; s < out.n_shared; ++s) if (free_at[s] <= ivs[i].start && (best == NONE || free_at[s] > free_at[best])) best = s;
+      if (best == NONE) { out.why = "shared LDS slots exhausted"; return; }
+      ivs[i].slot = best;
+      free_at[best] = ivs[i].end + 1;
+    }
+  }
+  out.n_transfer = C.copies.size();
+  // ---- the waves' lists with their M_SEND ops, then the ordinary allocator ----------------------------------------------
+  std::vector<std::vector<std::vector<UOp>>> sends(NW, std::vector<std::vector<UOp>>(C.cur_epoch));
+  for (const Interval &iv : ivs) {
+    const uint32_t w = (uint32_t)C.owner[iv.node];
+    sends[w][iv.start].push_back(UOp{M_SEND, iv.slot, C.pub_ref[iv.node] & ~1u, 0, 0.0});
+  }
+  for (const CoopBuild::Copy &c : C.copies) C.B[c.wave]->u[c.uop].a = ivs[c.interval].slot;
+  for (uint32_t w = 0; w < NW; ++w) {
+    std::vector<UOp> u;
+    u.reserve(C.B[w]->u.size() + 64);
+    uint32_t e = 0;
+    for (uint32_t j = 0; j < C.B[w]->u.size(); ++j) {
+      if (e < C.cur_epoch && j == bar_pos[w][e]) { for (const UOp &s : sends[w][e]) u.push_back(s); e++; }
+      u.push_back(C.B[w]->u[j]);
+    }
+    OptParams q = prm;
+    q.n_lds = out.n_priv_lds;
+    if (!fit_registers(u, q, out.wave[w])) { out.why = out.wave[w].why; return; }
+    Alloc A(p, out.wave[w].params, u, C.B[w]->next_vid, out.wave[w]);
+    A.run();
+    out.wave[w].ops.swap(A.out);
+    hoist_loads(out.wave[w].ops, out.wave[w].params);
+    sort_load_runs(out.wave[w].ops);
+  }
+  out.supported = true;
 }
 
 }  // namespace fdg

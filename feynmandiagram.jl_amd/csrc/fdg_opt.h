@@ -45,7 +45,12 @@ enum MKind : uint8_t {
   M_DIV1 = 23,    // r[d] = 1.0 / (+-r[a])                    correctly rounded (v_div_scale / v_div_fmas / v_div_fixup)
   M_CONST = 24,   // r[d] = imm                               (operand a is only a scheduling anchor)
   // M_SEL with imm == 2: cond(x) = isfinite(x)
+  // ---- cooperative variant: the four waves of a CU work on one tile and hand values over through shared LDS slots ----
+  M_SEND = 25,    // shared[d] = r[a]                          visible to the other waves after the next M_BARRIER
+  M_RECV = 26,    // r[d] = shared[a]
+  M_BARRIER = 27, // s_barrier (every wave's program has the same number of them per tile)
 };
+inline bool mop_has_a(uint8_t k) { return k != M_RECV && k != M_BARRIER; }
 inline bool mop_has_b(uint8_t k) { return k == M_MUL || k == M_ADD || k == M_FMA || k == M_SEL || k == M_FMAK; }
 inline bool mop_has_c(uint8_t k) { return k == M_FMA || k == M_FMAC || k == M_SEL; }
 inline bool mop_is_macro(uint8_t k) { return (k >= M_EXP && k <= M_SELC) || k == M_DIV1; }   // needs the emitter's temporaries
@@ -85,6 +90,7 @@ struct OptProgram {
   uint32_t n_reg_used = 0, n_lds_used = 0, n_mem_used = 0, n_acc_used = 0;
   // statistics
   uint64_t n_valu = 0, n_ld_leaf = 0, n_ld_lds = 0, n_ld_mem = 0, n_st_lds = 0, n_st_mem = 0, n_ld_acc = 0, n_st_acc = 0;
+  uint64_t n_send = 0, n_recv = 0, n_barrier = 0;   // cooperative programs
   uint32_t max_live = 0;
   uint32_t mc_n_k = 0, mc_n_t = 0;   // build_mc_program: input columns 0..mc_n_k-1 are momentum components, the next mc_n_t are times
   bool supported = true;    // false: graph uses something the ISA path does not cover
@@ -111,6 +117,24 @@ struct SchedOp { uint8_t kind; uint32_t d, a, b; double imm; };
 bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp> &ops, uint32_t &n_value, std::string &why);
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2 = nullptr,
                      const OptProgram *prog_acc = nullptr, const OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0);
+
+// Cooperative variant: the four waves of a CU (one per SIMD) evaluate ONE 64-sample tile together.  Each wave runs its own
+// straight-line program on its share of the graph with its own registers, AGPRs, private LDS slots and panel; a value
+// another wave needs is published into a shared LDS slot (M_SEND) and becomes readable after the next M_BARRIER (M_RECV).
+// Per-sample on-chip state is four times that of the one-wave kernels -- the design point for graphs whose live set
+// overflows one lane.  Every wave's program contains the same number of barriers.
+struct CoopProgram {
+  static constexpr uint32_t NW = 4;
+  OptProgram wave[NW];
+  uint32_t n_shared = 0;       // shared LDS slots (of 512 bytes) in front of the waves' private ones
+  uint32_t n_priv_lds = 0;     // private LDS slots of each wave
+  uint32_t n_epoch = 0;        // barriers per tile
+  uint64_t n_transfer = 0;     // values handed over per tile
+  uint64_t n_duplicate = 0;    // fold steps computed by more than one wave
+  bool supported = false;
+  std::string why;
+};
+void build_coop_program(const Lowered &p, const OptParams &prm, CoopProgram &out);
 
 void rm_plan_stats(const Lowered &p, const OptProgram &prog, uint32_t bufs, uint64_t &fetches, uint64_t &gathers);
 // gfx950 wait-state table of the emitter (fdg_isa.cpp): check of a finished listing, and the table as text

@@ -923,6 +923,28 @@ int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop *
   return FDG_OK;
 }
 
+int fdg_graph_coop_program(const fdg_graph *g, const fdg_opt_params *q, uint32_t wave, fdg_mop **ops, uint64_t *n_ops, uint32_t *info) {
+  if (!g || !ops || !n_ops || wave >= fdg::CoopProgram::NW) { set_error("null argument or wave out of range"); return FDG_E_INVALID; }
+  fdg::OptParams prm = to_params(q);
+  if (!q || !q->n_acc) prm.n_acc = 124;
+  fdg::CoopProgram cp;
+  fdg::build_coop_program(g->prog, prm, cp);
+  if (!cp.supported) { set_error("the cooperative variant does not cover this graph: " + cp.why); return FDG_E_UNSUPPORTED; }
+  const fdg::OptProgram &prog = cp.wave[wave];
+  fdg_mop *m = (fdg_mop *)std::malloc(std::max<size_t>(1, prog.ops.size()) * sizeof(fdg_mop));
+  if (!m) { set_error("out of memory"); return FDG_E_NOMEM; }
+  for (size_t i = 0; i < prog.ops.size(); ++i) {
+    const fdg::MOp &o = prog.ops[i];
+    m[i] = fdg_mop{o.kind, o.nega, o.negb, o.negc, o.d, o.a, o.b, o.imm, o.c, o.param};
+  }
+  *ops = m; *n_ops = prog.ops.size();
+  if (info) {
+    info[0] = prog.n_reg_used; info[1] = prog.n_lds_used; info[2] = prog.n_mem_used; info[3] = prog.n_acc_used;
+    info[4] = cp.n_shared; info[5] = cp.n_epoch; info[6] = (uint32_t)cp.n_transfer; info[7] = (uint32_t)cp.n_duplicate;
+  }
+  return FDG_OK;
+}
+
 int fdg_graph_mc_program(const fdg_graph *g, const fdg_leaf_tables *tab, const fdg_opt_params *q, fdg_mop **ops, uint64_t *n_ops,
                          uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used) {
   if (!g || !tab || !ops || !n_ops) { set_error("null argument"); return FDG_E_INVALID; }

@@ -193,6 +193,14 @@ int fdg_graph_set_opt_params(fdg_graph *g, const fdg_opt_params *prm);
 int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *prm, fdg_mop **ops, uint64_t *n_ops,
                           uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used);
 
+/* The program of wave `wave` (0..3) of the cooperative variant -- the four waves of a CU evaluate one 64-sample tile
+ * together, each on its share of the graph, values crossing between waves through shared LDS slots (kinds 25 SEND
+ * shared[d]=r[a], 26 RECV r[d]=shared[a], 27 BARRIER) -- for inspection and host-side replay.  info[8] (optional):
+ * registers, private LDS slots, panel slots, AGPR pairs of this wave; shared slots, barriers per tile, hand-overs per
+ * tile, fold steps computed by more than one wave.  Host-only.  FDG_E_UNSUPPORTED when the graph has no wide root sum. */
+int fdg_graph_coop_program(const fdg_graph *g, const fdg_opt_params *prm, uint32_t wave, fdg_mop **ops, uint64_t *n_ops,
+                           uint32_t *info);
+
 /* Evaluate B samples, buffers in device memory.
  *   leaf value i of sample b : d_leaf[b*leaf_sample_stride + i*leaf_leaf_stride]
  *   root value k of sample b : d_root[b*root_sample_stride + k*root_root_stride]

@@ -294,6 +294,65 @@ def test_integer_powers_in_the_optimizing_back_end(libfdg, budget, tmp_path):
         assert capi.isa_check_hazards(text)[0] == 0
 
 
+def replay_coop(progs, info, leaf, R):
+    """Four wave programs of the cooperative variant, epoch by epoch: a value sent in one epoch is readable from the next
+    (writes are committed at the barrier); reading a slot that another wave is overwriting in the same epoch is an error."""
+    B = leaf.shape[0]
+    shared = np.full((max(info["n_shared"], 1), B), np.nan)
+    root = np.zeros((B, R))
+    st = []
+    for w, ops in enumerate(progs):
+        iw = info["waves"][w]
+        st.append(dict(reg=np.full((max(iw["n_reg"], 1), B), np.nan), lds=np.full((max(iw["n_lds"], 1), B), np.nan),
+                       mem=np.full((max(iw["n_mem"], 1), B), np.nan), acc=np.full((max(iw["n_acc"], 1), B), np.nan), pc=0))
+    n_bar = [int((ops["kind"] == 27).sum()) for ops in progs]
+    assert len(set(n_bar)) == 1 and n_bar[0] == info["n_epoch"]
+    for _epoch in range(info["n_epoch"]):
+        pending, read_slots = {}, set()
+        for w, ops in enumerate(progs):
+            s = st[w]
+            reg, lds, mem, acc = s["reg"], s["lds"], s["mem"], s["acc"]
+            while True:
+                o = ops[s["pc"]]; s["pc"] += 1
+                k, d, a, b = int(o["kind"]), int(o["d"]), int(o["a"]), int(o["b"])
+                sa = -1.0 if o["nega"] else 1.0
+                sb = -1.0 if o["negb"] else 1.0
+                if k == 27: break
+                elif k == 25: assert d not in pending; pending[d] = (w, reg[a].copy())
+                elif k == 26: read_slots.add((a, w)); reg[d] = shared[a]
+                elif k == 0: reg[d] = leaf[:, a]
+                elif k == 1: reg[d] = lds[a]
+                elif k == 2: reg[d] = mem[a]
+                elif k == 3: lds[d] = reg[a]
+                elif k == 4: mem[d] = reg[a]
+                elif k == 5: reg[d] = (sa * reg[a]) * (sb * reg[b])
+                elif k == 6: reg[d] = (sa * reg[a]) + (sb * reg[b])
+                elif k == 7: reg[d] = (sa * reg[a]) * o["imm"]
+                elif k == 8: root[:, d] = sa * reg[a]
+                elif k == 10: reg[d] = acc[a]
+                elif k == 11: acc[d] = reg[a]
+                else: raise AssertionError(k)
+        for slot, (w, val) in pending.items():
+            assert not [1 for (sl, rw) in read_slots if sl == slot and rw != w], ("slot overwritten while still read", slot)
+            shared[slot] = val
+    assert all(st[w]["pc"] == len(progs[w]) for w in range(4))
+    return root
+
+
+@pytest.mark.parametrize("name", ["sigma4_standin", "gv_sigma5", "sigma4_worstcase", "synthetic_small"])
+def test_cooperative_programs_replay_exactly(libfdg, name):
+    """The cooperative variant (four waves of a CU on one tile): who computes a term changes, the folds do not.
+    The four programs replayed with their barriers give the oracle's bits; every wave's program has the same number of
+    barriers; nothing is read from a shared slot in the epoch in which it is rewritten."""
+    t = workloads.get(name)
+    h = capi.GraphHandle(t)
+    progs, info = h.coop_program()
+    leaf = oracle.philox_uniform(5, t.n_leaf, 79)
+    got = replay_coop(progs, info, leaf, t.n_root)
+    assert np.array_equal(got, oracle.eval_static(t, leaf))
+    assert info["n_transfer"] > 0
+
+
 def test_isa_jit_assembles_without_device(libfdg, tmp_path):
     t = workloads.get("gv_sigma4")
     h = capi.GraphHandle(t)
