@@ -356,7 +356,7 @@ void emit_scaled_addr(Emit &E, int dst, int base, int mul8, uint32_t k) {
   E.ins("s_addc_u32 s" + std::to_string(dst + 1) + ", s" + std::to_string(base + 1) + ", s" + std::to_string(S_X + 1));
 }
 
-struct KernelMeta { std::string name; uint32_t lds_bytes, accum, n_agpr; int n_args, n_sgpr; };
+struct KernelMeta { std::string name; uint32_t lds_bytes, accum, n_agpr; int n_args, n_sgpr; uint32_t wg = 64; };
 
 // Prints one kernel.  W = samples per lane: 1 (64-sample tiles, 8-byte accesses) or 2 (128-sample
 // tiles: a value is two doubles in four VGPRs, every memory access is 16 bytes per lane -- the
@@ -415,8 +415,12 @@ static void rm_plan(const Lowered &p, const OptProgram &prog, uint32_t rm_bufs, 
   }
 }
 
+// One wave's section of the cooperative kernel (emit_coop below): no kernel header or descriptor of its own; lane = thread id
+// & 63; private LDS slots behind the shared ones (addressed through their own base register); the wave's panel inside the
+// workgroup's; M_SEND / M_RECV / M_BARRIER.
+struct CoopSec { uint32_t wave, n_shared, priv_base_bytes, panel_wg_bytes, panel_prefix_bytes; };
 static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog, const std::string &kname, int W, bool accumulate = false,
-                              uint32_t rm_bufs = 0) {
+                              uint32_t rm_bufs = 0, const CoopSec *cs = nullptr) {
   E.vm_issued = E.lg_issued = E.vm_done = E.lg_done = 0;
   E.pend.assign(std::max<uint32_t>(prog.n_reg_used, 1), {0, 0});
   const uint32_t SLOT = 512u * W;                 // bytes of one LDS / panel slot of a wave
@@ -427,8 +431,12 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const int TSH = W == 2 ? 7 : 6;                 // log2(samples per tile)
   const std::string sfx = "_" + kname;
   std::ostringstream &os = E.os;
-  os << "\t.text\n\t.protected\t" << kname << "\n\t.globl\t" << kname << "\n\t.p2align\t8\n\t.type\t" << kname << ",@function\n";
-  os << kname << ":\n";
+  if (!cs) {
+    os << "\t.text\n\t.protected\t" << kname << "\n\t.globl\t" << kname << "\n\t.p2align\t8\n\t.type\t" << kname << ",@function\n";
+    os << kname << ":\n";
+  } else {
+    os << ".Lsec" << sfx << ":\n";
+  }
   auto S = [](int r) { return "s" + std::to_string(r); };
   auto S2 = [](int r) { return "s[" + std::to_string(r) + ":" + std::to_string(r + 1) + "]"; };
   auto V = [](int r) { return "v" + std::to_string(r); };
@@ -444,6 +452,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const bool dbg_noleaf = dbg && std::strstr(dbg, "noleaf");
   const bool dbg_nolds = dbg && std::strstr(dbg, "nolds");
   // ---- prologue ------------------------------------------------------------
+  if (cs) E.ins("v_and_b32_e32 v0, 63, v0");          // lane within the wave (the workgroup has four waves)
   E.ins("s_load_dwordx8 s[4:11], s[0:1], 0x0");
   E.ins("s_load_dwordx8 s[12:19], s[0:1], 0x20");
   E.ins("s_load_dwordx2 s[20:21], s[0:1], 0x40");
@@ -484,6 +493,12 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   // row-major variant: per-lane source offset of the LDS-direct loads, and the eight swizzled read addresses
   const uint32_t rm0 = tmp0 + 2 * n_tmp_pairs;                   // v[rm0] = source offset, v[rm0 + 1 + j] = read address of piece j
   const int S_ROW8 = S_DELTA, S_FA = S_DELTA + 2;                // (the delta table is not used by this variant)
+  // cooperative section: v[rm0] = lane * 8 + base of this wave's private LDS slots, v[rm0 + 1] = lane * 8 + 64 KB (shared slots
+  // 128 and up; the first 128 are reached from V_LANE8 with the 16-bit offset field)
+  if (cs) {
+    E.ins("v_add_u32_e32 v" + std::to_string(rm0) + ", " + hex32(cs->priv_base_bytes) + ", " + V(V_LANE8));
+    E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 1) + ", 0x10000, " + V(V_LANE8));
+  }
   if (rm_bufs) {
     const std::string vg = "v" + std::to_string(rm0);
     auto vj = [&](int j) { return "v" + std::to_string(rm0 + 1 + j); };
@@ -554,10 +569,14 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_lshr_b64 " + S2(S_X) + ", " + S2(S_X) + ", " + std::to_string(TSH));
   E.ins("s_mov_b32 " + S(S_NTILES) + ", " + S(S_X));
   E.ins("s_mov_b32 " + S(S_TILE) + ", s2");
-  E.ins("s_mul_i32 " + S(S_X) + ", s2, " + hex32(panel_bytes_per_wave));
-  E.ins("s_mul_hi_u32 " + S(S_X + 1) + ", s2, " + hex32(panel_bytes_per_wave));
+  E.ins("s_mul_i32 " + S(S_X) + ", s2, " + hex32(cs ? cs->panel_wg_bytes : panel_bytes_per_wave));
+  E.ins("s_mul_hi_u32 " + S(S_X + 1) + ", s2, " + hex32(cs ? cs->panel_wg_bytes : panel_bytes_per_wave));
   E.ins("s_add_u32 " + S(S_PANEL) + ", " + S(S_WS) + ", " + S(S_X));
   E.ins("s_addc_u32 " + S(S_PANEL + 1) + ", " + S(S_WS + 1) + ", " + S(S_X + 1));
+  if (cs && cs->panel_prefix_bytes) {
+    E.ins("s_add_u32 " + S(S_PANEL) + ", " + S(S_PANEL) + ", " + hex32(cs->panel_prefix_bytes));
+    E.ins("s_addc_u32 " + S(S_PANEL + 1) + ", " + S(S_PANEL + 1) + ", 0");
+  }
   E.ins("s_cmp_ge_u32 " + S(S_TILE) + ", " + S(S_NTILES));
   E.ins("s_cbranch_scc0 .Ltile" + sfx);
   E.ins("s_endpgm");   // (the host never launches more waves than tiles)
@@ -679,8 +698,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     uint64_t sq = 0;
     auto use = [&](uint32_t r) { if (r < E.pend.size() && E.pend[r].first == 1) sq = std::max(sq, E.pend[r].second); };
     switch (q.kind) {
-      case M_LD_LEAF: case M_LD_LDS: case M_LD_MEM: case M_LD_ACC: use(q.d); break;
-      case M_ST_LDS: case M_ST_MEM: case M_ST_ACC: case M_ROOT: use(q.a); break;
+      case M_LD_LEAF: case M_LD_LDS: case M_LD_MEM: case M_LD_ACC: case M_RECV: use(q.d); break;
+      case M_ST_LDS: case M_ST_MEM: case M_ST_ACC: case M_ROOT: case M_SEND: use(q.a); break;
       case M_MUL: case M_ADD: use(q.a); use(q.b); use(q.d); break;
       case M_FMA: use(q.a); use(q.b); use(q.c); use(q.d); break;
       case M_FMAC: use(q.a); use(q.c); use(q.d); break;
@@ -763,13 +782,29 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       case M_LD_LDS:
         if (dbg_nolds) break;
         E.wait_reg(o.d);
-        E.ins(DSR + vall(o.d) + ", " + V(V_LANE8) + " offset:" + std::to_string(o.a * SLOT));
+        E.ins(DSR + vall(o.d) + ", " + (cs ? "v" + std::to_string(rm0) : V(V_LANE8)) + " offset:" + std::to_string(o.a * SLOT));
         E.pend[o.d] = {2, ++E.lg_issued};
+        break;
+      case M_RECV:           // a value another wave published before the last barrier
+        E.wait_reg(o.d);
+        E.ins(DSR + vall(o.d) + ", " + (o.a < 128 ? V(V_LANE8) : "v" + std::to_string(rm0 + 1)) + " offset:" + std::to_string((o.a % 128) * SLOT));
+        E.pend[o.d] = {2, ++E.lg_issued};
+        break;
+      case M_SEND:
+        E.wait_reg(o.a);
+        E.ins(DSW + (o.d < 128 ? V(V_LANE8) : "v" + std::to_string(rm0 + 1)) + ", " + vall(o.a) + " offset:" + std::to_string((o.d % 128) * SLOT));
+        ++E.lg_issued;
+        break;
+      case M_BARRIER:        // this wave's LDS traffic of the epoch has completed; then all four waves meet
+        E.ins("s_waitcnt lgkmcnt(0)");
+        E.lg_done = E.lg_issued;
+        for (auto &pp : E.pend) if (pp.first == 2) pp.first = 0;
+        E.ins("s_barrier");
         break;
       case M_ST_LDS:
         if (dbg_nolds) break;
         E.wait_reg(o.a);
-        E.ins(DSW + V(V_LANE8) + ", " + vall(o.a) + " offset:" + std::to_string(o.d * SLOT));
+        E.ins(DSW + (cs ? "v" + std::to_string(rm0) : V(V_LANE8)) + ", " + vall(o.a) + " offset:" + std::to_string(o.d * SLOT));
         ++E.lg_issued;
         break;
       case M_MUL:
@@ -997,9 +1032,10 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_endpgm");
 
   // ---- kernel descriptor -------------------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 9 : 0), 8);
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 9 : 0) + (cs ? 2 : 0), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
   const uint32_t n_agpr = RW * prog.n_acc_used;
+  if (cs) return KernelMeta{kname, lds_bytes, accum, n_agpr, 10, (mc || has_macro) ? S_END : S_POOL + 2 * 16};
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
   os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";
   os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size " << (mc ? 128 : 80) << "\n\t\t.amdhsa_user_sgpr_count 2\n";
@@ -1017,6 +1053,52 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
 }
 
 }  // namespace
+
+// The cooperative kernel: a workgroup of four waves (one per SIMD: the register and LDS requests leave room for nothing else
+// on the CU); the entry reads the wave's number and jumps to that wave's section.
+static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, const std::string &kname) {
+  std::ostringstream &os = E.os;
+  os << "\t.text\n\t.protected\t" << kname << "\n\t.globl\t" << kname << "\n\t.p2align\t8\n\t.type\t" << kname << ",@function\n";
+  os << kname << ":\n";
+  E.hz.reset();
+  E.ins("v_lshrrev_b32_e32 v1, 6, v0");
+  E.ins("v_readfirstlane_b32 s3, v1");
+  for (uint32_t w = 0; w < CoopProgram::NW; ++w) {
+    const std::string lab = ".Lsec_" + kname + "_w" + std::to_string(w), here = ".Lpc_" + kname + "_d" + std::to_string(w);
+    E.ins("s_cmp_lg_u32 s3, " + std::to_string(w));
+    E.ins("s_cbranch_scc1 .Lnot_" + kname + "_" + std::to_string(w));
+    E.ins("s_getpc_b64 s[4:5]");
+    os << here << ":\n";
+    E.ins("s_add_u32 s4, s4, (" + lab + "-" + here + ")&0xffffffff");
+    E.ins("s_addc_u32 s5, s5, (" + lab + "-" + here + ")>>32");
+    E.ins("s_setpc_b64 s[4:5]");
+    os << ".Lnot_" << kname << "_" << w << ":\n";
+  }
+  E.ins("s_endpgm");
+  uint32_t panel_wg = 0, prefix[CoopProgram::NW];
+  for (uint32_t w = 0; w < CoopProgram::NW; ++w) { prefix[w] = panel_wg; panel_wg += std::max<uint32_t>(cp.wave[w].n_mem_used, 1) * 512u; }
+  uint32_t accum = 0, n_agpr = 0;
+  int n_sgpr = 0;
+  for (uint32_t w = 0; w < CoopProgram::NW; ++w) {
+    const CoopSec cs{w, cp.n_shared, (cp.n_shared + w * cp.n_priv_lds) * 512u, panel_wg, prefix[w]};
+    E.hz.reset();
+    const KernelMeta m = emit_kernel(E, p, cp.wave[w], kname + "_w" + std::to_string(w), 1, false, 0, &cs);
+    accum = std::max(accum, m.accum); n_agpr = std::max(n_agpr, m.n_agpr); n_sgpr = std::max(n_sgpr, m.n_sgpr);
+  }
+  const uint32_t lds_bytes = (cp.n_shared + CoopProgram::NW * cp.n_priv_lds) * 512u;
+  os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
+  os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";
+  os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size 80\n\t\t.amdhsa_user_sgpr_count 2\n";
+  os << "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1\n\t\t.amdhsa_system_sgpr_workgroup_id_x 1\n";
+  os << "\t\t.amdhsa_system_vgpr_workitem_id 0\n";
+  os << "\t\t.amdhsa_next_free_vgpr " << (accum + n_agpr) << "\n\t\t.amdhsa_next_free_sgpr " << n_sgpr << "\n";
+  os << "\t\t.amdhsa_accum_offset " << accum << "\n\t\t.amdhsa_reserve_vcc 1\n";
+  os << "\t\t.amdhsa_float_round_mode_32 0\n\t\t.amdhsa_float_round_mode_16_64 0\n";
+  os << "\t\t.amdhsa_float_denorm_mode_32 3\n\t\t.amdhsa_float_denorm_mode_16_64 3\n";
+  os << "\t\t.amdhsa_dx10_clamp 1\n\t\t.amdhsa_ieee_mode 1\n";
+  os << "\t.end_amdhsa_kernel\n";
+  return KernelMeta{kname, lds_bytes, accum, n_agpr, 10, n_sgpr};
+}
 
 // What the row-major variant of `prog` would move with `bufs` staging buffers: chunk fetches (8 KB each) and gathered leaves.
 void rm_plan_stats(const Lowered &p, const OptProgram &prog, uint32_t bufs, uint64_t &fetches, uint64_t &gathers) {
@@ -1067,7 +1149,7 @@ std::string isa_hazard_table() {
 // One code object: the W = 1 kernel `kname`, and, when prog2 is given, the two-samples-per-lane kernel
 // `kname`_w2 next to it.
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2,
-                     const OptProgram *prog_acc, const OptProgram *prog_rm, uint32_t rm_bufs) {
+                     const OptProgram *prog_acc, const OptProgram *prog_rm, uint32_t rm_bufs, const CoopProgram *coop) {
   Emit E;
   E.os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n";
   std::vector<KernelMeta> ks;
@@ -1075,6 +1157,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   if (prog2) ks.push_back(emit_kernel(E, p, *prog2, kname + "_w2", 2));
   if (prog_acc) ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc", 1, true));
   if (prog_rm && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm, kname + "_rm", 1, false, rm_bufs));
+  if (coop && coop->supported) { ks.push_back(emit_coop(E, p, *coop, kname + "_coop")); ks.back().wg = 256; }
   std::ostringstream &os = E.os;
   os << "\t.text\n\t.amdgpu_metadata\n---\namdhsa.kernels:\n";
   const char *kinds[16] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",
@@ -1087,7 +1170,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
       if (std::strcmp(kinds[i], "global_buffer") == 0) os << "        .address_space: global\n";
     }
     os << "    .group_segment_fixed_size: " << k.lds_bytes << "\n    .kernarg_segment_align: 8\n    .kernarg_segment_size: " << 8 * k.n_args << "\n";
-    os << "    .max_flat_workgroup_size: 64\n    .name: " << k.name << "\n    .private_segment_fixed_size: 0\n";
+    os << "    .max_flat_workgroup_size: " << k.wg << "\n    .name: " << k.name << "\n    .private_segment_fixed_size: 0\n";
     os << "    .sgpr_count: " << (k.n_sgpr + 6) << "\n    .sgpr_spill_count: 0\n    .symbol: " << k.name << ".kd\n";
     os << "    .uniform_work_group_size: 1\n    .uses_dynamic_stack: false\n    .vgpr_count: " << (k.accum + k.n_agpr)
        << "\n    .vgpr_spill_count: 0\n    .wavefront_size: 64\n";

@@ -610,6 +610,10 @@ struct Alloc {
   OptProgram &prog;
 
   uint32_t leaf_lo = 0, leaf_n = 0;          // values leaf_lo .. leaf_lo+leaf_n-1 are input columns (re-loadable)
+  // cooperative programs: while a value sits in a shared slot (from its M_SEND to the end of the publication interval)
+  // that slot is its home for the owner too -- no private register, AGPR or LDS slot is tied up by it
+  std::vector<std::vector<uint32_t>> expire;  // [barrier number] values whose shared slot is released after that barrier
+  uint32_t n_barrier_seen = 0;
 
   Alloc(const Lowered &p_, const OptParams &prm_, const std::vector<UOp> &u_, uint32_t nv_, OptProgram &pr)
       : p(p_), prm(prm_), u(u_), nv(nv_), prog(pr) { leaf_n = p.L; }
@@ -749,7 +753,21 @@ struct Alloc {
       if (prm.lookahead_leaf) prefetch_window(pf_leaf, j, prm.lookahead_leaf, 3);
       if (prm.lookahead_mem) prefetch_window(pf_mem, j, prm.lookahead_mem, 2);
       if (prm.lookahead_lds) prefetch_window(pf_lds, j, prm.lookahead_lds, 1);
-      if (o.kind == M_BARRIER) { out.push_back(MOp{M_BARRIER, 0, 0, 0, 0, 0, 0.0}); prog.n_barrier++; continue; }
+      if (o.kind == M_BARRIER) {
+        if (n_barrier_seen < expire.size())
+          for (uint32_t v : expire[n_barrier_seen]) {
+            if (home_kind[v] != 5) continue;
+            if (next_use(v) != std::numeric_limits<uint32_t>::max() && reg_of[v] == NONE) {      // still needed: back into a register
+              const uint32_t r = take_reg(j, true);
+              out.push_back(MOp{M_RECV, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_recv++;
+              reg_of[v] = r; owner[r] = v; lock[r] = j;
+            }
+            home_kind[v] = (v >= leaf_lo && v < leaf_lo + leaf_n) ? 3 : 0;
+          }
+        n_barrier_seen++;
+        out.push_back(MOp{M_BARRIER, 0, 0, 0, 0, 0, 0.0}); prog.n_barrier++;
+        continue;
+      }
       if (o.kind == M_RECV) {             // a value another wave published: it stays re-loadable from its shared slot for its whole life
         const uint32_t rd = take_reg(j, true);
         reg_of[o.d] = rd; owner[rd] = o.d; lock[rd] = j;
@@ -779,6 +797,15 @@ struct Alloc {
       if (o.kind == M_SEND) {
         out.push_back(MOp{M_SEND, 0, 0, o.d, ra, 0, 0.0});
         prog.n_send++;
+        if (reg_of[va] != NONE || next_use(va) != std::numeric_limits<uint32_t>::max()) {
+          if (home_kind[va] != 3) release_home(va);
+          if (next_use(va) != std::numeric_limits<uint32_t>::max()) {
+            home_kind[va] = 5; home_slot[va] = o.d;
+            const uint32_t e_end = (uint32_t)o.imm;
+            if (expire.size() <= e_end) expire.resize(e_end + 1);
+            expire[e_end].push_back(va);
+          }
+        }
         continue;
       }
       const uint32_t rd = take_reg(j);
@@ -1137,7 +1164,7 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
 // Shorter epochs keep fewer hand-overs in flight: when the shared slots run out the schedule is rebuilt with a smaller budget.
 void build_coop_program(const Lowered &p, const OptParams &prm, CoopProgram &out) {
   const char *te = std::getenv("FDG_COOP_EPOCH_OPS");
-  if (te) { build_coop_once(p, prm, (size_t)std::max(8, std::atoi(te)), 2, out); return; }
+  if (te) { const char *ge = std::getenv("FDG_COOP_GAP"); build_coop_once(p, prm, (size_t)std::max(8, std::atoi(te)), ge ? (uint32_t)std::atoi(ge) : 2u, out); return; }
   for (size_t budget : {192, 128, 96, 64, 48}) {
     build_coop_once(p, prm, budget, budget > 64 ? 2u : 1u, out);
     if (out.supported || out.why != "shared LDS slots exhausted") return;
@@ -1149,6 +1176,7 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
   constexpr uint32_t NW = CoopProgram::NW;
   const uint32_t L = p.L;
   CoopBuild C(p);
+  if (const char *e = std::getenv("FDG_COOP_COPY_WINDOW")) C.copy_window = (uint32_t)std::max(1, std::atoi(e));
   for (uint32_t k = 0; k < p.R; ++k) if (p.root_slot[k] != FDG_NO_ROOT) C.rootlist.push_back({p.root_slot[k], k});
   std::sort(C.rootlist.begin(), C.rootlist.end());
   for (uint32_t w = 0; w < NW; ++w) {
@@ -1233,6 +1261,7 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
   }
   // ---- publication intervals and shared slots ---------------------------------------------------------------------------
   out.n_priv_lds = 16;
+  if (const char *e = std::getenv("FDG_COOP_PRIV_LDS")) out.n_priv_lds = (uint32_t)std::max(1, std::min(70, std::atoi(e)));
   out.n_shared = 312 - NW * out.n_priv_lds;
   struct Interval { uint32_t node, start, end, slot; };
   std::vector<Interval> ivs;
@@ -1267,7 +1296,7 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
   std::vector<std::vector<std::vector<UOp>>> sends(NW, std::vector<std::vector<UOp>>(C.cur_epoch));
   for (const Interval &iv : ivs) {
     const uint32_t w = (uint32_t)C.owner[iv.node];
-    sends[w][iv.start].push_back(UOp{M_SEND, iv.slot, C.pub_ref[iv.node] & ~1u, 0, 0.0});
+    sends[w][iv.start].push_back(UOp{M_SEND, iv.slot, C.pub_ref[iv.node] & ~1u, 0, (double)iv.end});   // imm: last epoch the slot holds it
   }
   for (const CoopBuild::Copy &c : C.copies) C.B[c.wave]->u[c.uop].a = ivs[c.interval].slot;
   for (uint32_t w = 0; w < NW; ++w) {

@@ -115,8 +115,10 @@ void build_mc_program(const Lowered &p, const LeafSpec &ls, const OptParams &prm
 // (value << 1) | negate.  kind: M_MUL d = a*b, M_ADD d = a+b, M_MULC d = a*imm, M_ROOT root[d] = a.
 struct SchedOp { uint8_t kind; uint32_t d, a, b; double imm; };
 bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp> &ops, uint32_t &n_value, std::string &why);
+struct CoopProgram;
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2 = nullptr,
-                     const OptProgram *prog_acc = nullptr, const OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0);
+                     const OptProgram *prog_acc = nullptr, const OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0,
+                     const CoopProgram *coop = nullptr);
 
 // Cooperative variant: the four waves of a CU (one per SIMD) evaluate ONE 64-sample tile together.  Each wave runs its own
 // straight-line program on its share of the graph with its own registers, AGPRs, private LDS slots and panel; a value

@@ -384,6 +384,7 @@ static int ensure_module(fdg_graph *g) {
     if (g->has_w2) { hipFunction_t f2; HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_isa_eval_w2")); g->fn_isa_w2 = f2; }
     if (g->has_acc) { hipFunction_t f3; HIP_TRY(hipModuleGetFunction(&f3, m, "fdg_isa_eval_acc")); g->fn_isa_acc = f3; }
     if (g->has_rm) { hipFunction_t f4; HIP_TRY(hipModuleGetFunction(&f4, m, "fdg_isa_eval_rm")); g->fn_isa_rm = f4; }
+    if (g->has_coop) { hipFunction_t f5; HIP_TRY(hipModuleGetFunction(&f5, m, "fdg_isa_eval_coop")); g->fn_isa_coop = f5; }
     return FDG_OK;
   }
   hipFunction_t f1, f2;
@@ -535,6 +536,18 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // the kernel forms a lane's offset (lane * stride * 8) in 32 bits: strides that large are brought into the
     // leaf-major workspace first (leaves) or refused (roots); neither occurs with the layouts of DESIGN.md 2
     const bool wide_ss = ss < 0 || ss >= (1ll << 23);           // (the offset is unsigned: negative strides too)
+    // Cooperative variant: one workgroup of four waves per CU, every workgroup walks tiles of 64 samples; leaf-major input.
+    if (mode == 0 && g->has_coop && g->fn_isa_coop && !(ls == 1 && ss != 1 && p.L > 1) && !wide_ss && !(rs < 0 || rs >= (1ll << 23)) &&
+        !std::getenv("FDG_ISA_NO_COOP")) {
+      long nwg = std::min<long>((long)((B + 63) / 64), (long)g->n_cu), lss = ss, lls = ls, rrs = rs, rrk = rk, n = (long)B;
+      rc = ensure_ws(g, std::max(panel_all + (size_t)grid3 * R * 512u + 4096, (size_t)g->coop_panel_wg * (size_t)nwg + 4096));
+      if (rc) return rc;
+      void *a_wsp = g->d_ws;
+      const double *nowt = nullptr;
+      void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &n, &nwg, (void *)&nowt};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_coop, (unsigned)nwg, 1, 1, 256, 1, 1, 0, st, args, nullptr));
+      return FDG_OK;
+    }
     // Row-major leaves ([B, L], leaf stride 1) and evaluation: full 64-row tiles go through the variant that stages chunks
     // of rows in LDS itself -- the matrix is read once, in place; the last B % 64 rows take the general path below.
     if (mode == 0 && g->has_rm && g->fn_isa_rm && ls == 1 && ss >= (int64_t)p.L && !wide_ss && p.L >= 16 && B >= 64 &&
@@ -972,8 +985,8 @@ static bool has_opt_params(const fdg_graph *g) { return g->has_opt; }
 static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags,
                         std::vector<char> &co, std::string &hash, const fdg::OptProgram *prog2 = nullptr,
                         const fdg::OptProgram *prog_acc = nullptr, const char *kname = "fdg_isa_eval",
-                        const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0) {
-  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc, prog_rm, rm_bufs);
+                        const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr) {
+  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc, prog_rm, rm_bufs, coop);
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
   hash = hbuf;
@@ -1004,8 +1017,15 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
 
 static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<char> &co, const std::string &hash, unsigned flags,
                         const fdg::OptProgram *prog2 = nullptr, const fdg::OptProgram *prog_acc = nullptr,
-                        const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0) {
+                        const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr) {
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
+  g->has_coop = coop && coop->supported;
+  g->fn_isa_coop = nullptr;
+  if (g->has_coop) {
+    g->coop_panel_wg = 0;
+    for (uint32_t w = 0; w < fdg::CoopProgram::NW; ++w) g->coop_panel_wg += std::max<uint32_t>(coop->wave[w].n_mem_used, 1) * 512u;
+    g->coop_lds_bytes = (coop->n_shared + fdg::CoopProgram::NW * coop->n_priv_lds) * 512u;
+  }
   g->code_object.swap(co);
   g->isa = true;
   g->fn_isa = nullptr;
@@ -1161,9 +1181,25 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
 
 struct IsaVariants {
   fdg::OptProgram p2, pa, pr;
+  fdg::CoopProgram coop;
   bool w2 = false, acc = false;
   uint32_t rm_bufs = 0;
 };
+// The cooperative variant (four waves of a CU on one tile) is assembled for programs whose one-wave form
+// spills to the HBM panel in earnest (more than one panel access per 20 fold steps); FDG_ISA_COOP=1 / 0 forces / forbids.
+static void build_coop(const fdg_graph *g, const fdg::OptProgram &prog, IsaVariants &V) {
+  const char *e = std::getenv("FDG_ISA_COOP");
+  if (e && e[0] == '0') return;
+  (void)prog;
+  fdg::OptParams q = cfg_B();
+  q.vn_window = 200;
+  if (!(e && e[0] == '1')) {
+    fdg::OptProgram ref;                      // the one-wave program without recomputation decides
+    build_prog(g, q, ref);
+    if (!ref.supported || (ref.n_ld_mem + ref.n_st_mem) * 20 <= ref.n_valu) return;
+  }
+  fdg::build_coop_program(g->prog, q, V.coop);
+}
 static void build_variants(const fdg_graph *g, const fdg::OptParams &chosen, bool allow_w2, IsaVariants &V) {
   V.w2 = allow_w2 && !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, V.p2);
   V.acc = build_acc_program(g, chosen, V.pa);
@@ -1171,10 +1207,12 @@ static void build_variants(const fdg_graph *g, const fdg::OptParams &chosen, boo
 }
 static int assemble_and_install(fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags, IsaVariants &V) {
   std::vector<char> co; std::string hash;
+  build_coop(g, prog, V);
+  const fdg::CoopProgram *coop = V.coop.supported ? &V.coop : nullptr;
   const int rc = assemble_isa(g, prog, dir, flags, co, hash, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, "fdg_isa_eval",
-                              V.rm_bufs ? &V.pr : nullptr, V.rm_bufs);
+                              V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop);
   if (rc) return rc;
-  install_isa(g, prog, co, hash, flags, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, V.rm_bufs ? &V.pr : nullptr, V.rm_bufs);
+  install_isa(g, prog, co, hash, flags, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop);
   return FDG_OK;
 }
 

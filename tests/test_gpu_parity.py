@@ -652,6 +652,33 @@ def test_entry_points_are_graph_capturable(libfdg, cuda):
     assert np.array_equal(root.cpu().numpy(), oracle.eval_static(t, leaf.cpu().numpy()))
 
 
+@pytest.mark.parametrize("name", ["sigma4_standin", "sigma4_worstcase", "gv_sigma5", "synthetic_small"])
+def test_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_path, name):
+    """fdg_isa_eval_coop: the four waves of a CU evaluate one 64-sample tile together, each on its share of the graph,
+    values crossing through shared LDS slots between s_barrier epochs.  Forced here on graphs that would not
+    ask for it; ragged and single-tile batches, more tiles than workgroups; bit for bit against the oracle."""
+    import torch
+    monkeypatch.setenv("FDG_ISA_COOP", "1")
+    t = workloads.get(name)
+    cache = tmp_path / "c"
+    cache.mkdir(mode=0o700)
+    f = fd.compile_table(t, specialize="isa", cache_dir=str(cache), flags=capi.FDG_SPEC_KEEP_SOURCE)
+    listing = "".join(open(os.path.join(cache, x)).read() for x in os.listdir(cache) if x.endswith(".s"))
+    assert "fdg_isa_eval_coop:" in listing and "s_barrier" in listing
+    for B in (1, 63, 64, 65, 1000, 40_001):
+        leaf = dev_leaves(cuda, B, t.n_leaf, 33, 0, "leaf_major")
+        root = torch.full((t.n_root, B), -3.0, dtype=torch.float64, device=cuda).t()
+        f(root, leaf)
+        torch.cuda.synchronize()
+        want = oracle.eval_static(t, leaf.cpu().numpy(), np.full((B, t.n_root), -3.0))
+        assert np.array_equal(root.cpu().numpy(), want), (name, B)
+    monkeypatch.setenv("FDG_ISA_NO_COOP", "1")          # the same handle through its one-wave kernel: the same bits
+    root2 = torch.zeros_like(root)
+    f(root2, leaf)
+    torch.cuda.synchronize()
+    assert torch.equal(root, root2)
+
+
 def test_host_matrices_in_either_order(libfdg, cuda):
     """fdg_eval_strided: host matrices row-major (compile_Python's layout) or column-major (a Julia Matrix), leaves and
     roots independently, padded leaf rows, chunked through the device -- the same bits, no transposition copy."""

@@ -139,6 +139,8 @@ def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch
             opts.append(None)
         if seed % 3 == 0:
             monkeypatch.setenv("FDG_REMAT_WINDOW", str(int(rng.choice([8, 60, 400]))))
+        if seed % 2 == 1:                  # the cooperative variant wherever the graph has a wide root sum (it then takes the leaf-major calls)
+            monkeypatch.setenv("FDG_ISA_COOP", "1")
         for opt in opts:
             f = fd.compile_table(t, specialize="isa", opt=opt, cache_dir=str(cache), flags=capi.FDG_SPEC_KEEP_SOURCE)
             for layout in ("leaf_major", "sample_major"):
@@ -156,6 +158,7 @@ def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch
                 assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0))[live] <= 1e-12 * np.maximum(1.0, np.abs(wr).sum(0))[live]), (seed, opt)
         monkeypatch.delenv("FDG_ISA_W2", raising=False)
         monkeypatch.delenv("FDG_REMAT_WINDOW", raising=False)
+        monkeypatch.delenv("FDG_ISA_COOP", raising=False)
         for lst in glob.glob(str(cache / "*.s")):
             n, rep = capi.isa_check_hazards(open(lst).read())
             assert n == 0, (seed, rep)
