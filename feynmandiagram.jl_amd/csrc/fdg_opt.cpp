@@ -1268,16 +1268,29 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
   {
     std::vector<std::vector<uint32_t>> by_node(p.N);
     for (uint32_t i = 0; i < C.copies.size(); ++i) by_node[C.copies[i].node].push_back(i);
-    for (uint32_t n = 0; n < p.N; ++n) {
-      auto &v = by_node[n];
-      if (v.empty()) continue;
-      std::sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return C.copies[a].e_first < C.copies[b].e_first; });
-      for (uint32_t ci : v) {
-        CoopBuild::Copy &c = C.copies[ci];
-        if (!ivs.empty() && ivs.back().node == n && c.e_first - 1 <= ivs.back().end + gap) ivs.back().end = std::max(ivs.back().end, c.e_last);
-        else ivs.push_back(Interval{n, c.e_first - 1, c.e_last, NONE});
-        c.interval = (uint32_t)ivs.size() - 1;
+    for (uint32_t n = 0; n < p.N; ++n)
+      std::sort(by_node[n].begin(), by_node[n].end(), [&](uint32_t a, uint32_t b) { return C.copies[a].e_first < C.copies[b].e_first; });
+    // the value a node publishes may itself be a received copy (a one-child Sum of a remote node): its M_SEND is a use of that
+    // copy, at the end of the publishing interval's first epoch -- the copy's own interval must reach that far, which may in turn
+    // move that interval's end; repeated until nothing moves
+    std::vector<std::unordered_map<uint32_t, uint32_t>> copy_vid(NW);
+    for (uint32_t i = 0; i < C.copies.size(); ++i) copy_vid[C.copies[i].wave][C.B[C.copies[i].wave]->u[C.copies[i].uop].d] = i;
+    for (int pass = 0; pass < 64; ++pass) {
+      ivs.clear();
+      for (uint32_t n = 0; n < p.N; ++n)
+        for (uint32_t ci : by_node[n]) {
+          CoopBuild::Copy &c = C.copies[ci];
+          if (!ivs.empty() && ivs.back().node == n && c.e_first - 1 <= ivs.back().end + gap) ivs.back().end = std::max(ivs.back().end, c.e_last);
+          else ivs.push_back(Interval{n, c.e_first - 1, c.e_last, NONE});
+          c.interval = (uint32_t)ivs.size() - 1;
+        }
+      bool moved = false;
+      for (const Interval &iv : ivs) {
+        const uint32_t w = (uint32_t)C.owner[iv.node];
+        auto it = copy_vid[w].find(C.pub_ref[iv.node] >> 1);
+        if (it != copy_vid[w].end() && C.copies[it->second].e_last < iv.start) { C.copies[it->second].e_last = iv.start; moved = true; }
       }
+      if (!moved) break;
     }
     std::vector<uint32_t> order(ivs.size());
     for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;

@@ -117,6 +117,30 @@ def fuzz_table(seed: int):
 FUZZ_SEEDS = list(range(1000, 1056))
 
 
+def test_cooperative_programs_on_random_graphs(libfdg):
+    """The cooperative variant's four programs (tests/test_next_rows.py: replay_coop) on the fuzz graphs that have a wide
+    root: oracle bits including the sign of zeros, equal barrier counts, no shared slot rewritten in an epoch in which another
+    wave still reads it (a node whose value is a received copy publishes that copy: its M_SEND keeps the copy's slot alive)."""
+    from test_next_rows import replay_coop
+    n = 0
+    for seed in list(FUZZ_SEEDS) + list(range(2000, 2030)):
+        t, _ = fuzz_table(seed)
+        h = capi.GraphHandle(t)
+        try:
+            progs, info = h.coop_program()
+        except capi.FdgError as e:
+            assert e.code == capi.FDG_E_UNSUPPORTED
+            continue
+        n += 1
+        leaf = oracle.philox_uniform(24, t.n_leaf, seed) * 2 - 0.7
+        want = oracle.eval_static(t, leaf)
+        with np.errstate(all="ignore"):
+            got = replay_coop(progs, info, leaf, t.n_root)
+        live = t.root_slot != FDG_NO_ROOT
+        assert same(got[:, live], want[:, live]), seed
+    assert n >= 10
+
+
 @pytest.mark.gpu
 def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch):
     """The optimizing back end under random register / LDS / AGPR budgets (spills through every level), value-numbering
