@@ -122,7 +122,7 @@ struct fdg_graph {
   void *fn_isa_rm = nullptr;
   uint32_t isa4_vgpr = 0, isa4_lds_bytes = 0, isa4_mem_slots = 0;
   // cooperative variant: the four waves of a CU evaluate one tile together (graphs whose live set overflows one lane)
-  bool has_coop = false;
+  bool has_coop = false, coop_enabled = false;
   void *fn_isa_coop = nullptr;
   uint32_t coop_panel_wg = 0, coop_lds_bytes = 0;
   // companion HIP-source kernels of an ISA-specialised handle, used for sample-major input (FDG_SPEC_ROW_MAJOR_COMPANION)

@@ -537,7 +537,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // leaf-major workspace first (leaves) or refused (roots); neither occurs with the layouts of DESIGN.md 2
     const bool wide_ss = ss < 0 || ss >= (1ll << 23);           // (the offset is unsigned: negative strides too)
     // Cooperative variant: one workgroup of four waves per CU, every workgroup walks tiles of 64 samples; leaf-major input.
-    if (mode == 0 && g->has_coop && g->fn_isa_coop && !(ls == 1 && ss != 1 && p.L > 1) && !wide_ss && !(rs < 0 || rs >= (1ll << 23)) &&
+    if (mode == 0 && g->has_coop && g->coop_enabled && g->fn_isa_coop && !(ls == 1 && ss != 1 && p.L > 1) && !wide_ss && !(rs < 0 || rs >= (1ll << 23)) &&
         !std::getenv("FDG_ISA_NO_COOP")) {
       long nwg = std::min<long>((long)((B + 63) / 64), (long)g->n_cu), lss = ss, lls = ls, rrs = rs, rrk = rk, n = (long)B;
       rc = ensure_ws(g, std::max(panel_all + (size_t)grid3 * R * 512u + 4096, (size_t)g->coop_panel_wg * (size_t)nwg + 4096));
@@ -1020,6 +1020,7 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
                         const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr) {
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
   g->has_coop = coop && coop->supported;
+  g->coop_enabled = g->has_coop;
   g->fn_isa_coop = nullptr;
   if (g->has_coop) {
     g->coop_panel_wg = 0;
@@ -1184,6 +1185,7 @@ struct IsaVariants {
   fdg::CoopProgram coop;
   bool w2 = false, acc = false;
   uint32_t rm_bufs = 0;
+  int coop_verdict = 2;        // 0 / 1: a remembered measurement says the cooperative variant loses / wins; 2: none
 };
 // The cooperative variant (four waves of a CU on one tile) is assembled for programs whose one-wave form
 // spills to the HBM panel in earnest (more than one panel access per 20 fold steps); FDG_ISA_COOP=1 / 0 forces / forbids.
@@ -1207,7 +1209,7 @@ static void build_variants(const fdg_graph *g, const fdg::OptParams &chosen, boo
 }
 static int assemble_and_install(fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags, IsaVariants &V) {
   std::vector<char> co; std::string hash;
-  build_coop(g, prog, V);
+  if (V.coop_verdict != 0) build_coop(g, prog, V);
   const fdg::CoopProgram *coop = V.coop.supported ? &V.coop : nullptr;
   const int rc = assemble_isa(g, prog, dir, flags, co, hash, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, "fdg_isa_eval",
                               V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop);
@@ -1222,12 +1224,15 @@ static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   std::vector<char> buf;
   if (!read_file(tuned, buf)) return 0;
   fdg::OptParams q;
+  int tuned_coop = 2;
   buf.push_back(0);
   {
     fdg_opt_params r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // seven numbers, or nine: ... recompute window and cost (files written before round 2 have seven)
-    if (std::sscanf(buf.data(), "%u %u %u %u %u %u %u %u %u", &r.n_reg, &r.n_lds, &r.n_acc, &r.lookahead_lds, &r.lookahead_mem, &r.lookahead_leaf, &r.vn_window,
-                    &r.remat_window, &r.remat_cost) < 7) return 0;
+    unsigned coop_flag = 2;      // tenth number: the tuner's verdict on the cooperative variant (absent: the static criterion decides)
+    if (std::sscanf(buf.data(), "%u %u %u %u %u %u %u %u %u %u", &r.n_reg, &r.n_lds, &r.n_acc, &r.lookahead_lds, &r.lookahead_mem, &r.lookahead_leaf, &r.vn_window,
+                    &r.remat_window, &r.remat_cost, &coop_flag) < 7) return 0;
+    tuned_coop = (int)coop_flag;
     if (r.n_reg < 4) return 0;
     q = to_params(&r);          // the same clamps as parameters handed over through the ABI
     if (!r.n_acc) q.n_acc = 0;
@@ -1238,6 +1243,7 @@ static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   if (!prog.supported) return 0;
   IsaVariants V;
   build_variants(g, q, true, V);
+  V.coop_verdict = tuned_coop;
   const int rc = assemble_and_install(g, prog, dir, flags, V);
   return rc ? rc : 1;
 }
@@ -1318,16 +1324,37 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
     }
     if (ms_min < best_ms) { best_ms = ms_min; best = (int)c; }
   }
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  hipFree(d_leaf); hipFree(d_root);
-  if (best < 0) { set_error("autotune: no candidate configuration ran"); return FDG_E_JIT; }
+  if (best < 0) { hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d_leaf); hipFree(d_root); set_error("autotune: no candidate configuration ran"); return FDG_E_JIT; }
   fdg::OptProgram prog;
   build_prog(g, cand[best], prog);
   IsaVariants V;
   build_variants(g, cand[best], true, V);
   rc = assemble_and_install(g, prog, dir, flags, V);
+  // the cooperative variant, when the graph got one, against the best one-wave kernel
+  bool coop_wins = false;
+  if (rc == FDG_OK && g->has_coop) {
+    float t[2] = {1e30f, 1e30f};
+    for (int use = 0; use < 2; ++use) {
+      g->coop_enabled = use != 0;
+      bool ok_run = true;
+      for (int w = 0; w < 6 && ok_run; ++w) ok_run = fdg_run_locked(g, 0, d_leaf, 1, Bt, d_root, p.R, 1, nullptr, nullptr, Bt, nullptr) == FDG_OK;
+      for (int rep = 0; rep < 5 && ok_run; ++rep) {
+        hipEventRecord(e0, nullptr);
+        ok_run = fdg_run_locked(g, 0, d_leaf, 1, Bt, d_root, p.R, 1, nullptr, nullptr, Bt, nullptr) == FDG_OK;
+        hipEventRecord(e1, nullptr);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ok_run) t[use] = std::min(t[use], ms);
+      }
+    }
+    coop_wins = t[1] < t[0];
+    g->coop_enabled = coop_wins;
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipFree(d_leaf); hipFree(d_root);
   if (rc) return rc;
-  const std::string line = to_line(cand[best]) + "\n";
+  const std::string line = to_line(cand[best]) + (g->has_coop ? (coop_wins ? " 1" : " 0") : "") + "\n";
   write_file(tuned, line.c_str(), line.size());
   return FDG_OK;
 }

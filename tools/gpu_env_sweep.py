@@ -27,7 +27,7 @@ for setting in sys.argv[2:]:
     os.environ.update(kv)
     try:
         t0 = time.time()
-        f = fd.compile_table(t, specialize="isa", cache_dir="/tmp/fdg-sweep-cache")
+        f = fd.compile_table(t, specialize="isa", cache_dir=os.environ.get("SWEEP_CACHE", "/tmp/fdg-sweep-cache"))
         tc = time.time() - t0
         root.zero_()
         f(root, leaf); torch.cuda.synchronize()
