@@ -7,6 +7,7 @@
 #include <array>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <limits>
@@ -1303,6 +1304,17 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
       ivs[i].slot = best;
       free_at[best] = ivs[i].end + 1;
     }
+  }
+  if (std::getenv("FDG_COOP_DEBUG")) {
+    std::vector<uint32_t> occ(C.cur_epoch + 2, 0);
+    for (const Interval &iv : ivs) for (uint32_t e = iv.start; e <= iv.end && e < occ.size(); ++e) occ[e]++;
+    uint64_t sum = 0; uint32_t mx = 0;
+    for (uint32_t e = 0; e < C.cur_epoch; ++e) { sum += occ[e]; mx = std::max(mx, occ[e]); }
+    std::fprintf(stderr, "[coop] epochs %u intervals %zu copies %zu slot occupancy avg %.1f max %u of %u\n", C.cur_epoch, ivs.size(), C.copies.size(),
+                 (double)sum / std::max(1u, C.cur_epoch), mx, out.n_shared);
+    std::vector<uint32_t> len_hist(8, 0);
+    for (const Interval &iv : ivs) len_hist[std::min<uint32_t>(7, (iv.end - iv.start) / 4)]++;
+    for (uint32_t k = 0; k < 8; ++k) std::fprintf(stderr, "  interval length %u..%u epochs: %u\n", 4 * k, 4 * k + 3, len_hist[k]);
   }
   out.n_transfer = C.copies.size();
   // ---- the waves' lists with their M_SEND ops, then the ordinary allocator ----------------------------------------------

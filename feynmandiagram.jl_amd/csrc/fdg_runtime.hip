@@ -1195,6 +1195,9 @@ static void build_coop(const fdg_graph *g, const fdg::OptProgram &prog, IsaVaria
   (void)prog;
   fdg::OptParams q = cfg_B();
   q.vn_window = 200;
+  if (const char *x = std::getenv("FDG_COOP_LA_LEAF")) q.lookahead_leaf = (uint32_t)std::atoi(x);
+  if (const char *x = std::getenv("FDG_COOP_LA_MEM")) q.lookahead_mem = (uint32_t)std::atoi(x);
+  if (const char *x = std::getenv("FDG_COOP_LA_LDS")) q.lookahead_lds = (uint32_t)std::atoi(x);
   if (!(e && e[0] == '1')) {
     fdg::OptProgram ref;                      // the one-wave program without recomputation decides
     build_prog(g, q, ref);
