@@ -199,7 +199,7 @@ def compile_Julia(graphs, filename: str, root=None, func_name: str = "eval_graph
     return leafmap
 
 
-def compile_C(graphs, filename: str, datatype: str = "double ", root=None, func_name: str = "eval_graph"):
+def compile_C(graphs, filename: str, datatype="Float64", root=None, func_name: str = "eval_graph"):
     s, leafmap = to_Cstr(graphs, root=root, datatype=datatype, name=func_name)
     _append(filename, s, "#include <math.h>\n")    # static.jl:272-276
     return leafmap

@@ -235,10 +235,35 @@ def to_julia_str(graphs, root=None, name: str = "eval_graph!"):
     return table_to_julia_str(table, ids, name), leafmap
 
 
-def to_Cstr(graphs, root=None, datatype: str = "double ", name: str = "eval_graph"):
-    """static.jl:155-197: returns ``(text, leafmap)``."""
+def julia_to_C_typestr(datatype) -> str:
+    """static.jl:134-153: the C spelling of the Julia weight type ``to_Cstr`` / ``compile_C`` take as ``datatype``.  Accepts the
+    Julia names (``"Float64"``, ``"Float32"``, ``"Int64"``, ``"Int32"``, ``"ComplexF32"``, ``"ComplexF64"``), numpy dtypes /
+    Python types of the same meaning, an ``"Array{T}"`` / ``"Vector{T}"`` of one of them (a pointer), or an already spelled C
+    type ending in a blank or ``*``.  Anything else: ``error("Unsupported type")`` as in the reference."""
+    table = {"Float64": "double ", "Float32": "float ", "Int64": "long long ", "Int32": "int ",
+             "ComplexF32": "complex float ", "ComplexF64": "complex double ",
+             "float64": "double ", "float32": "float ", "int64": "long long ", "int32": "int ",
+             "complex64": "complex float ", "complex128": "complex double ", "float": "double ", "int": "long long ", "complex": "complex double "}
+    if isinstance(datatype, str):
+        if datatype.endswith((" ", "*")) and datatype.strip("* ") in {v.strip() for v in table.values()}:
+            return datatype
+        for wrap in ("Array{", "Vector{", "Matrix{"):
+            if datatype.startswith(wrap) and datatype.endswith("}"):
+                return julia_to_C_typestr(datatype[len(wrap):-1].split(",")[0].strip()) + "*"
+        if datatype in table:
+            return table[datatype]
+        raise ValueError("Unsupported type")
+    name = getattr(datatype, "__name__", None) or str(getattr(datatype, "name", datatype))
+    if name in table:
+        return table[name]
+    raise ValueError("Unsupported type")
+
+
+def to_Cstr(graphs, root=None, datatype="Float64", name: str = "eval_graph"):
+    """static.jl:155-197: returns ``(text, leafmap)``; ``datatype`` as ``julia_to_C_typestr`` takes it (default: the
+    reference's ``_dtype.weight`` = Float64)."""
     table, leafmap, ids = lower(graphs, root)
-    return table_to_Cstr(table, ids, name, datatype), leafmap
+    return table_to_Cstr(table, ids, name, julia_to_C_typestr(datatype)), leafmap
 
 
 def to_python_str(graphs, root=None, name: str = "eval_graph", in_place: bool = False):

@@ -423,3 +423,38 @@ def test_call_value_is_the_last_root_statement(libfdg):
     # the other way round: the leaf's statement precedes the node's
     f2, _ = Compilers.compile([c, S], specialize=False)
     assert f2._last_root_value([7.0, 3.0]) == 3.0
+
+
+def test_c_text_datatypes(tmp_path):
+    """to_Cstr / compile_C's `datatype` keyword (static.jl:134-153, 155-158): every type the reference maps, spelled the
+    reference's way; the float text compiles and follows the double one to single precision; the complex text compiles."""
+    import subprocess
+    from feynmandiagram_jl_amd.lowering import julia_to_C_typestr
+    assert [julia_to_C_typestr(x) for x in ("Float64", "Float32", "Int64", "Int32", "ComplexF32", "ComplexF64")] == \
+        ["double ", "float ", "long long ", "int ", "complex float ", "complex double "]
+    assert julia_to_C_typestr("Vector{Float32}") == "float *" and julia_to_C_typestr(np.float32) == "float "
+    with pytest.raises(ValueError, match="Unsupported type"):
+        julia_to_C_typestr("BigFloat")
+    graphs, _ = fixtures.sigma2_graphs()
+    text64, _ = Compilers.to_Cstr(graphs)
+    text32, _ = Compilers.to_Cstr(graphs, datatype="Float32", name="eval32")
+    textc, _ = Compilers.to_Cstr(graphs, datatype="ComplexF64", name="evalc")
+    assert text64.startswith("\nvoid eval_graph(double *root, double *leafVal)") and "void eval32(float *root, float *leafVal)" in text32
+    assert "    complex double  g" in textc                 # (the reference's declaration line: type string, then " g<id>,")
+    src = tmp_path / "t.c"
+    src.write_text("#include <math.h>\n#include <complex.h>\n#include <stdio.h>\n" + text64 + text32 + textc + """
+int main(void) {
+  double l[8], r[2]; float lf[8], rf[2]; complex double lc[8], rc[2];
+  for (int i = 0; i < 8; ++i) { l[i] = 0.3 + 0.07 * i; lf[i] = (float)l[i]; lc[i] = l[i]; }
+  eval_graph(r, l); eval32(rf, lf); evalc(rc, lc);
+  printf("%.17g %.17g %.9g %.9g %.17g %.17g\\n", r[0], r[1], rf[0], rf[1], creal(rc[0]), creal(rc[1]));
+  return 0;
+}
+""")
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-O1", "-ffp-contract=off", str(src), "-o", str(exe), "-lm"])
+    v = [float(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert abs(v[2] - v[0]) <= 1e-5 * max(1.0, abs(v[0])) and abs(v[3] - v[1]) <= 1e-5 * max(1.0, abs(v[1]))
+    assert v[4] == v[0] and v[5] == v[1]
+    leafmap = Compilers.compile_C(graphs, str(tmp_path / "out.c"), datatype="Float32")
+    assert "float *root" in (tmp_path / "out.c").read_text() and len(leafmap) == 8
