@@ -799,7 +799,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         E.ins("s_waitcnt lgkmcnt(0)");
         E.lg_done = E.lg_issued;
         for (auto &pp : E.pend) if (pp.first == 2) pp.first = 0;
-        E.ins("s_barrier");
+        if (!(dbg && std::strstr(dbg, "nobarrier"))) E.ins("s_barrier");     // (timing experiment: results are garbage without it)
         break;
       case M_ST_LDS:
         if (dbg_nolds) break;
