@@ -252,11 +252,14 @@ class GraphHandle:
                       kw.get("lookahead_leaf", 0), kw.get("n_acc", 0), kw.get("vn_window", 0), 0, 0, 0)
         progs, per_wave = [], []
         info = None
-        for w in range(4):
+        for w in range(16):         # four waves, or 8 / 16 with FDG_COOP_WAVES
             ops = C.POINTER(MOp)()
             n = C.c_uint64()
             inf = (C.c_uint32 * 8)()
-            check(lib().fdg_graph_coop_program(self._h, C.byref(q), w, C.byref(ops), C.byref(n), inf))
+            rc = lib().fdg_graph_coop_program(self._h, C.byref(q), w, C.byref(ops), C.byref(n), inf)
+            if rc != 0 and w >= 4:
+                break
+            check(rc)
             try:
                 progs.append(np.frombuffer(C.string_at(ops, n.value * C.sizeof(MOp)), dtype=MOP_DTYPE).copy())
             finally:

@@ -124,7 +124,7 @@ struct fdg_graph {
   // cooperative variant: the four waves of a CU evaluate one tile together (graphs whose live set overflows one lane)
   bool has_coop = false, coop_enabled = false;
   void *fn_isa_coop = nullptr;
-  uint32_t coop_panel_wg = 0, coop_lds_bytes = 0;
+  uint32_t coop_panel_wg = 0, coop_lds_bytes = 0, coop_threads = 256;
   // companion HIP-source kernels of an ISA-specialised handle, used for sample-major input (FDG_SPEC_ROW_MAJOR_COMPANION)
   std::vector<char> alt_code;
   void *alt_module = nullptr, *fn_alt_sm = nullptr, *fn_alt_gen = nullptr;

@@ -1063,7 +1063,7 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
   E.hz.reset();
   E.ins("v_lshrrev_b32_e32 v1, 6, v0");
   E.ins("v_readfirstlane_b32 s3, v1");
-  for (uint32_t w = 0; w < CoopProgram::NW; ++w) {
+  for (uint32_t w = 0; w < cp.n_wave; ++w) {
     const std::string lab = ".Lsec_" + kname + "_w" + std::to_string(w), here = ".Lpc_" + kname + "_d" + std::to_string(w);
     E.ins("s_cmp_lg_u32 s3, " + std::to_string(w));
     E.ins("s_cbranch_scc1 .Lnot_" + kname + "_" + std::to_string(w));
@@ -1075,17 +1075,17 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
     os << ".Lnot_" << kname << "_" << w << ":\n";
   }
   E.ins("s_endpgm");
-  uint32_t panel_wg = 0, prefix[CoopProgram::NW];
-  for (uint32_t w = 0; w < CoopProgram::NW; ++w) { prefix[w] = panel_wg; panel_wg += std::max<uint32_t>(cp.wave[w].n_mem_used, 1) * 512u; }
+  uint32_t panel_wg = 0, prefix[CoopProgram::MAXW];
+  for (uint32_t w = 0; w < cp.n_wave; ++w) { prefix[w] = panel_wg; panel_wg += std::max<uint32_t>(cp.wave[w].n_mem_used, 1) * 512u; }
   uint32_t accum = 0, n_agpr = 0;
   int n_sgpr = 0;
-  for (uint32_t w = 0; w < CoopProgram::NW; ++w) {
+  for (uint32_t w = 0; w < cp.n_wave; ++w) {
     const CoopSec cs{w, cp.n_shared, (cp.n_shared + w * cp.n_priv_lds) * 512u, panel_wg, prefix[w]};
     E.hz.reset();
     const KernelMeta m = emit_kernel(E, p, cp.wave[w], kname + "_w" + std::to_string(w), 1, false, 0, &cs);
     accum = std::max(accum, m.accum); n_agpr = std::max(n_agpr, m.n_agpr); n_sgpr = std::max(n_sgpr, m.n_sgpr);
   }
-  const uint32_t lds_bytes = (cp.n_shared + CoopProgram::NW * cp.n_priv_lds) * 512u;
+  const uint32_t lds_bytes = (cp.n_shared + cp.n_wave * cp.n_priv_lds) * 512u;
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
   os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";
   os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size 80\n\t\t.amdhsa_user_sgpr_count 2\n";
@@ -1157,7 +1157,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   if (prog2) ks.push_back(emit_kernel(E, p, *prog2, kname + "_w2", 2));
   if (prog_acc) ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc", 1, true));
   if (prog_rm && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm, kname + "_rm", 1, false, rm_bufs));
-  if (coop && coop->supported) { ks.push_back(emit_coop(E, p, *coop, kname + "_coop")); ks.back().wg = 256; }
+  if (coop && coop->supported) { ks.push_back(emit_coop(E, p, *coop, kname + "_coop")); ks.back().wg = 64 * coop->n_wave; }
   std::ostringstream &os = E.os;
   os << "\t.text\n\t.amdgpu_metadata\n---\namdhsa.kernels:\n";
   const char *kinds[16] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",

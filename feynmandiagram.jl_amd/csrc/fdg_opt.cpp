@@ -1160,21 +1160,21 @@ struct CoopBuild {
 
 }  // namespace
 
-static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budget, uint32_t gap, CoopProgram &out);
+static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budget, uint32_t gap, CoopProgram &out, uint32_t NW);
 
 // Shorter epochs keep fewer hand-overs in flight: when the shared slots run out the schedule is rebuilt with a smaller budget.
-void build_coop_program(const Lowered &p, const OptParams &prm, CoopProgram &out) {
+void build_coop_program(const Lowered &p, const OptParams &prm, CoopProgram &out, uint32_t n_wave) {
   const char *te = std::getenv("FDG_COOP_EPOCH_OPS");
-  if (te) { const char *ge = std::getenv("FDG_COOP_GAP"); build_coop_once(p, prm, (size_t)std::max(8, std::atoi(te)), ge ? (uint32_t)std::atoi(ge) : 2u, out); return; }
+  if (te) { const char *ge = std::getenv("FDG_COOP_GAP"); build_coop_once(p, prm, (size_t)std::max(8, std::atoi(te)), ge ? (uint32_t)std::atoi(ge) : 2u, out, n_wave); return; }
   for (size_t budget : {192, 128, 96, 64, 48}) {
-    build_coop_once(p, prm, budget, budget > 64 ? 2u : 1u, out);
+    build_coop_once(p, prm, budget, budget > 64 ? 2u : 1u, out, n_wave);
     if (out.supported || out.why != "shared LDS slots exhausted") return;
   }
 }
 
-static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budget, uint32_t gap, CoopProgram &out) {
+static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budget, uint32_t gap, CoopProgram &out, uint32_t NW) {
   out = CoopProgram();
-  constexpr uint32_t NW = CoopProgram::NW;
+  out.n_wave = NW;
   const uint32_t L = p.L;
   CoopBuild C(p);
   if (const char *e = std::getenv("FDG_COOP_COPY_WINDOW")) C.copy_window = (uint32_t)std::max(1, std::atoi(e));
@@ -1261,7 +1261,7 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
     }
   }
   // ---- publication intervals and shared slots ---------------------------------------------------------------------------
-  out.n_priv_lds = 16;
+  out.n_priv_lds = NW == 4 ? 16 : (NW == 8 ? 8 : 4);
   if (const char *e = std::getenv("FDG_COOP_PRIV_LDS")) out.n_priv_lds = (uint32_t)std::max(1, std::min(70, std::atoi(e)));
   out.n_shared = 312 - NW * out.n_priv_lds;
   struct Interval { uint32_t node, start, end, slot; };

@@ -126,8 +126,9 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
 // Per-sample on-chip state is four times that of the one-wave kernels -- the design point for graphs whose live set
 // overflows one lane.  Every wave's program contains the same number of barriers.
 struct CoopProgram {
-  static constexpr uint32_t NW = 4;
-  OptProgram wave[NW];
+  static constexpr uint32_t MAXW = 16;
+  uint32_t n_wave = 4;         // 4: one wave per SIMD, AGPRs as a spill level; 8: two per SIMD (256 registers each, no AGPR level)
+  OptProgram wave[MAXW];
   uint32_t n_shared = 0;       // shared LDS slots (of 512 bytes) in front of the waves' private ones
   uint32_t n_priv_lds = 0;     // private LDS slots of each wave
   uint32_t n_epoch = 0;        // barriers per tile
@@ -136,7 +137,7 @@ struct CoopProgram {
   bool supported = false;
   std::string why;
 };
-void build_coop_program(const Lowered &p, const OptParams &prm, CoopProgram &out);
+void build_coop_program(const Lowered &p, const OptParams &prm, CoopProgram &out, uint32_t n_wave = 4);
 
 void rm_plan_stats(const Lowered &p, const OptProgram &prog, uint32_t bufs, uint64_t &fetches, uint64_t &gathers);
 // gfx950 wait-state table of the emitter (fdg_isa.cpp): check of a finished listing, and the table as text

@@ -545,7 +545,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       void *a_wsp = g->d_ws;
       const double *nowt = nullptr;
       void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &n, &nwg, (void *)&nowt};
-      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_coop, (unsigned)nwg, 1, 1, 256, 1, 1, 0, st, args, nullptr));
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_coop, (unsigned)nwg, 1, 1, g->coop_threads, 1, 1, 0, st, args, nullptr));
       return FDG_OK;
     }
     // Row-major leaves ([B, L], leaf stride 1) and evaluation: full 64-row tiles go through the variant that stages chunks
@@ -936,12 +936,19 @@ int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop *
   return FDG_OK;
 }
 
+// waves of a cooperative workgroup: 8 (two per SIMD, 256 registers each: the second wave covers memory latency) unless asked otherwise
+static uint32_t coop_waves() { const char *e = std::getenv("FDG_COOP_WAVES"); const int n = e ? std::atoi(e) : 8; return n == 4 ? 4u : (n == 16 ? 16u : 8u); }
+
 int fdg_graph_coop_program(const fdg_graph *g, const fdg_opt_params *q, uint32_t wave, fdg_mop **ops, uint64_t *n_ops, uint32_t *info) {
-  if (!g || !ops || !n_ops || wave >= fdg::CoopProgram::NW) { set_error("null argument or wave out of range"); return FDG_E_INVALID; }
+  if (!g || !ops || !n_ops || wave >= fdg::CoopProgram::MAXW) { set_error("null argument or wave out of range"); return FDG_E_INVALID; }
   fdg::OptParams prm = to_params(q);
   if (!q || !q->n_acc) prm.n_acc = 124;
   fdg::CoopProgram cp;
-  fdg::build_coop_program(g->prog, prm, cp);
+  const uint32_t nw = coop_waves();
+  if (nw >= 8) prm.n_acc = 0;
+  if (nw == 16) prm.n_reg = std::min<uint32_t>(prm.n_reg, 58);
+  fdg::build_coop_program(g->prog, prm, cp, nw);
+  if (cp.supported && wave >= cp.n_wave) { set_error("wave out of range"); return FDG_E_INVALID; }
   if (!cp.supported) { set_error("the cooperative variant does not cover this graph: " + cp.why); return FDG_E_UNSUPPORTED; }
   const fdg::OptProgram &prog = cp.wave[wave];
   fdg_mop *m = (fdg_mop *)std::malloc(std::max<size_t>(1, prog.ops.size()) * sizeof(fdg_mop));
@@ -1024,8 +1031,9 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
   g->fn_isa_coop = nullptr;
   if (g->has_coop) {
     g->coop_panel_wg = 0;
-    for (uint32_t w = 0; w < fdg::CoopProgram::NW; ++w) g->coop_panel_wg += std::max<uint32_t>(coop->wave[w].n_mem_used, 1) * 512u;
-    g->coop_lds_bytes = (coop->n_shared + fdg::CoopProgram::NW * coop->n_priv_lds) * 512u;
+    for (uint32_t w = 0; w < coop->n_wave; ++w) g->coop_panel_wg += std::max<uint32_t>(coop->wave[w].n_mem_used, 1) * 512u;
+    g->coop_lds_bytes = (coop->n_shared + coop->n_wave * coop->n_priv_lds) * 512u;
+    g->coop_threads = 64 * coop->n_wave;
   }
   g->code_object.swap(co);
   g->isa = true;
@@ -1185,7 +1193,7 @@ struct IsaVariants {
   fdg::CoopProgram coop;
   bool w2 = false, acc = false;
   uint32_t rm_bufs = 0;
-  int coop_verdict = 2;        // 0 / 1: a remembered measurement says the cooperative variant loses / wins; 2: none
+  int coop_verdict = -1;       // a remembered measurement: 0 = the cooperative variant loses, 4 / 8 = it wins with that many waves; -1: none
 };
 // The cooperative variant (four waves of a CU on one tile) is assembled for programs whose one-wave form
 // spills to the HBM panel in earnest (more than one panel access per 20 fold steps); FDG_ISA_COOP=1 / 0 forces / forbids.
@@ -1203,7 +1211,13 @@ static void build_coop(const fdg_graph *g, const fdg::OptProgram &prog, IsaVaria
     build_prog(g, q, ref);
     if (!ref.supported || (ref.n_ld_mem + ref.n_st_mem) * 20 <= ref.n_valu) return;
   }
-  fdg::build_coop_program(g->prog, q, V.coop);
+  for (uint32_t nw : {V.coop_verdict > 0 ? (uint32_t)V.coop_verdict : coop_waves(), 4u}) {    // (four waves when eight run out of shared slots)
+    fdg::OptParams qw = q;
+    if (nw >= 8) qw.n_acc = 0;                // two waves per SIMD: 256 registers each
+    if (nw == 16) qw.n_reg = 58;              // four per SIMD: 128 registers each
+    fdg::build_coop_program(g->prog, qw, V.coop, nw);
+    if (V.coop.supported || V.coop_verdict > 0) break;
+  }
 }
 static void build_variants(const fdg_graph *g, const fdg::OptParams &chosen, bool allow_w2, IsaVariants &V) {
   V.w2 = allow_w2 && !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, V.p2);
@@ -1227,15 +1241,15 @@ static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   std::vector<char> buf;
   if (!read_file(tuned, buf)) return 0;
   fdg::OptParams q;
-  int tuned_coop = 2;
+  int tuned_coop = -1;
   buf.push_back(0);
   {
     fdg_opt_params r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // seven numbers, or nine: ... recompute window and cost (files written before round 2 have seven)
-    unsigned coop_flag = 2;      // tenth number: the tuner's verdict on the cooperative variant (absent: the static criterion decides)
+    int coop_flag = -1;          // tenth number: the tuner's verdict on the cooperative variant (absent: the static criterion decides)
     if (std::sscanf(buf.data(), "%u %u %u %u %u %u %u %u %u %u", &r.n_reg, &r.n_lds, &r.n_acc, &r.lookahead_lds, &r.lookahead_mem, &r.lookahead_leaf, &r.vn_window,
-                    &r.remat_window, &r.remat_cost, &coop_flag) < 7) return 0;
-    tuned_coop = (int)coop_flag;
+                    &r.remat_window, &r.remat_cost, (unsigned *)&coop_flag) < 7) return 0;
+    tuned_coop = coop_flag == 1 ? 4 : coop_flag;       // (files of the first cooperative version wrote 1 for four waves)
     if (r.n_reg < 4) return 0;
     q = to_params(&r);          // the same clamps as parameters handed over through the ABI
     if (!r.n_acc) q.n_acc = 0;
@@ -1333,12 +1347,12 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   IsaVariants V;
   build_variants(g, cand[best], true, V);
   rc = assemble_and_install(g, prog, dir, flags, V);
-  // the cooperative variant, when the graph got one, against the best one-wave kernel
-  bool coop_wins = false;
-  if (rc == FDG_OK && g->has_coop) {
-    float t[2] = {1e30f, 1e30f};
-    for (int use = 0; use < 2; ++use) {
-      g->coop_enabled = use != 0;
+  // the cooperative variant, when the graph gets one, with eight and with four waves against the best one-wave kernel
+  int coop_best = 0;
+  const bool had_coop = rc == FDG_OK && g->has_coop;
+  if (had_coop) {
+    auto time_it = [&]() {
+      float tm = 1e30f;
       bool ok_run = true;
       for (int w = 0; w < 6 && ok_run; ++w) ok_run = fdg_run_locked(g, 0, d_leaf, 1, Bt, d_root, p.R, 1, nullptr, nullptr, Bt, nullptr) == FDG_OK;
       for (int rep = 0; rep < 5 && ok_run; ++rep) {
@@ -1348,16 +1362,31 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
         hipEventSynchronize(e1);
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
-        if (ok_run) t[use] = std::min(t[use], ms);
+        if (ok_run) tm = std::min(tm, ms);
       }
+      return tm;
+    };
+    g->coop_enabled = false;
+    float t_best = time_it();
+    for (int nw : {8, 4}) {
+      IsaVariants Vw;
+      build_variants(g, cand[best], true, Vw);
+      Vw.coop_verdict = nw;
+      if (assemble_and_install(g, prog, dir, flags, Vw) != FDG_OK || !g->has_coop) continue;
+      g->coop_enabled = true;
+      const float tw = time_it();
+      if (tw < t_best) { t_best = tw; coop_best = nw; }
     }
-    coop_wins = t[1] < t[0];
-    g->coop_enabled = coop_wins;
+    IsaVariants Vf;
+    build_variants(g, cand[best], true, Vf);
+    Vf.coop_verdict = coop_best;
+    rc = assemble_and_install(g, prog, dir, flags, Vf);
+    g->coop_enabled = g->has_coop;
   }
   hipEventDestroy(e0); hipEventDestroy(e1);
   hipFree(d_leaf); hipFree(d_root);
   if (rc) return rc;
-  const std::string line = to_line(cand[best]) + (g->has_coop ? (coop_wins ? " 1" : " 0") : "") + "\n";
+  const std::string line = to_line(cand[best]) + (had_coop ? " " + std::to_string(coop_best) : std::string()) + "\n";
   write_file(tuned, line.c_str(), line.size());
   return FDG_OK;
 }

@@ -652,13 +652,15 @@ def test_entry_points_are_graph_capturable(libfdg, cuda):
     assert np.array_equal(root.cpu().numpy(), oracle.eval_static(t, leaf.cpu().numpy()))
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("name", ["sigma4_standin", "sigma4_worstcase", "gv_sigma5", "synthetic_small"])
-def test_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_path, name):
-    """fdg_isa_eval_coop: the four waves of a CU evaluate one 64-sample tile together, each on its share of the graph,
+def test_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_path, name, waves):
+    """fdg_isa_eval_coop: four or eight waves of a CU evaluate one 64-sample tile together, each on its share of the graph,
     values crossing through shared LDS slots between s_barrier epochs.  Forced here on graphs that would not
     ask for it; ragged and single-tile batches, more tiles than workgroups; bit for bit against the oracle."""
     import torch
     monkeypatch.setenv("FDG_ISA_COOP", "1")
+    monkeypatch.setenv("FDG_COOP_WAVES", str(waves))
     t = workloads.get(name)
     cache = tmp_path / "c"
     cache.mkdir(mode=0o700)

@@ -335,18 +335,21 @@ def replay_coop(progs, info, leaf, R):
         for slot, (w, val) in pending.items():
             assert not [1 for (sl, rw) in read_slots if sl == slot and rw != w], ("slot overwritten while still read", slot)
             shared[slot] = val
-    assert all(st[w]["pc"] == len(progs[w]) for w in range(4))
+    assert all(st[w]["pc"] == len(progs[w]) for w in range(len(progs)))
     return root
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("name", ["sigma4_standin", "gv_sigma5", "sigma4_worstcase", "synthetic_small"])
-def test_cooperative_programs_replay_exactly(libfdg, name):
+def test_cooperative_programs_replay_exactly(libfdg, monkeypatch, name, waves):
     """The cooperative variant (four waves of a CU on one tile): who computes a term changes, the folds do not.
     The four programs replayed with their barriers give the oracle's bits; every wave's program has the same number of
     barriers; nothing is read from a shared slot in the epoch in which it is rewritten."""
+    monkeypatch.setenv("FDG_COOP_WAVES", str(waves))      # one or two waves per SIMD (two: 256 registers each, no AGPR level)
     t = workloads.get(name)
     h = capi.GraphHandle(t)
     progs, info = h.coop_program()
+    assert len(progs) == waves
     leaf = oracle.philox_uniform(5, t.n_leaf, 79)
     got = replay_coop(progs, info, leaf, t.n_root)
     assert np.array_equal(got, oracle.eval_static(t, leaf))

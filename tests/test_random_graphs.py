@@ -125,6 +125,7 @@ def test_cooperative_programs_on_random_graphs(libfdg):
     n = 0
     for seed in list(FUZZ_SEEDS) + list(range(2000, 2030)):
         t, _ = fuzz_table(seed)
+        os.environ["FDG_COOP_WAVES"] = "4" if seed % 2 else "8"
         h = capi.GraphHandle(t)
         try:
             progs, info = h.coop_program()
@@ -138,6 +139,7 @@ def test_cooperative_programs_on_random_graphs(libfdg):
             got = replay_coop(progs, info, leaf, t.n_root)
         live = t.root_slot != FDG_NO_ROOT
         assert same(got[:, live], want[:, live]), seed
+    os.environ.pop("FDG_COOP_WAVES", None)
     assert n >= 10
 
 
@@ -165,6 +167,7 @@ def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch
             monkeypatch.setenv("FDG_REMAT_WINDOW", str(int(rng.choice([8, 60, 400]))))
         if seed % 2 == 1:                  # the cooperative variant wherever the graph has a wide root sum (it then takes the leaf-major calls)
             monkeypatch.setenv("FDG_ISA_COOP", "1")
+            monkeypatch.setenv("FDG_COOP_WAVES", "4" if seed % 4 == 1 else "8")
         for opt in opts:
             f = fd.compile_table(t, specialize="isa", opt=opt, cache_dir=str(cache), flags=capi.FDG_SPEC_KEEP_SOURCE)
             for layout in ("leaf_major", "sample_major"):
@@ -183,6 +186,7 @@ def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch
         monkeypatch.delenv("FDG_ISA_W2", raising=False)
         monkeypatch.delenv("FDG_REMAT_WINDOW", raising=False)
         monkeypatch.delenv("FDG_ISA_COOP", raising=False)
+        monkeypatch.delenv("FDG_COOP_WAVES", raising=False)
         for lst in glob.glob(str(cache / "*.s")):
             n, rep = capi.isa_check_hazards(open(lst).read())
             assert n == 0, (seed, rep)
