@@ -264,14 +264,15 @@ and `d_T` (`B × n_tau`) in place when they are Julia column-major matrices -- t
 `kF`, `beta`, `lambda` are arguments of that kernel: one code object, assembled here, serves every parameter set.
 """
 function specialize_fused!(f::GraphFunc, leafType::Vector{Int}, leafOrder::Vector{Int}, leafInTau::Vector{Int}, leafOutTau::Vector{Int},
-    leafLoopIndex::Vector{Int}, loopbasis::Matrix{Float64}; dim::Int=3, n_tau::Int, cache_dir::String=get(ENV, "FDG_CACHE_DIR", "/tmp/fdg-cache"),
+    leafLoopIndex::Vector{Int}, loopbasis::Matrix{Float64}; dim::Int=3, n_tau::Int, cache_dir::Union{Nothing,String}=nothing,   # nothing: the library's per-user default (include/fdg.h)
     kF::Float64=0.0, beta::Float64=0.0, lambda::Float64=0.0)
     a = [Int32.(v) for v in (leafType, leafOrder, leafInTau, leafOutTau, leafLoopIndex)]
     bs = Matrix{Float64}(loopbasis)      # column-major n_loop × n_basis == row-major [n_basis][n_loop]
     GC.@preserve a bs begin
         tab = _FdgLeafTables(length(a[1]), size(bs, 2), size(bs, 1), dim, n_tau, pointer(a[1]), pointer(a[2]), pointer(a[3]),
             pointer(a[4]), pointer(a[5]), pointer(bs), kF, beta, lambda)
-        _fdg_check(ccall((:fdg_graph_specialize_fused, _libfdg), Cint, (Ptr{Cvoid}, Ref{_FdgLeafTables}, Cstring, Cuint), f.handle, tab, cache_dir, Cuint(0)))
+        _fdg_check(ccall((:fdg_graph_specialize_fused, _libfdg), Cint, (Ptr{Cvoid}, Ref{_FdgLeafTables}, Cstring, Cuint), f.handle, tab,
+            isnothing(cache_dir) ? C_NULL : cache_dir, Cuint(0)))
     end
     return f
 end
