@@ -79,6 +79,7 @@ struct Builder {
   // the same bits).  A widely shared value whose uses are thousands of ops apart would otherwise sit in a spill slot and
   // come back through the HBM panel for every use; its operands -- lower-order sub-diagrams that many nodes keep reading --
   // usually are still on chip.  Roots are exempt.
+  uint32_t term_window = 1, term_recent = 400;    // out-of-order evaluation of a wide node's terms (see build_uops)
   uint64_t remat_window = 0;
   uint32_t remat_cost = 8;
   std::vector<uint8_t> remat_ok;   // [N]
@@ -452,7 +453,35 @@ void build_uops(Builder &B) {
       B.need(c);
       if (!B.available(c)) {
         if (B.ref_of[c] != NONE) B.n_remat++;
-        st.push_back(Frame{c - L, 0, NONE});
+        // Terms of a wide Sum / Prod may be COMPUTED out of order (their values wait for their turn in the left fold, which
+        // stays in order): among the next `term_window` terms the one that shares most operands with what was touched
+        // recently goes first, so that diagrams built from the same propagators are evaluated while those are on chip.
+        uint32_t pick = c;
+        const uint32_t k = p.off[f.n + 1] - p.off[f.n];
+        if (B.term_window > 1 && k >= 16 && B.ref_of[c] == NONE) {
+          double best = -1.0;
+          for (uint32_t j = f.i; j < k && j < f.i + B.term_window; ++j) {
+            const uint32_t cj = p.idx[p.off[f.n] + j];
+            if (cj < L || B.ref_of[cj] != NONE) continue;
+            uint32_t tot = 0, rec = 0;
+            auto look = [&](uint32_t v) {
+              tot++;
+              const uint32_t r = B.ref_of[v];
+              if (r == NONE) return;
+              const uint32_t vid = r >> 1;
+              if (vid < B.born.size() && B.born[vid] > 0 && (uint64_t)B.u.size() - B.born[vid] < B.term_recent) rec++;
+            };
+            const uint32_t nj = cj - L;
+            for (uint32_t e = p.off[nj]; e < p.off[nj + 1]; ++e) {
+              const uint32_t v = p.idx[e];
+              look(v);
+              if (v >= L && B.ref_of[v] == NONE) for (uint32_t e2 = p.off[v - L]; e2 < p.off[v - L + 1]; ++e2) look(p.idx[e2]);
+            }
+            const double score = tot ? (double)rec / tot : 0.0;
+            if (score > best + 1e-12) { best = score; pick = cj; }
+          }
+        }
+        st.push_back(Frame{pick - L, 0, NONE});
         continue;
       }
       if (step(st.back())) st.pop_back();
@@ -928,6 +957,8 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   B0.remat_window = prm.remat_window;
   B0.remat_cost = prm.remat_cost;
   if (const char *rw = std::getenv("FDG_REMAT_WINDOW")) B0.remat_window = (uint64_t)std::atoll(rw);     // experiments
+  if (const char *tw = std::getenv("FDG_TERM_WINDOW")) B0.term_window = (uint32_t)std::max(1, std::atoi(tw));
+  if (const char *tr = std::getenv("FDG_TERM_RECENT")) B0.term_recent = (uint32_t)std::max(1, std::atoi(tr));
   build_uops(B0);
   Lowered plain;
   const bool retry = !B0.ok && B0.why == "inconsistent schedule groups";
