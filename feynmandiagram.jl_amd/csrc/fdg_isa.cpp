@@ -577,6 +577,28 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("s_add_u32 " + S(S_PANEL) + ", " + S(S_PANEL) + ", " + hex32(cs->panel_prefix_bytes));
     E.ins("s_addc_u32 " + S(S_PANEL + 1) + ", " + S(S_PANEL + 1) + ", 0");
   }
+  // Panel addresses: slot s lives at panel + SLOT s, and the instruction's signed 13-bit offset reaches 4 KB either way
+  // of an SGPR base.  The pool's unused pairs hold panel + 8192 k for the 8 KB windows the program touches most, set
+  // once per wave, so that those accesses need no scalar add (the others build their base in S_A as before).
+  std::map<uint32_t, int> panel_base;          // window k (bytes 8192 k - 4096 .. 8192 k + 4095) -> first SGPR of its base pair
+  if (!mc) {
+    std::map<uint32_t, uint64_t> hist;
+    for (const MOp &o : prog.ops) {
+      if (o.kind != M_LD_MEM && o.kind != M_ST_MEM) continue;
+      const uint32_t slot = o.kind == M_LD_MEM ? o.a : o.d;
+      const uint64_t byte = (uint64_t)slot * SLOT;
+      if (byte >= 4096) hist[(uint32_t)((byte + 4096) / 8192)]++;
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> v;
+    for (auto &kv : hist) v.push_back({kv.second, kv.first});
+    std::sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
+    for (size_t i = 0; i < v.size() && pool.size() + i < (size_t)N_POOL; ++i) {
+      const int r = S_POOL + 2 * (int)(pool.size() + i);
+      panel_base[v[i].second] = r;
+      E.ins("s_add_u32 " + S(r) + ", " + S(S_PANEL) + ", " + hex32(v[i].second * 8192u));
+      E.ins("s_addc_u32 " + S(r + 1) + ", " + S(S_PANEL + 1) + ", 0");
+    }
+  }
   E.ins("s_cmp_ge_u32 " + S(S_TILE) + ", " + S(S_NTILES));
   E.ins("s_cbranch_scc0 .Ltile" + sfx);
   E.ins("s_endpgm");   // (the host never launches more waves than tiles)
@@ -626,6 +648,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     const uint64_t byte = (uint64_t)slot * SLOT;
     const uint64_t hi = byte & ~4095ull, lo = byte & 4095ull;
     if (hi == 0) return S2(S_PANEL) + " offset:" + std::to_string(lo);
+    const auto it = panel_base.find((uint32_t)((byte + 4096) / 8192));
+    if (it != panel_base.end()) return S2(it->second) + " offset:" + std::to_string((int64_t)byte - (int64_t)it->first * 8192);
     E.ins("s_add_u32 " + S(S_A) + ", " + S(S_PANEL) + ", " + hex32((uint32_t)hi));
     E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_PANEL + 1) + ", " + hex32((uint32_t)(hi >> 32)));
     return S2(S_A) + " offset:" + std::to_string(lo);
