@@ -30,10 +30,19 @@ WORKLOAD_NOTES = {
     "gv_sigma4_taylor2": " (config 4: 4-loop self-energy with Taylor-mode AD counterterms of order 2 in the coupling: reference GV catalog Sigma4_0_0.diag through the restated reader, taylorAD and optimize!; 7373 nodes; the 4-loop Parquet graph itself needs the Julia front end)",
     "gv_sigma5": " (config 3 stand-in (i) / config 5: reference GV catalog Sigma5_0_0.diag through the restated reader + optimize!)",
     "gv_sigma6": " (config 3 stand-in (i): reference GV catalog Sigma6_0_0.diag through the restated reader + optimize!)",
+    "parquet_sigma4": " (config 3: the 4-loop Parquet self-energy, Parquet.build(DiagPara(type=SigmaDiag, innerLoopNum=4, hasTau=true, filter=[NoHartree])) + optimize! "
+                      "through the restated front end (feynmandiagram.jl_amd/parquet.py; pinned by the reference's diagram counts 1, 3, 18, 171 and its rendering of the "
+                      "2-loop graph); the reference's default interaction, ChargeCharge Instant: 1325 nodes after optimize!, 3646 before)",
+    "parquet_sigma4_dyn": " (config 3 with a Dynamic interaction: 4819 nodes)",
+    "parquet_sigma4_insdyn": " (config 3 with an Instant + Dynamic interaction: 20147 nodes)",
+    "parquet_sigma4_taylor2": " (config 4: the 4-loop Parquet self-energy with Taylor-mode AD counterterms of order 2 in the coupling, restated taylorAD + optimize!: 7421 nodes, 12 roots)",
+    "parquet_sigma2": " (configs 1-2 from the restated Parquet front end, one optimize! pass: 19 nodes)",
 }
 DEFAULT_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcase": 1_000_000, "synthetic_small": 8_000_000,
              "gv_sigma4": 8_000_000, "gv_sigma5": 2_000_000, "gv_sigma6": 500_000, "gv_sigma4_taylor2": 4_000_000,
-             "gv_sigma5_taylor2": 1_000_000}
+             "gv_sigma5_taylor2": 1_000_000, "parquet_sigma2": 64_000_000, "parquet_sigma3": 16_000_000, "parquet_sigma4": 100_000_000,
+             "parquet_sigma4_dyn": 8_000_000, "parquet_sigma4_insdyn": 4_000_000, "parquet_sigma4_taylor2": 8_000_000,
+             "parquet_sigma4_dyn_taylor2": 2_000_000, "parquet_sigma4_insdyn_taylor2": 1_000_000}
 PARITY_NOTE = ("bit-exact vs our restatement of the Julia evaluator (oracle/); the reference's known-answer tests pin structure, "
                "leaf numbering and factors, not the rounding of the n-ary folds")
 
@@ -86,6 +95,19 @@ class Case:
         return bool(np.array_equal(got, want)), float(np.abs(got - want).max()) if n else 0.0, n
 
 
+def observable_sum(root):
+    """Column sums of the root matrix, the observable of the final reduction.  For a Julia-layout matrix (R long rows)
+    torch's reduction runs one workgroup per row -- 50 ms for 4 x 10^8 doubles -- so the rows are summed in two stages."""
+    if root.stride(0) != 1 or root.shape[0] < (1 << 16):
+        return root.sum(dim=0)
+    rt = root.t()                                  # [R, B], rows contiguous
+    R, B = rt.shape
+    c = 1 << 14
+    nb = B // c
+    acc = rt[:, :nb * c].reshape(R, nb, c).sum(dim=2).sum(dim=1)
+    return acc + rt[:, nb * c:].sum(dim=1) if nb * c < B else acc
+
+
 def roofline_of(st, B, avg_kernel_s, kernel, accumulate=False):
     bytes_per_eval = st["bytes_alg_accumulate"] if accumulate else st["bytes_alg"]
     achieved = bytes_per_eval * B / avg_kernel_s / 1e9
@@ -135,7 +157,7 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
     roofline fraction, and a bitwise check of a sample against the oracle."""
     import torch
     try:
-        c = Case(workload, layout, DEFAULT_B.get(workload, 1_000_000), dev)
+        c = Case(workload, layout, 16_000_000 if workload == "parquet_sigma4" else DEFAULT_B.get(workload, 1_000_000), dev)
         ms = c.timed(steps, warm)
         avg = sum(ms) / len(ms) / 1e3
         ok, dev_max, n = c.parity_sample()
@@ -219,9 +241,9 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)   # 100 steps x 4e6 samples = 4e8 samples (config 3 names 1e8)
+    ap.add_argument("--steps", type=int, default=100)   # one step = config 3's 1e8 samples on the default workload
     ap.add_argument("--warmup", type=int, default=60)   # power management needs ~40 launches (50 ms) to settle: 1.4 -> 1.04 ms per launch
-    ap.add_argument("--workload", default="gv_sigma4_taylor2")
+    ap.add_argument("--workload", default="parquet_sigma4")
     ap.add_argument("--samples", type=int, default=0, help="samples per step per GPU (0 = workload default)")
     ap.add_argument("--layout", default="leaf_major", choices=["sample_major", "leaf_major"],
                     help="leaf_major = a Julia column-major B x L matrix (the host language's native layout); "
@@ -266,6 +288,10 @@ def main():
     # default = config 3's 10^8 samples), and a leaf-major matrix whose column stride is a power of two aliases HBM
     # channels (measured: -3 % on the default workload, -14 % on sigma2).
     B = args.samples or DEFAULT_B.get(args.workload, 1_000_000)
+    t_probe = workloads.get(args.workload)
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    while not args.samples and 8 * B * (t_probe.n_leaf + t_probe.n_root) > 0.6 * free_b and B > 1_000_000:
+        B //= 2                         # (a 288 GB device holds config 3's 1e8 samples of 84 leaves, 70 GB, with room to spare)
     # per-rank Philox offset: results do not depend on how samples are sharded
     start, count = shard_range(B * world, rank, world)          # weak scaling: B samples per GPU
     assert count == B
@@ -278,7 +304,7 @@ def main():
     step = case.step
 
     step()
-    _ = root.sum(dim=0)                   # load the reduction used for the final observable now: a pause between the
+    _ = observable_sum(root)              # load the reduction used for the final observable now: a pause between the
     torch.cuda.synchronize()              # warm-up and the timed steps would let the clocks fall back
     # Clock settling: after idle the first ~50 launches run at transient clocks (boost, then throttle, then the
     # sustained state: 1.10 -> 1.40 -> 1.05-1.15 ms per launch on the default workload).  The timed steps are meant to
@@ -297,7 +323,7 @@ def main():
     for i in range(args.steps):
         step()
         ev[i + 1].record(stream)          # same stream the kernel is launched on
-    acc = root.sum(dim=0)                 # final observable accumulation
+    acc = observable_sum(root)            # final observable accumulation
     reduce_observable(acc, comm=comm)     # the one collective: R doubles over xGMI (RCCL)
     torch.cuda.synchronize()
     if dist:
@@ -369,7 +395,9 @@ def main():
         if rank == 0 and world == 1:
             sec = []
             head = (args.workload, args.layout)
-            for wl, lay in (("sigma2", "leaf_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "leaf_major"), ("gv_sigma5", "leaf_major"),
+            for wl, lay in (("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "leaf_major"),
+                            ("parquet_sigma4_insdyn", "leaf_major"), ("parquet_sigma4_taylor2", "leaf_major"),
+                            ("sigma2", "leaf_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "leaf_major"), ("gv_sigma5", "leaf_major"),
                             ("gv_sigma6", "leaf_major"), ("gv_sigma4_taylor2", "leaf_major"), ("gv_sigma4_taylor2", "sample_major")):
                 if (wl, lay) != head:
                     sec.append(secondary_case(wl, lay, dev, copy_gbs=copy_gbs))
@@ -378,7 +406,7 @@ def main():
                                      "launch stream); never part of `value`.  " + PARITY_NOTE)
     if rank == 0:
         if world == 1 and not args.no_mc_step and args.backend == "isa":
-            out["mc_step"] = mc_step(t, args.workload, B, dev, args.fast_math)
+            out["mc_step"] = mc_step(t, args.workload, min(B, 16_000_000), dev, args.fast_math)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
         dist.destroy_process_group()

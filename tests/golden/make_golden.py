@@ -45,6 +45,9 @@ def main():
     kat.append(dict(name="gv_sigma_all_ones", source="src/frontend/GV_diagrams/groups_sigma/Sigma{4,5,6}_0_0.diag: sum over diagrams of SymFactor*sum(SpinFactor), per external-tau group (tests/golden/make_gv_tables.py)",
                     leaf="ones", expect={"4": [21.0, 3.0], "5": [-31.0, -77.0], "6": [233.0, 167.0]},
                     note="computed from the catalog text, independent of the reader/optimizer restatements"))
+    kat.append(dict(name="parquet_sigma_diagram_counts", source="test/front_end.jl:600-652 with src/frontend/parquet/benchmark/diagram_count.jl:53-66 "
+                    "(spin 2, bosonic signs, filter [NoHartree, Girreducible]): all leaves 1 => (-1)^n * count_sigma_G2v(n, 2)",
+                    leaf="ones", expect={"1": -1.0, "2": 3.0, "3": -18.0, "4": 171.0}, note="exact (integers); tests/test_parquet.py"))
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(kat, f, indent=1, ensure_ascii=False)
     for name, B, seed in (("sigma2", 257, 1234), ("synthetic_small", 64, 1234), ("sigma4_standin", 16, 1234),
@@ -62,6 +65,20 @@ def main():
                             seed=np.int64(seed), leaf=leaf, root_static=root, root_interp=root_interp,
                             **({k: np.load(os.path.join(HERE, f"{name}.npz"))[k] for k in ("leaf_base", "leaf_dorder", "sched_group")}
                                if name.endswith("taylor2") else {}))
+        print(name, t.stats(), root[0])
+    # the 4-loop Parquet self-energy (configs 3 and 4) from the restated front end: tables built on the fly, the
+    # vectors pin the builder + optimize! + lowering + oracle chain against regressions
+    for name, B, seed in (("parquet_sigma4", 64, 1234), ("parquet_sigma4_taylor2", 32, 1234)):
+        t = workloads.get(name)
+        leaf = oracle.philox_uniform(B, t.n_leaf, seed)
+        root = oracle.eval_static(t, leaf)
+        assert np.array_equal(root, oracle.eval_static_numpy(t, leaf))
+        tn = t.normalized()
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), n_leaf=np.int64(tn.n_leaf), op=tn.op, power=tn.power,
+                            child_off=tn.child_off, child_idx=tn.child_idx, child_fac=tn.child_fac, root_slot=tn.root_slot,
+                            name=np.array(tn.name), leaf_pos=tn.leaf_positions().astype(np.uint32), seed=np.int64(seed), leaf=leaf,
+                            root_static=root, root_interp=oracle.eval_interp(t, leaf),
+                            **({} if tn.sched_group is None else {"sched_group": tn.sched_group}))
         print(name, t.stats(), root[0])
 
 

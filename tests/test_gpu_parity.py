@@ -40,7 +40,8 @@ def run(f, leaf):
 
 
 @pytest.mark.parametrize("spec", [False, True, "isa"], ids=["interp", "hipjit", "isa"])
-@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma5", "gv_sigma4_taylor2"])
+@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma5", "gv_sigma4_taylor2",
+                                  "parquet_sigma4", "parquet_sigma4_taylor2"])
 def test_golden_vectors_on_device(libfdg, cuda, name, spec):
     import torch
     z = np.load(os.path.join(GOLD, f"{name}.npz"))
@@ -61,7 +62,8 @@ def test_device_philox_matches_twin(libfdg, cuda):
 
 @pytest.mark.parametrize("spec", [False, True, "isa"], ids=["interp", "hipjit", "isa"])
 @pytest.mark.parametrize("layout", ["sample_major", "leaf_major", "padded"])
-@pytest.mark.parametrize("name,B", [("sigma2", 100003), ("synthetic_small", 5000), ("sigma4_standin", 1500), ("gv_sigma5", 3001)])
+@pytest.mark.parametrize("name,B", [("sigma2", 100003), ("synthetic_small", 5000), ("sigma4_standin", 1500), ("gv_sigma5", 3001),
+                                    ("parquet_sigma4", 20011), ("parquet_sigma4_insdyn", 1500)])
 def test_parity_layouts(libfdg, cuda, name, B, layout, spec):
     t = workloads.get(name)
     f = fd.compile_table(t, specialize=spec)
@@ -208,6 +210,42 @@ def test_config2_sigma2_ten_million_samples(libfdg, cuda):
     # the Julia-native layout (column-major B x L matrix) through the ISA kernel
     lt = leaf.t().contiguous().t()
     assert np.array_equal(run(fd.compile_table(t, specialize="isa"), lt), want)
+
+
+def test_config3_parquet_sigma4_at_full_size(libfdg, cuda):
+    """BASELINE.json config 3 as stated: the 4-loop Parquet self-energy (restated front end, tests/test_parquet.py), fp64,
+    10^8 samples resident on one GPU (70 GB), one launch.  No CPU oracle over the whole batch: a seeded spot check of
+    4000 scattered samples and of the last (ragged) tile against the oracle, bit for bit; chunk invariance (a sample's
+    roots do not depend on where it sits in a batch); determinism; and the interpreter kernel on a slice."""
+    import torch
+    t = workloads.get("parquet_sigma4")
+    B = 100_000_000 + 37
+    free_b, _ = torch.cuda.mem_get_info(cuda)
+    if 8 * B * (t.n_leaf + 2 * t.n_root) > 0.8 * free_b:
+        pytest.skip("needs 75 GB of device memory")
+    fs = fd.compile_table(t, specialize="isa")
+    leaf = dev_leaves(cuda, B, t.n_leaf, 1234, 0, "leaf_major")
+    root = fs(None, leaf)
+    torch.cuda.synchronize()
+    idx = np.sort(np.random.default_rng(1).choice(B, 4000, replace=False))
+    idx[-64:] = np.arange(B - 64, B)
+    sub = leaf[torch.from_numpy(idx).to(cuda)].cpu().numpy()
+    want = oracle.eval_static(t, sub)
+    assert np.array_equal(root[torch.from_numpy(idx).to(cuda)].cpu().numpy(), want)
+    again = fs(None, leaf)
+    torch.cuda.synchronize()
+    assert torch.equal(root, again)
+    del again
+    a = fs(None, leaf[71_234_567:71_234_567 + 300_001])
+    fi = fd.compile_table(t, specialize=False)
+    b = fi(None, leaf[5_000_000:5_000_000 + 100_003])
+    torch.cuda.synchronize()
+    assert torch.equal(a, root[71_234_567:71_234_567 + 300_001])
+    assert torch.equal(b, root[5_000_000:5_000_000 + 100_003])
+    # the leaf matrix is what the counter-based generator defines for these (sample, leaf) positions
+    probe = np.array([0, 1, 99_999_999, B - 1])
+    assert np.array_equal(leaf[torch.from_numpy(probe).to(cuda)].cpu().numpy(),
+                          np.stack([oracle.philox_uniform(1, t.n_leaf, 1234, int(i))[0] for i in probe]))
 
 
 def test_full_size_properties_sigma4(libfdg, cuda):
@@ -777,7 +815,8 @@ def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch):
     import torch
     from feynmandiagram_jl_amd.nodetable import NodeTable
     for name, z in (("gv_sigma4", dict(np.load(os.path.join(GOLD, "gv_sigma4_leafstates.npz")))), ("gv_sigma4_taylor2", _taylor2_tables()),
-                    ("gv_sigma5", dict(np.load(os.path.join(GOLD, "gv_sigma5_leafstates.npz"))))):
+                    ("gv_sigma5", dict(np.load(os.path.join(GOLD, "gv_sigma5_leafstates.npz")))),
+                    ("parquet_sigma4", workloads.leafstates("parquet_sigma4")), ("parquet_sigma4_taylor2", workloads.leafstates("parquet_sigma4_taylor2"))):
         t = workloads.get(name)
         L, R = t.n_leaf, t.n_root
         B, dim, n_loop, n_tau = (8_011 if name == "gv_sigma5" else 30_011), 3, int(z["basis"].shape[1]), int(z["n_tau"])

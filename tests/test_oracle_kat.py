@@ -70,7 +70,8 @@ def test_sigma2_fixture_all_ones():
     assert i[0].tolist() == [1.0, -1.0]
 
 
-@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma5", "gv_sigma4_taylor2"])
+@pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma5", "gv_sigma4_taylor2",
+                                  "parquet_sigma4", "parquet_sigma4_taylor2"])
 def test_golden_vectors(name):
     z = np.load(os.path.join(GOLD, f"{name}.npz"))
     t = NodeTable.load(os.path.join(GOLD, f"{name}.npz"))

@@ -1,0 +1,202 @@
+"""The restated Parquet front end (feynmandiagram.jl_amd/parquet.py), pinned by the reference's own tests of it
+(test/front_end.jl:120-700: parameters, partitions, index helpers, filters, the diagram counts of the self-energy, the
+validity of Green's functions), by the optimized 2-loop graph the reference renders in assets/sigma_o2.svg (SURVEY.md
+Appendix A) and by value invariance under ``optimize!``.  No GPU."""
+import numpy as np
+import pytest
+
+import oracle
+from feynmandiagram_jl_amd import fixtures, optimize, parquet as pq, workloads
+from feynmandiagram_jl_amd.graph import Graph
+from feynmandiagram_jl_amd.lowering import lower
+from feynmandiagram_jl_amd.parquet import (ChargeCharge, DiagPara, Dynamic, Girreducible, GreenDiag, Instant, Interaction, NoFock,
+                                           NoHartree, SigmaDiag, Ver4Diag, reconstruct)
+
+
+def all_ones(graphs):
+    t, _, _ = lower(list(graphs))
+    return oracle.eval_static(t, np.ones((1, t.n_leaf)))[0]
+
+
+# ---- test/front_end.jl:126-146 ------------------------------------------------------------------------------------
+def test_parameter_equality():
+    p = DiagPara(type=Ver4Diag, innerLoopNum=1)
+    q = DiagPara(type=Ver4Diag, innerLoopNum=2)
+    a = DiagPara(type=Ver4Diag, innerLoopNum=2)
+    assert p != q and q == a
+    assert a != reconstruct(a, transferLoop=(0.0, 0.0, 0.0))
+    assert a != reconstruct(a, interaction=())
+    # a reconstructed parameter keeps firstLoopIdx, totalLoopNum ... of the old type
+    assert reconstruct(a, type=SigmaDiag) != DiagPara(type=SigmaDiag, innerLoopNum=2)
+    # defaults of the keyword constructor (parquet.jl:104-125)
+    s = DiagPara(type=SigmaDiag, innerLoopNum=4)
+    assert (s.firstLoopIdx, s.totalLoopNum, s.firstTauIdx, s.totalTauNum) == (2, 5, 1, 4)
+    v = DiagPara(type=Ver4Diag, innerLoopNum=2, interaction=(Interaction(ChargeCharge, (Instant, Dynamic)),))
+    assert (v.firstLoopIdx, v.totalLoopNum, v.totalTauNum) == (4, 5, 6)
+
+
+# ---- test/front_end.jl:149-156 (compared as sets there too) ---------------------------------------------------------
+def test_ordered_partition():
+    as_set = lambda p: {tuple(x) for x in p}
+    assert as_set(pq.orderedPartition(5, 2)) == {(4, 1), (1, 4), (2, 3), (3, 2)}
+    assert as_set(pq.orderedPartition(3, 2, 0)) == {(3, 0), (0, 3), (1, 2), (2, 1)}
+    p = pq.orderedPartition(2, 4, 0)
+    assert len(p) == len(as_set(p)) == 10 and all(sum(x) == 2 for x in p)
+    assert pq.orderedPartition(0, 2, 0) == [[0, 0]]
+
+
+# ---- test/front_end.jl:158-183 ----------------------------------------------------------------------------------------
+def test_find_first_indices():
+    for partition, first, want in (([1, 1, 2, 1], 1, [1, 2, 3, 5]), ([1, 1, 2, 1], 0, [0, 1, 2, 4]), ([1, 0, 2, 0], 1, [1, 2, 2, 4]), ([1], 1, [1])):
+        idx, total = pq.findFirstLoopIdx(partition, first)
+        assert idx == want and total == sum(partition) + first - 1
+    kinds = [Ver4Diag, GreenDiag, Ver4Diag, GreenDiag]
+    assert pq.findFirstTauIdx([1, 1, 2, 1], kinds, 1, 1)[0] == [1, 3, 4, 7]
+    assert pq.findFirstTauIdx([1, 1, 2, 1], kinds, 0, 1)[0] == [0, 2, 3, 6]
+    assert pq.findFirstTauIdx([1, 0, 2, 0], kinds, 1, 1)[0] == [1, 3, 3, 6]
+
+
+# ---- test/front_end.jl:185-219 ----------------------------------------------------------------------------------------
+def test_filters():
+    assert pq.isValidG([Girreducible], 0) and not pq.isValidG([Girreducible], 1) and not pq.isValidG([Girreducible], 2)
+    assert pq.isValidG([NoFock], 0) and pq.isValidG([NoFock], 1)
+    assert not pq.isValidG([NoFock, NoHartree], 1) and pq.isValidG([NoFock, NoHartree], 2)
+    for n, sub, want in ((0, True, False), (1, True, False), (2, True, False), (0, False, False), (1, False, True), (2, False, True)):
+        assert pq.isValidSigma([Girreducible], n, sub) == want
+    assert not pq.isValidSigma([NoFock], 0, True)
+    assert pq.isValidSigma([NoFock], 1, True)
+    assert not pq.isValidSigma([NoFock, NoHartree], 1, True)
+    assert pq.isValidSigma([NoFock, NoHartree], 2, True)
+    assert not pq.isValidSigma([NoFock], 0, False)
+    assert pq.isValidSigma([NoFock], 1, False) and pq.isValidSigma([NoFock, NoHartree], 1, False) and pq.isValidSigma([NoFock], 2, False)
+
+
+# ---- test/front_end.jl:600-652: the number of self-energy diagrams of the G^2 v expansion ------------------------------
+@pytest.mark.parametrize("loops", [1, 2, 3, 4])
+def test_sigma_diagram_counts(loops):
+    para = DiagPara(type=SigmaDiag, hasTau=True, innerLoopNum=loops, totalLoopNum=loops + 1, totalTauNum=loops, isFermi=False, spin=2,
+                    firstLoopIdx=2, firstTauIdx=1, filter=(NoHartree, Girreducible), interaction=(Interaction(ChargeCharge, Instant),),
+                    extra=pq.ParquetBlocks(phi=(pq.PHEr, pq.PPr), ppi=(pq.PHr, pq.PHEr)))
+    extK = [1.0] + [0.0] * loops
+    rows = pq.sigma(para, extK, False)
+    merged = pq.mergeby([r["diagram"] for r in rows])           # `mergeby(diag)` of the test: one Sum over the rows
+    assert len(merged) == 1
+    num = all_ones(merged)[0]
+    want = {1: 1, 2: 3, 3: 18, 4: 171}[loops]                   # 1, 1 + spin, 4 + 5 spin + spin^2, 27 + 40 spin + 14 spin^2 + spin^3
+    assert pq.count_sigma_G2v(loops, 2) == want
+    assert num * (-1) ** loops == want
+    assert all(r["extT"][0] == para.firstTauIdx for r in rows)
+
+
+# ---- test/front_end.jl:654-699 ----------------------------------------------------------------------------------------
+def test_green_validity():
+    def buildG(loops, extT, filter):
+        para = DiagPara(type=GreenDiag, hasTau=True, innerLoopNum=loops, isFermi=True, spin=2, filter=filter,
+                        interaction=(Interaction(ChargeCharge, Instant),))
+        extK = [1.0] + [0.0] * (para.totalLoopNum - 1)
+        return pq.green(para, extK, extT) if pq.isValidG(para) else None
+
+    assert isinstance(buildG(0, (1, 2), (NoHartree, Girreducible)), Graph)
+    assert buildG(1, (1, 2), (NoHartree, Girreducible)) is None
+    assert buildG(2, (1, 2), (NoHartree, Girreducible)) is None
+    assert isinstance(buildG(0, (1, 2), (NoHartree, NoFock)), Graph)
+    assert buildG(1, (1, 2), (NoHartree, NoFock)) is None
+    assert isinstance(buildG(2, (1, 2), (NoHartree, NoFock)), Graph)
+
+
+# ---- README.md:55-72 + assets/sigma_o2.svg ------------------------------------------------------------------------------
+def _canonical(t):
+    """The node table up to the order of a node's operands: (op, power, sorted (child signature, factor)) per value."""
+    sig = {}
+    for i in range(t.n_leaf):
+        sig[i] = (-1, i, ())
+    for n in range(t.n_node):
+        lo, hi = int(t.child_off[n]), int(t.child_off[n + 1])
+        ch = sorted((repr(sig[int(t.child_idx[e])]), float(t.child_fac[e])) for e in range(lo, hi))
+        sig[t.n_leaf + n] = (int(t.op[n]), int(t.power[n]), tuple(ch))
+    return [sig[int(r)] for r in t.root_slot]
+
+
+def test_two_loop_self_energy_is_the_graph_of_the_reference_rendering():
+    """``Parquet.build(DiagPara(type=SigmaDiag, innerLoopNum=2, hasTau=true, filter=[NoHartree]))`` + ``optimize!``.
+    The rendering shows the graph after chains left behind by the merge of linear combinations were flattened as well
+    (a second ``optimize!``: 18 nodes; one pass leaves one unary node, 19); graphviz does not keep the order of a
+    node's operands, so the comparison is up to that order -- the leaf numbering, which the rendering prints
+    (G1..G8), is compared exactly."""
+    para = DiagPara(type=SigmaDiag, innerLoopNum=2, hasTau=True, filter=(NoHartree,))
+    rows = pq.build(para)
+    assert [(r["type"], r["extT"]) for r in rows] == [(Instant, (1, 1)), (Dynamic, (1, 2))]        # README.md:66-68
+    graphs = [r["diagram"] for r in rows]
+    before = all_ones(graphs)
+    optimize.optimize_(graphs)
+    once, _, _ = lower(graphs)
+    assert (once.n_leaf, once.n_node, once.n_root) == (8, 19, 2)
+    optimize.optimize_(graphs)
+    mine, leafmap, _ = lower(graphs)
+    ref, ref_leafmap, _ = lower(fixtures.sigma2_graphs()[0])
+    assert (mine.n_leaf, mine.n_node, mine.n_root) == (ref.n_leaf, ref.n_node, ref.n_root) == (8, 18, 2)
+    assert np.array_equal(mine.op, ref.op) and np.array_equal(mine.child_off, ref.child_off) and np.array_equal(mine.root_slot, ref.root_slot)
+    assert _canonical(mine) == _canonical(ref)
+    kinds = ["G" if type(leafmap[i + 1].properties).__name__ == "BareGreenId" else "V" for i in range(8)]
+    assert kinds == [ref_leafmap[i + 1].name for i in range(8)] == ["G", "G", "V", "G", "V", "V", "G", "G"]
+    assert list(before) == list(all_ones(graphs)) == [1.0, -1.0]
+    # the same workload as a named table
+    t = workloads.get("parquet_sigma2")
+    assert np.array_equal(t.child_idx, once.normalized().child_idx)
+
+
+@pytest.mark.parametrize("name, sizes", [("parquet_sigma3", (27, 156, 3)), ("parquet_sigma4", (84, 1325, 4)), ("parquet_sigma4_dyn", (175, 4819, 7)),
+                                         ("parquet_sigma4_insdyn", (312, 20147, 8)), ("parquet_sigma4_taylor2", (116, 7421, 12))])
+def test_four_loop_self_energy_tables(name, sizes):
+    t = workloads.get(name)
+    assert (t.n_leaf, t.n_node, t.n_root) == sizes
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0.5, 1.5, size=(3, t.n_leaf))
+    assert np.array_equal(oracle.eval_static(t, x), oracle.eval_interp(t, x)) or np.allclose(oracle.eval_static(t, x), oracle.eval_interp(t, x), rtol=1e-12)
+
+
+def test_optimize_keeps_the_value_of_the_four_loop_self_energy():
+    for types in ((Instant,), (Dynamic,), (Instant, Dynamic)):
+        para = DiagPara(type=SigmaDiag, innerLoopNum=4, hasTau=True, filter=(NoHartree,), interaction=(Interaction(ChargeCharge, types),))
+        rows = pq.build(para)
+        assert all(r["extT"][0] == 1 for r in rows)
+        graphs = [r["diagram"] for r in rows]
+        raw, lm_raw, _ = lower(graphs)
+        # leaves with equal identities get equal values, as they do after the merge of duplicated leaves
+        rng = np.random.default_rng(9)
+        val = {}
+        x = np.array([[val.setdefault(lm_raw[i + 1].properties.equiv_key(), rng.uniform(0.5, 1.5)) for i in range(raw.n_leaf)]])
+        want = oracle.eval_static(raw, x)[0]
+        optimize.optimize_(graphs)
+        opt, lm, _ = lower(graphs)
+        assert opt.n_leaf == len(val)
+        y = np.array([[val[lm[i + 1].properties.equiv_key()] for i in range(opt.n_leaf)]])
+        got = oracle.eval_static(opt, y)[0]
+        assert np.allclose(got, want, rtol=1e-11, atol=0)
+
+
+def test_taylor_expansion_of_the_parquet_self_energy_satisfies_the_series_identity():
+    """Config 4 on the real graph: f(V0 + x V1 + x^2 V2) = c0 + x c1 + x^2 c2 + O(x^3), checked independently of the
+    Taylor restatement (as tests/golden/make_gv_tables.py does for the GV graphs)."""
+    from feynmandiagram_jl_amd import gv, taylor
+    graphs, rows = workloads.parquet_graphs("parquet_sigma3")
+    t0, lm0, _ = lower(graphs)
+    d = taylor.taylorAD(graphs, [2], [lambda pr: isinstance(pr, gv.BareInteractionId)])
+    allg = [g for o in sorted(d) for g in d[o]]
+    optimize.optimize_(allg)
+    t, lm, _ = lower(allg)
+    R = len(rows)
+    assert t.n_root == 3 * R
+    key0 = {lm0[i + 1].properties.equiv_key(): i for i in range(t0.n_leaf)}
+    base = [key0[lm[i + 1].properties.equiv_key()] for i in range(t.n_leaf)]
+    dord = [int(lm[i + 1].orders[0]) if len(lm[i + 1].orders) == 1 else 0 for i in range(t.n_leaf)]
+    rng = np.random.default_rng(3)
+    v = rng.uniform(0.5, 1.5, size=(3, t0.n_leaf))
+    is_v = np.array([isinstance(lm0[i + 1].properties, gv.BareInteractionId) for i in range(t0.n_leaf)])
+    x = 1e-3
+    f_x = oracle.eval_static(t0, (v[0] + np.where(is_v, x * v[1] + x * x * v[2], 0.0))[None, :])[0]
+    c = oracle.eval_static(t, np.array([[v[dord[i], base[i]] for i in range(t.n_leaf)]]))[0].reshape(3, R)
+    series = c[0] + x * c[1] + x * x * c[2]
+    scale = np.abs(c).sum(axis=0) + 1.0
+    assert np.all(np.abs(series - f_x) <= 1e-7 * scale)
+    assert np.all(np.abs(c[0] + x * c[1] - f_x) >= np.abs(series - f_x))

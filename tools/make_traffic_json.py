@@ -7,7 +7,12 @@ import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root, out_path = sys.argv[1], sys.argv[2]
 SAMPLES = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "gv_sigma4": 8_000_000, "gv_sigma5": 2_000_000, "gv_sigma6": 500_000,
-           "gv_sigma4_taylor2": 4_000_000}
+           "gv_sigma4_taylor2": 4_000_000, "parquet_sigma4": 100_000_000, "parquet_sigma4_dyn": 8_000_000, "parquet_sigma4_insdyn": 4_000_000,
+           "parquet_sigma4_taylor2": 8_000_000}
+if os.path.exists(out_path):          # keep the entries of earlier profile sets: only the workloads found under `root` are replaced
+    prev = json.load(open(out_path))
+else:
+    prev = {}
 out = {"_comment": "HBM-side traffic of the evaluator kernel from separate rocprofv3 --pmc passes (tools/prof_r02.sh; summaries in "
                    "profiles/r02_pmc_*.txt): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; factor 2 = the guide's gfx950 FETCH_SIZE "
                    "correction, calibrated on sigma2 (80 B per evaluation).  Infinity-Cache hits are included in FETCH_SIZE: this is "
@@ -34,5 +39,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     key = wl if lay == "leaf_major" else wl + ":" + lay
     out[key] = {"layout": lay, "samples": B, "kernels": kernels, "fetch_kib": fetch, "write_kib": write,
                 "bytes_per_eval": round((2 * fetch + write) * 1024 / B, 1), "source": f"profiles/r02_pmc_{wl}_{lay}.txt"}
+for k, v in prev.items():
+    out.setdefault(k, v)
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps(out, indent=1))

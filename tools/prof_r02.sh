@@ -15,7 +15,9 @@ python $R/tools/rocpd_stats.py --last=100 $(find "$OUT/trace_headline" -name "*.
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t -- python $R/bench.py --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/trace.log"
 python $R/tools/rocpd_stats.py $(find "$OUT/trace" -name "*.db") > "$OUT/kernel_stats.txt" 2>&1
 [ "${PROF_TRACE_ONLY:-0}" = 1 ] && { cat "$OUT/kernel_stats_headline.txt" "$OUT/kernel_stats.txt"; exit 0; }
-for spec in "gv_sigma4_taylor2 leaf_major" "gv_sigma4_taylor2 sample_major" "sigma4_standin leaf_major" "gv_sigma5 leaf_major" "gv_sigma6 leaf_major" "gv_sigma4 leaf_major" "sigma2 leaf_major"; do
+SPECS=("parquet_sigma4 leaf_major" "parquet_sigma4 sample_major" "parquet_sigma4_dyn leaf_major" "parquet_sigma4_insdyn leaf_major" "parquet_sigma4_taylor2 leaf_major")
+[ "${PROF_PARQUET_ONLY:-0}" = 1 ] || SPECS+=("gv_sigma4_taylor2 leaf_major" "gv_sigma4_taylor2 sample_major" "sigma4_standin leaf_major" "gv_sigma5 leaf_major" "gv_sigma6 leaf_major" "gv_sigma4 leaf_major" "sigma2 leaf_major")
+for spec in "${SPECS[@]}"; do
   set -- $spec
   W=$1; LAY=$2
   i=0
