@@ -4,8 +4,8 @@ measured on the *real* 4-loop Parquet self-energy rather than on a stand-in.
 
 Reference: src/frontend/parquet/parquet.jl:57-143 (Interaction, ParquetBlocks, DiagPara), common.jl (build,
 orderedPartition, index helpers), filter.jl (notProper, isValidG, isValidSigma), operation.jl:1-176 (mergeby),
-vertex4.jl (vertex4, bubble!, bubble2diag!, RPA_chain!, bareVer4, legBasis, tauBasis), sigma.jl, green.jl;
-ids: src/frontend/diagram_id.jl.
+vertex4.jl (vertex4, bubble!, bubble2diag!, RPA_chain!, bareVer4, legBasis, tauBasis), sigma.jl, green.jl,
+vertex3.jl, polarization.jl; ids: src/frontend/diagram_id.jl.
 
 What is reproduced, and what cannot be.  The *graph* -- nodes, operators, factors, leaves and their identities (so the
 leaf merging of ``optimize!``), the loop-momentum and time indices -- follows the reference line by line.  Two places of
@@ -14,12 +14,14 @@ the reference iterate a hash container, whose order depends on the Julia version
 ``Dict{Any,Any}`` in ``bubble!``.  They decide in which order the terms of some Sums are listed, i.e. the
 floating-point association of those Sums, not the graph; here the first uses the order in which Combinatorics.jl yields
 the permutations and the second insertion order.  Pinned by: the optimized 2-loop graph of assets/sigma_o2.svg
- reproduced statement for statement, and the diagram counts 1, 3, 18, 171 of
-test/front_end.jl:600-652.
+ reproduced up to the order of operands, and the diagram counts of the reference's own tests: the
+self-energy (1, 3, 18, 171; test/front_end.jl:600-652), the 3-point vertex (1, 10, 109; :701-755) and the polarization
+in three variants (2, 2, 20, 218 / 2, 2, 32, 326 / 2, 2, 28, 274; :758-826) -- the last two exercise ``vertex4`` with
+all three channels at the top level.
 
 Not restated: the fully irreducible vertex ``Alli`` at 3 and 4 loops (read from the GV vertex catalogs,
-vertex4.jl:112-120) -- the self-energy up to 4 loops never reaches it (its sub-vertices have at most 2 loops);
-vertex3 / polarization / ep_coupling.
+vertex4.jl:112-120) -- the self-energy and the polarization up to 4 loops never reach it (their sub-vertices have at
+most 2 loops); ep_coupling.
 """
 from __future__ import annotations
 
@@ -29,9 +31,9 @@ from dataclasses import dataclass, field, replace
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 from .graph import Graph, Prod, Sum
-from .gv import BareGreenId, BareInteractionId, GenericId, SigmaId, _Id
+from .gv import BareGreenId, BareInteractionId, GenericId, PolarId, SigmaId, _Id
 
-__all__ = ["DiagPara", "Interaction", "ParquetBlocks", "build", "sigma", "vertex4", "green", "orderedPartition",
+__all__ = ["DiagPara", "Interaction", "ParquetBlocks", "build", "sigma", "vertex4", "vertex3", "polarization", "green", "orderedPartition",
            "findFirstLoopIdx", "findFirstTauIdx", "isValidG", "isValidSigma", "mergeby", "count_sigma_G2v"]
 
 # enums (frontends.jl:9-47, parquet.jl:43-54); the integer is the enum's value, which DataFrames sorts groups by
@@ -265,6 +267,15 @@ class GreenId(_Id):
 
     def equiv_key(self):
         return ("Green", self.para, self.type, self.extK, self.extT)
+
+
+class Ver3Id(_Id):
+    def __init__(self, para, response: str, *, k, t=(0, 0, 0)):
+        self.para, self.response = para, response
+        self.extK, self.extT = tuple(tuple(float(x) for x in kk) for kk in k), tuple(t)
+
+    def equiv_key(self):
+        return ("Ver3", self.para, self.response, self.extK, self.extT)
 
 
 class Ver4Id(_Id):
@@ -673,13 +684,143 @@ def sigma(para: DiagPara, extK=None, subdiagram: bool = False, *, name: str = "S
     return out
 
 
+# --- vertex3.jl -------------------------------------------------------------------------------------------------------------
+def vertex3(para: DiagPara, _extK=None, subdiagram: bool = False, *, name: str = "Gamma3", channels=(PHr, PHEr, PPr, Alli),
+            blocks: Optional[ParquetBlocks] = None) -> List[Row]:
+    """vertex3.jl:21-112: Gamma3 = G_in G_out Gamma4.  Rows ``{response, extT, diagram, hash}``."""
+    blocks = blocks or ParquetBlocks()
+    if _extK is None:
+        _extK = [getK(para.totalLoopNum, 1), getK(para.totalLoopNum, 2)]
+    assert para.type == Ver3Diag and para.innerLoopNum >= 1
+    for k in _extK:
+        assert len(k) >= para.totalLoopNum
+    q, Kin = list(_extK[0][:para.totalLoopNum]), list(_extK[1][:para.totalLoopNum])
+    Kout = _vadd(Kin, q, 1.0, -1.0)
+    assert not _isapprox_vec(q, Kin) and not _isapprox_vec(q, Kout)
+    extK = [q, Kin, Kout]
+    if Proper in para.filter and (len(para.transferLoop) != len(q) or not _isapprox_vec(para.transferLoop, q)):   # _properVer3Para
+        para = reconstruct(para, transferLoop=tuple(q))
+    t0 = para.firstTauIdx
+    out: List[Row] = []
+    LoopIdx = para.firstLoopIdx
+    K = [0.0] * len(q)
+    K[LoopIdx - 1] = 1.0
+    Kq = _vadd(K, q)
+    legK = [Kin, Kout, K, Kq]
+    for oVer4, oGin, oGout in orderedPartition(para.innerLoopNum - 1, 3, 0):
+        idx, maxLoop = findFirstLoopIdx([oVer4, oGin, oGout], LoopIdx + 1)
+        assert maxLoop <= para.totalLoopNum
+        Ver4Kidx, GinKidx, GoutKidx = idx
+        ver4t0 = para.firstTauIdx + 1 if para.hasTau else para.firstTauIdx
+        idx, maxTau = findFirstTauIdx([oVer4, oGin, oGout], [Ver4Diag, GreenDiag, GreenDiag], ver4t0, _interactionTauNum(para))
+        assert maxTau <= para.totalTauNum
+        Ver4Tidx, GinTidx, GoutTidx = idx
+        if not (isValidG(para.filter, oGin) and isValidG(para.filter, oGout)):
+            continue
+        paraGin = reconstruct(para, type=GreenDiag, innerLoopNum=oGin, firstLoopIdx=GinKidx, firstTauIdx=GinTidx)
+        paraGout = reconstruct(para, type=GreenDiag, innerLoopNum=oGout, firstLoopIdx=GoutKidx, firstTauIdx=GoutTidx)
+        paraVer4 = reconstruct(para, type=Ver4Diag, innerLoopNum=oVer4, firstLoopIdx=Ver4Kidx, firstTauIdx=Ver4Tidx)
+        ver4 = vertex4(paraVer4, legK, True, channels=channels, blocks=blocks)
+        if not ver4:
+            continue
+        if para.hasTau:
+            assert all(r["extT"][INL] == ver4t0 for r in ver4)
+        df = [dict(r, extT=(t0, r["extT"][INL], r["extT"][OUTL]), GinT=(t0, r["extT"][INR]), GoutT=(r["extT"][OUTR], t0)) for r in ver4]
+        for v4 in mergeby(df, ["response", "GinT", "GoutT", "extT"], operator=Sum()):
+            response = v4["response"]
+            assert response in (UpUp, UpDown)
+            gin = green(paraGin, K, v4["GinT"], True, name="Gin", blocks=blocks)
+            gout = green(paraGout, Kq, v4["GoutT"], True, name="Gout", blocks=blocks)
+            d = Graph([gin, gout, v4["diagram"]], properties=Ver3Id(para, response, k=extK, t=v4["extT"]), operator=Prod(), name=name)
+            out.append(dict(response=response, extT=v4["extT"], diagram=d))
+    if out:
+        out = mergeby(out, ["response", "extT"], name=name, getid=lambda g: Ver3Id(para, g[0]["response"], k=extK, t=g[0]["extT"]))
+    return out
+
+
+# --- polarization.jl --------------------------------------------------------------------------------------------------------
+def polarization(para: DiagPara, extK=None, subdiagram: bool = False, *, name: str = "Pi",
+                 blocks: Optional[ParquetBlocks] = None) -> List[Row]:
+    """polarization.jl:17-127: Pi = -G G (the bare bubble) + G G Gamma3.  Rows ``{response, extT, diagram, hash}``."""
+    blocks = blocks or ParquetBlocks()
+    extK = list(extK if extK is not None else getK(para.totalLoopNum, 1))
+    assert para.type == PolarDiag and para.innerLoopNum >= 1 and len(extK) >= para.totalLoopNum
+    if Proper not in para.filter or len(para.transferLoop) != len(extK) or _isapprox_vec(para.transferLoop, extK):   # _properPolarPara
+        para = reconstruct(para, transferLoop=tuple(extK), filter=(Proper,) + tuple(f for f in para.filter if f != Proper))
+    extK = extK[:para.totalLoopNum]
+    LoopIdx = para.firstLoopIdx
+    K = [0.0] * len(extK)
+    K[LoopIdx - 1] = 1.0
+    assert not _isapprox_vec(K, extK)
+    t0 = para.firstTauIdx
+    extT = (t0, t0 + 1) if para.hasTau else (t0, t0)
+    KmQ = _vadd(K, extK, 1.0, -1.0)
+    legK = [extK, K, KmQ]
+    polar: List[Row] = []
+    for oVer3, oGin, oGout in orderedPartition(para.innerLoopNum - 1, 3, 0):
+        idx, maxLoop = findFirstLoopIdx([oVer3, oGin, oGout], LoopIdx + 1)
+        assert maxLoop <= para.totalLoopNum
+        Ver3Kidx, GinKidx, GoutKidx = idx
+        if not (isValidG(para.filter, oGin) and isValidG(para.filter, oGout)):
+            continue
+        if oVer3 == 0:                                    # Pi0 = G G
+            gt0 = extT[1] + 1 if para.hasTau else extT[0]
+            idx, maxTau = findFirstTauIdx([oGin, oGout], [GreenDiag, GreenDiag], gt0, _interactionTauNum(para))
+            assert maxTau <= para.totalTauNum
+            GinTidx, GoutTidx = idx
+            paraGin = reconstruct(para, type=GreenDiag, innerLoopNum=oGin, firstLoopIdx=GinKidx, firstTauIdx=GinTidx)
+            paraGout = reconstruct(para, type=GreenDiag, innerLoopNum=oGout, firstLoopIdx=GoutKidx, firstTauIdx=GoutTidx)
+            gin = green(paraGin, K, (extT[0], extT[1]), True, name="Gin")
+            gout = green(paraGout, KmQ, (extT[1], extT[0]), True, name="Gout")
+            d = Graph.new([gin, gout], properties=PolarId(para, UpUp, k=extK, t=extT), operator=Prod(), name=name,
+                          factor=-1.0 if para.isFermi else 1.0)
+            polar.append(dict(response=UpUp, extT=extT, diagram=d))
+        else:                                             # composite polarization
+            idx, maxTau = findFirstTauIdx([oVer3, oGin, oGout], [Ver3Diag, GreenDiag, GreenDiag], extT[1], _interactionTauNum(para))
+            assert maxTau <= para.totalTauNum
+            Ver3Tidx, GinTidx, GoutTidx = idx
+            paraGin = reconstruct(para, type=GreenDiag, innerLoopNum=oGin, firstLoopIdx=GinKidx, firstTauIdx=GinTidx)
+            paraGout = reconstruct(para, type=GreenDiag, innerLoopNum=oGout, firstLoopIdx=GoutKidx, firstTauIdx=GoutTidx)
+            paraVer3 = reconstruct(para, type=Ver3Diag, innerLoopNum=oVer3, firstLoopIdx=Ver3Kidx, firstTauIdx=Ver3Tidx)
+            ver3 = vertex3(paraVer3, legK, True, blocks=blocks)
+            if not ver3:
+                continue
+            if para.hasTau:
+                assert all(r["extT"][0] == extT[1] for r in ver3) and all(r["extT"][1] == ver3[0]["extT"][1] for r in ver3)
+            df = [dict(r, extT=extT, GinT=(extT[0], r["extT"][1]), GoutT=(r["extT"][2], extT[0])) for r in ver3]
+            for v3 in mergeby(df, ["response", "GinT", "GoutT", "extT"], operator=Sum()):
+                response = v3["response"]
+                assert response in (UpUp, UpDown)
+                gin = green(paraGin, K, v3["GinT"], True, name="Gin", blocks=blocks)
+                gout = green(paraGout, KmQ, v3["GoutT"], True, name="Gout", blocks=blocks)
+                d = Graph([gin, gout, v3["diagram"]], properties=PolarId(para, response, k=extK, t=v3["extT"]), operator=Prod(), name=name)
+                polar.append(dict(response=response, extT=v3["extT"], diagram=d))
+    if polar:
+        polar = mergeby(polar, ["response", "extT"], name=name, getid=lambda g: PolarId(para, g[0]["response"], k=extK, t=extT))
+    return polar
+
+
 def build(para: DiagPara, extK=None, subdiagram: bool = False, *, channels=(PHr, PHEr, PPr, Alli)) -> List[Row]:
     """common.jl:1-28."""
     if para.type == Ver4Diag:
         return vertex4(para, extK, subdiagram, channels=channels)
     if para.type == SigmaDiag:
         return sigma(para, extK if extK is not None else getK(para.totalLoopNum, 1), subdiagram)
+    if para.type == PolarDiag:
+        return polarization(para, extK if extK is not None else getK(para.totalLoopNum, 1), subdiagram)
+    if para.type == Ver3Diag:
+        return vertex3(para, extK if extK is not None else [getK(para.totalLoopNum, 1), getK(para.totalLoopNum, 2)], subdiagram, channels=channels)
     raise NotImplementedError("not implemented!")
+
+
+def count_ver3_G2v(innerLoopNum: int, spin: int) -> int:
+    """benchmark/diagram_count.jl:23-36."""
+    return {0: 1, 1: 1, 2: 4 + 3 * spin, 3: 27 + 31 * spin + 5 * spin ** 2}[innerLoopNum]
+
+
+def count_polar_G2v(innerLoopNum: int, spin: int) -> int:
+    """benchmark/diagram_count.jl:73-76."""
+    return spin * count_ver3_G2v(innerLoopNum - 1, spin)
 
 
 def count_sigma_G2v(innerLoopNum: int, spin: int) -> int:

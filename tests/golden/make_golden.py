@@ -48,6 +48,11 @@ def main():
     kat.append(dict(name="parquet_sigma_diagram_counts", source="test/front_end.jl:600-652 with src/frontend/parquet/benchmark/diagram_count.jl:53-66 "
                     "(spin 2, bosonic signs, filter [NoHartree, Girreducible]): all leaves 1 => (-1)^n * count_sigma_G2v(n, 2)",
                     leaf="ones", expect={"1": -1.0, "2": 3.0, "3": -18.0, "4": 171.0}, note="exact (integers); tests/test_parquet.py"))
+    kat.append(dict(name="parquet_vertex3_and_polarization_diagram_counts", source="test/front_end.jl:701-755 (count_ver3_G2v), :758-826 "
+                    "(count_polar_G2v, count_polar_g2v_noFock, count_polar_g2v_noFock_upup); src/frontend/parquet/benchmark/diagram_count.jl",
+                    leaf="ones", expect={"ver3_G2v": [1, 10, 109], "polar_G2v": [2, 2, 20, 218], "polar_g2v_noFock": [2, 2, 32, 326],
+                                         "polar_g2v_noFock_upup": [2, 2, 28, 274]},
+                    note="num * (-1)^n resp. num * spin * (-1)^(n-1); exact; tests/test_parquet.py"))
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(kat, f, indent=1, ensure_ascii=False)
     for name, B, seed in (("sigma2", 257, 1234), ("synthetic_small", 64, 1234), ("sigma4_standin", 16, 1234),

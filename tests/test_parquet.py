@@ -88,6 +88,38 @@ def test_sigma_diagram_counts(loops):
     assert all(r["extT"][0] == para.firstTauIdx for r in rows)
 
 
+# ---- test/front_end.jl:701-755: the 3-point vertex; :758-826: the polarization (three variants) -------------------------
+@pytest.mark.parametrize("loops", [1, 2, 3])
+def test_vertex3_diagram_counts(loops):
+    para = DiagPara(type=pq.Ver3Diag, innerLoopNum=loops, isFermi=False, hasTau=True, filter=(NoHartree, Girreducible, pq.Proper),
+                    interaction=(Interaction(ChargeCharge, Instant),))
+    Q, KinL = [0.0] * para.totalLoopNum, [0.0] * para.totalLoopNum
+    Q[0], KinL[1] = 1.0, 1.0
+    rows = pq.vertex3(para, [Q, KinL])
+    num = all_ones([pq.mergeby(rows)[0]["diagram"]])[0]
+    assert num * (-1) ** loops == pq.count_ver3_G2v(loops, 2) == {1: 1, 2: 10, 3: 109}[loops]
+
+
+@pytest.mark.parametrize("loops", [1, 2, 3, 4])
+def test_polarization_diagram_counts(loops):
+    def polar(filter):
+        para = DiagPara(type=pq.PolarDiag, innerLoopNum=loops, isFermi=False, hasTau=True, filter=filter, interaction=(Interaction(ChargeCharge, Instant),))
+        Q = [1.0] + [0.0] * (para.totalLoopNum - 1)
+        return para, pq.polarization(para, Q)
+
+    sign = 2 * (-1) ** (loops - 1)                       # num * spin * (-1)^(n-1)
+    para, rows = polar((NoHartree, Girreducible))        # G^2 v expansion
+    assert all_ones([pq.mergeby(rows)[0]["diagram"]])[0] * sign == pq.count_polar_G2v(loops, 2) == {1: 2, 2: 2, 3: 20, 4: 218}[loops]
+    para, rows = polar((NoHartree, NoFock))              # g^2 v expansion: Green's functions carry self-energy insertions
+    assert all_ones([pq.mergeby(rows)[0]["diagram"]])[0] * sign == {1: 2, 2: 2, 3: 32, 4: 326}[loops]
+    assert rows[0]["response"] == pq.UpUp
+    assert all_ones([rows[0]["diagram"]])[0] * sign == {1: 2, 2: 2, 3: 28, 4: 274}[loops]        # <n_up n_up> alone
+    assert all(r["extT"] == (para.firstTauIdx, para.firstTauIdx + 1) for r in rows)
+    # a parameter that names Proper explicitly builds as well (test/front_end.jl:785)
+    if loops == 1:
+        assert len(polar((pq.Proper, NoHartree, NoFock))[1]) == 1
+
+
 # ---- test/front_end.jl:654-699 ----------------------------------------------------------------------------------------
 def test_green_validity():
     def buildG(loops, extT, filter):
