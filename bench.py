@@ -37,12 +37,16 @@ WORKLOAD_NOTES = {
     "parquet_sigma4_insdyn": " (config 3 with an Instant + Dynamic interaction: 20147 nodes)",
     "parquet_sigma4_taylor2": " (config 4: the 4-loop Parquet self-energy with Taylor-mode AD counterterms of order 2 in the coupling, restated taylorAD + optimize!: 7421 nodes, 12 roots)",
     "parquet_sigma2": " (configs 1-2 from the restated Parquet front end, one optimize! pass: 19 nodes)",
+    "parquet_sigma5": " (the 5-loop Parquet self-energy: 11407 nodes; its sub-vertices use the fully irreducible vertex of the reference's GV catalogs)",
+    "parquet_ver4_4": " (the graph example/benchmark.jl builds: Parquet.vertex4(DiagPara(type=Ver4Diag, innerLoopNum=4)) + optimize!, 44854 nodes, 180 roots)",
+    "gv_ver4_4": " (the graph example/benchmark_GV.jl:23 builds: GV.diagsGV_ver4(4) + optimize!, catalog Vertex44_0_0.diag, 31803 nodes, 26 roots)",
 }
 DEFAULT_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcase": 1_000_000, "synthetic_small": 8_000_000,
              "gv_sigma4": 8_000_000, "gv_sigma5": 2_000_000, "gv_sigma6": 500_000, "gv_sigma4_taylor2": 4_000_000,
              "gv_sigma5_taylor2": 1_000_000, "parquet_sigma2": 64_000_000, "parquet_sigma3": 16_000_000, "parquet_sigma4": 100_000_000,
              "parquet_sigma4_dyn": 8_000_000, "parquet_sigma4_insdyn": 4_000_000, "parquet_sigma4_taylor2": 8_000_000,
-             "parquet_sigma4_dyn_taylor2": 2_000_000, "parquet_sigma4_insdyn_taylor2": 1_000_000}
+             "parquet_sigma4_dyn_taylor2": 2_000_000, "parquet_sigma4_insdyn_taylor2": 1_000_000, "parquet_sigma5": 2_000_000,
+             "parquet_ver4_4": 500_000, "gv_ver4_4": 500_000}
 PARITY_NOTE = ("bit-exact vs our restatement of the Julia evaluator (oracle/); the reference's known-answer tests pin structure, "
                "leaf numbering and factors, not the rounding of the n-ary folds")
 
@@ -396,8 +400,8 @@ def main():
             sec = []
             head = (args.workload, args.layout)
             for wl, lay in (("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "leaf_major"),
-                            ("parquet_sigma4_insdyn", "leaf_major"), ("parquet_sigma4_taylor2", "leaf_major"),
-                            ("sigma2", "leaf_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "leaf_major"), ("gv_sigma5", "leaf_major"),
+                            ("parquet_sigma4_insdyn", "leaf_major"), ("parquet_sigma4_taylor2", "leaf_major"), ("parquet_sigma5", "leaf_major"),
+                            ("parquet_ver4_4", "leaf_major"), ("gv_ver4_4", "leaf_major"), ("sigma2", "leaf_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "leaf_major"), ("gv_sigma5", "leaf_major"),
                             ("gv_sigma6", "leaf_major"), ("gv_sigma4_taylor2", "leaf_major"), ("gv_sigma4_taylor2", "sample_major")):
                 if (wl, lay) != head:
                     sec.append(secondary_case(wl, lay, dev, copy_gbs=copy_gbs))

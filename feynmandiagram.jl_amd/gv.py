@@ -17,7 +17,8 @@ from typing import List, Optional, Sequence, Tuple
 
 from .graph import Graph, Prod, Sum, linear_combination, multi_product
 
-__all__ = ["read_diagrams", "diagsGV", "BareGreenId", "BareInteractionId", "SigmaId", "PolarId", "GenericId"]
+__all__ = ["read_diagrams", "diagsGV", "read_vertex4diagrams", "diagsGV_ver4", "parse_vertex4_catalog", "BareGreenId", "BareInteractionId",
+           "SigmaId", "PolarId", "GenericId", "Ver4Id"]
 
 _INT = re.compile(r"[-+]?\d+")
 
@@ -50,8 +51,8 @@ class _Id:
 class BareGreenId(_Id):
     """diagram_id.jl:19-33: equality on (type, extT, extK)."""
 
-    def __init__(self, k, t, type: str = "Dynamic"):
-        self.type, self.extK, self.extT = type, mirror_symmetrize(k), tuple(t)
+    def __init__(self, k, t, type: str = "Dynamic", symmetrize: bool = True):
+        self.type, self.extK, self.extT = type, (mirror_symmetrize(k) if symmetrize else tuple(float(x) for x in k)), tuple(t)
 
     def equiv_key(self):
         return ("G", self.type, self.extT, self.extK)
@@ -60,8 +61,9 @@ class BareGreenId(_Id):
 class BareInteractionId(_Id):
     """diagram_id.jl:35-69: all equal-time extT pairs compare equal."""
 
-    def __init__(self, response: str, k, t=(0, 0), type: str = "Instant"):
-        self.response, self.type, self.extK, self.extT = response, type, mirror_symmetrize(k), tuple(t)
+    def __init__(self, response: str, k, t=(0, 0), type: str = "Instant", symmetrize: bool = True):
+        self.response, self.type, self.extT = response, type, tuple(t)
+        self.extK = mirror_symmetrize(k) if symmetrize else tuple(float(x) for x in k)
 
     def equiv_key(self):
         t = "equal-time" if self.extT[0] == self.extT[1] else self.extT
@@ -91,6 +93,18 @@ class GenericId(_Id):
 
     def equiv_key(self):
         return ("Generic", self.para, self.extra)
+
+
+class Ver4Id(_Id):
+    """diagram_id.jl:166-185.  ``para`` is a ``DiagPara`` for Parquet-built vertices and the pair (Di/Ex, innerLoopNum)
+    for the ones read from a GV catalog (readfile.jl:397-398)."""
+
+    def __init__(self, para, response: str, type: str = "Dynamic", *, k, t=(0, 0, 0, 0), chan: str = "AnyChan"):
+        self.para, self.response, self.type, self.channel = para, response, type, chan
+        self.extK, self.extT = tuple(tuple(float(x) for x in kk) for kk in k), tuple(t)
+
+    def equiv_key(self):
+        return ("Ver4", self.para, self.response, self.type, self.channel, self.extK, self.extT)
 
 
 def _exchange(perm: List[int], legs: List[List[int]], index: int, ext_num: int, offset_ver4: int):
@@ -259,3 +273,180 @@ def diagsGV(diag_type: str, order: int, root_dir: str, spinPolarPara: float = 0.
         raise ValueError(f"no support for {diag_type} diagram")
     d, stem = sub[diag_type]
     return read_diagrams(f"{root_dir}/{d}/{stem}{order}_0_0.diag", diag_type, spinPolarPara)
+
+
+# --- the 4-point vertex catalogs (groups_vertex4/Vertex4<n>_0_0.diag, Vertex4I<n>_0_0.diag) ---------------------------------
+_KEYWORDS_VER4 = ["Vertex4", "DiagNum", "Order", "GNum", "Ver4Num", "LoopNum", "ExtLoopIndex", "DummyLoopIndex", "TauNum", "DummyTauIndex"]
+
+
+def parse_vertex4_catalog(filename: str) -> dict:
+    """The numbers of a vertex catalog as arrays (header: readfile.jl:191-218; blocks: :267-333): ``GNum, verNum, loopNum``
+    and, per Hugenholtz diagram, ``permutation`` (0-based as in the file), ``symfactor``, ``channel``, ``gtype``, ``tau`` (first
+    VertexBasis row), ``loopbasis [loopNum][GNum]``, ``ver4legs``, ``spin``, ``diex``, ``proper``.  This is the form the
+    package ships the two fully-irreducible catalogs in (data/vertex4I<n>.npz): data of the reference, not its text."""
+    import numpy as np
+    with open(filename) as f:
+        lines = f.read().split("\n")
+    diagNum, loopNum, verNum, GNum = 1, 1, 0, 2
+    pos = 0
+    for kw in _KEYWORDS_VER4:
+        line = lines[pos]
+        if len(line) == 0:
+            break
+        v = _ints(line)
+        if kw == "DiagNum":
+            diagNum = v[0]
+        elif kw == "GNum":
+            GNum = v[0]
+        elif kw == "Ver4Num":
+            verNum = v[1]
+        elif kw == "LoopNum":
+            loopNum = v[0]
+        pos += 1
+    assert lines[pos] == ""
+    pos += 1
+    out = dict(GNum=GNum, verNum=verNum, loopNum=loopNum, permutation=[], symfactor=[], channel=[], gtype=[], tau=[], loopbasis=[],
+               ver4legs=[], spin=[], diex=[], proper=[])
+    for _ in range(diagNum):
+        blk = []
+        while pos < len(lines) and lines[pos] != "":
+            blk.append(lines[pos])
+            pos += 1
+        pos += 1
+        it = iter(blk)
+
+        def expect(title):
+            ln = next(it)
+            assert title in ln, (title, ln)
+
+        expect("Permutation")
+        out["permutation"].append(_ints(next(it)))
+        expect("SymFactor")
+        out["symfactor"].append(float(next(it)))
+        expect("Channel")
+        out["channel"].append(next(it).strip())
+        expect("GType")
+        out["gtype"].append(_ints(next(it)))
+        expect("VertexBasis")
+        out["tau"].append(_ints(next(it)))
+        next(it)
+        expect("LoopBasis")
+        out["loopbasis"].append([[int(v) for v in next(it).split()] for _ in range(loopNum)])
+        expect("Ver4Legs")
+        out["ver4legs"].append([] if verNum == 0 else [_ints(x) for x in next(it).split("|")[:verNum]])
+        expect("WType")
+        if verNum > 0:
+            next(it)
+        expect("SpinFactor")
+        out["spin"].append(_ints(next(it)))
+        expect("Di/Ex")
+        out["diex"].append(_ints(next(it)))
+        expect("Proper/ImProper")
+        out["proper"].append(_ints(next(it)))
+    chans = ["Alli", "PHr", "PHEr", "PPr"]
+    return dict(GNum=np.int64(GNum), verNum=np.int64(verNum), loopNum=np.int64(loopNum), permutation=np.array(out["permutation"], np.int32),
+                symfactor=np.array(out["symfactor"], np.float64), channel=np.array([chans.index(c) for c in out["channel"]], np.int32),
+                gtype=np.array(out["gtype"], np.int32), tau=np.array(out["tau"], np.int32), loopbasis=np.array(out["loopbasis"], np.int32),
+                ver4legs=np.array(out["ver4legs"], np.int32).reshape(len(out["spin"]), verNum, 4), spin=np.array(out["spin"], np.int32),
+                diex=np.array(out["diex"], np.int32), proper=np.array(out["proper"], np.int32))
+
+
+def _one_vertex4(cat: dict, d: int, spinPolarPara: float, channels, filter) -> Optional[Tuple[Graph, Graph]]:
+    # readfile.jl:267-410
+    GNum, verNum, loopNum = int(cat["GNum"]), int(cat["verNum"]), int(cat["loopNum"])
+    flag_proper = "Proper" in filter
+    isDynamic = verNum != 1
+    permutation = [int(x) + 1 for x in cat["permutation"][d]]
+    assert len(permutation) == len(set(permutation)) == GNum
+    symfactor = float(cat["symfactor"][d])
+    channel = ["Alli", "PHr", "PHEr", "PPr"][int(cat["channel"][d])]
+    if channel not in channels:
+        return None
+    opGType = [int(x) for x in cat["gtype"][d]]
+    tau = [int(x) for x in cat["tau"][d]]                  # (not shifted: readfile.jl:301)
+    basis = [[int(cat["loopbasis"][d][i][g]) for i in range(loopNum)] for g in range(GNum)]
+    ver4Legs = [[int(x) for x in leg] for leg in cat["ver4legs"][d]]
+    spinFactors = [int(x) for x in cat["spin"][d]]
+    DiEx = [int(x) for x in cat["diex"][d]]
+    proper = [int(x) for x in cat["proper"][d]]
+    innerLoopNum = loopNum - 3
+    extK = [[0.0] * loopNum for _ in range(4)]
+    for i in range(3):
+        extK[i][i] = 1.0
+        extK[3][i] = float((-1) ** i)
+    extIndex = [1, 0, 2, 0]
+    for ind1, ind2 in enumerate(permutation, start=1):
+        if ind1 in (1, 2):
+            continue
+        if opGType[ind1 - 1] == -2:
+            if ind2 == 1:
+                extIndex[1] = ind1
+            elif ind2 == 2:
+                extIndex[3] = ind1
+            else:
+                raise ValueError(f"error GType for ({ind1}, {ind2}).")
+    greens = []
+    for ind1, ind2 in enumerate(permutation, start=1):
+        if opGType[ind1 - 1] == -2:
+            continue
+        greens.append(Graph([], properties=BareGreenId(k=basis[ind1 - 1], t=(tau[ind1 - 1], tau[ind2 - 1]))))
+    fermi_greenProd = Graph(greens, operator=Prod())
+    inter_Di: List[Graph] = []
+    inter_Ex: List[Graph] = []
+    for iex, sf in enumerate(spinFactors, start=1):
+        if sf == 0:
+            continue
+        if flag_proper and proper[iex - 1] == 1:
+            continue
+        permu, legs_ex = _exchange(permutation, ver4Legs, iex, 2, 0)
+        extIndex[0], extIndex[2] = permu[0], permu[1]
+        leafs = []
+        for leg in legs_ex:
+            ind1, ind2 = leg[1] + 1, leg[3] + 1
+            cur = [a - b for a, b in zip(basis[leg[0]], basis[ind1 - 1])]
+            assert cur == [a - b for a, b in zip(basis[ind2 - 1], basis[leg[2]])]     # momentum conservation
+            leafs.append(Graph([], properties=BareInteractionId("ChargeCharge", k=cur, t=(tau[ind1 - 1], tau[ind2 - 1]))))
+        (inter_Di if DiEx[iex - 1] == 0 else inter_Ex).append(Graph.new(leafs, operator=Prod(), factor=sf * symfactor))
+    typ = "Dynamic" if isDynamic else "Instant"
+    extT = tuple(tau[i - 1] for i in extIndex)
+    id_Di = Ver4Id((0, innerLoopNum), "UpDown", typ, k=extK, t=extT, chan=channel)
+    id_Ex = Ver4Id((1, innerLoopNum), "ChargeCharge", typ, k=extK, t=extT, chan=channel)
+    if not fermi_greenProd.subgraphs:
+        return Graph(inter_Di, operator=Sum(), properties=id_Di), Graph(inter_Ex, operator=Sum(), properties=id_Ex)
+    return (multi_product(fermi_greenProd, Graph(inter_Di, operator=Sum()), properties=id_Di),
+            multi_product(fermi_greenProd, Graph(inter_Ex, operator=Sum()), properties=id_Ex))
+
+
+def read_vertex4diagrams(catalog, spinPolarPara: float = 0.0, filter=("NoHartree",), channels=("PHr", "PHEr", "PPr", "Alli")) -> List[Graph]:
+    """readfile.jl:191-265.  ``catalog``: a ``.diag`` file name or the arrays of ``parse_vertex4_catalog``.  Returns, per group of
+    external times and channel, the pair (UpUp, UpDown) -- UpDown = the direct diagrams, UpUp = direct + exchange.  (The
+    reference walks the groups in the order of a ``Dict``'s keys; here in order of first appearance.)"""
+    cat = parse_vertex4_catalog(catalog) if isinstance(catalog, str) else catalog
+    diagrams: List[Graph] = []
+    for d in range(len(cat["symfactor"])):
+        pair = _one_vertex4(cat, d, spinPolarPara, channels, filter)
+        if pair is not None:
+            diagrams.extend(pair)
+    innerLoopNum = int(cat["loopNum"]) - 3
+    groups = {}
+    keys: List[tuple] = []
+    for g in diagrams:
+        pr = g.properties
+        groups.setdefault((pr.extT, pr.channel, pr.para[0]), []).append(g)
+        if (pr.extT, pr.channel) not in keys:
+            keys.append((pr.extT, pr.channel))
+    out: List[Graph] = []
+    for extT, channel in keys:
+        di, ex = groups[(extT, channel, 0)], groups[(extT, channel, 1)]
+        gId = di[0].properties
+        gud = linear_combination(di, properties=gId)                    # direct = UpDown
+        gEx = linear_combination(ex, properties=ex[0].properties)
+        guu = Graph([gud, gEx], properties=Ver4Id((2, innerLoopNum), "UpUp", gId.type, k=gId.extK, t=gId.extT, chan=gId.channel))
+        out.extend([guu, gud])
+    return out
+
+
+def diagsGV_ver4(order: int, root_dir: str, spinPolarPara: float = 0.0, channels=("PHr", "PHEr", "PPr", "Alli"), filter=("NoHartree",)) -> List[Graph]:
+    """GV.jl:106-114."""
+    stem = "Vertex4I" if list(channels) == ["Alli"] else "Vertex4"
+    return read_vertex4diagrams(f"{root_dir}/groups_vertex4/{stem}{order}_0_0.diag", spinPolarPara, filter, channels)

@@ -19,19 +19,22 @@ self-energy (1, 3, 18, 171; test/front_end.jl:600-652), the 3-point vertex (1, 1
 in three variants (2, 2, 20, 218 / 2, 2, 32, 326 / 2, 2, 28, 274; :758-826) -- the last two exercise ``vertex4`` with
 all three channels at the top level.
 
-Not restated: the fully irreducible vertex ``Alli`` at 3 and 4 loops (read from the GV vertex catalogs,
-vertex4.jl:112-120) -- the self-energy and the polarization up to 4 loops never reach it (their sub-vertices have at
-most 2 loops); ep_coupling.
+The fully irreducible vertex ``Alli`` at 3 and 4 loops comes, as in the reference, from the GV vertex catalogs
+(``vertex4I_diags``, parquet.jl:216-231; their numbers ship as data/vertex4I<n>.npz) through ``update_extKT``.  Not
+restated: ep_coupling.
 """
 from __future__ import annotations
 
+import copy
+import functools
 import itertools
 import math
+import os
 from dataclasses import dataclass, field, replace
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
-from .graph import Graph, Prod, Sum
-from .gv import BareGreenId, BareInteractionId, GenericId, PolarId, SigmaId, _Id
+from .graph import Graph, Prod, Sum, uid
+from .gv import BareGreenId, BareInteractionId, GenericId, PolarId, SigmaId, Ver4Id, _Id
 
 __all__ = ["DiagPara", "Interaction", "ParquetBlocks", "build", "sigma", "vertex4", "vertex3", "polarization", "green", "orderedPartition",
            "findFirstLoopIdx", "findFirstTauIdx", "isValidG", "isValidSigma", "mergeby", "count_sigma_G2v"]
@@ -276,15 +279,6 @@ class Ver3Id(_Id):
 
     def equiv_key(self):
         return ("Ver3", self.para, self.response, self.extK, self.extT)
-
-
-class Ver4Id(_Id):
-    def __init__(self, para, response: str, type: str = Dynamic, *, k, t=(0, 0, 0, 0), chan: str = AnyChan):
-        self.para, self.response, self.type, self.channel = para, response, type, chan
-        self.extK, self.extT = tuple(tuple(float(x) for x in kk) for kk in k), tuple(t)
-
-    def equiv_key(self):
-        return ("Ver4", self.para, self.response, self.type, self.channel, self.extK, self.extT)
 
 
 # --- operation.jl: mergeby ----------------------------------------------------------------------------------------------
@@ -560,8 +554,7 @@ def vertex4(para: DiagPara, extK=None, subdiagram: bool = False, *, channels=(PH
         for c in channels:
             if c == Alli:
                 if 3 <= loopNum <= 4:
-                    raise NotImplementedError("the fully irreducible vertex at 3 and 4 loops comes from the GV vertex catalogs "
-                                              "(vertex4.jl:112-120); not restated")
+                    addAlli(ver4df, para, legK)
                 continue
             for p in orderedPartition(loopNum - 1, 4, 0):
                 if c in (PHr, PHEr, PPr):
@@ -573,6 +566,85 @@ def vertex4(para: DiagPara, extK=None, subdiagram: bool = False, *, channels=(PH
                          getid=lambda g: Ver4Id(para, g[0]["response"], g[0]["type"], k=legK, t=g[0]["extT"]))
     assert all(r["extT"][0] == para.firstTauIdx for r in ver4df)
     return ver4df
+
+
+# --- the fully irreducible vertex from the GV catalogs (parquet.jl:216-231, vertex4.jl:112-120, operation.jl:178-257) ---------
+@functools.lru_cache(maxsize=None)
+def get_ver4I(order: int):
+    """``vertex4I_diags[order]`` = ``diagsGV_ver4(order, channels=[Alli], filter=[NoHartree])`` for order 3 and 4, from the
+    catalog numbers shipped in data/vertex4I<order>.npz (tests/golden/make_vertex4_catalogs.py)."""
+    import numpy as np
+    from .gv import read_vertex4diagrams
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"vertex4I{order}.npz")
+    return read_vertex4diagrams(dict(np.load(path)), 0.0, (NoHartree,), (Alli,))
+
+
+def _preorder(g: Graph):
+    stack = [g]
+    while stack:
+        n = stack.pop()
+        yield n
+        stack.extend(reversed(n.subgraphs))
+
+
+def update_extKT(diags: Sequence[Graph], para: DiagPara, legK, extraLoopIdx: Optional[int] = None) -> List[Graph]:
+    """operation.jl:178-257: a copy of the catalog's graphs re-expressed in the caller's loop basis and time indices.  Vertex
+    ids take the caller's legs; a propagator's momentum, written in the catalog's basis (three external loops, then the
+    inner ones), becomes sum_i K_i legK_i plus its inner components moved to the positions the external legs do not use.
+    As in the reference, an id whose time indices do not shift keeps the momentum as computed, one that shifts is rebuilt
+    through its constructor (which applies the mirror symmetry)."""
+    graphs = copy.deepcopy(list(diags))
+    visited = set()
+    tauIdx = para.firstTauIdx
+    n = len(legK[0])
+    extK = [list(k) for k in legK[:-1]]
+    for graph in graphs:
+        tau_shift = tauIdx - graph.properties.extT[0]
+        for node in _preorder(graph):
+            if id(node) in visited:
+                continue
+            visited.add(id(node))
+            node.id = uid()
+            prop = node.properties
+            if prop is None or not hasattr(prop, "extK") or not hasattr(prop, "extT"):
+                continue
+            T = tuple(t + tau_shift for t in prop.extT)
+            if isinstance(prop, (Ver4Id, Ver3Id)):
+                node.properties = (Ver4Id(para, prop.response, prop.type, k=[k[:n] for k in legK], t=T, chan=prop.channel)
+                                   if isinstance(prop, Ver4Id) else Ver3Id(para, prop.response, k=[k[:n] for k in legK[:3]], t=T))
+            elif isinstance(prop, (BareGreenId, BareInteractionId, GreenId, SigmaId, PolarId)):
+                K = [float(x) for x in prop.extK]
+                orig = len(K)
+                if orig < n:
+                    K += [0.0] * (n - orig)
+                    if extraLoopIdx is not None:
+                        K[-1] = K[extraLoopIdx - 1]
+                        K[extraLoopIdx - 1] = 0.0
+                else:
+                    K = K[:n]
+                sumK = [0.0] * n
+                for i, k in enumerate(extK):
+                    sumK = [a + K[i] * b for a, b in zip(sumK, k)]
+                chosen: List[int] = []
+                for i in sorted(range(len(extK)), key=lambda i: sum(1 for x in extK[i] if x != 0)):
+                    j = next(idx for idx in range(n) if idx not in chosen and extK[i][idx] != 0)
+                    chosen.append(j)
+                    K[i], K[j] = K[j], K[i]
+                newK = [sumK[idx] + (K[idx] if idx not in chosen else 0.0) for idx in range(n)]
+                sym = tau_shift != 0
+                if isinstance(prop, BareGreenId):
+                    node.properties = BareGreenId(k=newK, t=T, type=prop.type, symmetrize=sym)
+                elif isinstance(prop, BareInteractionId):
+                    node.properties = BareInteractionId(prop.response, k=newK, t=T, type=prop.type, symmetrize=sym)
+                else:
+                    raise NotImplementedError("composite ids do not occur in the catalog graphs")
+    return graphs
+
+
+def addAlli(ver4df: List[Row], para: DiagPara, legK) -> None:          # vertex4.jl:112-120
+    for g in update_extKT(get_ver4I(para.innerLoopNum), para, legK, para.firstLoopIdx - 1):
+        Id = g.properties
+        ver4df.append(dict(response=Id.response, type=Id.type, extT=Id.extT, diagram=g))
 
 
 # --- green.jl ---------------------------------------------------------------------------------------------------------------

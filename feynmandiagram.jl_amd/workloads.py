@@ -20,7 +20,12 @@ Each maps to a config of BASELINE.json:
                     Instant (the reference's default; 4 loops: L 84, N 1 325, R 4), ``_dyn`` Dynamic (L 175, N 4 819,
                     R 7), ``_insdyn`` both (L 312, N 20 147, R 8: the size BASELINE.json quotes as "~10^4 nodes" lies
                     between the last two); ``_taylor2``: taylorAD of order 2 in the coupling + optimize! (config 4).
-                    Built on the fly, no data file.
+                    Built on the fly, no data file.  ``parquet_sigma5`` (L 274, N 11 407, R 5) and above use the fully
+                    irreducible vertex of the GV catalogs (data/vertex4I<n>.npz).
+  parquet_ver4_4    the graph example/benchmark.jl builds: ``Parquet.vertex4(DiagPara(type=Ver4Diag, innerLoopNum=4))`` +
+                    optimize! (L 984, N 44 854, 180 roots)
+  gv_ver4_4         the graph example/benchmark_GV.jl builds: ``GV.diagsGV_ver4(4)`` + optimize! (catalog Vertex44_0_0.diag,
+                    1 190 Hugenholtz diagrams: L 1 514, N 31 803, 26 roots; tests/golden/make_vertex4_catalogs.py)
   synthetic_small   a 1000-node graph for quick parity runs
 """
 from __future__ import annotations
@@ -38,7 +43,7 @@ DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 PREBUILT = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "sigma4_taylor_standin", "gv_sigma4",
             "gv_sigma5", "gv_sigma6", "gv_sigma4_taylor2", "gv_sigma5_taylor2", "parquet_sigma2", "parquet_sigma3",
             "parquet_sigma4", "parquet_sigma4_dyn", "parquet_sigma4_insdyn", "parquet_sigma4_taylor2",
-            "parquet_sigma4_dyn_taylor2", "parquet_sigma4_insdyn_taylor2")
+            "parquet_sigma4_dyn_taylor2", "parquet_sigma4_insdyn_taylor2", "parquet_sigma5", "parquet_ver4_4", "gv_ver4_4")
 PREBUILT_HIP = ("sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma5", "gv_sigma4_taylor2")
 
 
@@ -56,26 +61,26 @@ def get(name: str) -> NodeTable:
         return synthetic_parquet_like(10000, 300, 2, seed=20241220, structure="random")
     if name == "synthetic_small":
         return synthetic_parquet_like(1000, 64, 2, seed=7, structure="random")
-    if name.startswith("gv_sigma"):
+    if name.startswith("gv_sigma") or name.startswith("gv_ver4"):
         return NodeTable.load(os.path.join(DATA, name + ".npz"))
     if name == "sigma4_taylor_standin":
         return _with_powers(synthetic_parquet_like(30000, 300, 6, seed=20241221), 0.02, 99)
-    if name.startswith("parquet_sigma"):
+    if name.startswith("parquet_"):
         return _parquet(name)
     raise KeyError(name)
 
 
 def parquet_graphs(name: str):
-    """The optimized graphs of a ``parquet_sigma<n>[_dyn|_insdyn]`` workload and the front end's table rows."""
+    """The optimized graphs of a ``parquet_sigma<n>[_dyn|_insdyn]`` / ``parquet_ver4_<n>`` workload and the front end's table rows."""
     import re
 
     from . import optimize, parquet as pq
-    m = re.fullmatch(r"parquet_sigma(\d)(_dyn|_insdyn)?", name)
+    m = re.fullmatch(r"parquet_(sigma|ver4_)(\d)(_dyn|_insdyn)?", name)
     if not m:
         raise KeyError(name)
-    types = {None: (pq.Instant,), "_dyn": (pq.Dynamic,), "_insdyn": (pq.Instant, pq.Dynamic)}[m.group(2)]
-    para = pq.DiagPara(type=pq.SigmaDiag, innerLoopNum=int(m.group(1)), hasTau=True, filter=(pq.NoHartree,),
-                       interaction=(pq.Interaction(pq.ChargeCharge, types),))
+    types = {None: (pq.Instant,), "_dyn": (pq.Dynamic,), "_insdyn": (pq.Instant, pq.Dynamic)}[m.group(3)]
+    para = pq.DiagPara(type=pq.SigmaDiag if m.group(1) == "sigma" else pq.Ver4Diag, innerLoopNum=int(m.group(2)), hasTau=True,
+                       filter=(pq.NoHartree,), interaction=(pq.Interaction(pq.ChargeCharge, types),))
     rows = pq.build(para)
     graphs = [r["diagram"] for r in rows]
     optimize.optimize_(graphs)
@@ -127,7 +132,7 @@ def leafstates(name: str):
     """The ``FrontEnds.leafstates`` tables of a GV workload, in leafVal order (``leaf_type``, ``leaf_order``, ``tau_in``,
     ``tau_out``, ``loop_index``, ``basis``, ``n_tau``), or None.  For the Taylor-expanded graphs a leaf is (leaf of the
     original graph, derivative order in the coupling): the fixture of the original graph re-indexed."""
-    if name.startswith("parquet_sigma"):
+    if name.startswith("parquet_"):
         return _parquet_leafstates(name)
     base = name[:-len("_taylor2")] if name.endswith("_taylor2") else name
     path = os.path.join(DATA, base + "_leafstates.npz")

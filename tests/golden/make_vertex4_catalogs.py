@@ -1,0 +1,56 @@
+"""The numbers of the reference's fully-irreducible 4-point-vertex catalogs
+(src/frontend/GV_diagrams/groups_vertex4/Vertex4I{3,4}_0_0.diag) as arrays -> feynmandiagram.jl_amd/data/vertex4I{3,4}.npz,
+which ``Parquet.vertex4`` needs for its ``Alli`` channel at 3 and 4 loops (parquet.jl:216-231); and the node table of
+``GV.diagsGV_ver4(4)`` + ``optimize!`` (the graph example/benchmark_GV.jl:23 builds) -> data/gv_ver4_4.npz.
+
+Checked here independently of the reader: the all-leaves-one value of every (UpUp, UpDown) pair equals the sums of
+SymFactor * SpinFactor over the catalog (direct terms for UpDown, all terms for UpUp).
+
+Needs /root/reference (this container only).  Run: python tests/golden/make_vertex4_catalogs.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+RD = "/root/reference/src/frontend/GV_diagrams"
+DATA = os.path.join(ROOT, "feynmandiagram.jl_amd", "data")
+
+import oracle  # noqa: E402
+from feynmandiagram_jl_amd import gv, optimize  # noqa: E402
+from feynmandiagram_jl_amd.lowering import lower  # noqa: E402
+
+
+def catalog_sums(c, channel=None):
+    sel = [d for d in range(len(c["symfactor"])) if channel is None or int(c["channel"][d]) == channel]
+    di = sum(float(c["symfactor"][d]) * float(c["spin"][d][c["diex"][d] == 0].sum()) for d in sel)
+    ex = sum(float(c["symfactor"][d]) * float(c["spin"][d][c["diex"][d] == 1].sum()) for d in sel)
+    return di + ex, di
+
+
+def main():
+    for order in (3, 4):
+        c = gv.parse_vertex4_catalog(f"{RD}/groups_vertex4/Vertex4I{order}_0_0.diag")
+        graphs = gv.read_vertex4diagrams(c, channels=("Alli",))
+        t, _, _ = lower(graphs)
+        v = oracle.eval_static(t, np.ones((1, t.n_leaf)))[0]
+        assert len(graphs) == 2 and tuple(v) == catalog_sums(c), (order, v, catalog_sums(c))
+        np.savez_compressed(os.path.join(DATA, f"vertex4I{order}.npz"), **c)
+        print(f"Vertex4I{order}: {len(c['symfactor'])} Hugenholtz diagrams, all-ones (UpUp, UpDown) = {tuple(v)} == catalog sums")
+    # example/benchmark_GV.jl:23: diagsGV_ver4(4) with every channel
+    graphs = gv.diagsGV_ver4(4, RD)
+    raw, _, _ = lower(graphs)
+    v_raw = oracle.eval_static(raw, np.ones((1, raw.n_leaf)))[0]
+    optimize.optimize_(graphs)
+    t, _, _ = lower(graphs, name="gv_ver4_4_optimized")
+    v = oracle.eval_static(t, np.ones((1, t.n_leaf)))[0]
+    assert list(v) == list(v_raw)
+    t.save(os.path.join(DATA, "gv_ver4_4.npz"))
+    print("gv_ver4_4", t.stats(), "roots", t.n_root, "all-ones", v[:8])
+
+
+if __name__ == "__main__":
+    main()

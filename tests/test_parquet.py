@@ -7,6 +7,7 @@ import pytest
 
 import oracle
 from feynmandiagram_jl_amd import fixtures, optimize, parquet as pq, workloads
+from feynmandiagram_jl_amd.gv import mirror_symmetrize
 from feynmandiagram_jl_amd.graph import Graph
 from feynmandiagram_jl_amd.lowering import lower
 from feynmandiagram_jl_amd.parquet import (ChargeCharge, DiagPara, Dynamic, Girreducible, GreenDiag, Instant, Interaction, NoFock,
@@ -232,3 +233,111 @@ def test_taylor_expansion_of_the_parquet_self_energy_satisfies_the_series_identi
     scale = np.abs(c).sum(axis=0) + 1.0
     assert np.all(np.abs(series - f_x) <= 1e-7 * scale)
     assert np.all(np.abs(c[0] + x * c[1] - f_x) >= np.abs(series - f_x))
+
+
+# ---- the fully irreducible vertex from the GV catalogs (parquet.jl:216-231, vertex4.jl:112-120, operation.jl:178-257) -------
+REF_GV = "/root/reference/src/frontend/GV_diagrams"
+
+
+def _catalog_sums(c):
+    n = len(c["symfactor"])
+    di = sum(float(c["symfactor"][d]) * float(c["spin"][d][c["diex"][d] == 0].sum()) for d in range(n))
+    ex = sum(float(c["symfactor"][d]) * float(c["spin"][d][c["diex"][d] == 1].sum()) for d in range(n))
+    return [di + ex, di]
+
+
+@pytest.mark.parametrize("order, want", [(3, [0.0, 2.0]), (4, [0.0, -26.0])])
+def test_irreducible_vertex_catalogs(order, want):
+    """(UpUp, UpDown) of ``diagsGV_ver4(order, channels=[Alli])``: all leaves 1 => the catalog's own sums of
+    SymFactor * SpinFactor (direct terms for UpDown, direct + exchange for UpUp), computed from the numbers directly."""
+    import os
+    from feynmandiagram_jl_amd import gv
+    graphs = pq.get_ver4I(order)
+    assert [g.properties.response for g in graphs] == [pq.UpUp, pq.UpDown] and all(g.properties.channel == pq.Alli for g in graphs)
+    assert list(all_ones(graphs)) == want
+    c = dict(np.load(os.path.join(os.path.dirname(pq.__file__), "data", f"vertex4I{order}.npz")))
+    assert _catalog_sums(c) == want
+    if os.path.isdir(REF_GV):                   # the shipped arrays are the catalog's numbers
+        ref = gv.parse_vertex4_catalog(f"{REF_GV}/groups_vertex4/Vertex4I{order}_0_0.diag")
+        assert all(np.array_equal(ref[k], c[k]) for k in ref)
+
+
+def test_irreducible_vertex_enters_the_parquet_equations_with_the_right_multiplicity(monkeypatch):
+    """The 5-loop polarization is the first object whose sub-vertices reach 3 loops.  The reference's count functions go
+    that far (count_polar_g2v_noFock_upup / _updown(5) = 3586 / 844, benchmark/diagram_count.jl:82-118) although its test
+    stops at 4 loops: the catalog's factors carry fermionic signs, so counting needs their absolute values -- with those
+    the numbers are met exactly; with the signs as they are, the catalog vertex contributes (0, 4) instead of (168, 84)."""
+    import functools
+    import os
+    from feynmandiagram_jl_amd import gv
+    para = DiagPara(type=pq.PolarDiag, innerLoopNum=5, isFermi=False, hasTau=True, filter=(NoHartree, NoFock), interaction=(Interaction(ChargeCharge, Instant),))
+    Q = [1.0] + [0.0] * (para.totalLoopNum - 1)
+    with_signs = all_ones([r["diagram"] for r in pq.polarization(para, Q)]) * 2
+    assert list(with_signs) == [3418.0, 764.0]
+
+    def bosonic(order):
+        c = dict(np.load(os.path.join(os.path.dirname(pq.__file__), "data", f"vertex4I{order}.npz")))
+        c["spin"], c["symfactor"] = np.abs(c["spin"]), np.abs(c["symfactor"])
+        return gv.read_vertex4diagrams(c, 0.0, (NoHartree,), (pq.Alli,))
+
+    monkeypatch.setattr(pq, "get_ver4I", functools.lru_cache(maxsize=None)(bosonic))
+    rows = pq.polarization(para, Q)
+    assert [r["response"] for r in rows] == [pq.UpUp, pq.UpDown]
+    assert list(all_ones([r["diagram"] for r in rows]) * 2) == [3586.0, 844.0]
+
+
+def test_catalog_vertex_in_the_callers_basis():
+    """``update_extKT``: every propagator's momentum in the caller's basis is one linear image of its momentum in the
+    catalog's basis (up to the mirror symmetry), the three external loops go to the caller's legs, the inner loops to
+    positions of their own; time indices shift by firstTauIdx - 1; the copy shares no node with the cached graphs."""
+    # a 3-loop sub-vertex of a bubble whose own loop is number 4: inner loops 5..7 of 7, legs built from loops 1, 2 and 4
+    para = DiagPara(type=Ver4Diag, innerLoopNum=3, firstLoopIdx=5, firstTauIdx=3, totalLoopNum=7, totalTauNum=8)
+    legK = [[1.0, 0, 0, 0, 0, 0, 0], [0, 1.0, 0, 0, 0, 0, 0], [0, 0, 0, 1.0, 0, 0, 0]]
+    legK.append([a + c - b for a, b, c in zip(*legK)])
+    old = pq.get_ver4I(3)
+    new = pq.update_extKT(old, para, legK, para.firstLoopIdx - 1)
+    pairs = []
+    ids_old = set()
+
+    def walk(a, b):
+        ids_old.add(a.id)
+        assert b.id not in ids_old
+        if not a.subgraphs:
+            pairs.append((a.properties, b.properties))
+        assert len(a.subgraphs) == len(b.subgraphs) and a.subgraph_factors == b.subgraph_factors
+        for x, y in zip(a.subgraphs, b.subgraphs):
+            walk(x, y)
+
+    for a, b in zip(old, new):
+        walk(a, b)
+        assert b.properties.extT == tuple(t + 2 for t in a.properties.extT) and b.properties.para == para
+        assert [list(k) for k in b.properties.extK] == [[float(x) for x in k] for k in legK]
+    A = np.array([p.extK for p, _ in pairs])                    # [n_leaf, 6]
+    Bn = np.array([q.extK for _, q in pairs])                   # [n_leaf, 7]
+    assert all(q.extT == tuple(t + 2 for t in p.extT) for p, q in pairs)
+    # the legs are unit vectors here, so the map is a placement: find, for every position of the new basis, the component
+    # of the old one it copies (by absolute values, the mirror symmetry may flip a leaf's overall sign) ...
+    place = {}
+    for pnew in range(Bn.shape[1]):
+        if not np.any(Bn[:, pnew]):
+            continue
+        cands = [q for q in range(A.shape[1]) if np.array_equal(np.abs(A[:, q]), np.abs(Bn[:, pnew]))]
+        assert len(cands) == 1, (pnew, cands)
+        place[pnew] = cands[0]
+    assert place == {0: 0, 1: 1, 3: 2, 4: 4, 5: 5, 6: 3}       # legs 1-3 -> their positions; the catalog's inner loop at position 4
+    P = np.zeros((A.shape[1], Bn.shape[1]))                    # (the bubble's loop here) moves to 7, the others stay: loops 5..7
+    for pnew, q in place.items():
+        P[q, pnew] = 1.0
+    img = A @ P
+    assert np.all(np.all(img == Bn, axis=1) | np.all(-img == Bn, axis=1))       # ... one placement for all leaves, up to that sign
+    assert all(tuple(q.extK) == mirror_symmetrize(list(q.extK)) for _, q in pairs)
+
+
+@pytest.mark.parametrize("name, sizes", [("parquet_sigma5", (274, 11407, 5)), ("parquet_ver4_4", (984, 44854, 180)), ("gv_ver4_4", (1514, 31803, 26))])
+def test_larger_graphs_of_the_reference_examples(name, sizes):
+    """5-loop Parquet self-energy; the graph of example/benchmark.jl (``Parquet.vertex4``, 4 loops, 180 rows -- its list of
+    root indices ``inds`` runs to 178); the graph of example/benchmark_GV.jl:23 (``GV.diagsGV_ver4(4)``)."""
+    t = workloads.get(name)
+    assert (t.n_leaf, t.n_node, t.n_root) == sizes
+    x = np.random.default_rng(2).uniform(0.5, 1.5, size=(2, t.n_leaf))
+    assert np.allclose(oracle.eval_static(t, x), oracle.eval_interp(t, x), rtol=1e-10, atol=1e-9)
