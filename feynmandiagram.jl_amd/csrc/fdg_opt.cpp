@@ -383,37 +383,49 @@ void build_uops(Builder &B) {
   // needs the most nodes, then always continue with the root whose cone is already computed to the
   // largest extent -- graphs that share most of their sub-expressions (Taylor coefficients of one
   // diagram, instant/dynamic parts) are finished while the shared values are still on chip.
-  if (tops.size() > 1 && tops.size() <= 64) {
-    const size_t R = tops.size();
-    std::vector<std::vector<uint8_t>> cone(R, std::vector<uint8_t>(p.N, 0));
+  // (Bit sets: 180 roots x 45 000 nodes -- the 4-loop vertex function of example/benchmark.jl -- take 0.1 s.  With
+  // FDG_ROOT_RECENT=w the overlap counts only the cones of the last w roots: what is likely to be on chip still.)
+  static const size_t max_roots = std::getenv("FDG_ROOT_ORDER_MAX") ? (size_t)std::atoi(std::getenv("FDG_ROOT_ORDER_MAX")) : 1024;
+  if (tops.size() > 1 && tops.size() <= max_roots) {
+    const size_t R = tops.size(), W = (p.N + 63) / 64;
+    std::vector<std::vector<uint64_t>> cone(R, std::vector<uint64_t>(W, 0));
     std::vector<uint64_t> csize(R, 0);
     std::vector<uint32_t> stk;
     for (size_t r = 0; r < R; ++r) {
       stk.assign(1, tops[r]);
-      cone[r][tops[r]] = 1;
+      cone[r][tops[r] >> 6] |= 1ull << (tops[r] & 63);
       while (!stk.empty()) {
         const uint32_t n = stk.back(); stk.pop_back();
         csize[r]++;
         for (uint32_t e = p.off[n]; e < p.off[n + 1]; ++e) {
           const uint32_t c = p.idx[e];
-          if (c >= L && !cone[r][c - L]) { cone[r][c - L] = 1; stk.push_back(c - L); }
+          if (c >= L && !((cone[r][(c - L) >> 6] >> ((c - L) & 63)) & 1)) { cone[r][(c - L) >> 6] |= 1ull << ((c - L) & 63); stk.push_back(c - L); }
         }
       }
     }
-    std::vector<uint8_t> done(p.N, 0), used(R, 0);
+    static const size_t recent = std::getenv("FDG_ROOT_RECENT") ? (size_t)std::atoi(std::getenv("FDG_ROOT_RECENT")) : 0;
+    std::vector<uint64_t> done(W, 0);
+    std::vector<uint8_t> used(R, 0);
     std::vector<uint32_t> ordered;
+    std::vector<size_t> order_idx;
     for (size_t k = 0; k < R; ++k) {
+      if (recent && k) {                       // only what the last `recent` roots touched
+        std::fill(done.begin(), done.end(), 0);
+        for (size_t q = order_idx.size() > recent ? order_idx.size() - recent : 0; q < order_idx.size(); ++q)
+          for (size_t w = 0; w < W; ++w) done[w] |= cone[order_idx[q]][w];
+      }
       size_t best = R; double best_score = -1.0;
       for (size_t r = 0; r < R; ++r) {
         if (used[r]) continue;
         uint64_t ov = 0;
-        if (k) for (uint32_t n = 0; n < p.N; ++n) ov += (cone[r][n] & done[n]);
+        if (k) for (size_t w = 0; w < W; ++w) ov += (uint64_t)__builtin_popcountll(cone[r][w] & done[w]);
         const double score = k ? (double)ov / (double)csize[r] + 1e-9 * (double)csize[r] / (double)p.N : (double)csize[r];
         if (score > best_score) { best_score = score; best = r; }
       }
       used[best] = 1;
       ordered.push_back(tops[best]);
-      for (uint32_t n = 0; n < p.N; ++n) done[n] |= cone[best][n];
+      order_idx.push_back(best);
+      if (!recent) for (size_t w = 0; w < W; ++w) done[w] |= cone[best][w];
     }
     tops.swap(ordered);
   }

@@ -438,10 +438,11 @@ def test_c_abi_communicator_world_one(libfdg, cuda):
         c2.close()
 
 
-@pytest.mark.parametrize("name,B", [("gv_sigma6", 3001), ("gv_sigma5_taylor2", 2049)])
+@pytest.mark.parametrize("name,B", [("gv_sigma6", 3001), ("gv_sigma5_taylor2", 2049), ("parquet_sigma5", 3001), ("parquet_ver4_4", 2049), ("gv_ver4_4", 2049)])
 def test_large_real_graphs(libfdg, cuda, name, B):
-    """The two largest graphs built from reference data (6-loop GV self-energy, 49 390 nodes; 5-loop GV
-    self-energy with second-order Taylor counterterms, 115 588 nodes, 786 Power{2}): optimizing back end and
+    """The largest graphs built from reference data (6-loop GV self-energy, 49 390 nodes; 5-loop GV
+    self-energy with second-order Taylor counterterms, 115 588 nodes, 786 Power{2}; the 5-loop Parquet self-energy; the
+    graphs of example/benchmark.jl -- 180 roots -- and example/benchmark_GV.jl): optimizing back end and
     interpreter against the oracle, bit for bit, both layouts; accumulate within 1e-12 of the scaled sum."""
     import torch
     t = workloads.get(name)

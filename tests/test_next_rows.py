@@ -212,7 +212,7 @@ def replay(ops, n_reg, n_lds, n_mem, n_acc, leaf, R):
 
 
 @pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma4", "gv_sigma5",
-                                  "gv_sigma4_taylor2", "parquet_sigma4", "parquet_sigma4_insdyn", "parquet_sigma4_taylor2"])
+                                  "gv_sigma4_taylor2", "parquet_sigma4", "parquet_sigma4_insdyn", "parquet_sigma4_taylor2", "parquet_sigma5", "parquet_ver4_4"])
 @pytest.mark.parametrize("budget", [dict(), dict(n_reg=120, n_lds=80, n_acc=124), dict(n_reg=9, n_lds=3, n_acc=2, lookahead_leaf=40)])
 def test_allocated_program_replays_exactly(libfdg, name, budget):
     """Scheduler + Belady allocator + load hoisting move values, never change them:
