@@ -359,32 +359,14 @@ struct Builder {
 
 struct Frame { uint32_t n, i, acc; };
 
-void build_uops(Builder &B) {
-  const Lowered &p = B.p;
+// Order in which the roots are evaluated (values do not depend on it): start with the root that
+// needs the most nodes, then always continue with the root whose cone is already computed to the
+// largest extent -- graphs that share most of their sub-expressions (Taylor coefficients of one
+// diagram, instant/dynamic parts, the rows of a vertex function) are finished while the shared values are still on chip.
+// (Bit sets: 180 roots x 45 000 nodes -- the 4-loop vertex function of example/benchmark.jl -- take 0.1 s.  With
+// FDG_ROOT_RECENT=w the overlap counts only the cones of the last w roots: what is likely to be on chip still.)
+static void order_roots(const Lowered &p, std::vector<uint32_t> &tops) {
   const uint32_t L = p.L;
-  std::vector<std::vector<uint32_t>> roots_of((size_t)0);
-  std::vector<std::pair<uint32_t, uint32_t>> rootlist;
-  for (uint32_t k = 0; k < p.R; ++k)
-    if (p.root_slot[k] != FDG_NO_ROOT) rootlist.push_back({p.root_slot[k], k});
-  std::sort(rootlist.begin(), rootlist.end());
-  auto emit_roots = [&](uint32_t v) {
-    auto it = std::lower_bound(rootlist.begin(), rootlist.end(), std::make_pair(v, 0u));
-    for (; it != rootlist.end() && it->first == v; ++it) B.u.push_back(UOp{M_ROOT, it->second, B.ref_of[v], 0, 0.0});
-  };
-  for (auto &rk : rootlist)
-    if (rk.first < L) { B.need(rk.first); B.u.push_back(UOp{M_ROOT, rk.second, B.ref_of[rk.first], 0, 0.0}); }
-
-  std::vector<Frame> st;
-  // roots in statement order of the reference (increasing node index)
-  std::vector<uint32_t> tops;
-  for (auto &rk : rootlist) if (rk.first >= L) tops.push_back(rk.first - L);
-  tops.erase(std::unique(tops.begin(), tops.end()), tops.end());
-  // Order in which the roots are evaluated (values do not depend on it): start with the root that
-  // needs the most nodes, then always continue with the root whose cone is already computed to the
-  // largest extent -- graphs that share most of their sub-expressions (Taylor coefficients of one
-  // diagram, instant/dynamic parts) are finished while the shared values are still on chip.
-  // (Bit sets: 180 roots x 45 000 nodes -- the 4-loop vertex function of example/benchmark.jl -- take 0.1 s.  With
-  // FDG_ROOT_RECENT=w the overlap counts only the cones of the last w roots: what is likely to be on chip still.)
   static const size_t max_roots = std::getenv("FDG_ROOT_ORDER_MAX") ? (size_t)std::atoi(std::getenv("FDG_ROOT_ORDER_MAX")) : 1024;
   if (tops.size() > 1 && tops.size() <= max_roots) {
     const size_t R = tops.size(), W = (p.N + 63) / 64;
@@ -428,7 +410,31 @@ void build_uops(Builder &B) {
       if (!recent) for (size_t w = 0; w < W; ++w) done[w] |= cone[best][w];
     }
     tops.swap(ordered);
-  }
+}
+
+}
+
+void build_uops(Builder &B) {
+  const Lowered &p = B.p;
+  const uint32_t L = p.L;
+  std::vector<std::vector<uint32_t>> roots_of((size_t)0);
+  std::vector<std::pair<uint32_t, uint32_t>> rootlist;
+  for (uint32_t k = 0; k < p.R; ++k)
+    if (p.root_slot[k] != FDG_NO_ROOT) rootlist.push_back({p.root_slot[k], k});
+  std::sort(rootlist.begin(), rootlist.end());
+  auto emit_roots = [&](uint32_t v) {
+    auto it = std::lower_bound(rootlist.begin(), rootlist.end(), std::make_pair(v, 0u));
+    for (; it != rootlist.end() && it->first == v; ++it) B.u.push_back(UOp{M_ROOT, it->second, B.ref_of[v], 0, 0.0});
+  };
+  for (auto &rk : rootlist)
+    if (rk.first < L) { B.need(rk.first); B.u.push_back(UOp{M_ROOT, rk.second, B.ref_of[rk.first], 0, 0.0}); }
+
+  std::vector<Frame> st;
+  // roots in statement order of the reference (increasing node index)
+  std::vector<uint32_t> tops;
+  for (auto &rk : rootlist) if (rk.first >= L) tops.push_back(rk.first - L);
+  tops.erase(std::unique(tops.begin(), tops.end()), tops.end());
+  order_roots(p, tops);
   // One fold step of frame f (operand already computed).  Returns true when the node is finished.
   auto step = [&](Frame &f) -> bool {
     const uint32_t n = f.n, a = p.off[n], k = p.off[n + 1] - a;
@@ -1239,10 +1245,17 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
     if (rk.first < L) { C.B[0]->u.push_back(UOp{M_ROOT, rk.second, C.B[0]->ref_of[rk.first], 0, 0.0}); continue; }
     if (root_nodes.empty() || root_nodes.back() != rk.first - L) root_nodes.push_back(rk.first - L);
   }
+  // Many roots (the rows of a vertex function): whole roots are dealt to the waves, in the order that keeps what they share
+  // on chip (order_roots); with a few roots the terms of each are dealt, a home wave folding them as they arrive.
+  size_t n_wide = 0;
+  for (uint32_t rn : root_nodes) n_wide += (p.off[rn + 1] - p.off[rn] >= 8 && p.op[rn] != FDG_OP_POWER);
+  const char *rte = std::getenv("FDG_COOP_ROOT_TASKS");
+  const bool root_tasks = rte ? rte[0] == '1' : root_nodes.size() > 4 * (size_t)NW;
+  if (root_tasks) order_roots(p, root_nodes);
   std::vector<std::vector<uint32_t>> term_lists;
   for (uint32_t rn : root_nodes) {
     const uint32_t k = p.off[rn + 1] - p.off[rn];
-    if (k >= 8 && p.op[rn] != FDG_OP_POWER) {
+    if (!root_tasks && k >= 8 && p.op[rn] != FDG_OP_POWER) {
       C.is_wide_root[rn] = 1;
       C.wides.push_back(CoopBuild::Wide{rn, (uint32_t)(C.wides.size() % NW), 0, NONE, false});
       std::vector<uint32_t> t;
@@ -1252,7 +1265,8 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
       C.tasks.push_back(L + rn);
     }
   }
-  if (C.wides.empty()) { out.why = "no wide root to distribute"; return; }
+  if (C.wides.empty() && !root_tasks) { out.why = "no wide root to distribute"; return; }
+  (void)n_wide;
   for (size_t i = 0;; ++i) {                           // the wide roots' terms, interleaved
     bool any = false;
     for (auto &t : term_lists) if (i < t.size()) { C.tasks.push_back(t[i]); any = true; }

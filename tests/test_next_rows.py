@@ -340,9 +340,10 @@ def replay_coop(progs, info, leaf, R):
 
 
 @pytest.mark.parametrize("waves", [4, 8])
-@pytest.mark.parametrize("name", ["sigma4_standin", "gv_sigma5", "sigma4_worstcase", "synthetic_small"])
+@pytest.mark.parametrize("name", ["sigma4_standin", "gv_sigma5", "sigma4_worstcase", "synthetic_small", "parquet_ver4_3"])
 def test_cooperative_programs_replay_exactly(libfdg, monkeypatch, name, waves):
     """The cooperative variant (four waves of a CU on one tile): who computes a term changes, the folds do not.
+    (With many roots -- the 84 rows of the 3-loop Parquet vertex function -- whole roots are dealt to the waves instead.)
     The four programs replayed with their barriers give the oracle's bits; every wave's program has the same number of
     barriers; nothing is read from a shared slot in the epoch in which it is rewritten."""
     monkeypatch.setenv("FDG_COOP_WAVES", str(waves))      # one or two waves per SIMD (two: 256 registers each, no AGPR level)
