@@ -107,6 +107,7 @@ struct fdg_graph {
   // ISA specialization (fdg_isa.cpp): one wave = 64 samples, persistent grid
   bool isa = false;
   void *fn_isa = nullptr;
+  void *fn_isa_nt = nullptr, *fn_isa_acc_nt = nullptr;   // streaming variants (non-temporal leaf loads / root stores) for line-aligned batches
   uint32_t isa_vgpr = 0, isa_lds_bytes = 0, isa_mem_slots = 0;
   // optional two-samples-per-lane variant in the same code object (sample stride 1, full 128-sample tiles)
   bool has_w2 = false;

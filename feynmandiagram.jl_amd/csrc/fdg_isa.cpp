@@ -267,6 +267,7 @@ struct HzTracker {
 struct Emit {
   std::ostringstream os;
   HzTracker hz;
+  bool streaming = false;     // the kernel being printed is the variant for line-aligned batches: non-temporal leaf loads and root stores
   uint64_t n_auto_nop = 0;
   uint64_t vm_issued = 0, lg_issued = 0, vm_done = 0, lg_done = 0;
   // pending[reg] = (kind 0 none / 1 vm / 2 lgkm, seq)
@@ -445,6 +446,20 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   auto vall = [&](uint32_t r) { const int b = V_BASE + RW * r; return "v[" + std::to_string(b) + ":" + std::to_string(b + RW - 1) + "]"; };
   const std::string LD = W == 2 ? "global_load_dwordx4 " : "global_load_dwordx2 ";
   const std::string ST = W == 2 ? "global_store_dwordx4 " : "global_store_dwordx2 ";
+  // cache policy of the leaf stream (experiment knob): FDG_ISA_LEAF_POLICY="nt" / "sc1" / "sc0 sc1" ...
+  const std::string leaf_policy_env = std::getenv("FDG_ISA_LEAF_POLICY") ? std::string(" ") + std::getenv("FDG_ISA_LEAF_POLICY") : std::string();
+  const std::string root_policy = std::getenv("FDG_ISA_ROOT_POLICY") ? std::string(" ") + std::getenv("FDG_ISA_ROOT_POLICY") : std::string(E.streaming ? " nt" : "");
+  // Streaming variant: a leaf's last load of the tile and the root stores are non-temporal -- the lines are not needed again, and
+  // a read stream with a few stores in it runs 5-10 % faster that way (tools/ubench/tile_ahead.hip: 5.73 -> 6.32 TB/s).  Only for
+  // batches whose tiles are whole cache lines (the runtime checks strides and bases): a line shared by two tiles would be
+  // fetched twice.  Earlier loads of a leaf that is loaded again stay as they are (the re-load may still find the line in L2).
+  std::vector<uint8_t> final_load(prog.ops.size(), 0);
+  if (E.streaming) {
+    std::vector<uint8_t> seen(p.L + 1, 0);
+    for (size_t i = prog.ops.size(); i-- > 0;)
+      if (prog.ops[i].kind == M_LD_LEAF && prog.ops[i].a < seen.size() && !seen[prog.ops[i].a]) { seen[prog.ops[i].a] = 1; final_load[i] = 1; }
+  }
+  std::string leaf_policy = leaf_policy_env;
   const std::string DSR = W == 2 ? "ds_read_b128 " : "ds_read_b64 ";
   const std::string DSW = W == 2 ? "ds_write_b128 " : "ds_write_b64 ";
 
@@ -751,6 +766,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       case M_LD_LEAF:
         if (dbg_noleaf) break;   // timing experiments only (results are garbage)
         E.wait_reg(o.d);
+        if (E.streaming && leaf_policy_env.empty()) leaf_policy = final_load[this_op] ? " nt" : "";
         if (rm_bufs) {
           const int b = rm_ld_buf[this_op];
           if (b >= 0) {          // from the staging buffer: lane = row, piece (leaf - chunk start) / 2, half (leaf - chunk start) % 2
@@ -762,7 +778,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
           } else {               // gathered: eight bytes of each lane's own row
             E.ins("s_add_u32 " + S(S_LP) + ", " + S(S_LT) + ", " + hex32(o.a * 8u));
             E.ins("s_addc_u32 " + S(S_LP + 1) + ", " + S(S_LT + 1) + ", 0");
-            E.ins(LD + vall(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_LP));
+            E.ins(LD + vall(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_LP) + leaf_policy);
             E.pend[o.d] = {1, ++E.vm_issued};
           }
           break;
@@ -786,7 +802,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
           }
           last_leaf = o.a;
         }
-        E.ins(LD + vall(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_LP));
+        E.ins(LD + vall(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_LP) + leaf_policy);
         E.pend[o.d] = {1, ++E.vm_issued};
         break;
       case M_LD_MEM: {
@@ -997,9 +1013,9 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
           if (o.nega) {
             E.ins("v_mov_b32_e32 " + V(V_TMP) + ", v" + std::to_string(src));
             E.ins("v_xor_b32_e32 " + V(V_TMP + 1) + ", 0x80000000, v" + std::to_string(src + 1));
-            E.ins("global_store_dwordx2 " + V(V_ROOTOFF) + ", v[" + std::to_string(V_TMP) + ":" + std::to_string(V_TMP + 1) + "], " + S2(S_A));
+            E.ins("global_store_dwordx2 " + V(V_ROOTOFF) + ", v[" + std::to_string(V_TMP) + ":" + std::to_string(V_TMP + 1) + "], " + S2(S_A) + root_policy);
           } else {
-            E.ins("global_store_dwordx2 " + V(V_ROOTOFF) + ", v[" + std::to_string(src) + ":" + std::to_string(src + 1) + "], " + S2(S_A));
+            E.ins("global_store_dwordx2 " + V(V_ROOTOFF) + ", v[" + std::to_string(src) + ":" + std::to_string(src + 1) + "], " + S2(S_A) + root_policy);
           }
           ++E.vm_issued;
         }
@@ -1180,6 +1196,14 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   ks.push_back(emit_kernel(E, p, prog, kname, 1));
   if (prog2) ks.push_back(emit_kernel(E, p, *prog2, kname + "_w2", 2));
   if (prog_acc) ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc", 1, true));
+  // the same programs once more for batches whose tiles are whole cache lines (see `streaming` in emit_kernel); not for programs
+  // so long that a second copy would double a minute of assembly
+  if (!std::getenv("FDG_ISA_NO_STREAMING") && prog.ops.size() <= 60000 && prog.mc_n_k == 0 && prog.mc_n_t == 0) {
+    E.streaming = true;
+    ks.push_back(emit_kernel(E, p, prog, kname + "_nt", 1));
+    if (prog_acc && prog_acc->ops.size() <= 60000) ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc_nt", 1, true));
+    E.streaming = false;
+  }
   if (prog_rm && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm, kname + "_rm", 1, false, rm_bufs));
   if (coop && coop->supported) { ks.push_back(emit_coop(E, p, *coop, kname + "_coop")); ks.back().wg = 64 * coop->n_wave; }
   std::ostringstream &os = E.os;

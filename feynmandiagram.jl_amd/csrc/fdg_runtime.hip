@@ -384,6 +384,8 @@ static int ensure_module(fdg_graph *g) {
     hipFunction_t f;
     HIP_TRY(hipModuleGetFunction(&f, m, "fdg_isa_eval"));
     g->module = m; g->fn_isa = f;
+    { hipFunction_t fn; g->fn_isa_nt = hipModuleGetFunction(&fn, m, "fdg_isa_eval_nt") == hipSuccess ? (void *)fn : nullptr; (void)hipGetLastError(); }
+    { hipFunction_t fn; g->fn_isa_acc_nt = (g->has_acc && hipModuleGetFunction(&fn, m, "fdg_isa_eval_acc_nt") == hipSuccess) ? (void *)fn : nullptr; (void)hipGetLastError(); }
     if (g->has_w2) { hipFunction_t f2; HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_isa_eval_w2")); g->fn_isa_w2 = f2; }
     if (g->has_acc) { hipFunction_t f3; HIP_TRY(hipModuleGetFunction(&f3, m, "fdg_isa_eval_acc")); g->fn_isa_acc = f3; }
     if (g->has_rm) { hipFunction_t f4; HIP_TRY(hipModuleGetFunction(&f4, m, "fdg_isa_eval_rm")); g->fn_isa_rm = f4; }
@@ -490,13 +492,19 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     const size_t panel_all = (std::max(std::max(panel, panel3), panel4) + 4095) & ~(size_t)4095;
     rc = ensure_ws(g, panel_all + (size_t)grid3 * R * 512u + 4096);
     if (rc) return rc;
+    // a matrix whose 64-sample tiles are whole 128-byte lines (samples of a column contiguous, column stride a multiple of 16
+    // doubles, base on a line): the streaming variants may be used (non-temporal accesses would fetch a shared line twice)
+    auto line_aligned = [](const void *base, long sample_stride, long col_stride) {
+      return sample_stride == 1 && (col_stride & 15) == 0 && ((uintptr_t)base & 127) == 0 && !std::getenv("FDG_ISA_NO_STREAMING");
+    };
     // fused accumulation: acc[k] += sum_b w_b root_k(b) with per-lane accumulators inside the evaluator
     auto launch_acc = [&](const double *lf, long lss, long lls, const double *wt, long n) -> int {
       void *a_wsp = g->d_ws;
       double *part = (double *)((char *)g->d_ws + panel_all);
       long nwg = std::min<long>((n + 63) / 64, grid3), zero = 0;
       void *args[] = {(void *)&lf, &lss, &lls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt};
-      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+      void *fn = g->fn_isa_acc_nt && line_aligned(lf, lss, lls) ? g->fn_isa_acc_nt : g->fn_isa_acc;
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
       hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
       HIP_TRY(hipGetLastError());
       return FDG_OK;
@@ -521,7 +529,8 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
         long nwg = std::min<long>((n1 + 63) / 64, grid);
         const double *nowt = nullptr;
         void *args[] = {(void *)&lf1, &lss, &lls, (void *)&rt1, &rrs, &rrk, &a_wsp, &n1, &nwg, (void *)&nowt};
-        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+        void *fn = g->fn_isa_nt && line_aligned(lf1, lss, lls) && line_aligned(rt1, rrs, rrk) ? g->fn_isa_nt : g->fn_isa;
+        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
       }
       return FDG_OK;
     };
@@ -846,7 +855,7 @@ int fdg_graph_release_device(fdg_graph *g) {
     g->ws_bound = true;
     g->ws_key = nullptr;
   }
-  if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; g->fn_eval_sm = g->fn_eval_gen = nullptr; g->fn_isa = nullptr; }
+  if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; g->fn_eval_sm = g->fn_eval_gen = nullptr; g->fn_isa = nullptr; g->fn_isa_nt = g->fn_isa_acc_nt = nullptr; }
   if (g->fused_module) { hipModuleUnload((hipModule_t)g->fused_module); g->fused_module = nullptr; g->fn_fused = nullptr; }
   if (g->alt_module) { hipModuleUnload((hipModule_t)g->alt_module); g->alt_module = nullptr; g->fn_alt_sm = g->fn_alt_gen = nullptr; }
   if (g->mc_module) { hipModuleUnload((hipModule_t)g->mc_module); g->mc_module = nullptr; g->fn_mc = g->fn_mc_acc = nullptr; }
@@ -1041,6 +1050,7 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
   g->code_object.swap(co);
   g->isa = true;
   g->fn_isa = nullptr;
+  g->fn_isa_nt = g->fn_isa_acc_nt = nullptr;
   g->fn_isa_w2 = nullptr;
   g->fn_isa_acc = nullptr;
   g->has_acc = prog_acc != nullptr;
@@ -1668,7 +1678,7 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
   if (g->alt_module) { hipModuleUnload((hipModule_t)g->alt_module); g->alt_module = nullptr; }
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
   g->isa = false;
-  g->fn_isa = g->fn_isa_w2 = g->fn_isa_acc = nullptr;
+  g->fn_isa = g->fn_isa_w2 = g->fn_isa_acc = g->fn_isa_nt = g->fn_isa_acc_nt = nullptr;
   g->fn_eval_sm = g->fn_eval_gen = nullptr;
   g->has_w2 = g->has_acc = false;
   g->code_object.swap(co);

@@ -248,6 +248,45 @@ def test_config3_parquet_sigma4_at_full_size(libfdg, cuda):
                           np.stack([oracle.philox_uniform(1, t.n_leaf, 1234, int(i))[0] for i in probe]))
 
 
+@pytest.mark.parametrize("name", ["parquet_sigma4", "gv_sigma4", "gv_sigma5", "sigma2", "gv_sigma4_taylor2"])
+def test_streaming_variant_on_line_aligned_batches(libfdg, cuda, name, monkeypatch):
+    """Batches whose 64-sample tiles are whole cache lines (column stride a multiple of 16 doubles, bases on a line) take the
+    kernels with non-temporal leaf loads and root stores (`fdg_isa_eval_nt`, `fdg_isa_eval_acc_nt`); any other batch the
+    plain ones.  Same program, same bits: aligned, misaligned (odd stride; a view that starts 8 bytes into a line) and the
+    variant switched off must agree with each other and with the oracle; accumulate within the stated tolerance."""
+    import torch
+    t = workloads.get(name)
+    f = fd.compile_table(t, specialize="isa")
+    B = 64 * 331 + 16                                           # a multiple of 16, with a ragged last tile
+    leaf = dev_leaves(cuda, B, t.n_leaf, 77, 5, "leaf_major")
+    assert leaf.stride(1) % 16 == 0 and leaf.data_ptr() % 128 == 0
+    want = oracle.eval_static(t, leaf.cpu().numpy())
+    got = run(f, leaf)
+    assert np.array_equal(got, want)
+    odd = torch.empty((t.n_leaf, B + 1), dtype=torch.float64, device=cuda)[:, 1:].t()      # starts 8 bytes into a line, odd column stride
+    odd.copy_(leaf)
+    assert odd.data_ptr() % 128 != 0
+    assert np.array_equal(run(f, odd), want)
+    w = torch.rand(B, dtype=torch.float64, device=cuda)
+    acc = f.accumulate(leaf, w)
+    acc_odd = f.accumulate(odd, w)
+    torch.cuda.synchronize()
+    wr = want * w.cpu().numpy()[:, None]
+    for a in (acc, acc_odd):
+        assert np.all(np.abs(a.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0)))
+    monkeypatch.setenv("FDG_ISA_NO_STREAMING", "1")
+    assert np.array_equal(run(f, leaf), want)
+    monkeypatch.delenv("FDG_ISA_NO_STREAMING")
+    # the listing holds both forms
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        os.chmod(d, 0o700)
+        g = fd.compile_table(t, specialize="isa", cache_dir=d, flags=capi.FDG_SPEC_KEEP_SOURCE)
+        text = "".join(open(os.path.join(d, x)).read() for x in os.listdir(d) if x.endswith(".s"))
+        assert "fdg_isa_eval_nt:" in text and " nt\n" in text
+        assert np.array_equal(run(g, leaf), want)
+
+
 def test_full_size_properties_sigma4(libfdg, cuda):
     """Size-independent properties at a large batch of the headline graph (no CPU
     oracle over the whole batch): chunk invariance (a sample's roots do not
