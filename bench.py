@@ -165,7 +165,9 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
         ms = c.timed(steps, warm)
         avg = sum(ms) / len(ms) / 1e3
         ok, dev_max, n = c.parity_sample()
-        roof = roofline_of(c.st, c.B, avg, "fdg_isa_eval")
+        kern = ("fdg_isa_eval_coop" if workload in ("sigma4_standin", "sigma4_worstcase") else "fdg_isa_eval_nt" if layout == "leaf_major" and c.B % 16 == 0
+                else "fdg_isa_eval_rm" if layout == "sample_major" else "fdg_isa_eval")
+        roof = roofline_of(c.st, c.B, avg, kern)
         attach_traffic(roof, workload, layout, c.B, avg)
         if copy_gbs:
             roof["frac_of_measured_copy"] = roof["achieved"] / copy_gbs
@@ -369,6 +371,8 @@ def main():
     }
     kname = {"isa": "fdg_isa_eval", "interp": "fdg_interp", "auto": "fdg_isa_eval / fdg_spec_sm",
              "hip": "fdg_spec_sm" if args.layout == "sample_major" else "fdg_spec_gen"}[args.backend]
+    if args.backend == "isa" and args.layout == "leaf_major" and B % 16 == 0 and not os.environ.get("FDG_ISA_NO_STREAMING"):
+        kname = "fdg_isa_eval_nt"        # line-aligned column-major batch: the streaming form of the kernel
     copy_gbs = None
     if rank == 0:
         out["roofline"] = roofline_of(st, B, avg_kernel_s, kname)
