@@ -380,7 +380,7 @@ def main():
         try:
             copy_gbs = measured_copy(dev)
             out["roofline"]["measured_copy_gbs"] = copy_gbs
-            out["roofline"]["measured_copy_kernel"] = "fdg_copy_device (16 B per lane, 2 GiB, read + write counted)"
+            out["roofline"]["measured_copy_kernel"] = "fdg_copy_device (16 B per lane, non-temporal loads and stores, 2 GiB, read + write counted)"
             out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
         except RuntimeError:
             pass

@@ -262,20 +262,25 @@ fdg_fill_uniform(double *__restrict__ leaf, long B, uint32_t L, long ss, long ls
 
 // Harness only: the box's streaming ceiling.  16 bytes per lane; every workgroup copies its own contiguous span, four
 // 4 KB pieces in flight per wave (of the variants in tools/ubench/copy_rate.hip this one streams fastest on MI355X:
-// 5.5-5.7 TB/s read + write, against 4.7-5.3 for grid-strided loops and 5.05 for hipMemcpyDtoD).
+// 5.5-5.7 TB/s read + write, against 4.7-5.3 for grid-strided loops and 5.05 for hipMemcpyDtoD; 5.9-6.0 with non-temporal
+// loads and stores, the default).
 typedef double fdg_v2d __attribute__((ext_vector_type(2)));
-__global__ void __launch_bounds__(256)
-fdg_copy16(const fdg_v2d *__restrict__ src, fdg_v2d *__restrict__ dst, long n16) {
+template <bool NT>
+__device__ __forceinline__ void fdg_copy16_body(const fdg_v2d *__restrict__ src, fdg_v2d *__restrict__ dst, long n16) {
   const long per = (n16 + gridDim.x - 1) / gridDim.x;
   const long lo = blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
+  auto ld = [&](long i) { return NT ? __builtin_nontemporal_load(src + i) : src[i]; };
+  auto st = [&](long i, fdg_v2d v) { if (NT) __builtin_nontemporal_store(v, dst + i); else dst[i] = v; };
   for (long i = lo + threadIdx.x; i < hi; i += 1024) {
-    const fdg_v2d a = src[i], b = i + 256 < hi ? src[i + 256] : a, c = i + 512 < hi ? src[i + 512] : a, d = i + 768 < hi ? src[i + 768] : a;
-    dst[i] = a;
-    if (i + 256 < hi) dst[i + 256] = b;
-    if (i + 512 < hi) dst[i + 512] = c;
-    if (i + 768 < hi) dst[i + 768] = d;
+    const fdg_v2d a = ld(i), b = i + 256 < hi ? ld(i + 256) : a, c = i + 512 < hi ? ld(i + 512) : a, d = i + 768 < hi ? ld(i + 768) : a;
+    st(i, a);
+    if (i + 256 < hi) st(i + 256, b);
+    if (i + 512 < hi) st(i + 512, c);
+    if (i + 768 < hi) st(i + 768, d);
   }
 }
+__global__ void __launch_bounds__(256) fdg_copy16(const fdg_v2d *__restrict__ src, fdg_v2d *__restrict__ dst, long n16) { fdg_copy16_body<false>(src, dst, n16); }
+__global__ void __launch_bounds__(256) fdg_copy16_nt(const fdg_v2d *__restrict__ src, fdg_v2d *__restrict__ dst, long n16) { fdg_copy16_body<true>(src, dst, n16); }
 
 // ============================================================================
 // host side
@@ -1774,7 +1779,10 @@ int fdg_copy_device(double *d_dst, const double *d_src, int64_t n, void *stream)
   if (!d_dst || !d_src || (((uintptr_t)d_dst | (uintptr_t)d_src) & 15)) { set_error("fdg_copy_device: null or not 16-byte aligned"); return FDG_E_INVALID; }
   const long n16 = (long)(n / 2);
   const long grid = std::max<long>(1, std::min<long>(n16 / 1024, 65536L));
-  hipLaunchKernelGGL(fdg_copy16, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const fdg_v2d *)d_src, (fdg_v2d *)d_dst, n16);
+  if (!std::getenv("FDG_COPY_PLAIN"))     // non-temporal accesses: 5.96 TB/s against 5.53 (the ceiling a stream is measured against)
+    hipLaunchKernelGGL(fdg_copy16_nt, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const fdg_v2d *)d_src, (fdg_v2d *)d_dst, n16);
+  else
+    hipLaunchKernelGGL(fdg_copy16, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const fdg_v2d *)d_src, (fdg_v2d *)d_dst, n16);
   HIP_TRY(hipGetLastError());
   return FDG_OK;
 }
