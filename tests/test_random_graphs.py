@@ -172,7 +172,9 @@ def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch
             f = fd.compile_table(t, specialize="isa", opt=opt, cache_dir=str(cache), flags=capi.FDG_SPEC_KEEP_SOURCE)
             for layout in ("leaf_major", "sample_major"):
                 leaf = torch.from_numpy(np.ascontiguousarray(h_leaf.T)).to(cuda).t() if layout == "leaf_major" else torch.from_numpy(h_leaf).to(cuda)
-                root = torch.full((B, t.n_root), 9.0, dtype=torch.float64, device=cuda)
+                # (even seeds: the roots as a Julia column-major matrix too -- with B a multiple of 16 the streaming kernels run)
+                root = (torch.full((t.n_root, B), 9.0, dtype=torch.float64, device=cuda).t() if layout == "leaf_major" and seed % 2 == 0
+                        else torch.full((B, t.n_root), 9.0, dtype=torch.float64, device=cuda))
                 f(root, leaf)
                 torch.cuda.synchronize()
                 assert same(root.cpu().numpy(), want), (seed, opt, layout, B)

@@ -25,7 +25,8 @@ for seed in range(first, last + 1):
         f = fd.compile_table(t, specialize="isa", opt=opt, cache_dir="/tmp/fzs", flags=capi.FDG_SPEC_KEEP_SOURCE)
         for layout in ("leaf_major", "sample_major"):
             leaf = torch.from_numpy(np.ascontiguousarray(h_leaf.T)).to(dev).t() if layout == "leaf_major" else torch.from_numpy(h_leaf).to(dev)
-            root = torch.full((B, t.n_root), 9.0, dtype=torch.float64, device=dev)
+            root = (torch.full((t.n_root, B), 9.0, dtype=torch.float64, device=dev).t() if layout == "leaf_major" and seed % 2 == 0
+                    else torch.full((B, t.n_root), 9.0, dtype=torch.float64, device=dev))
             f(root, leaf); torch.cuda.synchronize()
             got = root.cpu().numpy()
             bad = ~((got == want) | (np.isnan(got) & np.isnan(want))) | ((np.signbit(got) != np.signbit(want)) & ~np.isnan(want))
