@@ -9,12 +9,15 @@ include/fdg.h, plus the host-side mirror of the reference interface for it.
 from . import graph as ComputationalGraphs
 from . import compilers as Compilers
 from . import frontends as FrontEnds
+from . import parquet as Parquet          # the reference's module names: FeynmanDiagram.Parquet, .GV, .Taylor
+from . import gv as GV
+from . import taylor as Taylor
 from .graph import (FeynmanGraph, Graph, PostOrderDFS, Power, Prod, Sum, Unitary, constant_graph,
                     external_vertex, linear_combination, multi_product)
 from .nodetable import NodeTable, synthetic_parquet_like, from_program
 from .lowering import lower
 from .compilers import GraphFunc, compile_table
 
-__all__ = ["ComputationalGraphs", "Compilers", "FrontEnds", "Graph", "FeynmanGraph", "Sum", "Prod", "Power", "Unitary",
+__all__ = ["ComputationalGraphs", "Compilers", "FrontEnds", "Parquet", "GV", "Taylor", "Graph", "FeynmanGraph", "Sum", "Prod", "Power", "Unitary",
            "constant_graph", "external_vertex", "linear_combination", "multi_product", "PostOrderDFS",
            "NodeTable", "synthetic_parquet_like", "from_program", "lower", "GraphFunc", "compile_table"]

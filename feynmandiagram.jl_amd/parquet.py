@@ -30,7 +30,7 @@ import functools
 import itertools
 import math
 import os
-from dataclasses import dataclass, field, replace
+from dataclasses import dataclass, replace
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 from .graph import Graph, Prod, Sum, uid
