@@ -53,11 +53,12 @@ class GraphFunc:
             # through the HIP-source JIT.  Both are JIT back ends of the same ABI, not fallbacks to a CPU.
             try:
                 self.handle.specialize(cache_dir, flags | capi.FDG_SPEC_ISA)
-                # compile_Python's row-major [B, L] is the reference's batched layout.  The ISA kernel wants
-                # leaf-major tiles and would transpose chunks first (two extra HBM passes); for small graphs
-                # the HIP-source kernels, whose lanes read their own rows, are faster on that layout
-                # (2-loop self-energy: 4.1e10 vs 1.6e10 evals/s), so they ride along as a companion.
-                if self.table.stats()["flops_alg"] <= 4000 and self.n_leaf <= 256:
+                # compile_Python's row-major [B, L] is the reference's batched layout.  Graphs with 16 leaves or more read it in
+                # place through the ISA back end's row-major variant (LDS staging: 4-loop self-energies 5.7e9 evals/s against
+                # 1.7e9 for the HIP-source kernels); below 16 leaves there is no such variant and the ISA kernel would transpose
+                # chunks first, so the HIP-source kernels, whose lanes read their own rows, ride along as a companion
+                # (2-loop self-energy: 4.3e10 vs 1.5e10 evals/s).
+                if self.n_leaf < 16:
                     self.handle.specialize(cache_dir, flags | capi.FDG_SPEC_ROW_MAJOR_COMPANION)
             except capi.FdgError as e:
                 if e.code != capi.FDG_E_UNSUPPORTED:

@@ -152,8 +152,9 @@ function compile_hip(graphs::AbstractVector{<:AbstractGraph};
         rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, flags)
         if rc == -2 && backend == :isa      # FDG_E_UNSUPPORTED: e.g. Power{N}, N > 3 -> HIP-source JIT
             rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, Cuint(0))
-        elseif rc == 0 && backend == :isa && length(idx) <= 4000 && L <= 256
-            # small graph: HIP-source companion for row-major [B, L] input (FDG_SPEC_ROW_MAJOR_COMPANION = 16)
+        elseif rc == 0 && backend == :isa && L < 16
+            # fewer than 16 leaves: no row-major variant of the ISA kernel; HIP-source companion for row-major [B, L] input
+            # (FDG_SPEC_ROW_MAJOR_COMPANION = 16)
             rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, Cuint(16))
         end
         _fdg_check(rc)

@@ -122,7 +122,7 @@ typedef struct fdg_graph_info {
 #define FDG_SPEC_ROW_MAJOR_COMPANION 16u /* keep the handle's current (FDG_SPEC_ISA) kernels and add the HIP-source ones next to
                                    * them; sample-major input (compile_Python's [B,L]: leaf stride 1) is then evaluated by the
                                    * companion, whose lanes read their own rows, instead of being transposed for the ISA
-                                   * kernel.  Worth it for small graphs (a few hundred nodes); same bits either way. */
+                                   * kernel.  Worth it below 16 leaves, where the ISA back end has no row-major variant of its own; same bits either way. */
 #define FDG_SPEC_ISA 4u           /* optimizing back end: own scheduler + register allocator, gfx950
                                      assembly printed directly (one VALU instruction per fold step) */
 

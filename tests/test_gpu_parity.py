@@ -567,8 +567,9 @@ def test_fused_mc_step(libfdg, cuda):
 
 
 def test_auto_backend_row_major_companion(libfdg, cuda):
-    """compile(..., "auto") on a small graph keeps the HIP-source kernels next to the ISA ones and evaluates
-    row-major [B, L] input (compile_Python's layout) with them; both layouts and accumulate give the oracle's bits."""
+    """compile(..., "auto") on a graph with fewer than 16 leaves keeps the HIP-source kernels next to the ISA ones and
+    evaluates row-major [B, L] input (compile_Python's layout) with them; larger graphs read it through the ISA back end's
+    row-major variant; both layouts and accumulate give the oracle's bits."""
     import torch
     for name in ("sigma2", "gv_sigma4"):
         t = workloads.get(name)
