@@ -89,6 +89,17 @@ def test_sigma_diagram_counts(loops):
     assert all(r["extT"][0] == para.firstTauIdx for r in rows)
 
 
+@pytest.mark.parametrize("loops", [1, 2, 3, 4])
+def test_sigma_diagram_counts_with_dynamic_interactions(loops):
+    """The same count with a Dynamic interaction (every line carries two time indices instead of one: same diagrams), and with
+    an Instant + Dynamic one (every one of the n interaction lines is either: 2^n times as many)."""
+    for types, mult in (((Dynamic,), 1), ((Instant, Dynamic), 2 ** loops)):
+        para = DiagPara(type=SigmaDiag, innerLoopNum=loops, isFermi=False, filter=(NoHartree, Girreducible), interaction=(Interaction(ChargeCharge, types),))
+        rows = pq.sigma(para, [1.0] + [0.0] * loops, False)
+        assert sum(all_ones([r["diagram"] for r in rows])) * (-1) ** loops == mult * pq.count_sigma_G2v(loops, 2)
+        assert all(r["extT"][0] == para.firstTauIdx for r in rows)
+
+
 # ---- test/front_end.jl:701-755: the 3-point vertex; :758-826: the polarization (three variants) -------------------------
 @pytest.mark.parametrize("loops", [1, 2, 3])
 def test_vertex3_diagram_counts(loops):
