@@ -370,3 +370,26 @@ def test_larger_graphs_of_the_reference_examples(name, sizes):
     assert (t.n_leaf, t.n_node, t.n_root) == sizes
     x = np.random.default_rng(2).uniform(0.5, 1.5, size=(2, t.n_leaf))
     assert np.allclose(oracle.eval_static(t, x), oracle.eval_interp(t, x), rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize("loops", [1, 2, 3, 4])
+def test_vertex_function_sums_agree_with_the_gv_vertex_catalogs(loops):
+    """``Parquet.vertex4(DiagPara(type=Ver4Diag, innerLoopNum=n))`` against ``GV.diagsGV_ver4(n)`` (catalogs
+    groups_vertex4/Vertex4<n>_0_0.diag: 3, 18, 138, 1 190 Hugenholtz diagrams): with all leaves 1 the UpDown rows sum to the
+    catalog's sum of SymFactor * SpinFactor over direct terms -- 2, -9, 40, -168 -- and the UpUp rows (direct + exchange) to 0;
+    no sign between them this time.  n = 4 is the graph of example/benchmark.jl against that of example/benchmark_GV.jl."""
+    import os
+    from feynmandiagram_jl_amd import gv
+    want = {1: 2.0, 2: -9.0, 3: 40.0, 4: -168.0}[loops]
+    rows = pq.vertex4(DiagPara(type=Ver4Diag, innerLoopNum=loops))
+    assert len(rows) == {1: 6, 2: 30, 3: 84, 4: 180}[loops]
+    v = all_ones([r["diagram"] for r in rows])
+    assert sum(x for x, r in zip(v, rows) if r["response"] == pq.UpDown) == want
+    assert sum(x for x, r in zip(v, rows) if r["response"] == pq.UpUp) == 0.0
+    if loops == 4:                                   # the shipped table of diagsGV_ver4(4): roots are (UpUp, UpDown) pairs
+        t = workloads.get("gv_ver4_4")
+        g = oracle.eval_static(t, np.ones((1, t.n_leaf)))[0]
+        assert g[1::2].sum() == want and g[0::2].sum() == 0.0
+    if os.path.isdir(REF_GV):
+        c = gv.parse_vertex4_catalog(f"{REF_GV}/groups_vertex4/Vertex4{loops}_0_0.diag")
+        assert _catalog_sums(c) == [0.0, want]
