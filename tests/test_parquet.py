@@ -393,3 +393,22 @@ def test_vertex_function_sums_agree_with_the_gv_vertex_catalogs(loops):
     if os.path.isdir(REF_GV):
         c = gv.parse_vertex4_catalog(f"{REF_GV}/groups_vertex4/Vertex4{loops}_0_0.diag")
         assert _catalog_sums(c) == [0.0, want]
+
+
+@pytest.mark.parametrize("loops", [1, 2, 3, 4, 5])
+def test_polarization_sums_agree_with_the_gv_polarization_catalogs(loops):
+    """``Parquet.polarization`` (fermionic, NoHartree) against the GV catalogs groups_charge/Polar<n>_0_0.diag and
+    groups_spin/Polar<n>_0_0.diag: with all leaves 1, spin * (UpUp + UpDown) is the charge catalog's sum of
+    SymFactor * SpinFactor (-2, 6, -10, -42, 558) and spin * (UpUp - UpDown) the spin catalog's (-2, 6, -18, 46, -66);
+    5 loops include the catalog vertex."""
+    import os
+    from feynmandiagram_jl_amd import gv
+    charge = {1: -2.0, 2: 6.0, 3: -10.0, 4: -42.0, 5: 558.0}[loops]
+    spin = {1: -2.0, 2: 6.0, 3: -18.0, 4: 46.0, 5: -66.0}[loops]
+    rows = pq.polarization(DiagPara(type=pq.PolarDiag, innerLoopNum=loops, filter=(NoHartree,)))
+    d = {r["response"]: float(x) for x, r in zip(all_ones([r["diagram"] for r in rows]), rows)}
+    uu, ud = d.get(pq.UpUp, 0.0), d.get(pq.UpDown, 0.0)
+    assert (2 * (uu + ud), 2 * (uu - ud)) == (charge, spin)
+    if os.path.isdir(REF_GV):
+        assert all_ones(gv.diagsGV("chargePolar", loops, REF_GV)).tolist() == [charge]
+        assert all_ones(gv.diagsGV("spinPolar", loops, REF_GV)).tolist() == [spin]
