@@ -17,7 +17,9 @@ the permutations and the second insertion order.  Pinned by: the optimized 2-loo
  reproduced up to the order of operands, and the diagram counts of the reference's own tests: the
 self-energy (1, 3, 18, 171; test/front_end.jl:600-652), the 3-point vertex (1, 10, 109; :701-755) and the polarization
 in three variants (2, 2, 20, 218 / 2, 2, 32, 326 / 2, 2, 28, 274; :758-826) -- the last two exercise ``vertex4`` with
-all three channels at the top level.
+all three channels at the top level; and by the reference's other front end: with fermionic signs the all-ones sums of
+the self-energy (2..6 loops), the vertex function (1..4) and the polarization (1..5) equal the sums of
+SymFactor * SpinFactor of the GV catalogs (tests/test_parquet.py).
 
 The fully irreducible vertex ``Alli`` at 3 and 4 loops comes, as in the reference, from the GV vertex catalogs
 (``vertex4I_diags``, parquet.jl:216-231; their numbers ship as data/vertex4I<n>.npz) through ``update_extKT``.  Not

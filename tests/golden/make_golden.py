@@ -53,6 +53,11 @@ def main():
                     leaf="ones", expect={"ver3_G2v": [1, 10, 109], "polar_G2v": [2, 2, 20, 218], "polar_g2v_noFock": [2, 2, 32, 326],
                                          "polar_g2v_noFock_upup": [2, 2, 28, 274]},
                     note="num * (-1)^n resp. num * spin * (-1)^(n-1); exact; tests/test_parquet.py"))
+    kat.append(dict(name="parquet_against_gv_catalog_sums", source="src/frontend/GV_diagrams/groups_sigma/Sigma{2..6}_0_0.diag, groups_vertex4/Vertex4{1..4}_0_0.diag, "
+                    "groups_charge|groups_spin/Polar{1..5}_0_0.diag: sums of SymFactor*SpinFactor computed from the catalog text",
+                    leaf="ones", expect={"sigma_dynamic_instant": {"2": [1, -1], "3": [-5, 1], "4": [21, 3], "5": [-77, -31], "6": [233, 167]},
+                                         "vertex4_updown": [2, -9, 40, -168], "polar_charge": [-2, 6, -10, -42, 558], "polar_spin": [-2, 6, -18, 46, -66]},
+                    note="the Parquet builder's fermionic graphs give the same sums (self-energy: times -1); tests/test_parquet.py"))
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(kat, f, indent=1, ensure_ascii=False)
     for name, B, seed in (("sigma2", 257, 1234), ("synthetic_small", 64, 1234), ("sigma4_standin", 16, 1234),
