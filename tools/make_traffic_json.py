@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root, out_path = sys.argv[1], sys.argv[2]
 SAMPLES = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "gv_sigma4": 8_000_000, "gv_sigma5": 2_000_000, "gv_sigma6": 500_000,
            "gv_sigma4_taylor2": 4_000_000, "parquet_sigma4": 100_000_000, "parquet_sigma4_dyn": 8_000_000, "parquet_sigma4_insdyn": 4_000_000,
-           "parquet_sigma4_taylor2": 8_000_000}
+           "parquet_sigma4_taylor2": 8_000_000, "parquet_sigma5": 2_000_000, "parquet_ver4_4": 500_000, "gv_ver4_4": 500_000}
 if os.path.exists(out_path):          # keep the entries of earlier profile sets: only the workloads found under `root` are replaced
     prev = json.load(open(out_path))
 else:
