@@ -459,7 +459,7 @@ def mc_step(t, workload, B, dev, fast_math):
         ms = e0.elapsed_time(e1) / n
         return {"value": B / ms * 1e3, "unit": "samples/s", "ms_per_call": ms, "samples_per_call": B,
                 "what": "fdg_mc_accumulate_device: leaves from (K, T) + graph + weighted accumulation; on this handle one kernel of the "
-                        "optimizing back end for programs of up to 40 000 ops (leaves are values computed in registers), leaf kernel + evaluator above",
+                        "optimizing back end for programs of up to 40 000 + 30 L ops (leaves are values computed in registers), leaf kernel + evaluator above",
                 "input_bytes_per_sample": 8 * (n_loop * dim + n_tau + 1), "parameters": {"kF": kF, "beta": beta, "lambda": lam},
                 "parity": "graph part bit-exact given the kernel's leaves; leaves within 1e-13 relative / 1e-12 of the largest Leibniz term of the oracle's (tests/test_gpu_parity.py)"}
     except Exception as e:                      # secondary: never takes the headline line down

@@ -1462,8 +1462,13 @@ bool fdg_mc_isa_supported(fdg_graph *g, const fdg_leaf_tables *tab, std::string 
   why = prog.why;
   // Very large graphs keep leaf kernel + evaluator: a leaf that is a computed value must be spilled where a leaf that is
   // input is simply read again, and beyond the on-chip levels that traffic outweighs the leaf matrix it saves
-  // (measured: 5-loop self-energy, 13 000 ops, one kernel 1.67x faster; its Taylor expansion, 67 000 ops, 0.9x)
-  if (recommended) *recommended = prog.supported && prog.n_valu <= 40000;
+  // (measured: 5-loop self-energy, 13 000 ops, one kernel 1.67x faster; its Taylor expansion, 479 leaves and 79 000 ops, 0.9x;
+  // the 4-loop vertex function of example/benchmark.jl, 984 leaves and 65 000 ops, 1.68x).  The other route writes and reads
+  // 16 bytes per leaf and sample, which is worth some tens of fold steps: the budget grows with the number of leaves.
+  if (std::getenv("FDG_MC_DEBUG"))
+    std::fprintf(stderr, "[mc] one-kernel program: valu %llu ld_leaf %llu ld_mem %llu st_mem %llu ld_lds %llu st_lds %llu\n", (unsigned long long)prog.n_valu,
+                 (unsigned long long)prog.n_ld_leaf, (unsigned long long)prog.n_ld_mem, (unsigned long long)prog.n_st_mem, (unsigned long long)prog.n_ld_lds, (unsigned long long)prog.n_st_lds);
+  if (recommended) *recommended = prog.supported && prog.n_valu <= 40000 + 30ull * g->prog.L;
   return prog.supported;
 }
 
