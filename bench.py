@@ -21,6 +21,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6    # AMD spec, FMA counted as 2 (not in the local guide)
+# The arithmetic contract forbids contraction, so a fold step is one v_add_f64 / v_mul_f64: half the FMA figure.
+# 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12 lane-operations per second (measured on the box, settled clocks: 34.4e12).
+FP64_NOFMA_PEAK_TOPS = 39.3
+FP64_NOFMA_MEASURED_TOPS = 34.4
+CONFIG5_TOTAL_SAMPLES = 1_000_000_000     # BASELINE.json config 5: 10^9 samples over the GPUs of the node
+LINE_LIMIT = 3000                         # bytes of the stdout line (the driver keeps the last ~8 KB of stdout)
+DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
 
 
 WORKLOAD_NOTES = {
@@ -31,7 +38,7 @@ WORKLOAD_NOTES = {
     "gv_sigma5": " (config 3 stand-in (i) / config 5: reference GV catalog Sigma5_0_0.diag through the restated reader + optimize!)",
     "gv_sigma6": " (config 3 stand-in (i): reference GV catalog Sigma6_0_0.diag through the restated reader + optimize!)",
     "parquet_sigma4": " (config 3: the 4-loop Parquet self-energy, Parquet.build(DiagPara(type=SigmaDiag, innerLoopNum=4, hasTau=true, filter=[NoHartree])) + optimize! "
-                      "through the restated front end (feynmandiagram.jl_amd/parquet.py; pinned by the reference's diagram counts 1, 3, 18, 171 and its rendering of the "
+                      "through the restated front end (feynmandiagram.jl_amd/producers/parquet.py; pinned by the reference's diagram counts 1, 3, 18, 171 and its rendering of the "
                       "2-loop graph); the reference's default interaction, ChargeCharge Instant: 1325 nodes after optimize!, 3646 before)",
     "parquet_sigma4_dyn": " (config 3 with a Dynamic interaction: 4819 nodes)",
     "parquet_sigma4_insdyn": " (config 3 with an Instant + Dynamic interaction: 20147 nodes)",
@@ -41,6 +48,12 @@ WORKLOAD_NOTES = {
     "parquet_ver4_4": " (the graph example/benchmark.jl builds: Parquet.vertex4(DiagPara(type=Ver4Diag, innerLoopNum=4)) + optimize!, 44854 nodes, 180 roots)",
     "gv_ver4_4": " (the graph example/benchmark_GV.jl:23 builds: GV.diagsGV_ver4(4) + optimize!, catalog Vertex44_0_0.diag, 31803 nodes, 26 roots)",
 }
+SHORT_NOTES = {     # <= 120 characters: what the stdout line says about the workload (the long notes go to bench_detail.json)
+    "parquet_sigma4": "parquet_sigma4: config 3, 4-loop Parquet self-energy (NoHartree) + optimize!, restated front end, 1325 nodes",
+    "parquet_sigma4_taylor2": "parquet_sigma4_taylor2: config 4, 4-loop Parquet self-energy + Taylor AD order 2 in the coupling, 7421 nodes",
+    "gv_sigma5": "gv_sigma5: config 5, GV 5th-order self-energy (catalog Sigma5_0_0.diag) + optimize!, 3897 nodes",
+    "sigma2": "sigma2: config 2, optimized 2-loop Parquet self-energy (reference rendering assets/sigma_o2.svg)",
+}
 DEFAULT_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcase": 1_000_000, "synthetic_small": 8_000_000,
              "gv_sigma4": 8_000_000, "gv_sigma5": 2_000_000, "gv_sigma6": 500_000, "gv_sigma4_taylor2": 4_000_000,
              "gv_sigma5_taylor2": 1_000_000, "parquet_sigma2": 64_000_000, "parquet_sigma3": 16_000_000, "parquet_sigma4": 100_000_000,
@@ -49,6 +62,57 @@ DEFAULT_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcas
              "parquet_ver4_4": 500_000, "gv_ver4_4": 500_000}
 PARITY_NOTE = ("bit-exact vs our restatement of the Julia evaluator (oracle/); the reference's known-answer tests pin structure, "
                "leaf numbering and factors, not the rounding of the n-ary folds")
+
+
+DRY = False      # --dry-run: no device work at all (gloo on CPU tensors); exercises sharding, the collective and the stdout line
+
+
+def sync():
+    if not DRY:
+        import torch
+        torch.cuda.synchronize()
+
+
+class Stamps:
+    """n+1 time stamps on the launch stream: HIP events (torch.cuda.Event sees only torch's current stream -- the one
+    the kernels are launched on), or host clocks in a dry run."""
+
+    def __init__(self, n, stream):
+        import torch
+        self.n, self.stream = n, stream
+        self.ev = [None] * (n + 1) if DRY else [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+
+    def record(self, i):
+        if DRY:
+            self.ev[i] = time.perf_counter()
+        else:
+            self.ev[i].record(self.stream)
+
+    def ms(self):
+        if DRY:
+            return [max((self.ev[i + 1] - self.ev[i]) * 1e3, 1e-6) for i in range(self.n)]
+        return [self.ev[i].elapsed_time(self.ev[i + 1]) for i in range(self.n)]
+
+
+class DryFunc:
+    """Stand-in for the compiled evaluator in a dry run: touches nothing but the accumulator, to which every call adds the
+    number of samples of the shard -- so the one collective's result is checkable (it must equal the job's sample count)."""
+
+    def __init__(self, count):
+        self.count = count
+
+    def __call__(self, root, leaf):
+        return root
+
+    def accumulate(self, leaf, w, acc):
+        acc += float(self.count)
+        return acc
+
+    def kernel_info(self):
+        return {"last_kernel": "dry-run", "n_valu": [0, 0, 0]}
+
+    def info(self):
+        return {"max_live": 0, "spec_vgpr": 0, "spec_lds_bytes": 0, "spec_scratch_bytes": 0}
 
 
 class Case:
@@ -62,6 +126,12 @@ class Case:
         self.t = t = workloads.get(workload)
         self.st = t.stats()
         L, R = t.n_leaf, t.n_root
+        self.sample_offset = sample_offset
+        if DRY:
+            self.f, self.stream = DryFunc(B), None
+            self.leaf = torch.zeros((1, L), dtype=torch.float64)
+            self.root = torch.zeros((min(B, 64), R), dtype=torch.float64)
+            return
         self.f = fd.compile_table(t, specialize={"isa": "isa", "isa-autotune": "isa-autotune", "auto": "auto", "hip": True, "interp": False}[backend], flags=flags)
         if layout == "sample_major":          # compile_Python's row-major [B, L] / [B, R]
             self.leaf = torch.empty((B, L), dtype=torch.float64, device=dev)
@@ -80,14 +150,14 @@ class Case:
         import torch
         for _ in range(warm):
             self.step()
-        torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-        ev[0].record(self.stream)
+        sync()
+        ev = Stamps(steps, self.stream)
+        ev.record(0)
         for i in range(steps):
             self.step()
-            ev[i + 1].record(self.stream)
-        torch.cuda.synchronize()
-        return [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+            ev.record(i + 1)
+        sync()
+        return ev.ms()
 
     def parity_sample(self, n=2048):
         """The first n samples of the last launch against the oracle's restatement of the compiled evaluator (C, one thread)."""
@@ -112,18 +182,44 @@ def observable_sum(root):
     return acc + rt[:, nb * c:].sum(dim=1) if nb * c < B else acc
 
 
-def roofline_of(st, B, avg_kernel_s, kernel, accumulate=False):
+def roofline_of(st, B, avg_kernel_s, kernel, accumulate=False, ops_exec=None):
+    """Both roofs of one launch and the one that binds.  HBM: algorithmic bytes 8(L+R) per evaluation (8L when the
+    roots are accumulated on chip) against 8 TB/s.  Vector ALU: the fold steps the kernel EXECUTES per evaluation
+    (`ops_exec`, from fdg_graph_kernel_info: after value numbering, one v_add_f64 / v_mul_f64 each -- no FMA by
+    contract) against 39.3e12 lane-op/s.  `bound` is the roof whose minimum time for this launch is larger; `frac`,
+    `achieved`, `peak`, `unit` refer to it; the other roof's fraction is printed next to it."""
     bytes_per_eval = st["bytes_alg_accumulate"] if accumulate else st["bytes_alg"]
-    achieved = bytes_per_eval * B / avg_kernel_s / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_eval * B}
+    gbs = bytes_per_eval * B / avg_kernel_s / 1e9
+    frac_hbm = gbs / HBM_PEAK_GBS
+    out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_hbm, "traffic": None,
+           "kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_eval * B,
+           "frac_hbm": frac_hbm, "frac_valu": None, "ops_exec_per_eval": ops_exec}
+    if ops_exec:
+        tops = ops_exec * B / avg_kernel_s / 1e12
+        out["frac_valu"] = tops / FP64_NOFMA_PEAK_TOPS
+        out["valu_tops"] = tops
+        out["frac_valu_of_measured_peak"] = tops / FP64_NOFMA_MEASURED_TOPS
+        if out["frac_valu"] > frac_hbm:      # the launch cannot be shorter than ops / peak: the vector ALU is the binding roof
+            out.update({"bound": "valu_fp64", "achieved": tops, "peak": FP64_NOFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": out["frac_valu"]})
+    return out
+
+
+def kernel_of(f, slot=0):
+    """(name of the kernel the last call launched, fold steps it executes per evaluation) from the handle itself."""
+    try:
+        ki = f.kernel_info()
+    except Exception:
+        return "", None
+    name = ki["last_kernel"]
+    slot = 1 if "_acc" in name else 2 if name.endswith("_rm") else 0
+    return name, (ki["n_valu"][slot] or None)
 
 
 def attach_traffic(roof, workload, layout, B, avg_kernel_s):
     """HBM bytes per launch from the rocprofv3 --pmc passes of the same command (bench.py cannot collect counters on
     itself): profiles/r02_traffic.json holds bytes per evaluation, scaled here to this batch -- a value from the named
     profile, not a measurement of this run."""
-    for fn in ("r02_traffic.json", "r01_traffic.json"):
+    for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", fn))).get(workload if layout == "leaf_major" else workload + ":" + layout)
         except (OSError, ValueError):
@@ -133,8 +229,9 @@ def attach_traffic(roof, workload, layout, B, avg_kernel_s):
             roof["traffic_gbs"] = tr["bytes_per_eval"] * B / avg_kernel_s / 1e9
             roof["traffic_frac"] = roof["traffic_gbs"] / HBM_PEAK_GBS
             roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
-            roof["traffic_source"] = ("NOT measured in this run: (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes, profiles/" + fn +
-                                      " (" + tr.get("source", "") + "), per evaluation, scaled to this batch")
+            roof["traffic_source"] = "profiles/" + fn + " (separate --pmc pass, not this run)"
+            roof["traffic_source_detail"] = ("(2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (" + tr.get("source", "") +
+                                             "), per evaluation, scaled to this batch")
             return
 
 
@@ -165,9 +262,8 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
         ms = c.timed(steps, warm)
         avg = sum(ms) / len(ms) / 1e3
         ok, dev_max, n = c.parity_sample()
-        kern = ("fdg_isa_eval_coop" if workload in ("sigma4_standin", "sigma4_worstcase") else "fdg_isa_eval_nt" if layout == "leaf_major" and c.B % 16 == 0
-                else "fdg_isa_eval_rm" if layout == "sample_major" else "fdg_isa_eval")
-        roof = roofline_of(c.st, c.B, avg, kern)
+        kern, ops_exec = kernel_of(c.f)
+        roof = roofline_of(c.st, c.B, avg, kern, ops_exec=ops_exec)
         attach_traffic(roof, workload, layout, c.B, avg)
         if copy_gbs:
             roof["frac_of_measured_copy"] = roof["achieved"] / copy_gbs
@@ -186,53 +282,62 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
         return {"workload": workload, "layout": layout, "error": f"{type(e).__name__}: {e}"}
 
 
+def config5_steps(world, per_gpu=None, total=CONFIG5_TOTAL_SAMPLES):
+    """Steps per rank so that all ranks together evaluate BASELINE.json's 10^9 samples (independent of --steps)."""
+    per_gpu = per_gpu or DEFAULT_B["gv_sigma5"]
+    return max(1, -(-total // (per_gpu * world)))
+
+
 def config5(dev, rank, world, dist, comm, steps, warm):
-    """BASELINE.json config 5 (example/benchmark_GV.jl as BASELINE.json words it: the GV 5th-order self-energy, samples
+    """BASELINE.json config 5 (example/benchmark_GV.jl as BASELINE.json words it: the GV 5th-order self-energy, 10^9 samples
     sharded over the GPUs, one final reduce): per step fdg_accumulate_device on this rank's shard -- weighted
-    accumulation inside the evaluator, roots never reach HBM --, after the last step ONE all-reduce of R doubles."""
+    accumulation inside the evaluator, roots never reach HBM --, after the last step ONE all-reduce of R doubles.
+    `steps` = config5_steps(world): 500 steps of 2e6 samples on one GPU, 63 on eight."""
     import torch
     from feynmandiagram_jl_amd.sharding import reduce_observable, shard_range
     try:
         B = DEFAULT_B["gv_sigma5"]
         start, count = shard_range(B * world, rank, world)
         c = Case("gv_sigma5", "leaf_major", count, dev, sample_offset=start)
-        w = torch.rand(count, dtype=torch.float64, device=dev)
+        w = torch.rand(1 if DRY else count, dtype=torch.float64, device=dev)
         acc = torch.zeros(c.t.n_root, dtype=torch.float64, device=dev)
         for _ in range(warm):
             c.f.accumulate(c.leaf, w, acc)
         acc.zero_()
-        torch.cuda.synchronize()
+        sync()
         if dist:
             dist.barrier()
-            torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            sync()
+        ev = Stamps(steps, c.stream)
         t0 = time.perf_counter()
-        ev[0].record(c.stream)
+        ev.record(0)
         for i in range(steps):
             c.f.accumulate(c.leaf, w, acc)
-            ev[i + 1].record(c.stream)
+            ev.record(i + 1)
         reduce_observable(acc, comm=comm)     # the one collective: R doubles over xGMI (RCCL)
-        torch.cuda.synchronize()
+        sync()
         if dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
         elapsed = time.perf_counter() - t0
         if dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+        ms = ev.ms()
         avg = sum(ms) / len(ms) / 1e3
         total = float(count) * steps * world
-        roof = roofline_of(c.st, count, avg, "fdg_isa_eval_acc + fdg_reduce_lane_partials", accumulate=True)
+        kern, ops_exec = kernel_of(c.f)
+        roof = roofline_of(c.st, count, avg, kern + " + fdg_reduce_lane_partials", accumulate=True, ops_exec=ops_exec)
         out = {"workload": "gv_sigma5" + WORKLOAD_NOTES["gv_sigma5"], "value": total / elapsed, "unit": "samples/s (whole job)", "n_gpus": world,
                "steps": steps, "warmup": warm, "samples_per_step_per_gpu": count, "total_samples": total,
-               "samples_to_config5_total": "1e9 samples = %d steps of this size at this GPU count" % round(1e9 / (count * world)),
+               "shard_offset_rank0": start, "baseline_total_samples": CONFIG5_TOTAL_SAMPLES,
                "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "roofline_rank0": roof,
                "observable": [float(x) for x in acc.cpu()],
                "what": "fdg_accumulate_device per step on the rank's shard; one all-reduce of R doubles after the last step, inside the timed region"}
         del c, w
-        torch.cuda.empty_cache()
+        if not DRY:
+            torch.cuda.empty_cache()
         return out
     except Exception as e:
         return {"workload": "gv_sigma5", "error": f"{type(e).__name__}: {e}"}
@@ -266,7 +371,12 @@ def main():
     ap.add_argument("--no-mc-step", action="store_true", help="skip the secondary measurement of the whole Monte-Carlo step (leaves from momenta and times)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other workloads (config 2, 3 stand-ins, 5, row-major layout) measured after the headline")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no device work: one process per rank on the CPU (gloo), the evaluator replaced by a stub that adds the shard's "
+                         "sample count to the accumulator; checks sharding, the one collective and the stdout line (tests/test_bench_line.py)")
     args = ap.parse_args()
+    global DRY
+    DRY = bool(args.dry_run)
 
     import numpy as np
     import torch
@@ -283,10 +393,14 @@ def main():
     if world > 1 or os.environ.get("FDG_BENCH_FORCE_DIST"):   # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    comm = make_comm(rank, world) if (dist and args.comm == "fdg") else None
+        dist.init_process_group("gloo" if DRY else "nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+    if DRY:
+        dev = torch.device("cpu")
+        args.no_cpu_baseline = args.no_mc_step = True
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    comm = make_comm(rank, world) if (dist and args.comm == "fdg" and not DRY) else None
 
     if args.interp:
         args.backend = "interp"
@@ -295,7 +409,7 @@ def main():
     # channels (measured: -3 % on the default workload, -14 % on sigma2).
     B = args.samples or DEFAULT_B.get(args.workload, 1_000_000)
     t_probe = workloads.get(args.workload)
-    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    free_b = (1 << 62) if DRY else torch.cuda.mem_get_info(dev)[0]
     while not args.samples and 8 * B * (t_probe.n_leaf + t_probe.n_root) > 0.6 * free_b and B > 1_000_000:
         B //= 2                         # (a 288 GB device holds config 3's 1e8 samples of 84 leaves, 70 GB, with room to spare)
     # per-rank Philox offset: results do not depend on how samples are sharded
@@ -311,7 +425,7 @@ def main():
 
     step()
     _ = observable_sum(root)              # load the reduction used for the final observable now: a pause between the
-    torch.cuda.synchronize()              # warm-up and the timed steps would let the clocks fall back
+    sync()                                # warm-up and the timed steps would let the clocks fall back
     # Clock settling: after idle the first ~50 launches run at transient clocks (boost, then throttle, then the
     # sustained state: 1.10 -> 1.40 -> 1.05-1.15 ms per launch on the default workload).  The timed steps are meant to
     # show the sustained rate, so at least 60 untimed launches precede them whatever --warmup says (disclosed in the
@@ -319,28 +433,28 @@ def main():
     settle = max(0, 60 - args.warmup)
     for _ in range(settle + args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if dist:
         dist.barrier()
-        torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        sync()
+    ev = Stamps(args.steps, stream)
     t0 = time.perf_counter()
-    ev[0].record(stream)
+    ev.record(0)
     for i in range(args.steps):
         step()
-        ev[i + 1].record(stream)          # same stream the kernel is launched on
+        ev.record(i + 1)                  # same stream the kernel is launched on
     acc = observable_sum(root)            # final observable accumulation
     reduce_observable(acc, comm=comm)     # the one collective: R doubles over xGMI (RCCL)
-    torch.cuda.synchronize()
+    sync()
     if dist:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     elapsed = time.perf_counter() - t0
     if dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    kern_ms = ev.ms()
     avg_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3
 
     total_evals = float(B) * args.steps * world
@@ -358,26 +472,28 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64" if not args.fast_math else "f64 (fused multiply-add: within 1e-12, not bit-identical)",
-        "data": "synthetic",
+        "data": "synthetic" if not DRY else "dry-run: no device work, timings meaningless",
         "config": {"workload": args.workload + WORKLOAD_NOTES.get(args.workload, ""),
                    "graph": t.name, "n_leaf": L, "n_node": t.n_node, "n_edge": t.n_edge, "n_root": R,
                    "flops_per_eval": st["flops_alg"], "bytes_per_eval": st["bytes_alg"],
-                   "samples_per_step_per_gpu": B, "layout": args.layout, "settle_steps": settle,
+                   "samples_per_step_per_gpu": B, "layout": args.layout, "settle_steps": settle, "shard_offset_rank0": start,
                    "kernel": {"isa": "fdg_isa_eval (per-graph gfx950 assembly)", "hip": "fdg_spec (per-graph HIP source, hiprtc)",
                               "auto": "fdg_isa_eval, or its HIP-source companion fdg_spec_sm for row-major input of small graphs",
                               "interp": "fdg_interp (table interpreter)"}[args.backend],
                    "parallelism": f"samples sharded x{world}, one all-reduce of {R} doubles",
                    "parity": PARITY_NOTE},
     }
-    kname = {"isa": "fdg_isa_eval", "interp": "fdg_interp", "auto": "fdg_isa_eval / fdg_spec_sm",
-             "hip": "fdg_spec_sm" if args.layout == "sample_major" else "fdg_spec_gen"}[args.backend]
-    if args.backend == "isa" and args.layout == "leaf_major" and B % 16 == 0 and not os.environ.get("FDG_ISA_NO_STREAMING"):
-        kname = "fdg_isa_eval_nt"        # line-aligned column-major batch: the streaming form of the kernel
+    kname, ops_exec = kernel_of(f)        # the kernel the library actually launched, and what it executes per evaluation
     copy_gbs = None
     if rank == 0:
-        out["roofline"] = roofline_of(st, B, avg_kernel_s, kname)
-        achieved = out["roofline"]["achieved"]
+        out["roofline"] = roofline_of(st, B, avg_kernel_s, kname, ops_exec=ops_exec)
+        achieved = st["bytes_alg"] * B / avg_kernel_s / 1e9
+        fr = sorted(st["bytes_alg"] * B / (m * 1e-3) / 1e9 / HBM_PEAK_GBS for m in kern_ms)
+        out["roofline"]["frac_hbm_min_over_steps"] = fr[0]
+        out["roofline"]["frac_hbm_max_over_steps"] = fr[-1]
         try:
+            if DRY:
+                raise RuntimeError("dry run")
             copy_gbs = measured_copy(dev)
             out["roofline"]["measured_copy_gbs"] = copy_gbs
             out["roofline"]["measured_copy_kernel"] = "fdg_copy_device (16 B per lane, non-temporal loads and stores, 2 GiB, read + write counted)"
@@ -393,14 +509,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(t, leaf, root, args.cpu_seconds)
     del case, leaf, root, f, step
-    torch.cuda.empty_cache()
+    if not DRY:
+        torch.cuda.empty_cache()
     # ---- after and outside the headline's timed region ---------------------------------------------------------
     if args.backend == "isa" and not args.no_secondary and not args.fast_math:
         # config 5 runs on every rank (its one collective needs them all); the rest on rank 0 at N = 1 only
-        c5 = config5(dev, rank, world, dist if world > 1 or os.environ.get("FDG_BENCH_FORCE_DIST") else None, comm, steps=max(20, min(args.steps, 100)), warm=30)
+        c5 = config5(dev, rank, world, dist if world > 1 or os.environ.get("FDG_BENCH_FORCE_DIST") else None, comm, steps=config5_steps(world), warm=30)
         if rank == 0:
             out["config5"] = c5
-        if rank == 0 and world == 1:
+        if rank == 0 and world == 1 and not DRY:
             sec = []
             head = (args.workload, args.layout)
             for wl, lay in (("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "leaf_major"),
@@ -415,9 +532,82 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_mc_step and args.backend == "isa":
             out["mc_step"] = mc_step(t, args.workload, min(B, 16_000_000), dev, args.fast_math)
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        # the full objects go to bench_detail.json (and stderr); stdout gets ONE short line the driver can parse
+        try:
+            with open(DETAIL_PATH, "w") as fh:
+                json.dump(out, fh, indent=1)
+        except OSError as e:
+            print(f"[bench] cannot write {DETAIL_PATH}: {e}", file=sys.stderr)
+        print("[bench] detail: " + json.dumps(out), file=sys.stderr)
+        os.write(real_stdout, (compact_line(out) + "\n").encode())
     if dist:
         dist.destroy_process_group()
+
+
+def _r(x, n=4):
+    """Short number for the stdout line: n significant digits."""
+    if x is None or isinstance(x, (str, bool, int)):
+        return x
+    return float(f"{x:.{n}g}")
+
+
+def compact_line(full):
+    """The ONE stdout line: the contract's keys, the headline's roofline and cpu_baseline, and the other measurements as
+    short rows -- everything else stays in bench_detail.json.  Kept under LINE_LIMIT bytes (tests/test_bench_line.py)."""
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data") if k in full}
+    line["value"] = _r(line.get("value"), 6)
+    line["ms_per_step"] = _r(line.get("ms_per_step"), 6)
+    cfg = full.get("config", {})
+    line["config"] = {"workload": SHORT_NOTES.get(cfg.get("workload", "").split(" ")[0], cfg.get("workload", "").split(" ")[0])[:120]}
+    for k in ("n_leaf", "n_node", "n_root", "samples_per_step_per_gpu", "layout", "settle_steps", "parallelism"):
+        if k in cfg:
+            line["config"][k] = cfg[k]
+    roof = full.get("roofline")
+    if roof:
+        keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_kernel_ms",
+                "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy",
+                "ops_exec_per_eval")
+        line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:60]) for k in keep if k in roof}
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": str(cb.get("sample", ""))[:110], "gpu_matches_cpu_bitwise": cb.get("gpu_matches_cpu_bitwise")}
+    sec = full.get("secondary")
+    if sec:
+        line["secondary_cols"] = ["workload", "layout", "evals_per_s", "bound", "frac", "frac_hbm", "frac_valu", "traffic_ratio", "bitwise"]
+        rows = []
+        for e in sec:
+            if "error" in e:
+                rows.append([e.get("workload", "?")[:24], e.get("layout"), None, "error", None, None, None, None, False])
+                continue
+            r = e["roofline"]
+            rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm"}.get(e["layout"], e["layout"]), _r(e["value"]),
+                         {"hbm": "hbm", "valu_fp64": "valu"}.get(r["bound"], r["bound"]), _r(r["frac"], 3), _r(r.get("frac_hbm"), 3),
+                         _r(r.get("frac_valu"), 3), _r(r.get("traffic_over_algorithmic"), 3), e.get("gpu_matches_cpu_bitwise")])
+        line["secondary"] = rows
+    c5 = full.get("config5")
+    if c5:
+        if "error" in c5:
+            line["config5"] = {"error": c5["error"][:80]}
+        else:
+            r = c5.get("roofline_rank0", {})
+            line["config5"] = {"workload": "gv_sigma5", "value": _r(c5["value"], 5), "unit": "samples/s", "n_gpus": c5["n_gpus"], "total_samples": c5["total_samples"],
+                               "steps": c5["steps"], "bound": r.get("bound"), "frac": _r(r.get("frac"), 3), "frac_hbm": _r(r.get("frac_hbm"), 3),
+                               "frac_valu": _r(r.get("frac_valu"), 3)}
+    mc = full.get("mc_step")
+    if mc:
+        line["mc_step"] = {"value": _r(mc.get("value"), 5), "unit": "samples/s", "leaf_parity": "unpinned (Lehmann.jl absent)",
+                           "max_dev_over_Sk": _r(mc.get("max_dev_over_Sk"), 3), "max_dev_over_Ak": _r(mc.get("max_dev_over_Ak"), 3)} if "error" not in mc else {"error": mc["error"][:80]}
+    line["detail"] = "bench_detail.json"
+    text = json.dumps(line, separators=(",", ":"))
+    # never let the line outgrow the driver's capture: drop the optional parts, least important first
+    for k in ("mc_step", "secondary", "secondary_cols", "config5"):
+        if len(text) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
 
 
 def mc_step(t, workload, B, dev, fast_math):
@@ -457,7 +647,28 @@ def mc_step(t, workload, B, dev, fast_math):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
+        # checker (outside any timed region): the first 2048 samples against the pure oracle chain -- numpy leaves from
+        # (K, T), then the oracle's graph -- relative to the root's own term scale S_k (BASELINE.json's bar: 1e-12) and to
+        # the absolute-value graph A_k (the first-order bound for leaves that differ in their last bit)
+        dev_S = dev_A = None
+        try:
+            import oracle
+            nchk = int(min(B, 2048))
+            Kh = dK[:, :nchk].t().contiguous().cpu().numpy().reshape(nchk, n_loop, dim)
+            Th = dT[:, :nchk].t().contiguous().cpu().numpy()
+            h_leaf = oracle.leaf_values(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], Kh, Th, kF, beta, lam)
+            want = oracle.eval_static(t, h_leaf)
+            rt = torch.zeros((nchk, t.n_root), dtype=torch.float64, device=dev)
+            h.mc_eval_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, rt.data_ptr(), t.n_root, 1, nchk, st)
+            torch.cuda.synchronize()
+            err = np.abs(rt.cpu().numpy() - want)
+            dev_S = float(np.nanmax(err / np.maximum(1.0, oracle.root_scale(t, h_leaf))))
+            dev_A = float(np.nanmax(err / np.maximum(1.0, oracle.abs_graph_scale(t, h_leaf))))
+        except Exception as e:
+            print(f"[bench] mc_step checker: {type(e).__name__}: {e}", file=sys.stderr)
         return {"value": B / ms * 1e3, "unit": "samples/s", "ms_per_call": ms, "samples_per_call": B,
+                "max_dev_over_Sk": dev_S, "max_dev_over_Ak": dev_A, "checked_samples": 2048,
+                "leaf_parity": "unpinned: green_derive restates Lehmann.jl's published definition (Lehmann.jl is not in the reference checkout); pinned by mpmath only",
                 "what": "fdg_mc_accumulate_device: leaves from (K, T) + graph + weighted accumulation; on this handle one kernel of the "
                         "optimizing back end for programs of up to 40 000 + 30 L ops (leaves are values computed in registers), leaf kernel + evaluator above",
                 "input_bytes_per_sample": 8 * (n_loop * dim + n_tau + 1), "parameters": {"kF": kF, "beta": beta, "lambda": lam},

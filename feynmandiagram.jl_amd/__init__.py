@@ -5,19 +5,18 @@ computational graphs (package directory ``feynmandiagram.jl_amd``; import it as
 Scope: the graph *evaluation* hot path only --
 ``Compilers.compile`` -> ``eval_graph!(root, leafVal)`` -- behind the C ABI of
 include/fdg.h, plus the host-side mirror of the reference interface for it.
+The restated producers of the benchmark graphs (Parquet / GV / optimize! / Taylor) live in ``producers/``: workload
+generators for tests and bench.py, not product, and not exported here.
 """
 from . import graph as ComputationalGraphs
 from . import compilers as Compilers
 from . import frontends as FrontEnds
-from . import parquet as Parquet          # the reference's module names: FeynmanDiagram.Parquet, .GV, .Taylor
-from . import gv as GV
-from . import taylor as Taylor
 from .graph import (FeynmanGraph, Graph, PostOrderDFS, Power, Prod, Sum, Unitary, constant_graph,
                     external_vertex, linear_combination, multi_product)
 from .nodetable import NodeTable, synthetic_parquet_like, from_program
 from .lowering import lower
 from .compilers import GraphFunc, compile_table
 
-__all__ = ["ComputationalGraphs", "Compilers", "FrontEnds", "Parquet", "GV", "Taylor", "Graph", "FeynmanGraph", "Sum", "Prod", "Power", "Unitary",
+__all__ = ["ComputationalGraphs", "Compilers", "FrontEnds", "Graph", "FeynmanGraph", "Sum", "Prod", "Power", "Unitary",
            "constant_graph", "external_vertex", "linear_combination", "multi_product", "PostOrderDFS",
            "NodeTable", "synthetic_parquet_like", "from_program", "lower", "GraphFunc", "compile_table"]

@@ -32,6 +32,7 @@ EXPORTS = [
     "fdg_eval_strided", "fdg_graph_coop_program", "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
+    "fdg_graph_kernel_info",
 ]
 COMM_ID_BYTES = 128
 
@@ -63,6 +64,12 @@ class GraphInfo(C.Structure):
 
     def asdict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class KernelInfo(C.Structure):
+    _fields_ = [("last_kernel", C.c_char * 48), ("n_valu", C.c_uint64 * 3), ("n_ld_leaf", C.c_uint32 * 3),
+                ("n_panel", C.c_uint32 * 3), ("n_lds", C.c_uint32 * 3), ("waves_per_cu", C.c_uint32 * 3),
+                ("has_acc", C.c_uint32), ("has_rm", C.c_uint32), ("has_coop", C.c_uint32), ("rm_bufs", C.c_uint32)]
 
 
 class LeafTables(C.Structure):
@@ -109,6 +116,10 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
+    # the code objects and tuned parameters shipped with the package: a read-only secondary lookup (fdg_runtime.hip: read_cached)
+    ro = os.environ.get("FDG_CACHE_RO_DIR", "")
+    if KERNEL_CACHE not in ro.split(":"):
+        os.environ["FDG_CACHE_RO_DIR"] = (ro + ":" if ro else "") + KERNEL_CACHE
     L = C.CDLL(LIB_PATH)
     vp, i64, u64, u32, dp = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p
     L.fdg_last_error.restype = C.c_char_p
@@ -116,6 +127,7 @@ def lib():
     L.fdg_graph_create.argtypes = [C.POINTER(GraphDesc), C.POINTER(vp)]
     L.fdg_graph_destroy.argtypes = [vp]
     L.fdg_graph_query.argtypes = [vp, C.POINTER(GraphInfo)]
+    L.fdg_graph_kernel_info.argtypes = [vp, C.POINTER(KernelInfo)]
     L.fdg_graph_emit_source.argtypes = [vp, C.c_uint, C.POINTER(C.c_char_p)]
     L.fdg_free.argtypes = [vp]
     L.fdg_free.restype = None
@@ -202,6 +214,18 @@ class GraphHandle:
         check(lib().fdg_graph_query(self._h, C.byref(gi)))
         return gi.asdict()
 
+    def kernel_info(self) -> dict:
+        """What the ISA kernels of this handle execute per evaluation (slot 0 evaluator, 1 accumulate, 2 row-major) and the
+        name of the kernel the last device call launched."""
+        ki = KernelInfo()
+        check(lib().fdg_graph_kernel_info(self._h, C.byref(ki)))
+        out = {"last_kernel": ki.last_kernel.decode()}
+        for k in ("n_valu", "n_ld_leaf", "n_panel", "n_lds", "waves_per_cu"):
+            out[k] = [int(x) for x in getattr(ki, k)]
+        for k in ("has_acc", "has_rm", "has_coop", "rm_bufs"):
+            out[k] = int(getattr(ki, k))
+        return out
+
     def emit_source(self, flags: int = 0) -> str:
         s = C.c_char_p()
         check(lib().fdg_graph_emit_source(self._h, flags, C.byref(s)))
@@ -269,9 +293,10 @@ class GraphHandle:
         return progs, info
 
     def specialize(self, cache_dir: Optional[str] = None, flags: int = 0):
-        cd = cache_dir if cache_dir is not None else os.environ.get("FDG_CACHE_DIR", KERNEL_CACHE)
-        os.makedirs(cd, exist_ok=True)
-        check(lib().fdg_graph_specialize(self._h, cd.encode(), flags))
+        """``cache_dir`` None: the library's per-user cache ($FDG_CACHE_DIR, $XDG_CACHE_HOME/fdg, ~/.cache/fdg); the
+        kernel_cache directory shipped inside the package is only *read* (``FDG_CACHE_RO_DIR``, set in :func:`lib`), so a
+        root-owned or read-only installation works.  ``__graft_entry__.build()`` passes ``KERNEL_CACHE`` to fill it."""
+        check(lib().fdg_graph_specialize(self._h, cache_dir.encode() if cache_dir else None, flags))
 
     # raw-pointer device entry points (ints are device addresses) ----------- #
     def eval_device(self, d_leaf: int, ss: int, ls: int, d_root: int, rs: int, rk: int, B: int, stream: int = 0):
@@ -283,9 +308,7 @@ class GraphHandle:
     # fused Monte-Carlo step: leaves from (K, T) in registers, then the graph --------------------- #
     def specialize_fused(self, tables, cache_dir: Optional[str] = None, flags: int = 0):
         """``tables`` = the struct returned by make_leaf_tables."""
-        cd = cache_dir if cache_dir is not None else os.environ.get("FDG_CACHE_DIR", KERNEL_CACHE)
-        os.makedirs(cd, exist_ok=True)
-        check(lib().fdg_graph_specialize_fused(self._h, C.byref(tables), cd.encode(), flags))
+        check(lib().fdg_graph_specialize_fused(self._h, C.byref(tables), cache_dir.encode() if cache_dir else None, flags))
 
     def mc_eval_device(self, d_K, ks, kc, d_T, ts, tc, kF, beta, lam, d_root, rs, rk, B, stream=0):
         check(lib().fdg_mc_eval_device(self._h, d_K, ks, kc, d_T, ts, tc, kF, beta, lam, d_root, rs, rk, B, stream))

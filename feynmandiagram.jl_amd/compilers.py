@@ -53,12 +53,13 @@ class GraphFunc:
             # through the HIP-source JIT.  Both are JIT back ends of the same ABI, not fallbacks to a CPU.
             try:
                 self.handle.specialize(cache_dir, flags | capi.FDG_SPEC_ISA)
-                # compile_Python's row-major [B, L] is the reference's batched layout.  Graphs with 16 leaves or more read it in
-                # place through the ISA back end's row-major variant (LDS staging: 4-loop self-energies 5.7e9 evals/s against
-                # 1.7e9 for the HIP-source kernels); below 16 leaves there is no such variant and the ISA kernel would transpose
-                # chunks first, so the HIP-source kernels, whose lanes read their own rows, ride along as a companion
-                # (2-loop self-energy: 4.3e10 vs 1.5e10 evals/s).
-                if self.n_leaf < 16:
+                # compile_Python's row-major [B, L] is the reference's batched layout.  Most graphs read it in place through
+                # the ISA back end's row-major variant (LDS staging: 4-loop self-energies 5.7e9 evals/s against 1.7e9 for
+                # the HIP-source kernels).  Handles without that variant (fewer than 16 leaves, the tiny-graph
+                # configuration, plans that would re-fetch too much) would transpose chunks in front of the ISA kernel, so
+                # for small graphs the HIP-source kernels, whose lanes read their own rows, ride along as a companion
+                # (2-loop self-energy: 4.3e10 vs 1.5e10 evals/s).  The handle says which case it is.
+                if not self.handle.kernel_info()["has_rm"] and self.n_leaf > 1 and self.table.n_node <= 4000:
                     self.handle.specialize(cache_dir, flags | capi.FDG_SPEC_ROW_MAJOR_COMPANION)
             except capi.FdgError as e:
                 if e.code != capi.FDG_E_UNSUPPORTED:
@@ -76,6 +77,9 @@ class GraphFunc:
     # -- introspection ------------------------------------------------------- #
     def info(self) -> dict:
         return self.handle.info()
+
+    def kernel_info(self) -> dict:
+        return self.handle.kernel_info()
 
     def specialize(self, cache_dir: Optional[str] = None, flags: int = 0) -> "GraphFunc":
         self.handle.specialize(cache_dir, flags)

@@ -122,6 +122,11 @@ struct fdg_graph {
   bool has_rm = false;
   void *fn_isa_rm = nullptr;
   uint32_t isa4_vgpr = 0, isa4_lds_bytes = 0, isa4_mem_slots = 0;
+  // what the installed programs execute per evaluation (fdg_graph_kernel_info): [0] eval, [1] accumulate, [2] row-major
+  uint64_t st_valu[3] = {0, 0, 0};
+  uint32_t st_ld_leaf[3] = {0, 0, 0}, st_panel[3] = {0, 0, 0}, st_lds[3] = {0, 0, 0};
+  uint32_t rm_bufs = 0;
+  const char *last_kernel = "";    // evaluator kernel of the last device call (guarded by mu)
   // cooperative variant: the four waves of a CU evaluate one tile together (graphs whose live set overflows one lane)
   bool has_coop = false, coop_enabled = false;
   void *fn_isa_coop = nullptr;
@@ -185,6 +190,7 @@ namespace fdg { const char *last_error_cstr(); }
 uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull);
 int fdg_cache_dir(const char *arg, std::string &dir);   // resolves, creates (0700) and vets the JIT cache directory
 bool read_file(const std::string &path, std::vector<char> &out);
+bool read_cached(const std::string &dir, const std::string &fname, std::vector<char> &out);   // dir, then $FDG_CACHE_RO_DIR
 bool write_file(const std::string &path, const char *data, size_t n);
 int compile_hiprtc(const std::string &src, bool fast, std::vector<char> &co, std::string &log);
 int compile_hipcc(const std::string &src_path, const std::string &out_path, bool fast, std::string &log);

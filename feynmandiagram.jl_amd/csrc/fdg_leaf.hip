@@ -248,7 +248,7 @@ static hipFunction_t leaf_spec_function(const fdg_leaf_tables *tab, const std::v
   const bool have_dir = fdg_cache_dir(nullptr, dir) == FDG_OK;     // no usable cache directory: compile, do not cache
   const std::string base = dir + "/fdg_leaf_" + hbuf;
   std::vector<char> co;
-  if (!have_dir || !read_file(base + ".hsaco", co)) {
+  if (!read_cached(have_dir ? dir : std::string(), std::string("fdg_leaf_") + hbuf + ".hsaco", co)) {
     std::string log;
     if (compile_hiprtc(src, false, co, log) != 0) {
       cache.push_back(LeafModule{dev, hbuf, nullptr, nullptr});   // do not retry on every call
@@ -413,7 +413,7 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
   { const int rcd = fdg_cache_dir(cache_dir, dir); if (rcd) return rcd; }
   const std::string base = dir + "/fdg_fused_" + hbuf;
   std::vector<char> co;
-  if (!read_file(base + ".hsaco", co)) {
+  if (!read_cached(dir, std::string("fdg_fused_") + hbuf + ".hsaco", co)) {
     std::string log;
     if (compile_hiprtc(src, false, co, log) != 0) {
       std::string log2;

@@ -1320,7 +1320,7 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
   // ---- publication intervals and shared slots ---------------------------------------------------------------------------
   out.n_priv_lds = NW == 4 ? 16 : (NW == 8 ? 8 : 4);
   if (const char *e = std::getenv("FDG_COOP_PRIV_LDS")) out.n_priv_lds = (uint32_t)std::max(1, std::min(70, std::atoi(e)));
-  out.n_shared = 312 - NW * out.n_priv_lds;
+  out.n_shared = std::min<uint32_t>(256, 312 - NW * out.n_priv_lds);   // (the emitter addresses shared slots as two banks of 128)
   struct Interval { uint32_t node, start, end, slot; };
   std::vector<Interval> ivs;
   {

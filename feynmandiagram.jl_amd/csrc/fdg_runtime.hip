@@ -13,6 +13,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -469,6 +470,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_spec_gen"));
       g->alt_module = m; g->fn_alt_sm = f1; g->fn_alt_gen = f2;
     }
+    g->last_kernel = "fdg_spec_sm";
     return launch_hip_source(g, (hipFunction_t)g->fn_alt_sm, mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st);
   }
   if (!g->code_object.empty() && g->isa) {
@@ -502,6 +504,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     auto line_aligned = [](const void *base, long sample_stride, long col_stride) {
       return sample_stride == 1 && (col_stride & 15) == 0 && ((uintptr_t)base & 127) == 0 && !std::getenv("FDG_ISA_NO_STREAMING");
     };
+    bool named = false;
     // fused accumulation: acc[k] += sum_b w_b root_k(b) with per-lane accumulators inside the evaluator
     auto launch_acc = [&](const double *lf, long lss, long lls, const double *wt, long n) -> int {
       void *a_wsp = g->d_ws;
@@ -509,6 +512,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       long nwg = std::min<long>((n + 63) / 64, grid3), zero = 0;
       void *args[] = {(void *)&lf, &lss, &lls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt};
       void *fn = g->fn_isa_acc_nt && line_aligned(lf, lss, lls) ? g->fn_isa_acc_nt : g->fn_isa_acc;
+      g->last_kernel = fn == g->fn_isa_acc ? "fdg_isa_eval_acc" : "fdg_isa_eval_acc_nt";
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
       hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
       HIP_TRY(hipGetLastError());
@@ -525,6 +529,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
         const double *nowt = nullptr;
         void *args[] = {(void *)&lf, &lss, &lls, (void *)&rt, &rrs, &rrk, &a_wsp, &n2, &nwg, (void *)&nowt};
         HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_w2, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+        g->last_kernel = "fdg_isa_eval_w2";
         done = n2;
       }
       if (done < n) {
@@ -535,6 +540,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
         const double *nowt = nullptr;
         void *args[] = {(void *)&lf1, &lss, &lls, (void *)&rt1, &rrs, &rrk, &a_wsp, &n1, &nwg, (void *)&nowt};
         void *fn = g->fn_isa_nt && line_aligned(lf1, lss, lls) && line_aligned(rt1, rrs, rrk) ? g->fn_isa_nt : g->fn_isa;
+        if (!named && done == 0) g->last_kernel = fn == g->fn_isa ? "fdg_isa_eval" : "fdg_isa_eval_nt";
         HIP_TRY(hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
       }
       return FDG_OK;
@@ -563,6 +569,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       const double *nowt = nullptr;
       void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &n, &nwg, (void *)&nowt};
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_coop, (unsigned)nwg, 1, 1, g->coop_threads, 1, 1, 0, st, args, nullptr));
+      g->last_kernel = "fdg_isa_eval_coop";
       return FDG_OK;
     }
     // Row-major leaves ([B, L], leaf stride 1) and evaluation: full 64-row tiles go through the variant that stages chunks
@@ -575,6 +582,8 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       const double *nowt = nullptr;
       void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &n4, &nwg, (void *)&nowt};
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rm, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+      g->last_kernel = "fdg_isa_eval_rm";
+      named = true;                    // (the last B % 64 rows below do not rename the call)
       if (n4 == B) return FDG_OK;
       d_leaf += (size_t)n4 * (size_t)ss;
       d_root += (size_t)n4 * (size_t)rs;
@@ -652,11 +661,13 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
   if (!g->code_object.empty()) {
     rc = ensure_module(g);
     if (rc) return rc;
+    g->last_kernel = ls == 1 ? "fdg_spec_sm" : "fdg_spec_gen";
     return launch_hip_source(g, (hipFunction_t)((ls == 1) ? g->fn_eval_sm : g->fn_eval_gen), mode, d_leaf, ss, ls, d_root, rs, rk,
                              d_weight, d_acc, B, st);
   }
 
   // interpreter
+  g->last_kernel = "fdg_interp";
   rc = ensure_code(g);
   if (rc) return rc;
   const bool staged = (ls == 1 && ss != 1 && p.L > 0);
@@ -701,14 +712,15 @@ uint64_t fnv1a(const std::string &s, uint64_t h) {
 }
 
 // Cache artefacts are code that will run on the GPU and parameters that size register files: only files owned by the
-// calling user and not writable by anybody else are read back (FDG_CACHE_TRUST=1 lifts the ownership test, e.g. for a
-// read-only cache shipped by an administrator).
+// calling user or by root and not writable by everybody are read back.  (The group bit is not tested: the assembler and
+// the linker create their outputs under the caller's umask, 0664/0775 under umask 002, and the directory they sit in is
+// vetted by fdg_cache_dir.  FDG_CACHE_TRUST=1 lifts the ownership test.)
 static bool cache_trust() { static const bool t = std::getenv("FDG_CACHE_TRUST") != nullptr; return t; }
 bool read_file(const std::string &path, std::vector<char> &out) {
   const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
   if (fd < 0) return false;
   struct stat sb;
-  if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || (!cache_trust() && (sb.st_uid != geteuid() || (sb.st_mode & 022)))) { ::close(fd); return false; }
+  if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || (!cache_trust() && ((sb.st_uid != geteuid() && sb.st_uid != 0) || (sb.st_mode & 002)))) { ::close(fd); return false; }
   out.resize((size_t)sb.st_size);
   size_t got = 0;
   while (got < out.size()) {
@@ -721,9 +733,39 @@ bool read_file(const std::string &path, std::vector<char> &out) {
   return !out.empty();
 }
 
-// written under a process-unique name, then renamed: readers (other ranks JIT-ing the same graph) never see half a file
+// Lookup of a cached artefact: the (writable, vetted) cache directory first, then the read-only directories named by
+// $FDG_CACHE_RO_DIR (colon-separated; e.g. the kernel_cache a package ships, which may belong to root or sit in a
+// read-only checkout).  A read-only directory and the file in it must belong to the caller or to root and must not be
+// world-writable; nothing is ever written there.
+bool read_cached(const std::string &dir, const std::string &fname, std::vector<char> &out) {
+  if (!dir.empty() && read_file(dir + "/" + fname, out)) return true;
+  const char *ro = std::getenv("FDG_CACHE_RO_DIR");
+  if (!ro || !*ro) return false;
+  std::string all = ro;
+  size_t pos = 0;
+  while (pos <= all.size()) {
+    const size_t e = all.find(':', pos);
+    const std::string d = all.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+    pos = e == std::string::npos ? all.size() + 1 : e + 1;
+    if (d.empty() || d == dir) continue;
+    struct stat sb;
+    if (stat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) continue;
+    if (!cache_trust() && ((sb.st_uid != geteuid() && sb.st_uid != 0) || (sb.st_mode & 002))) continue;
+    if (read_file(d + "/" + fname, out)) return true;
+  }
+  return false;
+}
+
+// suffix of intermediate files: unique per process AND per call (two threads of one process may specialise two handles of
+// the same graph at the same time)
+static std::string tmp_suffix() {
+  static std::atomic<unsigned long> counter{0};
+  return ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(counter.fetch_add(1));
+}
+
+// written under a unique name, then renamed: readers (other ranks JIT-ing the same graph) never see half a file
 bool write_file(const std::string &path, const char *data, size_t n) {
-  const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+  const std::string tmp = path + tmp_suffix();
   const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
   if (fd < 0) return false;
   size_t put = 0;
@@ -750,12 +792,24 @@ int fdg_cache_dir(const char *arg, std::string &dir) {
   if (dir.find_first_of("'\"\n") != std::string::npos) { set_error("cache directory path contains a quote or a newline: " + dir); return FDG_E_INVALID; }
   mkdir(dir.c_str(), 0700);
   struct stat sb;
-  if (stat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) { set_error("cannot create the cache directory " + dir); return FDG_E_JIT; }
-  if (!cache_trust() && (sb.st_uid != geteuid() || (sb.st_mode & 022))) {
-    set_error("cache directory " + dir + " must be owned by the calling user and not be writable by group or others (FDG_CACHE_TRUST=1 overrides)");
-    return FDG_E_JIT;
+  const bool exists = stat(dir.c_str(), &sb) == 0 && S_ISDIR(sb.st_mode);
+  const bool usable = exists && (cache_trust() || (sb.st_uid == geteuid() && !(sb.st_mode & 022)));
+  if (usable) return FDG_OK;
+  if (!(arg && *arg)) {
+    // the default location cannot be used (foreign owner, group-writable home, read-only file system): compile into a
+    // private directory of this process instead of failing -- nothing is cached across runs then
+    static std::mutex mu;
+    static std::string priv;
+    std::lock_guard<std::mutex> lk(mu);
+    if (priv.empty()) {
+      char tmpl[] = "/tmp/fdg-XXXXXX";
+      if (mkdtemp(tmpl)) priv = tmpl;
+    }
+    if (!priv.empty()) { dir = priv; return FDG_OK; }
   }
-  return FDG_OK;
+  if (!exists) { set_error("cannot create the cache directory " + dir); return FDG_E_JIT; }
+  set_error("cache directory " + dir + " must be owned by the calling user and not be writable by group or others (FDG_CACHE_TRUST=1 overrides)");
+  return FDG_E_JIT;
 }
 
 // runs argv (no shell), stdout + stderr appended to `log_path`; returns the exit status, -1 when it could not be run
@@ -768,7 +822,7 @@ static int run_cmd(const std::vector<std::string> &argv, const std::string &log_
   if (pid == 0) {
     const int fd = ::open(log_path.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0600);
     if (fd >= 0) { dup2(fd, 1); dup2(fd, 2); ::close(fd); }
-    execv(av[0], av.data());
+    execvp(av[0], av.data());      // PATH search: FDG_HIPCC=hipcc or a relative FDG_LLVM_BIN work
     _exit(127);
   }
   int status = 0;
@@ -803,10 +857,11 @@ int compile_hiprtc(const std::string &src, bool fast, std::vector<char> &co, std
 
 int compile_hipcc(const std::string &src_path, const std::string &out_path, bool fast, std::string &log) {
   const char *hipcc = std::getenv("FDG_HIPCC");
-  const std::string tmp = out_path + ".tmp." + std::to_string((long)getpid());
+  const std::string tmp = out_path + tmp_suffix();
   const int rc = run_cmd({hipcc ? hipcc : "/opt/rocm/bin/hipcc", "--genco", "--offload-arch=gfx950", "-O3",
                           fast ? "-ffp-contract=fast" : "-ffp-contract=off", "-o", tmp, src_path}, tmp + ".log");
   log = slurp_and_remove(tmp + ".log");
+  if (rc == 0) ::chmod(tmp.c_str(), 0644);      // whatever the umask: the artefact must pass read_file's vetting
   if (rc != 0 || std::rename(tmp.c_str(), out_path.c_str()) != 0) { std::remove(tmp.c_str()); return -1; }
   return 0;
 }
@@ -884,6 +939,26 @@ int fdg_graph_query(const fdg_graph *g, fdg_graph_info *o) {
   o->max_live = p.max_live; o->n_slot_lds = p.lds_slots; o->n_slot_mem = p.mem_slots; o->n_ops = p.n_ops;
   o->specialized = g->code_object.empty() ? 0 : 1;
   o->spec_vgpr = g->spec_vgpr; o->spec_lds_bytes = g->spec_lds; o->spec_scratch_bytes = g->spec_scratch;
+  return FDG_OK;
+}
+
+int fdg_graph_kernel_info(fdg_graph *g, fdg_kernel_info *o) {
+  if (!g || !o) { set_error("null argument"); return FDG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  std::memset(o, 0, sizeof *o);
+  std::snprintf(o->last_kernel, sizeof o->last_kernel, "%s", g->last_kernel ? g->last_kernel : "");
+  if (!(g->isa && !g->code_object.empty())) return FDG_OK;
+  auto wpc = [](uint32_t vgpr, uint32_t lds_bytes) {      // the rule of fdg_run_locked (without its environment override)
+    const uint32_t valloc = std::max<uint32_t>(8, (vgpr + 7) & ~7u);
+    uint32_t per_cu = std::min<uint32_t>(8, 512 / valloc) * 4;
+    if (lds_bytes) per_cu = std::min<uint32_t>(per_cu, (160u * 1024u) / lds_bytes);
+    return std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32));
+  };
+  for (int i = 0; i < 3; ++i) { o->n_valu[i] = g->st_valu[i]; o->n_ld_leaf[i] = g->st_ld_leaf[i]; o->n_panel[i] = g->st_panel[i]; o->n_lds[i] = g->st_lds[i]; }
+  o->waves_per_cu[0] = wpc(g->isa_vgpr, g->isa_lds_bytes);
+  if (g->has_acc) o->waves_per_cu[1] = wpc(g->isa3_vgpr, g->isa3_lds_bytes);
+  if (g->has_rm) o->waves_per_cu[2] = wpc(g->isa4_vgpr, g->isa4_lds_bytes);
+  o->has_acc = g->has_acc; o->has_rm = g->has_rm; o->has_coop = g->has_coop && g->coop_enabled; o->rm_bufs = g->rm_bufs;
   return FDG_OK;
 }
 
@@ -1015,10 +1090,10 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
   hash = hbuf;
   const std::string base = dir + "/fdg_isa_" + hbuf;
-  if (!read_file(base + ".hsaco", co)) {
+  if (!read_cached(dir, std::string("fdg_isa_") + hbuf + ".hsaco", co)) {
     // every intermediate under a process-unique name (ranks of one job assemble the same graph at the same time);
     // the code object appears under its final name by rename
-    const std::string tmp = base + ".tmp." + std::to_string((long)getpid());
+    const std::string tmp = base + tmp_suffix();
     if (!write_file(tmp + ".s", src.c_str(), src.size())) { set_error("cannot write " + tmp + ".s"); return FDG_E_JIT; }
     const char *llvm = std::getenv("FDG_LLVM_BIN");
     const std::string bin = llvm ? llvm : "/opt/rocm/lib/llvm/bin";
@@ -1028,6 +1103,7 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
     std::remove((tmp + ".o").c_str());
     if (flags & FDG_SPEC_KEEP_SOURCE) std::rename((tmp + ".s").c_str(), (base + ".s").c_str());
     else std::remove((tmp + ".s").c_str());
+    if (rc == 0) ::chmod((tmp + ".hsaco").c_str(), 0644);     // ld.lld creates it 0775/0777 & ~umask
     if (rc != 0 || std::rename((tmp + ".hsaco").c_str(), (base + ".hsaco").c_str()) != 0 || !read_file(base + ".hsaco", co)) {
       std::remove((tmp + ".hsaco").c_str());
       set_error("assembling the ISA kernel failed:\n" + log.substr(0, 2000));
@@ -1082,6 +1158,17 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
   g->isa_lds_bytes = prog.n_lds_used * 512u;
   g->isa_mem_slots = prog.n_mem_used;
   g->spec_vgpr = g->isa_vgpr; g->spec_lds = g->isa_lds_bytes; g->spec_scratch = 0;
+  {
+    const fdg::OptProgram *pp[3] = {&prog, prog_acc, g->has_rm ? prog_rm : nullptr};
+    for (int i = 0; i < 3; ++i) {
+      g->st_valu[i] = pp[i] ? pp[i]->n_valu : 0;
+      g->st_ld_leaf[i] = pp[i] ? (uint32_t)pp[i]->n_ld_leaf : 0;
+      g->st_panel[i] = pp[i] ? (uint32_t)(pp[i]->n_ld_mem + pp[i]->n_st_mem) : 0;
+      g->st_lds[i] = pp[i] ? (uint32_t)(pp[i]->n_ld_lds + pp[i]->n_st_lds) : 0;
+    }
+    g->rm_bufs = g->has_rm ? rm_bufs : 0;
+    g->last_kernel = "";
+  }
   g->spec_source_hash = hash;
   g->spec_flags = flags;
 }
@@ -1257,7 +1344,7 @@ static int assemble_and_install(fdg_graph *g, const fdg::OptProgram &prog, const
 static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   const std::string tuned = tuned_path(g, dir);
   std::vector<char> buf;
-  if (!read_file(tuned, buf)) return 0;
+  if (!read_cached(dir, tuned.substr(dir.size() + 1), buf)) return 0;
   fdg::OptParams q;
   int tuned_coop = -1;
   buf.push_back(0);
@@ -1659,7 +1746,7 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
   { const int rcd = fdg_cache_dir(cache_dir, dir); if (rcd) return rcd; }
   const std::string base = dir + "/fdg_" + hbuf;
   std::vector<char> co;
-  if (!read_file(base + ".hsaco", co)) {
+  if (!read_cached(dir, std::string("fdg_") + hbuf + ".hsaco", co)) {
     std::string log;
     const char *force = std::getenv("FDG_JIT");  // "hipcc" forces the subprocess path
     int rc = -1;

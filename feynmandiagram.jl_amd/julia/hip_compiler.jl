@@ -150,12 +150,17 @@ function compile_hip(graphs::AbstractVector{<:AbstractGraph};
         flags = backend == :isa ? (FDG_SPEC_ISA | (autotune ? FDG_SPEC_AUTOTUNE : Cuint(0))) : Cuint(0)
         cdir = isnothing(cache_dir) ? C_NULL : cache_dir
         rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, flags)
-        if rc == -2 && backend == :isa      # FDG_E_UNSUPPORTED: e.g. Power{N}, N > 3 -> HIP-source JIT
+        if rc == -2 && backend == :isa      # FDG_E_UNSUPPORTED (the ISA back end covers every operator of the reference; kept for future ones)
             rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, Cuint(0))
-        elseif rc == 0 && backend == :isa && L < 16
-            # fewer than 16 leaves: no row-major variant of the ISA kernel; HIP-source companion for row-major [B, L] input
-            # (FDG_SPEC_ROW_MAJOR_COMPANION = 16)
-            rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, Cuint(16))
+        elseif rc == 0 && backend == :isa && L > 1 && length(op) <= 4000
+            # a handle without a row-major variant of the ISA kernel (fdg_kernel_info.has_rm == 0: fewer than 16 leaves, the
+            # tiny-graph configuration): HIP-source companion for row-major [B, L] input (FDG_SPEC_ROW_MAJOR_COMPANION = 16)
+            ki = zeros(UInt8, 160)              # sizeof(fdg_kernel_info): 48 + 3*8 + 4*3*4 + 4*4 = 136, rounded up
+            _fdg_check(ccall((:fdg_graph_kernel_info, _libfdg), Cint, (Ptr{Cvoid}, Ptr{UInt8}), h[], ki))
+            has_rm = reinterpret(UInt32, ki[125:128])[1]      # offset 124: has_acc at 120, has_rm at 124
+            if has_rm == 0
+                rc = ccall((:fdg_graph_specialize, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cuint), h[], cdir, Cuint(16))
+            end
         end
         _fdg_check(rc)
     end

@@ -15,7 +15,7 @@ import math
 import re
 from typing import List, Optional, Sequence, Tuple
 
-from .graph import Graph, Prod, Sum, linear_combination, multi_product
+from ..graph import Graph, Prod, Sum, linear_combination, multi_product
 
 __all__ = ["read_diagrams", "diagsGV", "read_vertex4diagrams", "diagsGV_ver4", "parse_vertex4_catalog", "BareGreenId", "BareInteractionId",
            "SigmaId", "PolarId", "GenericId", "Ver4Id"]

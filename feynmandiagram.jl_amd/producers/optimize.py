@@ -14,7 +14,7 @@ from __future__ import annotations
 
 from typing import Dict, List, Sequence
 
-from .graph import Graph, Power, Prod, Sum, isleaf, onechild, unary_istrivial
+from ..graph import Graph, Power, Prod, Sum, isleaf, onechild, unary_istrivial
 
 __all__ = ["optimize_", "remove_duplicated_leaves_", "flatten_all_chains_", "merge_all_linear_combinations_",
            "remove_all_zero_valued_subgraphs_", "remove_duplicated_nodes_", "isequiv", "count_operation"]

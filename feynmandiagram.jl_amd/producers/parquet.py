@@ -35,7 +35,7 @@ import os
 from dataclasses import dataclass, replace
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
-from .graph import Graph, Prod, Sum, uid
+from ..graph import Graph, Prod, Sum, uid
 from .gv import BareGreenId, BareInteractionId, GenericId, PolarId, SigmaId, Ver4Id, _Id
 
 __all__ = ["DiagPara", "Interaction", "ParquetBlocks", "build", "sigma", "vertex4", "vertex3", "polarization", "green", "orderedPartition",
@@ -577,7 +577,7 @@ def get_ver4I(order: int):
     catalog numbers shipped in data/vertex4I<order>.npz (tests/golden/make_vertex4_catalogs.py)."""
     import numpy as np
     from .gv import read_vertex4diagrams
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"vertex4I{order}.npz")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", f"vertex4I{order}.npz")
     return read_vertex4diagrams(dict(np.load(path)), 0.0, (NoHartree,), (Alli,))
 
 

@@ -20,7 +20,7 @@ from __future__ import annotations
 import math
 from typing import Callable, Dict, Generic, List, Optional, Sequence, Tuple, TypeVar
 
-from .graph import Graph, Power, Prod, Sum, isleaf
+from ..graph import Graph, Power, Prod, Sum, isleaf
 
 T = TypeVar("T")
 Order = Tuple[int, ...]

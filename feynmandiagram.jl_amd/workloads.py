@@ -15,7 +15,7 @@ Each maps to a config of BASELINE.json:
                     restated optimize! (tests/golden/make_gv_tables.py; shipped in data/)
   sigma4_taylor_standin  config 4: the same enlarged x3 with 2 % Power{2} nodes
   parquet_sigma{2,3,4}[_dyn|_insdyn][_taylor2]
-                    configs 1-4 from the restated Parquet front end (parquet.py): ``Parquet.build(DiagPara(type=SigmaDiag,
+                    configs 1-4 from the restated Parquet front end (producers/parquet.py): ``Parquet.build(DiagPara(type=SigmaDiag,
                     innerLoopNum=n, hasTau=true, filter=[NoHartree]))`` -> ``optimize!``; interaction ChargeCharge
                     Instant (the reference's default; 4 loops: L 84, N 1 325, R 4), ``_dyn`` Dynamic (L 175, N 4 819,
                     R 7), ``_insdyn`` both (L 312, N 20 147, R 8: the size BASELINE.json quotes as "~10^4 nodes" lies
@@ -74,7 +74,7 @@ def parquet_graphs(name: str):
     """The optimized graphs of a ``parquet_sigma<n>[_dyn|_insdyn]`` / ``parquet_ver4_<n>`` workload and the front end's table rows."""
     import re
 
-    from . import optimize, parquet as pq
+    from .producers import optimize, parquet as pq
     m = re.fullmatch(r"parquet_(sigma|ver4_)(\d)(_dyn|_insdyn)?", name)
     if not m:
         raise KeyError(name)
@@ -90,7 +90,7 @@ def parquet_graphs(name: str):
 @functools.lru_cache(maxsize=None)
 def _parquet_lowered(name: str):
     """(table, leafmap) of a parquet workload."""
-    from . import gv, optimize, taylor
+    from .producers import gv, optimize, taylor
     from .lowering import lower
     taylor2 = name.endswith("_taylor2")
     graphs, _ = parquet_graphs(name[:-len("_taylor2")] if taylor2 else name)

@@ -25,6 +25,8 @@
  *                            travel to HBM.
  *   fdg_fill_uniform_device <- test/bench harness: counter-based leaf values on
  *                            device (the examples draw them from MCIntegration).
+ *   fdg_graph_kernel_info <- no counterpart (the reference's evaluator is one Julia function): which hand-written
+ *                            kernel ran and what it executes per evaluation, for the roofline in bench.py.
  *   fdg_graph_destroy, fdg_graph_query, fdg_last_error: lifetime / errors
  *                            (Julia exceptions in the reference, static.jl:6-11).
  *
@@ -134,6 +136,22 @@ int fdg_version(void);
 int fdg_graph_create(const fdg_graph_desc *desc, fdg_graph **out);
 int fdg_graph_destroy(fdg_graph *g);
 int fdg_graph_query(const fdg_graph *g, fdg_graph_info *info);
+
+/* What the specialised kernels of a handle execute per evaluation and which of them the last device call launched --
+ * the figures a roofline needs (bench.py: executed fold steps against the fp64 issue peak, bytes against HBM) without
+ * guessing on the host side which variant the library picked.  Counts are per sample (one lane); slot 0 = the evaluator
+ * (fdg_isa_eval[_nt]), 1 = fused accumulation (fdg_isa_eval_acc[_nt]), 2 = the row-major variant (fdg_isa_eval_rm).
+ * All zero for handles that are not specialised with FDG_SPEC_ISA.  No counterpart in the reference. */
+typedef struct fdg_kernel_info {
+  char last_kernel[48];       /* name of the evaluator kernel the last device call on this handle launched ("" = none yet) */
+  uint64_t n_valu[3];         /* vector-ALU fold steps executed per evaluation (after value numbering / recomputation) */
+  uint32_t n_ld_leaf[3];      /* leaf loads from the input matrix (> n_live_leaf: leaves evicted and read again) */
+  uint32_t n_panel[3];        /* loads + stores of the HBM workspace panel */
+  uint32_t n_lds[3];          /* loads + stores of per-lane LDS slots */
+  uint32_t waves_per_cu[3];   /* resident waves per CU the launch uses */
+  uint32_t has_acc, has_rm, has_coop, rm_bufs;
+} fdg_kernel_info;
+int fdg_graph_kernel_info(fdg_graph *g, fdg_kernel_info *info);
 
 /* Emits HIP source for a straight-line kernel of this graph (one lane = one
  * sample, values in VGPRs, compiler-managed overflow) and returns it as a

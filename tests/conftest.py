@@ -28,3 +28,10 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU is visible (the product has no CPU fallback)")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def no_shipped_cache(libfdg, monkeypatch):
+    """Tests that look at what a specialisation writes into their own cache directory: without the read-only lookup of the
+    code objects shipped in feynmandiagram.jl_amd/kernel_cache (a hit there writes nothing)."""
+    monkeypatch.setenv("FDG_CACHE_RO_DIR", "")

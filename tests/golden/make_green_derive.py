@@ -34,6 +34,17 @@ def main():
                     d = mp.diff(f, mp.mpf(w), n)
                     val = (-1) ** n * d / mp.factorial(n)
                     rows.append((tau, w, beta, n, float(val)))
+    # the parameter set of example/benchmark.jl:10-13,46-51 itself: kF = 1.919, beta = 3.0, w = k^2 - kF^2 with |k| drawn by
+    # FermiK(dim, kF, 0.2 kF, 10 kF) (so k from 0 to ~10 kF, most of the weight within 0.2 kF of the Fermi surface), tau in (-beta, beta)
+    kF, beta = 1.919, 3.0
+    ks = [0.0, 0.5 * kF, 0.8 * kF, 0.9 * kF, 0.95 * kF, kF, 1.05 * kF, 1.1 * kF, 1.2 * kF, 1.5 * kF, 2.0 * kF, 5.0 * kF, 10.0 * kF]
+    taus = list(rng.uniform(-beta, beta, 10)) + [0.0, 1e-10, -1e-10, beta * (1 - 1e-12), 0.5 * beta, -0.5 * beta]
+    for tau in taus:
+        for k in ks:
+            w = k * k - kF * kF
+            for n in range(1, 6):
+                d = mp.diff(lambda x: kernel(tau, x, beta), mp.mpf(w), n)
+                rows.append((tau, w, beta, n, float((-1) ** n * d / mp.factorial(n))))
     a = np.array(rows)
     np.savez_compressed(os.path.join(HERE, "green_derive.npz"), tau=a[:, 0], w=a[:, 1], beta=a[:, 2], order=a[:, 3].astype(np.int32), value=a[:, 4])
     print("green_derive.npz:", a.shape[0], "points")

@@ -3,7 +3,7 @@ the reference: src/frontend/GV_diagrams/groups_sigma/Sigma{4,5,6}_0_0.diag).
 
     diagsGV(:sigma, order)  ->  optimize!  ->  Compilers lowering  ->  .npz
 
-All three steps are our restatements (feynmandiagram.jl_amd/gv.py, optimize.py,
+All three steps are our restatements (feynmandiagram.jl_amd/producers/gv.py, optimize.py,
 lowering.py); Julia is unavailable, so the tables are NOT checked against the
 reference's own graph objects.  What is checked here, independently of those
 restatements, is the all-leaves-one value of every root: it must equal the sum
@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 RD = "/root/reference/src/frontend/GV_diagrams"
 
 import oracle  # noqa: E402
-from feynmandiagram_jl_amd import gv, optimize  # noqa: E402
+from feynmandiagram_jl_amd.producers import gv, optimize  # noqa: E402
 from feynmandiagram_jl_amd.lowering import lower  # noqa: E402
 
 
@@ -72,7 +72,7 @@ def taylor_tables():
     coupling (every BareInteractionId leaf depends on the expansion variable, README.md:83).  Checked
     independently of the Taylor restatement: the original graph evaluated at V = V0 + x V1 + x^2 V2
     must equal c0 + x c1 + x^2 c2 up to O(x^3)."""
-    from feynmandiagram_jl_amd import taylor
+    from feynmandiagram_jl_amd.producers import taylor
     for order in (4, 5):
         graphs = gv.diagsGV("sigma", order, RD)
         optimize.optimize_(graphs)

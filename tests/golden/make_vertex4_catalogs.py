@@ -20,7 +20,7 @@ RD = "/root/reference/src/frontend/GV_diagrams"
 DATA = os.path.join(ROOT, "feynmandiagram.jl_amd", "data")
 
 import oracle  # noqa: E402
-from feynmandiagram_jl_amd import gv, optimize  # noqa: E402
+from feynmandiagram_jl_amd.producers import gv, optimize  # noqa: E402
 from feynmandiagram_jl_amd.lowering import lower  # noqa: E402
 
 

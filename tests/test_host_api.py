@@ -217,7 +217,8 @@ def test_dead_code_is_dropped_but_roots_kept(libfdg):
     assert info["n_live_node"] == 2 and info["n_live_leaf"] == 2 and info["flops_alg"] == 4
 
 
-def test_emit_source_and_jit_without_device(libfdg, tmp_path):
+def test_emit_source_and_jit_without_device(libfdg, tmp_path, monkeypatch):
+    monkeypatch.setenv("FDG_CACHE_RO_DIR", "")           # (without the shipped kernel_cache: the point is to compile)
     t = workloads.get("sigma2")
     h = capi.GraphHandle(t)
     src = h.emit_source()
@@ -274,7 +275,7 @@ def test_fused_step_specializes_without_device(libfdg, tmp_path):
     assert e.value.code == capi.FDG_E_UNSUPPORTED                     # "this leaftype ... not implemented!" (benchmark.jl:79)
 
 
-def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypatch):
+def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypatch, no_shipped_cache):
     """Route 3 of fdg_graph_specialize_fused (handle specialised with FDG_SPEC_ISA): the kernels -- eval and accumulate --
     are assembled right away, host-only, and do not depend on kF, beta, lambda (kernel arguments); the assembly carries
     the exp / reciprocal sequences (v_rndne_f64, v_ldexp_f64, v_rcp_f64 followed by the wait state gfx950 needs) and
@@ -365,11 +366,13 @@ def test_package_tables_equal_golden_fixtures():
     assert not os.path.commonpath([workloads.DATA, gold]) == gold
 
 
-def test_cache_directory_is_vetted(tmp_path):
+def test_cache_directory_is_vetted(tmp_path, monkeypatch):
     """JIT-ed code objects are read back by predictable name, so the cache directory must belong to the caller and must
     not be writable by anybody else; a world-writable artefact inside it is ignored and rebuilt; no shell sees the path."""
     import stat
     from feynmandiagram_jl_amd import capi, workloads
+    capi.lib()
+    monkeypatch.setenv("FDG_CACHE_RO_DIR", "")
     t = workloads.get("sigma2")
     good = tmp_path / "cache"
     good.mkdir(mode=0o700)
@@ -394,6 +397,70 @@ def test_cache_directory_is_vetted(tmp_path):
     with pytest.raises(capi.FdgError) as e:
         capi.GraphHandle(t).specialize(str(quoted), capi.FDG_SPEC_ISA)
     assert e.value.code == capi.FDG_E_INVALID
+
+
+def test_artefacts_pass_the_vetting_under_any_umask_and_shipped_cache_is_read_only(tmp_path, monkeypatch):
+    """ The linker creates its output under the caller's umask -- 0775 under umask 002 --, which the vetting of
+    the cache used to refuse, so every specialisation failed after a successful assembly.  The artefact is chmod'ed before
+    it is renamed into place, and reads only insist on "owned by the caller or root, not world-writable".  The kernel_cache
+    shipped inside the package is a read-only secondary lookup ($FDG_CACHE_RO_DIR): a hit there writes nothing anywhere;
+    the default (per-user) directory is used when no directory is passed, so a root-owned installation works."""
+    import stat
+    from feynmandiagram_jl_amd import capi, workloads
+    capi.lib()
+    monkeypatch.setenv("FDG_CACHE_RO_DIR", "")
+    t = workloads.get("sigma2")
+    old = os.umask(0o002)
+    try:
+        a = tmp_path / "a"
+        a.mkdir(mode=0o700)
+        capi.GraphHandle(t).specialize(str(a), capi.FDG_SPEC_ISA)
+        objs = [p for p in a.iterdir() if p.suffix == ".hsaco"]
+        assert len(objs) == 1 and stat.S_IMODE(objs[0].stat().st_mode) == 0o644
+        capi.GraphHandle(t).specialize(str(a), capi.FDG_SPEC_ISA)            # read back, not an error
+        os.chmod(objs[0], 0o664)                                             # group-writable artefact in a vetted directory: accepted
+        m0 = objs[0].stat().st_mtime_ns
+        capi.GraphHandle(t).specialize(str(a), capi.FDG_SPEC_ISA)
+        assert objs[0].stat().st_mtime_ns == m0
+    finally:
+        os.umask(old)
+    # the shipped cache as a read-only secondary: nothing is written into the primary on a hit, nothing ever into the secondary
+    monkeypatch.setenv("FDG_CACHE_RO_DIR", "/nonexistent:" + str(a))
+    os.chmod(a, 0o555)
+    b = tmp_path / "b"
+    b.mkdir(mode=0o700)
+    h = capi.GraphHandle(t)
+    h.specialize(str(b), capi.FDG_SPEC_ISA)
+    assert h.info()["specialized"] == 1 and not list(b.iterdir())
+    os.chmod(a, 0o700)
+    # no directory given: the library's per-user default, not the package directory
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "xdg"))
+    (tmp_path / "xdg").mkdir(mode=0o700)
+    monkeypatch.setenv("FDG_CACHE_RO_DIR", "")
+    monkeypatch.delenv("FDG_CACHE_DIR", raising=False)
+    capi.GraphHandle(t).specialize(None, capi.FDG_SPEC_ISA)
+    assert [p for p in (tmp_path / "xdg" / "fdg").iterdir() if p.suffix == ".hsaco"]
+    # an unusable default location (here: group-writable) does not fail the call: a private directory of the process is used
+    os.chmod(tmp_path / "xdg" / "fdg", 0o770)
+    for p in (tmp_path / "xdg" / "fdg").iterdir():
+        p.unlink()
+    capi.GraphHandle(t).specialize(None, capi.FDG_SPEC_ISA)
+    assert not list((tmp_path / "xdg" / "fdg").iterdir())
+
+
+def test_kernel_info_names_the_variants(libfdg):
+    """fdg_graph_kernel_info: what the installed ISA programs execute per evaluation; bench.py takes the kernel name and the
+    executed fold steps from here instead of guessing which variant the library launched."""
+    from feynmandiagram_jl_amd import capi, workloads
+    t = workloads.get("parquet_sigma4")
+    f = fd.compile_table(t, specialize="isa")
+    ki = f.kernel_info()
+    assert ki["last_kernel"] == "" and ki["has_acc"] == 1 and ki["has_rm"] == 1 and ki["rm_bufs"] >= 2
+    assert 0 < ki["n_valu"][0] <= t.stats()["flops_alg"] and ki["n_ld_leaf"][0] == t.n_leaf and ki["n_panel"] == [0, 0, 0]
+    assert ki["waves_per_cu"][0] == 8 and ki["waves_per_cu"][2] >= 4
+    assert fd.compile_table(t).kernel_info()["n_valu"] == [0, 0, 0]          # the interpreter: nothing installed
+    small = fd.compile_table(workloads.get("sigma2"), specialize="auto")     # < 16 leaves: no row-major variant -> companion
+    assert small.kernel_info()["has_rm"] == 0
 
 
 def test_exponent_and_root_count_bounds():

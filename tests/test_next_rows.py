@@ -11,11 +11,12 @@ import pytest
 
 import oracle
 import feynmandiagram_jl_amd as fd
-from feynmandiagram_jl_amd import capi, optimize, workloads
+from feynmandiagram_jl_amd import capi, workloads
+from feynmandiagram_jl_amd.producers import optimize
 from feynmandiagram_jl_amd.graph import AbstractOperator, Graph, Power, Prod, Sum
 from feynmandiagram_jl_amd.lowering import lower
 from feynmandiagram_jl_amd.nodetable import NodeTable
-from feynmandiagram_jl_amd.optimize import isequiv
+from feynmandiagram_jl_amd.producers.optimize import isequiv
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 REF_GV = "/root/reference/src/frontend/GV_diagrams"
@@ -123,7 +124,7 @@ def test_gv_tables_match_catalog_sums():
 
 @pytest.mark.skipif(not os.path.isdir(REF_GV), reason="reference checkout not present (GPU box)")
 def test_gv_reader_reproduces_committed_tables():
-    from feynmandiagram_jl_amd import gv
+    from feynmandiagram_jl_amd.producers import gv
     # leaf counts before/after optimize for sigma 2..4
     for order, (l_raw, l_opt, n_feyn) in {2: (12, 8, 3), 3: (117, 32, 24), 4: (1329, 111, 243)}.items():
         graphs = gv.diagsGV("sigma", order, REF_GV)
@@ -144,7 +145,8 @@ def test_gv_reader_reproduces_committed_tables():
 @pytest.mark.skipif(not os.path.isdir(REF_GV), reason="reference checkout not present (GPU box)")
 def test_leafstates_on_gv_sigma3():
     """frontends.jl:178-232 over the leafmap of Compilers.compile-order lowering."""
-    from feynmandiagram_jl_amd import gv, FrontEnds
+    from feynmandiagram_jl_amd import FrontEnds
+    from feynmandiagram_jl_amd.producers import gv
     graphs = gv.diagsGV("sigma", 3, REF_GV)
     optimize.optimize_(graphs)
     t, leafmap, _ = lower(graphs)
@@ -165,7 +167,7 @@ def test_leafstates_on_gv_sigma3():
 
 
 def test_gv_interaction_equal_time_equivalence():
-    from feynmandiagram_jl_amd.gv import BareGreenId, BareInteractionId, mirror_symmetrize
+    from feynmandiagram_jl_amd.producers.gv import BareGreenId, BareInteractionId, mirror_symmetrize
     # diagram_id.jl:49-69, 81-96
     assert BareInteractionId("ChargeCharge", [0, 1, 0], (1, 1)) == BareInteractionId("ChargeCharge", [0, -1, 0], (2, 2))
     assert BareInteractionId("ChargeCharge", [0, 1, 0], (1, 2)) != BareInteractionId("ChargeCharge", [0, 1, 0], (2, 1))
@@ -266,7 +268,7 @@ POWERS = (-7, -4, -3, -2, -1, 4, 5, 6, 7, 12, 33)
 
 
 @pytest.mark.parametrize("budget", [dict(), dict(n_reg=9, n_lds=3, n_acc=2)])
-def test_integer_powers_in_the_optimizing_back_end(libfdg, budget, tmp_path):
+def test_integer_powers_in_the_optimizing_back_end(libfdg, budget, tmp_path, no_shipped_cache):
     """Power{N} for any literal N (static.jl:34-46): Julia evaluates `(g)^N` through literal_pow (N = 2, 3, -1, -2) and
     Base.Math.pow_body otherwise -- power by squaring with a compensated low word, fused multiply-adds, a correctly
     rounded division for N < 0.  The optimizing back end spells that algorithm out in its own ops (fdg_opt.cpp
@@ -357,7 +359,7 @@ def test_cooperative_programs_replay_exactly(libfdg, monkeypatch, name, waves):
     assert info["n_transfer"] > 0
 
 
-def test_isa_jit_assembles_without_device(libfdg, tmp_path):
+def test_isa_jit_assembles_without_device(libfdg, tmp_path, no_shipped_cache):
     t = workloads.get("gv_sigma4")
     h = capi.GraphHandle(t)
     h.specialize(str(tmp_path), capi.FDG_SPEC_ISA | capi.FDG_SPEC_KEEP_SOURCE)
@@ -381,7 +383,7 @@ def test_isa_covers_any_literal_power(libfdg, tmp_path):
 # ---- Taylor-mode AD ------------------------------------------- #
 def test_taylorseries_numeric_kats():
     # test/taylor.jl:44-63
-    from feynmandiagram_jl_amd.taylor import getcoeff, set_variables
+    from feynmandiagram_jl_amd.producers.taylor import getcoeff, set_variables
     a, b, c, d, e = set_variables("a b c d e", orders=[3, 3, 3, 3, 3])
     F1 = (a + b) * (a + b) * (a + b)
     assert [getcoeff(F1, o) for o in ([2, 1, 0, 0, 0], [1, 2, 0, 0, 0], [3, 0, 0, 0, 0], [0, 3, 0, 0, 0])] == [3.0, 3.0, 1.0, 1.0]
@@ -395,7 +397,7 @@ def test_taylorseries_numeric_kats():
 def _getdiagram(spin):
     # test/taylor.jl:115-161 with the leaf ids the reference uses
     import math
-    from feynmandiagram_jl_amd.gv import BareGreenId, BareInteractionId
+    from feynmandiagram_jl_amd.producers.gv import BareGreenId, BareInteractionId
     gK = [[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 0.0, 1.0]]
     gT = [(1, 2), (2, 1)]
     g = [Graph([], properties=BareGreenId(k=gK[i], t=gT[i]), name="G") for i in range(2)]
@@ -414,8 +416,8 @@ def test_taylor_ad_of_parquet_like_graph():
     """test/taylor.jl:181-208: every Taylor coefficient leaf set to 1/taylor_factorial(order), so all
     derivatives equal 1: coefficient [i,j] = (spin-2)*factor * 2^(#differentiated kinds) / i!j!."""
     import math
-    from feynmandiagram_jl_amd import taylor
-    from feynmandiagram_jl_amd.gv import BareGreenId, BareInteractionId
+    from feynmandiagram_jl_amd.producers import taylor
+    from feynmandiagram_jl_amd.producers.gv import BareGreenId, BareInteractionId
     spin = 0.5
     factor = 1 / (2 * math.pi) ** 3
     root = _getdiagram(spin)
@@ -442,7 +444,7 @@ def test_taylorAD_groups_by_order_and_evaluates_on_any_backend(libfdg):
     enlarged graph set lowers through the same pipeline (config 4's shape: Power{2} nodes appear)."""
     if not os.path.isdir(REF_GV):
         pytest.skip("reference checkout not present (GPU box)")
-    from feynmandiagram_jl_amd import gv, taylor
+    from feynmandiagram_jl_amd.producers import gv, taylor
     graphs = gv.diagsGV("sigma", 3, REF_GV)
     optimize.optimize_(graphs)
     d = taylor.taylorAD(graphs, [2], [lambda pr: isinstance(pr, gv.BareInteractionId)])

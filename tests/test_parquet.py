@@ -1,4 +1,4 @@
-"""The restated Parquet front end (feynmandiagram.jl_amd/parquet.py), pinned by the reference's own tests of it
+"""The restated Parquet front end (feynmandiagram.jl_amd/producers/parquet.py), pinned by the reference's own tests of it
 (test/front_end.jl:120-700: parameters, partitions, index helpers, filters, the diagram counts of the self-energy, the
 validity of Green's functions), by the optimized 2-loop graph the reference renders in assets/sigma_o2.svg (SURVEY.md
 Appendix A) and by value invariance under ``optimize!``.  No GPU."""
@@ -6,11 +6,12 @@ import numpy as np
 import pytest
 
 import oracle
-from feynmandiagram_jl_amd import fixtures, optimize, parquet as pq, workloads
-from feynmandiagram_jl_amd.gv import mirror_symmetrize
+from feynmandiagram_jl_amd import fixtures, workloads
+from feynmandiagram_jl_amd.producers import optimize, parquet as pq
+from feynmandiagram_jl_amd.producers.gv import mirror_symmetrize
 from feynmandiagram_jl_amd.graph import Graph
 from feynmandiagram_jl_amd.lowering import lower
-from feynmandiagram_jl_amd.parquet import (ChargeCharge, DiagPara, Dynamic, Girreducible, GreenDiag, Instant, Interaction, NoFock,
+from feynmandiagram_jl_amd.producers.parquet import (ChargeCharge, DiagPara, Dynamic, Girreducible, GreenDiag, Instant, Interaction, NoFock,
                                            NoHartree, SigmaDiag, Ver4Diag, reconstruct)
 
 
@@ -240,7 +241,7 @@ def test_optimize_keeps_the_value_of_the_four_loop_self_energy():
 def test_taylor_expansion_of_the_parquet_self_energy_satisfies_the_series_identity():
     """Config 4 on the real graph: f(V0 + x V1 + x^2 V2) = c0 + x c1 + x^2 c2 + O(x^3), checked independently of the
     Taylor restatement (as tests/golden/make_gv_tables.py does for the GV graphs)."""
-    from feynmandiagram_jl_amd import gv, taylor
+    from feynmandiagram_jl_amd.producers import gv, taylor
     graphs, rows = workloads.parquet_graphs("parquet_sigma3")
     t0, lm0, _ = lower(graphs)
     d = taylor.taylorAD(graphs, [2], [lambda pr: isinstance(pr, gv.BareInteractionId)])
@@ -280,11 +281,11 @@ def test_irreducible_vertex_catalogs(order, want):
     """(UpUp, UpDown) of ``diagsGV_ver4(order, channels=[Alli])``: all leaves 1 => the catalog's own sums of
     SymFactor * SpinFactor (direct terms for UpDown, direct + exchange for UpUp), computed from the numbers directly."""
     import os
-    from feynmandiagram_jl_amd import gv
+    from feynmandiagram_jl_amd.producers import gv
     graphs = pq.get_ver4I(order)
     assert [g.properties.response for g in graphs] == [pq.UpUp, pq.UpDown] and all(g.properties.channel == pq.Alli for g in graphs)
     assert list(all_ones(graphs)) == want
-    c = dict(np.load(os.path.join(os.path.dirname(pq.__file__), "data", f"vertex4I{order}.npz")))
+    c = dict(np.load(os.path.join(workloads.DATA, f"vertex4I{order}.npz")))
     assert _catalog_sums(c) == want
     if os.path.isdir(REF_GV):                   # the shipped arrays are the catalog's numbers
         ref = gv.parse_vertex4_catalog(f"{REF_GV}/groups_vertex4/Vertex4I{order}_0_0.diag")
@@ -298,14 +299,14 @@ def test_irreducible_vertex_enters_the_parquet_equations_with_the_right_multipli
     the numbers are met exactly; with the signs as they are, the catalog vertex contributes (0, 4) instead of (168, 84)."""
     import functools
     import os
-    from feynmandiagram_jl_amd import gv
+    from feynmandiagram_jl_amd.producers import gv
     para = DiagPara(type=pq.PolarDiag, innerLoopNum=5, isFermi=False, hasTau=True, filter=(NoHartree, NoFock), interaction=(Interaction(ChargeCharge, Instant),))
     Q = [1.0] + [0.0] * (para.totalLoopNum - 1)
     with_signs = all_ones([r["diagram"] for r in pq.polarization(para, Q)]) * 2
     assert list(with_signs) == [3418.0, 764.0]
 
     def bosonic(order):
-        c = dict(np.load(os.path.join(os.path.dirname(pq.__file__), "data", f"vertex4I{order}.npz")))
+        c = dict(np.load(os.path.join(workloads.DATA, f"vertex4I{order}.npz")))
         c["spin"], c["symfactor"] = np.abs(c["spin"]), np.abs(c["symfactor"])
         return gv.read_vertex4diagrams(c, 0.0, (NoHartree,), (pq.Alli,))
 
@@ -379,7 +380,7 @@ def test_vertex_function_sums_agree_with_the_gv_vertex_catalogs(loops):
     catalog's sum of SymFactor * SpinFactor over direct terms -- 2, -9, 40, -168 -- and the UpUp rows (direct + exchange) to 0;
     no sign between them this time.  n = 4 is the graph of example/benchmark.jl against that of example/benchmark_GV.jl."""
     import os
-    from feynmandiagram_jl_amd import gv
+    from feynmandiagram_jl_amd.producers import gv
     want = {1: 2.0, 2: -9.0, 3: 40.0, 4: -168.0}[loops]
     rows = pq.vertex4(DiagPara(type=Ver4Diag, innerLoopNum=loops))
     assert len(rows) == {1: 6, 2: 30, 3: 84, 4: 180}[loops]
@@ -402,7 +403,7 @@ def test_polarization_sums_agree_with_the_gv_polarization_catalogs(loops):
     SymFactor * SpinFactor (-2, 6, -10, -42, 558) and spin * (UpUp - UpDown) the spin catalog's (-2, 6, -18, 46, -66);
     5 loops include the catalog vertex."""
     import os
-    from feynmandiagram_jl_amd import gv
+    from feynmandiagram_jl_amd.producers import gv
     charge = {1: -2.0, 2: 6.0, 3: -10.0, 4: -42.0, 5: 558.0}[loops]
     spin = {1: -2.0, 2: 6.0, 3: -18.0, 4: 46.0, 5: -66.0}[loops]
     rows = pq.polarization(DiagPara(type=pq.PolarDiag, innerLoopNum=loops, filter=(NoHartree,)))
