@@ -122,6 +122,10 @@ struct fdg_graph {
   bool has_rm = false;
   void *fn_isa_rm = nullptr;
   uint32_t isa4_vgpr = 0, isa4_lds_bytes = 0, isa4_mem_slots = 0;
+  // ... and its fused-accumulate form (row-major leaves, roots never written)
+  bool has_rm_acc = false;
+  void *fn_isa_rm_acc = nullptr;
+  uint32_t isa5_vgpr = 0, isa5_lds_bytes = 0, isa5_mem_slots = 0;
   // what the installed programs execute per evaluation (fdg_graph_kernel_info): [0] eval, [1] accumulate, [2] row-major
   uint64_t st_valu[3] = {0, 0, 0};
   uint32_t st_ld_leaf[3] = {0, 0, 0}, st_panel[3] = {0, 0, 0}, st_lds[3] = {0, 0, 0};

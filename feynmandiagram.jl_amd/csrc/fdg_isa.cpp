@@ -515,17 +515,26 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 1) + ", 0x10000, " + V(V_LANE8));
   }
   if (rm_bufs) {
-    const std::string vg = "v" + std::to_string(rm0);
+    // v[rm0] / v[rm0 + 9]: source offsets of the LDS-direct loads of even / odd instructions n of a chunk -- lane l fetches
+    // piece (l % 8) ^ s of row 8 n + l / 8, s = (row / 2) % 8 = (4 n + l / 16) % 8: l / 16 for even n, that ^ 4 for odd n;
+    // v[rm0 + 1 + j]: where lane = row r finds piece j: r * 128 + ((j ^ ((r / 2) % 8)) * 16).  With this swizzle the 32 rows
+    // a ds_read_b64 services per LDS cycle pair fall on 16 distinct bank groups x 2 halves (two-way instead of four-way
+    // conflict with s = r % 8), and the 16 rows of a ds_read_b128 group on all 64 banks.
+    const std::string vg = "v" + std::to_string(rm0), vg2 = "v" + std::to_string(rm0 + 9);
     auto vj = [&](int j) { return "v" + std::to_string(rm0 + 1 + j); };
     E.ins("v_lshrrev_b32_e32 " + vj(0) + ", 3, v0");                                   // l / 8
-    E.ins("v_and_b32_e32 " + vj(1) + ", 7, v0");                                       // l % 8
-    E.ins("v_xor_b32_e32 " + vj(1) + ", " + vj(1) + ", " + vj(0));                     // piece this lane fetches
-    E.ins("v_lshlrev_b32_e32 " + vj(1) + ", 4, " + vj(1));
     E.ins("v_mul_lo_u32 " + vj(0) + ", " + vj(0) + ", " + S(S_SS));                    // (l / 8) rows further
     E.ins("v_lshlrev_b32_e32 " + vj(0) + ", 3, " + vj(0));
+    E.ins("v_lshrrev_b32_e32 " + vj(1) + ", 4, v0");                                   // l / 16
+    E.ins("v_and_b32_e32 " + vj(2) + ", 7, v0");                                       // l % 8
+    E.ins("v_xor_b32_e32 " + vj(1) + ", " + vj(1) + ", " + vj(2));                     // piece this lane fetches (even n)
+    E.ins("v_xor_b32_e32 " + vj(2) + ", 4, " + vj(1));                                 // ... (odd n)
+    E.ins("v_lshlrev_b32_e32 " + vj(1) + ", 4, " + vj(1));
+    E.ins("v_lshlrev_b32_e32 " + vj(2) + ", 4, " + vj(2));
     E.ins("v_add_u32_e32 " + vg + ", " + vj(0) + ", " + vj(1));
+    E.ins("v_add_u32_e32 " + vg2 + ", " + vj(0) + ", " + vj(2));
     E.ins("v_lshlrev_b32_e32 " + V(V_TMP) + ", 7, v0");                                // row * 128
-    E.ins("v_and_b32_e32 " + V(V_TMP + 1) + ", 7, v0");                                // row % 8
+    E.ins("v_bfe_u32 " + V(V_TMP + 1) + ", v0, 1, 3");                                 // (row / 2) % 8
     for (int j = 0; j < 8; ++j) {
       E.ins("v_xor_b32_e32 " + vj(j) + ", " + std::to_string(j) + ", " + V(V_TMP + 1));
       E.ins("v_lshlrev_b32_e32 " + vj(j) + ", 4, " + vj(j));
@@ -706,6 +715,11 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   std::vector<std::vector<RmFetch>> rm_fetch;       // [op index] fetches issued in front of that op
   std::vector<int> rm_ld_buf;                       // [op index] staging buffer an LD_LEAF reads, -1 = gathered from memory
   if (rm_bufs) rm_plan(p, prog, rm_bufs, rm_fetch, rm_ld_buf);
+  // Cache policy of the LDS-direct loads (experiment knob FDG_ISA_RM_POLICY="nt" ...).  Non-temporal loads stream 6.9 instead of
+  // 6.1 TB/s in a bare loop over rows that are whole cache lines (tools/ubench/rm_stream.hip), but a row of L doubles is not: the
+  // 128-byte segments of consecutive chunks share lines, and a line fetched non-temporally is fetched again from memory for the
+  // next chunk (measured: parquet_sigma4 6.2 -> 3.6e9 evals/s).  Plain loads it is.
+  const std::string rm_policy = std::getenv("FDG_ISA_RM_POLICY") && std::getenv("FDG_ISA_RM_POLICY")[0] ? std::string(" ") + std::getenv("FDG_ISA_RM_POLICY") : std::string();
   std::vector<uint64_t> rm_ready(rm_bufs, 0);        // vm sequence number of the last load of the chunk in each buffer
   auto rm_emit_fetch = [&](const RmFetch &f) {
     // the buffer's previous readers have been issued; their data must have left the LDS before it is overwritten
@@ -720,7 +734,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         E.ins("s_add_u32 " + S(S_FA) + ", " + S(S_FA) + ", " + S(S_ROW8));
         E.ins("s_addc_u32 " + S(S_FA + 1) + ", " + S(S_FA + 1) + ", " + S(S_ROW8 + 1));
       }
-      E.ins("global_load_lds_dwordx4 v" + std::to_string(rm0) + ", " + S2(S_FA));
+      E.ins("global_load_lds_dwordx4 v" + std::to_string((n & 1) ? rm0 + 9 : rm0) + ", " + S2(S_FA) + rm_policy);
       ++E.vm_issued;
     }
     rm_ready[f.buf] = E.vm_issued;
@@ -1072,7 +1086,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_endpgm");
 
   // ---- kernel descriptor -------------------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 9 : 0) + (cs ? 2 : 0), 8);
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? 2 : 0), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
   const uint32_t n_agpr = RW * prog.n_acc_used;
   if (cs) return KernelMeta{kname, lds_bytes, accum, n_agpr, 10, (mc || has_macro) ? S_END : S_POOL + 2 * 16};
@@ -1189,7 +1203,8 @@ std::string isa_hazard_table() {
 // One code object: the W = 1 kernel `kname`, and, when prog2 is given, the two-samples-per-lane kernel
 // `kname`_w2 next to it.
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2,
-                     const OptProgram *prog_acc, const OptProgram *prog_rm, uint32_t rm_bufs, const CoopProgram *coop) {
+                     const OptProgram *prog_acc, const OptProgram *prog_rm, uint32_t rm_bufs, const CoopProgram *coop,
+                     const OptProgram *prog_rm_acc) {
   Emit E;
   E.os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n";
   std::vector<KernelMeta> ks;
@@ -1205,6 +1220,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
     E.streaming = false;
   }
   if (prog_rm && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm, kname + "_rm", 1, false, rm_bufs));
+  if (prog_rm_acc && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm_acc, kname + "_rm_acc", 1, true, rm_bufs));
   if (coop && coop->supported) { ks.push_back(emit_coop(E, p, *coop, kname + "_coop")); ks.back().wg = 64 * coop->n_wave; }
   std::ostringstream &os = E.os;
   os << "\t.text\n\t.amdgpu_metadata\n---\namdhsa.kernels:\n";

@@ -79,6 +79,7 @@ struct Builder {
   // the same bits).  A widely shared value whose uses are thousands of ops apart would otherwise sit in a spill slot and
   // come back through the HBM panel for every use; its operands -- lower-order sub-diagrams that many nodes keep reading --
   // usually are still on chip.  Roots are exempt.
+  bool keep_root_order = false;
   uint32_t term_window = 1, term_recent = 400;    // out-of-order evaluation of a wide node's terms (see build_uops)
   uint64_t remat_window = 0;
   uint32_t remat_cost = 8;
@@ -434,7 +435,7 @@ void build_uops(Builder &B) {
   std::vector<uint32_t> tops;
   for (auto &rk : rootlist) if (rk.first >= L) tops.push_back(rk.first - L);
   tops.erase(std::unique(tops.begin(), tops.end()), tops.end());
-  order_roots(p, tops);
+  if (!B.keep_root_order) order_roots(p, tops);
   // One fold step of frame f (operand already computed).  Returns true when the node is finished.
   auto step = [&](Frame &f) -> bool {
     const uint32_t n = f.n, a = p.off[n], k = p.off[n + 1] - a;
@@ -974,6 +975,7 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   B0.vn_touch = std::getenv("FDG_VN_BIRTH_WINDOW") == nullptr;   // default: the window counts from the last read
   B0.remat_window = prm.remat_window;
   B0.remat_cost = prm.remat_cost;
+  B0.keep_root_order = prm.keep_root_order;
   if (const char *rw = std::getenv("FDG_REMAT_WINDOW")) B0.remat_window = (uint64_t)std::atoll(rw);     // experiments
   if (const char *tw = std::getenv("FDG_TERM_WINDOW")) B0.term_window = (uint32_t)std::max(1, std::atoi(tw));
   if (const char *tr = std::getenv("FDG_TERM_RECENT")) B0.term_recent = (uint32_t)std::max(1, std::atoi(tr));
@@ -983,7 +985,7 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   if (retry) { plain = p; plain.sched_group.clear(); }
   Builder B1(retry ? plain : p);
   B1.value_numbering = B0.value_numbering; B1.vn_window = B0.vn_window; B1.vn_touch = B0.vn_touch;
-  B1.remat_window = B0.remat_window; B1.remat_cost = B0.remat_cost;
+  B1.remat_window = B0.remat_window; B1.remat_cost = B0.remat_cost; B1.keep_root_order = B0.keep_root_order;
   if (retry) build_uops(B1);
   Builder &B = retry ? B1 : B0;
   out.supported = B.ok;

@@ -80,6 +80,8 @@ struct OptParams {
   bool fma = false;               // FDG_SPEC_FAST_MATH: a product used once, by a sum, is fused into it (v_fma_f64)
   uint32_t remat_window = 0;      // > 0: the value of a cheap node not read for this many ops is forgotten and computed again by its
   uint32_t remat_cost = 4;        //      next consumer (nodes whose own fold has at most remat_cost steps); exact, trades arithmetic for spills
+  bool keep_root_order = false;   // roots in the reference's statement order instead of the cone-overlap order: leaves are numbered by first
+                                  // visit in that order, so their first uses then walk the leaf index monotonically (row-major variant)
   uint32_t reserve_pairs = 0;     // VGPR pairs the kernel variant keeps above the values (accumulators, weight): the value budget shrinks
                                   // by this and by the temporaries the program's macro ops need, so that everything stays below v256
 };
@@ -118,7 +120,7 @@ bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp>
 struct CoopProgram;
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2 = nullptr,
                      const OptProgram *prog_acc = nullptr, const OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0,
-                     const CoopProgram *coop = nullptr);
+                     const CoopProgram *coop = nullptr, const OptProgram *prog_rm_acc = nullptr);
 
 // Cooperative variant: the four waves of a CU (one per SIMD) evaluate ONE 64-sample tile together.  Each wave runs its own
 // straight-line program on its share of the graph with its own registers, AGPRs, private LDS slots and panel; a value

@@ -395,6 +395,7 @@ static int ensure_module(fdg_graph *g) {
     if (g->has_w2) { hipFunction_t f2; HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_isa_eval_w2")); g->fn_isa_w2 = f2; }
     if (g->has_acc) { hipFunction_t f3; HIP_TRY(hipModuleGetFunction(&f3, m, "fdg_isa_eval_acc")); g->fn_isa_acc = f3; }
     if (g->has_rm) { hipFunction_t f4; HIP_TRY(hipModuleGetFunction(&f4, m, "fdg_isa_eval_rm")); g->fn_isa_rm = f4; }
+    if (g->has_rm_acc) { hipFunction_t f6; HIP_TRY(hipModuleGetFunction(&f6, m, "fdg_isa_eval_rm_acc")); g->fn_isa_rm_acc = f6; }
     if (g->has_coop) { hipFunction_t f5; HIP_TRY(hipModuleGetFunction(&f5, m, "fdg_isa_eval_coop")); g->fn_isa_coop = f5; }
     return FDG_OK;
   }
@@ -496,8 +497,10 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     const size_t panel3 = (size_t)std::max<uint32_t>(g->isa3_mem_slots, 1) * 512u * (size_t)grid3;
     const long grid4 = g->has_rm ? (long)g->n_cu * waves_per_cu(g->isa4_vgpr, g->isa4_lds_bytes) : 0;
     const size_t panel4 = (size_t)std::max<uint32_t>(g->isa4_mem_slots, 1) * 512u * (size_t)grid4;
-    const size_t panel_all = (std::max(std::max(panel, panel3), panel4) + 4095) & ~(size_t)4095;
-    rc = ensure_ws(g, panel_all + (size_t)grid3 * R * 512u + 4096);
+    const long grid5 = g->has_rm_acc ? (long)g->n_cu * waves_per_cu(g->isa5_vgpr, g->isa5_lds_bytes) : 0;
+    const size_t panel5 = (size_t)std::max<uint32_t>(g->isa5_mem_slots, 1) * 512u * (size_t)grid5;
+    const size_t panel_all = (std::max(std::max(panel, panel3), std::max(panel4, panel5)) + 4095) & ~(size_t)4095;
+    rc = ensure_ws(g, panel_all + (size_t)std::max(grid3, grid5) * R * 512u + 4096);
     if (rc) return rc;
     // a matrix whose 64-sample tiles are whole 128-byte lines (samples of a column contiguous, column stride a multiple of 16
     // doubles, base on a line): the streaming variants may be used (non-temporal accesses would fetch a shared line twice)
@@ -512,7 +515,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       long nwg = std::min<long>((n + 63) / 64, grid3), zero = 0;
       void *args[] = {(void *)&lf, &lss, &lls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt};
       void *fn = g->fn_isa_acc_nt && line_aligned(lf, lss, lls) ? g->fn_isa_acc_nt : g->fn_isa_acc;
-      g->last_kernel = fn == g->fn_isa_acc ? "fdg_isa_eval_acc" : "fdg_isa_eval_acc_nt";
+      if (!named) g->last_kernel = fn == g->fn_isa_acc ? "fdg_isa_eval_acc" : "fdg_isa_eval_acc_nt";
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
       hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
       HIP_TRY(hipGetLastError());
@@ -572,23 +575,33 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       g->last_kernel = "fdg_isa_eval_coop";
       return FDG_OK;
     }
-    // Row-major leaves ([B, L], leaf stride 1) and evaluation: full 64-row tiles go through the variant that stages chunks
-    // of rows in LDS itself -- the matrix is read once, in place; the last B % 64 rows take the general path below.
-    if (mode == 0 && g->has_rm && g->fn_isa_rm && ls == 1 && ss >= (int64_t)p.L && !wide_ss && p.L >= 16 && B >= 64 &&
-        !(rs < 0 || rs >= (1ll << 23)) && !std::getenv("FDG_ISA_NO_RM")) {
-      long n4 = (long)(B & ~(int64_t)63);
-      long nwg = std::min<long>(n4 / 64, grid4), lss = ss, lls = ls, rrs = rs, rrk = rk;
+    // Row-major leaves ([B, L], leaf stride 1): full 64-row tiles go through the variant that stages chunks of rows in LDS
+    // itself -- the matrix is read once, in place -- for evaluation and for fused accumulation alike; the last B % 64 rows
+    // go through the plain kernel with the caller's strides (its lanes gather their own rows: fine for under a tile).
+    const bool rm_shape = ls == 1 && ss >= (int64_t)p.L && !wide_ss && p.L >= 16 && B >= 64 && !std::getenv("FDG_ISA_NO_RM");
+    if (rm_shape && ((mode == 0 && g->has_rm && g->fn_isa_rm && !(rs < 0 || rs >= (1ll << 23))) || (fused_acc && g->has_rm_acc && g->fn_isa_rm_acc))) {
+      const long n4 = (long)(B & ~(int64_t)63), lss = ss, lls = ls, tail = (long)B - n4;
       void *a_wsp = g->d_ws;
-      const double *nowt = nullptr;
-      void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &n4, &nwg, (void *)&nowt};
-      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rm, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
-      g->last_kernel = "fdg_isa_eval_rm";
-      named = true;                    // (the last B % 64 rows below do not rename the call)
-      if (n4 == B) return FDG_OK;
-      d_leaf += (size_t)n4 * (size_t)ss;
-      d_root += (size_t)n4 * (size_t)rs;
-      roots = d_root;
-      B -= n4;
+      if (mode == 0) {
+        long nwg = std::min<long>(n4 / 64, grid4), rrs = rs, rrk = rk, nn = n4;
+        const double *nowt = nullptr;
+        void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt};
+        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rm, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+        g->last_kernel = "fdg_isa_eval_rm";
+        named = true;                    // (the last B % 64 rows below do not rename the call)
+        if (tail) { rc = launch_isa(d_leaf + (size_t)n4 * (size_t)ss, lss, lls, d_root + (size_t)n4 * (size_t)rs, rrs, rrk, tail); if (rc) return rc; }
+      } else {
+        double *part = (double *)((char *)g->d_ws + panel_all);
+        long nwg = std::min<long>(n4 / 64, grid5), zero = 0, nn = n4;
+        void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&part, &zero, &zero, &a_wsp, &nn, &nwg, (void *)&d_weight};
+        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rm_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+        hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
+        HIP_TRY(hipGetLastError());
+        g->last_kernel = "fdg_isa_eval_rm_acc";
+        named = true;
+        if (tail) { rc = launch_acc(d_leaf + (size_t)n4 * (size_t)ss, lss, lls, d_weight ? d_weight + n4 : nullptr, tail); if (rc) return rc; }
+      }
+      return FDG_OK;
     }
     if (mode == 0 && (rs < 0 || rs >= (1ll << 23))) { set_error("root sample stride negative or of 2^23 elements or more is not supported by the ISA kernel"); return FDG_E_UNSUPPORTED; }
     if ((ls == 1 && ss != 1 && p.L > 1) || (wide_ss && p.L > 0)) {
@@ -1084,8 +1097,9 @@ static bool has_opt_params(const fdg_graph *g) { return g->has_opt; }
 static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags,
                         std::vector<char> &co, std::string &hash, const fdg::OptProgram *prog2 = nullptr,
                         const fdg::OptProgram *prog_acc = nullptr, const char *kname = "fdg_isa_eval",
-                        const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr) {
-  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc, prog_rm, rm_bufs, coop);
+                        const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr,
+                        const fdg::OptProgram *prog_rm_acc = nullptr) {
+  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc, prog_rm, rm_bufs, coop, prog_rm_acc);
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
   hash = hbuf;
@@ -1117,7 +1131,8 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
 
 static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<char> &co, const std::string &hash, unsigned flags,
                         const fdg::OptProgram *prog2 = nullptr, const fdg::OptProgram *prog_acc = nullptr,
-                        const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr) {
+                        const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr,
+                        const fdg::OptProgram *prog_rm_acc = nullptr) {
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
   g->has_coop = coop && coop->supported;
   g->coop_enabled = g->has_coop;
@@ -1144,9 +1159,16 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
   g->has_rm = prog_rm != nullptr && rm_bufs > 0;
   g->fn_isa_rm = nullptr;
   if (g->has_rm) {
-    g->isa4_vgpr = ((6 + 2 * std::max<uint32_t>(prog_rm->n_reg_used, 1) + tmp_vgprs(*prog_rm) + 9 + 3) & ~3u) + 2 * prog_rm->n_acc_used;
+    g->isa4_vgpr = ((6 + 2 * std::max<uint32_t>(prog_rm->n_reg_used, 1) + tmp_vgprs(*prog_rm) + 10 + 3) & ~3u) + 2 * prog_rm->n_acc_used;
     g->isa4_lds_bytes = ((prog_rm->n_lds_used * 512u + 1023u) & ~1023u) + rm_bufs * 8192u;
     g->isa4_mem_slots = prog_rm->n_mem_used;
+  }
+  g->has_rm_acc = g->has_rm && prog_rm_acc != nullptr;
+  g->fn_isa_rm_acc = nullptr;
+  if (g->has_rm_acc) {
+    g->isa5_vgpr = ((6 + 2 * std::max<uint32_t>(prog_rm_acc->n_reg_used, 1) + 2 * (g->prog.R + 2) + tmp_vgprs(*prog_rm_acc) + 10 + 3) & ~3u) + 2 * prog_rm_acc->n_acc_used;
+    g->isa5_lds_bytes = ((prog_rm_acc->n_lds_used * 512u + 1023u) & ~1023u) + rm_bufs * 8192u;
+    g->isa5_mem_slots = prog_rm_acc->n_mem_used;
   }
   g->has_w2 = prog2 != nullptr;
   if (prog2) {
@@ -1264,7 +1286,7 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
 // part of the LDS budget turned into staging buffers of 8 KB, nine VGPRs of addresses, and leaf loads that come from
 // LDS (short prefetch distance).  Not for the tiny-graph configuration (its waves have 5 KB of LDS each; such graphs
 // take the HIP-source companion) nor for graphs of fewer than 16 leaves.
-static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chosen, fdg::OptProgram &pr) {
+static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chosen, fdg::OptProgram &pr, fdg::OptParams *qsel = nullptr) {
   if (g->prog.L < 16 || std::getenv("FDG_ISA_NO_RM")) return 0;
   if (chosen.n_reg < 100) return 0;                              // tiny-graph configuration
   // One wave per SIMD whatever the leaf-major kernel runs with: 40 KB of LDS per wave hold up to four staging buffers -- the
@@ -1275,28 +1297,61 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
   // gets no such variant: the chunked transposition in front of the leaf-major kernel is cheaper there.
   const uint32_t n_chunk = (g->prog.L + 15) / 16;
   const char *e = std::getenv("FDG_ISA_RM_BUFS");
+  // Two waves per SIMD when the program is small enough: the variant is bound by memory latency (one wave per SIMD spends
+  // ~46 % of its cycles waiting for its chunks), and what hides latency is a second wave with its own two
+  // buffers in flight.  Budget per wave: 256 registers (120 values + the nine address registers, no AGPR level) and
+  // 20 KB of LDS = two staging buffers + eight slots.  Taken when nothing then spills to the HBM panel and two buffers
+  // keep re-fetching within a quarter of the chunk count.
+  const char *ew = std::getenv("FDG_ISA_RM_WAVES");
+  if (!(ew && std::atoi(ew) == 1) && !e) {
+    // (both root orders are tried: in the reference's order the first uses of the leaves walk the row monotonically)
+    for (int keep = 0; keep < 2; ++keep) {
+      fdg::OptParams q = cfg_A();
+      q.vn_window = chosen.vn_window;
+      q.n_lds = 8;
+      q.reserve_pairs = 5;
+      q.lookahead_leaf = 48;
+      if (const char *la = std::getenv("FDG_ISA_RM_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
+      q.keep_root_order = keep != 0;
+      build_prog(g, q, pr);
+      if (!pr.supported || pr.n_ld_mem + pr.n_st_mem != 0) continue;
+      uint64_t fetches = 0, gathers = 0;
+      fdg::rm_plan_stats(g->prog, pr, 2, fetches, gathers);
+      if (std::getenv("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] two waves per SIMD (root order %d): %u chunks, %llu fetches, %llu gathers with 2 buffers; lds slots %u\n", keep, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, pr.n_lds_used);
+      if (fetches * 4 <= (uint64_t)n_chunk * 5 + 4 && (fetches * 8192 + gathers * 2048) * 2 <= (uint64_t)g->prog.L * 512 * 5) { if (qsel) *qsel = q; return 2; }
+    }
+  }
   for (uint32_t bufs = e ? (uint32_t)std::max(1, std::min(4, std::atoi(e))) : 2u; bufs <= 4; ++bufs) {
-    fdg::OptParams q = cfg_B();
-    q.vn_window = chosen.vn_window;
-    q.n_lds = 80u - bufs * 16u - 2u;                             // (two slots lost to the 1 KB alignment of the buffers)
-    q.reserve_pairs = 5;
-    q.lookahead_leaf = 48;
-    build_prog(g, q, pr);
-    if (!pr.supported) return 0;
-    uint64_t fetches = 0, gathers = 0;
-    fdg::rm_plan_stats(g->prog, pr, bufs, fetches, gathers);
-    const bool cheap = fetches * 4 <= (uint64_t)n_chunk * 5 + 4;
+    uint64_t best_cost = ~0ull, best_fetches = 0, best_gathers = 0;
+    fdg::OptProgram cand;
+    for (int keep = 0; keep < 2; ++keep) {
+      fdg::OptParams q = cfg_B();
+      q.vn_window = chosen.vn_window;
+      q.n_lds = 80u - bufs * 16u - 2u;                             // (two slots lost to the 1 KB alignment of the buffers)
+      q.reserve_pairs = 5;
+      q.lookahead_leaf = 48;
+      if (const char *la = std::getenv("FDG_ISA_RM_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
+      q.keep_root_order = keep != 0;
+      build_prog(g, q, cand);
+      if (!cand.supported) { if (keep == 0) return 0; continue; }
+      uint64_t fetches = 0, gathers = 0;
+      fdg::rm_plan_stats(g->prog, cand, bufs, fetches, gathers);
+      if (std::getenv("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] one wave per SIMD (root order %d): %u chunks, %llu fetches, %llu gathers with %u buffers, %llu panel accesses\n", keep, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, bufs, (unsigned long long)(cand.n_ld_mem + cand.n_st_mem));
+      const uint64_t cost = fetches * 8192 + gathers * 2048 + (cand.n_ld_mem + cand.n_st_mem) * 1024;
+      if (cost < best_cost) { best_cost = cost; best_fetches = fetches; best_gathers = gathers; pr = std::move(cand); if (qsel) *qsel = q; }
+    }
+    const bool cheap = best_fetches * 4 <= (uint64_t)n_chunk * 5 + 4;
     if (!cheap && bufs < 4 && !e) continue;
-    if ((fetches * 8192 + gathers * 2048) * 2 > (uint64_t)g->prog.L * 512 * 5) return 0;
+    if ((best_fetches * 8192 + best_gathers * 2048) * 2 > (uint64_t)g->prog.L * 512 * 5) return 0;
     return bufs;
   }
   return 0;
 }
 
 struct IsaVariants {
-  fdg::OptProgram p2, pa, pr;
+  fdg::OptProgram p2, pa, pr, pra;
   fdg::CoopProgram coop;
-  bool w2 = false, acc = false;
+  bool w2 = false, acc = false, rm_acc = false;
   uint32_t rm_bufs = 0;
   int coop_verdict = -1;       // a remembered measurement: 0 = the cooperative variant loses, 4 / 8 = it wins with that many waves; -1: none
 };
@@ -1327,16 +1382,28 @@ static void build_coop(const fdg_graph *g, const fdg::OptProgram &prog, IsaVaria
 static void build_variants(const fdg_graph *g, const fdg::OptParams &chosen, bool allow_w2, IsaVariants &V) {
   V.w2 = allow_w2 && !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, V.p2);
   V.acc = build_acc_program(g, chosen, V.pa);
-  V.rm_bufs = build_rm_program(g, chosen, V.pr);
+  fdg::OptParams qrm;
+  V.rm_bufs = build_rm_program(g, chosen, V.pr, &qrm);
+  // fused accumulation of row-major input: the row-major program once more with R + 2 fewer value registers
+  V.rm_acc = false;
+  if (V.rm_bufs && V.acc && g->prog.R >= 1 && g->prog.R <= 16 && !std::getenv("FDG_ISA_NO_RM_ACC")) {
+    qrm.reserve_pairs += g->prog.R + 2;
+    build_prog(g, qrm, V.pra);
+    uint64_t fetches = 0, gathers = 0;
+    if (V.pra.supported) fdg::rm_plan_stats(g->prog, V.pra, V.rm_bufs, fetches, gathers);
+    V.rm_acc = V.pra.supported && (fetches * 8192 + gathers * 2048) * 2 <= (uint64_t)g->prog.L * 512 * 5 &&
+               ((V.pra.n_lds_used * 512u + 1023u) & ~1023u) + V.rm_bufs * 8192u <= 160u * 1024u;
+  }
 }
 static int assemble_and_install(fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags, IsaVariants &V) {
   std::vector<char> co; std::string hash;
   if (V.coop_verdict != 0) build_coop(g, prog, V);
   const fdg::CoopProgram *coop = V.coop.supported ? &V.coop : nullptr;
   const int rc = assemble_isa(g, prog, dir, flags, co, hash, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, "fdg_isa_eval",
-                              V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop);
+                              V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop, V.rm_acc ? &V.pra : nullptr);
   if (rc) return rc;
-  install_isa(g, prog, co, hash, flags, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop);
+  install_isa(g, prog, co, hash, flags, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop,
+              V.rm_acc ? &V.pra : nullptr);
   return FDG_OK;
 }
 

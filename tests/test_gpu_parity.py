@@ -500,6 +500,44 @@ def test_large_real_graphs(libfdg, cuda, name, B):
         assert np.all(np.abs(acc.cpu().numpy() - (want * wn).sum(0)) <= TOL * np.maximum(1.0, np.abs(want * wn).sum(0)))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["parquet_sigma4", "parquet_sigma4_dyn", "gv_sigma4_taylor2", "gv_sigma5", "parquet_sigma5"])
+def test_row_major_variant_eval_accumulate_and_ragged_batches(libfdg, cuda, name):
+    """compile_Python's row-major [B, L] (compiler_python.jl:23,28,45-47) through the ISA back end never takes a
+    transposition pass: full 64-row tiles are read in place by fdg_isa_eval_rm (evaluation) / fdg_isa_eval_rm_acc (fused
+    accumulation), the last B % 64 rows by the plain kernel with the caller's strides.  Values are the oracle's bits for
+    batches of a whole number of tiles, with a ragged tail, of less than one tile, with padded rows and with
+    column-major roots; the handle reports the kernel it launched."""
+    import torch
+    t = workloads.get(name)
+    f = fd.compile_table(t, specialize="isa")
+    assert f.kernel_info()["has_rm"] == 1
+    L, R = t.n_leaf, t.n_root
+    for B, pitch in ((64 * 300 + 37, L), (64 * 257, L), (63, L), (64, L), (64 * 100 + 1, L + 5), (64 * 40 + 63, (L + 15) // 16 * 16)):
+        h_leaf = oracle.philox_uniform(B, L, 1234, 5 * B) - 0.25
+        want = oracle.eval_static(t, h_leaf)
+        buf = torch.full((B, pitch), float("nan"), dtype=torch.float64, device=cuda)
+        leaf = buf[:, :L]
+        leaf.copy_(torch.from_numpy(h_leaf))
+        got = run(f, leaf)
+        assert np.array_equal(got, want), (name, B, pitch, float(np.abs(got - want).max()))
+        assert f.kernel_info()["last_kernel"] == ("fdg_isa_eval_rm" if B >= 64 else "fdg_isa_eval"), (B, f.kernel_info()["last_kernel"])
+        root_cm = torch.zeros((R, B), dtype=torch.float64, device=cuda).t()          # a Julia B x R matrix next to row-major leaves
+        f(root_cm, leaf)
+        torch.cuda.synchronize()
+        assert np.array_equal(root_cm.cpu().numpy(), want), (name, B, "column-major roots")
+        w = torch.rand(B, dtype=torch.float64, device=cuda)
+        acc = f.accumulate(leaf, w)
+        torch.cuda.synchronize()
+        wn = w.cpu().numpy()[:, None]
+        assert np.all(np.abs(acc.cpu().numpy() - (want * wn).sum(0)) <= TOL * np.maximum(1.0, np.abs(want * wn).sum(0))), (name, B, pitch)
+        if R <= 16 and B >= 64:
+            assert f.kernel_info()["last_kernel"] == "fdg_isa_eval_rm_acc", f.kernel_info()["last_kernel"]
+        acc1 = f.accumulate(leaf, None)                                                # weight NULL = 1
+        torch.cuda.synchronize()
+        assert np.all(np.abs(acc1.cpu().numpy() - want.sum(0)) <= TOL * np.maximum(1.0, np.abs(want).sum(0))), (name, B, "unit weights")
+
+
 def test_many_roots_accumulate_and_eval(libfdg, cuda):
     """More roots than the fused accumulation keeps in registers (R = 24 > 16): the optimizing back end writes
     roots to its scratch buffer and reduces them with the separate kernels; values still the oracle's bits."""
