@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(64) k_lds(const double *__restrict__ src, long
   };
   for (long s = 0; s < NB - 1 && s < nstream; ++s) issue(s);
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  double hold[ROOTS > 20 ? ROOTS - 20 : 1][4];
   for (long s = 0; s < nstream; ++s) {
     // (vmcnt counts loads and stores in issue order: right after a tile's two root stores the wait for the landed chunk must
     //  allow them to stay outstanding too, or the wave sits out the stores' whole latency -- ROOTS >= 10 model the naive wait)
@@ -106,10 +107,20 @@ __global__ void __launch_bounds__(64) k_lds(const double *__restrict__ src, long
       put_roots<ROOTS % 10>(root, tile, l, a0, a1, a2, a3, lds + NB * 8192);
       a0 = a1 = a2 = a3 = 0;
     }
-    if (ROOTS > 20 && s % (nchunk * (ROOTS - 20)) == nchunk * (ROOTS - 20) - 1) {     // one store event every (ROOTS - 20) tiles
-      const long tile = blockIdx.x + (s / nchunk) * gridDim.x;
-      put_roots<1>(root, tile, l, a0, a1, a2, a3, lds + NB * 8192);
+    if (ROOTS > 20 && s % nchunk == nchunk - 1) {     // the roots of T = ROOTS - 20 tiles are kept in registers and written together
+      constexpr int T = ROOTS > 20 ? ROOTS - 20 : 1;
+      const long tl = s / nchunk;                    // this wave's tile counter
+      const int slot = (int)(tl % T);
+#pragma unroll
+      for (int q = 0; q < T; ++q) if (q == slot) { hold[q][0] = a0; hold[q][1] = a1; hold[q][2] = a2; hold[q][3] = a3; }
       a0 = a1 = a2 = a3 = 0;
+      if (slot == T - 1 || s == nstream - 1) {
+#pragma unroll
+        for (int q = 0; q < T; ++q) if (q <= slot) {
+          const long tile = blockIdx.x + (tl - slot + q) * gridDim.x;
+          put_roots<1>(root, tile, l, hold[q][0], hold[q][1], hold[q][2], hold[q][3], lds + NB * 8192);
+        }
+      }
     }
   }
   if (!ROOTS) root[blockIdx.x * 64 + l] = a0 + a1 + a2 + a3;
@@ -185,7 +196,7 @@ int main(int argc, char **argv) {
 #define LDSRUN3(NB, WPC, KK, RR, AUX) { char nm[96]; snprintf(nm, sizeof nm, "LDS-direct, %d buffers, %d waves/CU, roots %d, load policy bits %d", NB, WPC, RR, AUX); \
     hipFuncSetAttribute((const void *)k_lds<NB, KK, RR, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / WPC); \
     run(nm, [&] { hipLaunchKernelGGL((k_lds<NB, KK, RR, AUX>), dim3(256 * WPC), dim3(64), 160 * 1024 / WPC / 1024 * 1024, 0, src, pitch, ntile, nchunk, root); }, rows, L); }
-  LDSRUN3(2, 6, 6, 22, 0) LDSRUN3(2, 6, 6, 24, 0) LDSRUN3(2, 6, 6, 28, 0)
+  LDSRUN3(2, 6, 6, 22, 0) LDSRUN3(2, 6, 6, 24, 0) LDSRUN3(2, 6, 6, 28, 0) LDSRUN3(2, 6, 6, 36, 0)
 #define LINRUN(KK, RR, WPC) { char nm[96]; snprintf(nm, sizeof nm, "linear read of the same bytes, K=%d, roots %d, %d waves/CU", KK, RR, WPC); \
     run(nm, [&] { hipLaunchKernelGGL((k_lin<KK, RR>), dim3(256 * WPC), dim3(64), 0, 0, src, pitch, ntile, nchunk, root); }, rows, L); }
   LINRUN(6, 0, 8) LINRUN(6, 1, 8) LINRUN(6, 2, 8) LINRUN(6, 5, 8) LINRUN(6, 6, 8)
