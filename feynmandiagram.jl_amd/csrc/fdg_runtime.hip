@@ -189,15 +189,18 @@ fdg_reduce_lane_partials(const double *__restrict__ partial, uint32_t nwave, uin
   }
 }
 
-// partial[blk][k] = sum over the block's samples of w[b] * root[b][k]  (row-major roots)
+// partial[blk][k] = sum over the block's samples of w[b] * root_k[b]   (root k of sample b at root[k * ld + b]: the scratch
+// matrix is kept column-major, so every pass over a root is a coalesced stream -- with row-major scratch the 180 roots of
+// example/benchmark.jl's vertex function cost 180 strided passes and the reduction took as long as the evaluation)
 __global__ void __launch_bounds__(256)
-fdg_weighted_partials(const double *__restrict__ root, const double *__restrict__ weight, long B, uint32_t R,
+fdg_weighted_partials(const double *__restrict__ root, long ld, const double *__restrict__ weight, long B, uint32_t R,
                       double *__restrict__ partial) {
   __shared__ double sh[256];
   for (uint32_t k = 0; k < R; ++k) {
+    const double *rk = root + (size_t)k * (size_t)ld;
     double s = 0.0;
     for (long b = blockIdx.x * 256L + threadIdx.x; b < B; b += (long)gridDim.x * 256L)
-      s = s + (weight ? weight[b] : 1.0) * root[b * R + k];
+      s = s + (weight ? weight[b] : 1.0) * rk[b];
     s = fdg_block_sum256(s, sh);
     if (threadIdx.x == 0) partial[(size_t)blockIdx.x * R + k] = s;
   }
@@ -551,13 +554,13 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     double *roots = d_root;
     long a_rs = rs, a_rk = rk;
     if (mode == 1 && !fused_acc) {
-      const size_t need = (size_t)B * std::max<uint32_t>(R, 1) * sizeof(double) + (size_t)2048 * R * sizeof(double);
+      const size_t need = (size_t)((B + 15) & ~(int64_t)15) * std::max<uint32_t>(R, 1) * sizeof(double) + (size_t)2048 * R * sizeof(double);
       if (g->ws2_bytes < need) {
         if (g->d_ws2) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws2)); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
         if (hipMalloc(&g->d_ws2, need) != hipSuccess) { set_error("hipMalloc(root scratch) failed"); return FDG_E_NOMEM; }
         g->ws2_bytes = need;
       }
-      roots = (double *)g->d_ws2; a_rs = R; a_rk = 1;
+      roots = (double *)g->d_ws2; a_rs = 1; a_rk = (long)((B + 15) & ~(int64_t)15);      // column-major scratch: root k of sample b at roots[k * ld + b]
     }
     // the kernel forms a lane's offset (lane * stride * 8) in 32 bits: strides that large are brought into the
     // leaf-major workspace first (leaves) or refused (roots); neither occurs with the layouts of DESIGN.md 2
@@ -662,9 +665,9 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       if (rc) return rc;
     }
     if (mode == 1 && !fused_acc) {
-      double *partial = roots + (size_t)B * R;
+      double *partial = roots + (size_t)a_rk * R;
       const uint32_t pb = (uint32_t)std::min<long>(2048, nblk);
-      hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb), dim3(256), 0, st, roots, d_weight, (long)B, R, partial);
+      hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb), dim3(256), 0, st, roots, a_rk, d_weight, (long)B, R, partial);
       hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, pb, R, d_acc);
       HIP_TRY(hipGetLastError());
     }
@@ -1267,7 +1270,9 @@ static bool auto_program_w2(const fdg_graph *g, fdg::OptProgram &p2) {
 // the values, so its program is allocated with that many fewer registers (same configuration otherwise).
 static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, fdg::OptProgram &pa) {
   const uint32_t extra = g->prog.R + 2;
-  if (g->prog.R == 0 || g->prog.R > 16 || chosen.n_reg < extra + 8 || std::getenv("FDG_ISA_NO_FUSED_ACC")) return false;
+  // (up to 40 roots: the 26 rows of example/benchmark_GV.jl's vertex function keep their sums in registers; beyond that the
+  //  accumulators would take more than a third of the value registers and the roots go through the column-major scratch)
+  if (g->prog.R == 0 || g->prog.R > 40 || chosen.n_reg < extra + 64 || std::getenv("FDG_ISA_NO_FUSED_ACC")) return false;
   fdg::OptParams q = chosen;
   // stay inside the occupancy step of the eval kernel (VGPRs per wave: 64 -> 8 waves/SIMD ... 256 -> 2, 512 -> 1)
   static const uint32_t steps[] = {64, 72, 80, 96, 128, 168, 256, 512};
@@ -1314,7 +1319,8 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
       if (const char *la = std::getenv("FDG_ISA_RM_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
       q.keep_root_order = keep != 0;
       build_prog(g, q, pr);
-      if (!pr.supported || pr.n_ld_mem + pr.n_st_mem != 0) continue;
+      const char *pp = std::getenv("FDG_ISA_RM_PANEL_PCT");
+      if (!pr.supported || (pr.n_ld_mem + pr.n_st_mem) * 100 > pr.n_valu * (uint64_t)(pp ? std::atoi(pp) : 0)) continue;
       uint64_t fetches = 0, gathers = 0;
       fdg::rm_plan_stats(g->prog, pr, 2, fetches, gathers);
       if (std::getenv("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] two waves per SIMD (root order %d): %u chunks, %llu fetches, %llu gathers with 2 buffers; lds slots %u\n", keep, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, pr.n_lds_used);
@@ -1386,7 +1392,7 @@ static void build_variants(const fdg_graph *g, const fdg::OptParams &chosen, boo
   V.rm_bufs = build_rm_program(g, chosen, V.pr, &qrm);
   // fused accumulation of row-major input: the row-major program once more with R + 2 fewer value registers
   V.rm_acc = false;
-  if (V.rm_bufs && V.acc && g->prog.R >= 1 && g->prog.R <= 16 && !std::getenv("FDG_ISA_NO_RM_ACC")) {
+  if (V.rm_bufs && V.acc && g->prog.R >= 1 && g->prog.R <= 40 && !std::getenv("FDG_ISA_NO_RM_ACC")) {
     qrm.reserve_pairs += g->prog.R + 2;
     build_prog(g, qrm, V.pra);
     uint64_t fetches = 0, gathers = 0;
@@ -1666,7 +1672,7 @@ int fdg_mc_isa_build(fdg_graph *g) {
   }
   if (!pe.supported) { set_error("the fused ISA step does not cover this graph / these leaves: " + pe.why); return FDG_E_UNSUPPORTED; }
   const uint32_t R = g->prog.R;
-  bool has_acc = R >= 1 && R <= 16;
+  bool has_acc = R >= 1 && R <= 40 && q.n_reg >= R + 2 + 64;
   if (has_acc) {
     fdg::OptParams qa = q;
     qa.reserve_pairs = R + 2;        // (build_mc_program takes the macro ops' temporaries off the value budget itself)
@@ -1712,17 +1718,18 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
     // more than 16 roots: no room for the accumulators next to the values -- roots to a scratch matrix, then the
     // deterministic weighted reduction the other back ends use
     if (R == 0) return FDG_OK;
-    const size_t need = (size_t)B * R * sizeof(double) + (size_t)2048 * R * sizeof(double);
+    const int64_t ld = (B + 15) & ~(int64_t)15;                  // column-major scratch (see fdg_weighted_partials)
+    const size_t need = (size_t)ld * R * sizeof(double) + (size_t)2048 * R * sizeof(double);
     if (g->ws2_bytes < need) {
       if (g->d_ws2) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws2)); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
       if (hipMalloc(&g->d_ws2, need) != hipSuccess) { set_error("hipMalloc(root scratch) failed"); return FDG_E_NOMEM; }
       g->ws2_bytes = need;
     }
-    double *roots = (double *)g->d_ws2, *partial = roots + (size_t)B * R;
-    rc = fdg_mc_isa_run(g, 0, d_K, ks, kc, d_T, ts, tc, kF, beta, lambda, roots, (int64_t)R, 1, nullptr, nullptr, B, st);
+    double *roots = (double *)g->d_ws2, *partial = roots + (size_t)ld * R;
+    rc = fdg_mc_isa_run(g, 0, d_K, ks, kc, d_T, ts, tc, kF, beta, lambda, roots, 1, ld, nullptr, nullptr, B, st);
     if (rc) return rc;
     const uint32_t pb = (uint32_t)std::min<long>(2048, (long)((B + 255) / 256));
-    hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb), dim3(256), 0, st, roots, d_weight, (long)B, R, partial);
+    hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb), dim3(256), 0, st, roots, (long)ld, d_weight, (long)B, R, partial);
     hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, pb, R, d_acc);
     HIP_TRY(hipGetLastError());
     return FDG_OK;

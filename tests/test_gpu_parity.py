@@ -538,24 +538,30 @@ def test_row_major_variant_eval_accumulate_and_ragged_batches(libfdg, cuda, name
         assert np.all(np.abs(acc1.cpu().numpy() - want.sum(0)) <= TOL * np.maximum(1.0, np.abs(want).sum(0))), (name, B, "unit weights")
 
 
-def test_many_roots_accumulate_and_eval(libfdg, cuda):
-    """More roots than the fused accumulation keeps in registers (R = 24 > 16): the optimizing back end writes
-    roots to its scratch buffer and reduces them with the separate kernels; values still the oracle's bits."""
+@pytest.mark.parametrize("n_root", [24, 48])
+def test_many_roots_accumulate_and_eval(libfdg, cuda, n_root):
+    """Up to 40 roots the optimizing back end keeps the weighted sums in registers (fdg_isa_eval_acc); with more, it writes
+    the roots to a column-major scratch matrix and reduces them with the separate kernels (every pass over a root a
+    coalesced stream); leaf-major and row-major input, ragged batch; values the oracle's bits, sums within 1e-12."""
     import torch
     from feynmandiagram_jl_amd.nodetable import synthetic_parquet_like
-    t = synthetic_parquet_like(n_node=600, n_leaf=40, n_root=24, seed=5)
-    assert t.n_root == 24
+    t = synthetic_parquet_like(n_node=600, n_leaf=40, n_root=n_root, seed=5)
+    assert t.n_root == n_root
     B = 70_001
     for spec in ("isa", True, False):
         f = fd.compile_table(t, specialize=spec)
-        leaf = dev_leaves(cuda, B, t.n_leaf, 3, 0, "leaf_major" if spec == "isa" else "sample_major")
-        want = oracle.eval_static(t, leaf.cpu().numpy())
-        assert np.array_equal(run(f, leaf), want)
-        w = torch.rand(B, dtype=torch.float64, device=cuda)
-        acc = f.accumulate(leaf, w)
-        torch.cuda.synchronize()
-        wn = w.cpu().numpy()[:, None]
-        assert np.all(np.abs(acc.cpu().numpy() - (want * wn).sum(0)) <= TOL * np.maximum(1.0, np.abs(want * wn).sum(0)))
+        for layout in (("leaf_major", "sample_major") if spec == "isa" else ("sample_major",)):
+            leaf = dev_leaves(cuda, B, t.n_leaf, 3, 0, layout)
+            want = oracle.eval_static(t, leaf.cpu().numpy())
+            assert np.array_equal(run(f, leaf), want)
+            w = torch.rand(B, dtype=torch.float64, device=cuda)
+            acc = f.accumulate(leaf, w)
+            torch.cuda.synchronize()
+            wn = w.cpu().numpy()[:, None]
+            assert np.all(np.abs(acc.cpu().numpy() - (want * wn).sum(0)) <= TOL * np.maximum(1.0, np.abs(want * wn).sum(0))), (n_root, spec, layout)
+            if spec == "isa":
+                k = f.kernel_info()["last_kernel"]
+                assert ("_acc" in k) == (n_root <= 40), (n_root, layout, k)
 
 
 def test_fused_mc_step(libfdg, cuda):
