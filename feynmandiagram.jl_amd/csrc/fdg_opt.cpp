@@ -975,7 +975,7 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   B0.vn_touch = std::getenv("FDG_VN_BIRTH_WINDOW") == nullptr;   // default: the window counts from the last read
   B0.remat_window = prm.remat_window;
   B0.remat_cost = prm.remat_cost;
-  B0.keep_root_order = prm.keep_root_order;
+  B0.keep_root_order = prm.keep_root_order || std::getenv("FDG_KEEP_ROOT_ORDER") != nullptr;     // (the environment switch is for experiments)
   if (const char *rw = std::getenv("FDG_REMAT_WINDOW")) B0.remat_window = (uint64_t)std::atoll(rw);     // experiments
   if (const char *tw = std::getenv("FDG_TERM_WINDOW")) B0.term_window = (uint32_t)std::max(1, std::atoi(tw));
   if (const char *tr = std::getenv("FDG_TERM_RECENT")) B0.term_recent = (uint32_t)std::max(1, std::atoi(tr));

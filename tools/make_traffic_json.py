@@ -2,10 +2,11 @@
 """profiles/r02_traffic.json from the PMC passes of tools/prof_r02.sh: per workload and layout, HBM-side bytes per
 evaluation of the evaluator kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / samples  (FETCH_SIZE / WRITE_SIZE in KiB per
 dispatch; the factor 2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md's HBM section, calibrated on sigma2 where
-the byte count is known: 64 B read + 16 B written per evaluation).  usage: make_traffic_json.py gpurun_out/prof_<tag> out.json"""
+the byte count is known: 64 B read + 16 B written per evaluation).  usage: make_traffic_json.py gpurun_out/prof_<tag> out.json [r03]"""
 import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root, out_path = sys.argv[1], sys.argv[2]
+TAG = sys.argv[3] if len(sys.argv) > 3 else "r02"        # prefix of the summaries kept under profiles/
 SAMPLES = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "gv_sigma4": 8_000_000, "gv_sigma5": 2_000_000, "gv_sigma6": 500_000,
            "gv_sigma4_taylor2": 4_000_000, "parquet_sigma4": 100_000_000, "parquet_sigma4_dyn": 8_000_000, "parquet_sigma4_insdyn": 4_000_000,
            "parquet_sigma4_taylor2": 8_000_000, "parquet_sigma5": 2_000_000, "parquet_ver4_4": 500_000, "gv_ver4_4": 500_000}
@@ -38,7 +39,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     B = SAMPLES[wl]
     key = wl if lay == "leaf_major" else wl + ":" + lay
     out[key] = {"layout": lay, "samples": B, "kernels": kernels, "fetch_kib": fetch, "write_kib": write,
-                "bytes_per_eval": round((2 * fetch + write) * 1024 / B, 1), "source": f"profiles/r02_pmc_{wl}_{lay}.txt"}
+                "bytes_per_eval": round((2 * fetch + write) * 1024 / B, 1), "source": f"profiles/{TAG}_pmc_{wl}_{lay}.txt"}
 for k, v in prev.items():
     out.setdefault(k, v)
 json.dump(out, open(out_path, "w"), indent=1)
