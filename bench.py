@@ -370,6 +370,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc-step", action="store_true", help="skip the secondary measurement of the whole Monte-Carlo step (leaves from momenta and times)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other workloads (config 2, 3 stand-ins, 5, row-major layout) measured after the headline")
+    ap.add_argument("--secondary", default="", help="comma-separated workload:layout pairs to measure after the headline instead of the full list")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--dry-run", action="store_true",
                     help="no device work: one process per rank on the CPU (gloo), the evaluator replaced by a stub that adds the shard's "
@@ -520,10 +521,11 @@ def main():
         if rank == 0 and world == 1 and not DRY:
             sec = []
             head = (args.workload, args.layout)
-            for wl, lay in (("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "leaf_major"),
-                            ("parquet_sigma4_insdyn", "leaf_major"), ("parquet_sigma4_taylor2", "leaf_major"), ("parquet_sigma5", "leaf_major"),
-                            ("parquet_ver4_4", "leaf_major"), ("gv_ver4_4", "leaf_major"), ("sigma2", "leaf_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "leaf_major"), ("gv_sigma5", "leaf_major"),
-                            ("gv_sigma6", "leaf_major"), ("gv_sigma4_taylor2", "leaf_major"), ("gv_sigma4_taylor2", "sample_major")):
+            full = (("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "leaf_major"),
+                    ("parquet_sigma4_insdyn", "leaf_major"), ("parquet_sigma4_taylor2", "leaf_major"), ("parquet_sigma5", "leaf_major"),
+                    ("parquet_ver4_4", "leaf_major"), ("gv_ver4_4", "leaf_major"), ("sigma2", "leaf_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "leaf_major"), ("gv_sigma5", "leaf_major"),
+                    ("gv_sigma6", "leaf_major"), ("gv_sigma4_taylor2", "leaf_major"), ("gv_sigma4_taylor2", "sample_major"))
+            for wl, lay in (tuple(tuple(x.split(":")) for x in args.secondary.split(",")) if args.secondary else full):
                 if (wl, lay) != head:
                     sec.append(secondary_case(wl, lay, dev, copy_gbs=copy_gbs))
             out["secondary"] = sec

@@ -1570,9 +1570,11 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
 }
 
 static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
-  if (!has_opt_params(g) && !std::getenv("FDG_IGNORE_TUNED")) {
-    const int t = use_tuned(g, dir, flags);        // a remembered on-device choice wins (no device needed to use it)
-    if (t != 0) return t < 0 ? t : FDG_OK;
+  if (!has_opt_params(g)) {
+    if (!std::getenv("FDG_IGNORE_TUNED")) {          // (with the switch and FDG_SPEC_AUTOTUNE: tune again, overwriting the remembered choice)
+      const int t = use_tuned(g, dir, flags);        // a remembered on-device choice wins (no device needed to use it)
+      if (t != 0) return t < 0 ? t : FDG_OK;
+    }
     if (flags & FDG_SPEC_AUTOTUNE) return autotune_isa(g, dir, flags);
   }
   fdg::OptProgram prog;

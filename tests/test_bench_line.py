@@ -105,3 +105,34 @@ def test_dry_run_of_bench_itself(world, tmp_path):
     # every rank added its shard's sample count once per step; ONE all-reduce summed the ranks
     assert detail["config5"]["observable"][0] == c5["total_samples"]
     assert detail["config"]["shard_offset_rank0"] == 0 and detail["config5"]["shard_offset_rank0"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_line_on_the_device(tmp_path):
+    """The real thing, shortened: `python bench.py` on cuda:0 with a smaller batch and two secondary rows.  One parseable
+    line; the kernel named in it is the one the library launched (hand-written ISA, from fdg_graph_kernel_info); roofline
+    and cpu_baseline present and consistent; every checked sample bit-equal to the CPU port."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "3", "--samples", "4000000", "--cpu-seconds", "2",
+           "--secondary", "parquet_sigma4:sample_major,gv_sigma5:leaf_major"]
+    p = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < bench.LINE_LIMIT, p.stdout[-2000:]
+    got = json.loads(lines[0][-8000:])
+    assert got["metric"] == "graph-evaluations/sec" and got["n_gpus"] == 1 and got["steps"] == 5 and got["dtype"] == "f64" and got["vs_baseline"] is None
+    assert got["config"]["workload"].startswith("parquet_sigma4") and got["config"]["samples_per_step_per_gpu"] == 4000000
+    r = got["roofline"]
+    assert r["kernel"] == "fdg_isa_eval_nt" and r["bound"] == "hbm" and r["ops_exec_per_eval"] > 0
+    assert abs(r["achieved"] - got["value"] * 704 / 1e9) / r["achieved"] < 0.1          # 8 (L + R) bytes per evaluation, HIP events vs wall clock
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3 and r["frac_hbm_min_over_steps"] <= r["frac"] + 1e-9 <= r["frac_hbm_max_over_steps"] + 2e-9
+    assert got["value"] > 1e9 and r["frac"] > 0.3                                        # (a smaller batch than the default: not the headline's figure)
+    c = got["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_matches_cpu_bitwise"] is True
+    rows = {(x[0], x[1]): x for x in got["secondary"]}
+    assert set(rows) == {("parquet_sigma4", "rm"), ("gv_sigma5", "lm")} and all(x[-1] is True for x in rows.values())
+    assert got["config5"]["total_samples"] >= 10**9 and got["config5"]["n_gpus"] == 1
+    assert got["mc_step"]["value"] > 0 and got["mc_step"]["max_dev_over_Sk"] < 1e-11 and got["mc_step"]["max_dev_over_Ak"] < 1e-14
+    detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
+    assert detail["secondary"][0]["roofline"]["kernel"] == "fdg_isa_eval_rm"
+    assert detail["config5"]["roofline_rank0"]["kernel"].startswith("fdg_isa_eval_acc")
