@@ -101,6 +101,30 @@ def test_kat_through_device(libfdg, cuda, spec):
 
 
 @pytest.mark.parametrize("spec", [False, True, "isa"], ids=["interp", "hipjit", "isa"])
+def test_reference_taylor_kat_through_device(libfdg, cuda, spec):
+    """test/taylor.jl:97-113 on the device: the 16 Taylor coefficients of the 2nd-order GV self-energy (fixture
+    tests/golden/gv_sigma2_counterterm_kat.*) with all leaves 1 are the counter-term catalogs' numbers, exactly, for every
+    sample of a batch in both layouts; and the shipped config-4 graphs give the catalogs Sigma4_<k>_0 / Sigma5_<k>_0."""
+    import json
+    import torch
+    from feynmandiagram_jl_amd.nodetable import NodeTable
+    t = NodeTable.load(os.path.join(GOLD, "gv_sigma2_counterterm_kat.npz"))
+    want = json.load(open(os.path.join(GOLD, "gv_sigma2_counterterm_kat.json")))["expected"]
+    f = fd.compile_table(t, specialize=spec)
+    B = 64 * 3 + 5
+    for leaf in (torch.ones((B, t.n_leaf), dtype=torch.float64, device=cuda), torch.ones((t.n_leaf, B), dtype=torch.float64, device=cuda).t()):
+        got = run(f, leaf)
+        assert got.shape == (B, 16) and all(got[b].tolist() == want for b in (0, 63, 64, B - 1)) and np.all(got == got[0])
+    for name, exp in (("gv_sigma4_taylor2", [21.0, 3.0, 84.0, 12.0, 210.0, 30.0]), ("gv_sigma5_taylor2", [-31.0, -77.0, -155.0, -385.0])):
+        if spec is True and name == "gv_sigma5_taylor2":
+            continue                                   # (115 588 nodes through hiprtc: minutes)
+        tw = workloads.get(name)
+        fw = fd.compile_table(tw, specialize=spec)
+        got = run(fw, torch.ones((130, tw.n_leaf), dtype=torch.float64, device=cuda))
+        assert got[0].tolist()[:len(exp)] == exp and np.all(got == got[0]), name
+
+
+@pytest.mark.parametrize("spec", [False, True, "isa"], ids=["interp", "hipjit", "isa"])
 def test_edge_cases(libfdg, cuda, spec):
     import torch
     # leaf as root, interior root, missing root id (left untouched), duplicate id, Power nodes, fan-in 40

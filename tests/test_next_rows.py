@@ -616,3 +616,42 @@ def test_mc_program_refuses_what_its_formulas_do_not_cover(libfdg):
     tab, _keep = capi.make_leaf_tables(z["leaf_type"], order, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]), 1.9, 3.0, 1.2)
     with pytest.raises(capi.FdgError, match="order above 5"):
         capi.GraphHandle(t).mc_program(tab)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_GV), reason="reference checkout not present (GPU box)")
+def test_taylor_coefficients_equal_the_counterterm_catalogs_orders_1_to_4():
+    """The identity of test/taylor.jl:97-113 beyond the order the reference tests: for the 1st- to 4th-order GV self-energy and
+    every counter-term catalog Sigma<n>_<VerOrder>_<GOrder>.diag with GOrder, VerOrder <= 2 that the reference ships (32 files),
+    the two-variable Taylor coefficient [GOrder, VerOrder] of the restated expansion equals the catalog's sum of
+    SymFactor * SpinFactor per external-time group, exactly; and the committed fixture is what the generator produces."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_gv_counterterm_kat as mk
+    from feynmandiagram_jl_amd.graph import PostOrderDFS, isleaf
+    from feynmandiagram_jl_amd.producers import gv, taylor
+    table, expected, _ = mk.build()
+    ref = NodeTable.load(os.path.join(os.path.dirname(__file__), "golden", "gv_sigma2_counterterm_kat.npz"))
+    for k in ("op", "power", "child_off", "child_idx", "child_fac", "root_slot"):
+        assert np.array_equal(getattr(table, k), getattr(ref, k)), k
+    n_checked = 0
+    for order in (1, 2, 3, 4):
+        graphs = gv.diagsGV("sigma", order, REF_GV)
+        taylor.set_variables("x y", orders=[2, 2])
+        dep = {n.id: [isinstance(n.properties, gv.BareGreenId), isinstance(n.properties, gv.BareInteractionId)]
+               for g in graphs for n in PostOrderDFS(g) if isleaf(n)}
+        series = []
+        for g in graphs:
+            t = taylor.taylorexpansion(g, dep)
+            series.append(t[0] if isinstance(t, tuple) else t)
+        for go in range(3):
+            for vo in range(3):
+                path = f"{REF_GV}/groups_sigma/Sigma{order}_{vo}_{go}.diag"
+                if not os.path.exists(path):
+                    continue
+                want = mk.catalog_sums(path)
+                for g, s in zip(graphs, series):
+                    tb, _, _ = lower([s.coeffs[(go, vo)]])
+                    got = float(oracle.eval_static(tb, np.ones((1, tb.n_leaf)))[0][0])
+                    assert got == want[tuple(x - 1 for x in g.properties.extT)], (order, go, vo, g.properties.extT)
+                n_checked += 1
+    assert n_checked == 32

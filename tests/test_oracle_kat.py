@@ -103,6 +103,32 @@ def test_c_backend_text_compiles_and_matches():
         assert np.array_equal(cb(leaf, 3), oracle.eval_static(t, leaf))
 
 
+def test_kat_taylor_of_gv_sigma_against_the_counterterm_catalogs():
+    """test/taylor.jl:97-113 ("Taylor AD of Sigma FeynmanGraph"): with all leaves 1, the Taylor coefficient [GOrder, VerOrder] of
+    the 2nd-order GV self-energy (x on fermionic, y on bosonic lines, orders [2, 2]) equals the counter-term catalog
+    Sigma2_<VerOrder>_<GOrder>.diag evaluated the same way, for the eight orders the reference tests and both external-time
+    groups, exactly (`==`).  The fixture (tests/golden/make_gv_counterterm_kat.py) holds the node table whose 16 roots are
+    those coefficients -- built by the restated reader and Taylor pass -- and the 16 numbers computed from the catalog text."""
+    t = NodeTable.load(os.path.join(GOLD, "gv_sigma2_counterterm_kat.npz"))
+    kat = json.load(open(os.path.join(GOLD, "gv_sigma2_counterterm_kat.json")))
+    assert t.n_root == 16 == len(kat["expected"]) and kat["orders"] == [[2, 0, 0], [2, 0, 1], [2, 0, 2], [2, 1, 0], [2, 1, 1], [2, 2, 0], [2, 1, 2], [2, 2, 2]]
+    s, i = both(t, np.ones(t.n_leaf))
+    assert s[0].tolist() == kat["expected"] == i[0].tolist()
+    assert kat["expected"][:2] == [1.0, -1.0] and kat["expected"][-2:] == [18.0, -18.0]
+
+
+def test_kat_config4_workloads_meet_the_counterterm_catalogs():
+    """The same identity on the shipped config-4 graphs: order-k Taylor coefficients in the coupling of the 4- and 5-loop GV
+    self-energy, all leaves 1, are the sums of SymFactor * SpinFactor of the catalogs Sigma4_<k>_0.diag / Sigma5_<k>_0.diag
+    (numbers from the catalog text, tests/golden/make_gv_counterterm_kat.py: catalog_sums; Sigma5_2_0 does not exist); the
+    Parquet form of the 4-loop graph carries the fermionic sign, so its four rows sum to minus the GV totals per order."""
+    one = lambda name: oracle.eval_static(workloads.get(name), np.ones((1, workloads.get(name).n_leaf)))[0].tolist()
+    assert one("gv_sigma4_taylor2") == [21.0, 3.0, 84.0, 12.0, 210.0, 30.0]            # Sigma4_0_0, Sigma4_1_0, Sigma4_2_0: (dynamic, instant)
+    assert one("gv_sigma5_taylor2")[:4] == [-31.0, -77.0, -155.0, -385.0]               # Sigma5_0_0, Sigma5_1_0
+    p = np.array(one("parquet_sigma4_taylor2")).reshape(3, 4).sum(axis=1)
+    assert p.tolist() == [-(21.0 + 3.0), -(84.0 + 12.0), -(210.0 + 30.0)]
+
+
 def test_power_nodes():
     g1 = fd.Graph([])
     g2 = fd.Graph([])
