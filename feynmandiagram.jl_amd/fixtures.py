@@ -117,3 +117,37 @@ def kat_taylor_getdiagram(spin: float = 2.0, D: int = 3):
     vsum = Graph([vdd, vde, ved], operator=Sum())
     root = Graph.new([vsum, ggn], operator=Prod(), factor=1 / (2 * math.pi) ** D, name="root")
     return root, (spin - 2.0) / (2 * math.pi) ** D
+
+
+def kat_first_derivatives():
+    """test/computational_graph.jl:930-988 (the "forwardAD_root!" set): F3 = g1 + g2, F2 = 2 g1 + g3 + 3 F3 with g3 = 2 * leaf,
+    F1 = (3 g1) F2 F3, F0 = F1 F3, F0' = F1 + F3; the reference evaluates the first-derivative graphs of F1, F2, F3, F0, F0' on
+    leaf vectors [g1, g2, g3, dg1, dg2, dg3] and holds the values below (exact ==).  The legacy graph AD that builds those graphs
+    is out of scope; the same directional derivatives are the order-1 Taylor coefficients of the restated Taylor pass with every
+    leaf depending on the variable.  Returns ``(table, [(leaf vector in leafVal order, [expected root or None, ...]), ...])``:
+    known answers of the reference on leaf vectors that are not all ones, through the lowering's leaf numbering."""
+    import numpy as np
+    from .lowering import lower
+    from .graph import linear_combination
+    from .producers import taylor
+    reset_uid()
+    g1, g2, g3 = Graph([]), Graph([]), Graph.new([], factor=2.0)
+    F3 = g1 + g2
+    F2 = linear_combination([g1, g3, F3], [2, 1, 3])
+    F1 = Graph([g1, F2, F3], operator=Prod(), subgraph_factors=[3.0, 1.0, 1.0])
+    F0 = F1 * F3
+    F0r = F1 + F3
+    taylor.set_variables("x", orders=[1])
+    leaves = [g1, g2, g3.subgraphs[0]]                 # eldest(g3): the leaf under the wrapping Prod that carries the factor
+    series, cmap = taylor.taylorexpansion([F1, F2, F3, F0, F0r], {l.id: [True] for l in leaves})
+    table, leafmap, _ = lower([s.coeffs[(1,)] for s in series], name="kat_first_derivatives")
+    where = {id(cmap[l.id].coeffs[(o,)]): k + 3 * o for k, l in enumerate(leaves) for o in (0, 1)}
+    cases = []
+    for values, want in (((1.0, 1.0, 1.0, 1.0, 0.0, 0.0), [120.0, 5.0, 1.0, 300.0, None]),
+                         ((5.0, -1.0, 2.0, 0.0, 1.0, 0.0), [570.0, 3.0, 1.0, 3840.0, None]),
+                         ((5.0, -1.0, 2.0, 0.0, 0.0, 1.0), [120.0, 2.0, 0.0, 480.0, 120.0])):
+        v = np.zeros(table.n_leaf)
+        for idx, obj in leafmap.items():
+            v[idx - 1] = values[where[id(obj)]]
+        cases.append((v, want))
+    return table, cases

@@ -115,6 +115,12 @@ def test_reference_taylor_kat_through_device(libfdg, cuda, spec):
     for leaf in (torch.ones((B, t.n_leaf), dtype=torch.float64, device=cuda), torch.ones((t.n_leaf, B), dtype=torch.float64, device=cuda).t()):
         got = run(f, leaf)
         assert got.shape == (B, 16) and all(got[b].tolist() == want for b in (0, 63, 64, B - 1)) and np.all(got == got[0])
+    # test/computational_graph.jl:930-988: known answers on leaf vectors that are not all ones (fixtures.kat_first_derivatives)
+    td, cases = fixtures.kat_first_derivatives()
+    fdv = fd.compile_table(td, specialize=spec)
+    for leaf, wantd in cases:
+        got = run(fdv, torch.from_numpy(np.tile(leaf, (70, 1))).to(cuda))
+        assert all(got[b, k] == w for b in (0, 63, 69) for k, w in enumerate(wantd) if w is not None), (leaf, got[0])
     for name, exp in (("gv_sigma4_taylor2", [21.0, 3.0, 84.0, 12.0, 210.0, 30.0]), ("gv_sigma5_taylor2", [-31.0, -77.0, -155.0, -385.0])):
         if spec is True and name == "gv_sigma5_taylor2":
             continue                                   # (115 588 nodes through hiprtc: minutes)

@@ -129,6 +129,18 @@ def test_kat_config4_workloads_meet_the_counterterm_catalogs():
     assert p.tolist() == [-(21.0 + 3.0), -(84.0 + 12.0), -(210.0 + 30.0)]
 
 
+def test_kat_first_derivatives_with_explicit_leaf_vectors():
+    """test/computational_graph.jl:930-988: 120, 5, 1 / 570, 3, 1 / 120, 2, 0 / 300, 3840, 480 / 120 on explicit leaf vectors
+    (fixtures.kat_first_derivatives: the derivative graphs come from the restated Taylor pass), both evaluators, exact."""
+    t, cases = fixtures.kat_first_derivatives()
+    assert t.n_leaf == 6 and t.n_root == 5 and len(cases) == 3
+    for leaf, want in cases:
+        st, it = both(t, leaf)
+        for k, w in enumerate(want):
+            if w is not None:
+                assert st[0, k] == w == it[0, k], (leaf, k, st[0], it[0])
+
+
 def test_power_nodes():
     g1 = fd.Graph([])
     g2 = fd.Graph([])
