@@ -993,6 +993,10 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   if (!B.ok) return;
   if (prm.n_reg < 4) { out.supported = false; out.why = "too few registers"; return; }
   if (prm.fma) fuse_fma(B.u, B.next_vid);
+  if (prm.roots_last) {             // ... in root order, so that neighbours in memory are neighbours in the program
+    auto tail = std::stable_partition(B.u.begin(), B.u.end(), [](const UOp &o) { return o.kind != M_ROOT; });
+    std::stable_sort(tail, B.u.end(), [](const UOp &x, const UOp &y) { return x.d < y.d; });
+  }
   if (!fit_registers(B.u, prm, out)) return;
   Alloc A(p, out.params, B.u, B.next_vid, out);
   A.run();

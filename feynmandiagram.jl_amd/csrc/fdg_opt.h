@@ -80,6 +80,8 @@ struct OptParams {
   bool fma = false;               // FDG_SPEC_FAST_MATH: a product used once, by a sum, is fused into it (v_fma_f64)
   uint32_t remat_window = 0;      // > 0: the value of a cheap node not read for this many ops is forgotten and computed again by its
   uint32_t remat_cost = 4;        //      next consumer (nodes whose own fold has at most remat_cost steps); exact, trades arithmetic for spills
+  bool roots_last = false;        // all root stores at the end of the tile, back to back (row-major roots: the R stores of a row then hit their
+                                  // shared cache lines together instead of hundreds of ops apart)
   bool keep_root_order = false;   // roots in the reference's statement order instead of the cone-overlap order: leaves are numbered by first
                                   // visit in that order, so their first uses then walk the leaf index monotonically (row-major variant)
   uint32_t reserve_pairs = 0;     // VGPR pairs the kernel variant keeps above the values (accumulators, weight): the value budget shrinks

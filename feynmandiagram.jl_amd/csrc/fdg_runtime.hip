@@ -1318,6 +1318,7 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
       q.lookahead_leaf = 48;
       if (const char *la = std::getenv("FDG_ISA_RM_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
       q.keep_root_order = keep != 0;
+      q.roots_last = true;             // the R stores of a row back to back: they share cache lines when the roots are row-major too (+7-11 %)
       build_prog(g, q, pr);
       const char *pp = std::getenv("FDG_ISA_RM_PANEL_PCT");
       if (!pr.supported || (pr.n_ld_mem + pr.n_st_mem) * 100 > pr.n_valu * (uint64_t)(pp ? std::atoi(pp) : 0)) continue;
@@ -1338,6 +1339,7 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
       q.lookahead_leaf = 48;
       if (const char *la = std::getenv("FDG_ISA_RM_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
       q.keep_root_order = keep != 0;
+      q.roots_last = true;             // the R stores of a row back to back: they share cache lines when the roots are row-major too (+7-11 %)
       build_prog(g, q, cand);
       if (!cand.supported) { if (keep == 0) return 0; continue; }
       uint64_t fetches = 0, gathers = 0;
@@ -1394,6 +1396,7 @@ static void build_variants(const fdg_graph *g, const fdg::OptParams &chosen, boo
   V.rm_acc = false;
   if (V.rm_bufs && V.acc && g->prog.R >= 1 && g->prog.R <= 40 && !std::getenv("FDG_ISA_NO_RM_ACC")) {
     qrm.reserve_pairs += g->prog.R + 2;
+    qrm.roots_last = false;           // (accumulation: a root is consumed where it is finished)
     build_prog(g, qrm, V.pra);
     uint64_t fetches = 0, gathers = 0;
     if (V.pra.supported) fdg::rm_plan_stats(g->prog, V.pra, V.rm_bufs, fetches, gathers);
