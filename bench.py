@@ -26,7 +26,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6    # AMD spec, FMA counted as 2 (not in the local g
 FP64_NOFMA_PEAK_TOPS = 39.3
 FP64_NOFMA_MEASURED_TOPS = 34.4
 CONFIG5_TOTAL_SAMPLES = 1_000_000_000     # BASELINE.json config 5: 10^9 samples over the GPUs of the node
-LINE_LIMIT = 3000                         # bytes of the stdout line (the driver keeps the last ~8 KB of stdout)
+LINE_LIMIT = 3600                         # bytes of the stdout line (the driver keeps the last ~8 KB of stdout)
 DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
 
 
@@ -509,6 +509,32 @@ def main():
         out["kernel_info"] = {k: info[k] for k in ("max_live", "spec_vgpr", "spec_lds_bytes", "spec_scratch_bytes")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(t, leaf, root, args.cpu_seconds)
+        if world == 1 and args.backend == "isa" and not DRY and not args.fast_math:
+            # The Monte-Carlo use of the same launch (after and outside the timed region, never part of `value`): weighted
+            # accumulation inside the evaluator on the SAME resident batch -- fdg_accumulate_device: roots never reach HBM, so
+            # the read stream has no stores in it.  Algorithmic bytes per sample: 8 L + 8 (the weight).
+            try:
+                wgt = torch.rand(B, dtype=torch.float64, device=dev)
+                accv = torch.zeros(R, dtype=torch.float64, device=dev)
+                n_acc = int(max(3, min(args.steps, 30)))
+                for _ in range(5):
+                    f.accumulate(leaf, wgt, accv)
+                sync()
+                eva = Stamps(n_acc, stream)
+                eva.record(0)
+                for i in range(n_acc):
+                    f.accumulate(leaf, wgt, accv)
+                    eva.record(i + 1)
+                sync()
+                ms_acc = eva.ms()
+                avg_acc = sum(ms_acc) / len(ms_acc) / 1e3
+                ka, ops_a = kernel_of(f)
+                ra = roofline_of({"bytes_alg": 8 * (L + 1), "bytes_alg_accumulate": 8 * (L + 1)}, B, avg_acc, ka, accumulate=True, ops_exec=ops_a)
+                out["accumulate"] = {"value": B / avg_acc, "unit": "samples/s", "samples_per_launch": B, "timed_launches": n_acc, "avg_kernel_ms": avg_acc * 1e3,
+                                     "roofline": ra, "what": "fdg_accumulate_device on the headline's resident batch (acc[k] += sum_b w_b root_k(b), roots never written)"}
+                del wgt, accv
+            except Exception as e:
+                out["accumulate"] = {"error": f"{type(e).__name__}: {e}"}
     del case, leaf, root, f, step
     if not DRY:
         torch.cuda.empty_cache()
@@ -597,6 +623,11 @@ def compact_line(full):
             line["config5"] = {"workload": "gv_sigma5", "value": _r(c5["value"], 5), "unit": "samples/s", "n_gpus": c5["n_gpus"], "total_samples": c5["total_samples"],
                                "steps": c5["steps"], "bound": r.get("bound"), "frac": _r(r.get("frac"), 3), "frac_hbm": _r(r.get("frac_hbm"), 3),
                                "frac_valu": _r(r.get("frac_valu"), 3)}
+    ac = full.get("accumulate")
+    if ac:
+        line["accumulate"] = ({"error": ac["error"][:80]} if "error" in ac else
+                              {"value": _r(ac["value"], 5), "unit": "samples/s", "kernel": ac["roofline"]["kernel"], "frac_hbm": _r(ac["roofline"]["frac_hbm"], 4),
+                               "frac_valu": _r(ac["roofline"]["frac_valu"], 3)})
     mc = full.get("mc_step")
     if mc:
         line["mc_step"] = {"value": _r(mc.get("value"), 5), "unit": "samples/s", "leaf_parity": "unpinned (Lehmann.jl absent)",
@@ -604,7 +635,7 @@ def compact_line(full):
     line["detail"] = "bench_detail.json"
     text = json.dumps(line, separators=(",", ":"))
     # never let the line outgrow the driver's capture: drop the optional parts, least important first
-    for k in ("mc_step", "secondary", "secondary_cols", "config5"):
+    for k in ("mc_step", "accumulate", "secondary", "secondary_cols", "config5"):
         if len(text) <= LINE_LIMIT:
             break
         line.pop(k, None)

@@ -34,6 +34,7 @@ def _canned(n_secondary=15):
             "cpu_baseline": {"value": 7.7e7, "unit": "evals/s", "cores": 256, "kind": "port", "sample": long, "gpu_matches_cpu_bitwise": True, "max_abs_dev": 0.0},
             "config5": {"workload": "gv_sigma5" + long, "value": 1.5e9, "unit": "samples/s (whole job)", "n_gpus": 1, "steps": 500, "total_samples": 1e9,
                         "roofline_rank0": dict(roof, bound="valu_fp64"), "observable": [1.0, 2.0], "what": long},
+            "accumulate": {"value": 9.38e9, "unit": "samples/s", "roofline": dict(roof, kernel="fdg_isa_eval_acc_nt", frac_hbm=0.797), "what": long},
             "secondary": sec, "secondary_note": long,
             "mc_step": {"value": 7.2e9, "unit": "samples/s", "what": long, "max_dev_over_Sk": 4.4e-13, "max_dev_over_Ak": 1.6e-15, "parity": long}}
 
@@ -54,6 +55,7 @@ def test_line_is_short_and_keeps_the_contract_keys():
     assert got["secondary"][0][0] == "parquet_sigma4_insdyn" and got["secondary"][0][1] == "rm" and got["secondary"][1][3] == "valu"
     assert got["secondary"][-1][3] == "error"
     assert got["config5"]["total_samples"] == 1e9 and got["config5"]["bound"] == "valu_fp64"
+    assert got["accumulate"]["kernel"] == "fdg_isa_eval_acc_nt" and got["accumulate"]["frac_hbm"] == 0.797 and got["accumulate"]["value"] == 9.38e9
     assert got["mc_step"]["leaf_parity"].startswith("unpinned") and got["mc_step"]["max_dev_over_Sk"] == 4.4e-13
     assert abs(got["value"] - 8.2273456789e9) / 8.2e9 < 1e-5
 
@@ -132,6 +134,7 @@ def test_bench_line_on_the_device(tmp_path):
     rows = {(x[0], x[1]): x for x in got["secondary"]}
     assert set(rows) == {("parquet_sigma4", "rm"), ("gv_sigma5", "lm")} and all(x[-1] is True for x in rows.values())
     assert got["config5"]["total_samples"] >= 10**9 and got["config5"]["n_gpus"] == 1
+    assert got["accumulate"]["kernel"].startswith("fdg_isa_eval_acc") and got["accumulate"]["value"] > got["value"] * 0.8
     assert got["mc_step"]["value"] > 0 and got["mc_step"]["max_dev_over_Sk"] < 1e-11 and got["mc_step"]["max_dev_over_Ak"] < 1e-14
     detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
     assert detail["secondary"][0]["roofline"]["kernel"] == "fdg_isa_eval_rm"
