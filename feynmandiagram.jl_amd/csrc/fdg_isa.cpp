@@ -466,6 +466,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const char *dbg = std::getenv("FDG_ISA_DEBUG");
   const bool dbg_noleaf = dbg && std::strstr(dbg, "noleaf");
   const bool dbg_nolds = dbg && std::strstr(dbg, "nolds");
+  const bool dbg_novalu = dbg && std::strstr(dbg, "novalu");     // the memory stream of the program alone (waits included)
   // ---- prologue ------------------------------------------------------------
   if (cs) E.ins("v_and_b32_e32 v0, 63, v0");          // lane within the wave (the workgroup has four waves)
   E.ins("s_load_dwordx8 s[4:11], s[0:1], 0x0");
@@ -866,12 +867,14 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         E.wait_reg(o.a);
         E.wait_reg(o.b);
         E.wait_reg(o.d);
+        if (dbg_novalu) break;
         valu2(o.kind == M_MUL ? "v_mul_f64 " : "v_add_f64 ", o, (o.negb ? "-" : "") + vlo(o.b), (o.negb ? "-" : "") + vhi(o.b));
         break;
       case M_MULC: {
         E.wait_reg(o.a);
         E.wait_reg(o.d);
         const std::string c = op_const(o);
+        if (dbg_novalu) break;
         valu2("v_mul_f64 ", o, c, c);
         break;
       }
