@@ -24,6 +24,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6    # AMD spec, FMA counted as 2 (not in the local g
 # The arithmetic contract forbids contraction, so a fold step is one v_add_f64 / v_mul_f64: half the FMA figure.
 # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12 lane-operations per second (measured on the box, settled clocks: 34.4e12).
 FP64_NOFMA_PEAK_TOPS = 39.3
+SPEC_CLOCK_GHZ = 2.4            # the clock the 39.3 is quoted at; roofline.clock_ghz is what the chip sustained (power budget)
 FP64_NOFMA_MEASURED_TOPS = 34.4
 CONFIG5_TOTAL_SAMPLES = 1_000_000_000     # BASELINE.json config 5: 10^9 samples over the GPUs of the node
 LINE_LIMIT = 3600                         # bytes of the stdout line (the driver keeps the last ~8 KB of stdout)
@@ -115,6 +116,31 @@ class DryFunc:
         return {"max_live": 0, "spec_vgpr": 0, "spec_lds_bytes": 0, "spec_scratch_bytes": 0}
 
 
+def probe_start(dev, seconds):
+    """One sleeping wave on a side stream for about `seconds` (fdg_clock_probe_device): returns a handle for probe_stop, or None."""
+    if DRY:
+        return None
+    try:
+        import torch
+        from feynmandiagram_jl_amd import capi
+        side = torch.cuda.Stream(device=dev)
+        ticks = torch.zeros(2, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        capi.clock_probe_device(min(30.0, max(2e-4, seconds)), ticks.data_ptr(), side.cuda_stream)
+        return (side, ticks)
+    except Exception:
+        return None
+
+
+def probe_stop(probe):
+    """Shader clock in GHz the probe saw (s_memtime ticks per 100 MHz tick), None without a probe."""
+    if not probe:
+        return None
+    probe[0].synchronize()
+    c, w = (int(x) for x in probe[1].cpu())
+    return c / w * 0.1 if w > 0 else None
+
+
 class Case:
     """One workload resident on the device: handle, leaf batch (synthetic, Philox keyed by the global sample index), root buffer."""
 
@@ -145,18 +171,29 @@ class Case:
     def step(self):
         self.f(self.root, self.leaf)
 
-    def timed(self, steps, warm):
-        """`warm` untimed launches, then `steps` launches bracketed by HIP events on the launch stream.  Returns ms per launch (list)."""
+    def timed(self, steps, warm, step=None):
+        """`warm` untimed launches, then `steps` launches bracketed by HIP events on the launch stream.  Returns ms per launch (list).
+        Next to the timed launches one sleeping wave on a side stream (fdg_clock_probe_device) reads the shader clock the chip
+        sustains under this load: `self.clock_ghz` (None when the probe could not run)."""
         import torch
+        step = step or self.step
         for _ in range(warm):
-            self.step()
+            step()
         sync()
+        self.clock_ghz = None
+        probe = None
+        if not DRY and steps >= 2:
+            pre = Stamps(2, self.stream)          # two more untimed launches give the length of the region the probe has to cover
+            pre.record(0); step(); pre.record(1); step(); pre.record(2)
+            sync()
+            probe = probe_start(self.dev, 0.85 * min(pre.ms()) * 1e-3 * steps)
         ev = Stamps(steps, self.stream)
         ev.record(0)
         for i in range(steps):
-            self.step()
+            step()
             ev.record(i + 1)
         sync()
+        self.clock_ghz = probe_stop(probe)
         return ev.ms()
 
     def parity_sample(self, n=2048):
@@ -182,7 +219,7 @@ def observable_sum(root):
     return acc + rt[:, nb * c:].sum(dim=1) if nb * c < B else acc
 
 
-def roofline_of(st, B, avg_kernel_s, kernel, accumulate=False, ops_exec=None):
+def roofline_of(st, B, avg_kernel_s, kernel, accumulate=False, ops_exec=None, clock_ghz=None):
     """Both roofs of one launch and the one that binds.  HBM: algorithmic bytes 8(L+R) per evaluation (8L when the
     roots are accumulated on chip) against 8 TB/s.  Vector ALU: the fold steps the kernel EXECUTES per evaluation
     (`ops_exec`, from fdg_graph_kernel_info: after value numbering, one v_add_f64 / v_mul_f64 each -- no FMA by
@@ -201,6 +238,12 @@ def roofline_of(st, B, avg_kernel_s, kernel, accumulate=False, ops_exec=None):
         out["frac_valu_of_measured_peak"] = tops / FP64_NOFMA_MEASURED_TOPS
         if out["frac_valu"] > frac_hbm:      # the launch cannot be shorter than ops / peak: the vector ALU is the binding roof
             out.update({"bound": "valu_fp64", "achieved": tops, "peak": FP64_NOFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": out["frac_valu"]})
+    if clock_ghz:
+        # the shader clock the chip sustained during the timed launches (one sleeping wave on a side stream): the graphs at the
+        # compute/memory ridge run against the power budget (1.8-1.9 GHz), and the vector-ALU roof scales with it
+        out["clock_ghz"] = clock_ghz
+        if out.get("frac_valu") is not None:
+            out["frac_valu_at_clock"] = out["valu_tops"] / (FP64_NOFMA_PEAK_TOPS * clock_ghz / SPEC_CLOCK_GHZ)
     return out
 
 
@@ -263,7 +306,7 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
         avg = sum(ms) / len(ms) / 1e3
         ok, dev_max, n = c.parity_sample()
         kern, ops_exec = kernel_of(c.f)
-        roof = roofline_of(c.st, c.B, avg, kern, ops_exec=ops_exec)
+        roof = roofline_of(c.st, c.B, avg, kern, ops_exec=ops_exec, clock_ghz=c.clock_ghz)
         attach_traffic(roof, workload, layout, c.B, avg)
         if copy_gbs:
             roof["frac_of_measured_copy"] = roof["achieved"] / copy_gbs
@@ -301,13 +344,17 @@ def config5(dev, rank, world, dist, comm, steps, warm):
         c = Case("gv_sigma5", "leaf_major", count, dev, sample_offset=start)
         w = torch.rand(1 if DRY else count, dtype=torch.float64, device=dev)
         acc = torch.zeros(c.t.n_root, dtype=torch.float64, device=dev)
-        for _ in range(warm):
+        pre = Stamps(warm, c.stream)
+        pre.record(0)
+        for i in range(warm):
             c.f.accumulate(c.leaf, w, acc)
+            pre.record(i + 1)
         acc.zero_()
         sync()
         if dist:
             dist.barrier()
             sync()
+        probe = probe_start(dev, 0.85 * min(pre.ms()) * 1e-3 * steps) if warm else None     # (a sleeping wave on a side stream: the clock under this load)
         ev = Stamps(steps, c.stream)
         t0 = time.perf_counter()
         ev.record(0)
@@ -328,7 +375,7 @@ def config5(dev, rank, world, dist, comm, steps, warm):
         avg = sum(ms) / len(ms) / 1e3
         total = float(count) * steps * world
         kern, ops_exec = kernel_of(c.f)
-        roof = roofline_of(c.st, count, avg, kern + " + fdg_reduce_lane_partials", accumulate=True, ops_exec=ops_exec)
+        roof = roofline_of(c.st, count, avg, kern + " + fdg_reduce_lane_partials", accumulate=True, ops_exec=ops_exec, clock_ghz=probe_stop(probe))
         out = {"workload": "gv_sigma5" + WORKLOAD_NOTES["gv_sigma5"], "value": total / elapsed, "unit": "samples/s (whole job)", "n_gpus": world,
                "steps": steps, "warmup": warm, "samples_per_step_per_gpu": count, "total_samples": total,
                "shard_offset_rank0": start, "baseline_total_samples": CONFIG5_TOTAL_SAMPLES,
@@ -501,6 +548,14 @@ def main():
             out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
         except RuntimeError:
             pass
+        if not DRY:
+            # the clock the chip sustains under the headline launch: ten more launches AFTER the contract's timed region, with the
+            # probe wave on a side stream (the timed region itself runs without it)
+            case.timed(min(10, max(2, args.steps)), 0)
+            if case.clock_ghz:
+                out["roofline"]["clock_ghz"] = case.clock_ghz
+                if out["roofline"].get("frac_valu") is not None:
+                    out["roofline"]["frac_valu_at_clock"] = out["roofline"]["valu_tops"] / (FP64_NOFMA_PEAK_TOPS * case.clock_ghz / SPEC_CLOCK_GHZ)
         if args.backend == "isa":
             attach_traffic(out["roofline"], args.workload, args.layout, B, avg_kernel_s)
         out["valu_fp64"] = {"achieved_tflops": st["flops_alg"] * B / avg_kernel_s / 1e12,
@@ -595,7 +650,7 @@ def compact_line(full):
     if roof:
         keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_kernel_ms",
                 "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy",
-                "ops_exec_per_eval")
+                "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock")
         line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:60]) for k in keep if k in roof}
     cb = full.get("cpu_baseline")
     if cb:
@@ -603,16 +658,16 @@ def compact_line(full):
                                 "sample": str(cb.get("sample", ""))[:110], "gpu_matches_cpu_bitwise": cb.get("gpu_matches_cpu_bitwise")}
     sec = full.get("secondary")
     if sec:
-        line["secondary_cols"] = ["workload", "layout", "evals_per_s", "bound", "frac", "frac_hbm", "frac_valu", "traffic_ratio", "bitwise"]
+        line["secondary_cols"] = ["workload", "layout", "evals_per_s", "bound", "frac", "frac_hbm", "frac_valu", "traffic_ratio", "bitwise", "clock_ghz"]
         rows = []
         for e in sec:
             if "error" in e:
-                rows.append([e.get("workload", "?")[:24], e.get("layout"), None, "error", None, None, None, None, False])
+                rows.append([e.get("workload", "?")[:24], e.get("layout"), None, "error", None, None, None, None, False, None])
                 continue
             r = e["roofline"]
             rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm"}.get(e["layout"], e["layout"]), _r(e["value"]),
                          {"hbm": "hbm", "valu_fp64": "valu"}.get(r["bound"], r["bound"]), _r(r["frac"], 3), _r(r.get("frac_hbm"), 3),
-                         _r(r.get("frac_valu"), 3), _r(r.get("traffic_over_algorithmic"), 3), e.get("gpu_matches_cpu_bitwise")])
+                         _r(r.get("frac_valu"), 3), _r(r.get("traffic_over_algorithmic"), 3), e.get("gpu_matches_cpu_bitwise"), _r(r.get("clock_ghz"), 3)])
         line["secondary"] = rows
     c5 = full.get("config5")
     if c5:
@@ -622,7 +677,7 @@ def compact_line(full):
             r = c5.get("roofline_rank0", {})
             line["config5"] = {"workload": "gv_sigma5", "value": _r(c5["value"], 5), "unit": "samples/s", "n_gpus": c5["n_gpus"], "total_samples": c5["total_samples"],
                                "steps": c5["steps"], "bound": r.get("bound"), "frac": _r(r.get("frac"), 3), "frac_hbm": _r(r.get("frac_hbm"), 3),
-                               "frac_valu": _r(r.get("frac_valu"), 3)}
+                               "frac_valu": _r(r.get("frac_valu"), 3), "clock_ghz": _r(r.get("clock_ghz"), 3)}
     ac = full.get("accumulate")
     if ac:
         line["accumulate"] = ({"error": ac["error"][:80]} if "error" in ac else

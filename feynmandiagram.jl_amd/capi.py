@@ -28,7 +28,7 @@ FDG_SPEC_ROW_MAJOR_COMPANION = 16
 EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
-    "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
+    "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_clock_probe_device", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
     "fdg_eval_strided", "fdg_graph_coop_program", "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
@@ -138,6 +138,7 @@ def lib():
     L.fdg_accumulate_device.argtypes = [vp, dp, i64, i64, dp, dp, i64, vp]
     L.fdg_fill_uniform_device.argtypes = [dp, i64, u32, i64, i64, u64, u64, vp]
     L.fdg_copy_device.argtypes = [dp, dp, i64, vp]
+    L.fdg_clock_probe_device.argtypes = [C.c_double, vp, vp]
     L.fdg_isa_check_hazards.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
     L.fdg_graph_release_device.argtypes = [vp]
     L.fdg_leaf_eval_device.argtypes = [C.POINTER(LeafTables), dp, i64, i64, dp, i64, i64, dp, i64, i64, i64, vp]
@@ -358,6 +359,12 @@ def isa_check_hazards(asm_text: str):
 
 def copy_device(d_dst: int, d_src: int, n: int, stream: int = 0):
     check(lib().fdg_copy_device(d_dst, d_src, n, stream))
+
+
+def clock_probe_device(seconds: float, d_ticks: int, stream: int):
+    """One sleeping wave on ``stream`` for ``seconds``; afterwards ``d_ticks[0] / d_ticks[1] * 0.1`` is the shader clock in GHz
+    the chip sustained meanwhile (launch it on a side stream next to the kernels of interest)."""
+    check(lib().fdg_clock_probe_device(seconds, d_ticks, stream))
 
 
 def powi(x: float, n: int) -> float:

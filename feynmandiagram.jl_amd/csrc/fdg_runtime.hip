@@ -1979,6 +1979,32 @@ int fdg_copy_device(double *d_dst, const double *d_src, int64_t n, void *stream)
   return FDG_OK;
 }
 
+// Measurement aid: one wave that sleeps on a SIMD for `seconds` of wall time and reports how many shader-clock ticks
+// (s_memtime) and 100 MHz ticks (s_memrealtime) went by -- the clock the chip sustained under whatever ran next to it.
+// Eight VGPRs and no LDS: it fits beside two 248-register waves of an evaluator kernel on the same SIMD.
+__global__ void __launch_bounds__(64) fdg_clock_probe_kernel(long long *out, long long wall_ticks) {
+  if (threadIdx.x) return;
+  const long long w0 = wall_clock64(), c0 = clock64();
+  long long w, c;
+  do {
+    for (int i = 0; i < 16; ++i) __builtin_amdgcn_s_sleep(127);
+    w = wall_clock64(); c = clock64();
+  } while (w - w0 < wall_ticks);
+  out[0] = c - c0;
+  out[1] = w - w0;
+}
+
+int fdg_clock_probe_device(double seconds, int64_t *d_ticks, void *stream) {
+  if (!d_ticks) { set_error("fdg_clock_probe_device: null buffer"); return FDG_E_INVALID; }
+  if (!(seconds > 0) || seconds > 30.0) { set_error("fdg_clock_probe_device: seconds must lie in (0, 30]"); return FDG_E_INVALID; }
+  hipFuncAttributes at;
+  HIP_TRY(hipFuncGetAttributes(&at, reinterpret_cast<const void *>(fdg_clock_probe_kernel)));
+  if (at.numRegs > 16 || at.sharedSizeBytes != 0) { set_error("fdg_clock_probe_device: the probe no longer fits beside a full evaluator wave pair"); return FDG_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(fdg_clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long *)d_ticks, (long long)(seconds * 1e8));
+  HIP_TRY(hipGetLastError());
+  return FDG_OK;
+}
+
 int fdg_fill_uniform_device(double *d_leaf, int64_t B, uint32_t L, int64_t ss, int64_t ls, uint64_t seed,
                             uint64_t off, void *stream) {
   if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }

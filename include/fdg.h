@@ -270,6 +270,13 @@ int fdg_isa_check_hazards(const char *asm_text, char **report);
  * (the reference has no counterpart). */
 int fdg_copy_device(double *d_dst, const double *d_src, int64_t n, void *stream);
 
+/* Harness only (bench.py's `roofline.clock_ghz`): enqueues ONE wave on `stream` that sleeps for `seconds` of wall time
+ * (0 < seconds <= 30) and then writes d_ticks[0] = shader-clock ticks, d_ticks[1] = 100 MHz ticks that went by: launched on
+ * a side stream next to the evaluator it reports the clock the chip sustained under that load (the graphs at the
+ * compute/memory ridge run against the power budget: 1.8-1.9 GHz instead of 2.4).  8 VGPRs, no LDS: it shares a SIMD with
+ * two 248-register evaluator waves.  No counterpart in the reference. */
+int fdg_clock_probe_device(double seconds, int64_t *d_ticks, void *stream);
+
 /* ---- leaf values on device (the caller's side of the path) ----------------
  * The per-sample leaf loop of the reference's example integrand (example/benchmark.jl:58-81):
  *   loops = K[:, 1:n_loop] * basis                       (FrontEnds.update, src/frontend/pool.jl:69-76)
