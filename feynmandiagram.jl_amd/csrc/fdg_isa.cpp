@@ -467,6 +467,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const bool dbg_noleaf = dbg && std::strstr(dbg, "noleaf");
   const bool dbg_nolds = dbg && std::strstr(dbg, "nolds");
   const bool dbg_novalu = dbg && std::strstr(dbg, "novalu");     // the memory stream of the program alone (waits included)
+  const bool dbg_nopanel = dbg && std::strstr(dbg, "nopanel");   // no spill traffic to the HBM panel
   // ---- prologue ------------------------------------------------------------
   if (cs) E.ins("v_and_b32_e32 v0, 63, v0");          // lane within the wave (the workgroup has four waves)
   E.ins("s_load_dwordx8 s[4:11], s[0:1], 0x0");
@@ -821,6 +822,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         E.pend[o.d] = {1, ++E.vm_issued};
         break;
       case M_LD_MEM: {
+        if (dbg_nopanel) break;
         E.wait_reg(o.d);
         const std::string opnd = panel_operand(o.a);
         E.ins(LD + vall(o.d) + ", " + V(V_LANE8) + ", " + opnd);
@@ -828,6 +830,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         break;
       }
       case M_ST_MEM: {
+        if (dbg_nopanel) break;
         E.wait_reg(o.a);
         const std::string opnd = panel_operand(o.d);
         E.ins(ST + V(V_LANE8) + ", " + vall(o.a) + ", " + opnd);

@@ -708,6 +708,27 @@ struct Alloc {
     }
     // Belady: evict the resident value whose next use is farthest away
     uint32_t best = NONE, best_nu = 0;
+    // When the on-chip overflow levels are full the candidates do not cost the same: a value without a home takes a panel store
+    // and a panel load (on the graphs with a thousand leaves both miss L2), a leaf or a value that already has a panel home one
+    // load, a value parked in LDS / AGPRs next to nothing -- so the distances are compared per access (round 3: panel + leaf
+    // accesses 3.33 -> 3.05 x L on the GV 4-loop vertex function, +4-6 % there, +7 % on the synthetic stand-in, neutral on the
+    // graphs that do not spill; profiles/r03_log_evict_cost.txt).  FDG_EVICT_COST=0: the plain farthest-next-use rule.
+    static const int evict_cost = std::getenv("FDG_EVICT_COST") ? std::atoi(std::getenv("FDG_EVICT_COST")) : 2;
+    if (evict_cost && free_lds.empty() && lds_next >= prm.n_lds && free_acc.empty() && acc_next >= prm.n_acc) {
+      double best_score = -1.0;
+      for (uint32_t r = 0; r < prm.n_reg; ++r) {
+        if (owner[r] == NONE || lock[r] == pos) continue;
+        const uint32_t v = owner[r];
+        const uint32_t nu = next_use(v);
+        double score;
+        if (nu == std::numeric_limits<uint32_t>::max()) score = 1e30;
+        else {
+          const double c = home_kind[v] == 0 ? (double)evict_cost : (home_kind[v] == 1 || home_kind[v] == 4 ? 0.5 : 1.0);
+          score = (double)(nu - pos) / c;
+        }
+        if (score > best_score) { best_score = score; best = r; best_nu = nu; }
+      }
+    } else
     for (uint32_t r = 0; r < prm.n_reg; ++r) {
       if (owner[r] == NONE || lock[r] == pos) continue;
       const uint32_t nu = next_use(owner[r]);

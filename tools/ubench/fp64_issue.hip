@@ -26,7 +26,13 @@
                 "v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59"
 
 template <int REPT, int P, int BIGREG>
-__global__ void k(double *out, long long *clk, int iters) {
+__global__ void k(double *out, long long *clk, int iters, int dephase) {
+  // dephase > 0: wave w of the CU (and every CU differently) idles w * dephase cycles first, so that the waves sharing an
+  // instruction cache walk the body at different places (the evaluator's persistent waves drift apart the same way)
+  if (dephase > 0) {
+    const long long t0 = clock64(), wait = (long long)dephase * (long long)(((threadIdx.x >> 6) + 1) * 7 + (blockIdx.x % 13));
+    while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
   if (BIGREG == 1) asm volatile("v_mov_b32 v247, 0" ::: "v247");      // 248 VGPRs: at most two waves per SIMD
   if (BIGREG == 2) asm volatile("v_mov_b32 v160, 0" ::: "v160");      // 168 VGPRs: at most three
   asm volatile("v_mov_b32 v20, 0\n v_mov_b32 v21, 0x3ff00000\n v_mov_b32 v22, 0\n v_mov_b32 v23, 0x3ff00000\n v_mov_b32 v24, 0\n v_mov_b32 v25, 0x3ff00000\n"
@@ -52,15 +58,15 @@ __global__ void k(double *out, long long *clk, int iters) {
 
 static double *d_out; static long long *d_clk;
 
-template <int REPT, int P, int BIGREG> void run(const char *name, int wps) {
+template <int REPT, int P, int BIGREG> void run(const char *name, int wps, int dephase = 0) {
   const int block = 64 * 4 * (wps > 4 ? 4 : wps), grid = 256 * (wps > 4 ? wps / 4 : 1);
   const long long ops_target = 1 << 24;                      // ops per wave
   const int iters = (int)(ops_target / (8LL * REPT));
-  hipLaunchKernelGGL((k<REPT, P, BIGREG>), dim3(grid), dim3(block), 0, 0, d_out, d_clk, iters > 16 ? iters / 16 : 1);
+  hipLaunchKernelGGL((k<REPT, P, BIGREG>), dim3(grid), dim3(block), 0, 0, d_out, d_clk, iters > 16 ? iters / 16 : 1, 0);
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  hipLaunchKernelGGL((k<REPT, P, BIGREG>), dim3(grid), dim3(block), 0, 0, d_out, d_clk, iters);
+  hipLaunchKernelGGL((k<REPT, P, BIGREG>), dim3(grid), dim3(block), 0, 0, d_out, d_clk, iters, dephase);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const int n_wave = grid * block / 64;
@@ -70,6 +76,7 @@ template <int REPT, int P, int BIGREG> void run(const char *name, int wps) {
   const double ghz = cs / ws * 0.1;                          // wall clock: 100 MHz
   const double ops_wave = (double)iters * 8 * REPT;
   const double cyc_per_op_simd = (cs / n_wave) / ops_wave / wps;          // shader-clock cycles a SIMD spends per op
+  if (dephase) printf("dephased %6d: ", dephase);
   printf("%-26s body %6d ops (%4d KB)  waves/SIMD=%d  %8.3f ms  %6.2f T op/s  clock %.2f GHz  cycles/op/SIMD %.2f\n", name, 8 * REPT, 8 * REPT * 8 / 1024, wps, ms,
          ops_wave * n_wave * 64 / ms / 1e9, ghz, cyc_per_op_simd);
   hipEventDestroy(e0); hipEventDestroy(e1);
@@ -97,5 +104,7 @@ int main() {
   for (int w : {1, 2}) run<8192, 3, 1>("3-addr, 248 VGPRs", w);
   for (int w : {1, 2, 3}) run<64, 3, 2>("3-addr, 168 VGPRs", w);
   for (int w : {1, 2, 3}) run<8192, 3, 2>("3-addr, 168 VGPRs", w);
+  // the instruction cache: the same bodies with the waves of a CU out of phase
+  for (int w : {1, 2}) { run<64, 3, 1>("3-addr, 248 VGPRs", w, 3000); run<2048, 3, 1>("3-addr, 248 VGPRs", w, 3000); run<8192, 3, 1>("3-addr, 248 VGPRs", w, 3000); run<8192, 3, 1>("3-addr, 248 VGPRs", w, 30000); }
   return 0;
 }
