@@ -272,6 +272,7 @@ struct Emit {
   uint64_t vm_issued = 0, lg_issued = 0, vm_done = 0, lg_done = 0;
   // pending[reg] = (kind 0 none / 1 vm / 2 lgkm, seq)
   std::vector<std::pair<uint8_t, uint64_t>> pend;
+  std::vector<uint64_t> pend_acc;      // [AGPR pair] vm sequence number of the leaf load that lands in it (0: none outstanding)
 
   // every instruction goes through here: the wait states the hazard table demands are put in front of it
   void ins(const std::string &s) {
@@ -318,6 +319,7 @@ struct Emit {
     vm_done = vm_issued;
     lg_done = lg_issued;
     for (auto &p : pend) p.first = 0;
+    for (auto &p : pend_acc) p = 0;
   }
 };
 
@@ -457,7 +459,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   if (E.streaming) {
     std::vector<uint8_t> seen(p.L + 1, 0);
     for (size_t i = prog.ops.size(); i-- > 0;)
-      if (prog.ops[i].kind == M_LD_LEAF && prog.ops[i].a < seen.size() && !seen[prog.ops[i].a]) { seen[prog.ops[i].a] = 1; final_load[i] = 1; }
+      if ((prog.ops[i].kind == M_LD_LEAF || prog.ops[i].kind == M_LD_LEAF_ACC) && prog.ops[i].a < seen.size() && !seen[prog.ops[i].a]) { seen[prog.ops[i].a] = 1; final_load[i] = 1; }
   }
   std::string leaf_policy = leaf_policy_env;
   const std::string DSR = W == 2 ? "ds_read_b128 " : "ds_read_b64 ";
@@ -552,7 +554,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   {
     std::map<int64_t, int> hist;
     int64_t last = -1;
-    for (const MOp &o : prog.ops) if (o.kind == M_LD_LEAF) {
+    for (const MOp &o : prog.ops) if (o.kind == M_LD_LEAF || o.kind == M_LD_LEAF_ACC) {
       const bool same_space = !mc || (o.a < n_k && last < (int64_t)n_k);     // only steps inside the first column space use the table
       if (last >= 0 && same_space && (int64_t)o.a - last > 1) hist[(int64_t)o.a - last]++;
       last = o.a;
@@ -753,7 +755,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     uint64_t sq = 0;
     auto use = [&](uint32_t r) { if (r < E.pend.size() && E.pend[r].first == 1) sq = std::max(sq, E.pend[r].second); };
     switch (q.kind) {
-      case M_LD_LEAF: case M_LD_LDS: case M_LD_MEM: case M_LD_ACC: case M_RECV: use(q.d); break;
+      case M_LD_ACC: use(q.d); if (q.a < E.pend_acc.size()) sq = std::max(sq, E.pend_acc[q.a]); break;
+      case M_LD_LEAF: case M_LD_LDS: case M_LD_MEM: case M_RECV: use(q.d); break;
       case M_ST_LDS: case M_ST_MEM: case M_ST_ACC: case M_ROOT: case M_SEND: use(q.a); break;
       case M_MUL: case M_ADD: use(q.a); use(q.b); use(q.d); break;
       case M_FMA: use(q.a); use(q.b); use(q.c); use(q.d); break;
@@ -779,9 +782,10 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       }
     }
     switch (o.kind) {
+      case M_LD_LEAF_ACC:
       case M_LD_LEAF:
         if (dbg_noleaf) break;   // timing experiments only (results are garbage)
-        E.wait_reg(o.d);
+        if (o.kind == M_LD_LEAF) E.wait_reg(o.d);
         if (E.streaming && leaf_policy_env.empty()) leaf_policy = final_load[this_op] ? " nt" : "";
         if (rm_bufs) {
           const int b = rm_ld_buf[this_op];
@@ -817,6 +821,12 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
             emit_scaled_addr(E, S_LP, S_LT, S_LS8, o.a);
           }
           last_leaf = o.a;
+        }
+        if (o.kind == M_LD_LEAF_ACC) {       // lands in an AGPR pair; its previous occupant was read (v_accvgpr_read) earlier in program order
+          E.ins(LD + "a[" + std::to_string(RW * o.d) + ":" + std::to_string(RW * o.d + RW - 1) + "], " + V(V_LEAFOFF) + ", " + S2(S_LP) + leaf_policy);
+          if (E.pend_acc.size() <= o.d) E.pend_acc.resize(o.d + 1, 0);
+          E.pend_acc[o.d] = ++E.vm_issued;
+          break;
         }
         E.ins(LD + vall(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_LP) + leaf_policy);
         E.pend[o.d] = {1, ++E.vm_issued};
@@ -1002,6 +1012,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       }
       case M_LD_ACC:
         E.wait_reg(o.d);
+        if (o.a < E.pend_acc.size() && E.pend_acc[o.a]) { E.wait_vm(E.pend_acc[o.a]); E.pend_acc[o.a] = 0; }     // a landing slot: the load must have arrived
         for (int k = 0; k < RW; ++k)
           E.ins("v_accvgpr_read_b32 v" + std::to_string(V_BASE + RW * o.d + k) + ", a" + std::to_string(RW * o.a + k));
         break;

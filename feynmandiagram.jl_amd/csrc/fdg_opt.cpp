@@ -655,6 +655,9 @@ struct Alloc {
   std::deque<uint32_t> free_regs;
   std::vector<uint32_t> free_lds, free_mem, free_acc;
   uint32_t lds_next = 0, mem_next = 0, acc_next = 0, reg_hw = 0;
+  // landing slots (home_kind 6): the last n_land AGPR pairs; a leaf sits in one from its M_LD_LEAF_ACC to its move into a register
+  std::vector<uint32_t> free_land;
+  uint32_t n_land = 0, n_acc_spill = 0;
   std::vector<MOp> out;
   OptProgram &prog;
 
@@ -665,7 +668,12 @@ struct Alloc {
   uint32_t n_barrier_seen = 0;
 
   Alloc(const Lowered &p_, const OptParams &prm_, const std::vector<UOp> &u_, uint32_t nv_, OptProgram &pr)
-      : p(p_), prm(prm_), u(u_), nv(nv_), prog(pr) { leaf_n = p.L; }
+      : p(p_), prm(prm_), u(u_), nv(nv_), prog(pr) {
+    leaf_n = p.L;
+    n_land = prm.n_land < prm.n_acc ? prm.n_land : 0;
+    n_acc_spill = prm.n_acc - n_land;
+    for (uint32_t i = n_land; i-- > 0;) free_land.push_back(n_acc_spill + i);
+  }
 
   uint32_t next_use(uint32_t v) const {
     return up[v] < uses[v].size() ? uses[v][up[v]] : std::numeric_limits<uint32_t>::max();
@@ -677,7 +685,7 @@ struct Alloc {
   }
   bool get_acc(uint32_t &s) {
     if (!free_acc.empty()) { s = free_acc.back(); free_acc.pop_back(); return true; }
-    if (acc_next < prm.n_acc) { s = acc_next++; return true; }
+    if (acc_next < n_acc_spill) { s = acc_next++; return true; }
     return false;
   }
   uint32_t get_mem() {
@@ -685,6 +693,7 @@ struct Alloc {
     return mem_next++;
   }
   void release_home(uint32_t v) {
+    if (home_kind[v] == 6) { free_land.push_back(home_slot[v]); home_kind[v] = 3; return; }
     if (home_kind[v] == 1) free_lds.push_back(home_slot[v]);
     else if (home_kind[v] == 2) free_mem.push_back(home_slot[v]);
     else if (home_kind[v] == 4) free_acc.push_back(home_slot[v]);
@@ -714,7 +723,7 @@ struct Alloc {
     // accesses 3.33 -> 3.05 x L on the GV 4-loop vertex function, +4-6 % there, +7 % on the synthetic stand-in, neutral on the
     // graphs that do not spill; profiles/r03_log_evict_cost.txt).  FDG_EVICT_COST=0: the plain farthest-next-use rule.
     static const int evict_cost = std::getenv("FDG_EVICT_COST") ? std::atoi(std::getenv("FDG_EVICT_COST")) : 2;
-    if (evict_cost && free_lds.empty() && lds_next >= prm.n_lds && free_acc.empty() && acc_next >= prm.n_acc) {
+    if (evict_cost && free_lds.empty() && lds_next >= prm.n_lds && free_acc.empty() && acc_next >= n_acc_spill) {
       double best_score = -1.0;
       for (uint32_t r = 0; r < prm.n_reg; ++r) {
         if (owner[r] == NONE || lock[r] == pos) continue;
@@ -758,6 +767,10 @@ struct Alloc {
     if (reg_of[v] != NONE) { lock[reg_of[v]] = pos; return reg_of[v]; }
     const uint32_t r = take_reg(pos, true);
     switch (home_kind[v]) {
+      case 6:      // landed: out of its slot (which is free again from here on), the input matrix stays its home
+        out.push_back(MOp{M_LD_ACC, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_acc++;
+        free_land.push_back(home_slot[v]); home_kind[v] = 3;
+        break;
       case 1: out.push_back(MOp{M_LD_LDS, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_lds++; break;
       case 2: out.push_back(MOp{M_LD_MEM, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_mem++; break;
       case 4: out.push_back(MOp{M_LD_ACC, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_acc++; break;
@@ -769,7 +782,7 @@ struct Alloc {
   }
   // Issue the load of value v now (op position j) for its use at op q > j.
   void prefetch(uint32_t v, uint32_t j, uint32_t q) {
-    if (reg_of[v] != NONE || home_kind[v] == 0 || home_kind[v] == 4) return;
+    if (reg_of[v] != NONE || home_kind[v] == 0 || home_kind[v] == 4 || home_kind[v] == 6) return;
     const uint32_t r = take_reg(j, true, q);
     if (r == NONE) return;
     switch (home_kind[v]) {
@@ -799,6 +812,27 @@ struct Alloc {
       }
     }
   }
+  // scan pointer `pf` up to j + lookahead_land: a leaf that is neither in a register nor landed gets a landing slot while there is one
+  void landing_window(uint32_t &pf, uint32_t j) {
+    if (!n_land) return;
+    const uint64_t lim = std::min<uint64_t>((uint64_t)u.size(), (uint64_t)j + prm.lookahead_land + 1);
+    if (pf <= j) pf = j + 1;
+    auto land = [&](uint32_t v) {
+      if (free_land.empty() || home_kind[v] != 3 || reg_of[v] != NONE) return;
+      const uint32_t s = free_land.back(); free_land.pop_back();
+      out.push_back(MOp{M_LD_LEAF_ACC, 0, 0, s, v - leaf_lo, 0, 0.0});
+      prog.n_ld_leaf++; prog.n_ld_land++;
+      home_kind[v] = 6; home_slot[v] = s;
+    };
+    for (; pf < lim; ++pf) {
+      if (free_land.empty()) return;          // (the pointer stays: what it has not seen is looked at again when a slot is free)
+      const UOp &o = u[pf];
+      if (!mop_has_a(o.kind)) continue;
+      land(o.a >> 1);
+      if (mop_has_b(o.kind)) land(o.b >> 1);
+      if (mop_has_c(o.kind)) land(o.c >> 1);
+    }
+  }
   void run() {
     uses.assign(nv, {});
     for (uint32_t j = 0; j < u.size(); ++j) {
@@ -817,10 +851,11 @@ struct Alloc {
     lock.assign(prm.n_reg, NONE);
     for (uint32_t r = 0; r < prm.n_reg; ++r) free_regs.push_back(r);
     uint32_t live = 0;
-    uint32_t pf_leaf = 0, pf_lds = 0, pf_mem = 0;
+    uint32_t pf_leaf = 0, pf_lds = 0, pf_mem = 0, pf_land = 0;
     for (uint32_t j = 0; j < u.size(); ++j) {
       const UOp &o = u[j];
       if (prm.lookahead_leaf) prefetch_window(pf_leaf, j, prm.lookahead_leaf, 3);
+      landing_window(pf_land, j);
       if (prm.lookahead_mem) prefetch_window(pf_mem, j, prm.lookahead_mem, 2);
       if (prm.lookahead_lds) prefetch_window(pf_lds, j, prm.lookahead_lds, 1);
       if (o.kind == M_BARRIER) {
@@ -894,7 +929,7 @@ struct Alloc {
     prog.n_reg_used = reg_hw;
     prog.n_lds_used = lds_next;
     prog.n_mem_used = mem_next;
-    prog.n_acc_used = acc_next;
+    prog.n_acc_used = n_land ? prm.n_acc : acc_next;     // (landing slots are the top of the range)
   }
 };
 

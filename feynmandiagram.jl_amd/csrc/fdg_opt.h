@@ -49,6 +49,8 @@ enum MKind : uint8_t {
   M_SEND = 25,    // shared[d] = r[a]                          visible to the other waves after the next M_BARRIER
   M_RECV = 26,    // r[d] = shared[a]
   M_BARRIER = 27, // s_barrier (every wave's program has the same number of them per tile)
+  // ---- one-wave configuration: leaf loads land in AGPR pairs long before their use (no VGPR is tied up by a load in flight) ----
+  M_LD_LEAF_ACC = 28, // acc[d] = leaf[a]                     (global_load into the AGPR pair; M_LD_ACC moves it to a VGPR pair at its use)
 };
 inline bool mop_has_a(uint8_t k) { return k != M_RECV && k != M_BARRIER; }
 inline bool mop_has_b(uint8_t k) { return k == M_MUL || k == M_ADD || k == M_FMA || k == M_SEL || k == M_FMAK; }
@@ -84,6 +86,10 @@ struct OptParams {
                                   // shared cache lines together instead of hundreds of ops apart)
   bool keep_root_order = false;   // roots in the reference's statement order instead of the cone-overlap order: leaves are numbered by first
                                   // visit in that order, so their first uses then walk the leaf index monotonically (row-major variant)
+  uint32_t n_land = 0;            // experiment (FDG_LAND): of the n_acc AGPR pairs, this many are landing slots for leaf loads issued up to
+  uint32_t lookahead_land = 1500; // lookahead_land ops ahead -- no VGPR pair is tied up by a load in flight, 2 KB more in flight per slot and CU.
+                                  // Measured neutral to -5 % (16-48 slots) on every one-wave kernel: their waits are not for leaves that were
+                                  // asked for too late (one wave per SIMD only; not for the row-major or Monte-Carlo programs)
   uint32_t reserve_pairs = 0;     // VGPR pairs the kernel variant keeps above the values (accumulators, weight): the value budget shrinks
                                   // by this and by the temporaries the program's macro ops need, so that everything stays below v256
 };
@@ -95,6 +101,7 @@ struct OptProgram {
   // statistics
   uint64_t n_valu = 0, n_ld_leaf = 0, n_ld_lds = 0, n_ld_mem = 0, n_st_lds = 0, n_st_mem = 0, n_ld_acc = 0, n_st_acc = 0;
   uint64_t n_send = 0, n_recv = 0, n_barrier = 0;   // cooperative programs
+  uint64_t n_ld_land = 0;                            // leaf loads that went through a landing slot (counted in n_ld_leaf too)
   uint32_t max_live = 0;
   uint32_t mc_n_k = 0, mc_n_t = 0;   // build_mc_program: input columns 0..mc_n_k-1 are momentum components, the next mc_n_t are times
   bool supported = true;    // false: graph uses something the ISA path does not cover

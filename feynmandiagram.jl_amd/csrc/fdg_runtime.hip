@@ -999,6 +999,7 @@ int fdg_graph_emit_source(const fdg_graph *g, unsigned flags, char **source) {
   return FDG_OK;
 }
 
+static void apply_land_env(fdg::OptParams &q);
 static fdg::OptParams to_params(const fdg_opt_params *q) {
   fdg::OptParams prm;
   if (q) {
@@ -1039,7 +1040,9 @@ int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop *
                           uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used) {
   if (!g || !ops || !n_ops) { set_error("null argument"); return FDG_E_INVALID; }
   fdg::OptProgram prog;
-  fdg::build_opt_program(g->prog, to_params(q), prog);
+  fdg::OptParams prm = to_params(q);
+  apply_land_env(prm);                         // (the experiment switch FDG_LAND reaches the exported program too: replayed in tests)
+  fdg::build_opt_program(g->prog, prm, prog);
   if (!prog.supported) { set_error("optimizing back end does not cover this graph: " + prog.why); return FDG_E_UNSUPPORTED; }
   fdg_mop *m = (fdg_mop *)std::malloc(std::max<size_t>(1, prog.ops.size()) * sizeof(fdg_mop));
   if (!m) { set_error("out of memory"); return FDG_E_NOMEM; }
@@ -1222,6 +1225,12 @@ static fdg::OptParams cfg_B() {
   fdg::OptParams B; B.n_reg = 120; B.n_lds = 80; B.n_acc = 124; B.lookahead_leaf = 100; B.lookahead_mem = 64; B.vn_window = 1000; return B;
 }
 
+// experiment switch: FDG_LAND=<n> AGPR landing slots for the leaf loads of the one-wave configuration (0 = none)
+static void apply_land_env(fdg::OptParams &q) {
+  if (const char *e = std::getenv("FDG_LAND")) q.n_land = q.n_acc ? std::min<uint32_t>((uint32_t)std::max(0, std::atoi(e)), q.n_acc / 2) : 0;
+  if (const char *e = std::getenv("FDG_LAND_LA")) q.lookahead_land = (uint32_t)std::max(1, std::atoi(e));
+}
+
 static fdg::OptParams auto_program(const fdg_graph *g, fdg::OptProgram &prog) {
   fdg::OptProgram ps;
   build_prog(g, cfg_S(), ps);
@@ -1230,8 +1239,10 @@ static fdg::OptParams auto_program(const fdg_graph *g, fdg::OptProgram &prog) {
   build_prog(g, cfg_A(), prog);
   if (prog.supported && (prog.n_ld_mem + prog.n_st_mem) * 100 > prog.n_valu) {   // > 1 % of the ops touch the HBM panel
     fdg::OptProgram pb;
-    build_prog(g, cfg_B(), pb);
-    if (pb.supported) { prog = std::move(pb); return cfg_B(); }
+    fdg::OptParams qb = cfg_B();
+    apply_land_env(qb);
+    build_prog(g, qb, pb);
+    if (pb.supported) { prog = std::move(pb); return qb; }
   }
   return cfg_A();
 }
@@ -1438,16 +1449,19 @@ static int use_tuned(fdg_graph *g, const std::string &dir, unsigned flags) {
   {
     fdg_opt_params r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // seven numbers, or nine: ... recompute window and cost (files written before round 2 have seven)
-    int coop_flag = -1;          // tenth number: the tuner's verdict on the cooperative variant (absent: the static criterion decides)
-    if (std::sscanf(buf.data(), "%u %u %u %u %u %u %u %u %u %u", &r.n_reg, &r.n_lds, &r.n_acc, &r.lookahead_lds, &r.lookahead_mem, &r.lookahead_leaf, &r.vn_window,
-                    &r.remat_window, &r.remat_cost, (unsigned *)&coop_flag) < 7) return 0;
+    int coop_flag = -1;          // tenth number: the tuner's verdict on the cooperative variant (absent or -1: the static criterion decides)
+    unsigned n_land = 0;         // eleventh: AGPR landing slots of the leaf loads (one-wave configuration)
+    if (std::sscanf(buf.data(), "%u %u %u %u %u %u %u %u %u %d %u", &r.n_reg, &r.n_lds, &r.n_acc, &r.lookahead_lds, &r.lookahead_mem, &r.lookahead_leaf, &r.vn_window,
+                    &r.remat_window, &r.remat_cost, &coop_flag, &n_land) < 7) return 0;
     tuned_coop = coop_flag == 1 ? 4 : coop_flag;       // (files of the first cooperative version wrote 1 for four waves)
     if (r.n_reg < 4) return 0;
     q = to_params(&r);          // the same clamps as parameters handed over through the ABI
     if (!r.n_acc) q.n_acc = 0;
     if (!r.n_lds) q.n_lds = 0;
     q.vn_window = r.vn_window;     // the tuner's own encoding: 0 = value numbering without a window (through the ABI 0 asks for the default)
+    q.n_land = q.n_acc ? std::min<uint32_t>(n_land, q.n_acc / 2) : 0;
   }
+  apply_land_env(q);
   fdg::OptProgram prog;
   build_prog(g, q, prog);
   if (!prog.supported) return 0;
@@ -1471,6 +1485,7 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
                   q.remat_window, q.remat_cost);
     return std::string(b);
   };
+  size_t n_first_stage = 0;
   std::vector<fdg::OptParams> cand;
   cand.push_back(cfg_S());
   cand.push_back(cfg_A());
@@ -1512,7 +1527,14 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   double best_ms = 1e300;
   int best = -1;
   std::string seen;
-  for (size_t c = 0; c < cand.size(); ++c) {
+  n_first_stage = cand.size();
+  for (size_t c = 0; ; ++c) {
+    if (c == cand.size()) {
+      // second stage (FDG_TUNE_LAND=1 only: measured neutral to -5 % on every one-wave kernel, profiles/r03_log_agpr_landing.txt):
+      // the best one-wave configuration once more with AGPR landing slots for its leaf loads
+      if (!std::getenv("FDG_TUNE_LAND") || cand.size() != n_first_stage || best < 0 || cand[best].n_acc < 64) break;
+      for (uint32_t nl : {16u, 32u, 48u}) { fdg::OptParams q = cand[best]; q.n_land = nl; cand.push_back(q); }
+    }
     fdg::OptProgram prog;
     build_prog(g, cand[c], prog);
     if (!prog.supported) continue;
@@ -1539,7 +1561,7 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
       hipEventElapsedTime(&ms, e0, e1);
       ms_min = std::min(ms_min, ms);
     }
-    if (std::getenv("FDG_TUNE_VERBOSE")) std::fprintf(stderr, "[tune] %s: %.3f ms per 8 launches of %ld (%llu ops, %llu leaf loads, %llu panel)\n", to_line(cand[c]).c_str(), ms_min, Bt,
+    if (std::getenv("FDG_TUNE_VERBOSE")) std::fprintf(stderr, "[tune] %s land %u: %.3f ms per 8 launches of %ld (%llu ops, %llu leaf loads, %llu panel)\n", to_line(cand[c]).c_str(), cand[c].n_land, ms_min, Bt,
                                                       (unsigned long long)prog.n_valu, (unsigned long long)prog.n_ld_leaf, (unsigned long long)(prog.n_ld_mem + prog.n_st_mem));
     if (ms_min < best_ms) { best_ms = ms_min; best = (int)c; }
   }
@@ -1588,7 +1610,7 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   hipEventDestroy(e0); hipEventDestroy(e1);
   hipFree(d_leaf); hipFree(d_root);
   if (rc) return rc;
-  const std::string line = to_line(cand[best]) + (had_coop ? " " + std::to_string(coop_best) : std::string()) + "\n";
+  const std::string line = to_line(cand[best]) + " " + std::to_string(had_coop ? coop_best : -1) + " " + std::to_string(cand[best].n_land) + "\n";
   write_file(tuned, line.c_str(), line.size());
   return FDG_OK;
 }
@@ -1606,6 +1628,7 @@ static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) 
   if (has_opt_params(g)) {
     const fdg_opt_params q = get_opt_params(g);
     chosen = to_params(&q);
+    apply_land_env(chosen);
     build_prog(g, chosen, prog);
   } else {
     chosen = auto_program(g, prog);

@@ -199,6 +199,7 @@ def replay(ops, n_reg, n_lds, n_mem, n_acc, leaf, R):
         elif k == 8: root[:, d] = sa * reg[a]
         elif k == 10: reg[d] = acc[a]
         elif k == 11: acc[d] = reg[a]
+        elif k == 28: acc[d] = leaf[:, a]          # a leaf load that lands in an AGPR pair
         elif k == 14: reg[d] = oracle.fma(sa * reg[a], sb * reg[b], (-1.0 if o["negc"] else 1.0) * reg[int(o["c"])])
         elif k == 15: reg[d] = oracle.fma(sa * reg[a], o["imm"], (-1.0 if o["negc"] else 1.0) * reg[int(o["c"])])
         elif k == 16: reg[d] = (sa * reg[a]) + o["imm"]

@@ -6,7 +6,7 @@ import numpy as np
 import feynmandiagram_jl_amd as fd
 from feynmandiagram_jl_amd import capi, workloads
 
-KINDS = {0: "ld_leaf", 1: "ld_lds", 2: "ld_mem", 3: "st_lds", 4: "st_mem", 5: "mul", 6: "add", 7: "mulc", 8: "root", 9: "mov", 10: "ld_acc", 11: "st_acc"}
+KINDS = {0: "ld_leaf", 1: "ld_lds", 2: "ld_mem", 3: "st_lds", 4: "st_mem", 5: "mul", 6: "add", 7: "mulc", 8: "root", 9: "mov", 10: "ld_acc", 11: "st_acc", 28: "ld_land"}
 CFG = {"A": dict(n_reg=120, n_lds=40, n_acc=0), "B": dict(n_reg=120, n_lds=80, n_acc=124)}
 
 def stats(name, cfg="B", **kw):
@@ -18,8 +18,9 @@ def stats(name, cfg="B", **kw):
     t0 = time.time()
     ops, nr, nl, nm = g.opt_program(**p)
     dt = time.time() - t0
-    c = np.bincount(ops["kind"], minlength=12)
+    c = np.bincount(ops["kind"], minlength=29)
     d = {KINDS[k]: int(c[k]) for k in KINDS}
+    d["ld_leaf"] += d["ld_land"]
     valu = d["mul"] + d["add"] + d["mulc"] + d["mov"]
     return dict(name=name, L=t.n_leaf, valu=valu, ld_leaf=d["ld_leaf"], ld_mem=d["ld_mem"], st_mem=d["st_mem"], ld_lds=d["ld_lds"],
                 st_lds=d["st_lds"], ld_acc=d["ld_acc"], st_acc=d["st_acc"], n_mem=nm, sec=round(dt, 2))
