@@ -23,12 +23,15 @@ KERNEL_CACHE = os.path.join(_HERE, "kernel_cache")
 FDG_OK = 0
 FDG_E_INVALID, FDG_E_UNSUPPORTED, FDG_E_NO_DEVICE, FDG_E_NOMEM, FDG_E_JIT, FDG_E_INTERNAL = -1, -2, -3, -4, -5, -6
 FDG_SPEC_DEFAULT, FDG_SPEC_KEEP_SOURCE, FDG_SPEC_FAST_MATH, FDG_SPEC_ISA, FDG_SPEC_AUTOTUNE = 0, 1, 2, 4, 8
+# element types of leafVal / root (include/fdg.h FDG_DT_*); names as the reference's julia_to_C_typestr takes them (static.jl:135-153)
+FDG_DT_F64, FDG_DT_F32, FDG_DT_C64, FDG_DT_C32 = 0, 1, 2, 3
+DTYPES = {"Float64": FDG_DT_F64, "Float32": FDG_DT_F32, "ComplexF64": FDG_DT_C64, "ComplexF32": FDG_DT_C32}
 FDG_SPEC_ROW_MAJOR_COMPANION = 16
 
 EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
-    "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_clock_probe_device", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
+    "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_clock_probe_device", "fdg_graph_specialize_typed", "fdg_eval_device_typed", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
     "fdg_eval_strided", "fdg_graph_coop_program", "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
@@ -139,6 +142,8 @@ def lib():
     L.fdg_fill_uniform_device.argtypes = [dp, i64, u32, i64, i64, u64, u64, vp]
     L.fdg_copy_device.argtypes = [dp, dp, i64, vp]
     L.fdg_clock_probe_device.argtypes = [C.c_double, vp, vp]
+    L.fdg_graph_specialize_typed.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint]
+    L.fdg_eval_device_typed.argtypes = [vp, C.c_int, vp, i64, i64, vp, i64, i64, i64, vp]
     L.fdg_isa_check_hazards.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
     L.fdg_graph_release_device.argtypes = [vp]
     L.fdg_leaf_eval_device.argtypes = [C.POINTER(LeafTables), dp, i64, i64, dp, i64, i64, dp, i64, i64, i64, vp]
@@ -298,6 +303,13 @@ class GraphHandle:
         kernel_cache directory shipped inside the package is only *read* (``FDG_CACHE_RO_DIR``, set in :func:`lib`), so a
         root-owned or read-only installation works.  ``__graft_entry__.build()`` passes ``KERNEL_CACHE`` to fill it."""
         check(lib().fdg_graph_specialize(self._h, cache_dir.encode() if cache_dir else None, flags))
+
+    def specialize_typed(self, dtype: int, cache_dir: Optional[str] = None, flags: int = 0):
+        """The per-graph kernel for an element type other than Float64 (FDG_DT_*)."""
+        check(lib().fdg_graph_specialize_typed(self._h, dtype, cache_dir.encode() if cache_dir else None, flags))
+
+    def eval_device_typed(self, dtype: int, d_leaf: int, ss: int, ls: int, d_root: int, rs: int, rk: int, B: int, stream: int = 0):
+        check(lib().fdg_eval_device_typed(self._h, dtype, d_leaf, ss, ls, d_root, rs, rk, B, stream))
 
     # raw-pointer device entry points (ints are device addresses) ----------- #
     def eval_device(self, d_leaf: int, ss: int, ls: int, d_root: int, rs: int, rk: int, B: int, stream: int = 0):

@@ -133,7 +133,7 @@ class GraphFunc:
         if not leaf.is_cuda:
             raise RuntimeError("torch leafVal must live on the GPU (no CPU fallback); pass a numpy array for host data")
         if leaf.dtype != torch.float64:
-            raise TypeError("leafVal must be float64")
+            return self._call_torch_typed(root, leaf)
         squeeze = leaf.dim() == 1
         if squeeze:
             leaf = leaf[None, :]
@@ -149,6 +149,35 @@ class GraphFunc:
         with torch.cuda.device(leaf.device):
             self.handle.eval_device(leaf.data_ptr(), leaf.stride(0), leaf.stride(1), r2.data_ptr(),
                                     r2.stride(0), r2.stride(1), B, st)
+        return root
+
+    def _call_torch_typed(self, root, leaf):
+        """Element types other than Float64: the generated function is generic in ``eltype(leafVal)`` (static.jl:98-133; the
+        types ``julia_to_C_typestr`` names, static.jl:135-153).  Float32, ComplexF64 and ComplexF32 tensors go through the
+        per-type kernel of ``fdg_graph_specialize_typed`` (compiled on first use); ``root`` has the leaves' type."""
+        import torch
+        dt = {torch.float32: capi.FDG_DT_F32, torch.complex128: capi.FDG_DT_C64, torch.complex64: capi.FDG_DT_C32}.get(leaf.dtype)
+        if dt is None:
+            raise TypeError(f"leafVal of element type {leaf.dtype} is not supported (Float64, Float32, ComplexF64, ComplexF32)")
+        if not hasattr(self, "_typed_ready"):
+            self._typed_ready = set()
+        if dt not in self._typed_ready:
+            self.handle.specialize_typed(dt)
+            self._typed_ready.add(dt)
+        squeeze = leaf.dim() == 1
+        if squeeze:
+            leaf = leaf[None, :]
+        B, Lc = leaf.shape
+        if Lc < self.n_leaf:
+            raise IndexError("BoundsError: leafVal has fewer columns than the graph has leaves")
+        if root is None:
+            root = torch.zeros((B, self.n_root), dtype=leaf.dtype, device=leaf.device)
+        r2 = root[None, :] if squeeze else root
+        if r2.dtype != leaf.dtype or not r2.is_cuda or r2.shape[0] != B or r2.shape[1] < self.n_root:
+            raise ValueError("root must be a [B, R] tensor of the leaves' element type on the same device")
+        st = torch.cuda.current_stream(leaf.device).cuda_stream
+        with torch.cuda.device(leaf.device):
+            self.handle.eval_device_typed(dt, leaf.data_ptr(), leaf.stride(0), leaf.stride(1), r2.data_ptr(), r2.stride(0), r2.stride(1), B, st)
         return root
 
     def accumulate(self, leaf, weight=None, acc=None):

@@ -111,13 +111,15 @@ static void emit_node_expr(std::ostringstream &os, const Lowered &p, uint32_t n)
 // bits, but values die soon after they are born, so the compiler keeps them in registers instead of scratch.
 // Leaves are g<i>, computed values v<id>; roots are collected in r<k>.  False: the schedule does not cover the
 // graph (Power{N}, N not 2 or 3) and the caller falls back to statement order.
-static bool emit_nodes_scheduled(std::ostringstream &os, const Lowered &p, const std::function<void(std::ostringstream &, uint32_t)> &load_leaf) {
+static bool emit_nodes_scheduled(std::ostringstream &os, const Lowered &p, const std::function<void(std::ostringstream &, uint32_t)> &load_leaf,
+                                 const char *decl = "const double", bool keep_minus_one = false) {
   if (std::getenv("FDG_HIP_TABLE_ORDER")) return false;
   std::vector<SchedOp> ops;
   uint32_t nv = 0;
   std::string why;
   OptParams prm;
   prm.vn_window = 200;
+  prm.keep_minus_one = keep_minus_one;
   if (!build_schedule(p, prm, ops, nv, why)) return false;
   auto ref = [&](uint32_t r) {
     const uint32_t v = r >> 1;
@@ -131,10 +133,10 @@ static bool emit_nodes_scheduled(std::ostringstream &os, const Lowered &p, const
     need(o.a);
     if (o.kind == M_MUL || o.kind == M_ADD) need(o.b);
     switch (o.kind) {
-      case M_MUL: os << "    const double v" << o.d << " = " << ref(o.a) << " * " << ref(o.b) << ";\n"; break;
-      case M_ADD: os << "    const double v" << o.d << " = " << ref(o.a) << " + " << ref(o.b) << ";\n"; break;
-      case M_MULC: os << "    const double v" << o.d << " = " << ref(o.a) << " * "; put_double(os, o.imm); os << ";\n"; break;
-      case M_ROOT: os << "    const double r" << o.d << " = " << ref(o.a) << ";\n"; break;   // (need(o.a) above covers leaf roots)
+      case M_MUL: os << "    " << decl << " v" << o.d << " = " << ref(o.a) << " * " << ref(o.b) << ";\n"; break;
+      case M_ADD: os << "    " << decl << " v" << o.d << " = " << ref(o.a) << " + " << ref(o.b) << ";\n"; break;
+      case M_MULC: os << "    " << decl << " v" << o.d << " = " << ref(o.a) << " * "; put_double(os, o.imm); os << ";\n"; break;
+      case M_ROOT: os << "    " << decl << " r" << o.d << " = " << ref(o.a) << ";\n"; break;   // (need(o.a) above covers leaf roots)
       default: return false;
     }
   }
@@ -247,6 +249,61 @@ std::string emit_hip_source(const Lowered &p, unsigned flags) {
   os << kPrelude;
   emit_kernel(os, p, true);
   emit_kernel(os, p, false);
+  return os.str();
+}
+
+// Element types other than Float64.  The function Compilers.compile returns is generic in eltype(leafVal) (static.jl:98-133: the
+// text has no type in it), and to_Cstr maps the weight types it knows (static.jl:135-153: Float32, ComplexF32, ComplexF64, ...).
+// What the generic function computes follows from Julia's promotion rules, which for these operations are C++'s: the factors are
+// printed into the text as Float64 literals (string interpolation of an F = Float64 factor), so `g * 1.5` of a Float32 g is a
+// Float64, a product of two Float32 values stays Float32, Complex{T} * Real scales both components, Complex * Complex is
+// (ar br - ai bi, ar bi + ai br) without contraction, and `root[k] = g` converts to eltype(root).  The kernel is the scheduled
+// body of fdg_spec_gen with `auto` values over a small complex type whose operators follow base/complex.jl.
+static const char *kTypedPrelude = R"SRC(
+template <class T> struct fdg_cx { T re, im; };
+template <class A, class B> __device__ __forceinline__ auto operator*(fdg_cx<A> z, fdg_cx<B> w) -> fdg_cx<decltype(z.re * w.re)> {
+  return {z.re * w.re - z.im * w.im, z.re * w.im + z.im * w.re};                  // base/complex.jl: *(z::Complex, w::Complex)
+}
+template <class A> __device__ __forceinline__ auto operator*(fdg_cx<A> z, double x) -> fdg_cx<decltype(z.re * x)> { return {z.re * x, z.im * x}; }
+template <class A> __device__ __forceinline__ auto operator*(fdg_cx<A> z, float x) -> fdg_cx<decltype(z.re * x)> { return {z.re * x, z.im * x}; }
+template <class A, class B> __device__ __forceinline__ auto operator+(fdg_cx<A> z, fdg_cx<B> w) -> fdg_cx<decltype(z.re + w.re)> {
+  return {z.re + w.re, z.im + w.im};
+}
+template <class A> __device__ __forceinline__ fdg_cx<A> operator-(fdg_cx<A> z) { return {-z.re, -z.im}; }
+template <class T, class S> __device__ __forceinline__ T fdg_conv(S x) { return (T)x; }
+template <class T, class S> __device__ __forceinline__ T fdg_conv_cx(fdg_cx<S> z) { T r; r.re = z.re; r.im = z.im; return r; }
+)SRC";
+
+std::string emit_hip_source_typed(const Lowered &p, int dtype, bool &ok, std::string &why) {
+  ok = true;
+  const bool cx = dtype == FDG_DT_C64 || dtype == FDG_DT_C32;
+  const char *T = dtype == FDG_DT_F32 ? "float" : dtype == FDG_DT_C64 ? "fdg_cx<double>" : dtype == FDG_DT_C32 ? "fdg_cx<float>" : "double";
+  std::ostringstream os;
+  os << "// generated by fdg_graph_specialize_typed: element type " << T << ", L=" << p.L << " N=" << p.N << " R=" << p.R << "\n";
+  os << "#include <hip/hip_runtime.h>\n" << kTypedPrelude;
+  os << "extern \"C\" __global__ void __launch_bounds__(256) fdg_spec_typed(const " << T << " *__restrict__ leaf, long ss, long ls, "
+     << T << " *__restrict__ root, long rs, long rk, long B) {\n";
+  os << "  const long nblk = (B + 255) / 256;\n  _Pragma(\"unroll 1\")\n  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {\n";
+  os << "    const long b = blk * 256 + threadIdx.x;\n    if (b >= B) continue;\n";
+  os << "    const " << T << " *lp = leaf + b * ss;\n";
+  std::vector<uint8_t> done(p.L, 0);
+  auto load_leaf = [&](std::ostringstream &o, uint32_t i) {
+    if (done[i] || !p.live[i]) return;
+    o << "    const " << T << " g" << i << " = lp[" << i << "l * ls];\n";
+    done[i] = 1;
+  };
+  std::ostringstream body;
+  if (!emit_nodes_scheduled(body, p, load_leaf, "const auto", dtype == FDG_DT_F32 || dtype == FDG_DT_C32)) {
+    ok = false;
+    why = "element types other than Float64 cover Sum, Prod and Power{2}, Power{3} (other literal powers go through Base.power_by_squaring / pow_body per type)";
+    return std::string();
+  }
+  os << body.str();
+  os << "    " << T << " *rp = root + b * rs;\n";
+  for (uint32_t k = 0; k < p.R; ++k)
+    if (p.root_slot[k] != FDG_NO_ROOT)
+      os << "    rp[" << k << "l * rk] = " << (cx ? "fdg_conv_cx<" : "fdg_conv<") << T << ">(r" << k << ");\n";      // setindex!: convert(eltype(root), g)
+  os << "  }\n}\n";
   return os.str();
 }
 

@@ -63,6 +63,7 @@ void build_interpreter_program(Lowered &p, uint32_t lds_slot_budget);
 
 // source emitter (fdg_emit.cpp)
 std::string emit_hip_source(const Lowered &p, unsigned flags);
+std::string emit_hip_source_typed(const Lowered &p, int dtype, bool &ok, std::string &why);
 std::string emit_fused_source(const Lowered &p, const std::string &leaf_stmts, const std::string &device_functions);
 
 // thread-local error
@@ -141,6 +142,9 @@ struct fdg_graph {
   // fused Monte-Carlo step: leaves computed in registers from (K, T), then the graph (HIP-source JIT)
   std::vector<char> fused_code;
   void *fused_module = nullptr, *fn_fused = nullptr;
+  // element types other than Float64 (fdg_graph_specialize_typed): one HIP-source kernel per type, [FDG_DT_*]
+  std::vector<char> typed_code[4];
+  void *typed_module[4] = {nullptr, nullptr, nullptr, nullptr}, *fn_typed[4] = {nullptr, nullptr, nullptr, nullptr};
   // ... or, for graphs too large for a compiler-scheduled kernel, leaf kernel -> chunk of leaves -> this handle's evaluator
   int mc_route = 0;                // 0 none, 1 fused HIP kernel, 2 leaf kernel + evaluator, 3 fused ISA kernel
   std::vector<int32_t> lt_i32[5];  // copy of the leafstates tables (type, order, tau_in, tau_out, loop_index)

@@ -119,9 +119,10 @@ struct Builder {
     vn_add[key] = d << 1;
     return d << 1;
   }
+  bool keep_minus_one = false;     // OptParams::keep_minus_one
   uint32_t mulc(uint32_t a, double f) {
     if (f == 1.0) return a;
-    if (f == -1.0) return a ^ 1u;
+    if (f == -1.0 && !keep_minus_one) return a ^ 1u;
     if (!value_numbering) { uint32_t d = fresh(); u.push_back(UOp{M_MULC, d, a, 0, f}); return d << 1; }
     const uint32_t sign = a & 1u, x = a & ~1u;
     auto &lst = vn_mulc[x];
@@ -1094,12 +1095,13 @@ bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp>
   B0.value_numbering = prm.vn_window != 1;
   B0.vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
   B0.vn_touch = std::getenv("FDG_VN_BIRTH_WINDOW") == nullptr;
+  B0.keep_minus_one = prm.keep_minus_one;
   build_uops(B0);
   Lowered plain;
   const bool retry = !B0.ok && B0.why == "inconsistent schedule groups";
   if (retry) { plain = p; plain.sched_group.clear(); }
   Builder B1(retry ? plain : p);
-  B1.value_numbering = B0.value_numbering; B1.vn_window = B0.vn_window; B1.vn_touch = B0.vn_touch;
+  B1.value_numbering = B0.value_numbering; B1.vn_window = B0.vn_window; B1.vn_touch = B0.vn_touch; B1.keep_minus_one = B0.keep_minus_one;
   if (retry) build_uops(B1);
   Builder &B = retry ? B1 : B0;
   why = B.why;

@@ -90,6 +90,8 @@ struct OptParams {
   uint32_t lookahead_land = 1500; // lookahead_land ops ahead -- no VGPR pair is tied up by a load in flight, 2 KB more in flight per slot and CU.
                                   // Measured neutral to -5 % (16-48 slots) on every one-wave kernel: their waits are not for leaves that were
                                   // asked for too late (one wave per SIMD only; not for the row-major or Monte-Carlo programs)
+  bool keep_minus_one = false;    // schedules for single-precision element types: `g * -1.0` stays a multiplication (it promotes the value to
+                                  // Float64 in the reference's generic function; as a sign on the operand it would not)
   uint32_t reserve_pairs = 0;     // VGPR pairs the kernel variant keeps above the values (accumulators, weight): the value budget shrinks
                                   // by this and by the temporaries the program's macro ops need, so that everything stays below v256
 };

@@ -946,6 +946,7 @@ int fdg_graph_release_device(fdg_graph *g) {
   if (g->fused_module) { hipModuleUnload((hipModule_t)g->fused_module); g->fused_module = nullptr; g->fn_fused = nullptr; }
   if (g->alt_module) { hipModuleUnload((hipModule_t)g->alt_module); g->alt_module = nullptr; g->fn_alt_sm = g->fn_alt_gen = nullptr; }
   if (g->mc_module) { hipModuleUnload((hipModule_t)g->mc_module); g->mc_module = nullptr; g->fn_mc = g->fn_mc_acc = nullptr; }
+  for (int t = 0; t < 4; ++t) if (g->typed_module[t]) { hipModuleUnload((hipModule_t)g->typed_module[t]); g->typed_module[t] = nullptr; g->fn_typed[t] = nullptr; }
   return FDG_OK;
 }
 
@@ -1904,6 +1905,72 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
   g->code_object.swap(co);
   g->spec_source_hash = hbuf;
   g->spec_flags = flags;
+  return FDG_OK;
+}
+
+// Element types other than Float64: one HIP-source kernel per (graph, type), JIT-compiled like the Float64 HIP-source kernels
+// (hiprtc, the hipcc subprocess as the second route), cached under the same rules.
+int fdg_graph_specialize_typed(fdg_graph *g, int dtype, const char *cache_dir, unsigned flags) {
+  if (!g) { set_error("null handle"); return FDG_E_INVALID; }
+  if (dtype == FDG_DT_F64) return FDG_OK;                       // the handle's ordinary kernels
+  if (dtype < 0 || dtype > FDG_DT_C32) { set_error("unknown element type"); return FDG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  bool ok = true; std::string why;
+  const std::string src = emit_hip_source_typed(g->prog, dtype, ok, why);
+  if (!ok) { set_error(why); return FDG_E_UNSUPPORTED; }
+  char hbuf[40];
+  std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("typed-strict")));
+  std::string dir;
+  { const int rcd = fdg_cache_dir(cache_dir, dir); if (rcd) return rcd; }
+  const std::string base = dir + "/fdg_" + hbuf;
+  std::vector<char> co;
+  if (!read_cached(dir, std::string("fdg_") + hbuf + ".hsaco", co)) {
+    std::string log;
+    const char *force = std::getenv("FDG_JIT");
+    int rc = -1;
+    if (!(force && std::strcmp(force, "hipcc") == 0)) rc = compile_hiprtc(src, false, co, log);
+    if (rc != 0) {
+      std::string log2;
+      if (!write_file(base + ".hip", src.c_str(), src.size())) { set_error("cannot write " + base + ".hip"); return FDG_E_JIT; }
+      rc = compile_hipcc(base + ".hip", base + ".hsaco", false, log2);
+      if (!(flags & FDG_SPEC_KEEP_SOURCE)) std::remove((base + ".hip").c_str());
+      if (rc != 0 || !read_file(base + ".hsaco", co)) { set_error("kernel specialization failed.\nhiprtc: " + log + "\nhipcc: " + log2); return FDG_E_JIT; }
+    } else {
+      write_file(base + ".hsaco", co.data(), co.size());
+    }
+  }
+  if (flags & FDG_SPEC_KEEP_SOURCE) write_file(base + ".hip", src.c_str(), src.size());
+  if (g->typed_module[dtype]) { hipModuleUnload((hipModule_t)g->typed_module[dtype]); g->typed_module[dtype] = nullptr; g->fn_typed[dtype] = nullptr; }
+  g->typed_code[dtype].swap(co);
+  return FDG_OK;
+}
+
+int fdg_eval_device_typed(fdg_graph *g, int dtype, const void *d_leaf, int64_t ss, int64_t ls, void *d_root, int64_t rs, int64_t rk,
+                          int64_t B, void *stream) {
+  if (!g) { set_error("null handle"); return FDG_E_INVALID; }
+  if (dtype == FDG_DT_F64) return fdg_eval_device(g, (const double *)d_leaf, ss, ls, (double *)d_root, rs, rk, B, stream);
+  if (dtype < 0 || dtype > FDG_DT_C32) { set_error("unknown element type"); return FDG_E_INVALID; }
+  if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->typed_code[dtype].empty()) { set_error("fdg_eval_device_typed: call fdg_graph_specialize_typed for this element type first"); return FDG_E_INVALID; }
+  if (B == 0 || g->prog.R == 0) return FDG_OK;
+  if ((g->prog.L && !d_leaf) || !d_root) { set_error("null device buffer"); return FDG_E_INVALID; }
+  int rc = ensure_device(g);
+  if (rc) return rc;
+  if (!g->typed_module[dtype]) {
+    hipModule_t m; hipFunction_t f;
+    hipError_t e = hipModuleLoadData(&m, g->typed_code[dtype].data());
+    if (e != hipSuccess) { set_error("hipModuleLoadData failed: " + std::string(hipGetErrorString(e))); return FDG_E_JIT; }
+    HIP_TRY(hipModuleGetFunction(&f, m, "fdg_spec_typed"));
+    g->typed_module[dtype] = m; g->fn_typed[dtype] = f;
+  }
+  const long nblk = (long)((B + 255) / 256);
+  const long grid = std::min<long>(nblk, (long)g->n_cu * 8);
+  long a_ss = ss, a_ls = ls, a_rs = rs, a_rk = rk, a_B = B;
+  void *args[] = {(void *)&d_leaf, &a_ss, &a_ls, (void *)&d_root, &a_rs, &a_rk, &a_B};
+  HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_typed[dtype], (unsigned)grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+  static const char *names[] = {"", "fdg_spec_typed<Float32>", "fdg_spec_typed<ComplexF64>", "fdg_spec_typed<ComplexF32>"};
+  g->last_kernel = names[dtype];
   return FDG_OK;
 }
 

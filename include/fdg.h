@@ -219,6 +219,27 @@ int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *prm, fdg_mop
 int fdg_graph_coop_program(const fdg_graph *g, const fdg_opt_params *prm, uint32_t wave, fdg_mop **ops, uint64_t *n_ops,
                            uint32_t *info);
 
+/* ---- element types other than Float64 -----------------------------------------------------------------------------
+ * The function Compilers.compile returns is generic in eltype(leafVal) (the generated text has no type in it,
+ * src/backend/static.jl:98-133); to_Cstr / compile_C map the weight types they know (static.jl:135-153: Float32, ComplexF32,
+ * ComplexF64, ...).  fdg_graph_specialize_typed compiles a per-graph HIP-source kernel for one such type,
+ * fdg_eval_device_typed evaluates with leaf and root buffers of that type (strides in elements; a complex element is the pair
+ * (re, im), as in Julia and C).  What it computes is what the Julia function computes on Vector{T} arguments: the factors are
+ * Float64 literals in the text, so a factor != 1 promotes a Float32 value to Float64 for the rest of its expression (Julia's
+ * promotion rules are C++'s here), products and sums of values of the type stay in the type, Complex * Complex is
+ * (ar br - ai bi, ar bi + ai br) without contraction, Complex * Real scales both components (base/complex.jl), and a root is
+ * converted to the element type when stored.  Covered: Sum, Prod, Power{2}, Power{3} (other literal powers take type-specific
+ * paths through Base.power_by_squaring: FDG_E_UNSUPPORTED).  No fused accumulation, no ISA back end for these types: they go
+ * through the compiler-scheduled kernel (every BASELINE configuration is Float64).  FDG_DT_F64 forwards to the ordinary entry
+ * points. */
+#define FDG_DT_F64 0
+#define FDG_DT_F32 1
+#define FDG_DT_C64 2
+#define FDG_DT_C32 3
+int fdg_graph_specialize_typed(fdg_graph *g, int dtype, const char *cache_dir, unsigned flags);
+int fdg_eval_device_typed(fdg_graph *g, int dtype, const void *d_leaf, int64_t leaf_sample_stride, int64_t leaf_leaf_stride,
+                          void *d_root, int64_t root_sample_stride, int64_t root_root_stride, int64_t n_sample, void *stream);
+
 /* Evaluate B samples, buffers in device memory.
  *   leaf value i of sample b : d_leaf[b*leaf_sample_stride + i*leaf_leaf_stride]
  *   root value k of sample b : d_root[b*root_sample_stride + k*root_root_stride]

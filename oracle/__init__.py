@@ -187,6 +187,112 @@ def eval_static_numpy(table, leaf: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------- #
+# Element types other than Float64.  The function Compilers.compile returns is generic (src/backend/static.jl:98-133: the
+# generated text carries no type), so on Vector{T} arguments it computes what Julia's promotion rules make of that text:
+#   * a factor is printed as a Float64 literal, so `g * f` of a Float32 (ComplexF32) g is a Float64 (ComplexF64);
+#   * `*` / `+` of two values promote to the wider of their types (conversion Float32 -> Float64 is exact);
+#   * Complex * Complex = (ar br - ai bi, ar bi + ai br), Complex * Real scales both parts, Complex + Complex is
+#     componentwise (base/complex.jl); n-ary `+` and `*` are left folds (base/operators.jl);
+#   * `x^2`, `x^3` are x*x and x*x*x (Base.literal_pow); other exponents are out of this twin's scope;
+#   * `root[k] = g` converts to eltype(root) (round to nearest).
+# A value is a pair (re, im) of real numpy arrays, im None for real types; every real operation is one numpy ufunc call in the
+# operands' common precision (float32 ufuncs round once to single), so nothing is contracted.  PARITY UNPINNED beyond the
+# reference's all-ones known answers (which are exact in every type): Julia cannot run here.
+_REAL = {"Float32": np.float32, "Float64": np.float64, "ComplexF32": np.float32, "ComplexF64": np.float64}
+
+
+def _prom(a, b):
+    if a.dtype == b.dtype:
+        return a, b
+    return a.astype(np.float64), b.astype(np.float64)
+
+
+def _t_mul(x, y):
+    (ar, ai), (br, bi) = x, y
+    if ai is None and bi is None:
+        a, b = _prom(ar, br)
+        return (a * b, None)
+    if bi is None:                                   # Complex * Real
+        r1, b1 = _prom(ar, br)
+        i1, b2 = _prom(ai, br)
+        return (r1 * b1, i1 * b2)
+    if ai is None:                                   # Real * Complex
+        a1, r1 = _prom(ar, br)
+        a2, i1 = _prom(ar, bi)
+        return (a1 * r1, a2 * i1)
+    ar2, br2 = _prom(ar, br)
+    ai2, bi2 = _prom(ai, bi)
+    return (ar2 * br2 - ai2 * bi2, ar2 * bi2 + ai2 * br2)
+
+
+def _t_mulc(x, f):
+    f64 = np.float64(f)
+    return tuple(None if c is None else c.astype(np.float64) * f64 for c in x)
+
+
+def _t_add(x, y):
+    (ar, ai), (br, bi) = x, y
+    a, b = _prom(ar, br)
+    if ai is None and bi is None:
+        return (a + b, None)
+    if ai is None or bi is None:
+        raise NotImplementedError("Real + Complex does not occur: all leaves have one element type")
+    c, d = _prom(ai, bi)
+    return (a + b, c + d)
+
+
+def eval_static_typed(table, leaf: np.ndarray, dtype: str) -> np.ndarray:
+    """``leaf``: [B, L] of the numpy type of ``dtype`` ("Float32", "ComplexF64", "ComplexF32", "Float64"); returns [B, R] of it."""
+    real = _REAL[dtype]
+    cx = dtype.startswith("Complex")
+    leaf = np.asarray(leaf)
+    if leaf.ndim == 1:
+        leaf = leaf[None, :]
+    L, N = int(table.n_leaf), int(table.op.shape[0])
+    if cx:
+        vals = [(np.ascontiguousarray(leaf[:, i].real).astype(real), np.ascontiguousarray(leaf[:, i].imag).astype(real)) for i in range(L)]
+    else:
+        vals = [(np.ascontiguousarray(leaf[:, i]).astype(real), None) for i in range(L)]
+    vals += [None] * N
+    off, idx, fac = table.child_off, table.child_idx, table.child_fac
+    for n in range(N):
+        a, b = int(off[n]), int(off[n + 1])
+        o = int(table.op[n])
+        term = lambda e: vals[int(idx[e])] if fac[e] == 1.0 else _t_mulc(vals[int(idx[e])], fac[e])
+        if o == OP_POWER:
+            x, pw = vals[int(idx[a])], int(table.power[n])
+            if pw == 2:
+                acc = _t_mul(x, x)
+            elif pw == 3:
+                acc = _t_mul(_t_mul(x, x), x)
+            else:
+                raise NotImplementedError("typed twin covers Power{2}, Power{3}")
+            if fac[a] != 1.0:
+                acc = _t_mulc(acc, fac[a])
+        elif o == OP_SUM:
+            acc = term(a)
+            for e in range(a + 1, b):
+                acc = _t_add(acc, term(e))
+        elif o == OP_PROD:
+            acc = term(a)
+            for e in range(a + 1, b):
+                acc = _t_mul(acc, vals[int(idx[e])])
+                if fac[e] != 1.0:
+                    acc = _t_mulc(acc, fac[e])
+        else:
+            raise NotImplementedError("operator")
+        vals[L + n] = acc
+    R = int(table.root_slot.shape[0])
+    out = np.zeros((leaf.shape[0], R), dtype=leaf.dtype)
+    for k in range(R):
+        s = int(table.root_slot[k])
+        if s != NO_ROOT:
+            re, im = vals[s]
+            out[:, k] = re.astype(real) if not cx else re.astype(real) + 1j * im.astype(real)
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # Philox4x32-10 twin of the device generator (fdg_fill_uniform_device)
 # --------------------------------------------------------------------------- #
 def philox_uniform(B: int, L: int, seed: int, sample_offset: int = 0) -> np.ndarray:

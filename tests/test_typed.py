@@ -1,0 +1,183 @@
+"""Element types other than Float64 (src/backend/static.jl:135-153 names them for to_Cstr; the function Compilers.compile
+returns is generic in eltype(leafVal), static.jl:98-133).
+
+CPU part: the typed twin of the oracle (oracle.eval_static_typed) against the reference's known answers (exact in every type),
+against the Float64 oracle where the two must coincide, against the gcc-compiled ``to_Cstr(...; datatype=ComplexF64)`` text, and
+on a hand-made case that separates Julia's promotion (a Float64 factor literal widens a Float32 value) from single-precision
+evaluation.  GPU part: the per-type kernels of fdg_graph_specialize_typed through the C ABI, bit for bit against that twin.
+Parity of the typed twin is UNPINNED beyond those answers (Julia cannot run here)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+import feynmandiagram_jl_amd as fd
+from feynmandiagram_jl_amd import capi, fixtures, workloads
+from feynmandiagram_jl_amd.lowering import lower, table_to_Cstr
+from feynmandiagram_jl_amd.nodetable import NodeTable, OP_POWER, OP_PROD, OP_SUM, from_program
+
+NP = {"Float32": np.float32, "ComplexF64": np.complex128, "ComplexF32": np.complex64, "Float64": np.float64}
+
+
+def rand_leaves(B, L, dtype, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.random((B, L)) - 0.3
+    if dtype.startswith("Complex"):
+        x = x + 1j * (rng.random((B, L)) - 0.6)
+    return x.astype(NP[dtype])
+
+
+def same_bits(a, b):
+    return a.dtype == b.dtype and a.shape == b.shape and np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+
+
+@pytest.mark.parametrize("dtype", ["Float32", "ComplexF64", "ComplexF32"])
+def test_typed_twin_meets_the_reference_known_answers(dtype):
+    # test/compiler.jl:4-15: (1 + 2) * 1.5 == 4.5 in every type
+    g, leaf, expect = fixtures.kat_compiler_jl()
+    t, _, _ = lower([g])
+    got = oracle.eval_static_typed(t, np.asarray([leaf], dtype=NP[dtype]), dtype)
+    assert got.dtype == NP[dtype] and got[0, 0] == expect
+    # test/computational_graph.jl:874-887: 26, 27, 702 on all-ones leaves
+    graphs, exp = fixtures.kat_evaluation()
+    t, _, _ = lower(list(graphs))
+    got = oracle.eval_static_typed(t, np.ones((1, t.n_leaf), dtype=NP[dtype]), dtype)
+    assert got[0].tolist() == [NP[dtype](e) for e in exp]
+
+
+@pytest.mark.parametrize("name", ["sigma2", "parquet_sigma3", "gv_sigma4", "gv_sigma4_taylor2"])
+def test_typed_twin_coincides_with_the_float64_oracle(name):
+    t = workloads.get(name)
+    x = rand_leaves(64, t.n_leaf, "Float64", 3)
+    want = oracle.eval_static(t, x)
+    assert same_bits(oracle.eval_static_typed(t, x, "Float64"), want)
+    z = oracle.eval_static_typed(t, x + 0j, "ComplexF64")           # purely real complex leaves: real parts are the Float64 results
+    assert np.array_equal(z.real, want) and not z.imag.any()
+
+
+def test_float32_values_are_widened_by_a_factor_literal():
+    """`g1 * 2.5 + g2 * g3` on Float32 leaves: the literal is a Float64 in the generated text, so the first term and the sum are
+    Float64 (Julia's promotion), the product of two leaves is a Float32; the root is rounded once, at the store."""
+    # leaves 0, 1, 2; value 3 = g1 * g2 (Prod); value 4 = g0 * 2.5 + g3 (Sum); root = value 4
+    t = from_program(3, [(OP_PROD, 0, [(1, 1.0), (2, 1.0)]), (OP_SUM, 0, [(0, 2.5), (3, 1.0)])], [4], name="promo").normalized()
+    a = np.float32(0.1) + np.arange(1000, dtype=np.float32) * np.float32(1e-3)
+    b = np.float32(1.7) - np.arange(1000, dtype=np.float32) * np.float32(3e-4)
+    c = np.float32(0.3) + np.arange(1000, dtype=np.float32) * np.float32(7e-4)
+    leaf = np.stack([a, b, c], axis=1)
+    got = oracle.eval_static_typed(t, leaf, "Float32")[:, 0]
+    julia = (a.astype(np.float64) * 2.5 + (b * c).astype(np.float64)).astype(np.float32)      # Float64(a) * 2.5 + Float64(b * c), then convert
+    single = a * np.float32(2.5) + b * c                                                         # what all-single arithmetic would give
+    assert same_bits(got, julia)
+    assert (julia != single).any()                  # the two readings differ on this input: the test separates them
+
+
+_CX_DRIVER = r"""
+void run_batch(double complex *leaf, double complex *root, long B, long L, long R) {
+  for (long b = 0; b < B; ++b) eval_graph(root + b * R, leaf + b * L);
+}
+"""
+
+
+@pytest.mark.parametrize("name", ["sigma2", "parquet_sigma3", "gv_sigma4"])
+def test_complex_twin_against_the_compiled_to_Cstr_text(name, tmp_path):
+    """The reference's own C emitter with datatype = ComplexF64 (static.jl:146-147: `complex double`), compiled by gcc without
+    contraction: C's complex * complex, complex * real literal and + are Julia's formulas on finite values."""
+    t = workloads.get(name)
+    assert not (np.asarray(t.op) == OP_POWER).any()        # (to_static's `pow(g, N)` is not complex C; none of these graphs has a Power node)
+    src = tmp_path / "cx.c"
+    src.write_text("#include <math.h>\n#include <complex.h>\n" + table_to_Cstr(t, ctype="double complex ") + "\n" + _CX_DRIVER)
+    so = tmp_path / "cx.so"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", str(src), "-o", str(so), "-lm"])
+    lib = C.CDLL(str(so))
+    lib.run_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long]
+    leaf = np.ascontiguousarray(rand_leaves(200, t.n_leaf, "ComplexF64", 11))
+    root = np.zeros((200, t.n_root), dtype=np.complex128)
+    lib.run_batch(leaf.ctypes.data, root.ctypes.data, 200, t.n_leaf, t.n_root)
+    assert same_bits(oracle.eval_static_typed(t, leaf, "ComplexF64"), root)
+
+
+def test_typed_kernels_compile_for_gfx950_and_refuse_what_they_do_not_cover(libfdg, tmp_path):
+    # hiprtc cross-compiles without a device; no evaluation here
+    t = workloads.get("parquet_sigma3")
+    g = capi.GraphHandle(t)
+    for dt in (capi.FDG_DT_F32, capi.FDG_DT_C64, capi.FDG_DT_C32):
+        g.specialize_typed(dt, str(tmp_path), capi.FDG_SPEC_KEEP_SOURCE)
+    texts = [open(os.path.join(tmp_path, f)).read() for f in os.listdir(tmp_path) if f.endswith(".hip")]
+    assert len(texts) == 3 and all("fdg_spec_typed" in x and "const auto v" in x for x in texts)
+    assert sum("fdg_cx<float> *__restrict__ leaf" in x for x in texts) == 1 and sum("const float *__restrict__ leaf" in x for x in texts) == 1
+    # a single-precision schedule keeps `* -1.0` as a multiplication (it widens the value), a double-precision one carries it as a sign
+    f32 = next(x for x in texts if "const float *__restrict__ leaf" in x)
+    c64 = next(x for x in texts if "fdg_cx<double> *__restrict__ leaf" in x)
+    assert "* -0x1p+0;" in f32 and "* -0x1p+0;" not in c64
+    # Power{5}: other literal powers take type-specific paths in Julia; the typed kernels say so instead of guessing
+    tp = from_program(1, [(OP_POWER, 5, [(0, 1.0)])], [1], name="p5").normalized()
+    with pytest.raises(capi.FdgError) as e:
+        capi.GraphHandle(tp).specialize_typed(capi.FDG_DT_F32, str(tmp_path))
+    assert e.value.code == capi.FDG_E_UNSUPPORTED
+    with pytest.raises(capi.FdgError):
+        g.specialize_typed(7, str(tmp_path))
+
+
+# ---------------------------------------------------------------------------------------------------------- GPU
+
+
+def dev_typed(cuda, x, layout):
+    import torch
+    h = torch.from_numpy(np.ascontiguousarray(x))
+    if layout == "leaf_major":           # a Julia column-major B x L matrix
+        d = torch.empty((x.shape[1], x.shape[0]), dtype=h.dtype, device=cuda).t()
+    elif layout == "padded":
+        d = torch.empty((x.shape[0], x.shape[1] + 3), dtype=h.dtype, device=cuda)[:, :x.shape[1]]
+    else:
+        d = torch.empty(x.shape, dtype=h.dtype, device=cuda)
+    d.copy_(h)
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["sample_major", "leaf_major", "padded"])
+@pytest.mark.parametrize("dtype", ["Float32", "ComplexF64", "ComplexF32"])
+@pytest.mark.parametrize("name", ["sigma2", "parquet_sigma3", "gv_sigma4", "synthetic_small", "parquet_sigma4", "gv_sigma4_taylor2"])
+def test_typed_kernels_match_the_typed_twin_bitwise(libfdg, cuda, name, dtype, layout):
+    import torch
+    t = workloads.get(name)
+    f = fd.compile_table(t, specialize="isa")            # the handle's Float64 kernels stay what they are; the typed one is added on first use
+    x = rand_leaves(4099, t.n_leaf, dtype, 5)
+    leaf = dev_typed(cuda, x, layout)
+    root = f(None, leaf)
+    torch.cuda.synchronize()
+    assert f.kernel_info()["last_kernel"].startswith("fdg_spec_typed<" + dtype)
+    got = root.cpu().numpy()
+    want = oracle.eval_static_typed(t, x, dtype)
+    assert same_bits(got, want), np.abs(got - want).max()
+    # the Float64 path of the same handle is untouched
+    x64 = rand_leaves(513, t.n_leaf, "Float64", 6)
+    r64 = f(None, torch.from_numpy(x64).to(cuda))
+    torch.cuda.synchronize()
+    assert same_bits(r64.cpu().numpy(), oracle.eval_static(t, x64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["Float32", "ComplexF64", "ComplexF32"])
+def test_typed_known_answers_through_the_device(libfdg, cuda, dtype):
+    import torch
+    tdt = {"Float32": torch.float32, "ComplexF64": torch.complex128, "ComplexF32": torch.complex64}[dtype]
+    g, leaf, expect = fixtures.kat_compiler_jl()
+    f, _ = fd.Compilers.compile([g], specialize="isa")
+    root = torch.zeros(1, dtype=tdt, device=cuda)
+    f(root, torch.tensor(leaf, dtype=tdt, device=cuda))
+    torch.cuda.synchronize()
+    assert root.cpu().numpy()[0] == expect
+    graphs, exp = fixtures.kat_evaluation()
+    f, lm = fd.Compilers.compile(list(graphs), specialize="isa")
+    root = torch.zeros(3, dtype=tdt, device=cuda)
+    f(root, torch.ones(len(lm), dtype=tdt, device=cuda))
+    torch.cuda.synchronize()
+    assert root.cpu().numpy().tolist() == [NP[dtype](e) for e in exp]
+    with pytest.raises(IndexError):
+        f(root, torch.ones(1, dtype=tdt, device=cuda))
+    with pytest.raises(TypeError):
+        f(None, torch.ones(len(lm), dtype=torch.int64, device=cuda))
