@@ -1915,6 +1915,7 @@ int fdg_graph_specialize_typed(fdg_graph *g, int dtype, const char *cache_dir, u
   if (dtype == FDG_DT_F64) return FDG_OK;                       // the handle's ordinary kernels
   if (dtype < 0 || dtype > FDG_DT_C32) { set_error("unknown element type"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
+  if (!g->typed_code[dtype].empty() && !(flags & FDG_SPEC_KEEP_SOURCE)) return FDG_OK;      // already there (the graph of a handle never changes)
   bool ok = true; std::string why;
   const std::string src = emit_hip_source_typed(g->prog, dtype, ok, why);
   if (!ok) { set_error(why); return FDG_E_UNSUPPORTED; }

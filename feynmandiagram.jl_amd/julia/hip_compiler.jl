@@ -199,6 +199,18 @@ function eval_device!(f::GraphFunc, d_root::Ptr{Float64}, d_leaf::Ptr{Float64}, 
         f.handle, d_leaf, leaf_strides[1], leaf_strides[2], d_root, root_strides[1], root_strides[2], B, stream))
 end
 
+# Element types other than Float64 (the function Compilers.compile returns is generic in eltype(leafVal)): the per-type kernel
+# is compiled on first use; a ComplexF64 element is the pair (re, im), strides count elements
+const _FDG_DT = Dict{DataType,Cint}(Float64 => 0, Float32 => 1, ComplexF64 => 2, ComplexF32 => 3)
+function eval_device!(f::GraphFunc, d_root::Ptr{T}, d_leaf::Ptr{T}, B::Integer;
+    leaf_strides=(1, B), root_strides=(1, B), stream::Ptr{Cvoid}=C_NULL) where {T<:Union{Float32,ComplexF64,ComplexF32}}
+    dt = _FDG_DT[T]
+    _fdg_check(ccall((:fdg_graph_specialize_typed, _libfdg), Cint, (Ptr{Cvoid}, Cint, Cstring, Cuint), f.handle, dt, C_NULL, Cuint(0)))
+    _fdg_check(ccall((:fdg_eval_device_typed, _libfdg), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}),
+        f.handle, dt, d_leaf, leaf_strides[1], leaf_strides[2], d_root, root_strides[1], root_strides[2], B, stream))
+end
+
 # acc[k] += sum_b weight[b] * root_k(b), everything on device
 function accumulate_device!(f::GraphFunc, d_acc::Ptr{Float64}, d_leaf::Ptr{Float64}, d_weight::Ptr{Float64}, B::Integer;
     leaf_strides=(1, B), stream::Ptr{Cvoid}=C_NULL)
