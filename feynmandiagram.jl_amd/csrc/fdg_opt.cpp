@@ -659,6 +659,7 @@ struct Alloc {
   // landing slots (home_kind 6): the last n_land AGPR pairs; a leaf sits in one from its M_LD_LEAF_ACC to its move into a register
   std::vector<uint32_t> free_land;
   uint32_t n_land = 0, n_acc_spill = 0;
+  const int evict_cost = std::getenv("FDG_EVICT_COST") ? std::atoi(std::getenv("FDG_EVICT_COST")) : 2;    // read per program (see take_reg)
   std::vector<MOp> out;
   OptProgram &prog;
 
@@ -723,7 +724,6 @@ struct Alloc {
     // load, a value parked in LDS / AGPRs next to nothing -- so the distances are compared per access (round 3: panel + leaf
     // accesses 3.33 -> 3.05 x L on the GV 4-loop vertex function, +4-6 % there, +7 % on the synthetic stand-in, neutral on the
     // graphs that do not spill; profiles/r03_log_evict_cost.txt).  FDG_EVICT_COST=0: the plain farthest-next-use rule.
-    static const int evict_cost = std::getenv("FDG_EVICT_COST") ? std::atoi(std::getenv("FDG_EVICT_COST")) : 2;
     if (evict_cost && free_lds.empty() && lds_next >= prm.n_lds && free_acc.empty() && acc_next >= n_acc_spill) {
       double best_score = -1.0;
       for (uint32_t r = 0; r < prm.n_reg; ++r) {

@@ -232,6 +232,27 @@ def test_allocated_program_replays_exactly(libfdg, name, budget):
     assert valu <= st["flops_alg"]          # factor -1 rides on source modifiers
 
 
+@pytest.mark.parametrize("name", ["parquet_sigma5", "gv_sigma5", "parquet_ver4_4"])
+@pytest.mark.parametrize("evict_cost", ["0", "2", "3"])
+def test_eviction_rule_and_landing_slots_replay_exactly(libfdg, monkeypatch, name, evict_cost):
+    """Two allocator choices of round 3 move values, never change them: the eviction rule that counts a spill without a home as
+    two accesses (FDG_EVICT_COST, default 2) and the experimental AGPR landing slots of the leaf loads (FDG_LAND, op kind 28).
+    Both switches are read per program."""
+    t = workloads.get(name)
+    h = capi.GraphHandle(t)
+    monkeypatch.setenv("FDG_EVICT_COST", evict_cost)
+    leaf = oracle.philox_uniform(9, t.n_leaf, 79)
+    want = oracle.eval_static(t, leaf)
+    for land in ("0", "16", "40"):
+        monkeypatch.setenv("FDG_LAND", land)
+        ops, nr, nl, nm = h.opt_program(n_reg=120, n_lds=80, n_acc=124, vn_window=2000)
+        assert np.array_equal(replay(ops, nr, nl, nm, h.last_n_acc, leaf, t.n_root), want)
+        n_land = int((ops["kind"] == 28).sum())
+        assert (n_land > 0) == (land != "0")
+        if n_land:       # a landed leaf is moved into a register (kind 10) before its slot is loaded again
+            assert h.last_n_acc == 124
+
+
 @pytest.mark.parametrize("name,window,cost", [("sigma4_standin", 1000, 4), ("sigma4_standin", 300, 8), ("gv_sigma4_taylor2", 200, 8),
                                               ("synthetic_small", 40, 8), ("gv_sigma5", 100, 16)])
 def test_forget_and_recompute_replays_exactly(libfdg, monkeypatch, name, window, cost):
