@@ -159,14 +159,59 @@ class Case:
             self.root = torch.zeros((min(B, 64), R), dtype=torch.float64)
             return
         self.f = fd.compile_table(t, specialize={"isa": "isa", "isa-autotune": "isa-autotune", "auto": "auto", "hip": True, "interp": False}[backend], flags=flags)
-        if layout == "sample_major":          # compile_Python's row-major [B, L] / [B, R]
+        self.stream = torch.cuda.current_stream()
+        self.allocate()
+
+    def allocate(self):
+        """(Re-)allocates the leaf and root matrices and fills the leaves (same Philox stream: same values wherever they land)."""
+        import torch
+        from feynmandiagram_jl_amd import capi
+        B, L, R, dev = self.B, self.t.n_leaf, self.t.n_root, self.dev
+        if self.layout == "sample_major":     # compile_Python's row-major [B, L] / [B, R]
             self.leaf = torch.empty((B, L), dtype=torch.float64, device=dev)
             self.root = torch.empty((B, R), dtype=torch.float64, device=dev)
         else:                                 # Julia column-major B x L / B x R matrices
             self.leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
             self.root = torch.empty((R, B), dtype=torch.float64, device=dev).t()
-        self.stream = torch.cuda.current_stream()
-        capi.fill_uniform_device(self.leaf.data_ptr(), B, L, self.leaf.stride(0), self.leaf.stride(1), 1234, sample_offset, self.stream.cuda_stream)
+        capi.fill_uniform_device(self.leaf.data_ptr(), B, L, self.leaf.stride(0), self.leaf.stride(1), 1234, self.sample_offset, self.stream.cuda_stream)
+
+    def choose_placement(self, trials, accept=0.745):
+        """Where the pages of a 70 GB matrix land decides between two rates of one and the same launch (11.4 or
+        12.9 ms, nothing in between, whatever the virtual address).  A production run allocates its sample batch once, so it can
+        afford to look: up to `trials` allocations (the best one so far stays allocated while the next is tried, with a block of
+        another size in front), each timed with a few launches, stop at the first that reaches `accept` of 8 TB/s.  Everything
+        happens before the warm-up; the contract's timed steps then run once, on the chosen allocation.  Returns the HBM
+        fractions of the trials in order (the first entry is what a single allocation would have given)."""
+        import torch
+        bytes_launch = self.st["bytes_alg"] * self.B
+        pads_mb = [0, 130, 2051, 3, 517, 64, 9000, 1]
+        fracs, best = [], None
+        for i in range(max(1, trials)):
+            pad = None
+            if i:
+                pad = torch.empty(pads_mb[i % len(pads_mb)] << 20, dtype=torch.uint8, device=self.dev)
+                self.allocate()
+            for _ in range(8):
+                self.step()
+            sync()
+            ev = Stamps(6, self.stream)
+            ev.record(0)
+            for k in range(6):
+                self.step()
+                ev.record(k + 1)
+            sync()
+            frac = bytes_launch / (min(ev.ms()) * 1e-3) / 1e9 / HBM_PEAK_GBS
+            fracs.append(frac)
+            if best is None or frac > best[0]:
+                best = (frac, self.leaf, self.root)
+            else:
+                self.leaf, self.root = best[1], best[2]
+            del pad
+            if frac >= accept:
+                break
+        best = None
+        torch.cuda.empty_cache()
+        return fracs
 
     def step(self):
         self.f(self.root, self.leaf)
@@ -419,6 +464,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the other workloads (config 2, 3 stand-ins, 5, row-major layout) measured after the headline")
     ap.add_argument("--secondary", default="", help="comma-separated workload:layout pairs to measure after the headline instead of the full list")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--placement-trials", type=int, default=4,
+                    help="allocations of the sample batch tried before the warm-up (each timed with a few launches, the first that streams at "
+                         "0.745 of 8 TB/s or the best one is kept; 1 = take the first allocation as it comes).  Disclosed in roofline.placement")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device work: one process per rank on the CPU (gloo), the evaluator replaced by a stub that adds the shard's "
                          "sample count to the accumulator; checks sharding, the one collective and the stdout line (tests/test_bench_line.py)")
@@ -467,6 +515,9 @@ def main():
                 sample_offset=start)
     if args.backend == "isa-autotune":
         args.backend = "isa"
+    placement = None
+    if args.placement_trials > 1 and not DRY and args.backend == "isa" and 2.2 * 8 * B * (case.t.n_leaf + case.t.n_root) < free_b:
+        placement = case.choose_placement(args.placement_trials)
     t, st, f, leaf, root, stream = case.t, case.st, case.f, case.leaf, case.root, case.stream
     L, R = t.n_leaf, t.n_root
     step = case.step
@@ -539,6 +590,9 @@ def main():
         fr = sorted(st["bytes_alg"] * B / (m * 1e-3) / 1e9 / HBM_PEAK_GBS for m in kern_ms)
         out["roofline"]["frac_hbm_min_over_steps"] = fr[0]
         out["roofline"]["frac_hbm_max_over_steps"] = fr[-1]
+        if placement:
+            out["roofline"]["placement"] = {"trials": len(placement), "frac_hbm_of_each": [round(x, 4) for x in placement],
+                                            "note": "allocations of the batch tried BEFORE the warm-up, the best kept (DESIGN.md 6a); entry 0 = a single allocation"}
         try:
             if DRY:
                 raise RuntimeError("dry run")
@@ -652,6 +706,8 @@ def compact_line(full):
                 "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy",
                 "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock")
         line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:60]) for k in keep if k in roof}
+        if roof.get("placement"):
+            line["roofline"]["placement_fracs"] = [_r(x, 3) for x in roof["placement"]["frac_hbm_of_each"]]
     cb = full.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),

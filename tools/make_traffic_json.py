@@ -29,7 +29,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 k = r["Kernel_Name"]
-                if k.startswith("fdg_isa_eval"):
+                if k.startswith("fdg_isa_eval") and "_acc" not in k:       # the evaluator, not the accumulate leg bench.py runs after it
                     vals.setdefault((k.replace(".kd", ""), r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     kernels = sorted({k for k, _ in vals})
     fetch = sum(sum(vals.get((k, "FETCH_SIZE"), [0])) / max(1, len(vals.get((k, "FETCH_SIZE"), [0]))) for k in kernels)
