@@ -184,7 +184,7 @@ class Case:
         fractions of the trials in order (the first entry is what a single allocation would have given)."""
         import torch
         bytes_launch = self.st["bytes_alg"] * self.B
-        pads_mb = [0, 130, 2051, 3, 517, 64, 9000, 1]
+        pads_mb = [0, 130, 2051, 3, 9000, 517, 64, 4100, 1, 33, 1027, 260]
         fracs, best = [], None
         for i in range(max(1, trials)):
             pad = None
@@ -464,7 +464,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the other workloads (config 2, 3 stand-ins, 5, row-major layout) measured after the headline")
     ap.add_argument("--secondary", default="", help="comma-separated workload:layout pairs to measure after the headline instead of the full list")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--placement-trials", type=int, default=4,
+    ap.add_argument("--placement-trials", type=int, default=8,
                     help="allocations of the sample batch tried before the warm-up (each timed with a few launches, the first that streams at "
                          "0.745 of 8 TB/s or the best one is kept; 1 = take the first allocation as it comes).  Disclosed in roofline.placement")
     ap.add_argument("--dry-run", action="store_true",
