@@ -468,6 +468,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const char *dbg = std::getenv("FDG_ISA_DEBUG");
   const bool dbg_noleaf = dbg && std::strstr(dbg, "noleaf");
   const bool dbg_nolds = dbg && std::strstr(dbg, "nolds");
+  const bool use_ldexp = std::getenv("FDG_ISA_NO_LDEXP") == nullptr;
   const bool dbg_novalu = dbg && std::strstr(dbg, "novalu");     // the memory stream of the program alone (waits included)
   const bool dbg_nopanel = dbg && std::strstr(dbg, "nopanel");   // no spill traffic to the HBM panel
   // ---- prologue ------------------------------------------------------------
@@ -886,8 +887,20 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       case M_MULC: {
         E.wait_reg(o.a);
         E.wait_reg(o.d);
-        const std::string c = op_const(o);
         if (dbg_novalu) break;
+        // A factor +-2^k (spin and symmetry factors mostly are: -2, 4, 0.5, ... -- 13 % of the executed ops of the GV 5-loop
+        // self-energy): x * 2^k is v_ldexp_f64(x, k) bit for bit -- both are the exactly scaled value rounded once, denormal
+        // results and overflow included -- and the sign rides on the source modifier.  The exponent adder instead of the
+        // multiplier array: the graphs that run against the power budget clock higher.  FDG_ISA_NO_LDEXP=1: v_mul_f64.
+        int k2 = 0;
+        const double m = std::frexp(std::fabs(o.imm), &k2);      // |imm| = m * 2^k2, m in [0.5, 1)
+        if (use_ldexp && !o.param && std::isfinite(o.imm) && o.imm != 0.0 && m == 0.5 && k2 - 1 >= -16 && k2 - 1 <= 64) {
+          const bool neg = (o.nega != 0) != std::signbit(o.imm);
+          E.ins("v_ldexp_f64 " + vlo(o.d) + ", " + (neg ? "-" : "") + vlo(o.a) + ", " + std::to_string(k2 - 1));
+          if (W == 2) E.ins("v_ldexp_f64 " + vhi(o.d) + ", " + (neg ? "-" : "") + vhi(o.a) + ", " + std::to_string(k2 - 1));
+          break;
+        }
+        const std::string c = op_const(o);
         valu2("v_mul_f64 ", o, c, c);
         break;
       }

@@ -384,6 +384,29 @@ def test_config4_taylor_standin_and_special_values(libfdg, cuda, spec):
     assert np.array_equal(np.signbit(got[m]), np.signbit(want[m]))
 
 
+def test_power_of_two_factors_through_ldexp_on_special_values(libfdg, cuda):
+    """A factor +-2^k is printed as v_ldexp_f64 (the exponent adder instead of the multiplier array): the exactly scaled value
+    rounded once, like the multiplication -- subnormal results, overflow to infinity, signed zeros and NaNs included.  One
+    root per factor, leaves that scale into and out of the subnormal range and over the top."""
+    import torch
+    facs = [2.0, -2.0, 4.0, 0.5, -0.5, 0.25, -8.0, 0.125, 2.0 ** -16, -(2.0 ** 64), 2.0 ** 40, 3.0, -0.75, 2.0 ** 65, 2.0 ** -17]
+    nodes = [(OP_SUM, 0, [(0, fc)]) for fc in facs] + [(OP_PROD, 0, [(0, fc), (1, 1.0)]) for fc in facs]
+    t = from_program(2, nodes, [2 + i for i in range(len(nodes))], name="pow2_factors").normalized()
+    x = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1.5e-323, 2.2250738585072014e-308, 2.225073858507201e-308,
+                  1.1125369292536007e-308, 3.3e-310, -7.7e-315, 1.7976931348623157e308, -1.7976931348623157e308, 8.98846567431158e307, 4.4942328371557893e307,
+                  1e300, 1e-300, 3.141592653589793, -2.718281828459045e-308, 6.3e-322], dtype=np.float64)
+    leaf = np.stack([np.repeat(x, len(x)), np.tile(x, len(x))], axis=1)
+    want = oracle.eval_static(t, leaf)
+    for spec in ("isa",):
+        f = fd.compile_table(t, specialize=spec)
+        got = run(f, torch.from_numpy(leaf).to(cuda))
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        m = ~np.isnan(want)
+        assert np.array_equal(got[m].view(np.uint64), want[m].view(np.uint64))
+    src = f.handle.emit_isa() if hasattr(f.handle, "emit_isa") else ""
+    assert not src or "v_ldexp_f64" in src
+
+
 def test_leaf_values_on_device_and_full_mc_step(libfdg, cuda):
     """SURVEY.md 8f row 3 (not fused): (K, T) -> leaves on device with the leafstates tables, then the
     evaluator, then the weighted accumulation -- the loop of example/benchmark.jl:58-87 without leaving the
