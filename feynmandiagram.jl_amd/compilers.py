@@ -106,6 +106,8 @@ class GraphFunc:
     def __call__(self, root, leafVal):
         if _is_torch(leafVal):
             return self._call_torch(root, leafVal)
+        if isinstance(leafVal, np.ndarray) and leafVal.dtype in (np.float32, np.complex128, np.complex64):
+            return self._call_numpy_typed(root, leafVal)
         leaf = np.asarray(leafVal, dtype=np.float64)
         if leaf.ndim == 1:
             if leaf.shape[0] < self.n_leaf:
@@ -149,6 +151,31 @@ class GraphFunc:
         with torch.cuda.device(leaf.device):
             self.handle.eval_device(leaf.data_ptr(), leaf.stride(0), leaf.stride(1), r2.data_ptr(),
                                     r2.stride(0), r2.stride(1), B, st)
+        return root
+
+    def _call_numpy_typed(self, root, leaf):
+        """Host arrays of an element type other than Float64: staged through the device (there is no CPU evaluator behind the ABI)."""
+        import torch
+        if not torch.cuda.is_available():
+            raise capi.FdgError(capi.FDG_E_NO_DEVICE, "no gfx950 device: the evaluator has no CPU fallback")
+        vec = leaf.ndim == 1
+        d_leaf = torch.from_numpy(np.ascontiguousarray(leaf)).cuda()
+        if vec:
+            if leaf.shape[0] < self.n_leaf:
+                raise IndexError(f"BoundsError: attempt to access {leaf.shape[0]}-element leafVal at index [{self.n_leaf}]")
+            if len(root) < self.n_root:
+                raise IndexError(f"BoundsError: attempt to access {len(root)}-element root at index [{self.n_root}]")
+        d_root = self._call_torch_typed(None, d_leaf)
+        torch.cuda.synchronize()
+        h = d_root.cpu().numpy()
+        if vec:
+            for k in range(self.n_root):
+                root[k] = h[k]
+            slots = [k for k in range(self.n_root) if int(self.table.root_slot[k]) != FDG_NO_ROOT]
+            return h[max(slots, key=lambda k: self._emission_rank(int(self.table.root_slot[k])))] if slots else None
+        if root is None:
+            return h
+        root[...] = h
         return root
 
     def _call_torch_typed(self, root, leaf):

@@ -384,6 +384,37 @@ def test_config4_taylor_standin_and_special_values(libfdg, cuda, spec):
     assert np.array_equal(np.signbit(got[m]), np.signbit(want[m]))
 
 
+def test_clock_probe_and_oversubscribed_grid(libfdg, cuda, monkeypatch):
+    """fdg_clock_probe_device: one sleeping wave on a side stream reports shader-clock ticks per 100 MHz tick while an
+    evaluation runs next to it; and the persistent launch gives the same bits whatever the oversubscription factor."""
+    import torch
+    t = workloads.get("parquet_sigma4")
+    f = fd.compile_table(t, specialize="isa")
+    B = 4_000_000 + 37
+    leaf = dev_leaves(cuda, B, t.n_leaf, 77, 0, "leaf_major")
+    root = torch.empty((t.n_root, B), dtype=torch.float64, device=cuda).t()
+    side = torch.cuda.Stream(device=cuda)
+    ticks = torch.zeros(2, dtype=torch.int64, device=cuda)
+    torch.cuda.synchronize()
+    capi.clock_probe_device(0.01, ticks.data_ptr(), side.cuda_stream)
+    for _ in range(12):
+        f(root, leaf)
+    torch.cuda.synchronize()
+    c, w = (int(x) for x in ticks.cpu())
+    assert 0.9e6 <= w <= 3e6 and 0.8 < c / w * 0.1 < 2.7          # about 10 ms of 100 MHz ticks; a shader clock between 0.8 and 2.7 GHz
+    with pytest.raises(capi.FdgError):
+        capi.clock_probe_device(100.0, ticks.data_ptr(), side.cuda_stream)
+    want = root[:8192].cpu().numpy().copy()
+    assert np.array_equal(want, oracle.eval_static(t, leaf[:8192].cpu().numpy()))
+    ref = root.clone()
+    for fac in ("1", "3", "16"):
+        monkeypatch.setenv("FDG_ISA_OVERSUB", fac)
+        root.zero_()
+        f(root, leaf)
+        torch.cuda.synchronize()
+        assert torch.equal(root, ref)
+
+
 def test_power_of_two_factors_through_ldexp_on_special_values(libfdg, cuda):
     """A factor +-2^k is printed as v_ldexp_f64 (the exponent adder instead of the multiplier array): the exactly scaled value
     rounded once, like the multiplication -- subnormal results, overflow to infinity, signed zeros and NaNs included.  One

@@ -181,3 +181,9 @@ def test_typed_known_answers_through_the_device(libfdg, cuda, dtype):
         f(root, torch.ones(1, dtype=tdt, device=cuda))
     with pytest.raises(TypeError):
         f(None, torch.ones(len(lm), dtype=torch.int64, device=cuda))
+    # host vectors of the type: the generated function's call convention (root mutated in place, last root returned)
+    g, leaf, expect = fixtures.kat_compiler_jl()
+    f, _ = fd.Compilers.compile([g], specialize="isa")
+    hroot = np.zeros(1, dtype=NP[dtype])
+    ret = f(hroot, np.asarray(leaf, dtype=NP[dtype]))
+    assert hroot[0] == expect and ret == expect and hroot.dtype == NP[dtype]
