@@ -22,10 +22,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6    # AMD spec, FMA counted as 2 (not in the local guide)
 # The arithmetic contract forbids contraction, so a fold step is one v_add_f64 / v_mul_f64: half the FMA figure.
-# 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12 lane-operations per second (measured on the box, settled clocks: 34.4e12).
+# 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12 lane-operations per second (measured: 38.0e12 at eight waves per SIMD, 36-37.7e12 at one
+# or two waves of a 248-register kernel, straight-line bodies, at 2.39-2.45 GHz: tools/ubench/fp64_issue.hip, profiles/r03_ubench_fp64_issue.txt).
 FP64_NOFMA_PEAK_TOPS = 39.3
 SPEC_CLOCK_GHZ = 2.4            # the clock the 39.3 is quoted at; roofline.clock_ghz is what the chip sustained (power budget)
-FP64_NOFMA_MEASURED_TOPS = 34.4
+FP64_NOFMA_MEASURED_TOPS = 38.0
 CONFIG5_TOTAL_SAMPLES = 1_000_000_000     # BASELINE.json config 5: 10^9 samples over the GPUs of the node
 LINE_LIMIT = 3600                         # bytes of the stdout line (the driver keeps the last ~8 KB of stdout)
 DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
