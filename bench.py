@@ -190,8 +190,14 @@ class Case:
         for i in range(max(1, trials)):
             pad = None
             if i:
-                pad = torch.empty(pads_mb[i % len(pads_mb)] << 20, dtype=torch.uint8, device=self.dev)
-                self.allocate()
+                try:
+                    pad = torch.empty(pads_mb[i % len(pads_mb)] << 20, dtype=torch.uint8, device=self.dev)
+                    self.allocate()
+                except RuntimeError:             # out of memory with two batches alive: keep what there is
+                    pad = None
+                    self.leaf, self.root = best[1], best[2]
+                    torch.cuda.empty_cache()
+                    break
             for _ in range(8):
                 self.step()
             sync()
