@@ -169,6 +169,7 @@ class GraphFunc:
         torch.cuda.synchronize()
         h = d_root.cpu().numpy()
         if vec:
+            h = h.reshape(-1)
             for k in range(self.n_root):
                 root[k] = h[k]
             slots = [k for k in range(self.n_root) if int(self.table.root_slot[k]) != FDG_NO_ROOT]

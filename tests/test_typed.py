@@ -187,3 +187,8 @@ def test_typed_known_answers_through_the_device(libfdg, cuda, dtype):
     hroot = np.zeros(1, dtype=NP[dtype])
     ret = f(hroot, np.asarray(leaf, dtype=NP[dtype]))
     assert hroot[0] == expect and ret == expect and hroot.dtype == NP[dtype]
+    graphs, exp = fixtures.kat_evaluation()            # three roots: the host vector path fills every one of them
+    f, lm = fd.Compilers.compile(list(graphs), specialize="isa")
+    hroot = np.zeros(3, dtype=NP[dtype])
+    ret = f(hroot, np.ones(len(lm), dtype=NP[dtype]))
+    assert hroot.tolist() == [NP[dtype](e) for e in exp] and ret == exp[-1]
