@@ -143,9 +143,9 @@ class GraphFunc:
         if Lc < self.n_leaf:
             raise IndexError("BoundsError: leafVal has fewer columns than the graph has leaves")
         if root is None:
-            root = torch.zeros((B, self.n_root), dtype=torch.float64, device=leaf.device)
+            root = torch.zeros((self.n_root,) if squeeze else (B, self.n_root), dtype=torch.float64, device=leaf.device)
         r2 = root[None, :] if squeeze else root
-        if r2.dtype != torch.float64 or r2.shape[0] != B or r2.shape[1] < self.n_root:
+        if r2.dim() != 2 or r2.dtype != torch.float64 or r2.shape[0] != B or r2.shape[1] < self.n_root:
             raise ValueError("root must be a float64 [B, R] tensor on the same device")
         st = torch.cuda.current_stream(leaf.device).cuda_stream
         with torch.cuda.device(leaf.device):
@@ -199,9 +199,9 @@ class GraphFunc:
         if Lc < self.n_leaf:
             raise IndexError("BoundsError: leafVal has fewer columns than the graph has leaves")
         if root is None:
-            root = torch.zeros((B, self.n_root), dtype=leaf.dtype, device=leaf.device)
+            root = torch.zeros((self.n_root,) if squeeze else (B, self.n_root), dtype=leaf.dtype, device=leaf.device)
         r2 = root[None, :] if squeeze else root
-        if r2.dtype != leaf.dtype or not r2.is_cuda or r2.shape[0] != B or r2.shape[1] < self.n_root:
+        if r2.dim() != 2 or r2.dtype != leaf.dtype or not r2.is_cuda or r2.shape[0] != B or r2.shape[1] < self.n_root:
             raise ValueError("root must be a [B, R] tensor of the leaves' element type on the same device")
         st = torch.cuda.current_stream(leaf.device).cuda_stream
         with torch.cuda.device(leaf.device):
