@@ -300,8 +300,8 @@ def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypa
     src = open(os.path.join(tmp_path, asm[0])).read()
     assert "fdg_isa_mc:" in src and "fdg_isa_mc_acc:" in src
     body = src.split("fdg_isa_mc_acc:")[0]
-    n_exp = body.count("v_ldexp_f64")
-    assert n_exp == body.count("v_rndne_f64") and n_exp >= 89          # one exponential per fermionic leaf + one per momentum
+    n_exp = body.count("v_rndne_f64")
+    assert n_exp >= 89 and body.count("v_ldexp_f64") >= n_exp          # one exponential per fermionic leaf + one per momentum (v_ldexp_f64 also carries the factors +-2^k)
     assert body.count("v_div_fixup_f64") == body.count("v_rcp_f64") > 0                # quotients: correctly rounded divisions
     assert capi.isa_check_hazards(src)[0] == 0
     assert body.count("global_load_dwordx2") <= 3 * (int(z["basis"].shape[1]) * 3 + int(z["n_tau"]))   # inputs (a few re-loads), no leaf matrix
