@@ -597,6 +597,8 @@ def main():
         fr = sorted(st["bytes_alg"] * B / (m * 1e-3) / 1e9 / HBM_PEAK_GBS for m in kern_ms)
         out["roofline"]["frac_hbm_min_over_steps"] = fr[0]
         out["roofline"]["frac_hbm_max_over_steps"] = fr[-1]
+        out["roofline"]["frac_hbm_median_over_steps"] = fr[len(fr) // 2]
+        out["roofline"]["frac_hbm_of_each_step"] = [round(st["bytes_alg"] * B / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for m in kern_ms]     # (detail file only)
         if placement:
             out["roofline"]["placement"] = {"trials": len(placement), "frac_hbm_of_each": [round(x, 4) for x in placement],
                                             "note": "allocations of the batch tried BEFORE the warm-up, the best kept (DESIGN.md 6a); entry 0 = a single allocation"}
@@ -710,7 +712,7 @@ def compact_line(full):
     roof = full.get("roofline")
     if roof:
         keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_kernel_ms",
-                "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy",
+                "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_median_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy",
                 "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock")
         line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:60]) for k in keep if k in roof}
         if roof.get("placement"):
