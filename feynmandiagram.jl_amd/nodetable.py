@@ -24,7 +24,7 @@ import numpy as np
 OP_SUM, OP_PROD, OP_POWER = 0, 1, 2
 FDG_NO_ROOT = 0xFFFFFFFF
 
-__all__ = ["NodeTable", "OP_SUM", "OP_PROD", "OP_POWER", "FDG_NO_ROOT",
+__all__ = ["NodeTable", "OP_SUM", "OP_PROD", "OP_POWER", "FDG_NO_ROOT", "complex_to_real",
            "synthetic_parquet_like", "from_program", "postorder_renumber"]
 
 
@@ -170,6 +170,68 @@ def from_program(n_leaf: int, nodes: Sequence[Tuple[int, int, Sequence[Tuple[int
                   np.array(fac, dtype=np.float64), np.array(list(roots), dtype=np.uint32), name)
     t.validate()
     return t
+
+
+def complex_to_real(t: NodeTable) -> NodeTable:
+    """The graph of ``t`` on complex values spelled out on their real and imaginary parts -- the Float64 table whose leaves are
+    ``re_0, im_0, re_1, im_1, ...`` (a row of a row-major ComplexF64 ``[B, L]`` matrix read as ``2 L`` doubles) and whose roots are
+    ``re, im`` of the original roots.  Every operation is the one Julia performs on ``Complex{Float64}`` values, with the
+    association the evaluator's own folds keep (base/complex.jl; base/operators.jl):
+
+    * ``z * f`` (Float64 factor): ``(re * f, im * f)`` -- one-child nodes ``(g * f)``;
+    * ``z + w``: componentwise, so a Sum node becomes two Sum nodes with the same children order and factors;
+    * ``z * w = (zr wr - zi wi, zr wi + zi wr)``: four products, ``P1 + P2 * -1.0`` (``x * -1.0`` is ``-x`` exactly) and ``P3 + P4``;
+      an n-ary Prod is the left fold of these with the factors applied where the text applies them;
+    * ``z^2 = z * z``, ``z^3 = (z * z) * z`` (Base.literal_pow); other exponents are not covered.
+
+    The Float64 evaluator then gives the bits of the generic function on ComplexF64 arguments (checked against
+    ``oracle.eval_static_typed`` and against the per-type device kernel in tests/test_typed.py)."""
+    t = t.normalized()
+    L = t.n_leaf
+    off, idx, fac = t.child_off, t.child_idx, t.child_fac
+    nodes: List[Tuple[int, int, List[Tuple[int, float]]]] = []
+    val: List[Optional[Tuple[int, int]]] = [(2 * l, 2 * l + 1) for l in range(L)] + [None] * t.n_node
+
+    def add(op, children):
+        nodes.append((op, 0, children))
+        return 2 * L + len(nodes) - 1
+
+    def scale(z, f):
+        return z if f == 1.0 else (add(OP_SUM, [(z[0], f)]), add(OP_SUM, [(z[1], f)]))
+
+    def cmul(z, w):
+        p1, p2 = add(OP_PROD, [(z[0], 1.0), (w[0], 1.0)]), add(OP_PROD, [(z[1], 1.0), (w[1], 1.0)])
+        re = add(OP_SUM, [(p1, 1.0), (p2, -1.0)])
+        p3, p4 = add(OP_PROD, [(z[0], 1.0), (w[1], 1.0)]), add(OP_PROD, [(z[1], 1.0), (w[0], 1.0)])
+        return re, add(OP_SUM, [(p3, 1.0), (p4, 1.0)])
+
+    for n in range(t.n_node):
+        a, b = int(off[n]), int(off[n + 1])
+        ch = [(val[int(idx[e])], float(fac[e])) for e in range(a, b)]
+        o = int(t.op[n])
+        if o == OP_SUM:
+            z = (add(OP_SUM, [(c[0], f) for c, f in ch]), add(OP_SUM, [(c[1], f) for c, f in ch]))
+        elif o == OP_PROD:
+            z = scale(ch[0][0], ch[0][1])
+            for c, f in ch[1:]:
+                z = scale(cmul(z, c), f)
+        elif o == OP_POWER and int(t.power[n]) in (2, 3):
+            x = ch[0][0]
+            z = cmul(x, x)
+            if int(t.power[n]) == 3:
+                z = cmul(z, x)
+            z = scale(z, ch[0][1])
+        else:
+            raise NotImplementedError("complex_to_real covers Sum, Prod, Power{2}, Power{3}")
+        val[L + n] = z
+    roots: List[int] = []
+    for k in range(t.n_root):
+        s_ = int(t.root_slot[k])
+        if s_ == FDG_NO_ROOT:
+            roots += [FDG_NO_ROOT, FDG_NO_ROOT]
+        else:
+            roots += [val[s_][0], val[s_][1]]
+    return from_program(2 * L, nodes, roots, name=(t.name or "graph") + ":complex_as_real")
 
 
 def synthetic_parquet_like(n_node: int = 10000, n_leaf: int = 300, n_root: int = 2,

@@ -99,6 +99,21 @@ def test_complex_twin_against_the_compiled_to_Cstr_text(name, tmp_path):
     assert same_bits(oracle.eval_static_typed(t, leaf, "ComplexF64"), root)
 
 
+@pytest.mark.parametrize("name", ["sigma2", "parquet_sigma3", "gv_sigma4", "gv_sigma4_taylor2"])
+def test_complex_graph_spelled_out_on_real_parts(name):
+    """nodetable.complex_to_real: the Float64 graph over (re, im) pairs evaluates, through the ordinary Float64 oracle in C, to the
+    bits of the typed twin in numpy -- two independent statements of Julia's Complex{Float64} arithmetic."""
+    from feynmandiagram_jl_amd.nodetable import complex_to_real
+    t = workloads.get(name)
+    r = complex_to_real(t)
+    assert r.n_leaf == 2 * t.n_leaf and r.n_root == 2 * t.n_root
+    z = np.ascontiguousarray(rand_leaves(40, t.n_leaf, "ComplexF64", 21))
+    got = oracle.eval_static(r, z.view(np.float64).reshape(40, -1))
+    assert same_bits(np.ascontiguousarray(got).view(np.complex128).reshape(40, -1), oracle.eval_static_typed(t, z, "ComplexF64"))
+    with pytest.raises(NotImplementedError):
+        complex_to_real(from_program(1, [(OP_POWER, 5, [(0, 1.0)])], [1]).normalized())
+
+
 def test_typed_kernels_compile_for_gfx950_and_refuse_what_they_do_not_cover(libfdg, tmp_path):
     # hiprtc cross-compiles without a device; no evaluation here
     t = workloads.get("parquet_sigma3")
@@ -149,7 +164,10 @@ def test_typed_kernels_match_the_typed_twin_bitwise(libfdg, cuda, name, dtype, l
     leaf = dev_typed(cuda, x, layout)
     root = f(None, leaf)
     torch.cuda.synchronize()
-    assert f.kernel_info()["last_kernel"].startswith("fdg_spec_typed<" + dtype)
+    if dtype == "ComplexF64" and layout != "leaf_major" and f._complex_twin:      # rows of re, im pairs: the graph spelled out on real parts, Float64 assembly kernels
+        assert f.last_typed_kernel.startswith("fdg_isa_eval_rm") and "ComplexF64 rows" in f.last_typed_kernel and name != "gv_sigma4_taylor2"
+    else:
+        assert f.last_typed_kernel.startswith("fdg_spec_typed<" + dtype)
     got = root.cpu().numpy()
     want = oracle.eval_static_typed(t, x, dtype)
     assert same_bits(got, want), np.abs(got - want).max()

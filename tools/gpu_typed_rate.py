@@ -29,5 +29,17 @@ for name in sys.argv[1:] or ["parquet_sigma4", "gv_sigma4", "parquet_sigma4_tayl
         want = oracle.eval_static_typed(t, h, dtype) if dtype != "Float64" else oracle.eval_static(t, h)
         ok = np.array_equal(np.ascontiguousarray(root[:n].cpu().numpy()).view(np.uint8), np.ascontiguousarray(want).view(np.uint8))
         bytes_eval = (t.n_leaf + t.n_root) * leaf.element_size()
-        print(f"{name:24s} {dtype:10s} {'exact' if ok else 'MISMATCH'}  {ms:.3f} ms  {B / ms * 1e3:.3e} evals/s  {bytes_eval * B / ms / 1e6:.0f} GB/s  {f.kernel_info()['last_kernel']}", flush=True)
+        print(f"{name:24s} {dtype:10s} leaf-major  {'exact' if ok else 'MISMATCH'}  {ms:.3f} ms  {B / ms * 1e3:.3e} evals/s  {bytes_eval * B / ms / 1e6:.0f} GB/s  {getattr(f, 'last_typed_kernel', None) if dtype != 'Float64' else f.kernel_info()['last_kernel']}", flush=True)
+        if dtype == "ComplexF64":       # rows of (re, im) pairs: the graph spelled out on real parts through the Float64 assembly kernels
+            lrm = leaf.contiguous()
+            rrm = torch.empty((B, t.n_root), dtype=td, device=dev)
+            for _ in range(5): f(rrm, lrm)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20): f(rrm, lrm)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            ok = np.array_equal(np.ascontiguousarray(rrm[:n].cpu().numpy()).view(np.uint8), np.ascontiguousarray(want).view(np.uint8))
+            print(f"{name:24s} {dtype:10s} row-major   {'exact' if ok else 'MISMATCH'}  {ms:.3f} ms  {B / ms * 1e3:.3e} evals/s  {bytes_eval * B / ms / 1e6:.0f} GB/s  {f.last_typed_kernel}", flush=True)
+            del lrm, rrm
         del leaf, root
