@@ -136,7 +136,33 @@ def test_typed_kernels_compile_for_gfx950_and_refuse_what_they_do_not_cover(libf
         g.specialize_typed(7, str(tmp_path))
 
 
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "typed_vectors.npz")
+
+
+@pytest.mark.parametrize("dtype", ["Float32", "ComplexF64", "ComplexF32"])
+@pytest.mark.parametrize("name", ["sigma2", "parquet_sigma3", "gv_sigma4"])
+def test_typed_twin_reproduces_the_committed_vectors(name, dtype):
+    z = np.load(GOLD)
+    leaf, want = z[f"{name}:{dtype}:leaf"], z[f"{name}:{dtype}:root"]
+    assert leaf.dtype == NP[dtype] and same_bits(oracle.eval_static_typed(workloads.get(name), leaf, dtype), want)
+
+
 # ---------------------------------------------------------------------------------------------------------- GPU
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["Float32", "ComplexF64", "ComplexF32"])
+@pytest.mark.parametrize("name", ["sigma2", "parquet_sigma3", "gv_sigma4"])
+def test_typed_committed_vectors_on_device(libfdg, cuda, name, dtype):
+    import torch
+    z = np.load(GOLD)
+    leaf, want = z[f"{name}:{dtype}:leaf"], z[f"{name}:{dtype}:root"]
+    f = fd.compile_table(workloads.get(name), specialize="isa")
+    for dev_leaf in (torch.from_numpy(leaf).to(cuda), dev_typed(cuda, leaf, "leaf_major")):      # rows (ComplexF64: the spelled-out graph) and columns
+        got = f(None, dev_leaf)
+        torch.cuda.synchronize()
+        assert same_bits(got.cpu().numpy(), want)
+
 
 
 def dev_typed(cuda, x, layout):
