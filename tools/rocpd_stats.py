@@ -28,7 +28,7 @@ def summarise(path, last=0):
                                            "where s.kernel_name = ? order by d.start", (name,))]
             tail = d[-last:]
             if tail:
-                out.append(f"{name[:60]:60s} last {len(tail)} launches (bench.py's timed steps): avg_us {sum(tail)/len(tail)/1e3:.2f}  "
+                out.append(f"{name[:60]:60s} last {len(tail)} launches (bench.py's timed steps and the dozen launches of the clock-probe leg after them: same kernel, same batch): avg_us {sum(tail)/len(tail)/1e3:.2f}  "
                            f"min_us {min(tail)/1e3:.2f}  max_us {max(tail)/1e3:.2f}")
     return "\n".join(out)
 
