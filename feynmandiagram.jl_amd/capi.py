@@ -31,7 +31,7 @@ FDG_SPEC_ROW_MAJOR_COMPANION = 16
 EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
-    "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_clock_probe_device", "fdg_graph_specialize_typed", "fdg_eval_device_typed", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
+    "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_clock_probe_device", "fdg_graph_specialize_typed", "fdg_eval_device_typed", "fdg_graph_create_complex_view", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
     "fdg_eval_strided", "fdg_graph_coop_program", "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
@@ -144,6 +144,7 @@ def lib():
     L.fdg_clock_probe_device.argtypes = [C.c_double, vp, vp]
     L.fdg_graph_specialize_typed.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint]
     L.fdg_eval_device_typed.argtypes = [vp, C.c_int, vp, i64, i64, vp, i64, i64, i64, vp]
+    L.fdg_graph_create_complex_view.argtypes = [vp, C.POINTER(vp)]
     L.fdg_isa_check_hazards.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
     L.fdg_graph_release_device.argtypes = [vp]
     L.fdg_leaf_eval_device.argtypes = [C.POINTER(LeafTables), dp, i64, i64, dp, i64, i64, dp, i64, i64, i64, vp]
@@ -192,6 +193,17 @@ class GraphHandle:
         self._h = h
         if getattr(t, "sched_group", None) is not None:
             self.set_schedule_groups(t.sched_group)
+
+    def complex_view(self) -> "GraphHandle":
+        """A new handle for this graph on Complex{Float64} values spelled out on real and imaginary parts (fdg_graph_create_complex_view):
+        a Float64 graph with 2 L leaves and 2 R roots.  ``table`` of the result is the host mirror's statement of the same construction."""
+        from .nodetable import complex_to_real
+        h = C.c_void_p()
+        check(lib().fdg_graph_create_complex_view(self._h, C.byref(h)))
+        v = GraphHandle.__new__(GraphHandle)
+        v.table = complex_to_real(self.table)
+        v._h = h
+        return v
 
     def set_schedule_groups(self, group):
         if group is None:

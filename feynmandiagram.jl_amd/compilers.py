@@ -47,7 +47,6 @@ class GraphFunc:
         interpreter, no JIT)."""
         self.table = table.normalized()
         self._specialize, self._cache_dir, self._flags = specialize, cache_dir, flags
-        self._complex_twin = None        # GraphFunc of nodetable.complex_to_real(table): ComplexF64 rows through the Float64 assembly back end
         self.handle = capi.GraphHandle(self.table)
         self.n_leaf, self.n_root = self.table.n_leaf, self.table.n_root
         if specialize == "auto":
@@ -189,36 +188,13 @@ class GraphFunc:
         dt = {torch.float32: capi.FDG_DT_F32, torch.complex128: capi.FDG_DT_C64, torch.complex64: capi.FDG_DT_C32}.get(leaf.dtype)
         if dt is None:
             raise TypeError(f"leafVal of element type {leaf.dtype} is not supported (Float64, Float32, ComplexF64, ComplexF32)")
-        # ComplexF64 rows (compile_Python's row-major [B, L]; a row is 2 L doubles re, im, re, im, ...): the same graph spelled out
-        # on real and imaginary parts is an ordinary Float64 graph, which the assembly back end reads in place (row-major variant)
-        if (dt == capi.FDG_DT_C64 and self._specialize in ("isa", "isa-autotune", "auto") and leaf.dim() == 2 and leaf.stride(1) == 1
-                and leaf.shape[1] >= self.n_leaf and (root is None or (root.dim() == 2 and root.dtype == leaf.dtype and root.stride(1) == 1
-                                                                        and root.shape[0] == leaf.shape[0] and root.shape[1] >= self.n_root))
-                and self._complex_twin is not False):
-            if self._complex_twin is None:
-                try:
-                    from .nodetable import complex_to_real
-                    self._complex_twin = GraphFunc(complex_to_real(self.table), specialize="isa", cache_dir=self._cache_dir, flags=self._flags)
-                    if not self._complex_twin.kernel_info()["has_rm"]:
-                        # no in-place row-major variant for the spelled-out graph (its leaves are re-read all over a long program): the
-                        # transposition in front of the leaf-major kernel loses to the per-type kernel (Taylor graph: 3.1e8 against 5.1e8)
-                        self._complex_twin = False
-                except (NotImplementedError, capi.FdgError):
-                    self._complex_twin = False           # (a Power the spelling does not cover, ...): the per-type kernel below
-            if self._complex_twin:
-                B = leaf.shape[0]
-                if root is None:
-                    root = torch.zeros((B, self.n_root), dtype=leaf.dtype, device=leaf.device)
-                lr = torch.view_as_real(leaf).flatten(1)          # [B, 2 * columns] doubles, no copy
-                rr = torch.view_as_real(root).flatten(1)
-                assert lr.data_ptr() == leaf.data_ptr() and rr.data_ptr() == root.data_ptr()
-                self._complex_twin(rr[:, :2 * self.n_root], lr)
-                self.last_typed_kernel = self._complex_twin.kernel_info()["last_kernel"] + " (ComplexF64 rows as 2 L doubles)"
-                return root
         if not hasattr(self, "_typed_ready"):
             self._typed_ready = set()
         if dt not in self._typed_ready:
-            self.handle.specialize_typed(dt)
+            # (FDG_SPEC_ISA: ComplexF64 rows -- compile_Python's row-major [B, L] -- additionally get the graph spelled out on real and
+            # imaginary parts through the Float64 assembly back end; the library decides per call which kernel a layout takes)
+            isa = self._specialize in ("isa", "isa-autotune", "auto")
+            self.handle.specialize_typed(dt, self._cache_dir, capi.FDG_SPEC_ISA if isa else 0)
             self._typed_ready.add(dt)
         squeeze = leaf.dim() == 1
         if squeeze:

@@ -58,6 +58,8 @@ struct Lowered {
 
 // lowering entry points (fdg_lower.cpp)
 int validate_desc(const fdg_graph_desc *d, std::string &err);
+struct RealTwinTable { uint32_t n_leaf = 0; std::vector<uint8_t> op; std::vector<int32_t> power; std::vector<uint32_t> off, idx, root_slot; std::vector<double> fac; };
+bool complex_to_real_table(const Lowered &p, RealTwinTable &out, std::string &why);
 void analyse(Lowered &p);
 void build_interpreter_program(Lowered &p, uint32_t lds_slot_budget);
 
@@ -145,6 +147,9 @@ struct fdg_graph {
   // element types other than Float64 (fdg_graph_specialize_typed): one HIP-source kernel per type, [FDG_DT_*]
   std::vector<char> typed_code[4];
   void *typed_module[4] = {nullptr, nullptr, nullptr, nullptr}, *fn_typed[4] = {nullptr, nullptr, nullptr, nullptr};
+  // ComplexF64 rows through the Float64 assembly back end: the graph spelled out on real and imaginary parts (owned; may be null)
+  fdg_graph *cx_twin = nullptr;
+  bool cx_twin_tried = false;
   // ... or, for graphs too large for a compiler-scheduled kernel, leaf kernel -> chunk of leaves -> this handle's evaluator
   int mc_route = 0;                // 0 none, 1 fused HIP kernel, 2 leaf kernel + evaluator, 3 fused ISA kernel
   std::vector<int32_t> lt_i32[5];  // copy of the leafstates tables (type, order, tau_in, tau_out, loop_index)

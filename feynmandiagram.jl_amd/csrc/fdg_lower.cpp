@@ -6,6 +6,8 @@
 // that cannot influence a root are dropped.  Each node's arithmetic is untouched.
 #include <algorithm>
 #include <cstring>
+#include <initializer_list>
+#include <utility>
 #include <limits>
 
 #include "fdg_internal.h"
@@ -18,6 +20,66 @@ void set_error(const std::string &s) { g_err = s; }
 const char *last_error_cstr() { return g_err.c_str(); }
 
 double powi(double x, int32_t n) { return fdg_powi_impl(x, n); }
+
+// The graph on Complex{Float64} values spelled out on their real and imaginary parts: a Float64 table whose leaves are
+// re_0, im_0, re_1, im_1, ... (a row of a row-major ComplexF64 [B, L] matrix read as 2 L doubles) and whose roots are (re, im)
+// of the original roots.  Every operation is the one Julia performs (base/complex.jl), in the association the evaluator's own folds
+// keep: z * f = (re f, im f) as one-child nodes "(g * f)"; z + w componentwise -- a Sum becomes two Sums with the same children
+// order and factors; z * w = (zr wr - zi wi, zr wi + zi wr) as four products, P1 + P2 * -1.0 (x * -1.0 is -x exactly) and
+// P3 + P4, an n-ary Prod being the left fold of these with the factors applied where the text applies them; z^2 = z z,
+// z^3 = (z z) z (Base.literal_pow).  The host mirror states the same construction in Python (nodetable.complex_to_real).
+bool complex_to_real_table(const Lowered &p, RealTwinTable &o, std::string &why) {
+  const uint32_t L = p.L;
+  o = RealTwinTable();
+  o.n_leaf = 2 * L;
+  o.off.assign(1, 0);
+  std::vector<std::pair<uint32_t, uint32_t>> val((size_t)L + p.N);
+  for (uint32_t l = 0; l < L; ++l) val[l] = {2 * l, 2 * l + 1};
+  auto add = [&](uint8_t op, std::initializer_list<std::pair<uint32_t, double>> ch) {
+    o.op.push_back(op); o.power.push_back(0);
+    for (auto &c : ch) { o.idx.push_back(c.first); o.fac.push_back(c.second); }
+    o.off.push_back((uint32_t)o.idx.size());
+    return 2 * L + (uint32_t)o.op.size() - 1;
+  };
+  using Z = std::pair<uint32_t, uint32_t>;
+  auto scale = [&](Z z, double f) -> Z { if (f == 1.0) return z; const uint32_t r = add(FDG_OP_SUM, {{z.first, f}}); const uint32_t i = add(FDG_OP_SUM, {{z.second, f}}); return {r, i}; };
+  auto cmul = [&](Z z, Z w) -> Z {
+    const uint32_t p1 = add(FDG_OP_PROD, {{z.first, 1.0}, {w.first, 1.0}}), p2 = add(FDG_OP_PROD, {{z.second, 1.0}, {w.second, 1.0}});
+    const uint32_t re = add(FDG_OP_SUM, {{p1, 1.0}, {p2, -1.0}});
+    const uint32_t p3 = add(FDG_OP_PROD, {{z.first, 1.0}, {w.second, 1.0}}), p4 = add(FDG_OP_PROD, {{z.second, 1.0}, {w.first, 1.0}});
+    return {re, add(FDG_OP_SUM, {{p3, 1.0}, {p4, 1.0}})};
+  };
+  for (uint32_t n = 0; n < p.N; ++n) {
+    const uint32_t a = p.off[n], b = p.off[n + 1];
+    Z z;
+    if (p.op[n] == FDG_OP_SUM) {
+      for (int part = 0; part < 2; ++part) {
+        o.op.push_back(FDG_OP_SUM); o.power.push_back(0);
+        for (uint32_t e = a; e < b; ++e) { o.idx.push_back(part ? val[p.idx[e]].second : val[p.idx[e]].first); o.fac.push_back(p.fac[e]); }
+        o.off.push_back((uint32_t)o.idx.size());
+        (part ? z.second : z.first) = 2 * L + (uint32_t)o.op.size() - 1;
+      }
+    } else if (p.op[n] == FDG_OP_PROD) {
+      z = scale(val[p.idx[a]], p.fac[a]);
+      for (uint32_t e = a + 1; e < b; ++e) z = scale(cmul(z, val[p.idx[e]]), p.fac[e]);
+    } else if (p.op[n] == FDG_OP_POWER && (p.power[n] == 2 || p.power[n] == 3)) {
+      const Z x = val[p.idx[a]];
+      z = cmul(x, x);
+      if (p.power[n] == 3) z = cmul(z, x);
+      z = scale(z, p.fac[a]);
+    } else {
+      why = "the spelled-out form of a complex graph covers Sum, Prod, Power{2}, Power{3}";
+      return false;
+    }
+    val[L + n] = z;
+  }
+  for (uint32_t k = 0; k < p.R; ++k) {
+    const uint32_t s = p.root_slot[k];
+    if (s == FDG_NO_ROOT) { o.root_slot.push_back(FDG_NO_ROOT); o.root_slot.push_back(FDG_NO_ROOT); }
+    else { o.root_slot.push_back(val[s].first); o.root_slot.push_back(val[s].second); }
+  }
+  return true;
+}
 
 int validate_desc(const fdg_graph_desc *d, std::string &err) {
   if (!d) { err = "null descriptor"; return FDG_E_INVALID; }

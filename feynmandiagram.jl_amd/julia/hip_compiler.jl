@@ -205,7 +205,9 @@ const _FDG_DT = Dict{DataType,Cint}(Float64 => 0, Float32 => 1, ComplexF64 => 2,
 function eval_device!(f::GraphFunc, d_root::Ptr{T}, d_leaf::Ptr{T}, B::Integer;
     leaf_strides=(1, B), root_strides=(1, B), stream::Ptr{Cvoid}=C_NULL) where {T<:Union{Float32,ComplexF64,ComplexF32}}
     dt = _FDG_DT[T]
-    _fdg_check(ccall((:fdg_graph_specialize_typed, _libfdg), Cint, (Ptr{Cvoid}, Cint, Cstring, Cuint), f.handle, dt, C_NULL, Cuint(0)))
+    # (flag 4 = FDG_SPEC_ISA: ComplexF64 batches whose rows are contiguous -- leaf_strides = (L, 1) -- additionally get the graph spelled out on
+    #  real and imaginary parts through the assembly back end; a column-major B x L Julia matrix takes the per-type kernel)
+    _fdg_check(ccall((:fdg_graph_specialize_typed, _libfdg), Cint, (Ptr{Cvoid}, Cint, Cstring, Cuint), f.handle, dt, C_NULL, Cuint(4)))
     _fdg_check(ccall((:fdg_eval_device_typed, _libfdg), Cint,
         (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}),
         f.handle, dt, d_leaf, leaf_strides[1], leaf_strides[2], d_root, root_strides[1], root_strides[2], B, stream))

@@ -237,6 +237,16 @@ int fdg_graph_coop_program(const fdg_graph *g, const fdg_opt_params *prm, uint32
 #define FDG_DT_C64 2
 #define FDG_DT_C32 3
 int fdg_graph_specialize_typed(fdg_graph *g, int dtype, const char *cache_dir, unsigned flags);
+/* ComplexF64 rows.  fdg_graph_create_complex_view returns a NEW handle (the caller's to destroy) for the Float64 graph that is g's
+ * graph on Complex{Float64} values spelled out on real and imaginary parts: leaves re_0, im_0, re_1, im_1, ... -- a row of a
+ * row-major ComplexF64 [B, L] matrix read as 2 L doubles --, roots (re, im) of g's roots, every operation the one
+ * base/complex.jl performs (z w = (zr wr - zi wi, zr wi + zi wr), z f = (re f, im f), + componentwise, z^2 = z z, z^3 = (z z) z)
+ * in the association of the evaluator's own folds, so the ordinary Float64 entry points give the generic function's bits on
+ * ComplexF64 arguments.  FDG_E_UNSUPPORTED for other powers.  fdg_graph_specialize_typed(g, FDG_DT_C64, dir, FDG_SPEC_ISA) builds such
+ * a view inside g and specialises it with the optimizing back end; fdg_eval_device_typed then sends row-major batches
+ * (leaf_leaf_stride == 1, root_root_stride == 1) through its in-place row-major kernel when it has one, everything else through
+ * the per-type kernel. */
+int fdg_graph_create_complex_view(const fdg_graph *g, fdg_graph **out);
 int fdg_eval_device_typed(fdg_graph *g, int dtype, const void *d_leaf, int64_t leaf_sample_stride, int64_t leaf_leaf_stride,
                           void *d_root, int64_t root_sample_stride, int64_t root_root_stride, int64_t n_sample, void *stream);
 
