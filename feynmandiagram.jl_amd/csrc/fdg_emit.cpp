@@ -112,7 +112,7 @@ static void emit_node_expr(std::ostringstream &os, const Lowered &p, uint32_t n)
 // Leaves are g<i>, computed values v<id>; roots are collected in r<k>.  False: the schedule does not cover the
 // graph (Power{N}, N not 2 or 3) and the caller falls back to statement order.
 static bool emit_nodes_scheduled(std::ostringstream &os, const Lowered &p, const std::function<void(std::ostringstream &, uint32_t)> &load_leaf,
-                                 const char *decl = "const double", bool keep_minus_one = false) {
+                                 const char *decl = "const double", bool keep_minus_one = false, bool mul_keeps_signs = false) {
   if (std::getenv("FDG_HIP_TABLE_ORDER")) return false;
   std::vector<SchedOp> ops;
   uint32_t nv = 0;
@@ -120,6 +120,7 @@ static bool emit_nodes_scheduled(std::ostringstream &os, const Lowered &p, const
   OptParams prm;
   prm.vn_window = 200;
   prm.keep_minus_one = keep_minus_one;
+  prm.mul_keeps_signs = mul_keeps_signs;
   if (!build_schedule(p, prm, ops, nv, why)) return false;
   auto ref = [&](uint32_t r) {
     const uint32_t v = r >> 1;
@@ -293,7 +294,11 @@ std::string emit_hip_source_typed(const Lowered &p, int dtype, bool &ok, std::st
     done[i] = 1;
   };
   std::ostringstream body;
-  if (!emit_nodes_scheduled(body, p, load_leaf, "const auto", dtype == FDG_DT_F32 || dtype == FDG_DT_C32)) {
+  // Single precision: `g * -1.0` stays a multiplication (it widens the value: Julia's promotion).  ComplexF64: -1 still rides as a sign
+  // (z * -1.0 is -z exactly, zeros included), but a product consumes a negated operand as it is -- ((-z) w) and -(z w) differ in the
+  // sign of a real part that cancels exactly: (-P1) + P2 = +0 where -(P1 - P2) = -0
+  const bool single = dtype == FDG_DT_F32 || dtype == FDG_DT_C32;
+  if (!emit_nodes_scheduled(body, p, load_leaf, "const auto", single, !single)) {
     ok = false;
     why = "element types other than Float64 cover Sum, Prod and Power{2}, Power{3} (other literal powers go through Base.power_by_squaring / pow_body per type)";
     return std::string();

@@ -95,6 +95,18 @@ struct Builder {
   }
   uint32_t op2(uint8_t k, uint32_t a, uint32_t b) {
     if (!value_numbering) { uint32_t d = fresh(); u.push_back(UOp{k, d, a, b, 0.0}); return d << 1; }
+    if (k == M_MUL && mul_keeps_signs) {
+      uint32_t x = a, y = b;
+      if (x > y) std::swap(x, y);
+      const uint64_t key = ((uint64_t)x << 32) | y;
+      auto it = vn_mul.find(key);
+      if (it != vn_mul.end() && fresh_enough(it->second)) { touch(it->second); return it->second; }
+      touch(x); touch(y);
+      uint32_t d = fresh();
+      u.push_back(UOp{M_MUL, d, x, y, 0.0});
+      vn_mul[key] = d << 1;
+      return d << 1;
+    }
     if (k == M_MUL) {
       const uint32_t sign = (a ^ b) & 1u;
       uint32_t x = a & ~1u, y = b & ~1u;
@@ -120,6 +132,7 @@ struct Builder {
     return d << 1;
   }
   bool keep_minus_one = false;     // OptParams::keep_minus_one
+  bool mul_keeps_signs = false;    // OptParams::mul_keeps_signs
   uint32_t mulc(uint32_t a, double f) {
     if (f == 1.0) return a;
     if (f == -1.0 && !keep_minus_one) return a ^ 1u;
@@ -1096,12 +1109,13 @@ bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp>
   B0.vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
   B0.vn_touch = std::getenv("FDG_VN_BIRTH_WINDOW") == nullptr;
   B0.keep_minus_one = prm.keep_minus_one;
+  B0.mul_keeps_signs = prm.mul_keeps_signs;
   build_uops(B0);
   Lowered plain;
   const bool retry = !B0.ok && B0.why == "inconsistent schedule groups";
   if (retry) { plain = p; plain.sched_group.clear(); }
   Builder B1(retry ? plain : p);
-  B1.value_numbering = B0.value_numbering; B1.vn_window = B0.vn_window; B1.vn_touch = B0.vn_touch; B1.keep_minus_one = B0.keep_minus_one;
+  B1.value_numbering = B0.value_numbering; B1.vn_window = B0.vn_window; B1.vn_touch = B0.vn_touch; B1.keep_minus_one = B0.keep_minus_one; B1.mul_keeps_signs = B0.mul_keeps_signs;
   if (retry) build_uops(B1);
   Builder &B = retry ? B1 : B0;
   why = B.why;

@@ -92,6 +92,8 @@ struct OptParams {
                                   // asked for too late (one wave per SIMD only; not for the row-major or Monte-Carlo programs)
   bool keep_minus_one = false;    // schedules for single-precision element types: `g * -1.0` stays a multiplication (it promotes the value to
                                   // Float64 in the reference's generic function; as a sign on the operand it would not)
+  bool mul_keeps_signs = false;   // schedules for ComplexF64 values: a product consumes a negated operand as it is instead of pulling the sign
+                                  // out -- ((-z) w) and -(z w) differ in the sign of a real part that cancels exactly
   uint32_t reserve_pairs = 0;     // VGPR pairs the kernel variant keeps above the values (accumulators, weight): the value budget shrinks
                                   // by this and by the temporaries the program's macro ops need, so that everything stays below v256
 };

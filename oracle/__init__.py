@@ -288,7 +288,11 @@ def eval_static_typed(table, leaf: np.ndarray, dtype: str) -> np.ndarray:
         s = int(table.root_slot[k])
         if s != NO_ROOT:
             re, im = vals[s]
-            out[:, k] = re.astype(real) if not cx else re.astype(real) + 1j * im.astype(real)
+            if cx:                                   # (componentwise: `re + 1j * im` would turn an infinite part into NaN)
+                out[:, k].real = re.astype(real)
+                out[:, k].imag = im.astype(real)
+            else:
+                out[:, k] = re.astype(real)
     return out
 
 

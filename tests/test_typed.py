@@ -110,6 +110,15 @@ def test_complex_graph_spelled_out_on_real_parts(name):
     z = np.ascontiguousarray(rand_leaves(40, t.n_leaf, "ComplexF64", 21))
     got = oracle.eval_static(r, z.view(np.float64).reshape(40, -1))
     assert same_bits(np.ascontiguousarray(got).view(np.complex128).reshape(40, -1), oracle.eval_static_typed(t, z, "ComplexF64"))
+    # infinite, huge, zero and NaN parts: the same parts become NaN / inf / -0.0 in both statements
+    zs = z[:8].copy()
+    zs[0, 0] = complex(np.inf, 1.0); zs[1, -1] = complex(2.0, -np.inf); zs[2, :] = 1e200 + 1e200j; zs[3, 0] = complex(np.nan, 0.0)
+    zs[4, :] = 0.0; zs[5, ::2] = complex(-0.0, 0.0); zs[6, :] = 1e-320 + 3e-310j
+    with np.errstate(all="ignore"):
+        a = np.ascontiguousarray(oracle.eval_static(r, zs.view(np.float64).reshape(8, -1)))
+        b = np.ascontiguousarray(oracle.eval_static_typed(t, zs, "ComplexF64")).view(np.float64).reshape(a.shape)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(a)])
+    assert np.array_equal(np.signbit(a[~np.isnan(a)]), np.signbit(b[~np.isnan(a)]))
     with pytest.raises(NotImplementedError):
         complex_to_real(from_program(1, [(OP_POWER, 5, [(0, 1.0)])], [1]).normalized())
     # the library's own construction (fdg_graph_create_complex_view, C++): same size, and its allocated program replays to the same bits
@@ -124,6 +133,24 @@ def test_complex_graph_spelled_out_on_real_parts(name):
         capi.GraphHandle(from_program(1, [(OP_POWER, 5, [(0, 1.0)])], [1]).normalized()).complex_view()
 
 
+def cancelling_product_case():
+    """(g * -1.0) * h with g_r h_r == g_i h_i: Julia's real part is (-g_r) h_r - (-g_i) h_i = +0.0; pulling the sign out, -(g_r h_r - g_i h_i),
+    would give -0.0.  Second root: h * (g * -1.0), third: the Sum g * -1.0 + g (imaginary and real parts cancel to +0.0)."""
+    t = from_program(2, [(OP_PROD, 0, [(0, -1.0), (1, 1.0)]), (OP_PROD, 0, [(1, 1.0), (0, -1.0)]), (OP_SUM, 0, [(0, -1.0), (0, 1.0)])], [2, 3, 4], name="cancel").normalized()
+    z = np.array([[1 + 1j, 1 + 1j], [2 + 3j, 3 + 2j], [0.5 - 0.25j, -1 - 2j], [1.5 + 0j, 0 + 2j]], dtype=np.complex128)
+    return t, z
+
+
+def test_sign_of_a_cancelling_real_part_in_the_twin():
+    t, z = cancelling_product_case()
+    want = oracle.eval_static_typed(t, z, "ComplexF64")
+    assert want[0, 0].real == 0.0 and not np.signbit(want[0, 0].real) and want[0, 0].imag == -2.0
+    assert not np.signbit(want[1, 0].real) and want[1, 0].real == 0.0
+    from feynmandiagram_jl_amd.nodetable import complex_to_real
+    got = oracle.eval_static(complex_to_real(t), z.view(np.float64).reshape(4, -1))
+    assert same_bits(np.ascontiguousarray(got).view(np.complex128).reshape(4, -1), want)
+
+
 def test_typed_kernels_compile_for_gfx950_and_refuse_what_they_do_not_cover(libfdg, tmp_path):
     # hiprtc cross-compiles without a device; no evaluation here
     t = workloads.get("parquet_sigma3")
@@ -133,10 +160,11 @@ def test_typed_kernels_compile_for_gfx950_and_refuse_what_they_do_not_cover(libf
     texts = [open(os.path.join(tmp_path, f)).read() for f in os.listdir(tmp_path) if f.endswith(".hip")]
     assert len(texts) == 3 and all("fdg_spec_typed" in x and "const auto v" in x for x in texts)
     assert sum("fdg_cx<float> *__restrict__ leaf" in x for x in texts) == 1 and sum("const float *__restrict__ leaf" in x for x in texts) == 1
-    # a single-precision schedule keeps `* -1.0` as a multiplication (it widens the value), a double-precision one carries it as a sign
+    # a single-precision schedule keeps `* -1.0` as a multiplication (it widens the value); a ComplexF64 one carries it as a sign, which a
+    # later product consumes on the operand ("(-g3) * v17") instead of pulling it out
     f32 = next(x for x in texts if "const float *__restrict__ leaf" in x)
     c64 = next(x for x in texts if "fdg_cx<double> *__restrict__ leaf" in x)
-    assert "* -0x1p+0;" in f32 and "* -0x1p+0;" not in c64
+    assert "* -0x1p+0;" in f32 and "* -0x1p+0;" not in c64 and " = (-" in c64
     # Power{5}: other literal powers take type-specific paths in Julia; the typed kernels say so instead of guessing
     tp = from_program(1, [(OP_POWER, 5, [(0, 1.0)])], [1], name="p5").normalized()
     with pytest.raises(capi.FdgError) as e:
@@ -214,6 +242,20 @@ def test_typed_kernels_match_the_typed_twin_bitwise(libfdg, cuda, name, dtype, l
     r64 = f(None, torch.from_numpy(x64).to(cuda))
     torch.cuda.synchronize()
     assert same_bits(r64.cpu().numpy(), oracle.eval_static(t, x64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["ComplexF64", "ComplexF32"])
+def test_sign_of_a_cancelling_real_part_on_device(libfdg, cuda, dtype):
+    import torch
+    t, z = cancelling_product_case()
+    z = z.astype(NP[dtype])
+    want = oracle.eval_static_typed(t, z, dtype)
+    f = fd.compile_table(t, specialize="isa")
+    for leaf in (torch.from_numpy(z).to(cuda), dev_typed(cuda, z, "leaf_major")):
+        got = f(None, leaf)
+        torch.cuda.synchronize()
+        assert same_bits(got.cpu().numpy(), want)          # bit for bit: the signs of the zeros included
 
 
 @pytest.mark.gpu
