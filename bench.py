@@ -471,7 +471,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the other workloads (config 2, 3 stand-ins, 5, row-major layout) measured after the headline")
     ap.add_argument("--secondary", default="", help="comma-separated workload:layout pairs to measure after the headline instead of the full list")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--placement-trials", type=int, default=8,
+    ap.add_argument("--placement-trials", type=int, default=12,
                     help="allocations of the sample batch tried before the warm-up (each timed with a few launches, the first that streams at "
                          "0.745 of 8 TB/s or the best one is kept; 1 = take the first allocation as it comes).  Disclosed in roofline.placement")
     ap.add_argument("--dry-run", action="store_true",
