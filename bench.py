@@ -185,18 +185,23 @@ class Case:
         fractions of the trials in order (the first entry is what a single allocation would have given)."""
         import torch
         bytes_launch = self.st["bytes_alg"] * self.B
+        need = 8 * self.B * (self.t.n_leaf + self.t.n_root)
         pads_mb = [0, 130, 2051, 3, 9000, 517, 64, 4100, 1, 33, 1027, 260]
-        fracs, best = [], None
+        fracs, best, losers = [], None, []
         for i in range(max(1, trials)):
             pad = None
             if i:
+                # a rejected batch stays allocated during the next trial when there is room for three (the new one then lands somewhere
+                # else); what is dropped goes back to the driver, not into torch's cache, or the next trial would get the same pages again
+                while losers and (len(losers) > 1 or torch.cuda.mem_get_info(self.dev)[0] < 1.15 * need):
+                    losers.pop(0)
+                    torch.cuda.empty_cache()
                 try:
                     pad = torch.empty(pads_mb[i % len(pads_mb)] << 20, dtype=torch.uint8, device=self.dev)
                     self.allocate()
-                except RuntimeError:             # out of memory with two batches alive: keep what there is
+                except RuntimeError:             # out of memory: keep what there is
                     pad = None
                     self.leaf, self.root = best[1], best[2]
-                    torch.cuda.empty_cache()
                     break
             for _ in range(8):
                 self.step()
@@ -210,13 +215,17 @@ class Case:
             frac = bytes_launch / (min(ev.ms()) * 1e-3) / 1e9 / HBM_PEAK_GBS
             fracs.append(frac)
             if best is None or frac > best[0]:
+                if best is not None:
+                    losers.append((best[1], best[2]))
                 best = (frac, self.leaf, self.root)
             else:
+                losers.append((self.leaf, self.root))
                 self.leaf, self.root = best[1], best[2]
             del pad
             if frac >= accept:
                 break
         best = None
+        losers.clear()
         torch.cuda.empty_cache()
         return fracs
 
