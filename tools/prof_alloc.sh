@@ -8,7 +8,9 @@ mkdir -p "$OUT"
 python $R/tools/gpu_alloc_probe.py parquet_sigma4 100000000 8 > "$OUT/plain.txt" 2>&1
 cd /tmp && export TMPDIR=/tmp
 i=0
-for grp in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum" "TCP_PENDING_STALL_CYCLES_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum GRBM_UTCL2_BUSY"; do
+# (PROF_ALLOC_GROUPS="grp1|grp2|...": other counter groups, e.g. the memory-side request counters)
+IFS='|' read -r -a GROUPS_ <<< "${PROF_ALLOC_GROUPS:-TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum|TCP_PENDING_STALL_CYCLES_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum GRBM_UTCL2_BUSY}"
+for grp in "${GROUPS_[@]}"; do
   i=$((i+1))
   D="$OUT/pass$i"; mkdir -p "$D"
   timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$D" -o p -- python $R/tools/gpu_alloc_probe.py parquet_sigma4 100000000 6 > "$D.log" 2>&1
@@ -31,4 +33,4 @@ for k in sorted(cnt, key=lambda x: int(x)):
     print(k, "%.3f" % dur.get(k, -1), "  ".join("%.4g" % cnt[k].get(n, -1) for n in names))
 PY
 done
-cat "$OUT/plain.txt"; grep "round" "$OUT"/pass*.log; head -40 "$OUT/pass1.txt"
+cat "$OUT/plain.txt"; grep "round" "$OUT"/pass*.log; for f in "$OUT"/pass*.txt; do echo "== $f"; head -60 "$f"; done
