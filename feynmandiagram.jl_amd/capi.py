@@ -27,6 +27,8 @@ FDG_SPEC_DEFAULT, FDG_SPEC_KEEP_SOURCE, FDG_SPEC_FAST_MATH, FDG_SPEC_ISA, FDG_SP
 FDG_DT_F64, FDG_DT_F32, FDG_DT_C64, FDG_DT_C32 = 0, 1, 2, 3
 DTYPES = {"Float64": FDG_DT_F64, "Float32": FDG_DT_F32, "ComplexF64": FDG_DT_C64, "ComplexF32": FDG_DT_C32}
 FDG_SPEC_ROW_MAJOR_COMPANION = 16
+FDG_ASSOC_STATIC, FDG_ASSOC_INTERP = 0, 1     # fdg_graph_set_association: static.jl's generated code / eval.jl's interpreter
+FDG_TILE_SAMPLES = 64
 
 EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
@@ -36,6 +38,7 @@ EXPORTS = [
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
     "fdg_graph_kernel_info",
+    "fdg_eval_device_tiled", "fdg_accumulate_device_tiled", "fdg_fill_uniform_device_tiled", "fdg_graph_set_association",
 ]
 COMM_ID_BYTES = 128
 
@@ -137,6 +140,10 @@ def lib():
     L.fdg_graph_specialize.argtypes = [vp, C.c_char_p, C.c_uint]
     L.fdg_eval_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, i64, vp]
     L.fdg_eval.argtypes = [vp, dp, dp, i64]
+    L.fdg_graph_set_association.argtypes = [vp, C.c_int]
+    L.fdg_eval_device_tiled.argtypes = [vp, dp, i64, i64, i64, dp, i64, i64, i64, i64, vp]
+    L.fdg_accumulate_device_tiled.argtypes = [vp, dp, i64, i64, i64, dp, dp, i64, vp]
+    L.fdg_fill_uniform_device_tiled.argtypes = [dp, i64, u32, i64, i64, i64, u64, u64, vp]
     L.fdg_eval_strided.argtypes = [vp, dp, i64, i64, dp, i64, i64, i64]
     L.fdg_accumulate_device.argtypes = [vp, dp, i64, i64, dp, dp, i64, vp]
     L.fdg_fill_uniform_device.argtypes = [dp, i64, u32, i64, i64, u64, u64, vp]
@@ -204,6 +211,10 @@ class GraphHandle:
         v.table = complex_to_real(self.table)
         v._h = h
         return v
+
+    def set_association(self, assoc: int):
+        """FDG_ASSOC_STATIC (the generated code, static.jl) or FDG_ASSOC_INTERP (eval!, eval.jl); before any specialisation."""
+        check(lib().fdg_graph_set_association(self._h, assoc))
 
     def set_schedule_groups(self, group):
         if group is None:
@@ -330,6 +341,13 @@ class GraphHandle:
     def accumulate_device(self, d_leaf: int, ss: int, ls: int, d_weight: int, d_acc: int, B: int, stream: int = 0):
         check(lib().fdg_accumulate_device(self._h, d_leaf, ss, ls, d_weight or None, d_acc, B, stream))
 
+    # tile-major batches: sample b at (b // 64) * tile stride + (b % 64) * sample stride (fdg.h) ------------------- #
+    def eval_device_tiled(self, d_leaf: int, ss: int, ls: int, lts: int, d_root: int, rs: int, rk: int, rts: int, B: int, stream: int = 0):
+        check(lib().fdg_eval_device_tiled(self._h, d_leaf, ss, ls, lts, d_root, rs, rk, rts, B, stream))
+
+    def accumulate_device_tiled(self, d_leaf: int, ss: int, ls: int, lts: int, d_weight: int, d_acc: int, B: int, stream: int = 0):
+        check(lib().fdg_accumulate_device_tiled(self._h, d_leaf, ss, ls, lts, d_weight or None, d_acc, B, stream))
+
     # fused Monte-Carlo step: leaves from (K, T) in registers, then the graph --------------------- #
     def specialize_fused(self, tables, cache_dir: Optional[str] = None, flags: int = 0):
         """``tables`` = the struct returned by make_leaf_tables."""
@@ -366,6 +384,11 @@ class GraphHandle:
 def fill_uniform_device(d_leaf: int, B: int, L: int, ss: int, ls: int, seed: int, sample_offset: int = 0,
                         stream: int = 0):
     check(lib().fdg_fill_uniform_device(d_leaf, B, L, ss, ls, seed, sample_offset, stream))
+
+
+def fill_uniform_device_tiled(d_leaf: int, B: int, L: int, ss: int, ls: int, lts: int, seed: int, sample_offset: int = 0,
+                               stream: int = 0):
+    check(lib().fdg_fill_uniform_device_tiled(d_leaf, B, L, ss, ls, lts, seed, sample_offset, stream))
 
 
 def isa_check_hazards(asm_text: str):

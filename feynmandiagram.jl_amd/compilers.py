@@ -41,13 +41,21 @@ class GraphFunc:
     """Callable evaluator bound to one lowered graph set (one ``fdg_graph``)."""
 
     def __init__(self, table: NodeTable, specialize=False, cache_dir: Optional[str] = None,
-                 flags: int = 0, opt: Optional[dict] = None):
+                 flags: int = 0, opt: Optional[dict] = None, association: str = "static"):
         """``specialize``: "auto" (ISA, else HIP source), "isa" / "isa-autotune" (optimizing back end,
         gfx950 assembly), True / "hip" (straight-line HIP source through hiprtc), False (table
-        interpreter, no JIT)."""
+        interpreter, no JIT).
+        ``association``: which of the reference's two evaluators the results equal bit for bit -- "static", the function
+        ``Compilers.compile`` generates (static.jl:13-46), or "eval", the interpreter ``eval!`` the reference's examples and
+        tests call (eval.jl:1-3,15-39; example/benchmark.jl:84-86), whose products fold the already scaled operands."""
+        if association not in ("static", "eval"):
+            raise ValueError('association must be "static" or "eval"')
         self.table = table.normalized()
         self._specialize, self._cache_dir, self._flags = specialize, cache_dir, flags
+        self.association = association
         self.handle = capi.GraphHandle(self.table)
+        if association == "eval":
+            self.handle.set_association(capi.FDG_ASSOC_INTERP)
         self.n_leaf, self.n_root = self.table.n_leaf, self.table.n_root
         if specialize == "auto":
             # best available: gfx950 assembly; graphs it does not cover (Power{N}, N not in {2,3}) go
@@ -153,6 +161,63 @@ class GraphFunc:
             self.handle.eval_device(leaf.data_ptr(), leaf.stride(0), leaf.stride(1), r2.data_ptr(),
                                     r2.stride(0), r2.stride(1), B, st)
         return root
+
+    # -- tile-major batches (fdg_eval_device_tiled): the layout the evaluator streams best ------------------------------ #
+    @staticmethod
+    def tile_major_empty(n_sample: int, n_col: int, device, dtype=None):
+        """An uninitialised tile-major batch for ``n_sample`` samples of ``n_col`` values: a ``[cld(B, 64), n_col, 64]``
+        tensor (tile, value, sample-in-tile) -- memory order of a Julia ``Array{Float64,3}(undef, 64, n_col, cld(B, 64))``."""
+        import torch
+        return torch.empty(((n_sample + 63) // 64, n_col, 64), dtype=dtype or torch.float64, device=device)
+
+    def _check_tiled(self, x, n_col, what):
+        import torch
+        if not (_is_torch(x) and x.is_cuda and x.dtype == torch.float64 and x.dim() == 3 and x.shape[2] == 64 and x.shape[1] >= n_col):
+            raise ValueError(f"{what} must be a float64 CUDA tensor of shape [tiles, >= {n_col}, 64] (tile, value, sample in tile)")
+
+    def eval_tiled(self, root, leaf, n_sample: Optional[int] = None):
+        """``root[t, k, l] = root_k(sample 64 t + l)`` from ``leaf[t, i, l]``: both tile-major (see :meth:`tile_major_empty`),
+        any strides.  ``n_sample`` defaults to all ``64 * tiles`` samples; lanes past it are neither read nor written."""
+        import torch
+        self._check_tiled(leaf, self.n_leaf, "leaf")
+        T = leaf.shape[0]
+        B = 64 * T if n_sample is None else int(n_sample)
+        if not (0 <= B <= 64 * T):
+            raise ValueError("n_sample exceeds the batch")
+        if root is None:
+            root = self.tile_major_empty(64 * T, self.n_root, leaf.device)
+        self._check_tiled(root, self.n_root, "root")
+        if root.shape[0] < (B + 63) // 64 or root.device != leaf.device:
+            raise ValueError("root holds fewer tiles than the samples need, or lives on another device")
+        st = torch.cuda.current_stream(leaf.device).cuda_stream
+        with torch.cuda.device(leaf.device):
+            self.handle.eval_device_tiled(leaf.data_ptr(), leaf.stride(2), leaf.stride(1), leaf.stride(0), root.data_ptr(),
+                                          root.stride(2), root.stride(1), root.stride(0), B, st)
+        return root
+
+    def accumulate_tiled(self, leaf, weight=None, acc=None, n_sample: Optional[int] = None):
+        """``acc[k] += sum_b weight[b] * root_k(b)`` over a tile-major leaf batch (``weight``: plain vector indexed by sample)."""
+        import torch
+        self._check_tiled(leaf, self.n_leaf, "leaf")
+        B = 64 * leaf.shape[0] if n_sample is None else int(n_sample)
+        if not (0 <= B <= 64 * leaf.shape[0]):
+            raise ValueError("n_sample exceeds the batch")
+        if acc is None:
+            acc = torch.zeros(self.n_root, dtype=torch.float64, device=leaf.device)
+        if (not acc.is_cuda or acc.device != leaf.device or acc.dtype != torch.float64 or not acc.is_contiguous()
+                or acc.numel() < self.n_root):
+            raise ValueError("acc must be a contiguous float64 tensor of at least n_root elements on the leaves' device")
+        w = 0
+        if weight is not None:
+            if (not weight.is_cuda or weight.device != leaf.device or weight.dtype != torch.float64 or weight.dim() != 1
+                    or weight.shape[0] < B):
+                raise ValueError("weight must be a float64 vector of at least n_sample elements on the leaves' device")
+            weight = weight.contiguous()
+            w = weight.data_ptr()
+        st = torch.cuda.current_stream(leaf.device).cuda_stream
+        with torch.cuda.device(leaf.device):
+            self.handle.accumulate_device_tiled(leaf.data_ptr(), leaf.stride(2), leaf.stride(1), leaf.stride(0), w, acc.data_ptr(), B, st)
+        return acc
 
     def _call_numpy_typed(self, root, leaf):
         """Host arrays of an element type other than Float64: staged through the device (there is no CPU evaluator behind the ABI)."""

@@ -94,6 +94,13 @@ static void emit_node_expr(std::ostringstream &os, const Lowered &p, uint32_t n)
       else t << "g" << p.idx[e];
       terms.push_back(t.str());
     }
+  } else if (p.assoc_interp) {      // eval!'s product (eval.jl:2): the operands are scaled first, then folded
+    for (uint32_t e = a; e < b; ++e) {
+      std::ostringstream t;
+      if (p.fac[e] != 1.0) { t << "(g" << p.idx[e] << " * "; put_double(t, p.fac[e]); t << ")"; }
+      else t << "g" << p.idx[e];
+      terms.push_back(t.str());
+    }
   } else {
     for (uint32_t e = a; e < b; ++e) {
       terms.push_back("g" + std::to_string(p.idx[e]));

@@ -22,9 +22,9 @@ inline uint32_t mkloc(uint32_t space, uint32_t idx) { return (space << 30) | idx
 // ---- micro-op header word ---------------------------------------------------
 // bits 3..0  : opcode;  bits 31..4 : operand count (SUM/PROD), exponent (POW,
 //              signed, stored biased by 2^27), root index (ROOT)
-constexpr uint32_t UOP_SUM = 0, UOP_PROD = 1, UOP_POW = 2, UOP_ROOT = 3, UOP_LEAF = 4, UOP_END = 5;
+constexpr uint32_t UOP_SUM = 0, UOP_PROD = 1, UOP_POW = 2, UOP_ROOT = 3, UOP_LEAF = 4, UOP_END = 5, UOP_PRODI = 6;   // PRODI: eval!'s product, operands scaled first
 // layouts (words):
-//   SUM/PROD : hdr, dst, then per operand: loc [, fac_lo, fac_hi]
+//   SUM/PROD/PRODI : hdr, dst, then per operand: loc [, fac_lo, fac_hi]
 //   POW      : hdr(exponent), dst, loc [, fac_lo, fac_hi]
 //   ROOT     : hdr(k), loc                      -- root[k] = value at loc
 //   LEAF     : hdr(0), dst, leaf_index          -- copy a leaf into an LDS slot
@@ -40,6 +40,8 @@ struct Lowered {
   std::vector<uint32_t> root_slot;
 
   std::vector<uint32_t> sched_group;   // optional [N]: producer's grouping hint for the scheduler
+  bool assoc_interp = false;           // FDG_ASSOC_INTERP: the association of eval! (src/computational_graph/eval.jl:1-3) instead of the
+                                       // generated code's: a Prod folds the already scaled operands, (w1 f1) * (w2 f2) * ...
 
   // analysis
   std::vector<uint8_t> live;       // [L+N] reachable from a root
@@ -190,7 +192,8 @@ int ensure_device(fdg_graph *g);                 // binds the handle to the curr
 int fdg_bind_stream_ws(fdg_graph *g, void *stream);   // makes the scratch set of `stream` the current one (caller holds g->mu)
 int ensure_ws(fdg_graph *g, size_t bytes);       // grows the handle's device workspace
 int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root, int64_t rs, int64_t rk,
-                   const double *d_weight, double *d_acc, int64_t B, hipStream_t st);   // caller holds g->mu
+                   const double *d_weight, double *d_acc, int64_t B, hipStream_t st,
+                   int64_t lts = 0, int64_t rts = 0);   // caller holds g->mu; lts / rts != 0: tile strides of a tile-major batch (fdg.h)
 int launch_reduce_partials(const double *partial, uint32_t nblk, uint32_t R, double *acc, hipStream_t st);
 // Monte-Carlo step through one ISA kernel (fdg_runtime.hip); callers hold g->mu
 bool fdg_mc_isa_supported(fdg_graph *g, const fdg_leaf_tables *tab, std::string &why, bool *recommended);

@@ -14,7 +14,11 @@
 //
 // Kernel arguments (all 8 bytes): leaf, ss, ls, root, rs, rk, ws, B, nwg, weight [, leaf2, ls2, -kF^2, beta, -beta, lambda:
 //   Monte-Carlo kernels, whose input columns n_k.. (the times) are leaf2[b*ss + (i - n_k)*ls2] and whose formulas read the
-//   four physical parameters from SGPRs]
+//   four physical parameters from SGPRs], lts, rts
+//   lts / rts: element distance between the first samples of consecutive tiles of the leaf / root arrays.  A plain strided
+//   matrix has lts = T ss (T = samples per tile, 64 or 128); a TILE-MAJOR batch leaf[b / 64][i][b % 64] (a Julia
+//   Array{Float64,3}(64, L, cld(B, 64))) has ss = 1, ls = 64, lts = 64 L: the 64 samples x L leaves of a tile are one
+//   contiguous block that its wave streams front to back.
 //   (the _acc variant keeps acc_k += w * root_k in registers and writes one partial per wave and root to `root`)
 //   leaf value i of sample b: leaf[b*ss + i*ls]; root k: root[b*rs + k*rk]
 #include <algorithm>
@@ -35,6 +39,8 @@ constexpr int S_LEAF = 4, S_SS = 6, S_LS = 8, S_ROOT = 10, S_RS = 12, S_RK = 14,
 constexpr int S_TILE = 22, S_NTILES = 23, S_LT = 24, S_RT = 26, S_PANEL = 28, S_LS8 = 30, S_RK8 = 32, S_A = 34,
               S_T = 36, S_C = 38, S_X = 40;  // S_X.. : scratch (4)
 constexpr int S_WGT = 44;
+constexpr int S_RTS = 44;    // root tile stride (kernels that write roots; the accumulating ones keep the weight pointer here)
+constexpr int S_LTS = 46;    // leaf tile stride
 constexpr int S_LP = 48;     // running pointer: column of the most recently loaded leaf in this tile
 constexpr int S_DELTA = 50;  // up to N_DELTA pairs: (leaf stride in bytes) x the most frequent index steps between consecutive loads
 constexpr int N_DELTA = 6;
@@ -479,6 +485,9 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   if (accumulate) E.ins("s_load_dwordx2 " + S2(S_WGT) + ", s[0:1], 0x48");
   const uint32_t n_k = prog.mc_n_k;               // > 0: Monte-Carlo kernel; input columns >= n_k come from the second base
   const bool mc = n_k > 0 || prog.mc_n_t > 0;
+  const int tile_arg = mc ? 0x80 : 0x50;          // lts, rts follow the other arguments
+  E.ins("s_load_dwordx2 " + S2(S_LTS) + ", s[0:1], " + hex32((uint32_t)tile_arg));
+  if (!accumulate) E.ins("s_load_dwordx2 " + S2(S_RTS) + ", s[0:1], " + hex32((uint32_t)tile_arg + 8));
   if (mc) {
     E.ins("s_load_dwordx4 s[" + std::to_string(S_LEAF2) + ":" + std::to_string(S_LEAF2 + 3) + "], s[0:1], 0x50");
     E.ins("s_load_dwordx8 s[" + std::to_string(S_PARAM) + ":" + std::to_string(S_PARAM + 7) + "], s[0:1], 0x60");
@@ -645,20 +654,19 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("s_cmp_ge_u32 " + S(S_T) + ", 64");
     E.ins("s_cselect_b64 exec, -1, " + S2(S_A));
   }
+  // dst = base + 8 * tile * stride   (tile: 32 bits, stride: the 64-bit tile stride in elements)
   auto tile_base = [&](int dst, int base, int stride) {
-    E.ins("s_mul_i32 " + S(S_A) + ", " + S(S_X) + ", " + S(stride));
-    E.ins("s_mul_hi_u32 " + S(S_A + 1) + ", " + S(S_X) + ", " + S(stride));
-    E.ins("s_mul_i32 " + S(S_T) + ", " + S(S_X) + ", " + S(stride + 1));
-    E.ins("s_add_u32 " + S(S_A + 1) + ", " + S(S_A + 1) + ", " + S(S_T));
-    E.ins("s_mul_i32 " + S(S_T) + ", " + S(S_X + 1) + ", " + S(stride));
+    E.ins("s_mul_i32 " + S(S_A) + ", " + S(S_TILE) + ", " + S(stride));
+    E.ins("s_mul_hi_u32 " + S(S_A + 1) + ", " + S(S_TILE) + ", " + S(stride));
+    E.ins("s_mul_i32 " + S(S_T) + ", " + S(S_TILE) + ", " + S(stride + 1));
     E.ins("s_add_u32 " + S(S_A + 1) + ", " + S(S_A + 1) + ", " + S(S_T));
     E.ins("s_lshl_b64 " + S2(S_A) + ", " + S2(S_A) + ", 3");
     E.ins("s_add_u32 " + S(dst) + ", " + S(base) + ", " + S(S_A));
     E.ins("s_addc_u32 " + S(dst + 1) + ", " + S(base + 1) + ", " + S(S_A + 1));
   };
-  tile_base(S_LT, S_LEAF, S_SS);
-  if (mc) tile_base(S_LT2, S_LEAF2, S_SS);
-  if (!accumulate) tile_base(S_RT, S_ROOT, S_RS);
+  tile_base(S_LT, S_LEAF, S_LTS);
+  if (mc) tile_base(S_LT2, S_LEAF2, S_LTS);
+  if (!accumulate) tile_base(S_RT, S_ROOT, S_RTS);
   if (accumulate) {
     // w = weight ? weight[b0 + lane] : 1.0   (consumed at the first root, long after this load)
     E.ins("v_mov_b32_e32 v" + std::to_string(acc0 + 2 * p.R) + ", 0");
@@ -1119,10 +1127,10 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? 2 : 0), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
   const uint32_t n_agpr = RW * prog.n_acc_used;
-  if (cs) return KernelMeta{kname, lds_bytes, accum, n_agpr, 10, (mc || has_macro) ? S_END : S_POOL + 2 * 16};
+  if (cs) return KernelMeta{kname, lds_bytes, accum, n_agpr, 12, (mc || has_macro) ? S_END : S_POOL + 2 * 16};
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
   os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";
-  os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size " << (mc ? 128 : 80) << "\n\t\t.amdhsa_user_sgpr_count 2\n";
+  os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size " << (mc ? 144 : 96) << "\n\t\t.amdhsa_user_sgpr_count 2\n";
   os << "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1\n\t\t.amdhsa_system_sgpr_workgroup_id_x 1\n";
   os << "\t\t.amdhsa_system_vgpr_workitem_id 0\n";
   const int n_sgpr = (mc || has_macro) ? S_END : S_POOL + 2 * 16;   // programs without leaf formulas: the 16-entry pool ends the map
@@ -1133,7 +1141,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   os << "\t\t.amdhsa_dx10_clamp 1\n\t\t.amdhsa_ieee_mode 1\n";
   os << "\t.end_amdhsa_kernel\n";
   (void)p;
-  return KernelMeta{kname, lds_bytes, accum, n_agpr, mc ? 16 : 10, n_sgpr};
+  return KernelMeta{kname, lds_bytes, accum, n_agpr, mc ? 18 : 12, n_sgpr};
 }
 
 }  // namespace
@@ -1172,7 +1180,7 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
   const uint32_t lds_bytes = (cp.n_shared + cp.n_wave * cp.n_priv_lds) * 512u;
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
   os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";
-  os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size 80\n\t\t.amdhsa_user_sgpr_count 2\n";
+  os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size 96\n\t\t.amdhsa_user_sgpr_count 2\n";
   os << "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1\n\t\t.amdhsa_system_sgpr_workgroup_id_x 1\n";
   os << "\t\t.amdhsa_system_vgpr_workitem_id 0\n";
   os << "\t\t.amdhsa_next_free_vgpr " << (accum + n_agpr) << "\n\t\t.amdhsa_next_free_sgpr " << n_sgpr << "\n";
@@ -1181,7 +1189,7 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
   os << "\t\t.amdhsa_float_denorm_mode_32 3\n\t\t.amdhsa_float_denorm_mode_16_64 3\n";
   os << "\t\t.amdhsa_dx10_clamp 1\n\t\t.amdhsa_ieee_mode 1\n";
   os << "\t.end_amdhsa_kernel\n";
-  return KernelMeta{kname, lds_bytes, accum, n_agpr, 10, n_sgpr};
+  return KernelMeta{kname, lds_bytes, accum, n_agpr, 12, n_sgpr};
 }
 
 // What the row-major variant of `prog` would move with `bufs` staging buffers: chunk fetches (8 KB each) and gathered leaves.
@@ -1254,14 +1262,15 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   if (coop && coop->supported) { ks.push_back(emit_coop(E, p, *coop, kname + "_coop")); ks.back().wg = 64 * coop->n_wave; }
   std::ostringstream &os = E.os;
   os << "\t.text\n\t.amdgpu_metadata\n---\namdhsa.kernels:\n";
-  const char *kinds[16] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",
+  const char *kinds[18] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",
                            "global_buffer", "by_value", "by_value", "global_buffer", "global_buffer", "by_value",
-                           "by_value", "by_value", "by_value", "by_value"};
+                           "by_value", "by_value", "by_value", "by_value", "by_value", "by_value"};
   for (const KernelMeta &k : ks) {
     os << "  - .agpr_count: " << k.n_agpr << "\n    .args:\n";
     for (int i = 0; i < k.n_args; ++i) {
-      os << "      - .offset: " << i * 8 << "\n        .size: 8\n        .value_kind: " << kinds[i] << "\n";
-      if (std::strcmp(kinds[i], "global_buffer") == 0) os << "        .address_space: global\n";
+      const char *kind = (k.n_args == 12 && i >= 10) ? "by_value" : kinds[i];      // (lts, rts end every argument list)
+      os << "      - .offset: " << i * 8 << "\n        .size: 8\n        .value_kind: " << kind << "\n";
+      if (std::strcmp(kind, "global_buffer") == 0) os << "        .address_space: global\n";
     }
     os << "    .group_segment_fixed_size: " << k.lds_bytes << "\n    .kernarg_segment_align: 8\n    .kernarg_segment_size: " << 8 * k.n_args << "\n";
     os << "    .max_flat_workgroup_size: " << k.wg << "\n    .name: " << k.name << "\n    .private_segment_fixed_size: 0\n";

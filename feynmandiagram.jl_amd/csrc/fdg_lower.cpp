@@ -31,6 +31,7 @@ double powi(double x, int32_t n) { return fdg_powi_impl(x, n); }
 bool complex_to_real_table(const Lowered &p, RealTwinTable &o, std::string &why) {
   const uint32_t L = p.L;
   o = RealTwinTable();
+  if (p.assoc_interp) { why = "the real-imaginary view spells out the generated code's association only"; return false; }
   o.n_leaf = 2 * L;
   o.off.assign(1, 0);
   std::vector<std::pair<uint32_t, uint32_t>> val((size_t)L + p.N);
@@ -242,7 +243,7 @@ void build_interpreter_program(Lowered &p, uint32_t lds_budget) {
     }
     const size_t hdr_at = c.size();
     if (p.op[n] == FDG_OP_POWER) c.push_back(UOP_POW | ((uint32_t)(p.power[n] + (1 << 27)) << 4));
-    else c.push_back((p.op[n] == FDG_OP_SUM ? UOP_SUM : UOP_PROD) | ((b - a) << 4));
+    else c.push_back((p.op[n] == FDG_OP_SUM ? UOP_SUM : (p.assoc_interp ? UOP_PRODI : UOP_PROD)) | ((b - a) << 4));
     c.push_back(0);  // dst, patched below
     for (uint32_t e = a; e < b; ++e) {
       uint32_t v = p.idx[e];

@@ -461,6 +461,9 @@ void build_uops(Builder &B) {
     if (p.op[n] == FDG_OP_SUM) {
       const uint32_t t = B.mulc(cr, fc);                       // c_i * f_i   (static.jl:18)
       acc = (f.i == 0) ? t : B.op2(M_ADD, acc, t);
+    } else if (p.op[n] == FDG_OP_PROD && p.assoc_interp) {
+      const uint32_t t = B.mulc(cr, fc);                       // acc * (c_i * f_i)    (eval.jl:2: prod(w * f)); f = 1 and f = -1
+      acc = (f.i == 0) ? t : B.op2(M_MUL, acc, t);             // leave the bits of w * f as they are (x * 1.0 == x, x * -1.0 == -x)
     } else if (p.op[n] == FDG_OP_PROD) {
       acc = (f.i == 0) ? cr : B.op2(M_MUL, acc, cr);           // ((acc * c_i) * f_i)  (static.jl:28)
       acc = B.mulc(acc, fc);
@@ -1187,6 +1190,10 @@ struct CoopBuild {
     if (p.op[n] == FDG_OP_SUM) {
       const uint32_t t = Bw.mulc(cr, fc);
       return i == 0 ? t : Bw.op2(M_ADD, acc, t);
+    }
+    if (p.op[n] == FDG_OP_PROD && p.assoc_interp) {
+      const uint32_t t = Bw.mulc(cr, fc);
+      return i == 0 ? t : Bw.op2(M_MUL, acc, t);
     }
     if (p.op[n] == FDG_OP_PROD) {
       acc = i == 0 ? cr : Bw.op2(M_MUL, acc, cr);

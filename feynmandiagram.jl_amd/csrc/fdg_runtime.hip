@@ -136,6 +136,14 @@ fdg_interp(const uint32_t *code_, const double *__restrict__ leaf, long ss, long
             if (wj & LOC_FAC) { x = x * factor(pc); pc += 2; }
             acc = acc + x;
           }
+        } else if (opc == UOP_PRODI) {      // eval!'s product: prod(w_i * f_i), every operand scaled before it is folded (eval.jl:2)
+#pragma unroll 1
+          for (uint32_t j = 1; j < arg; ++j) {
+            const uint32_t wj = code[pc++];
+            double x = fetch(wj);
+            if (wj & LOC_FAC) { x = x * factor(pc); pc += 2; }
+            acc = acc * x;
+          }
         } else {
 #pragma unroll 1
           for (uint32_t j = 1; j < arg; ++j) {
@@ -261,6 +269,21 @@ fdg_fill_uniform(double *__restrict__ leaf, long B, uint32_t L, long ss, long ls
     philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), (uint32_t)i, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
     const uint64_t m = ((uint64_t)(o[0] >> 5) << 26) | (uint64_t)(o[1] >> 6);  // 53 random bits
     leaf[b * ss + i * ls] = (double)m * 0x1.0p-53;
+  }
+}
+
+// the same values into a tile-major batch: sample b = 64 t + l lives at leaf[t * lts + l * ss + i * ls]
+__global__ void __launch_bounds__(256)
+fdg_fill_uniform_tiled(double *__restrict__ leaf, long B, uint32_t L, long ss, long ls, long lts, uint64_t seed, uint64_t off) {
+  const long ntile = (B + 63) / 64, total = ntile * 64L * (long)L;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const long l = e & 63, ti = e >> 6, t = ti / L, i = ti - t * L, b = 64 * t + l;
+    if (b >= B) continue;
+    const uint64_t s = off + (uint64_t)b;
+    uint32_t o[4];
+    philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), (uint32_t)i, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    const uint64_t m = ((uint64_t)(o[0] >> 5) << 26) | (uint64_t)(o[1] >> 6);
+    leaf[t * lts + l * ss + i * ls] = (double)m * 0x1.0p-53;
   }
 }
 
@@ -414,11 +437,9 @@ static int ensure_module(fdg_graph *g) {
 }
 
 // mode 0: roots -> d_root; mode 1: partial sums -> d_acc
-int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
-                   int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st);
-
 static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
-               int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st) {
+               int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st,
+               int64_t lts = 0, int64_t rts = 0) {
   if (!g) { set_error("null handle"); return FDG_E_INVALID; }
   if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
   if (B == 0) return FDG_OK;
@@ -428,7 +449,7 @@ static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t
   if (mode == 1 && g->prog.R == 0) return FDG_OK;        // no roots: nothing to accumulate
   std::lock_guard<std::mutex> lk(g->mu);
   { const int rcb = fdg_bind_stream_ws(g, (void *)st); if (rcb) return rcb; }
-  return fdg_run_locked(g, mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st);
+  return fdg_run_locked(g, mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st, lts, rts);
 }
 
 // launch of the compiler-scheduled per-graph kernels (fdg_spec_sm / fdg_spec_gen)
@@ -457,14 +478,24 @@ static int launch_hip_source(fdg_graph *g, hipFunction_t fn, int mode, const dou
 }
 
 int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
-                   int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st) {
+                   int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st,
+                   int64_t lts, int64_t rts) {
   int rc = ensure_device(g);
   if (rc) return rc;
   const Lowered &p = g->prog;
   const long nblk = (long)((B + 255) / 256);
   const uint32_t R = p.R;
+  // Tile-major batches (fdg_eval_device_tiled): tile t holds samples 64 t .. 64 t + 63 at base + t * tile stride.  Only the
+  // kernels of the optimizing back end take a tile stride; a plain strided matrix is the case tile stride = 64 * sample stride.
+  const bool tiled = lts != 0 || rts != 0;
+  if (tiled && !(!g->code_object.empty() && g->isa)) {
+    set_error("tile-major batches need a handle specialised with FDG_SPEC_ISA"); return FDG_E_UNSUPPORTED;
+  }
+  if (tiled && (lts < 0 || rts < 0 || ss < 0 || ss >= (1ll << 23) || (mode == 0 && (rs < 0 || rs >= (1ll << 23))))) {
+    set_error("tile-major batch: negative strides or sample strides of 2^23 elements or more are not supported"); return FDG_E_UNSUPPORTED;
+  }
 
-  if (!g->code_object.empty() && g->isa && !g->alt_code.empty() && ls == 1 && ss != 1 && p.L > 1) {
+  if (!g->code_object.empty() && g->isa && !g->alt_code.empty() && ls == 1 && ss != 1 && p.L > 1 && !tiled) {
     // sample-major input and a companion: its lanes read their own rows; no transposition pass
     if (!g->alt_module) {
       hipModule_t m; hipFunction_t f1, f2;
@@ -523,12 +554,13 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     };
     bool named = false;
     // fused accumulation: acc[k] += sum_b w_b root_k(b) with per-lane accumulators inside the evaluator
-    auto launch_acc = [&](const double *lf, long lss, long lls, const double *wt, long n) -> int {
+    auto launch_acc = [&](const double *lf, long lss, long lls, const double *wt, long n, long tls = 0) -> int {
       void *a_wsp = g->d_ws;
       double *part = (double *)((char *)g->d_ws + panel_all);
       long nwg = std::min<long>((n + 63) / 64, grid3), zero = 0;
-      void *args[] = {(void *)&lf, &lss, &lls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt};
-      void *fn = g->fn_isa_acc_nt && line_aligned(lf, lss, lls) ? g->fn_isa_acc_nt : g->fn_isa_acc;
+      if (!tls) tls = 64 * lss;
+      void *args[] = {(void *)&lf, &lss, &lls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt, &tls, &zero};
+      void *fn = g->fn_isa_acc_nt && line_aligned(lf, lss, lls) && (tls & 15) == 0 ? g->fn_isa_acc_nt : g->fn_isa_acc;
       if (!named) g->last_kernel = fn == g->fn_isa_acc ? "fdg_isa_eval_acc" : "fdg_isa_eval_acc_nt";
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
       hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
@@ -537,14 +569,15 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     };
     // one batch with sample stride `lss`: full 128-sample tiles through the two-samples-per-lane kernel
     // when there is one and the samples of a leaf are contiguous, the rest through the W = 1 kernel
-    auto launch_isa = [&](const double *lf, long lss, long lls, double *rt, long rrs, long rrk, long n) -> int {
+    auto launch_isa = [&](const double *lf, long lss, long lls, double *rt, long rrs, long rrk, long n, long tls = 0, long trs = 0) -> int {
       void *a_wsp = g->d_ws;
       long done = 0;
-      if (g->has_w2 && lss == 1 && n >= 128 && !std::getenv("FDG_ISA_NO_W2")) {
+      if (g->has_w2 && lss == 1 && n >= 128 && !tls && !trs && !std::getenv("FDG_ISA_NO_W2")) {
         long n2 = n & ~127l;
         long nwg = std::min<long>(n2 / 128, grid2);
         const double *nowt = nullptr;
-        void *args[] = {(void *)&lf, &lss, &lls, (void *)&rt, &rrs, &rrk, &a_wsp, &n2, &nwg, (void *)&nowt};
+        long tls2 = 128 * lss, trs2 = 128 * rrs;
+        void *args[] = {(void *)&lf, &lss, &lls, (void *)&rt, &rrs, &rrk, &a_wsp, &n2, &nwg, (void *)&nowt, &tls2, &trs2};
         HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_w2, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
         g->last_kernel = "fdg_isa_eval_w2";
         done = n2;
@@ -555,8 +588,10 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
         long n1 = n - done;
         long nwg = std::min<long>((n1 + 63) / 64, grid);
         const double *nowt = nullptr;
-        void *args[] = {(void *)&lf1, &lss, &lls, (void *)&rt1, &rrs, &rrk, &a_wsp, &n1, &nwg, (void *)&nowt};
-        void *fn = g->fn_isa_nt && line_aligned(lf1, lss, lls) && line_aligned(rt1, rrs, rrk) ? g->fn_isa_nt : g->fn_isa;
+        if (!tls) tls = 64 * lss;
+        if (!trs) trs = 64 * rrs;
+        void *args[] = {(void *)&lf1, &lss, &lls, (void *)&rt1, &rrs, &rrk, &a_wsp, &n1, &nwg, (void *)&nowt, &tls, &trs};
+        void *fn = g->fn_isa_nt && line_aligned(lf1, lss, lls) && line_aligned(rt1, rrs, rrk) && ((tls | trs) & 15) == 0 ? g->fn_isa_nt : g->fn_isa;
         if (!named && done == 0) g->last_kernel = fn == g->fn_isa ? "fdg_isa_eval" : "fdg_isa_eval_nt";
         HIP_TRY(hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
       }
@@ -584,7 +619,8 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       if (rc) return rc;
       void *a_wsp = g->d_ws;
       const double *nowt = nullptr;
-      void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &n, &nwg, (void *)&nowt};
+      long tls = lts ? (long)lts : 64 * lss, trs = rts ? (long)rts : 64 * rrs;
+      void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &n, &nwg, (void *)&nowt, &tls, &trs};
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_coop, (unsigned)nwg, 1, 1, g->coop_threads, 1, 1, 0, st, args, nullptr));
       g->last_kernel = "fdg_isa_eval_coop";
       return FDG_OK;
@@ -592,22 +628,22 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // Row-major leaves ([B, L], leaf stride 1): full 64-row tiles go through the variant that stages chunks of rows in LDS
     // itself -- the matrix is read once, in place -- for evaluation and for fused accumulation alike; the last B % 64 rows
     // go through the plain kernel with the caller's strides (its lanes gather their own rows: fine for under a tile).
-    const bool rm_shape = ls == 1 && ss >= (int64_t)p.L && !wide_ss && p.L >= 16 && B >= 64 && !std::getenv("FDG_ISA_NO_RM");
+    const bool rm_shape = ls == 1 && ss >= (int64_t)p.L && !wide_ss && p.L >= 16 && B >= 64 && !tiled && !std::getenv("FDG_ISA_NO_RM");
     if (rm_shape && ((mode == 0 && g->has_rm && g->fn_isa_rm && !(rs < 0 || rs >= (1ll << 23))) || (fused_acc && g->has_rm_acc && g->fn_isa_rm_acc))) {
       const long n4 = (long)(B & ~(int64_t)63), lss = ss, lls = ls, tail = (long)B - n4;
       void *a_wsp = g->d_ws;
       if (mode == 0) {
-        long nwg = std::min<long>(n4 / 64, grid4), rrs = rs, rrk = rk, nn = n4;
+        long nwg = std::min<long>(n4 / 64, grid4), rrs = rs, rrk = rk, nn = n4, tls = 64 * lss, trs = 64 * rrs;
         const double *nowt = nullptr;
-        void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt};
+        void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt, &tls, &trs};
         HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rm, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
         g->last_kernel = "fdg_isa_eval_rm";
         named = true;                    // (the last B % 64 rows below do not rename the call)
         if (tail) { rc = launch_isa(d_leaf + (size_t)n4 * (size_t)ss, lss, lls, d_root + (size_t)n4 * (size_t)rs, rrs, rrk, tail); if (rc) return rc; }
       } else {
         double *part = (double *)((char *)g->d_ws + panel_all);
-        long nwg = std::min<long>(n4 / 64, grid5), zero = 0, nn = n4;
-        void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&part, &zero, &zero, &a_wsp, &nn, &nwg, (void *)&d_weight};
+        long nwg = std::min<long>(n4 / 64, grid5), zero = 0, nn = n4, tls = 64 * lss;
+        void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&part, &zero, &zero, &a_wsp, &nn, &nwg, (void *)&d_weight, &tls, &zero};
         HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rm_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
         hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
         HIP_TRY(hipGetLastError());
@@ -618,7 +654,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       return FDG_OK;
     }
     if (mode == 0 && (rs < 0 || rs >= (1ll << 23))) { set_error("root sample stride negative or of 2^23 elements or more is not supported by the ISA kernel"); return FDG_E_UNSUPPORTED; }
-    if ((ls == 1 && ss != 1 && p.L > 1) || (wide_ss && p.L > 0)) {
+    if (!tiled && ((ls == 1 && ss != 1 && p.L > 1) || (wide_ss && p.L > 0))) {
       // sample-major input (compile_Python's [B, L]): the ISA kernel wants a wave's 64 samples of
       // one leaf contiguous, so chunks of the batch are transposed to leaf-major first
       // (2 extra HBM passes over the leaves; in-kernel LDS staging would avoid them -- DESIGN.md 8)
@@ -671,8 +707,9 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
         HIP_TRY(hipEventRecord((hipEvent_t)g->ev_k[buf], st));
       }
     } else {
-      rc = fused_acc ? launch_acc(d_leaf, (long)ss, (long)ls, d_weight, (long)B)
-                     : launch_isa(d_leaf, (long)ss, (long)ls, roots, a_rs, a_rk, (long)B);
+      // (accumulation through the root scratch writes it column-major: an ordinary strided array, whatever the leaves are)
+      rc = fused_acc ? launch_acc(d_leaf, (long)ss, (long)ls, d_weight, (long)B, (long)lts)
+                     : launch_isa(d_leaf, (long)ss, (long)ls, roots, a_rs, a_rk, (long)B, (long)lts, mode == 0 ? (long)rts : 0);
       if (rc) return rc;
     }
     if (mode == 1 && !fused_acc) {
@@ -893,6 +930,15 @@ int compile_hipcc(const std::string &src_path, const std::string &out_path, bool
   return 0;
 }
 
+// LDS budget of the interpreter: enough slots for the whole live set when it
+// is small (8 blocks/CU), otherwise 40 slots = 80 KiB per block (2 blocks/CU)
+static uint32_t interp_lds_budget() {
+  uint32_t budget = 40;
+  const char *env = std::getenv("FDG_LDS_SLOTS");
+  if (env) budget = (uint32_t)std::max(1, std::atoi(env));
+  return std::min(budget, 79u);
+}
+
 extern "C" {
 
 const char *fdg_last_error(void) { return fdg::last_error_cstr(); }
@@ -917,14 +963,25 @@ int fdg_graph_create(const fdg_graph_desc *d, fdg_graph **out) {
   p.fac.assign(d->child_fac, d->child_fac + p.E);
   p.root_slot.assign(d->root_slot, d->root_slot + p.R);
   analyse(p);
-  // LDS budget of the interpreter: enough slots for the whole live set when it
-  // is small (8 blocks/CU), otherwise 40 slots = 80 KiB per block (2 blocks/CU)
-  uint32_t budget = 40;
-  const char *env = std::getenv("FDG_LDS_SLOTS");
-  if (env) budget = (uint32_t)std::max(1, std::atoi(env));
-  budget = std::min(budget, 79u);
-  build_interpreter_program(p, budget);
+  build_interpreter_program(p, interp_lds_budget());
   *out = g;
+  return FDG_OK;
+}
+
+// Which of the reference's two evaluators the handle reproduces bit for bit (include/fdg.h).  Before any specialisation.
+int fdg_graph_set_association(fdg_graph *g, int assoc) {
+  if (!g) { set_error("null handle"); return FDG_E_INVALID; }
+  if (assoc != FDG_ASSOC_STATIC && assoc != FDG_ASSOC_INTERP) { set_error("unknown association"); return FDG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  const bool want = assoc == FDG_ASSOC_INTERP;
+  if (g->prog.assoc_interp == want) return FDG_OK;
+  if (!g->code_object.empty() || !g->alt_code.empty() || !g->fused_code.empty() || !g->mc_code.empty() || g->cx_twin || g->mc_route ||
+      !g->typed_code[1].empty() || !g->typed_code[2].empty() || !g->typed_code[3].empty()) {
+    set_error("fdg_graph_set_association must be called before the handle is specialised"); return FDG_E_INVALID;
+  }
+  g->prog.assoc_interp = want;
+  build_interpreter_program(g->prog, interp_lds_budget());
+  if (g->d_code) { hipDeviceSynchronize(); hipFree(g->d_code); g->d_code = nullptr; }      // (the stream is uploaded again on the next use)
   return FDG_OK;
 }
 
@@ -1262,6 +1319,7 @@ static std::string tuned_path(const fdg_graph *g, const std::string &dir) {
   if (p.E) { mix(p.idx.data(), p.idx.size() * 4); mix(p.fac.data(), p.fac.size() * 8); }
   if (p.R) mix(p.root_slot.data(), p.root_slot.size() * 4);
   if (!p.sched_group.empty()) mix(p.sched_group.data(), p.sched_group.size() * 4);
+  if (p.assoc_interp) mix("eval!", 5);
   char hb[40];
   std::snprintf(hb, sizeof hb, "%016llx", (unsigned long long)th);
   return dir + "/fdg_tuned_" + hb + ".txt";
@@ -1297,7 +1355,9 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
   const uint32_t extra = g->prog.R + 2;
   // (up to 40 roots: the 26 rows of example/benchmark_GV.jl's vertex function keep their sums in registers; beyond that the
   //  accumulators would take more than a third of the value registers and the roots go through the column-major scratch)
-  if (g->prog.R == 0 || g->prog.R > 40 || chosen.n_reg < extra + 64 || std::getenv("FDG_ISA_NO_FUSED_ACC")) return false;
+  // (few roots: eight value registers next to the accumulators are enough -- the tiny-graph configuration of the 2-loop
+  //  self-energies keeps 28; many roots must leave the values a working set worth having)
+  if (g->prog.R == 0 || g->prog.R > 40 || chosen.n_reg < extra + 8 || (g->prog.R > 16 && chosen.n_reg < extra + 64) || std::getenv("FDG_ISA_NO_FUSED_ACC")) return false;
   fdg::OptParams q = chosen;
   // stay inside the occupancy step of the eval kernel (VGPRs per wave: 64 -> 8 waves/SIMD ... 256 -> 2, 512 -> 1)
   static const uint32_t steps[] = {64, 72, 80, 96, 128, 168, 256, 512};
@@ -1724,7 +1784,7 @@ int fdg_mc_isa_build(fdg_graph *g) {
   }
   if (!pe.supported) { set_error("the fused ISA step does not cover this graph / these leaves: " + pe.why); return FDG_E_UNSUPPORTED; }
   const uint32_t R = g->prog.R;
-  bool has_acc = R >= 1 && R <= 40 && q.n_reg >= R + 2 + 64;
+  bool has_acc = R >= 1 && R <= 40 && q.n_reg >= R + 2 + 8 && (R <= 16 || q.n_reg >= R + 2 + 64);
   if (has_acc) {
     fdg::OptParams qa = q;
     qa.reserve_pairs = R + 2;        // (build_mc_program takes the macro ops' temporaries off the value budget itself)
@@ -1831,20 +1891,20 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
       x = X; x2 = X + (size_t)n_k * Bc; xls = xls2 = (long)Bc; xss = 1;
     }
     void *a_wsp = g->d_ws;
-    long nwg = std::min<long>((n + 63) / 64, grid), zero = 0;
+    long nwg = std::min<long>((n + 63) / 64, grid), zero = 0, tls = 64 * xss;
     double p_nkf2 = -(kF * kF), p_beta = beta, p_nbeta = -beta, p_lambda = lambda;     // MOp::param 1..4
     if (use_acc) {
       double *part = (double *)((char *)g->d_ws + panel);
       const double *wt = d_weight ? d_weight + c0 : nullptr;
-      void *args[] = {(void *)&x, &xss, &xls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt, (void *)&x2, &xls2, &p_nkf2, &p_beta, &p_nbeta, &p_lambda};
+      void *args[] = {(void *)&x, &xss, &xls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt, (void *)&x2, &xls2, &p_nkf2, &p_beta, &p_nbeta, &p_lambda, &tls, &zero};
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_mc_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
       hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
       HIP_TRY(hipGetLastError());
     } else {
       double *rt = d_root + c0 * rs;
-      long a_rs = (long)rs, a_rk = (long)rk;
+      long a_rs = (long)rs, a_rk = (long)rk, trs = 64 * a_rs;
       const double *nowt = nullptr;
-      void *args[] = {(void *)&x, &xss, &xls, (void *)&rt, &a_rs, &a_rk, &a_wsp, &n, &nwg, (void *)&nowt, (void *)&x2, &xls2, &p_nkf2, &p_beta, &p_nbeta, &p_lambda};
+      void *args[] = {(void *)&x, &xss, &xls, (void *)&rt, &a_rs, &a_rk, &a_wsp, &n, &nwg, (void *)&nowt, (void *)&x2, &xls2, &p_nkf2, &p_beta, &p_nbeta, &p_lambda, &tls, &trs};
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_mc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
     }
   }
@@ -2021,6 +2081,21 @@ int fdg_accumulate_device(fdg_graph *g, const double *d_leaf, int64_t ss, int64_
   return run(g, 1, d_leaf, ss, ls, nullptr, 0, 0, d_weight, d_acc, B, (hipStream_t)stream);
 }
 
+// Tile-major batches (include/fdg.h): a tile stride of 0 stands for 64 sample strides, i.e. the plain strided matrix.
+int fdg_eval_device_tiled(fdg_graph *g, const double *d_leaf, int64_t ss, int64_t ls, int64_t lts, double *d_root, int64_t rs,
+                          int64_t rk, int64_t rts, int64_t B, void *stream) {
+  if (lts < 0 || rts < 0) { set_error("negative tile stride"); return FDG_E_INVALID; }
+  if ((lts == 0 || lts == 64 * ss) && (rts == 0 || rts == 64 * rs)) return run(g, 0, d_leaf, ss, ls, d_root, rs, rk, nullptr, nullptr, B, (hipStream_t)stream);
+  return run(g, 0, d_leaf, ss, ls, d_root, rs, rk, nullptr, nullptr, B, (hipStream_t)stream, lts ? lts : 64 * ss, rts ? rts : 64 * rs);
+}
+
+int fdg_accumulate_device_tiled(fdg_graph *g, const double *d_leaf, int64_t ss, int64_t ls, int64_t lts, const double *d_weight,
+                                double *d_acc, int64_t B, void *stream) {
+  if (lts < 0) { set_error("negative tile stride"); return FDG_E_INVALID; }
+  if (lts == 0 || lts == 64 * ss) return run(g, 1, d_leaf, ss, ls, nullptr, 0, 0, d_weight, d_acc, B, (hipStream_t)stream);
+  return run(g, 1, d_leaf, ss, ls, nullptr, 0, 0, d_weight, d_acc, B, (hipStream_t)stream, lts, 0);
+}
+
 // host <-> device copy of an [n x m] block of a strided host matrix (element (b, i) at h[b*hs + i*hi]) to / from the
 // device block d[b*ds + i*di]; one of (hs, hi) and the matching one of (ds, di) is 1
 static hipError_t copy_block(double *d, int64_t ds, int64_t di, const double *h, int64_t hs, int64_t hi, int64_t n, int64_t m, bool to_device) {
@@ -2141,6 +2216,20 @@ int fdg_fill_uniform_device(double *d_leaf, int64_t B, uint32_t L, int64_t ss, i
   const long grid = std::min<long>((total + 255) / 256, 256L * 16);
   hipLaunchKernelGGL(fdg_fill_uniform, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_leaf, (long)B, L,
                      (long)ss, (long)ls, seed, off, (ls <= ss) ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  return FDG_OK;
+}
+
+int fdg_fill_uniform_device_tiled(double *d_leaf, int64_t B, uint32_t L, int64_t ss, int64_t ls, int64_t lts, uint64_t seed,
+                                  uint64_t off, void *stream) {
+  if (B < 0 || lts < 0) { set_error("n_sample < 0 or negative tile stride"); return FDG_E_INVALID; }
+  if (lts == 0 || lts == 64 * ss) return fdg_fill_uniform_device(d_leaf, B, L, ss, ls, seed, off, stream);
+  if (B == 0 || L == 0) return FDG_OK;
+  if (!d_leaf) { set_error("null device buffer"); return FDG_E_INVALID; }
+  const long total = (long)((B + 63) / 64) * 64L * L;
+  const long grid = std::min<long>((total + 255) / 256, 256L * 16);
+  hipLaunchKernelGGL(fdg_fill_uniform_tiled, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_leaf, (long)B, L,
+                     (long)ss, (long)ls, (long)lts, seed, off);
   HIP_TRY(hipGetLastError());
   return FDG_OK;
 }

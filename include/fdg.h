@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define FDG_VERSION 100 /* 0.1.0 */
+#define FDG_VERSION 101 /* 0.1.1: tile-major batches, interpreter association */
 
 #define FDG_OP_SUM 0u
 #define FDG_OP_PROD 1u
@@ -136,6 +136,19 @@ int fdg_version(void);
 int fdg_graph_create(const fdg_graph_desc *desc, fdg_graph **out);
 int fdg_graph_destroy(fdg_graph *g);
 int fdg_graph_query(const fdg_graph *g, fdg_graph_info *info);
+
+/* The reference has TWO evaluators of a graph, and they round differently:
+ *   FDG_ASSOC_STATIC (default): the generated eval_graph! of Compilers.compile (src/backend/static.jl:13-46), the contract above;
+ *   FDG_ASSOC_INTERP: the interpreter eval! (src/computational_graph/eval.jl:1-3,15-39), which the reference's examples and tests
+ *     call (example/benchmark.jl:84-86):  Sum = sum(w_i * f_i), Prod = prod(w_i * f_i) = (((w1*f1) * (w2*f2)) * (w3*f3)) ...,
+ *     Power{N} = w^N * f -- every operand is scaled by its factor BEFORE it enters the left fold (sum / prod over a generator
+ *     are left folds).  Multiplying by a factor 1.0 leaves the bits alone, so the two differ exactly where a Prod has a factor
+ *     other than +-1 on its second or a later operand: ((acc * w) * f) against (acc * (w * f)).
+ * A handle evaluates with ONE of them, on every back end (interpreter, HIP source, ISA, cooperative, Monte-Carlo step); choose
+ * before the first fdg_graph_specialize* call (FDG_E_INVALID afterwards).  Host-only. */
+#define FDG_ASSOC_STATIC 0
+#define FDG_ASSOC_INTERP 1
+int fdg_graph_set_association(fdg_graph *g, int assoc);
 
 /* What the specialised kernels of a handle execute per evaluation and which of them the last device call launched --
  * the figures a roofline needs (bench.py: executed fold steps against the fp64 issue peak, bytes against HBM) without
@@ -281,6 +294,31 @@ int fdg_eval_strided(fdg_graph *g, const double *leaf, int64_t leaf_sample_strid
 int fdg_accumulate_device(fdg_graph *g, const double *d_leaf, int64_t leaf_sample_stride,
                           int64_t leaf_leaf_stride, const double *d_weight, double *d_acc,
                           int64_t n_sample, void *stream);
+
+/* ---- tile-major batches ------------------------------------------------------------------------------------------------
+ * The layout the evaluator streams best, and the one a Monte-Carlo driver that owns its sample batch should allocate: samples
+ * are grouped in tiles of FDG_TILE_SAMPLES = 64 (one wave), and a tile's block of the array is contiguous,
+ *   leaf value i of sample b : d_leaf[(b / 64) * leaf_tile_stride + (b % 64) * leaf_sample_stride + i * leaf_leaf_stride]
+ *   root value k of sample b : d_root[(b / 64) * root_tile_stride + (b % 64) * root_sample_stride + k * root_root_stride]
+ * -- a Julia Array{Float64,3}(undef, 64, L, cld(B, 64)) is (sample, leaf, tile) strides (1, 64, 64 L); its roots
+ * Array{Float64,3}(undef, 64, R, cld(B, 64)) are (1, 64, 64 R).  A wave then reads ONE contiguous block of 512 L bytes front to
+ * back instead of 64 samples of each of L columns that lie B * 8 bytes apart: L concurrent address streams per wave become one,
+ * and every page of the batch is touched by one wave, once (the leaf-major matrix of the headline runs 0.66-0.77
+ * of the HBM roofline depending on where its pages landed; the tile-major batch does not show the two modes).  The buffers hold
+ * cld(n_sample, 64) whole tiles; lanes of a last partial tile are neither read nor written.  A tile stride of 0 stands for
+ * 64 * sample stride: the call is then exactly fdg_eval_device / fdg_accumulate_device on a strided matrix.  Same values,
+ * bit for bit, as every other layout.  Needs a handle specialised with FDG_SPEC_ISA (FDG_E_UNSUPPORTED otherwise).
+ * Stands in for: eval_graph!(root, leafVal) once per sample (static.jl:100,131), as fdg_eval_device does. */
+#define FDG_TILE_SAMPLES 64
+int fdg_eval_device_tiled(fdg_graph *g, const double *d_leaf, int64_t leaf_sample_stride, int64_t leaf_leaf_stride,
+                          int64_t leaf_tile_stride, double *d_root, int64_t root_sample_stride, int64_t root_root_stride,
+                          int64_t root_tile_stride, int64_t n_sample, void *stream);
+int fdg_accumulate_device_tiled(fdg_graph *g, const double *d_leaf, int64_t leaf_sample_stride, int64_t leaf_leaf_stride,
+                                int64_t leaf_tile_stride, const double *d_weight, double *d_acc, int64_t n_sample, void *stream);
+/* harness: fdg_fill_uniform_device's values (same counters: sample_offset + b, i) written into a tile-major batch */
+int fdg_fill_uniform_device_tiled(double *d_leaf, int64_t n_sample, uint32_t n_leaf, int64_t leaf_sample_stride,
+                                  int64_t leaf_leaf_stride, int64_t leaf_tile_stride, uint64_t seed, uint64_t sample_offset,
+                                  void *stream);
 
 /* d_leaf[b*ss + i*ls] = U[0,1) from Philox4x32-10, key = seed, counter =
  * (sample_offset + b, i): independent of launch geometry and of how samples

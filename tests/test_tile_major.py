@@ -1,0 +1,121 @@
+"""Tile-major batches (include/fdg.h: fdg_eval_device_tiled, fdg_accumulate_device_tiled, fdg_fill_uniform_device_tiled):
+sample b = 64 t + l of leaf i at leaf[t * tile_stride + l * sample_stride + i * leaf_stride] -- a Julia
+Array{Float64,3}(64, L, cld(B, 64)).  Same bits as every other layout; ragged batches; padded strides; the error behaviour."""
+import numpy as np
+import pytest
+
+import oracle
+import feynmandiagram_jl_amd as fd
+from feynmandiagram_jl_amd import capi, workloads
+
+
+def to_tiles(x, pad_cols=0, pad_tile=0):
+    """host [B, C] -> [T, C + pad_cols, 64] (+ pad_tile unused doubles per tile through a wider allocation); lanes past B hold NaN"""
+    B, C = x.shape
+    T = (B + 63) // 64
+    out = np.full((T, C + pad_cols, 64), np.nan)
+    full = np.full((T * 64, C), np.nan)
+    full[:B] = x
+    out[:, :C, :] = full.reshape(T, 64, C).transpose(0, 2, 1)
+    return out
+
+
+def from_tiles(r, B, C):
+    T = r.shape[0]
+    return r[:, :C, :].transpose(0, 2, 1).reshape(T * 64, C)[:B]
+
+
+def test_host_mirror_checks_shapes(libfdg):
+    t = workloads.get("sigma2")
+    f = fd.compile_table(t, specialize="isa")
+    with pytest.raises(ValueError):
+        f.eval_tiled(None, np.zeros((2, t.n_leaf, 64)))         # a host array: tile-major batches live on the device
+
+
+@pytest.mark.gpu
+def test_fill_uniform_tiled_is_the_same_philox_stream(libfdg, cuda):
+    import torch
+    B, L = 1000, 7
+    x = torch.full(((B + 63) // 64, L, 64), -1.0, dtype=torch.float64, device=cuda)
+    capi.fill_uniform_device_tiled(x.data_ptr(), B, L, 1, 64, 64 * L, 1234, 5, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    h = x.cpu().numpy()
+    assert np.array_equal(from_tiles(h, B, L), oracle.philox_uniform(B, L, 1234, 5))
+    assert (h.transpose(0, 2, 1).reshape(-1, L)[B:] == -1.0).all()          # lanes past the batch are not written
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sigma2", "parquet_sigma4", "gv_sigma5", "gv_sigma4_taylor2", "parquet_sigma4_insdyn"])
+@pytest.mark.parametrize("B", [1, 63, 64, 4099, 70001])
+def test_tile_major_evaluation_is_bit_exact(libfdg, cuda, name, B):
+    import torch
+    t = workloads.get(name)
+    L, R = t.n_leaf, t.n_root
+    f = fd.compile_table(t, specialize="isa")
+    h_leaf = oracle.philox_uniform(B, L, 77)
+    want = oracle.eval_static(t, h_leaf)
+    for pad_l, pad_r in ((0, 0), (3, 2)):
+        leaf = torch.from_numpy(to_tiles(h_leaf, pad_l)).to(cuda)
+        root = torch.full(((B + 63) // 64, R + pad_r, 64), 9.0, dtype=torch.float64, device=cuda)
+        f.eval_tiled(root, leaf, B)
+        torch.cuda.synchronize()
+        r = root.cpu().numpy()
+        assert np.array_equal(from_tiles(r, B, R), want), (name, B, pad_l, f.kernel_info()["last_kernel"])
+        tail = r.transpose(0, 2, 1).reshape(-1, R + pad_r)
+        assert (tail[B:] == 9.0).all() and (tail[:, R:] == 9.0).all()      # nothing outside the batch is written
+    # the unpadded, line-aligned batch takes the streaming form of the kernel
+    assert f.kernel_info()["last_kernel"] in ("fdg_isa_eval", "fdg_isa_eval_nt")
+    # fused accumulation over the same batch
+    w = oracle.philox_uniform(B, 1, 5)[:, 0]
+    acc = f.accumulate_tiled(torch.from_numpy(to_tiles(h_leaf)).to(cuda), torch.from_numpy(w).to(cuda), None, B).cpu().numpy()
+    ref = (want * w[:, None]).sum(axis=0)
+    scale = (np.abs(want) * w[:, None]).sum(axis=0) + 1e-300
+    assert np.all(np.abs(acc - ref) <= 1e-12 * scale), (name, B)
+
+
+@pytest.mark.gpu
+def test_tile_stride_zero_is_the_plain_matrix_and_other_back_ends_refuse(libfdg, cuda):
+    import torch
+    t = workloads.get("parquet_sigma4")
+    L, R, B = t.n_leaf, t.n_root, 777
+    h_leaf = oracle.philox_uniform(B, L, 9)
+    want = oracle.eval_static(t, h_leaf)
+    leaf = torch.from_numpy(np.ascontiguousarray(h_leaf.T)).to(cuda)          # leaf-major [L, B]
+    root = torch.zeros((R, B), dtype=torch.float64, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    f = fd.compile_table(t, specialize="isa")
+    f.handle.eval_device_tiled(leaf.data_ptr(), 1, B, 0, root.data_ptr(), 1, B, 0, B, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(root.cpu().numpy().T, want)
+    tl = torch.from_numpy(to_tiles(h_leaf)).to(cuda)
+    tr = torch.zeros(((B + 63) // 64, R, 64), dtype=torch.float64, device=cuda)
+    for spec in (True, False):
+        g = fd.compile_table(t, specialize=spec)
+        with pytest.raises(capi.FdgError) as e:
+            g.eval_tiled(tr, tl, B)
+        assert e.value.code == capi.FDG_E_UNSUPPORTED
+    with pytest.raises(capi.FdgError) as e:
+        f.handle.eval_device_tiled(tl.data_ptr(), 1, 64, -64, tr.data_ptr(), 1, 64, 64 * R, B, st)
+    assert e.value.code == capi.FDG_E_INVALID
+
+
+@pytest.mark.gpu
+def test_tile_major_batch_of_config_2_size(libfdg, cuda):
+    """BASELINE config 2's 10^7 samples of the 2-loop self-energy, tile-major, against the leaf-major evaluation of the same
+    Philox stream (the oracle checks a prefix)."""
+    import torch
+    t = workloads.get("sigma2")
+    L, R, B = t.n_leaf, t.n_root, 10_000_000 + 37
+    st = torch.cuda.current_stream().cuda_stream
+    f = fd.compile_table(t, specialize="isa")
+    leaf_t = f.tile_major_empty(B, L, cuda)
+    capi.fill_uniform_device_tiled(leaf_t.data_ptr(), B, L, 1, 64, 64 * L, 1234, 0, st)
+    root_t = f.eval_tiled(None, leaf_t, B)
+    leaf_c = torch.empty((L, B), dtype=torch.float64, device=cuda)
+    capi.fill_uniform_device(leaf_c.data_ptr(), B, L, 1, B, 1234, 0, st)
+    root_c = f(None, leaf_c.t())
+    torch.cuda.synchronize()
+    flat = root_t.permute(0, 2, 1).reshape(-1, R)[:B]
+    assert torch.equal(flat.view(torch.int64), root_c.view(torch.int64))
+    n = 5000
+    assert np.array_equal(flat[:n].cpu().numpy(), oracle.eval_static(t, oracle.philox_uniform(n, L, 1234)))
