@@ -110,6 +110,12 @@ class DryFunc:
         acc += float(self.count)
         return acc
 
+    def eval_tiled(self, root, leaf, n=None):
+        return root
+
+    def accumulate_tiled(self, leaf, w, acc, n=None):
+        return self.accumulate(leaf, w, acc)
+
     def kernel_info(self):
         return {"last_kernel": "dry-run", "n_valu": [0, 0, 0]}
 
@@ -157,80 +163,51 @@ class Case:
         if DRY:
             self.f, self.stream = DryFunc(B), None
             self.leaf = torch.zeros((1, L), dtype=torch.float64)
-            self.root = torch.zeros((min(B, 64), R), dtype=torch.float64)
+            self.root = torch.zeros((1, R, 64) if layout == "tile_major" else (min(B, 64), R), dtype=torch.float64)
             return
         self.f = fd.compile_table(t, specialize={"isa": "isa", "isa-autotune": "isa-autotune", "auto": "auto", "hip": True, "interp": False}[backend], flags=flags)
         self.stream = torch.cuda.current_stream()
         self.allocate()
 
     def allocate(self):
-        """(Re-)allocates the leaf and root matrices and fills the leaves (same Philox stream: same values wherever they land)."""
+        """Allocates the leaf and root batches ONCE, as they come from the allocator, and fills the leaves (Philox keyed by the global
+        sample index: the same values in every layout)."""
         import torch
         from feynmandiagram_jl_amd import capi
         B, L, R, dev = self.B, self.t.n_leaf, self.t.n_root, self.dev
+        st = self.stream.cuda_stream
+        if self.layout == "tile_major":       # fdg_eval_device_tiled: [tile, value, sample in tile] -- a Julia Array{Float64,3}(64, L, cld(B, 64))
+            T = (B + 63) // 64
+            self.leaf = torch.empty((T, L, 64), dtype=torch.float64, device=dev)
+            self.root = torch.zeros((T, R, 64), dtype=torch.float64, device=dev)      # (zeroed: lanes past B are never written)
+            capi.fill_uniform_device_tiled(self.leaf.data_ptr(), B, L, 1, 64, 64 * L, 1234, self.sample_offset, st)
+            return
         if self.layout == "sample_major":     # compile_Python's row-major [B, L] / [B, R]
             self.leaf = torch.empty((B, L), dtype=torch.float64, device=dev)
             self.root = torch.empty((B, R), dtype=torch.float64, device=dev)
         else:                                 # Julia column-major B x L / B x R matrices
             self.leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
             self.root = torch.empty((R, B), dtype=torch.float64, device=dev).t()
-        capi.fill_uniform_device(self.leaf.data_ptr(), B, L, self.leaf.stride(0), self.leaf.stride(1), 1234, self.sample_offset, self.stream.cuda_stream)
+        capi.fill_uniform_device(self.leaf.data_ptr(), B, L, self.leaf.stride(0), self.leaf.stride(1), 1234, self.sample_offset, st)
 
-    def choose_placement(self, trials, accept=0.745):
-        """Where the pages of a 70 GB matrix land decides between two rates of one and the same launch (11.4 or
-        12.9 ms, nothing in between, whatever the virtual address).  A production run allocates its sample batch once, so it can
-        afford to look: up to `trials` allocations (the best one so far stays allocated while the next is tried, with a block of
-        another size in front), each timed with a few launches, stop at the first that reaches `accept` of 8 TB/s.  Everything
-        happens before the warm-up; the contract's timed steps then run once, on the chosen allocation.  Returns the HBM
-        fractions of the trials in order (the first entry is what a single allocation would have given)."""
-        import torch
-        bytes_launch = self.st["bytes_alg"] * self.B
-        need = 8 * self.B * (self.t.n_leaf + self.t.n_root)
-        pads_mb = [0, 130, 2051, 3, 9000, 517, 64, 4100, 1, 33, 1027, 260]
-        fracs, best, losers = [], None, []
-        for i in range(max(1, trials)):
-            pad = None
-            if i:
-                # a rejected batch stays allocated during the next trial when there is room for three (the new one then lands somewhere
-                # else); what is dropped goes back to the driver, not into torch's cache, or the next trial would get the same pages again
-                while losers and (len(losers) > 1 or torch.cuda.mem_get_info(self.dev)[0] < 1.15 * need):
-                    losers.pop(0)
-                    torch.cuda.empty_cache()
-                try:
-                    pad = torch.empty(pads_mb[i % len(pads_mb)] << 20, dtype=torch.uint8, device=self.dev)
-                    self.allocate()
-                except RuntimeError:             # out of memory: keep what there is
-                    pad = None
-                    self.leaf, self.root = best[1], best[2]
-                    break
-            for _ in range(8):
-                self.step()
-            sync()
-            ev = Stamps(6, self.stream)
-            ev.record(0)
-            for k in range(6):
-                self.step()
-                ev.record(k + 1)
-            sync()
-            frac = bytes_launch / (min(ev.ms()) * 1e-3) / 1e9 / HBM_PEAK_GBS
-            fracs.append(frac)
-            if best is None or frac > best[0]:
-                if best is not None:
-                    losers.append((best[1], best[2]))
-                best = (frac, self.leaf, self.root)
-            else:
-                losers.append((self.leaf, self.root))
-                self.leaf, self.root = best[1], best[2]
-            del pad
-            if frac >= accept:
-                break
-        best = None
-        losers.clear()
-        torch.cuda.empty_cache()
-        return fracs
+    def head(self, x, n):
+        """The first n samples of a batch (leaf or root) as a host [n, C] array, whatever the layout."""
+        import numpy as np
+        if self.layout == "tile_major":
+            T = (n + 63) // 64
+            return np.ascontiguousarray(x[:T].permute(0, 2, 1).reshape(T * 64, x.shape[1])[:n].cpu().numpy())
+        return np.ascontiguousarray(x[:n].cpu().numpy())
 
     def step(self):
-        self.f(self.root, self.leaf)
+        if self.layout == "tile_major":
+            self.f.eval_tiled(self.root, self.leaf, self.B)
+        else:
+            self.f(self.root, self.leaf)
+
+    def accumulate(self, w, acc):
+        if self.layout == "tile_major":
+            return self.f.accumulate_tiled(self.leaf, w, acc, self.B)
+        return self.f.accumulate(self.leaf, w, acc)
 
     def timed(self, steps, warm, step=None):
         """`warm` untimed launches, then `steps` launches bracketed by HIP events on the launch stream.  Returns ms per launch (list).
@@ -262,14 +239,16 @@ class Case:
         import numpy as np
         import oracle
         n = int(min(n, self.B))
-        want = oracle.eval_static(self.t, np.ascontiguousarray(self.leaf[:n].cpu().numpy()), np.zeros((n, self.t.n_root)))
-        got = self.root[:n].cpu().numpy()
+        want = oracle.eval_static(self.t, self.head(self.leaf, n), np.zeros((n, self.t.n_root)))
+        got = self.head(self.root, n)
         return bool(np.array_equal(got, want)), float(np.abs(got - want).max()) if n else 0.0, n
 
 
 def observable_sum(root):
     """Column sums of the root matrix, the observable of the final reduction.  For a Julia-layout matrix (R long rows)
     torch's reduction runs one workgroup per row -- 50 ms for 4 x 10^8 doubles -- so the rows are summed in two stages."""
+    if root.dim() == 3:                            # tile-major [T, R, 64]
+        return root.sum(dim=2).sum(dim=0)
     if root.stride(0) != 1 or root.shape[0] < (1 << 16):
         return root.sum(dim=0)
     rt = root.t()                                  # [R, B], rows contiguous
@@ -319,24 +298,25 @@ def kernel_of(f, slot=0):
     return name, (ki["n_valu"][slot] or None)
 
 
+TRAFFIC_FILE = "r04_traffic.json"       # this round's PMC summaries only: a workload that is not in it gets traffic = null, never an older round's figure
+
+
 def attach_traffic(roof, workload, layout, B, avg_kernel_s):
     """HBM bytes per launch from the rocprofv3 --pmc passes of the same command (bench.py cannot collect counters on
-    itself): profiles/r02_traffic.json holds bytes per evaluation, scaled here to this batch -- a value from the named
+    itself): profiles/r04_traffic.json holds bytes per evaluation, scaled here to this batch -- a value from the named
     profile, not a measurement of this run."""
-    for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", fn))).get(workload if layout == "leaf_major" else workload + ":" + layout)
-        except (OSError, ValueError):
-            continue
-        if tr and tr.get("layout", "leaf_major") == layout:
-            roof["traffic"] = tr["bytes_per_eval"] * B
-            roof["traffic_gbs"] = tr["bytes_per_eval"] * B / avg_kernel_s / 1e9
-            roof["traffic_frac"] = roof["traffic_gbs"] / HBM_PEAK_GBS
-            roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/" + fn + " (separate --pmc pass, not this run)"
-            roof["traffic_source_detail"] = ("(2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (" + tr.get("source", "") +
-                                             "), per evaluation, scaled to this batch")
-            return
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE))).get(workload if layout == "leaf_major" else workload + ":" + layout)
+    except (OSError, ValueError):
+        return
+    if tr and tr.get("layout", "leaf_major") == layout:
+        roof["traffic"] = tr["bytes_per_eval"] * B
+        roof["traffic_gbs"] = tr["bytes_per_eval"] * B / avg_kernel_s / 1e9
+        roof["traffic_frac"] = roof["traffic_gbs"] / HBM_PEAK_GBS
+        roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
+        roof["traffic_source"] = "profiles/" + TRAFFIC_FILE + " (separate --pmc pass, not this run)"
+        roof["traffic_source_detail"] = ("(2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (" + tr.get("source", "") +
+                                         "), per evaluation, scaled to this batch")
 
 
 def measured_copy(dev):
@@ -402,13 +382,13 @@ def config5(dev, rank, world, dist, comm, steps, warm):
     try:
         B = DEFAULT_B["gv_sigma5"]
         start, count = shard_range(B * world, rank, world)
-        c = Case("gv_sigma5", "leaf_major", count, dev, sample_offset=start)
+        c = Case("gv_sigma5", "tile_major", count, dev, sample_offset=start)
         w = torch.rand(1 if DRY else count, dtype=torch.float64, device=dev)
         acc = torch.zeros(c.t.n_root, dtype=torch.float64, device=dev)
         pre = Stamps(warm, c.stream)
         pre.record(0)
         for i in range(warm):
-            c.f.accumulate(c.leaf, w, acc)
+            c.accumulate(w, acc)
             pre.record(i + 1)
         acc.zero_()
         sync()
@@ -420,7 +400,7 @@ def config5(dev, rank, world, dist, comm, steps, warm):
         t0 = time.perf_counter()
         ev.record(0)
         for i in range(steps):
-            c.f.accumulate(c.leaf, w, acc)
+            c.accumulate(w, acc)
             ev.record(i + 1)
         reduce_observable(acc, comm=comm)     # the one collective: R doubles over xGMI (RCCL)
         sync()
@@ -435,14 +415,19 @@ def config5(dev, rank, world, dist, comm, steps, warm):
         ms = ev.ms()
         avg = sum(ms) / len(ms) / 1e3
         total = float(count) * steps * world
+        shards = [[int(start), int(count)]]
+        if dist:                                  # (after the timed region) every rank's contiguous range of a step's samples, for the record
+            sh = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(sh, torch.tensor([start, count], dtype=torch.int64, device=dev))
+            shards = [[int(x[0]), int(x[1])] for x in sh]
         kern, ops_exec = kernel_of(c.f)
         roof = roofline_of(c.st, count, avg, kern + " + fdg_reduce_lane_partials", accumulate=True, ops_exec=ops_exec, clock_ghz=probe_stop(probe))
         out = {"workload": "gv_sigma5" + WORKLOAD_NOTES["gv_sigma5"], "value": total / elapsed, "unit": "samples/s (whole job)", "n_gpus": world,
                "steps": steps, "warmup": warm, "samples_per_step_per_gpu": count, "total_samples": total,
-               "shard_offset_rank0": start, "baseline_total_samples": CONFIG5_TOTAL_SAMPLES,
+               "shard_offset_rank0": start, "shards_of_a_step": shards, "baseline_total_samples": CONFIG5_TOTAL_SAMPLES,
                "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "roofline_rank0": roof,
                "observable": [float(x) for x in acc.cpu()],
-               "what": "fdg_accumulate_device per step on the rank's shard; one all-reduce of R doubles after the last step, inside the timed region"}
+               "layout": "tile_major", "what": "fdg_accumulate_device_tiled per step on the rank's shard (tile-major batch); one all-reduce of R doubles after the last step, inside the timed region"}
         del c, w
         if not DRY:
             torch.cuda.empty_cache()
@@ -464,9 +449,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=60)   # power management needs ~40 launches (50 ms) to settle: 1.4 -> 1.04 ms per launch
     ap.add_argument("--workload", default="parquet_sigma4")
     ap.add_argument("--samples", type=int, default=0, help="samples per step per GPU (0 = workload default)")
-    ap.add_argument("--layout", default="leaf_major", choices=["sample_major", "leaf_major"],
-                    help="leaf_major = a Julia column-major B x L matrix (the host language's native layout); "
-                         "sample_major = compile_Python's row-major [B, L]")
+    ap.add_argument("--layout", default="tile_major", choices=["tile_major", "sample_major", "leaf_major"],
+                    help="tile_major = the batch as [tile of 64 samples][leaf][sample in tile] (a Julia Array{Float64,3}(64, L, cld(B, 64)); "
+                         "fdg_eval_device_tiled): what a Monte-Carlo driver that owns its batch allocates, and the default; "
+                         "leaf_major = a Julia column-major B x L matrix; sample_major = compile_Python's row-major [B, L]")
     ap.add_argument("--backend", default="isa", choices=["isa", "isa-autotune", "auto", "hip", "interp"],
                     help="isa: optimizing back end, gfx950 assembly; hip: straight-line HIP source via hiprtc; interp: table interpreter")
     ap.add_argument("--interp", action="store_true", help="same as --backend interp")
@@ -480,9 +466,6 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the other workloads (config 2, 3 stand-ins, 5, row-major layout) measured after the headline")
     ap.add_argument("--secondary", default="", help="comma-separated workload:layout pairs to measure after the headline instead of the full list")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--placement-trials", type=int, default=12,
-                    help="allocations of the sample batch tried before the warm-up (each timed with a few launches, the first that streams at "
-                         "0.745 of 8 TB/s or the best one is kept; 1 = take the first allocation as it comes).  Disclosed in roofline.placement")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device work: one process per rank on the CPU (gloo), the evaluator replaced by a stub that adds the shard's "
                          "sample count to the accumulator; checks sharding, the one collective and the stdout line (tests/test_bench_line.py)")
@@ -531,9 +514,8 @@ def main():
                 sample_offset=start)
     if args.backend == "isa-autotune":
         args.backend = "isa"
-    placement = None
-    if args.placement_trials > 1 and not DRY and args.backend == "isa" and 2.2 * 8 * B * (case.t.n_leaf + case.t.n_root) < free_b:
-        placement = case.choose_placement(args.placement_trials)
+    if args.layout == "tile_major" and args.backend not in ("isa", "auto") and not DRY:
+        raise SystemExit("--layout tile_major needs the ISA back end (fdg_eval_device_tiled)")
     t, st, f, leaf, root, stream = case.t, case.st, case.f, case.leaf, case.root, case.stream
     L, R = t.n_leaf, t.n_root
     step = case.step
@@ -608,9 +590,7 @@ def main():
         out["roofline"]["frac_hbm_max_over_steps"] = fr[-1]
         out["roofline"]["frac_hbm_median_over_steps"] = fr[len(fr) // 2]
         out["roofline"]["frac_hbm_of_each_step"] = [round(st["bytes_alg"] * B / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for m in kern_ms]     # (detail file only)
-        if placement:
-            out["roofline"]["placement"] = {"trials": len(placement), "frac_hbm_of_each": [round(x, 4) for x in placement],
-                                            "note": "allocations of the batch tried BEFORE the warm-up, the best kept (DESIGN.md 6a); entry 0 = a single allocation"}
+        out["roofline"]["placement"] = "single allocation, as it came from the allocator (no trials)"
         try:
             if DRY:
                 raise RuntimeError("dry run")
@@ -635,7 +615,7 @@ def main():
                             "note": "secondary ceiling: add/mul only (no FMA contraction allowed), so the usable peak is half"}
         out["kernel_info"] = {k: info[k] for k in ("max_live", "spec_vgpr", "spec_lds_bytes", "spec_scratch_bytes")}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(t, leaf, root, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(t, case, args.cpu_seconds)
         if world == 1 and args.backend == "isa" and not DRY and not args.fast_math:
             # The Monte-Carlo use of the same launch (after and outside the timed region, never part of `value`): weighted
             # accumulation inside the evaluator on the SAME resident batch -- fdg_accumulate_device: roots never reach HBM, so
@@ -645,12 +625,12 @@ def main():
                 accv = torch.zeros(R, dtype=torch.float64, device=dev)
                 n_acc = int(max(3, min(args.steps, 30)))
                 for _ in range(5):
-                    f.accumulate(leaf, wgt, accv)
+                    case.accumulate(wgt, accv)
                 sync()
                 eva = Stamps(n_acc, stream)
                 eva.record(0)
                 for i in range(n_acc):
-                    f.accumulate(leaf, wgt, accv)
+                    case.accumulate(wgt, accv)
                     eva.record(i + 1)
                 sync()
                 ms_acc = eva.ms()
@@ -674,7 +654,7 @@ def main():
         if rank == 0 and world == 1 and not DRY:
             sec = []
             head = (args.workload, args.layout)
-            full = (("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "leaf_major"),
+            full = (("parquet_sigma4", "tile_major"), ("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "leaf_major"),
                     ("parquet_sigma4_insdyn", "leaf_major"), ("parquet_sigma4_taylor2", "leaf_major"), ("parquet_sigma5", "leaf_major"),
                     ("parquet_ver4_4", "leaf_major"), ("gv_ver4_4", "leaf_major"), ("sigma2", "leaf_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "leaf_major"), ("gv_sigma5", "leaf_major"),
                     ("gv_sigma6", "leaf_major"), ("gv_sigma4_taylor2", "leaf_major"), ("gv_sigma4_taylor2", "sample_major"))
@@ -727,7 +707,7 @@ def compact_line(full):
                 "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock")
         line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:60]) for k in keep if k in roof}
         if roof.get("placement"):
-            line["roofline"]["placement_fracs"] = [_r(x, 3) for x in roof["placement"]["frac_hbm_of_each"]]
+            line["roofline"]["placement"] = "single allocation"
     cb = full.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
@@ -741,7 +721,7 @@ def compact_line(full):
                 rows.append([e.get("workload", "?")[:24], e.get("layout"), None, "error", None, None, None, None, False, None])
                 continue
             r = e["roofline"]
-            rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm"}.get(e["layout"], e["layout"]), _r(e["value"]),
+            rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm", "tile_major": "tm"}.get(e["layout"], e["layout"]), _r(e["value"]),
                          {"hbm": "hbm", "valu_fp64": "valu"}.get(r["bound"], r["bound"]), _r(r["frac"], 3), _r(r.get("frac_hbm"), 3),
                          _r(r.get("frac_valu"), 3), _r(r.get("traffic_over_algorithmic"), 3), e.get("gpu_matches_cpu_bitwise"), _r(r.get("clock_ghz"), 3)])
         line["secondary"] = rows
@@ -841,7 +821,7 @@ def mc_step(t, workload, B, dev, fast_math):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def cpu_baseline(t, leaf, root, budget_s):
+def cpu_baseline(t, case, budget_s):
     """The reference's own C back-end text (to_Cstr shape, static.jl:155-197)
     compiled by gcc -O2 -ffp-contract=off (-O1 above 2*10^4 nodes, where -O2
     needs minutes) and called once per sample on the host cores, on a bounded
@@ -853,15 +833,15 @@ def cpu_baseline(t, leaf, root, budget_s):
     opt = "-O2" if t.n_node <= 20000 else "-O1"
     cb = oracle.CBaseline(table_to_Cstr(t), t.n_leaf, t.n_root, opt=opt)
     # single-core rate first (also the calibration for the threaded run)
-    n1 = min(int(leaf.shape[0]), 4096)
-    h1 = np.ascontiguousarray(leaf[:n1].cpu().numpy())
+    n1 = min(int(case.B), 4096)
+    h1 = case.head(case.leaf, n1)
     cb(h1[:256], 1)
     t0 = time.perf_counter()
     cb(h1, 1)
     rate1 = n1 / max(time.perf_counter() - t0, 1e-9)
     want = max(4096, rate1 * cores * 1.0)
-    n = int(min(leaf.shape[0], want, 1 << 22))
-    h = np.ascontiguousarray(leaf[:n].cpu().numpy())
+    n = int(min(case.B, want, 1 << 22))
+    h = case.head(case.leaf, n)
     cb(h[: min(n, 64 * cores)], cores)           # thread start-up outside the clock
     t0 = time.perf_counter()
     cb(h, cores)                                 # calibration pass with all threads
@@ -871,7 +851,7 @@ def cpu_baseline(t, leaf, root, budget_s):
     for _ in range(reps):
         ref = cb(h, cores)
     dt = time.perf_counter() - t0
-    got = root[:n].cpu().numpy()
+    got = case.head(case.root, n)
     # the interpreter the reference's examples actually call (IR.eval!, example/benchmark.jl:84-86):
     # its arithmetic restated in oracle/fdg_oracle.c, one thread
     ni = int(min(n, 2048))

@@ -39,6 +39,7 @@ EXPORTS = [
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
     "fdg_graph_kernel_info",
     "fdg_eval_device_tiled", "fdg_accumulate_device_tiled", "fdg_fill_uniform_device_tiled", "fdg_graph_set_association",
+    "fdg_batch_alloc", "fdg_batch_free",
 ]
 COMM_ID_BYTES = 128
 
@@ -141,6 +142,8 @@ def lib():
     L.fdg_eval_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, i64, vp]
     L.fdg_eval.argtypes = [vp, dp, dp, i64]
     L.fdg_graph_set_association.argtypes = [vp, C.c_int]
+    L.fdg_batch_alloc.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.fdg_batch_free.argtypes = [vp]
     L.fdg_eval_device_tiled.argtypes = [vp, dp, i64, i64, i64, dp, i64, i64, i64, i64, vp]
     L.fdg_accumulate_device_tiled.argtypes = [vp, dp, i64, i64, i64, dp, dp, i64, vp]
     L.fdg_fill_uniform_device_tiled.argtypes = [dp, i64, u32, i64, i64, i64, u64, u64, vp]
@@ -389,6 +392,17 @@ def fill_uniform_device(d_leaf: int, B: int, L: int, ss: int, ls: int, seed: int
 def fill_uniform_device_tiled(d_leaf: int, B: int, L: int, ss: int, ls: int, lts: int, seed: int, sample_offset: int = 0,
                                stream: int = 0):
     check(lib().fdg_fill_uniform_device_tiled(d_leaf, B, L, ss, ls, lts, seed, sample_offset, stream))
+
+
+def batch_alloc(n_bytes: int, chunk_bytes: int = 0) -> int:
+    """Device address of a batch backed by physical chunks of ``chunk_bytes`` (0: one allocation); :func:`batch_free` releases it."""
+    p = C.c_void_p()
+    check(lib().fdg_batch_alloc(n_bytes, chunk_bytes, C.byref(p)))
+    return int(p.value)
+
+
+def batch_free(ptr: int):
+    check(lib().fdg_batch_free(ptr))
 
 
 def isa_check_hazards(asm_text: str):

@@ -320,6 +320,15 @@ int fdg_fill_uniform_device_tiled(double *d_leaf, int64_t n_sample, uint32_t n_l
                                   int64_t leaf_leaf_stride, int64_t leaf_tile_stride, uint64_t seed, uint64_t sample_offset,
                                   void *stream);
 
+/* Device memory for a sample batch, backed explicitly (HIP virtual-memory management: one reserved address range, physical
+ * chunks of chunk_bytes created and mapped in address order; chunk_bytes 0 = one physical allocation for the whole batch) instead
+ * of by whatever state the driver's allocator is in when hipMalloc is called -- how a batch of tens of GB is backed decides
+ * which of two rates its stream runs at.  The pointer is an ordinary device pointer for every entry point above and
+ * for the caller's own kernels; release it with fdg_batch_free (synchronises the device).  The current device is used.
+ * No counterpart in the reference (its leaf vector is a Julia Vector on the host). */
+int fdg_batch_alloc(size_t bytes, size_t chunk_bytes, void **d_ptr);
+int fdg_batch_free(void *d_ptr);
+
 /* d_leaf[b*ss + i*ls] = U[0,1) from Philox4x32-10, key = seed, counter =
  * (sample_offset + b, i): independent of launch geometry and of how samples
  * are sharded over GPUs. */

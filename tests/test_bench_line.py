@@ -109,6 +109,29 @@ def test_dry_run_of_bench_itself(world, tmp_path):
     assert detail["config"]["shard_offset_rank0"] == 0 and detail["config5"]["shard_offset_rank0"] == 0
 
 
+def test_dry_run_with_eight_ranks_is_config_5_as_baseline_words_it(tmp_path):
+    """BASELINE.json configs[4]: 10^9 samples sharded across 8 GPUs with one final reduce.  The driver's own command line for
+    N = 8, on the CPU: 63 steps of 8 x 2*10^6 samples (10^9 rounded UP to whole steps: 1.008*10^9, said so in the line), eight
+    contiguous shards of a step in rank order, and the single collective sums every rank's samples."""
+    world = 8
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", "29637", os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--dry-run"]
+    p = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == 8 and got["scaling"] == "weak"
+    c5 = got["config5"]
+    per = bench.DEFAULT_B["gv_sigma5"]
+    assert c5["steps"] == 63 and c5["n_gpus"] == 8 and c5["total_samples"] == 63 * 8 * per == 1_008_000_000 >= 10**9
+    detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))["config5"]
+    assert detail["shards_of_a_step"] == [[r * per, per] for r in range(8)]
+    assert detail["observable"][0] == 1_008_000_000.0            # the one all-reduce: every rank added its shard once per step
+    assert detail["baseline_total_samples"] == 10**9
+
+
 @pytest.mark.gpu
 def test_bench_line_on_the_device(tmp_path):
     """The real thing, shortened: `python bench.py` on cuda:0 with a smaller batch and two secondary rows.  One parseable
@@ -116,7 +139,7 @@ def test_bench_line_on_the_device(tmp_path):
     and cpu_baseline present and consistent; every checked sample bit-equal to the CPU port."""
     env = dict(os.environ, PYTHONPATH=ROOT)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "3", "--samples", "4000000", "--cpu-seconds", "2",
-           "--secondary", "parquet_sigma4:sample_major,gv_sigma5:leaf_major"]
+           "--secondary", "parquet_sigma4:sample_major,gv_sigma5:leaf_major,parquet_sigma4:leaf_major"]
     p = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=1200)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -124,6 +147,7 @@ def test_bench_line_on_the_device(tmp_path):
     got = json.loads(lines[0][-8000:])
     assert got["metric"] == "graph-evaluations/sec" and got["n_gpus"] == 1 and got["steps"] == 5 and got["dtype"] == "f64" and got["vs_baseline"] is None
     assert got["config"]["workload"].startswith("parquet_sigma4") and got["config"]["samples_per_step_per_gpu"] == 4000000
+    assert got["config"]["layout"] == "tile_major" and got["roofline"]["placement"] == "single allocation"
     r = got["roofline"]
     assert r["kernel"] == "fdg_isa_eval_nt" and r["bound"] == "hbm" and r["ops_exec_per_eval"] > 0
     assert abs(r["achieved"] - got["value"] * 704 / 1e9) / r["achieved"] < 0.1          # 8 (L + R) bytes per evaluation, HIP events vs wall clock
@@ -133,7 +157,7 @@ def test_bench_line_on_the_device(tmp_path):
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_matches_cpu_bitwise"] is True
     rows = {(x[0], x[1]): x for x in got["secondary"]}
     i_bit, i_clk = got["secondary_cols"].index("bitwise"), got["secondary_cols"].index("clock_ghz")
-    assert set(rows) == {("parquet_sigma4", "rm"), ("gv_sigma5", "lm")} and all(x[i_bit] is True for x in rows.values())
+    assert set(rows) == {("parquet_sigma4", "rm"), ("gv_sigma5", "lm"), ("parquet_sigma4", "lm")} and all(x[i_bit] is True for x in rows.values())
     # the probe wave next to the timed launches: a plausible shader clock (the 5th-order graph runs against the power budget)
     assert all(x[i_clk] is None or 1.2 < x[i_clk] < 2.6 for x in rows.values()) and (r.get("clock_ghz") is None or 1.2 < r["clock_ghz"] < 2.6)
     assert got["config5"]["total_samples"] >= 10**9 and got["config5"]["n_gpus"] == 1

@@ -1,7 +1,8 @@
-"""N > 1 on real devices: two processes, one GPU each, the C-ABI communicator (fdg_comm_unique_id / fdg_comm_create /
+"""N > 1 on real devices: one process per GPU (world = 2, 4, 8 -- whichever the node has), the C-ABI communicator (fdg_comm_unique_id / fdg_comm_create /
 fdg_reduce_device: RCCL inside libfdg.so, no torch.distributed anywhere) around sharded evaluation + fused accumulation
-of the GV 5th-order self-energy (BASELINE.json config 5 in miniature).  Skipped when fewer than two GPUs are visible
-(the 1-GPU box of `gpurun`); the decomposition itself is covered on CPU by test_distributed_gloo.py."""
+of the GV 5th-order self-energy (BASELINE.json config 5 in miniature).  Each world size is skipped when fewer GPUs are visible
+(the 1-GPU box of `gpurun` skips all three); the decomposition itself is covered on CPU by test_distributed_gloo.py, the driver's
+own N = 8 command line by tests/test_bench_line.py::test_dry_run_with_eight_ranks_is_config_5_as_baseline_words_it."""
 import os
 
 import numpy as np
@@ -49,14 +50,15 @@ def _worker(rank, world, id_path, n_total, q):
     comm.close()
 
 
-def test_two_gpus_shard_and_reduce_through_the_c_abi(tmp_path):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gpus_shard_and_reduce_through_the_c_abi(tmp_path, world):
     import torch
-    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs (the final observable reduce over xGMI)")
+    if not torch.cuda.is_available() or torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs (the final observable reduce over xGMI)")
     import torch.multiprocessing as mp
     import oracle
     from feynmandiagram_jl_amd import workloads
-    n_total, world = 40_001, 2
+    n_total = 40_001
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, str(tmp_path / "comm_id"), n_total, q)) for r in range(world)]
@@ -72,6 +74,6 @@ def test_two_gpus_shard_and_reduce_through_the_c_abi(tmp_path):
     t = workloads.get("gv_sigma5")
     ref = oracle.eval_static(t, oracle.philox_uniform(n_total, t.n_leaf, 1234))
     scale = np.abs(ref).sum(axis=0)
-    assert np.array_equal(res[0][0], res[1][0])                                      # both ranks hold the same total
+    assert all(np.array_equal(res[0][0], res[r][0]) for r in range(1, world))         # every rank holds the same total
     assert np.all(np.abs(res[0][0] - ref.sum(axis=0)) <= 1e-12 * scale)             # sum order differs with the rank count
     assert np.allclose(res[0][1], scale, rtol=1e-12)
