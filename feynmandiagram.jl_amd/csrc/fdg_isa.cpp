@@ -276,6 +276,8 @@ struct Emit {
   bool streaming = false;     // the kernel being printed is the variant for line-aligned batches: non-temporal leaf loads and root stores
   uint64_t n_auto_nop = 0;
   uint64_t vm_issued = 0, lg_issued = 0, vm_done = 0, lg_done = 0;
+  uint64_t vm_slack = 0;      // FDG_ISA_DEBUG=noackwait (timing experiment, results may be garbage): waits let this many more operations stay
+                              // outstanding -- the tile's root stores -- to see what a wave that never waits for store acknowledgements would run at
   // pending[reg] = (kind 0 none / 1 vm / 2 lgkm, seq)
   std::vector<std::pair<uint8_t, uint64_t>> pend;
   std::vector<uint64_t> pend_acc;      // [AGPR pair] vm sequence number of the leaf load that lands in it (0: none outstanding)
@@ -300,7 +302,7 @@ struct Emit {
   void wait_reg(uint32_t r) {
     auto &p = pend[r];
     if (p.first == 1 && p.second > vm_done) {
-      uint64_t n = vm_issued - p.second;            // ops issued after it may stay outstanding
+      uint64_t n = vm_issued - p.second + vm_slack;            // ops issued after it may stay outstanding
       if (n > 63) n = 63;
       ins("s_waitcnt vmcnt(" + std::to_string(n) + ")");
       vm_done = std::max(vm_done, vm_issued - n);   // everything up to that seq has returned
@@ -316,7 +318,7 @@ struct Emit {
   }
   void wait_vm(uint64_t seq) {
     if (seq <= vm_done) return;
-    uint64_t n = std::min<uint64_t>(vm_issued - seq, 63);
+    uint64_t n = std::min<uint64_t>(vm_issued - seq + vm_slack, 63);
     ins("s_waitcnt vmcnt(" + std::to_string(n) + ")");
     vm_done = std::max(std::max(vm_done, vm_issued - n), seq);
   }
@@ -477,6 +479,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const bool use_ldexp = std::getenv("FDG_ISA_NO_LDEXP") == nullptr;
   const bool dbg_novalu = dbg && std::strstr(dbg, "novalu");     // the memory stream of the program alone (waits included)
   const bool dbg_nopanel = dbg && std::strstr(dbg, "nopanel");   // no spill traffic to the HBM panel
+  E.vm_slack = (dbg && std::strstr(dbg, "noackwait") && !accumulate) ? p.R : 0;
   // ---- prologue ------------------------------------------------------------
   if (cs) E.ins("v_and_b32_e32 v0, 63, v0");          // lane within the wave (the workgroup has four waves)
   E.ins("s_load_dwordx8 s[4:11], s[0:1], 0x0");

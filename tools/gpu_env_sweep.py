@@ -12,15 +12,25 @@ t = workloads.get(name)
 st = t.stats()
 L, R = t.n_leaf, t.n_root
 B = int(os.environ.get("SWEEP_B", max(1 << 14, min(4_000_000, int(2.4e9 / (8 * L))))))
-if os.environ.get("SWEEP_LAYOUT") == "sample_major":      # compile_Python's row-major [B, L] / [B, R]
+TILED = os.environ.get("SWEEP_LAYOUT") == "tile_major"      # fdg_eval_device_tiled: [tile, leaf, sample in tile]
+if TILED:
+    B = (B + 63) // 64 * 64
+    leaf = torch.empty((B // 64, L, 64), dtype=torch.float64, device=dev)
+    root = torch.empty((B // 64, R, 64), dtype=torch.float64, device=dev)
+elif os.environ.get("SWEEP_LAYOUT") == "sample_major":      # compile_Python's row-major [B, L] / [B, R]
     leaf = torch.empty((B, L), dtype=torch.float64, device=dev)
     root = torch.empty((B, R), dtype=torch.float64, device=dev)
 else:
     leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
     root = torch.empty((R, B), dtype=torch.float64, device=dev).t()
-capi.fill_uniform_device(leaf.data_ptr(), B, L, leaf.stride(0), leaf.stride(1), 11, 0, torch.cuda.current_stream().cuda_stream)
+if TILED:
+    capi.fill_uniform_device_tiled(leaf.data_ptr(), B, L, 1, 64, 64 * L, 11, 0, torch.cuda.current_stream().cuda_stream)
+else:
+    capi.fill_uniform_device(leaf.data_ptr(), B, L, leaf.stride(0), leaf.stride(1), 11, 0, torch.cuda.current_stream().cuda_stream)
 nchk = 4099
-want = oracle.eval_static(t, leaf[:nchk].cpu().numpy(), np.zeros((nchk, R)))
+rows = lambda x, n: (x[:(n + 63) // 64].permute(0, 2, 1).reshape(-1, x.shape[1])[:n] if TILED else x[:n]).cpu().numpy()
+run = lambda f: f.eval_tiled(root, leaf, B) if TILED else f(root, leaf)
+want = oracle.eval_static(t, rows(leaf, nchk), np.zeros((nchk, R)))
 for setting in sys.argv[2:]:
     kv = {} if setting == "-" else dict(x.split("=") for x in setting.split(","))
     old = {k: os.environ.get(k) for k in kv}
@@ -30,14 +40,14 @@ for setting in sys.argv[2:]:
         f = fd.compile_table(t, specialize="isa", cache_dir=os.environ.get("SWEEP_CACHE", "/tmp/fdg-sweep-cache"))
         tc = time.time() - t0
         root.zero_()
-        f(root, leaf); torch.cuda.synchronize()
-        ok = np.array_equal(root[:nchk].cpu().numpy(), want)
-        for _ in range(3): f(root, leaf)
+        run(f); torch.cuda.synchronize()
+        ok = np.array_equal(rows(root, nchk), want)
+        for _ in range(3): run(f)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = int(os.environ.get("SWEEP_N", 10))
         e0.record()
-        for _ in range(n): f(root, leaf)
+        for _ in range(n): run(f)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         i = f.info()

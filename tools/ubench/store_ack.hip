@@ -59,6 +59,47 @@ __global__ void __launch_bounds__(64, 2) k(const double *__restrict__ src, doubl
   }
   if (a0 + a1 + a2 + a3 == 12345.678) dst[0] = a1;
 }
+// MODE 3: true software pipelining across tiles: column g + Q of the (tile, column) stream is requested when column g is consumed, so
+// every load that is waited for during the Q columns after a tile's stores is OLDER than those stores; NS stores per tile (static)
+template <int NCOL, int Q, int NS, int TILED>
+__global__ void __launch_bounds__(64, 2) kp(const double *__restrict__ src, double *__restrict__ dst, long ntile, long col_stride, int ops) {
+  static_assert(NCOL % Q == 0, "Q must divide the column count");
+  const long wave = blockIdx.x, nw = gridDim.x;
+  double a0 = threadIdx.x * 1e-9 + 1.0, a1 = a0 + 1e-9, a2 = a0 + 2e-9, a3 = a0 + 3e-9;
+  const double m = 1.0000001;
+  auto at = [&](long t, int c) { return TILED ? src + (t * NCOL + c) * 64 + threadIdx.x : src + c * col_stride + t * 64 + threadIdx.x; };
+  auto out = [&](long t, int r) { return TILED ? dst + (t * 8 + r) * 64 + threadIdx.x : dst + r * col_stride + t * 64 + threadIdx.x; };
+  double v[Q];
+#pragma unroll
+  for (int c = 0; c < Q; ++c) v[c] = __builtin_nontemporal_load(at(wave, c));
+  for (long t = wave; t < ntile; t += nw) {
+    const long tn = t + nw < ntile ? t + nw : t;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+      s += v[c % Q];
+      v[c % Q] = __builtin_nontemporal_load(c + Q < NCOL ? at(t, c + Q) : at(tn, c + Q - NCOL));
+      OPS4(ops)
+    }
+#pragma unroll
+    for (int r = 0; r < NS; ++r) __builtin_nontemporal_store(s + a0 + r, out(t, r));
+  }
+  if (a0 + a1 + a2 + a3 == 12345.678) dst[0] = a1;
+}
+template <int NCOL, int Q, int NS, int TILED> void runp(const double *src, double *dst, long total_bytes, int ops) {
+  const long ntile = total_bytes / (NCOL * 512L);
+  const long cs = ntile * 64;
+  const int grid = 256 * 4 * 2;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((kp<NCOL, Q, NS, TILED>), dim3(grid), dim3(64), 0, 0, src, dst, ntile, cs, ops);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int w = 0; w < 5; ++w) hipLaunchKernelGGL((kp<NCOL, Q, NS, TILED>), dim3(grid), dim3(64), 0, 0, src, dst, ntile, cs, ops);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+  printf("%s pipelined Q=%2d columns=%3d ops/load=%2d stores=%d  %.3f ms  reads %.2f TB/s  reads+writes %.2f TB/s\n", TILED ? "tile-major" : "leaf-major", Q, NCOL, ops, NS, ms,
+         (double)ntile * NCOL * 512 / ms / 1e9, (double)ntile * (NCOL + NS) * 512 / ms / 1e9);
+}
 template <int NCOL, int MODE, int TILED> void run(const double *src, double *dst, long total_bytes, int ops, int nstore) {
   const long ntile = total_bytes / (NCOL * 512L);
   const long cs = ntile * 64;
@@ -101,10 +142,13 @@ int main(int argc, char **argv) {
     printf("-- %ld GB, backing: %s %zu MB\n", gb, chunk_mb ? "chunks of" : "hipMalloc", chunk_mb);
     for (int nstore : {0, 4}) {
       run<84, 0, 0>(src, dst, total, 12, nstore);
-      run<84, 1, 0>(src, dst, total, 12, nstore);
       run<84, 0, 1>(src, dst, total, 12, nstore);
-      run<84, 1, 1>(src, dst, total, 12, nstore);
     }
+    runp<84, 21, 0, 1>(src, dst, total, 12); runp<84, 21, 4, 1>(src, dst, total, 12);
+    runp<84, 28, 0, 1>(src, dst, total, 12); runp<84, 28, 4, 1>(src, dst, total, 12);
+    runp<84, 42, 0, 1>(src, dst, total, 12); runp<84, 42, 4, 1>(src, dst, total, 12);
+    runp<84, 42, 0, 0>(src, dst, total, 12); runp<84, 42, 4, 0>(src, dst, total, 12);
+    runp<84, 42, 8, 1>(src, dst, total, 12);
   }
   printf("last error: %s\n", hipGetErrorString(hipGetLastError()));
   return 0;
