@@ -294,6 +294,8 @@ def kernel_of(f, slot=0):
     except Exception:
         return "", None
     name = ki["last_kernel"]
+    if name == "fdg_isa_eval_pool":       # the pooled cooperative variant: fold steps of all its waves together
+        return name, (ki.get("pool_valu") or None)
     slot = 1 if "_acc" in name else 2 if name.endswith("_rm") else 0
     return name, (ki["n_valu"][slot] or None)
 
@@ -673,7 +675,7 @@ def main():
             head = (args.workload, args.layout)
             full = (("parquet_sigma4", "tile_major"), ("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "leaf_major"),
                     ("parquet_sigma4_insdyn", "tile_major"), ("parquet_sigma4_taylor2", "tile_major"), ("parquet_sigma4_taylor2", "leaf_major"), ("parquet_sigma4_taylor2", "tile_major+fma"),
-                    ("parquet_sigma5", "tile_major"), ("parquet_ver4_4", "tile_major"), ("gv_ver4_4", "leaf_major"), ("sigma2", "tile_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "tile_major"),
+                    ("parquet_sigma5", "tile_major"), ("parquet_ver4_4", "tile_major"), ("gv_ver4_4", "tile_major"), ("gv_ver4_4", "leaf_major"), ("sigma2", "tile_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "tile_major"),
                     ("gv_sigma5", "tile_major"), ("gv_sigma5", "leaf_major"), ("gv_sigma5", "tile_major+fma"),
                     ("gv_sigma6", "leaf_major"), ("gv_sigma4_taylor2", "tile_major"), ("gv_sigma4_taylor2", "sample_major"))
             for wl, lay in (tuple(tuple(x.split(":")) for x in args.secondary.split(",")) if args.secondary else full):

@@ -39,7 +39,7 @@ EXPORTS = [
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
     "fdg_graph_kernel_info",
     "fdg_eval_device_tiled", "fdg_accumulate_device_tiled", "fdg_fill_uniform_device_tiled", "fdg_graph_set_association",
-    "fdg_batch_alloc", "fdg_batch_free",
+    "fdg_batch_alloc", "fdg_batch_free", "fdg_graph_pool_program",
 ]
 COMM_ID_BYTES = 128
 
@@ -76,7 +76,8 @@ class GraphInfo(C.Structure):
 class KernelInfo(C.Structure):
     _fields_ = [("last_kernel", C.c_char * 48), ("n_valu", C.c_uint64 * 3), ("n_ld_leaf", C.c_uint32 * 3),
                 ("n_panel", C.c_uint32 * 3), ("n_lds", C.c_uint32 * 3), ("waves_per_cu", C.c_uint32 * 3),
-                ("has_acc", C.c_uint32), ("has_rm", C.c_uint32), ("has_coop", C.c_uint32), ("rm_bufs", C.c_uint32)]
+                ("has_acc", C.c_uint32), ("has_rm", C.c_uint32), ("has_coop", C.c_uint32), ("rm_bufs", C.c_uint32),
+                ("has_pool", C.c_uint32), ("pool_fetch", C.c_uint32), ("pool_valu", C.c_uint64)]
 
 
 class LeafTables(C.Structure):
@@ -165,6 +166,7 @@ def lib():
     L.fdg_graph_mc_program.argtypes = [vp, C.POINTER(LeafTables), C.POINTER(OptParams), C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64),
                                        C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.fdg_graph_coop_program.argtypes = [vp, C.POINTER(OptParams), u32, C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64), C.POINTER(u32)]
+    L.fdg_graph_pool_program.argtypes = [vp, C.POINTER(OptParams), u32, C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64), C.POINTER(u32)]
     L.fdg_graph_specialize_fused.argtypes = [vp, C.POINTER(LeafTables), C.c_char_p, C.c_uint]
     L.fdg_mc_eval_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, C.c_double, C.c_double, C.c_double, dp, i64, i64, i64, vp]
     L.fdg_mc_accumulate_device.argtypes = [vp, dp, i64, i64, dp, i64, i64, C.c_double, C.c_double, C.c_double, dp, dp, i64, vp]
@@ -254,7 +256,7 @@ class GraphHandle:
         out = {"last_kernel": ki.last_kernel.decode()}
         for k in ("n_valu", "n_ld_leaf", "n_panel", "n_lds", "waves_per_cu"):
             out[k] = [int(x) for x in getattr(ki, k)]
-        for k in ("has_acc", "has_rm", "has_coop", "rm_bufs"):
+        for k in ("has_acc", "has_rm", "has_coop", "rm_bufs", "has_pool", "pool_fetch", "pool_valu"):
             out[k] = int(getattr(ki, k))
         return out
 
@@ -301,7 +303,12 @@ class GraphHandle:
             lib().fdg_free(ops)
         return arr, nr.value, nl.value, nm.value
 
-    def coop_program(self, **kw):
+    def pool_program(self, **kw):
+        """The per-wave programs of the pooled cooperative variant (fdg_graph_pool_program): ``([ops_w0, ..], info)`` like
+        :meth:`coop_program`; ``info["n_transfer"]`` is the number of leaf fetches per tile."""
+        return self.coop_program(_pooled=True, **kw)
+
+    def coop_program(self, _pooled=False, **kw):
         """The four per-wave programs of the cooperative variant: ``([ops_w0, .., ops_w3], info)`` with
         ``info = dict(n_reg, n_lds, n_mem, n_acc per wave; n_shared, n_epoch, n_transfer, n_duplicate)``."""
         q = OptParams(kw.get("n_reg", 0), kw.get("n_lds", 0), kw.get("lookahead_lds", 0), kw.get("lookahead_mem", 0),
@@ -312,7 +319,7 @@ class GraphHandle:
             ops = C.POINTER(MOp)()
             n = C.c_uint64()
             inf = (C.c_uint32 * 8)()
-            rc = lib().fdg_graph_coop_program(self._h, C.byref(q), w, C.byref(ops), C.byref(n), inf)
+            rc = (lib().fdg_graph_pool_program if _pooled else lib().fdg_graph_coop_program)(self._h, C.byref(q), w, C.byref(ops), C.byref(n), inf)
             if rc != 0 and w >= 4:
                 break
             check(rc)

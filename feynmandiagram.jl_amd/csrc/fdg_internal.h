@@ -140,6 +140,11 @@ struct fdg_graph {
   bool has_coop = false, coop_enabled = false;
   void *fn_isa_coop = nullptr;
   uint32_t coop_panel_wg = 0, coop_lds_bytes = 0, coop_threads = 256;
+  // pooled cooperative variant: the waves of a CU evaluate one tile, whole roots each, leaves through a shared LDS pool (full tiles, sample stride 1)
+  bool has_pool = false;
+  void *fn_isa_pool = nullptr;
+  uint32_t pool_panel_wg = 0, pool_threads = 256, pool_fetch = 0;
+  uint64_t pool_valu = 0;
   // companion HIP-source kernels of an ISA-specialised handle, used for sample-major input (FDG_SPEC_ROW_MAJOR_COMPANION)
   std::vector<char> alt_code;
   void *alt_module = nullptr, *fn_alt_sm = nullptr, *fn_alt_gen = nullptr;

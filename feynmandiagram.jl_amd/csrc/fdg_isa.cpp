@@ -429,7 +429,7 @@ static void rm_plan(const Lowered &p, const OptProgram &prog, uint32_t rm_bufs, 
 // One wave's section of the cooperative kernel (emit_coop below): no kernel header or descriptor of its own; lane = thread id
 // & 63; private LDS slots behind the shared ones (addressed through their own base register); the wave's panel inside the
 // workgroup's; M_SEND / M_RECV / M_BARRIER.
-struct CoopSec { uint32_t wave, n_shared, priv_base_bytes, panel_wg_bytes, panel_prefix_bytes; };
+struct CoopSec { uint32_t wave, n_shared, priv_base_bytes, panel_wg_bytes, panel_prefix_bytes; bool pooled = false; };
 static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog, const std::string &kname, int W, bool accumulate = false,
                               uint32_t rm_bufs = 0, const CoopSec *cs = nullptr) {
   E.vm_issued = E.lg_issued = E.vm_done = E.lg_done = 0;
@@ -530,6 +530,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   if (cs) {
     E.ins("v_add_u32_e32 v" + std::to_string(rm0) + ", " + hex32(cs->priv_base_bytes) + ", " + V(V_LANE8));
     E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 1) + ", 0x10000, " + V(V_LANE8));
+    E.ins("v_lshlrev_b32_e32 v" + std::to_string(rm0 + 2) + ", 4, v0");          // lane * 16: source offset of a pool fetch (lanes 0..31 carry a leaf's 64 samples)
   }
   if (rm_bufs) {
     // v[rm0] / v[rm0 + 9]: source offsets of the LDS-direct loads of even / odd instructions n of a chunk -- lane l fetches
@@ -782,6 +783,9 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     return sq;
   };
   size_t op_index = 0;
+  std::vector<std::pair<uint64_t, uint32_t>> pool_pending;      // (vm sequence number, first epoch in which it is read) of this wave's pool fetches in flight
+  uint32_t bar_seen = 0;
+  bool pool_exec_low = false;
   for (const MOp &o : prog.ops) {
     if (rm_bufs) for (const RmFetch &f : rm_fetch[op_index]) rm_emit_fetch(f);
     const size_t this_op = op_index;
@@ -870,17 +874,35 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         E.ins(DSR + vall(o.d) + ", " + (o.a < 128 ? V(V_LANE8) : "v" + std::to_string(rm0 + 1)) + " offset:" + std::to_string((o.a % 128) * SLOT));
         E.pend[o.d] = {2, ++E.lg_issued};
         break;
+      case M_POOL_FETCH: {   // shared[d] = leaf[a]: 32 lanes x 16 bytes straight into the LDS slot, no register in between
+        if (!pool_exec_low) { E.ins("s_mov_b64 exec, 0xffffffff"); pool_exec_low = true; }
+        emit_scaled_addr(E, S_FA, S_LT, S_LS8, o.a);
+        E.ins("s_mov_b32 m0, " + hex32(o.d * SLOT));
+        E.ins("global_load_lds_dwordx4 v" + std::to_string(rm0 + 2) + ", " + S2(S_FA));
+        pool_pending.push_back({++E.vm_issued, (uint32_t)o.imm});
+        const bool more = this_op + 1 < prog.ops.size() && prog.ops[this_op + 1].kind == M_POOL_FETCH;
+        if (!more) { E.ins("s_mov_b64 exec, -1"); pool_exec_low = false; }
+        break;
+      }
       case M_SEND:
         E.wait_reg(o.a);
         E.ins(DSW + (o.d < 128 ? V(V_LANE8) : "v" + std::to_string(rm0 + 1)) + ", " + vall(o.a) + " offset:" + std::to_string((o.d % 128) * SLOT));
         ++E.lg_issued;
         break;
-      case M_BARRIER:        // this wave's LDS traffic of the epoch has completed; then all four waves meet
+      case M_BARRIER: {      // this wave's LDS traffic of the epoch has completed; then all four waves meet
+        // pooled programs: what this wave fetched for the epoch that starts behind this barrier has landed in the pool
+        uint64_t need_seq = 0;
+        for (auto it = pool_pending.begin(); it != pool_pending.end();) {
+          if (it->second <= bar_seen + 1) { need_seq = std::max(need_seq, it->first); it = pool_pending.erase(it); } else ++it;
+        }
+        if (need_seq && !(dbg && std::strstr(dbg, "nofetchwait"))) E.wait_vm(need_seq);     // (timing experiment: results are garbage without it)
+        bar_seen++;
         E.ins("s_waitcnt lgkmcnt(0)");
         E.lg_done = E.lg_issued;
         for (auto &pp : E.pend) if (pp.first == 2) pp.first = 0;
         if (!(dbg && std::strstr(dbg, "nobarrier"))) E.ins("s_barrier");     // (timing experiment: results are garbage without it)
         break;
+      }
       case M_ST_LDS:
         if (dbg_nolds) break;
         E.wait_reg(o.a);
@@ -1127,7 +1149,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_endpgm");
 
   // ---- kernel descriptor -------------------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? 2 : 0), 8);
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? 3 : 0), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
   const uint32_t n_agpr = RW * prog.n_acc_used;
   if (cs) return KernelMeta{kname, lds_bytes, accum, n_agpr, 12, (mc || has_macro) ? S_END : S_POOL + 2 * 16};
@@ -1175,7 +1197,7 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
   uint32_t accum = 0, n_agpr = 0;
   int n_sgpr = 0;
   for (uint32_t w = 0; w < cp.n_wave; ++w) {
-    const CoopSec cs{w, cp.n_shared, (cp.n_shared + w * cp.n_priv_lds) * 512u, panel_wg, prefix[w]};
+    const CoopSec cs{w, cp.n_shared, (cp.n_shared + w * cp.n_priv_lds) * 512u, panel_wg, prefix[w], cp.pooled};
     E.hz.reset();
     const KernelMeta m = emit_kernel(E, p, cp.wave[w], kname + "_w" + std::to_string(w), 1, false, 0, &cs);
     accum = std::max(accum, m.accum); n_agpr = std::max(n_agpr, m.n_agpr); n_sgpr = std::max(n_sgpr, m.n_sgpr);
@@ -1245,7 +1267,7 @@ std::string isa_hazard_table() {
 // `kname`_w2 next to it.
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2,
                      const OptProgram *prog_acc, const OptProgram *prog_rm, uint32_t rm_bufs, const CoopProgram *coop,
-                     const OptProgram *prog_rm_acc) {
+                     const OptProgram *prog_rm_acc, const CoopProgram *pool) {
   Emit E;
   E.os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n";
   std::vector<KernelMeta> ks;
@@ -1263,6 +1285,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   if (prog_rm && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm, kname + "_rm", 1, false, rm_bufs));
   if (prog_rm_acc && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm_acc, kname + "_rm_acc", 1, true, rm_bufs));
   if (coop && coop->supported) { ks.push_back(emit_coop(E, p, *coop, kname + "_coop")); ks.back().wg = 64 * coop->n_wave; }
+  if (pool && pool->supported) { ks.push_back(emit_coop(E, p, *pool, kname + "_pool")); ks.back().wg = 64 * pool->n_wave; }
   std::ostringstream &os = E.os;
   os << "\t.text\n\t.amdgpu_metadata\n---\namdhsa.kernels:\n";
   const char *kinds[18] = {"global_buffer", "by_value", "by_value", "global_buffer", "by_value", "by_value",

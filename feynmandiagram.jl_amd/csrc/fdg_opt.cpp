@@ -80,6 +80,7 @@ struct Builder {
   // come back through the HBM panel for every use; its operands -- lower-order sub-diagrams that many nodes keep reading --
   // usually are still on chip.  Roots are exempt.
   bool keep_root_order = false;
+  const std::vector<uint8_t> *root_mask = nullptr;   // pool programs: [R] the roots this wave computes and stores (others are not its business)
   uint32_t term_window = 1, term_recent = 400;    // out-of-order evaluation of a wide node's terms (see build_uops)
   uint64_t remat_window = 0;
   uint32_t remat_cost = 8;
@@ -435,7 +436,7 @@ void build_uops(Builder &B) {
   std::vector<std::vector<uint32_t>> roots_of((size_t)0);
   std::vector<std::pair<uint32_t, uint32_t>> rootlist;
   for (uint32_t k = 0; k < p.R; ++k)
-    if (p.root_slot[k] != FDG_NO_ROOT) rootlist.push_back({p.root_slot[k], k});
+    if (p.root_slot[k] != FDG_NO_ROOT && (!B.root_mask || (*B.root_mask)[k])) rootlist.push_back({p.root_slot[k], k});
   std::sort(rootlist.begin(), rootlist.end());
   auto emit_roots = [&](uint32_t v) {
     auto it = std::lower_bound(rootlist.begin(), rootlist.end(), std::make_pair(v, 0u));
@@ -676,6 +677,9 @@ struct Alloc {
   std::vector<uint32_t> free_land;
   uint32_t n_land = 0, n_acc_spill = 0;
   const int evict_cost = std::getenv("FDG_EVICT_COST") ? std::atoi(std::getenv("FDG_EVICT_COST")) : 2;    // read per program (see take_reg)
+  // pooled programs: a leaf comes back from the shared pool by an LDS read, so it is the cheapest thing to evict and is not parked anywhere
+  const double pool_leaf_cost = std::getenv("FDG_POOL_LEAF_COST") ? std::atof(std::getenv("FDG_POOL_LEAF_COST")) : 0.4;
+  const bool pool_nopark = std::getenv("FDG_POOL_NOPARK") != nullptr;
   std::vector<MOp> out;
   OptProgram &prog;
 
@@ -749,7 +753,7 @@ struct Alloc {
         double score;
         if (nu == std::numeric_limits<uint32_t>::max()) score = 1e30;
         else {
-          const double c = home_kind[v] == 0 ? (double)evict_cost : (home_kind[v] == 1 || home_kind[v] == 4 ? 0.5 : 1.0);
+          const double c = home_kind[v] == 0 ? (double)evict_cost : (home_kind[v] == 1 || home_kind[v] == 4 ? 0.5 : (home_kind[v] == 3 && prm.pool_leaves ? pool_leaf_cost : 1.0));
           score = (double)(nu - pos) / c;
         }
         if (score > best_score) { best_score = score; best = r; best_nu = nu; }
@@ -764,6 +768,17 @@ struct Alloc {
     const uint32_t v = owner[best];
     if (home_kind[v] == 0) {            // only copy is in the register: spill it
       uint32_t s;
+      if (prm.pool_leaves && free_lds.empty() && lds_next >= prm.n_lds && free_acc.empty() && acc_next >= n_acc_spill) {
+        // pooled programs: a leaf parked in an LDS slot or an AGPR pair gives its place to a value that would otherwise go to the HBM panel
+        // (the leaf comes back from the shared pool); the parked leaf that is needed again last goes
+        uint32_t drop = NONE, drop_nu = 0;
+        for (uint32_t x = leaf_lo; x < leaf_lo + leaf_n; ++x) {
+          if ((home_kind[x] != 1 && home_kind[x] != 4) || reg_of[x] != NONE) continue;
+          const uint32_t nu = next_use(x);
+          if (drop == NONE || nu > drop_nu) { drop = x; drop_nu = nu; }
+        }
+        if (drop != NONE) { (home_kind[drop] == 1 ? free_lds : free_acc).push_back(home_slot[drop]); home_kind[drop] = 3; }
+      }
       if (get_lds(s)) { out.push_back(MOp{M_ST_LDS, 0, 0, s, best, 0, 0.0}); home_kind[v] = 1; home_slot[v] = s; prog.n_st_lds++; }
       else if (get_acc(s)) { out.push_back(MOp{M_ST_ACC, 0, 0, s, best, 0, 0.0}); home_kind[v] = 4; home_slot[v] = s; prog.n_st_acc++; }
       else { s = get_mem(); out.push_back(MOp{M_ST_MEM, 0, 0, s, best, 0, 0.0}); home_kind[v] = 2; home_slot[v] = s; prog.n_st_mem++; }
@@ -771,7 +786,7 @@ struct Alloc {
       // a leaf: re-loadable from its source; park it in LDS when there is room so
       // the next use does not go back to HBM
       uint32_t s;
-      if (next_use(v) != std::numeric_limits<uint32_t>::max()) {
+      if (next_use(v) != std::numeric_limits<uint32_t>::max() && !(prm.pool_leaves && pool_nopark)) {
         if (get_lds(s)) { out.push_back(MOp{M_ST_LDS, 0, 0, s, best, 0, 0.0}); home_kind[v] = 1; home_slot[v] = s; prog.n_st_lds++; }
         else if (get_acc(s)) { out.push_back(MOp{M_ST_ACC, 0, 0, s, best, 0, 0.0}); home_kind[v] = 4; home_slot[v] = s; prog.n_st_acc++; }
       }
@@ -1482,6 +1497,256 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
     out.wave[w].ops.swap(A.out);
     hoist_loads(out.wave[w].ops, out.wave[w].params);
     sort_load_runs(out.wave[w].ops);
+  }
+  out.supported = true;
+}
+
+
+// =====================================================================================================================
+// Pooled cooperative variant (fdg_opt.h: build_pool_program).
+// =====================================================================================================================
+void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out, uint32_t NW, uint32_t epoch_ops, uint32_t ahead) {
+  out = CoopProgram();
+  out.n_wave = NW;
+  out.pooled = true;
+  const uint32_t L = p.L;
+  if (NW < 2 || NW > CoopProgram::MAXW) { out.why = "bad wave count"; return; }
+  if (p.sched_group.size() == p.N && p.N) { out.why = "schedule groups are not part of the pooled variant"; return; }
+  if (const char *e = std::getenv("FDG_POOL_EPOCH_OPS")) epoch_ops = (uint32_t)std::max(16, std::atoi(e));
+  if (const char *e = std::getenv("FDG_POOL_AHEAD")) ahead = (uint32_t)std::max(1, std::atoi(e));
+  if (!epoch_ops) epoch_ops = 128;
+  if (!ahead) ahead = 8;
+  // ---- roots to waves: largest cone first, to the wave where it adds the least to the heaviest load ----------------------------
+  std::vector<std::pair<uint32_t, uint32_t>> rootlist;
+  for (uint32_t k = 0; k < p.R; ++k) if (p.root_slot[k] != FDG_NO_ROOT) rootlist.push_back({p.root_slot[k], k});
+  std::vector<uint32_t> root_nodes;             // distinct internal nodes that are roots
+  for (auto &rk : rootlist) if (rk.first >= L) root_nodes.push_back(rk.first - L);
+  std::sort(root_nodes.begin(), root_nodes.end());
+  root_nodes.erase(std::unique(root_nodes.begin(), root_nodes.end()), root_nodes.end());
+  if (root_nodes.size() < 2 * (size_t)NW) { out.why = "fewer than two roots per wave: nothing to deal"; return; }
+  const size_t W64 = ((size_t)p.N + 63) / 64;
+  auto fold_cost = [&](uint32_t n) {
+    uint32_t c = p.off[n + 1] - p.off[n] - 1;
+    for (uint32_t e = p.off[n]; e < p.off[n + 1]; ++e) if (p.fac[e] != 1.0 && p.fac[e] != -1.0) c++;
+    if (p.op[n] == FDG_OP_POWER) c += 2;
+    return c;
+  };
+  std::vector<std::vector<uint64_t>> cone(root_nodes.size(), std::vector<uint64_t>(W64, 0));
+  std::vector<uint64_t> csize(root_nodes.size(), 0);
+  {
+    std::vector<uint32_t> stk;
+    for (size_t r = 0; r < root_nodes.size(); ++r) {
+      stk.assign(1, root_nodes[r]);
+      cone[r][root_nodes[r] >> 6] |= 1ull << (root_nodes[r] & 63);
+      while (!stk.empty()) {
+        const uint32_t n = stk.back(); stk.pop_back();
+        csize[r] += fold_cost(n);
+        for (uint32_t e = p.off[n]; e < p.off[n + 1]; ++e) {
+          const uint32_t c = p.idx[e];
+          if (c >= L && !((cone[r][(c - L) >> 6] >> ((c - L) & 63)) & 1)) { cone[r][(c - L) >> 6] |= 1ull << ((c - L) & 63); stk.push_back(c - L); }
+        }
+      }
+    }
+  }
+  // Largest cone first, each to the wave where load + affinity * (fold steps it adds there) is smallest: roots that share sub-expressions
+  // gather on one wave (what two waves both need is computed twice), and the waves finish together.  (FDG_POOL_DEAL=overlap deals in
+  // order_roots' order instead -- neighbours of that order on different waves at the same time: measured on the 4-loop GV vertex function
+  // that doubles the duplicated fold steps, 16 617 -> 67 062, and the pool traffic.)
+  std::vector<size_t> deal(root_nodes.size());
+  for (size_t i = 0; i < deal.size(); ++i) deal[i] = i;
+  if (!(std::getenv("FDG_POOL_DEAL") && std::string(std::getenv("FDG_POOL_DEAL")) == "overlap")) {
+    std::sort(deal.begin(), deal.end(), [&](size_t a, size_t b) { return csize[a] > csize[b] || (csize[a] == csize[b] && a < b); });
+  } else {
+    std::vector<uint32_t> ordered = root_nodes;
+    order_roots(p, ordered);
+    std::vector<size_t> pos(p.N, 0);
+    for (size_t i = 0; i < root_nodes.size(); ++i) pos[root_nodes[i]] = i;
+    for (size_t i = 0; i < ordered.size(); ++i) deal[i] = pos[ordered[i]];
+  }
+  std::vector<std::vector<uint64_t>> have(NW, std::vector<uint64_t>(W64, 0));
+  std::vector<uint64_t> load(NW, 0);
+  std::vector<uint32_t> wave_of_node(p.N, NONE);
+  const double affinity = std::getenv("FDG_POOL_AFFINITY") ? std::atof(std::getenv("FDG_POOL_AFFINITY")) : 2.0;
+  for (size_t r : deal) {
+    uint32_t best = 0; uint64_t best_load = ~0ull;
+    std::vector<uint64_t> add(NW, 0);
+    for (uint32_t w = 0; w < NW; ++w) {
+      uint64_t a = 0;
+      for (size_t i = 0; i < W64; ++i) {
+        uint64_t m = cone[r][i] & ~have[w][i];
+        while (m) { const uint32_t n = (uint32_t)(i * 64 + (size_t)__builtin_ctzll(m)); a += fold_cost(n); m &= m - 1; }
+      }
+      add[w] = a;
+      const uint64_t score = load[w] + (uint64_t)(affinity * (double)a);
+      if (score < best_load) { best_load = score; best = w; }
+    }
+    load[best] += add[best];
+    for (size_t i = 0; i < W64; ++i) have[best][i] |= cone[r][i];
+    wave_of_node[root_nodes[r]] = best;
+  }
+  uint64_t total_cost = 0, single_cost = 0;
+  for (uint32_t w = 0; w < NW; ++w) total_cost += load[w];
+  for (uint32_t n = 0; n < p.N; ++n) if (p.live[L + n]) single_cost += fold_cost(n);
+  out.n_duplicate = total_cost > single_cost ? total_cost - single_cost : 0;
+  // ---- every wave's schedule: the ordinary depth-first fold order over its own roots (own value numbering) ----------------------
+  std::vector<std::vector<uint8_t>> mask(NW, std::vector<uint8_t>(p.R, 0));
+  for (auto &rk : rootlist) mask[rk.first < L ? 0 : wave_of_node[rk.first - L]][rk.second] = 1;      // (roots that are leaves: wave 0 stores them)
+  std::vector<std::unique_ptr<Builder>> B;
+  for (uint32_t w = 0; w < NW; ++w) {
+    B.emplace_back(new Builder(p));
+    B[w]->value_numbering = prm.vn_window != 1;
+    B[w]->vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
+    B[w]->root_mask = &mask[w];
+    build_uops(*B[w]);                 // (order_roots inside orders the wave's own roots by what they share)
+    if (!B[w]->ok) { out.why = B[w]->why; return; }
+  }
+  // ---- registers per wave: leaves are re-loadable (from the pool: a short LDS read) ---------------------------------------------------------
+  out.n_priv_lds = NW <= 4 ? 16 : (NW == 8 ? 8 : 4);
+  if (const char *e = std::getenv("FDG_COOP_PRIV_LDS")) out.n_priv_lds = (uint32_t)std::max(1, std::min(70, std::atoi(e)));
+  out.n_shared = std::min<uint32_t>(256, 312 - NW * out.n_priv_lds);
+  if (const char *e = std::getenv("FDG_POOL_SLOTS")) out.n_shared = (uint32_t)std::max(8, std::min<int>((int)out.n_shared, std::atoi(e)));
+  for (uint32_t w = 0; w < NW; ++w) {
+    OptParams q = prm;
+    q.n_lds = out.n_priv_lds;
+    q.n_land = 0;
+    q.pool_leaves = true;
+    q.lookahead_leaf = std::min<uint32_t>(prm.lookahead_lds ? prm.lookahead_lds : 32, 64);      // a pool read is an LDS read
+    if (const char *e = std::getenv("FDG_POOL_READ_AHEAD")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(e));
+    if (!fit_registers(B[w]->u, q, out.wave[w])) { out.why = out.wave[w].why; return; }
+    Alloc A(p, out.wave[w].params, B[w]->u, B[w]->next_vid, out.wave[w]);
+    A.run();
+    out.wave[w].ops.swap(A.out);
+    hoist_loads(out.wave[w].ops, out.wave[w].params);
+  }
+  // ---- epochs.  The waves meet at a barrier every `epoch_ops` fold steps' worth of ESTIMATED TIME (in units of one fp64 op = four cycles):
+  //      the moves to and from AGPRs, the LDS accesses and the share of the pool fetches a wave issues are counted too, so that the waves
+  //      arrive together (by op count alone they arrive up to a quarter of an epoch apart, and every barrier then costs that).  Epoch 0, in
+  //      front of the opening barrier, only fetches.
+  auto op_time = [](const MOp &o) -> uint32_t {
+    switch (o.kind) {
+      case M_LD_ACC: case M_ST_ACC: return 2;
+      case M_LD_LEAF: case M_LD_LDS: case M_ST_LDS: case M_LD_MEM: case M_ST_MEM: case M_ROOT: return 1;
+      case M_BARRIER: return 0;
+      default: return 1 + mop_tmp_pairs(o.kind) * 4;
+    }
+  };
+  uint32_t n_epoch = 1;
+  {
+    uint64_t longest = 0;
+    for (uint32_t w = 0; w < NW; ++w) { uint64_t t = 0; for (const MOp &o : out.wave[w].ops) t += op_time(o); longest = std::max(longest, t); }
+    n_epoch = 1 + (uint32_t)((longest + epoch_ops - 1) / epoch_ops);
+  }
+  for (uint32_t w = 0; w < NW; ++w) {
+    std::vector<MOp> r;
+    r.reserve(out.wave[w].ops.size() + n_epoch);
+    r.push_back(MOp{M_BARRIER, 0, 0, 0, 0, 0, 0.0});
+    uint64_t t = 0; uint32_t nb = 1;
+    for (const MOp &o : out.wave[w].ops) {
+      r.push_back(o);
+      t += op_time(o);
+      while (nb < n_epoch && t >= (uint64_t)nb * epoch_ops) { r.push_back(MOp{M_BARRIER, 0, 0, 0, 0, 0, 0.0}); nb++; }
+    }
+    for (; nb < n_epoch; ++nb) r.push_back(MOp{M_BARRIER, 0, 0, 0, 0, 0, 0.0});
+    if (r.back().kind != M_BARRIER) { out.why = "internal: a pooled program does not end at a barrier"; return; }
+    out.wave[w].ops.swap(r);
+    out.wave[w].n_barrier = n_epoch;
+  }
+  out.n_epoch = n_epoch;
+  // ---- the pool: which leaf sits in which slot during which epochs (offline Belady at epoch granularity over all waves' reads) -----------
+  const uint32_t P = out.n_shared;
+  std::vector<std::vector<uint32_t>> read_ep(L);            // [leaf] epochs in which some wave reads it (ascending, unique)
+  for (uint32_t w = 0; w < NW; ++w) {
+    uint32_t e = 0;
+    for (const MOp &o : out.wave[w].ops) {
+      if (o.kind == M_BARRIER) { e++; continue; }
+      if (o.kind == M_LD_LEAF) read_ep[o.a].push_back(e);
+      if (o.kind == M_LD_LEAF_ACC) { out.why = "landing slots are not part of the pooled variant"; return; }
+    }
+  }
+  std::vector<std::vector<uint32_t>> need(n_epoch + 1);     // [epoch] leaves read in it
+  for (uint32_t l = 0; l < L; ++l) {
+    auto &v = read_ep[l];
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    for (uint32_t e : v) { if (e == 0 || e > n_epoch) { out.why = "internal: a leaf is read outside the compute epochs"; return; } need[e].push_back(l); }
+  }
+  struct Fetch { uint32_t leaf, slot, issue, ready; };
+  std::vector<Fetch> fetches;
+  std::vector<uint32_t> slot_of(L, NONE);                   // resident leaf -> slot
+  std::vector<uint32_t> in_slot(P, NONE), last_read(P, 0);  // slot -> leaf; last epoch in which the slot's content is read (as planned so far)
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> resid(L);   // [leaf] (first epoch readable, slot) per residency, ascending
+  auto next_read = [&](uint32_t l, uint32_t from) -> uint32_t {     // first read epoch >= from
+    auto &v = read_ep[l];
+    auto it = std::lower_bound(v.begin(), v.end(), from);
+    return it == v.end() ? std::numeric_limits<uint32_t>::max() : *it;
+  };
+  for (uint32_t e = 1; e <= n_epoch; ++e) {                 // epoch whose reads must be resident
+    const uint32_t first_issue = e > ahead ? e - ahead : 0;
+    static const uint32_t far = std::getenv("FDG_POOL_FAR") ? (uint32_t)std::atoi(std::getenv("FDG_POOL_FAR")) : 64;
+    for (uint32_t l : need[e]) {
+      if (slot_of[l] != NONE) { last_read[slot_of[l]] = std::max(last_read[slot_of[l]], e); continue; }
+      // The fetch is issued `ahead` epochs before the read when a slot is free by then, else as early after that as one becomes free
+      // (memory latency is a few epochs; the pool is small: the prefetch distance adapts to how much of it the epochs around need).
+      // Victim at a given issue epoch: an empty slot, else the slot nobody reads from that epoch on whose content is needed again farthest
+      // in the future (and not before the new content is).
+      uint32_t best = NONE, issue = first_issue;
+      for (; issue < e && best == NONE; ++issue) {
+        uint64_t best_key = 0;
+        for (uint32_t s2 = 0; s2 < P; ++s2) {
+          if (in_slot[s2] == NONE) { best = s2; break; }
+          if (last_read[s2] >= issue) continue;                          // (still being read when the fetch would be issued)
+          const uint32_t nr = next_read(in_slot[s2], issue);
+          if (nr <= e) continue;                                         // needed again before (or when) the new content is: keep it
+          // an EARLY fetch only takes a slot whose content is dead or far from its next read: being early must not cost a re-fetch
+          if (issue + 2 < e && nr != std::numeric_limits<uint32_t>::max() && nr <= e + far) continue;
+          const uint64_t key = (uint64_t)nr + 1;
+          if (key > best_key) { best_key = key; best = s2; }
+        }
+        if (best != NONE) break;
+      }
+      if (best == NONE) { out.why = "leaf pool exhausted"; return; }
+      if (in_slot[best] != NONE) slot_of[in_slot[best]] = NONE;
+      in_slot[best] = l; slot_of[l] = best; last_read[best] = e;
+      fetches.push_back(Fetch{l, best, issue, e});
+      resid[l].push_back({e, best});
+    }
+  }
+  out.n_fetch = fetches.size();
+  out.n_transfer = fetches.size();
+  if (std::getenv("FDG_POOL_DEBUG")) {
+    std::vector<uint32_t> hist(ahead + 2, 0);
+    uint64_t sum = 0;
+    for (const Fetch &f : fetches) { hist[std::min<uint32_t>(f.ready - f.issue, ahead + 1)]++; sum += f.ready - f.issue; }
+    std::fprintf(stderr, "[pool] %zu fetches, issued %.2f epochs of %u ops ahead on average;", fetches.size(), fetches.empty() ? 0.0 : (double)sum / (double)fetches.size(), epoch_ops);
+    for (uint32_t k = 1; k < hist.size(); ++k) std::fprintf(stderr, " %u:%u", k, hist[k]);
+    std::fprintf(stderr, "\n");
+  }
+  // ---- fetch ops into the waves' lists (round robin, right after the barrier that opens the issue epoch); leaf reads become pool reads -----
+  std::vector<std::vector<std::vector<Fetch>>> at(NW, std::vector<std::vector<Fetch>>(n_epoch + 1));
+  for (size_t i = 0; i < fetches.size(); ++i) at[i % NW][fetches[i].issue].push_back(fetches[i]);
+  for (uint32_t w = 0; w < NW; ++w) {
+    std::vector<MOp> r;
+    r.reserve(out.wave[w].ops.size() + fetches.size() / NW + 8);
+    uint32_t e = 0;
+    auto put_fetches = [&](uint32_t ep) {
+      for (const Fetch &f : at[w][ep]) { MOp m{M_POOL_FETCH, 0, 0, f.slot, f.leaf, 0, (double)f.ready}; r.push_back(m); }
+    };
+    put_fetches(0);       // epoch 0 is what precedes the program's opening barrier
+    for (const MOp &o : out.wave[w].ops) {
+      if (o.kind == M_BARRIER) { r.push_back(o); e++; if (e <= n_epoch) put_fetches(e); continue; }
+      if (o.kind == M_LD_LEAF) {
+        uint32_t slot = NONE;
+        for (const auto &pr : resid[o.a]) if (pr.first <= e) slot = pr.second;      // the residency that covers epoch e: the last one that started by then
+        if (slot == NONE) { out.why = "internal: leaf read without a residency"; return; }
+        MOp m{M_RECV, 0, 0, o.d, slot, 0, 0.0};
+        r.push_back(m);
+        out.wave[w].n_recv++;
+        continue;
+      }
+      r.push_back(o);
+    }
+    out.wave[w].n_ld_leaf = 0;
+    out.wave[w].ops.swap(r);
   }
   out.supported = true;
 }

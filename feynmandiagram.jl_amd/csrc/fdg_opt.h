@@ -51,8 +51,11 @@ enum MKind : uint8_t {
   M_BARRIER = 27, // s_barrier (every wave's program has the same number of them per tile)
   // ---- one-wave configuration: leaf loads land in AGPR pairs long before their use (no VGPR is tied up by a load in flight) ----
   M_LD_LEAF_ACC = 28, // acc[d] = leaf[a]                     (global_load into the AGPR pair; M_LD_ACC moves it to a VGPR pair at its use)
+  // ---- pooled cooperative variant: the tile's leaves go from memory into a shared LDS pool once (LDS-direct loads, no register in between,
+  //      issued epochs ahead) and every wave reads them from there (M_RECV) ----
+  M_POOL_FETCH = 29,  // shared[d] = leaf[a]                  readable from epoch (uint32_t)imm on; the issuing wave waits for it before the barrier in front
 };
-inline bool mop_has_a(uint8_t k) { return k != M_RECV && k != M_BARRIER; }
+inline bool mop_has_a(uint8_t k) { return k != M_RECV && k != M_BARRIER && k != M_POOL_FETCH; }
 inline bool mop_has_b(uint8_t k) { return k == M_MUL || k == M_ADD || k == M_FMA || k == M_SEL || k == M_FMAK; }
 inline bool mop_has_c(uint8_t k) { return k == M_FMA || k == M_FMAC || k == M_SEL; }
 inline bool mop_is_macro(uint8_t k) { return (k >= M_EXP && k <= M_SELC) || k == M_DIV1; }   // needs the emitter's temporaries
@@ -94,6 +97,7 @@ struct OptParams {
                                   // Float64 in the reference's generic function; as a sign on the operand it would not)
   bool mul_keeps_signs = false;   // schedules for ComplexF64 values: a product consumes a negated operand as it is instead of pulling the sign
                                   // out -- ((-z) w) and -(z w) differ in the sign of a real part that cancels exactly
+  bool pool_leaves = false;       // pooled cooperative programs: leaves are re-read from the shared LDS pool (cheap to evict, never parked)
   uint32_t reserve_pairs = 0;     // VGPR pairs the kernel variant keeps above the values (accumulators, weight): the value budget shrinks
                                   // by this and by the temporaries the program's macro ops need, so that everything stays below v256
 };
@@ -133,7 +137,7 @@ bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp>
 struct CoopProgram;
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2 = nullptr,
                      const OptProgram *prog_acc = nullptr, const OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0,
-                     const CoopProgram *coop = nullptr, const OptProgram *prog_rm_acc = nullptr);
+                     const CoopProgram *coop = nullptr, const OptProgram *prog_rm_acc = nullptr, const CoopProgram *pool = nullptr);
 
 // Cooperative variant: the four waves of a CU (one per SIMD) evaluate ONE 64-sample tile together.  Each wave runs its own
 // straight-line program on its share of the graph with its own registers, AGPRs, private LDS slots and panel; a value
@@ -149,10 +153,20 @@ struct CoopProgram {
   uint32_t n_epoch = 0;        // barriers per tile
   uint64_t n_transfer = 0;     // values handed over per tile
   uint64_t n_duplicate = 0;    // fold steps computed by more than one wave
+  bool pooled = false;         // build_pool_program: leaves come through the shared pool (M_POOL_FETCH / M_RECV); needs sample stride 1, leaf
+                               // offsets below 2^31 bytes from the tile's base (tile-major batches) and full 64-sample tiles
+  uint64_t n_fetch = 0;        // pooled: leaf fetches from memory per tile (>= the live leaves; what exceeds them was evicted from the pool and came again)
   bool supported = false;
   std::string why;
 };
 void build_coop_program(const Lowered &p, const OptParams &prm, CoopProgram &out, uint32_t n_wave = 4);
+// Pooled cooperative variant: whole roots are dealt to the waves of a CU (balanced by the fold steps each adds), every wave runs the ordinary
+// depth-first schedule on its roots, and NO wave loads a leaf from memory into a register: leaves are fetched into a shared LDS pool by
+// LDS-direct loads `ahead` epochs before their first reader needs them and stay there while any wave still reads them (offline Belady over
+// the merged read sequence of all waves at epoch granularity).  The vertex functions of the reference's two benchmark programs re-read their
+// leaves 2-3 times in the one-wave kernels because 324 on-chip values per sample cannot hold their 1000-1500 leaves; a CU's eight waves and the
+// pool together hold 1200.
+void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out, uint32_t n_wave = 8, uint32_t epoch_ops = 0, uint32_t ahead = 0);
 
 void rm_plan_stats(const Lowered &p, const OptProgram &prog, uint32_t bufs, uint64_t &fetches, uint64_t &gathers);
 // gfx950 wait-state table of the emitter (fdg_isa.cpp): check of a finished listing, and the table as text

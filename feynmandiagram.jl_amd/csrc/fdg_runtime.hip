@@ -423,6 +423,7 @@ static int ensure_module(fdg_graph *g) {
     if (g->has_rm) { hipFunction_t f4; HIP_TRY(hipModuleGetFunction(&f4, m, "fdg_isa_eval_rm")); g->fn_isa_rm = f4; }
     if (g->has_rm_acc) { hipFunction_t f6; HIP_TRY(hipModuleGetFunction(&f6, m, "fdg_isa_eval_rm_acc")); g->fn_isa_rm_acc = f6; }
     if (g->has_coop) { hipFunction_t f5; HIP_TRY(hipModuleGetFunction(&f5, m, "fdg_isa_eval_coop")); g->fn_isa_coop = f5; }
+    if (g->has_pool) { hipFunction_t f6; HIP_TRY(hipModuleGetFunction(&f6, m, "fdg_isa_eval_pool")); g->fn_isa_pool = f6; }
     return FDG_OK;
   }
   hipFunction_t f1, f2;
@@ -611,6 +612,25 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // the kernel forms a lane's offset (lane * stride * 8) in 32 bits: strides that large are brought into the
     // leaf-major workspace first (leaves) or refused (roots); neither occurs with the layouts of DESIGN.md 2
     const bool wide_ss = ss < 0 || ss >= (1ll << 23);           // (the offset is unsigned: negative strides too)
+    // Pooled cooperative variant: one workgroup per CU walks full 64-sample tiles; a leaf's 64 samples must be contiguous (the pool fetch
+    // reads 16 bytes per lane) and every leaf within 2^31 bytes of the tile's first -- tile-major batches, or small leaf-major matrices.
+    // The last B % 64 samples go through the one-wave kernel.
+    if (mode == 0 && g->has_pool && g->fn_isa_pool && ss == 1 && ls > 0 && (uint64_t)ls * 8u * (uint64_t)std::max<uint32_t>(p.L, 1) < (1ull << 31) && B >= 64 &&
+        !(rs < 0 || rs >= (1ll << 23)) && !std::getenv("FDG_ISA_NO_POOL")) {
+      const long n4 = (long)(B & ~(int64_t)63), tail = (long)B - n4;
+      long nwg = std::min<long>(n4 / 64, (long)g->n_cu), lss = ss, lls = ls, rrs = rs, rrk = rk;
+      rc = ensure_ws(g, std::max(panel_all + (size_t)grid3 * R * 512u + 4096, (size_t)g->pool_panel_wg * (size_t)nwg + 4096));
+      if (rc) return rc;
+      void *a_wsp = g->d_ws;
+      const double *nowt = nullptr;
+      long tls = lts ? (long)lts : 64 * lss, trs = rts ? (long)rts : 64 * rrs, nn = n4;
+      void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt, &tls, &trs};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_pool, (unsigned)nwg, 1, 1, g->pool_threads, 1, 1, 0, st, args, nullptr));
+      g->last_kernel = "fdg_isa_eval_pool";
+      named = true;
+      if (tail) { rc = launch_isa(d_leaf + (size_t)(n4 / 64) * (size_t)tls, lss, lls, d_root + (size_t)(n4 / 64) * (size_t)trs, rrs, rrk, tail, lts ? tls : 0, rts ? trs : 0); if (rc) return rc; }
+      return FDG_OK;
+    }
     // Cooperative variant: one workgroup of four waves per CU, every workgroup walks tiles of 64 samples; leaf-major input.
     if (mode == 0 && g->has_coop && g->coop_enabled && g->fn_isa_coop && !(ls == 1 && ss != 1 && p.L > 1) && !wide_ss && !(rs < 0 || rs >= (1ll << 23)) &&
         !std::getenv("FDG_ISA_NO_COOP")) {
@@ -1046,6 +1066,7 @@ int fdg_graph_kernel_info(fdg_graph *g, fdg_kernel_info *o) {
   if (g->has_acc) o->waves_per_cu[1] = wpc(g->isa3_vgpr, g->isa3_lds_bytes);
   if (g->has_rm) o->waves_per_cu[2] = wpc(g->isa4_vgpr, g->isa4_lds_bytes);
   o->has_acc = g->has_acc; o->has_rm = g->has_rm; o->has_coop = g->has_coop && g->coop_enabled; o->rm_bufs = g->rm_bufs;
+  o->has_pool = g->has_pool; o->pool_fetch = g->pool_fetch; o->pool_valu = g->pool_valu;
   return FDG_OK;
 }
 
@@ -1121,6 +1142,36 @@ int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop *
 // waves of a cooperative workgroup: 8 (two per SIMD, 256 registers each: the second wave covers memory latency) unless asked otherwise
 static uint32_t coop_waves() { const char *e = std::getenv("FDG_COOP_WAVES"); const int n = e ? std::atoi(e) : 8; return n == 4 ? 4u : (n == 16 ? 16u : 8u); }
 
+// parameters of the pooled cooperative variant: four waves, one per SIMD, with the AGPR level (eight waves of 256 registers each -- FDG_POOL_WAVES=8 --
+// spill to the panel and compute a quarter of the fold steps twice on the 4-loop vertex functions)
+static uint32_t pool_waves() { const char *e = std::getenv("FDG_POOL_WAVES"); const int n = e ? std::atoi(e) : 4; return n == 8 ? 8u : 4u; }
+static fdg::OptParams pool_params(fdg::OptParams q, uint32_t nw) {
+  q.n_reg = std::min<uint32_t>(q.n_reg ? q.n_reg : 120, 120);
+  q.n_acc = nw >= 8 ? 0 : 124;
+  q.n_land = 0;
+  q.lookahead_lds = 32;
+  return q;
+}
+
+static int coop_program_out(const fdg::CoopProgram &cp, uint32_t wave, fdg_mop **ops, uint64_t *n_ops, uint32_t *info);
+// (shorter epochs read fewer leaves at a time: tried when the pool cannot hold what a window of epochs reads)
+static void build_pool_auto(const fdg::Lowered &p, const fdg::OptParams &q, fdg::CoopProgram &cp, uint32_t nw) {
+  for (uint32_t ep : {128u, 64u, 32u, 16u}) {
+    fdg::build_pool_program(p, q, cp, nw, ep, 0);
+    if (cp.supported || cp.why != "leaf pool exhausted") break;
+  }
+}
+
+int fdg_graph_pool_program(const fdg_graph *g, const fdg_opt_params *q, uint32_t wave, fdg_mop **ops, uint64_t *n_ops, uint32_t *info) {
+  if (!g || !ops || !n_ops || wave >= fdg::CoopProgram::MAXW) { set_error("null argument or wave out of range"); return FDG_E_INVALID; }
+  fdg::CoopProgram cp;
+  const uint32_t nw = pool_waves();
+  build_pool_auto(g->prog, pool_params(to_params(q), nw), cp, nw);
+  if (cp.supported && wave >= cp.n_wave) { set_error("wave out of range"); return FDG_E_INVALID; }
+  if (!cp.supported) { set_error("the pooled cooperative variant does not cover this graph: " + cp.why); return FDG_E_UNSUPPORTED; }
+  return coop_program_out(cp, wave, ops, n_ops, info);
+}
+
 int fdg_graph_coop_program(const fdg_graph *g, const fdg_opt_params *q, uint32_t wave, fdg_mop **ops, uint64_t *n_ops, uint32_t *info) {
   if (!g || !ops || !n_ops || wave >= fdg::CoopProgram::MAXW) { set_error("null argument or wave out of range"); return FDG_E_INVALID; }
   fdg::OptParams prm = to_params(q);
@@ -1132,6 +1183,10 @@ int fdg_graph_coop_program(const fdg_graph *g, const fdg_opt_params *q, uint32_t
   fdg::build_coop_program(g->prog, prm, cp, nw);
   if (cp.supported && wave >= cp.n_wave) { set_error("wave out of range"); return FDG_E_INVALID; }
   if (!cp.supported) { set_error("the cooperative variant does not cover this graph: " + cp.why); return FDG_E_UNSUPPORTED; }
+  return coop_program_out(cp, wave, ops, n_ops, info);
+}
+
+static int coop_program_out(const fdg::CoopProgram &cp, uint32_t wave, fdg_mop **ops, uint64_t *n_ops, uint32_t *info) {
   const fdg::OptProgram &prog = cp.wave[wave];
   fdg_mop *m = (fdg_mop *)std::malloc(std::max<size_t>(1, prog.ops.size()) * sizeof(fdg_mop));
   if (!m) { set_error("out of memory"); return FDG_E_NOMEM; }
@@ -1175,8 +1230,8 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
                         std::vector<char> &co, std::string &hash, const fdg::OptProgram *prog2 = nullptr,
                         const fdg::OptProgram *prog_acc = nullptr, const char *kname = "fdg_isa_eval",
                         const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr,
-                        const fdg::OptProgram *prog_rm_acc = nullptr) {
-  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc, prog_rm, rm_bufs, coop, prog_rm_acc);
+                        const fdg::OptProgram *prog_rm_acc = nullptr, const fdg::CoopProgram *pool = nullptr) {
+  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc, prog_rm, rm_bufs, coop, prog_rm_acc, pool);
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
   hash = hbuf;
@@ -1209,8 +1264,18 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
 static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<char> &co, const std::string &hash, unsigned flags,
                         const fdg::OptProgram *prog2 = nullptr, const fdg::OptProgram *prog_acc = nullptr,
                         const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr,
-                        const fdg::OptProgram *prog_rm_acc = nullptr) {
+                        const fdg::OptProgram *prog_rm_acc = nullptr, const fdg::CoopProgram *pool = nullptr) {
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
+  g->has_pool = pool && pool->supported;
+  g->fn_isa_pool = nullptr;
+  if (g->has_pool) {
+    g->pool_panel_wg = 0;
+    for (uint32_t w = 0; w < pool->n_wave; ++w) g->pool_panel_wg += std::max<uint32_t>(pool->wave[w].n_mem_used, 1) * 512u;
+    g->pool_threads = 64 * pool->n_wave;
+    g->pool_fetch = (uint32_t)pool->n_fetch;
+    g->pool_valu = 0;
+    for (uint32_t w = 0; w < pool->n_wave; ++w) g->pool_valu += pool->wave[w].n_valu;
+  }
   g->has_coop = coop && coop->supported;
   g->coop_enabled = g->has_coop;
   g->fn_isa_coop = nullptr;
@@ -1443,7 +1508,7 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
 
 struct IsaVariants {
   fdg::OptProgram p2, pa, pr, pra;
-  fdg::CoopProgram coop;
+  fdg::CoopProgram coop, pool;
   bool w2 = false, acc = false, rm_acc = false;
   uint32_t rm_bufs = 0;
   int coop_verdict = -1;       // a remembered measurement: 0 = the cooperative variant loses, 4 / 8 = it wins with that many waves; -1: none
@@ -1489,15 +1554,33 @@ static void build_variants(const fdg_graph *g, const fdg::OptParams &chosen, boo
                ((V.pra.n_lds_used * 512u + 1023u) & ~1023u) + V.rm_bufs * 8192u <= 160u * 1024u;
   }
 }
+// The pooled cooperative variant (fdg_opt.h: build_pool_program) is assembled for graphs with at least two roots per wave whose one-wave
+// program goes back to memory for what it had already: leaf loads + panel accesses above 1.25 x the live leaves (the two vertex functions
+// of the reference's benchmark programs: 3.0 x and 1.3 x).  FDG_ISA_POOL=1 / 0 forces / forbids.
+static void build_pool(const fdg_graph *g, const fdg::OptProgram &prog, IsaVariants &V) {
+  V.pool = fdg::CoopProgram();
+  const char *e = std::getenv("FDG_ISA_POOL");
+  if (e && e[0] == '0') return;
+  if (g->isa_fma || prog.mc_n_k || prog.mc_n_t) return;
+  if (!(e && e[0] == '1') && (prog.n_ld_leaf + prog.n_ld_mem + prog.n_st_mem) * 4 <= (uint64_t)g->prog.n_live_leaf * 5) return;
+  const uint32_t nw = pool_waves();
+  fdg::OptParams q = pool_params(cfg_B(), nw);
+  q.vn_window = prog.params.vn_window;
+  build_pool_auto(g->prog, q, V.pool, nw);
+  if (std::getenv("FDG_POOL_DEBUG")) std::fprintf(stderr, "[pool] %s: %u waves, %u epochs, %llu fetches for %u leaves, %llu duplicated fold steps (%s)\n", V.pool.supported ? "built" : "not built",
+                                                  V.pool.n_wave, V.pool.n_epoch, (unsigned long long)V.pool.n_fetch, g->prog.n_live_leaf, (unsigned long long)V.pool.n_duplicate, V.pool.why.c_str());
+}
 static int assemble_and_install(fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags, IsaVariants &V) {
   std::vector<char> co; std::string hash;
   if (V.coop_verdict != 0) build_coop(g, prog, V);
+  build_pool(g, prog, V);
   const fdg::CoopProgram *coop = V.coop.supported ? &V.coop : nullptr;
+  const fdg::CoopProgram *pool = V.pool.supported ? &V.pool : nullptr;
   const int rc = assemble_isa(g, prog, dir, flags, co, hash, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, "fdg_isa_eval",
-                              V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop, V.rm_acc ? &V.pra : nullptr);
+                              V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop, V.rm_acc ? &V.pra : nullptr, pool);
   if (rc) return rc;
   install_isa(g, prog, co, hash, flags, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop,
-              V.rm_acc ? &V.pra : nullptr);
+              V.rm_acc ? &V.pra : nullptr, pool);
   return FDG_OK;
 }
 

@@ -163,6 +163,9 @@ typedef struct fdg_kernel_info {
   uint32_t n_lds[3];          /* loads + stores of per-lane LDS slots */
   uint32_t waves_per_cu[3];   /* resident waves per CU the launch uses */
   uint32_t has_acc, has_rm, has_coop, rm_bufs;
+  uint32_t has_pool;          /* the pooled cooperative variant (fdg_isa_eval_pool) is installed: full tiles of batches whose samples of a leaf are contiguous */
+  uint32_t pool_fetch;        /* ... leaf fetches from memory per evaluation (>= the live leaves) */
+  uint64_t pool_valu;         /* ... fold steps executed per evaluation, all waves together */
 } fdg_kernel_info;
 int fdg_graph_kernel_info(fdg_graph *g, fdg_kernel_info *info);
 
@@ -230,6 +233,15 @@ int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *prm, fdg_mop
  * registers, private LDS slots, panel slots, AGPR pairs of this wave; shared slots, barriers per tile, hand-overs per
  * tile, fold steps computed by more than one wave.  Host-only.  FDG_E_UNSUPPORTED when the graph has no wide root sum. */
 int fdg_graph_coop_program(const fdg_graph *g, const fdg_opt_params *prm, uint32_t wave, fdg_mop **ops, uint64_t *n_ops,
+                           uint32_t *info);
+
+/* The programs of the POOLED cooperative variant (fdg_isa_eval_pool): whole roots are dealt to the eight waves of a CU, and no wave
+ * loads a leaf from memory into a register -- the tile's leaves are fetched into a shared LDS pool (kind 29 POOL_FETCH shared[d] =
+ * leaf[a], readable from epoch (uint32)imm on; LDS-direct loads issued epochs ahead by the waves in turn) and read from there (kind 26).
+ * For graphs whose one-wave kernels re-read their leaves (the vertex functions of example/benchmark.jl and example/benchmark_GV.jl).
+ * info as for fdg_graph_coop_program, with info[6] = leaf fetches per tile.  Host-only.  FDG_E_UNSUPPORTED when the graph has fewer
+ * than two roots per wave or the pool cannot hold what an epoch reads. */
+int fdg_graph_pool_program(const fdg_graph *g, const fdg_opt_params *prm, uint32_t wave, fdg_mop **ops, uint64_t *n_ops,
                            uint32_t *info);
 
 /* ---- element types other than Float64 -----------------------------------------------------------------------------

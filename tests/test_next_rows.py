@@ -318,12 +318,17 @@ def test_integer_powers_in_the_optimizing_back_end(libfdg, budget, tmp_path, no_
         assert capi.isa_check_hazards(text)[0] == 0
 
 
+def _issued_in(fetch, slot, epoch):
+    return False        # (reads of a slot with a fetch in flight are caught at the read itself; kept for the assertion's wording)
+
+
 def replay_coop(progs, info, leaf, R):
     """Four wave programs of the cooperative variant, epoch by epoch: a value sent in one epoch is readable from the next
     (writes are committed at the barrier); reading a slot that another wave is overwriting in the same epoch is an error."""
     B = leaf.shape[0]
     shared = np.full((max(info["n_shared"], 1), B), np.nan)
     root = np.zeros((B, R))
+    pool_written = set()
     st = []
     for w, ops in enumerate(progs):
         iw = info["waves"][w]
@@ -331,8 +336,11 @@ def replay_coop(progs, info, leaf, R):
                        mem=np.full((max(iw["n_mem"], 1), B), np.nan), acc=np.full((max(iw["n_acc"], 1), B), np.nan), pc=0))
     n_bar = [int((ops["kind"] == 27).sum()) for ops in progs]
     assert len(set(n_bar)) == 1 and n_bar[0] == info["n_epoch"]
+    fetch = {}          # slot -> (epoch from which it is readable, values): a pool fetch in flight; nobody may read the slot before it has landed
     for _epoch in range(info["n_epoch"]):
         pending, read_slots = {}, set()
+        for slot in [s for s, (rdy, _v) in fetch.items() if rdy <= _epoch]:
+            shared[slot] = fetch.pop(slot)[1]
         for w, ops in enumerate(progs):
             s = st[w]
             reg, lds, mem, acc = s["reg"], s["lds"], s["mem"], s["acc"]
@@ -343,7 +351,10 @@ def replay_coop(progs, info, leaf, R):
                 sb = -1.0 if o["negb"] else 1.0
                 if k == 27: break
                 elif k == 25: assert d not in pending; pending[d] = (w, reg[a].copy())
-                elif k == 26: read_slots.add((a, w)); reg[d] = shared[a]
+                elif k == 26: assert a not in fetch, ("pool slot read while its fetch is in flight", a, _epoch); read_slots.add((a, w)); reg[d] = shared[a]
+                elif k == 29:       # pool fetch: shared[d] = leaf[a], readable from epoch imm on; the slot's old content must not be read any more
+                    assert d not in fetch and int(o["imm"]) > _epoch, ("pool slot fetched twice / ready too early", d, _epoch)
+                    fetch[d] = (int(o["imm"]), leaf[:, a].copy()); shared[d] = np.nan; pool_written.add(d)
                 elif k == 0: reg[d] = leaf[:, a]
                 elif k == 1: reg[d] = lds[a]
                 elif k == 2: reg[d] = mem[a]
@@ -359,6 +370,8 @@ def replay_coop(progs, info, leaf, R):
         for slot, (w, val) in pending.items():
             assert not [1 for (sl, rw) in read_slots if sl == slot and rw != w], ("slot overwritten while still read", slot)
             shared[slot] = val
+        # a slot whose fetch was issued in this epoch may be overwritten at any moment from then on: nobody read it in this epoch
+        assert not [1 for (sl, _rw) in read_slots if sl in fetch and fetch[sl][0] > _epoch and sl in pool_written and _issued_in(fetch, sl, _epoch)], "pool slot read in the epoch its fetch was issued"
     assert all(st[w]["pc"] == len(progs[w]) for w in range(len(progs)))
     return root
 
@@ -379,6 +392,34 @@ def test_cooperative_programs_replay_exactly(libfdg, monkeypatch, name, waves):
     got = replay_coop(progs, info, leaf, t.n_root)
     assert np.array_equal(got, oracle.eval_static(t, leaf))
     assert info["n_transfer"] > 0
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("name", ["parquet_ver4_3", "parquet_ver4_4", "gv_ver4_4"])
+def test_pooled_programs_replay_exactly(libfdg, monkeypatch, name, waves):
+    """The pooled cooperative variant (fdg_opt.h: build_pool_program): whole roots per wave, leaves through the shared LDS pool.  The
+    programs replayed epoch by epoch give the oracle's bits; no wave reads a leaf from memory; a pool slot is never read between the
+    issue of a fetch into it and the epoch from which that fetch is readable; every live leaf is fetched at least once."""
+    monkeypatch.setenv("FDG_POOL_WAVES", str(waves))
+    t = workloads.get(name)
+    h = capi.GraphHandle(t)
+    progs, info = h.pool_program()
+    assert len(progs) == waves
+    assert all(int((p["kind"] == 0).sum()) == 0 for p in progs)            # no LD_LEAF: every leaf read is a pool read
+    n_fetch = sum(int((p["kind"] == 29).sum()) for p in progs)
+    assert n_fetch == info["n_transfer"] >= h.info()["n_live_leaf"]
+    leaf = oracle.philox_uniform(3, t.n_leaf, 81)
+    got = replay_coop(progs, info, leaf, t.n_root)
+    assert np.array_equal(got, oracle.eval_static(t, leaf))
+    if waves == 4 and name == "gv_ver4_4":      # the graph of example/benchmark_GV.jl: memory-side accesses 3.0 x -> below 1.5 x the algorithmic L + R
+        panel = sum(int(np.isin(p["kind"], (2, 4)).sum()) for p in progs)
+        assert n_fetch + panel + t.n_root <= 1.5 * (t.n_leaf + t.n_root)
+
+
+def test_pooled_variant_needs_roots_to_deal(libfdg):
+    with pytest.raises(capi.FdgError) as e:
+        capi.GraphHandle(workloads.get("gv_sigma5")).pool_program()         # two roots: nothing to deal to four waves
+    assert e.value.code == capi.FDG_E_UNSUPPORTED
 
 
 def test_isa_jit_assembles_without_device(libfdg, tmp_path, no_shipped_cache):

@@ -119,3 +119,44 @@ def test_tile_major_batch_of_config_2_size(libfdg, cuda):
     assert torch.equal(flat.view(torch.int64), root_c.view(torch.int64))
     n = 5000
     assert np.array_equal(flat[:n].cpu().numpy(), oracle.eval_static(t, oracle.philox_uniform(n, L, 1234)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,force", [("parquet_ver4_3", True), ("parquet_ver4_4", False), ("gv_ver4_4", False)])
+def test_pooled_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_path, name, force):
+    """fdg_isa_eval_pool: the four waves of a CU evaluate one tile, whole roots each, the tile's leaves fetched once into
+    a shared LDS pool.  Taken for full tiles of tile-major batches (and of leaf-major matrices whose leaves lie within 2 GB); the last
+    B % 64 samples go through the one-wave kernel.  Bit-exact; the graphs of example/benchmark.jl and example/benchmark_GV.jl get it by
+    the library's own criterion, the 3-loop vertex function when forced."""
+    import torch
+    if force:
+        monkeypatch.setenv("FDG_ISA_POOL", "1")
+    t = workloads.get(name)
+    L, R = t.n_leaf, t.n_root
+    f = fd.compile_table(t, specialize="isa", cache_dir=str(tmp_path) if force else None)
+    ki = f.kernel_info()
+    assert ki["has_pool"] == 1 and ki["pool_fetch"] >= f.info()["n_live_leaf"]
+    for B in (64, 4099, 70016):
+        h_leaf = oracle.philox_uniform(B, L, 91)
+        want = oracle.eval_static(t, h_leaf)
+        leaf = torch.from_numpy(to_tiles(h_leaf)).to(cuda)
+        root = torch.full(((B + 63) // 64, R, 64), 9.0, dtype=torch.float64, device=cuda)
+        f.eval_tiled(root, leaf, B)
+        torch.cuda.synchronize()
+        assert f.kernel_info()["last_kernel"] == "fdg_isa_eval_pool"
+        r = root.cpu().numpy()
+        assert np.array_equal(from_tiles(r, B, R), want), (name, B)
+        assert (r.transpose(0, 2, 1).reshape(-1, R)[B:] == 9.0).all()
+    # a leaf-major matrix small enough for 32-bit leaf offsets takes the same kernel; a wide one the one-wave kernel
+    B = 6400
+    h_leaf = oracle.philox_uniform(B, L, 92)
+    leaf = torch.from_numpy(np.ascontiguousarray(h_leaf.T)).to(cuda).t()
+    got = f(None, leaf)
+    torch.cuda.synchronize()
+    assert f.kernel_info()["last_kernel"] == "fdg_isa_eval_pool"
+    assert np.array_equal(got.cpu().numpy(), oracle.eval_static(t, h_leaf))
+    monkeypatch.setenv("FDG_ISA_NO_POOL", "1")
+    got = f(None, leaf)
+    torch.cuda.synchronize()
+    assert f.kernel_info()["last_kernel"].startswith("fdg_isa_eval") and f.kernel_info()["last_kernel"] != "fdg_isa_eval_pool"
+    assert np.array_equal(got.cpu().numpy(), oracle.eval_static(t, h_leaf))
