@@ -61,7 +61,7 @@ DEFAULT_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcas
              "gv_sigma5_taylor2": 1_000_000, "parquet_sigma2": 64_000_000, "parquet_sigma3": 16_000_000, "parquet_sigma4": 100_000_000,
              "parquet_sigma4_dyn": 8_000_000, "parquet_sigma4_insdyn": 4_000_000, "parquet_sigma4_taylor2": 8_000_000,
              "parquet_sigma4_dyn_taylor2": 2_000_000, "parquet_sigma4_insdyn_taylor2": 1_000_000, "parquet_sigma5": 2_000_000,
-             "parquet_ver4_4": 500_000, "gv_ver4_4": 500_000}
+             "parquet_ver4_4": 512_000, "gv_ver4_4": 512_000}          # (whole 64-sample tiles: the pooled cooperative kernel takes full tiles)
 PARITY_NOTE = ("bit-exact vs our restatement of the Julia evaluator (oracle/); the reference's known-answer tests pin structure, "
                "leaf numbering and factors, not the rounding of the n-ary folds")
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/r02_traffic.json from the PMC passes of tools/prof_r02.sh: per workload and layout, HBM-side bytes per
+"""profiles/r04_traffic.json from the PMC passes of tools/prof_pmc_list.sh: per workload and layout, HBM-side bytes per
 evaluation of the evaluator kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / samples  (FETCH_SIZE / WRITE_SIZE in KiB per
 dispatch; the factor 2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md's HBM section, calibrated on sigma2 where
 the byte count is known: 64 B read + 16 B written per evaluation).  usage: make_traffic_json.py gpurun_out/prof_<tag> out.json [r03]"""
@@ -7,9 +7,8 @@ import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root, out_path = sys.argv[1], sys.argv[2]
 TAG = sys.argv[3] if len(sys.argv) > 3 else "r02"        # prefix of the summaries kept under profiles/
-SAMPLES = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "gv_sigma4": 8_000_000, "gv_sigma5": 2_000_000, "gv_sigma6": 500_000,
-           "gv_sigma4_taylor2": 4_000_000, "parquet_sigma4": 100_000_000, "parquet_sigma4_dyn": 8_000_000, "parquet_sigma4_insdyn": 4_000_000,
-           "parquet_sigma4_taylor2": 8_000_000, "parquet_sigma5": 2_000_000, "parquet_ver4_4": 500_000, "gv_ver4_4": 500_000}
+import bench
+SAMPLES = bench.DEFAULT_B           # the batch bench.py --workload W runs without --samples
 if os.path.exists(out_path):          # keep the entries of earlier profile sets: only the workloads found under `root` are replaced
     prev = json.load(open(out_path))
 else:
@@ -17,12 +16,12 @@ else:
 out = {"_comment": "HBM-side traffic of the evaluator kernel from separate rocprofv3 --pmc passes (tools/prof_r02.sh; summaries in "
                    "profiles/r02_pmc_*.txt): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; factor 2 = the guide's gfx950 FETCH_SIZE "
                    "correction, calibrated on sigma2 (80 B per evaluation).  Infinity-Cache hits are included in FETCH_SIZE: this is "
-                   "L2-miss traffic, an upper bound on HBM bytes.  Keys: workload, or workload:sample_major for the row-major layout."}
+                   "L2-miss traffic, an upper bound on HBM bytes.  Keys: workload (leaf-major matrix), workload:tile_major, workload:sample_major."}
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
         continue
     name = os.path.basename(d)[4:]
-    lay = "sample_major" if name.endswith("_sample_major") else "leaf_major"
+    lay = "sample_major" if name.endswith("_sample_major") else ("tile_major" if name.endswith("_tile_major") else "leaf_major")
     wl = name[: -len("_" + lay)]
     vals = {}
     for f in glob.glob(os.path.join(d, "pass*", "**", "*counter_collection.csv"), recursive=True):
