@@ -296,6 +296,8 @@ def kernel_of(f, slot=0):
     name = ki["last_kernel"]
     if name == "fdg_isa_eval_pool":       # the pooled cooperative variant: fold steps of all its waves together
         return name, (ki.get("pool_valu") or None)
+    if name == "fdg_isa_eval_rl":         # the linear row-major variant has its own program
+        return name, (ki.get("rl_valu") or None)
     slot = 1 if "_acc" in name else 2 if name.endswith("_rm") else 0
     return name, (ki["n_valu"][slot] or None)
 

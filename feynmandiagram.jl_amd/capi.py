@@ -77,7 +77,8 @@ class KernelInfo(C.Structure):
     _fields_ = [("last_kernel", C.c_char * 48), ("n_valu", C.c_uint64 * 3), ("n_ld_leaf", C.c_uint32 * 3),
                 ("n_panel", C.c_uint32 * 3), ("n_lds", C.c_uint32 * 3), ("waves_per_cu", C.c_uint32 * 3),
                 ("has_acc", C.c_uint32), ("has_rm", C.c_uint32), ("has_coop", C.c_uint32), ("rm_bufs", C.c_uint32),
-                ("has_pool", C.c_uint32), ("pool_fetch", C.c_uint32), ("pool_valu", C.c_uint64)]
+                ("has_pool", C.c_uint32), ("pool_fetch", C.c_uint32), ("pool_valu", C.c_uint64),
+                ("has_rl", C.c_uint32), ("rl_reserved", C.c_uint32), ("rl_valu", C.c_uint64)]
 
 
 class LeafTables(C.Structure):
@@ -256,7 +257,7 @@ class GraphHandle:
         out = {"last_kernel": ki.last_kernel.decode()}
         for k in ("n_valu", "n_ld_leaf", "n_panel", "n_lds", "waves_per_cu"):
             out[k] = [int(x) for x in getattr(ki, k)]
-        for k in ("has_acc", "has_rm", "has_coop", "rm_bufs", "has_pool", "pool_fetch", "pool_valu"):
+        for k in ("has_acc", "has_rm", "has_coop", "rm_bufs", "has_pool", "pool_fetch", "pool_valu", "has_rl", "rl_valu"):
             out[k] = int(getattr(ki, k))
         return out
 

@@ -226,9 +226,12 @@ class GraphFunc:
             raise capi.FdgError(capi.FDG_E_NO_DEVICE, "no gfx950 device: the evaluator has no CPU fallback")
         vec = leaf.ndim == 1
         d_leaf = torch.from_numpy(np.ascontiguousarray(leaf)).cuda()
+        live = [k for k in range(self.n_root) if int(self.table.root_slot[k]) != FDG_NO_ROOT]
         if vec:
             if leaf.shape[0] < self.n_leaf:
                 raise IndexError(f"BoundsError: attempt to access {leaf.shape[0]}-element leafVal at index [{self.n_leaf}]")
+            if root is None:
+                root = np.zeros(self.n_root, dtype=leaf.dtype)
             if len(root) < self.n_root:
                 raise IndexError(f"BoundsError: attempt to access {len(root)}-element root at index [{self.n_root}]")
         d_root = self._call_torch_typed(None, d_leaf)
@@ -236,13 +239,12 @@ class GraphFunc:
         h = d_root.cpu().numpy()
         if vec:
             h = h.reshape(-1)
-            for k in range(self.n_root):
+            for k in live:                   # (root[k] of an id that is in no graph keeps the caller's value, as in the generated function)
                 root[k] = h[k]
-            slots = [k for k in range(self.n_root) if int(self.table.root_slot[k]) != FDG_NO_ROOT]
-            return h[max(slots, key=lambda k: self._emission_rank(int(self.table.root_slot[k])))] if slots else None
+            return h[max(live, key=lambda k: self._emission_rank(int(self.table.root_slot[k])))] if live else None
         if root is None:
             return h
-        root[...] = h
+        root[:, live] = h[:, live]
         return root
 
     def _call_torch_typed(self, root, leaf):

@@ -140,6 +140,11 @@ struct fdg_graph {
   bool has_coop = false, coop_enabled = false;
   void *fn_isa_coop = nullptr;
   uint32_t coop_panel_wg = 0, coop_lds_bytes = 0, coop_threads = 256;
+  // linear row-major variant: contiguous rows, the tile's block streamed into an LDS image
+  bool has_rl = false;
+  void *fn_isa_rl = nullptr;
+  uint32_t isa6_vgpr = 0, isa6_lds_bytes = 0, isa6_mem_slots = 0;
+  uint64_t rl_valu = 0;
   // pooled cooperative variant: the waves of a CU evaluate one tile, whole roots each, leaves through a shared LDS pool (full tiles, sample stride 1)
   bool has_pool = false;
   void *fn_isa_pool = nullptr;

@@ -430,13 +430,17 @@ static void rm_plan(const Lowered &p, const OptProgram &prog, uint32_t rm_bufs, 
 // & 63; private LDS slots behind the shared ones (addressed through their own base register); the wave's panel inside the
 // workgroup's; M_SEND / M_RECV / M_BARRIER.
 struct CoopSec { uint32_t wave, n_shared, priv_base_bytes, panel_wg_bytes, panel_prefix_bytes; bool pooled = false; };
+// rl: the row-major variant for CONTIGUOUS rows (sample stride == L: compile_Python's [B, L] exactly) of graphs whose tile fits the LDS: a
+// tile's 64 rows are one block of 512 L bytes, streamed linearly into an LDS image by LDS-direct loads (1 KB per instruction, every cache
+// line of the matrix requested exactly once, non-temporal), and leaf i of lane = row r is read from image[r * 8 L + 8 i].
 static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog, const std::string &kname, int W, bool accumulate = false,
-                              uint32_t rm_bufs = 0, const CoopSec *cs = nullptr) {
+                              uint32_t rm_bufs = 0, const CoopSec *cs = nullptr, bool rl = false) {
   E.vm_issued = E.lg_issued = E.vm_done = E.lg_done = 0;
   E.pend.assign(std::max<uint32_t>(prog.n_reg_used, 1), {0, 0});
   const uint32_t SLOT = 512u * W;                 // bytes of one LDS / panel slot of a wave
   const uint32_t stage_base = (prog.n_lds_used * SLOT + 1023u) & ~1023u;
-  const uint32_t lds_bytes = rm_bufs ? stage_base + rm_bufs * RM_BUF_BYTES : prog.n_lds_used * SLOT;
+  const uint32_t rl_image = rl ? ((512u * p.L + 1023u) & ~1023u) : 0u;
+  const uint32_t lds_bytes = rl ? stage_base + rl_image : (rm_bufs ? stage_base + rm_bufs * RM_BUF_BYTES : prog.n_lds_used * SLOT);
   const uint32_t panel_bytes_per_wave = std::max<uint32_t>(prog.n_mem_used, 1) * SLOT;
   const int RW = 2 * W;                           // VGPRs per value
   const int TSH = W == 2 ? 7 : 6;                 // log2(samples per tile)
@@ -532,6 +536,10 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 1) + ", 0x10000, " + V(V_LANE8));
     E.ins("v_lshlrev_b32_e32 v" + std::to_string(rm0 + 2) + ", 4, v0");          // lane * 16: source offset of a pool fetch (lanes 0..31 carry a leaf's 64 samples)
   }
+  if (rl) {
+    E.ins("v_mul_u32_u24_e32 v" + std::to_string(rm0) + ", " + hex32(8u * p.L) + ", v0");      // lane * 8 L: this lane's row inside the image
+    E.ins("v_lshlrev_b32_e32 v" + std::to_string(rm0 + 1) + ", 4, v0");                        // lane * 16: source offset of the linear loads
+  }
   if (rm_bufs) {
     // v[rm0] / v[rm0 + 9]: source offsets of the LDS-direct loads of even / odd instructions n of a chunk -- lane l fetches
     // piece (l % 8) ^ s of row 8 n + l / 8, s = (row / 2) % 8 = (4 n + l / 16) % 8: l / 16 for even n, that ^ 4 for odd n;
@@ -576,7 +584,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     std::vector<std::pair<int, int64_t>> v;
     for (auto &kv : hist) if (kv.second >= 2) v.push_back({kv.second, kv.first});
     std::sort(v.begin(), v.end(), [](const auto &x, const auto &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
-    for (size_t i = 0; i < v.size() && i < (size_t)N_DELTA && !rm_bufs; ++i) delta_tab.push_back(v[i].second);
+    for (size_t i = 0; i < v.size() && i < (size_t)N_DELTA && !rm_bufs && !rl; ++i) delta_tab.push_back(v[i].second);
   }
   for (size_t k = 0; k < delta_tab.size(); ++k) {
     const int d = S_DELTA + 2 * (int)k;
@@ -685,6 +693,27 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     w_seq = ++E.vm_issued;     // counted on both paths: a phantom older op only makes later waits conservative
   }
 
+  uint64_t rl_ready = 0;
+  if (rl) {
+    // the tile's block: 512 L bytes from S_LT on, 1 KB per instruction (the last one half a wave wide when L is odd); the image's previous
+    // readers have drained (lgkmcnt(0) at the end of the tile)
+    const uint32_t n_inst = (512u * p.L + 1023u) / 1024u;
+    E.ins("s_mov_b64 " + S2(S_DELTA + 2) + ", " + S2(S_LT));
+    for (uint32_t n = 0; n < n_inst; ++n) {
+      if (n && n % 4 == 0) {
+        E.ins("s_add_u32 " + S(S_DELTA + 2) + ", " + S(S_DELTA + 2) + ", 0x1000");
+        E.ins("s_addc_u32 " + S(S_DELTA + 3) + ", " + S(S_DELTA + 3) + ", 0");
+      }
+      const bool half = (n + 1) * 1024u > 512u * p.L;
+      if (half) E.ins("s_mov_b64 exec, 0xffffffff");
+      // (the instruction's offset moves the LDS address as well as the global one: M0 only changes every four instructions)
+      if (n % 4 == 0 || half) E.ins("s_mov_b32 m0, " + hex32(stage_base + (n / 4) * 4096u));
+      E.ins("global_load_lds_dwordx4 v" + std::to_string(rm0 + 1) + ", " + S2(S_DELTA + 2) + " offset:" + std::to_string((n % 4) * 1024u) + " nt");
+      if (half) E.ins("s_mov_b64 exec, -1");
+      ++E.vm_issued;
+    }
+    rl_ready = E.vm_issued;
+  }
   auto panel_operand = [&](uint32_t slot) -> std::string {
     const uint64_t byte = (uint64_t)slot * SLOT;
     const uint64_t hi = byte & ~4095ull, lo = byte & 4095ull;
@@ -803,6 +832,12 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         if (dbg_noleaf) break;   // timing experiments only (results are garbage)
         if (o.kind == M_LD_LEAF) E.wait_reg(o.d);
         if (E.streaming && leaf_policy_env.empty()) leaf_policy = final_load[this_op] ? " nt" : "";
+        if (rl) {              // lane = row: image[row * 8 L + 8 leaf]
+          E.wait_vm(rl_ready);
+          E.ins("ds_read_b64 " + vall(o.d) + ", v" + std::to_string(rm0) + " offset:" + std::to_string(stage_base + o.a * 8u));
+          E.pend[o.d] = {2, ++E.lg_issued};
+          break;
+        }
         if (rm_bufs) {
           const int b = rm_ld_buf[this_op];
           if (b >= 0) {          // from the staging buffer: lane = row, piece (leaf - chunk start) / 2, half (leaf - chunk start) % 2
@@ -1149,7 +1184,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_endpgm");
 
   // ---- kernel descriptor -------------------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? 3 : 0), 8);
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? 3 : 0) + (rl ? 2 : 0), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
   const uint32_t n_agpr = RW * prog.n_acc_used;
   if (cs) return KernelMeta{kname, lds_bytes, accum, n_agpr, 12, (mc || has_macro) ? S_END : S_POOL + 2 * 16};
@@ -1267,7 +1302,7 @@ std::string isa_hazard_table() {
 // `kname`_w2 next to it.
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2,
                      const OptProgram *prog_acc, const OptProgram *prog_rm, uint32_t rm_bufs, const CoopProgram *coop,
-                     const OptProgram *prog_rm_acc, const CoopProgram *pool) {
+                     const OptProgram *prog_rm_acc, const CoopProgram *pool, const OptProgram *prog_rl) {
   Emit E;
   E.os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n";
   std::vector<KernelMeta> ks;
@@ -1284,6 +1319,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   }
   if (prog_rm && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm, kname + "_rm", 1, false, rm_bufs));
   if (prog_rm_acc && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm_acc, kname + "_rm_acc", 1, true, rm_bufs));
+  if (prog_rl) ks.push_back(emit_kernel(E, p, *prog_rl, kname + "_rl", 1, false, 0, nullptr, true));
   if (coop && coop->supported) { ks.push_back(emit_coop(E, p, *coop, kname + "_coop")); ks.back().wg = 64 * coop->n_wave; }
   if (pool && pool->supported) { ks.push_back(emit_coop(E, p, *pool, kname + "_pool")); ks.back().wg = 64 * pool->n_wave; }
   std::ostringstream &os = E.os;

@@ -424,6 +424,7 @@ static int ensure_module(fdg_graph *g) {
     if (g->has_rm_acc) { hipFunction_t f6; HIP_TRY(hipModuleGetFunction(&f6, m, "fdg_isa_eval_rm_acc")); g->fn_isa_rm_acc = f6; }
     if (g->has_coop) { hipFunction_t f5; HIP_TRY(hipModuleGetFunction(&f5, m, "fdg_isa_eval_coop")); g->fn_isa_coop = f5; }
     if (g->has_pool) { hipFunction_t f6; HIP_TRY(hipModuleGetFunction(&f6, m, "fdg_isa_eval_pool")); g->fn_isa_pool = f6; }
+    if (g->has_rl) { hipFunction_t f7; HIP_TRY(hipModuleGetFunction(&f7, m, "fdg_isa_eval_rl")); g->fn_isa_rl = f7; }
     return FDG_OK;
   }
   hipFunction_t f1, f2;
@@ -496,7 +497,9 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     set_error("tile-major batch: negative strides or sample strides of 2^23 elements or more are not supported"); return FDG_E_UNSUPPORTED;
   }
 
-  if (!g->code_object.empty() && g->isa && !g->alt_code.empty() && ls == 1 && ss != 1 && p.L > 1 && !tiled) {
+  const bool rl_shape = g->has_rl && mode == 0 && ls == 1 && ss == (int64_t)p.L && p.L >= 2 && B >= 64 && ((uintptr_t)d_leaf & 15) == 0 &&
+                        !(rs < 0 || rs >= (1ll << 23)) && !std::getenv("FDG_ISA_NO_RL");      // contiguous rows: the linear variant below
+  if (!g->code_object.empty() && g->isa && !g->alt_code.empty() && ls == 1 && ss != 1 && p.L > 1 && !tiled && !rl_shape) {
     // sample-major input and a companion: its lanes read their own rows; no transposition pass
     if (!g->alt_module) {
       hipModule_t m; hipFunction_t f1, f2;
@@ -648,6 +651,22 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // Row-major leaves ([B, L], leaf stride 1): full 64-row tiles go through the variant that stages chunks of rows in LDS
     // itself -- the matrix is read once, in place -- for evaluation and for fused accumulation alike; the last B % 64 rows
     // go through the plain kernel with the caller's strides (its lanes gather their own rows: fine for under a tile).
+    // Contiguous rows (sample stride == L, 16-byte aligned base): full tiles through the linear variant -- the tile's block streamed into an LDS image.
+    if (rl_shape && g->fn_isa_rl && !tiled) {
+      const long n4 = (long)(B & ~(int64_t)63), tail = (long)B - n4;
+      const long grid6 = (long)g->n_cu * waves_per_cu(g->isa6_vgpr, g->isa6_lds_bytes);
+      rc = ensure_ws(g, std::max(panel_all + (size_t)std::max(grid3, grid5) * R * 512u + 4096, (size_t)std::max<uint32_t>(g->isa6_mem_slots, 1) * 512u * (size_t)grid6 + 4096));
+      if (rc) return rc;
+      void *a_wsp = g->d_ws;
+      long nwg = std::min<long>(n4 / 64, grid6), lss = ss, lls = ls, rrs = rs, rrk = rk, nn = n4, tls = 64 * lss, trs = 64 * rrs;
+      const double *nowt = nullptr;
+      void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt, &tls, &trs};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rl, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+      g->last_kernel = "fdg_isa_eval_rl";
+      named = true;
+      if (tail) { rc = launch_isa(d_leaf + (size_t)n4 * (size_t)ss, lss, lls, d_root + (size_t)n4 * (size_t)rs, rrs, rrk, tail); if (rc) return rc; }
+      return FDG_OK;
+    }
     const bool rm_shape = ls == 1 && ss >= (int64_t)p.L && !wide_ss && p.L >= 16 && B >= 64 && !tiled && !std::getenv("FDG_ISA_NO_RM");
     if (rm_shape && ((mode == 0 && g->has_rm && g->fn_isa_rm && !(rs < 0 || rs >= (1ll << 23))) || (fused_acc && g->has_rm_acc && g->fn_isa_rm_acc))) {
       const long n4 = (long)(B & ~(int64_t)63), lss = ss, lls = ls, tail = (long)B - n4;
@@ -800,11 +819,14 @@ uint64_t fnv1a(const std::string &s, uint64_t h) {
 // the linker create their outputs under the caller's umask, 0664/0775 under umask 002, and the directory they sit in is
 // vetted by fdg_cache_dir.  FDG_CACHE_TRUST=1 lifts the ownership test.)
 static bool cache_trust() { static const bool t = std::getenv("FDG_CACHE_TRUST") != nullptr; return t; }
-bool read_file(const std::string &path, std::vector<char> &out) {
+// `deny`: permission bits that disqualify the file -- 002 inside the caller's own vetted cache directory (the assembler and the linker
+// create their outputs under the caller's umask: 0664 under umask 002), 022 for files found through $FDG_CACHE_RO_DIR (nothing legitimate is
+// written there by this process, so a group-writable artefact is not taken).
+static bool read_file_vetted(const std::string &path, std::vector<char> &out, mode_t deny) {
   const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
   if (fd < 0) return false;
   struct stat sb;
-  if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || (!cache_trust() && ((sb.st_uid != geteuid() && sb.st_uid != 0) || (sb.st_mode & 002)))) { ::close(fd); return false; }
+  if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || (!cache_trust() && ((sb.st_uid != geteuid() && sb.st_uid != 0) || (sb.st_mode & deny)))) { ::close(fd); return false; }
   out.resize((size_t)sb.st_size);
   size_t got = 0;
   while (got < out.size()) {
@@ -816,11 +838,12 @@ bool read_file(const std::string &path, std::vector<char> &out) {
   out.resize(got);
   return !out.empty();
 }
+bool read_file(const std::string &path, std::vector<char> &out) { return read_file_vetted(path, out, 002); }
 
 // Lookup of a cached artefact: the (writable, vetted) cache directory first, then the read-only directories named by
 // $FDG_CACHE_RO_DIR (colon-separated; e.g. the kernel_cache a package ships, which may belong to root or sit in a
-// read-only checkout).  A read-only directory and the file in it must belong to the caller or to root and must not be
-// world-writable; nothing is ever written there.
+// read-only checkout).  A read-only directory and the file in it must belong to the caller or to root and must be writable by
+// their owner only (no group or world write bit); nothing is ever written there.
 bool read_cached(const std::string &dir, const std::string &fname, std::vector<char> &out) {
   if (!dir.empty() && read_file(dir + "/" + fname, out)) return true;
   const char *ro = std::getenv("FDG_CACHE_RO_DIR");
@@ -834,8 +857,8 @@ bool read_cached(const std::string &dir, const std::string &fname, std::vector<c
     if (d.empty() || d == dir) continue;
     struct stat sb;
     if (stat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) continue;
-    if (!cache_trust() && ((sb.st_uid != geteuid() && sb.st_uid != 0) || (sb.st_mode & 002))) continue;
-    if (read_file(d + "/" + fname, out)) return true;
+    if (!cache_trust() && ((sb.st_uid != geteuid() && sb.st_uid != 0) || (sb.st_mode & 022))) continue;
+    if (read_file_vetted(d + "/" + fname, out, 022)) return true;
   }
   return false;
 }
@@ -1067,6 +1090,7 @@ int fdg_graph_kernel_info(fdg_graph *g, fdg_kernel_info *o) {
   if (g->has_rm) o->waves_per_cu[2] = wpc(g->isa4_vgpr, g->isa4_lds_bytes);
   o->has_acc = g->has_acc; o->has_rm = g->has_rm; o->has_coop = g->has_coop && g->coop_enabled; o->rm_bufs = g->rm_bufs;
   o->has_pool = g->has_pool; o->pool_fetch = g->pool_fetch; o->pool_valu = g->pool_valu;
+  o->has_rl = g->has_rl; o->rl_reserved = 0; o->rl_valu = g->rl_valu;
   return FDG_OK;
 }
 
@@ -1230,8 +1254,9 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
                         std::vector<char> &co, std::string &hash, const fdg::OptProgram *prog2 = nullptr,
                         const fdg::OptProgram *prog_acc = nullptr, const char *kname = "fdg_isa_eval",
                         const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr,
-                        const fdg::OptProgram *prog_rm_acc = nullptr, const fdg::CoopProgram *pool = nullptr) {
-  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc, prog_rm, rm_bufs, coop, prog_rm_acc, pool);
+                        const fdg::OptProgram *prog_rm_acc = nullptr, const fdg::CoopProgram *pool = nullptr,
+                        const fdg::OptProgram *prog_rl = nullptr) {
+  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc, prog_rm, rm_bufs, coop, prog_rm_acc, pool, prog_rl);
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
   hash = hbuf;
@@ -1264,8 +1289,19 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
 static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<char> &co, const std::string &hash, unsigned flags,
                         const fdg::OptProgram *prog2 = nullptr, const fdg::OptProgram *prog_acc = nullptr,
                         const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr,
-                        const fdg::OptProgram *prog_rm_acc = nullptr, const fdg::CoopProgram *pool = nullptr) {
+                        const fdg::OptProgram *prog_rm_acc = nullptr, const fdg::CoopProgram *pool = nullptr,
+                        const fdg::OptProgram *prog_rl = nullptr) {
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
+  g->has_rl = prog_rl != nullptr;
+  g->fn_isa_rl = nullptr;
+  if (g->has_rl) {
+    uint32_t t = 0;
+    for (const fdg::MOp &o : prog_rl->ops) t = std::max(t, fdg::mop_tmp_pairs(o.kind));
+    g->isa6_vgpr = ((6 + 2 * std::max<uint32_t>(prog_rl->n_reg_used, 1) + 2 * t + 2 + 3) & ~3u) + 2 * prog_rl->n_acc_used;
+    g->isa6_lds_bytes = ((prog_rl->n_lds_used * 512u + 1023u) & ~1023u) + ((512u * g->prog.L + 1023u) & ~1023u);
+    g->isa6_mem_slots = prog_rl->n_mem_used;
+    g->rl_valu = prog_rl->n_valu;
+  }
   g->has_pool = pool && pool->supported;
   g->fn_isa_pool = nullptr;
   if (g->has_pool) {
@@ -1507,7 +1543,8 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
 }
 
 struct IsaVariants {
-  fdg::OptProgram p2, pa, pr, pra;
+  fdg::OptProgram p2, pa, pr, pra, prl;
+  bool rl = false;
   fdg::CoopProgram coop, pool;
   bool w2 = false, acc = false, rm_acc = false;
   uint32_t rm_bufs = 0;
@@ -1570,17 +1607,35 @@ static void build_pool(const fdg_graph *g, const fdg::OptProgram &prog, IsaVaria
   if (std::getenv("FDG_POOL_DEBUG")) std::fprintf(stderr, "[pool] %s: %u waves, %u epochs, %llu fetches for %u leaves, %llu duplicated fold steps (%s)\n", V.pool.supported ? "built" : "not built",
                                                   V.pool.n_wave, V.pool.n_epoch, (unsigned long long)V.pool.n_fetch, g->prog.n_live_leaf, (unsigned long long)V.pool.n_duplicate, V.pool.why.c_str());
 }
+// The linear row-major variant (csrc/fdg_isa.cpp: `rl`): contiguous rows (sample stride == L) of graphs whose 64-row tile, 512 L bytes, leaves
+// room for two waves per CU or more.  One wave per SIMD at most, so the AGPR level is there; a leaf comes back from the image by an LDS read.
+static void build_rl(const fdg_graph *g, const fdg::OptParams &chosen, IsaVariants &V) {
+  V.rl = false;
+  const char *e = std::getenv("FDG_ISA_RL");
+  if ((e && e[0] == '0') || g->prog.L < 2 || 512u * g->prog.L > 72u * 1024u || g->isa_fma) return;
+  fdg::OptParams q = cfg_B();
+  q.vn_window = chosen.vn_window;
+  q.n_lds = 8;
+  q.reserve_pairs = 1;
+  q.lookahead_leaf = 32;
+  q.pool_leaves = true;          // (an evicted leaf is read again from the image: cheap, and it is not parked anywhere)
+  q.roots_last = true;
+  if (const char *la = std::getenv("FDG_ISA_RL_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
+  build_prog(g, q, V.prl);
+  V.rl = V.prl.supported && V.prl.n_ld_mem + V.prl.n_st_mem == 0;
+}
 static int assemble_and_install(fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags, IsaVariants &V) {
   std::vector<char> co; std::string hash;
   if (V.coop_verdict != 0) build_coop(g, prog, V);
   build_pool(g, prog, V);
+  build_rl(g, prog.params, V);
   const fdg::CoopProgram *coop = V.coop.supported ? &V.coop : nullptr;
   const fdg::CoopProgram *pool = V.pool.supported ? &V.pool : nullptr;
   const int rc = assemble_isa(g, prog, dir, flags, co, hash, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, "fdg_isa_eval",
-                              V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop, V.rm_acc ? &V.pra : nullptr, pool);
+                              V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop, V.rm_acc ? &V.pra : nullptr, pool, V.rl ? &V.prl : nullptr);
   if (rc) return rc;
   install_isa(g, prog, co, hash, flags, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop,
-              V.rm_acc ? &V.pra : nullptr, pool);
+              V.rm_acc ? &V.pra : nullptr, pool, V.rl ? &V.prl : nullptr);
   return FDG_OK;
 }
 
@@ -2130,10 +2185,15 @@ int fdg_eval_device_typed(fdg_graph *g, int dtype, const void *d_leaf, int64_t s
   if (g->typed_code[dtype].empty()) { set_error("fdg_eval_device_typed: call fdg_graph_specialize_typed for this element type first"); return FDG_E_INVALID; }
   if (B == 0 || g->prog.R == 0) return FDG_OK;
   if ((g->prog.L && !d_leaf) || !d_root) { set_error("null device buffer"); return FDG_E_INVALID; }
-  if (dtype == FDG_DT_C64 && g->cx_twin && ls == 1 && rk == 1 && ss >= (int64_t)g->prog.L && rs >= (int64_t)g->prog.R && B >= 64) {
+  // (rows whose doubled strides the assembly kernels cannot address go on to the per-type kernel, which takes any stride)
+  if (dtype == FDG_DT_C64 && g->cx_twin && ls == 1 && rk == 1 && ss >= (int64_t)g->prog.L && rs >= (int64_t)g->prog.R && B >= 64 &&
+      2 * ss < (1ll << 23) && 2 * rs < (1ll << 23)) {
     const int rct = fdg_eval_device(g->cx_twin, (const double *)d_leaf, 2 * ss, 1, (double *)d_root, 2 * rs, 1, B, stream);
-    if (rct == FDG_OK) g->last_kernel = "fdg_isa_eval_rm (ComplexF64 rows as 2 L doubles)";
-    return rct;
+    if (rct == FDG_OK) {
+      g->last_kernel = std::strcmp(g->cx_twin->last_kernel, "fdg_isa_eval_rl") == 0 ? "fdg_isa_eval_rl (ComplexF64 rows)" : "fdg_isa_eval_rm (ComplexF64 rows)";
+      return rct;
+    }
+    if (rct != FDG_E_UNSUPPORTED) return rct;
   }
   int rc = ensure_device(g);
   if (rc) return rc;

@@ -118,7 +118,12 @@ function lower_to_table(graphs::AbstractVector{G}; root::AbstractVector{Int}=[id
 end
 
 """
-    compile_hip(graphs; root, backend=:isa, autotune=false, groups=nothing, cache_dir=nothing)
+    compile_hip(graphs; root, backend=:isa, autotune=false, groups=nothing, cache_dir=nothing, association=:static)
+
+`association = :eval` makes the handle reproduce the interpreter `eval!` (src/computational_graph/eval.jl:1-3,15-39: every operand is
+scaled by its factor before it enters the fold, `Prod = (w1*f1) * (w2*f2) * ...`) instead of the generated code of `Compilers.compile`
+(src/backend/static.jl:13-46) -- `fdg_graph_set_association(h, FDG_ASSOC_INTERP)`; the two differ only where a `Prod` has a factor other
+than +-1 on its second or a later operand.
 
 `groups` (optional `Dict{Int,Int}`: node id => tag) is the scheduling hint of
 `fdg_graph_set_schedule_groups`: pass the coefficient -> original-node map of `taylorexpansion!`
@@ -127,13 +132,17 @@ together.  It never changes a value.
 """
 function compile_hip(graphs::AbstractVector{<:AbstractGraph};
     root::AbstractVector{Int}=[id(g) for g in graphs], backend::Symbol=:isa, autotune::Bool=false,
-    groups::Union{Nothing,Dict{Int,Int}}=nothing, cache_dir::Union{Nothing,String}=nothing)
+    groups::Union{Nothing,Dict{Int,Int}}=nothing, cache_dir::Union{Nothing,String}=nothing, association::Symbol=:static)
+    association in (:static, :eval) || error("association must be :static or :eval")
     L, op, power, off, idx, fac, root_slot, leafmap, last_root = lower_to_table(graphs; root=root)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve op power off idx fac root_slot begin
         desc = Ref(_FdgGraphDesc(UInt32(L), UInt32(length(op)), UInt32(length(root_slot)), UInt32(length(idx)),
             pointer(op), pointer(power), pointer(off), pointer(idx), pointer(fac), pointer(root_slot)))
         _fdg_check(ccall((:fdg_graph_create, _libfdg), Cint, (Ref{_FdgGraphDesc}, Ref{Ptr{Cvoid}}), desc, h))
+    end
+    if association == :eval      # FDG_ASSOC_INTERP = 1; before any specialisation
+        _fdg_check(ccall((:fdg_graph_set_association, _libfdg), Cint, (Ptr{Cvoid}, Cint), h[], Cint(1)))
     end
     if !isnothing(groups)
         # internal nodes in statement order, exactly the order lower_to_table numbered them
@@ -155,7 +164,7 @@ function compile_hip(graphs::AbstractVector{<:AbstractGraph};
         elseif rc == 0 && backend == :isa && L > 1 && length(op) <= 4000
             # a handle without a row-major variant of the ISA kernel (fdg_kernel_info.has_rm == 0: fewer than 16 leaves, the
             # tiny-graph configuration): HIP-source companion for row-major [B, L] input (FDG_SPEC_ROW_MAJOR_COMPANION = 16)
-            ki = zeros(UInt8, 160)              # sizeof(fdg_kernel_info): 48 + 3*8 + 4*3*4 + 4*4 = 136, rounded up
+            ki = zeros(UInt8, 256)              # sizeof(fdg_kernel_info) = 168 (48 + 3*8 + 4*3*4 + 4*4, then the pool / rl fields), rounded up
             _fdg_check(ccall((:fdg_graph_kernel_info, _libfdg), Cint, (Ptr{Cvoid}, Ptr{UInt8}), h[], ki))
             has_rm = reinterpret(UInt32, ki[125:128])[1]      # offset 124: has_acc at 120, has_rm at 124
             if has_rm == 0
@@ -213,6 +222,29 @@ function eval_device!(f::GraphFunc, d_root::Ptr{T}, d_leaf::Ptr{T}, B::Integer;
         f.handle, dt, d_leaf, leaf_strides[1], leaf_strides[2], d_root, root_strides[1], root_strides[2], B, stream))
 end
 
+# Tile-major batches (include/fdg.h: fdg_eval_device_tiled): the leaves as an Array{Float64,3}(undef, 64, L, cld(B, 64)) -- sample in tile,
+# leaf, tile -- and the roots as (64, R, cld(B, 64)); what a Monte-Carlo driver that owns its sample batch should allocate: one
+# contiguous block of 512 L bytes per wave instead of 64 samples of each of L columns.  Strides in elements: (sample, value, tile).
+function eval_device_tiled!(f::GraphFunc, d_root::Ptr{Float64}, d_leaf::Ptr{Float64}, B::Integer;
+    leaf_strides=(1, 64, 64 * f.n_leaf), root_strides=(1, 64, 64 * f.n_root), stream::Ptr{Cvoid}=C_NULL)
+    _fdg_check(ccall((:fdg_eval_device_tiled, _libfdg), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Int64, Int64, Ptr{Cvoid}),
+        f.handle, d_leaf, leaf_strides[1], leaf_strides[2], leaf_strides[3], d_root, root_strides[1], root_strides[2], root_strides[3], B, stream))
+end
+function accumulate_device_tiled!(f::GraphFunc, d_acc::Ptr{Float64}, d_leaf::Ptr{Float64}, d_weight::Ptr{Float64}, B::Integer;
+    leaf_strides=(1, 64, 64 * f.n_leaf), stream::Ptr{Cvoid}=C_NULL)
+    _fdg_check(ccall((:fdg_accumulate_device_tiled, _libfdg), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Cvoid}),
+        f.handle, d_leaf, leaf_strides[1], leaf_strides[2], leaf_strides[3], d_weight, d_acc, B, stream))
+end
+# device memory for a batch, backed by physical chunks of `chunk_bytes` (0: one allocation): fdg_batch_alloc / fdg_batch_free
+function batch_alloc(bytes::Integer; chunk_bytes::Integer=0)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    _fdg_check(ccall((:fdg_batch_alloc, _libfdg), Cint, (Csize_t, Csize_t, Ref{Ptr{Cvoid}}), bytes, chunk_bytes, p))
+    return p[]
+end
+batch_free(p::Ptr{Cvoid}) = _fdg_check(ccall((:fdg_batch_free, _libfdg), Cint, (Ptr{Cvoid},), p))
+
 # acc[k] += sum_b weight[b] * root_k(b), everything on device
 function accumulate_device!(f::GraphFunc, d_acc::Ptr{Float64}, d_leaf::Ptr{Float64}, d_weight::Ptr{Float64}, B::Integer;
     leaf_strides=(1, B), stream::Ptr{Cvoid}=C_NULL)
@@ -221,7 +253,7 @@ function accumulate_device!(f::GraphFunc, d_acc::Ptr{Float64}, d_leaf::Ptr{Float
         f.handle, d_leaf, leaf_strides[1], leaf_strides[2], d_weight, d_acc, B, stream))
 end
 
-export compile_hip, GraphFunc, eval_device!, accumulate_device!
+export compile_hip, GraphFunc, eval_device!, accumulate_device!, eval_device_tiled!, accumulate_device_tiled!, batch_alloc, batch_free
 
 # ---- multi-GPU: one Julia process per GPU, ONE reduction of the accumulated observable ------------ #
 # (include/fdg.h, "multi-GPU").  Rank 0 calls `comm_unique_id()` and ships the 128 bytes to the other

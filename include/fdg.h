@@ -166,6 +166,9 @@ typedef struct fdg_kernel_info {
   uint32_t has_pool;          /* the pooled cooperative variant (fdg_isa_eval_pool) is installed: full tiles of batches whose samples of a leaf are contiguous */
   uint32_t pool_fetch;        /* ... leaf fetches from memory per evaluation (>= the live leaves) */
   uint64_t pool_valu;         /* ... fold steps executed per evaluation, all waves together */
+  uint32_t has_rl;            /* the linear row-major variant (fdg_isa_eval_rl) is installed: contiguous rows, full tiles */
+  uint32_t rl_reserved;
+  uint64_t rl_valu;           /* ... fold steps it executes per evaluation */
 } fdg_kernel_info;
 int fdg_graph_kernel_info(fdg_graph *g, fdg_kernel_info *info);
 

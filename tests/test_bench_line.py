@@ -164,5 +164,5 @@ def test_bench_line_on_the_device(tmp_path):
     assert got["accumulate"]["kernel"].startswith("fdg_isa_eval_acc") and got["accumulate"]["value"] > got["value"] * 0.8
     assert got["mc_step"]["value"] > 0 and got["mc_step"]["max_dev_over_Sk"] < 1e-11 and got["mc_step"]["max_dev_over_Ak"] < 1e-14
     detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
-    assert detail["secondary"][0]["roofline"]["kernel"] == "fdg_isa_eval_rm"
+    assert detail["secondary"][0]["roofline"]["kernel"] == "fdg_isa_eval_rl"        # contiguous rows: the linear row-major variant
     assert detail["config5"]["roofline_rank0"]["kernel"].startswith("fdg_isa_eval_acc")

@@ -605,7 +605,9 @@ def test_row_major_variant_eval_accumulate_and_ragged_batches(libfdg, cuda, name
         leaf.copy_(torch.from_numpy(h_leaf))
         got = run(f, leaf)
         assert np.array_equal(got, want), (name, B, pitch, float(np.abs(got - want).max()))
-        assert f.kernel_info()["last_kernel"] == ("fdg_isa_eval_rm" if B >= 64 else "fdg_isa_eval"), (B, f.kernel_info()["last_kernel"])
+        # (contiguous rows of a graph whose tile fits the LDS take the linear variant fdg_isa_eval_rl, padded rows and larger graphs the chunked one)
+        linear = f.kernel_info()["has_rl"] == 1 and pitch == L
+        assert f.kernel_info()["last_kernel"] == (("fdg_isa_eval_rl" if linear else "fdg_isa_eval_rm") if B >= 64 else "fdg_isa_eval"), (B, f.kernel_info()["last_kernel"])
         root_cm = torch.zeros((R, B), dtype=torch.float64, device=cuda).t()          # a Julia B x R matrix next to row-major leaves
         f(root_cm, leaf)
         torch.cuda.synchronize()

@@ -161,3 +161,32 @@ def test_pooled_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_pat
     torch.cuda.synchronize()
     assert f.kernel_info()["last_kernel"].startswith("fdg_isa_eval") and f.kernel_info()["last_kernel"] != "fdg_isa_eval_pool"
     assert np.array_equal(got.cpu().numpy(), oracle.eval_static(t, h_leaf))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["parquet_sigma4", "sigma2", "parquet_sigma3", "gv_sigma4"])
+def test_linear_row_major_variant_on_device(libfdg, cuda, name):
+    """fdg_isa_eval_rl: compile_Python's row-major [B, L] with contiguous rows (src/backend/compiler_python.jl:23,28,45-47) -- a tile's 64 rows
+    are one block of 512 L bytes, streamed into an LDS image once, every cache line requested exactly once.  Bit-exact; the last B % 64 rows and
+    matrices with padded rows take the other kernels."""
+    import torch
+    t = workloads.get(name)
+    L, R = t.n_leaf, t.n_root
+    f = fd.compile_table(t, specialize="isa")
+    assert f.kernel_info()["has_rl"] == 1
+    for B in (64, 4099, 200_000):
+        h_leaf = oracle.philox_uniform(B, L, 93)
+        want = oracle.eval_static(t, h_leaf)
+        leaf = torch.from_numpy(h_leaf).to(cuda)
+        root = torch.full((B, R), 9.0, dtype=torch.float64, device=cuda)
+        f(root, leaf)
+        torch.cuda.synchronize()
+        assert f.kernel_info()["last_kernel"] == "fdg_isa_eval_rl", f.kernel_info()["last_kernel"]
+        assert np.array_equal(root.cpu().numpy(), want), (name, B)
+    # rows with padding between them are not one block: the chunked row-major variant (or the transposition) takes them
+    wide = torch.zeros((300, L + 3), dtype=torch.float64, device=cuda)
+    wide[:, :L] = torch.from_numpy(h_leaf[:300]).to(cuda)
+    got = f(None, wide[:, :L])
+    torch.cuda.synchronize()
+    assert f.kernel_info()["last_kernel"] != "fdg_isa_eval_rl"
+    assert np.array_equal(got.cpu().numpy(), want[:300])
