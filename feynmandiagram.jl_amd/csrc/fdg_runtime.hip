@@ -1612,10 +1612,14 @@ static void build_pool(const fdg_graph *g, const fdg::OptProgram &prog, IsaVaria
 static void build_rl(const fdg_graph *g, const fdg::OptParams &chosen, IsaVariants &V) {
   V.rl = false;
   const char *e = std::getenv("FDG_ISA_RL");
-  if ((e && e[0] == '0') || g->prog.L < 2 || 512u * g->prog.L > 72u * 1024u || g->isa_fma) return;
+  // Three waves per CU or more (image + eight LDS slots three times into 160 KB: up to 98 leaves): with two, a wave that waits for its
+  // tile has one partner to cover it and the variant loses to the chunked one -- measured at 116 and 155 leaves: 2.26 vs 2.75e9 and
+  // 2.34 vs 2.72e9 evaluations/s; equal at 111 (profiles/r04_log_rl_big.txt).  FDG_ISA_RL_MAX_KB overrides the bound on the image.
+  const uint32_t rl_max_bytes = std::getenv("FDG_ISA_RL_MAX_KB") ? (uint32_t)std::atoi(std::getenv("FDG_ISA_RL_MAX_KB")) * 1024u : (160u * 1024u / 3u - 8u * 512u);
+  if ((e && e[0] == '0') || g->prog.L < 2 || ((512u * g->prog.L + 1023u) & ~1023u) > rl_max_bytes || g->isa_fma) return;
   fdg::OptParams q = cfg_B();
   q.vn_window = chosen.vn_window;
-  q.n_lds = 8;
+  q.n_lds = 512u * g->prog.L > 72u * 1024u ? 0 : 8;
   q.reserve_pairs = 1;
   q.lookahead_leaf = 32;
   q.pool_leaves = true;          // (an evicted leaf is read again from the image: cheap, and it is not parked anywhere)

@@ -424,14 +424,26 @@ def test_artefacts_pass_the_vetting_under_any_umask_and_shipped_cache_is_read_on
         assert objs[0].stat().st_mtime_ns == m0
     finally:
         os.umask(old)
-    # the shipped cache as a read-only secondary: nothing is written into the primary on a hit, nothing ever into the secondary
+    # the shipped cache as a read-only secondary: nothing is written into the primary on a hit, nothing ever into the secondary.
+    #  What is found THROUGH $FDG_CACHE_RO_DIR must be writable by its owner only -- nothing legitimate is written there under
+    # the caller's umask --: the group-writable artefact is not taken (the kernel is assembled again into the primary), the 0644 one is.
     monkeypatch.setenv("FDG_CACHE_RO_DIR", "/nonexistent:" + str(a))
     os.chmod(a, 0o555)
+    c = tmp_path / "c"
+    c.mkdir(mode=0o700)
+    capi.GraphHandle(t).specialize(str(c), capi.FDG_SPEC_ISA)
+    assert [p for p in c.iterdir() if p.suffix == ".hsaco"]
+    os.chmod(objs[0], 0o644)
     b = tmp_path / "b"
     b.mkdir(mode=0o700)
     h = capi.GraphHandle(t)
     h.specialize(str(b), capi.FDG_SPEC_ISA)
     assert h.info()["specialized"] == 1 and not list(b.iterdir())
+    os.chmod(a, 0o775)                                                        # a group-writable read-only directory is not consulted at all
+    d = tmp_path / "d"
+    d.mkdir(mode=0o700)
+    capi.GraphHandle(t).specialize(str(d), capi.FDG_SPEC_ISA)
+    assert [p for p in d.iterdir() if p.suffix == ".hsaco"]
     os.chmod(a, 0o700)
     # no directory given: the library's per-user default, not the package directory
     monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "xdg"))

@@ -164,7 +164,7 @@ def test_pooled_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_pat
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["parquet_sigma4", "sigma2", "parquet_sigma3", "gv_sigma4"])
+@pytest.mark.parametrize("name", ["parquet_sigma4", "sigma2", "parquet_sigma3", "parquet_sigma2"])
 def test_linear_row_major_variant_on_device(libfdg, cuda, name):
     """fdg_isa_eval_rl: compile_Python's row-major [B, L] with contiguous rows (src/backend/compiler_python.jl:23,28,45-47) -- a tile's 64 rows
     are one block of 512 L bytes, streamed into an LDS image once, every cache line requested exactly once.  Bit-exact; the last B % 64 rows and
