@@ -1,7 +1,8 @@
 """GPU dev tool: which backing of the 70 GB batch gives which rate?  The headline launch (leaf-major and tile-major, evaluation
 and fused accumulation) over batches allocated by hipMalloc (through torch) and by fdg_batch_alloc with physical chunks of
 2 MB ... the whole batch, several rounds each with a pad of another size allocated first (moves the driver's allocator state).
-usage: gpu_placement_probe.py [workload] [B] [rounds] [policies, comma separated: malloc,whole,1024,32,2 (MB)]"""
+A policy "a/b" backs the leaves by a and the roots by b (does the evaluation rate follow where the 3.2 GB of roots land?).
+usage: gpu_placement_probe.py [workload] [B] [rounds] [policies, comma separated: malloc,whole,1024,32,2 (MB) or leaf/root pairs]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -56,7 +57,8 @@ class Buf:
 for pol in policies:
     for r in range(rounds):
         pad = torch.empty(max(1, shift_mb[r % len(shift_mb)]) << 20, dtype=torch.uint8, device=dev)
-        leaf = Buf(8 * L * Bp, pol); root = Buf(8 * R * Bp, pol)
+        lp, _, rp = pol.partition("/")
+        leaf = Buf(8 * L * Bp, lp); root = Buf(8 * R * Bp, rp or lp)
         out = []
         for lay in ("leaf-major", "tile-major"):
             if lay == "leaf-major":
@@ -69,7 +71,7 @@ for pol in policies:
                 ac = lambda: h.accumulate_device_tiled(leaf.ptr, 1, 64, 64 * L, 0, acc.data_ptr(), B, st)
             e, a = timed(ev), timed(ac)
             out.append(f"{lay}: eval {e:.3f} ms frac {8 * (L + R) * B / e / 1e6 / 8000:.3f}  acc {a:.3f} ms frac {8 * L * B / a / 1e6 / 8000:.3f}")
-        print(f"{pol:>6} round {r} pad {shift_mb[r % len(shift_mb)]:5d} MB  alloc {leaf.dt:.2f}+{root.dt:.2f} s  leaf @ {leaf.ptr:#x}  " + "  |  ".join(out), flush=True)
+        print(f"{pol:>13} round {r} pad {shift_mb[r % len(shift_mb)]:5d} MB  alloc {leaf.dt:.2f}+{root.dt:.2f} s  leaf @ {leaf.ptr:#x}  " + "  |  ".join(out), flush=True)
         leaf.free(); root.free()
         del pad
         torch.cuda.empty_cache()
