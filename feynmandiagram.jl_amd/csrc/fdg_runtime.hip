@@ -537,12 +537,28 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       while (f > 1 && (ntiles < resident * f * 4 || bytes_per_wg * (size_t)(resident * f) > ((size_t)32 << 20))) f >>= 1;
       return resident * f;
     };
-    const long grid = std::min<long>(ntiles, oversub((long)g->n_cu * waves_per_cu(g->isa_vgpr, g->isa_lds_bytes), (size_t)g->isa_mem_slots * 512u));
+    // Graphs bound by memory (fewer than 2.5 executed fold steps per algorithmic byte) stream faster from FEWER resident waves: four per CU
+    // (one per SIMD) keep 4 x L x 512 bytes in flight per CU -- enough for the latency-bandwidth product -- and the memory system sees a
+    // quarter of the concurrent streams (round 4, profiles/r04_log_waves.txt: headline +3-5 %, the 2-loop graph +6-15 %); the graphs at or
+    // above the ridge want every wave they can get.  FDG_ISA_MEM_WAVES / FDG_ISA_MEM_OVERSUB / FDG_ISA_MEM_RATIO override (0 waves = off).
+    auto shape = [&](uint64_t valu, uint64_t bytes, uint32_t vgpr, uint32_t lds, size_t bytes_per_wg) -> long {
+      const long full = (long)waves_per_cu(vgpr, lds);
+      const long mem_waves = std::getenv("FDG_ISA_MEM_WAVES") ? std::atol(std::getenv("FDG_ISA_MEM_WAVES")) : (p.L >= 24 ? 4 : 5);   // (a wave of a tiny graph keeps little in flight)
+      const long mem_over = std::getenv("FDG_ISA_MEM_OVERSUB") ? std::max(1l, std::atol(std::getenv("FDG_ISA_MEM_OVERSUB"))) : 1;
+      const double mem_ratio = std::getenv("FDG_ISA_MEM_RATIO") ? std::atof(std::getenv("FDG_ISA_MEM_RATIO")) : 2.5;
+      if (mem_waves > 0 && !std::getenv("FDG_ISA_WAVES_PER_CU") && !std::getenv("FDG_ISA_OVERSUB") && bytes && (double)valu < mem_ratio * (double)bytes && full > mem_waves) {
+        long f = mem_over;
+        while (f > 1 && ntiles < (long)g->n_cu * mem_waves * f * 4) f >>= 1;
+        return (long)g->n_cu * mem_waves * f;
+      }
+      return oversub((long)g->n_cu * full, bytes_per_wg);
+    };
+    const long grid = std::min<long>(ntiles, shape(g->st_valu[0], 8ull * (p.L + R), g->isa_vgpr, g->isa_lds_bytes, (size_t)g->isa_mem_slots * 512u));
     const long grid2 = g->has_w2 ? (long)g->n_cu * waves_per_cu(g->isa2_vgpr, g->isa2_lds_bytes) : 0;
     const size_t panel = std::max((size_t)std::max<uint32_t>(g->isa_mem_slots, 1) * 512u * (size_t)grid,
                                   (size_t)std::max<uint32_t>(g->isa2_mem_slots, 1) * 1024u * (size_t)grid2);
     const bool fused_acc = mode == 1 && g->has_acc && !std::getenv("FDG_ISA_NO_FUSED_ACC");
-    const long grid3 = g->has_acc ? oversub((long)g->n_cu * waves_per_cu(g->isa3_vgpr, g->isa3_lds_bytes), ((size_t)g->isa3_mem_slots + R) * 512u) : 0;
+    const long grid3 = g->has_acc ? shape(g->st_valu[1], 8ull * p.L, g->isa3_vgpr, g->isa3_lds_bytes, ((size_t)g->isa3_mem_slots + R) * 512u) : 0;
     const size_t panel3 = (size_t)std::max<uint32_t>(g->isa3_mem_slots, 1) * 512u * (size_t)grid3;
     const long grid4 = g->has_rm ? (long)g->n_cu * waves_per_cu(g->isa4_vgpr, g->isa4_lds_bytes) : 0;
     const size_t panel4 = (size_t)std::max<uint32_t>(g->isa4_mem_slots, 1) * 512u * (size_t)grid4;
