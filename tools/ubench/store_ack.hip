@@ -11,6 +11,8 @@
 // (dev tool; hipcc --offload-arch=gfx950 -O3 store_ack.hip -o /tmp/store_ack)
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <string>
+static int g_waves_per_cu = 8;      // resident waves per CU of the persistent grid (argv: --waves N)
 #define OPS4(n) for (int i = 0; i < (n); i += 4) asm volatile("v_mul_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_add_f64 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
 template <int NCOL, int MODE, int TILED>
 __global__ void __launch_bounds__(64, 2) k(const double *__restrict__ src, double *__restrict__ dst, long ntile, long col_stride, int ops, int nstore) {
@@ -103,7 +105,7 @@ template <int NCOL, int Q, int NS, int TILED> void runp(const double *src, doubl
 template <int NCOL, int MODE, int TILED> void run(const double *src, double *dst, long total_bytes, int ops, int nstore) {
   const long ntile = total_bytes / (NCOL * 512L);
   const long cs = ntile * 64;
-  const int grid = 256 * 4 * 2;
+  const int grid = 256 * g_waves_per_cu;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k<NCOL, MODE, TILED>), dim3(grid), dim3(64), 0, 0, src, dst, ntile, cs, ops, nstore);
   hipDeviceSynchronize();
@@ -132,6 +134,7 @@ static void *backed(size_t bytes, size_t chunk_mb) {
   return p;
 }
 int main(int argc, char **argv) {
+  if (argc > 2 && std::string(argv[argc - 2]) == "--waves") { g_waves_per_cu = atoi(argv[argc - 1]); argc -= 2; }
   const long gb = argc > 1 ? atol(argv[1]) : 32;
   const long total = gb << 30;
   for (int a = 2; a < (argc > 2 ? argc : 3); ++a) {
@@ -139,7 +142,7 @@ int main(int argc, char **argv) {
     double *src = (double *)backed(total + (1 << 20), chunk_mb), *dst = (double *)backed((total / 84) * 8 + (1 << 20), chunk_mb);
     if (!src || !dst) { printf("allocation failed (chunk %zu MB)\n", chunk_mb); return 1; }
     hipMemset(src, 0, total);
-    printf("-- %ld GB, backing: %s %zu MB\n", gb, chunk_mb ? "chunks of" : "hipMalloc", chunk_mb);
+    printf("-- %ld GB, backing: %s %zu MB, %d waves per CU\n", gb, chunk_mb ? "chunks of" : "hipMalloc", chunk_mb, g_waves_per_cu);
     for (int nstore : {0, 4}) {
       run<84, 0, 0>(src, dst, total, 12, nstore);
       run<84, 0, 1>(src, dst, total, 12, nstore);
