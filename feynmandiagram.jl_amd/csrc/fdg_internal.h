@@ -148,7 +148,7 @@ struct fdg_graph {
   // pooled cooperative variant: the waves of a CU evaluate one tile, whole roots each, leaves through a shared LDS pool (full tiles, sample stride 1)
   bool has_pool = false;
   void *fn_isa_pool = nullptr;
-  uint32_t pool_panel_wg = 0, pool_threads = 256, pool_fetch = 0;
+  uint32_t pool_panel_wg = 0, pool_threads = 256, pool_fetch = 0, pool_unit = 1;
   uint64_t pool_valu = 0;
   // companion HIP-source kernels of an ISA-specialised handle, used for sample-major input (FDG_SPEC_ROW_MAJOR_COMPANION)
   std::vector<char> alt_code;

@@ -429,7 +429,7 @@ static void rm_plan(const Lowered &p, const OptProgram &prog, uint32_t rm_bufs, 
 // One wave's section of the cooperative kernel (emit_coop below): no kernel header or descriptor of its own; lane = thread id
 // & 63; private LDS slots behind the shared ones (addressed through their own base register); the wave's panel inside the
 // workgroup's; M_SEND / M_RECV / M_BARRIER.
-struct CoopSec { uint32_t wave, n_shared, priv_base_bytes, panel_wg_bytes, panel_prefix_bytes; bool pooled = false; };
+struct CoopSec { uint32_t wave, n_shared, priv_base_bytes, panel_wg_bytes, panel_prefix_bytes; bool pooled = false; uint32_t pool_unit = 1; };
 // rl: the row-major variant for CONTIGUOUS rows (sample stride == L: compile_Python's [B, L] exactly) of graphs whose tile fits the LDS: a
 // tile's 64 rows are one block of 512 L bytes, streamed linearly into an LDS image by LDS-direct loads (1 KB per instruction, every cache
 // line of the matrix requested exactly once, non-temporal), and leaf i of lane = row r is read from image[r * 8 L + 8 i].
@@ -483,6 +483,12 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const bool use_ldexp = std::getenv("FDG_ISA_NO_LDEXP") == nullptr;
   const bool dbg_novalu = dbg && std::strstr(dbg, "novalu");     // the memory stream of the program alone (waits included)
   const bool dbg_nopanel = dbg && std::strstr(dbg, "nopanel");   // no spill traffic to the HBM panel
+  const bool dbg_norecv = dbg && std::strstr(dbg, "norecv");     // pooled / cooperative kernels without their reads of the shared LDS slots
+  const bool dbg_nofetch = dbg && std::strstr(dbg, "nopoolfetch");   // ... without the fetches into the pool
+  const bool dbg_noacc = dbg && std::strstr(dbg, "noacc");       // no AGPR moves
+  // experiment (results exact): a wave takes 2^c consecutive tiles, then jumps over the other waves' runs ("chunk<c>", c = 1 .. 9)
+  int tile_run = 0;
+  if (dbg && std::strstr(dbg, "chunk") && !cs) tile_run = std::max(0, std::min(9, std::atoi(std::strstr(dbg, "chunk") + 5)));
   E.vm_slack = (dbg && std::strstr(dbg, "noackwait") && !accumulate) ? p.R : 0;
   // ---- prologue ------------------------------------------------------------
   if (cs) E.ins("v_and_b32_e32 v0, 63, v0");          // lane within the wave (the workgroup has four waves)
@@ -618,7 +624,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_addc_u32 " + S(S_X + 1) + ", " + S(S_B + 1) + ", 0");
   E.ins("s_lshr_b64 " + S2(S_X) + ", " + S2(S_X) + ", " + std::to_string(TSH));
   E.ins("s_mov_b32 " + S(S_NTILES) + ", " + S(S_X));
-  E.ins("s_mov_b32 " + S(S_TILE) + ", s2");
+  if (tile_run) E.ins("s_lshl_b32 " + S(S_TILE) + ", s2, " + std::to_string(tile_run));
+  else E.ins("s_mov_b32 " + S(S_TILE) + ", s2");
   E.ins("s_mul_i32 " + S(S_X) + ", s2, " + hex32(cs ? cs->panel_wg_bytes : panel_bytes_per_wave));
   E.ins("s_mul_hi_u32 " + S(S_X + 1) + ", s2, " + hex32(cs ? cs->panel_wg_bytes : panel_bytes_per_wave));
   E.ins("s_add_u32 " + S(S_PANEL) + ", " + S(S_WS) + ", " + S(S_X));
@@ -905,18 +912,32 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         E.pend[o.d] = {2, ++E.lg_issued};
         break;
       case M_RECV:           // a value another wave published before the last barrier
+        if (dbg_norecv) break;
         E.wait_reg(o.d);
         E.ins(DSR + vall(o.d) + ", " + (o.a < 128 ? V(V_LANE8) : "v" + std::to_string(rm0 + 1)) + " offset:" + std::to_string((o.a % 128) * SLOT));
         E.pend[o.d] = {2, ++E.lg_issued};
         break;
-      case M_POOL_FETCH: {   // shared[d] = leaf[a]: 32 lanes x 16 bytes straight into the LDS slot, no register in between
-        if (!pool_exec_low) { E.ins("s_mov_b64 exec, 0xffffffff"); pool_exec_low = true; }
-        emit_scaled_addr(E, S_FA, S_LT, S_LS8, o.a);
+      case M_POOL_FETCH: {   // shared[d .. d + b - 1] = leaf[a .. a + b - 1]: 16 bytes per lane straight into the LDS slot(s), no register in between
+        if (dbg_nofetch) break;
+        const bool pair = o.b == 2;          // 64 lanes: two leaves adjacent in the tile (leaf stride 64, checked at launch) into two adjacent slots
+        if (!pair && !pool_exec_low) { E.ins("s_mov_b64 exec, 0xffffffff"); pool_exec_low = true; }
+        if (pair && pool_exec_low) { E.ins("s_mov_b64 exec, -1"); pool_exec_low = false; }
+        // the tile's leaves lie within 2 GB of its first (checked at launch): a 32-bit product; with pairs the stride is known
+        if (o.a == 0) {
+          E.ins("s_mov_b64 " + S2(S_FA) + ", " + S2(S_LT));
+        } else {
+          if (cs->pool_unit == 2) E.ins("s_add_u32 " + S(S_FA) + ", " + S(S_LT) + ", " + hex32(o.a * 512u));
+          else {
+            E.ins("s_mul_i32 " + S(S_X) + ", " + S(S_LS8) + ", " + hex32(o.a));
+            E.ins("s_add_u32 " + S(S_FA) + ", " + S(S_LT) + ", " + S(S_X));
+          }
+          E.ins("s_addc_u32 " + S(S_FA + 1) + ", " + S(S_LT + 1) + ", 0");
+        }
         E.ins("s_mov_b32 m0, " + hex32(o.d * SLOT));
         E.ins("global_load_lds_dwordx4 v" + std::to_string(rm0 + 2) + ", " + S2(S_FA));
         pool_pending.push_back({++E.vm_issued, (uint32_t)o.imm});
         const bool more = this_op + 1 < prog.ops.size() && prog.ops[this_op + 1].kind == M_POOL_FETCH;
-        if (!more) { E.ins("s_mov_b64 exec, -1"); pool_exec_low = false; }
+        if (!more && pool_exec_low) { E.ins("s_mov_b64 exec, -1"); pool_exec_low = false; }
         break;
       }
       case M_SEND:
@@ -1092,12 +1113,14 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         break;
       }
       case M_LD_ACC:
+        if (dbg_noacc) break;
         E.wait_reg(o.d);
         if (o.a < E.pend_acc.size() && E.pend_acc[o.a]) { E.wait_vm(E.pend_acc[o.a]); E.pend_acc[o.a] = 0; }     // a landing slot: the load must have arrived
         for (int k = 0; k < RW; ++k)
           E.ins("v_accvgpr_read_b32 v" + std::to_string(V_BASE + RW * o.d + k) + ", a" + std::to_string(RW * o.a + k));
         break;
       case M_ST_ACC:
+        if (dbg_noacc) break;
         E.wait_reg(o.a);
         for (int k = 0; k < RW; ++k)
           E.ins("v_accvgpr_write_b32 a" + std::to_string(RW * o.d + k) + ", v" + std::to_string(V_BASE + RW * o.a + k));
@@ -1143,7 +1166,17 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   // (LDS / panel slots are re-written next tile; same-wave memory ops stay in program order.)
   for (uint32_t r = 0; r < E.pend.size(); ++r) E.wait_reg(r);   // loads never consumed (evicted prefetches): no WAW into the next tile
   E.ins("s_waitcnt lgkmcnt(0)");
-  E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", " + S(S_NWG));
+  if (tile_run) {
+    E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", 1");
+    E.ins("s_and_b32 " + S(S_X) + ", " + S(S_TILE) + ", " + std::to_string((1 << tile_run) - 1));
+    E.ins("s_cbranch_scc1 .Lrun" + sfx);
+    E.ins("s_lshl_b32 " + S(S_X) + ", " + S(S_NWG) + ", " + std::to_string(tile_run));
+    E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", " + S(S_X));
+    E.ins("s_sub_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", " + std::to_string(1 << tile_run));
+    os << ".Lrun" << sfx << ":\n";
+  } else {
+    E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", " + S(S_NWG));
+  }
   E.ins("s_cmp_ge_u32 " + S(S_TILE) + ", " + S(S_NTILES));
   E.ins("s_cbranch_scc0 .Lback" + sfx);
   if (accumulate) {
@@ -1232,7 +1265,7 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
   uint32_t accum = 0, n_agpr = 0;
   int n_sgpr = 0;
   for (uint32_t w = 0; w < cp.n_wave; ++w) {
-    const CoopSec cs{w, cp.n_shared, (cp.n_shared + w * cp.n_priv_lds) * 512u, panel_wg, prefix[w], cp.pooled};
+    const CoopSec cs{w, cp.n_shared, (cp.n_shared + w * cp.n_priv_lds) * 512u, panel_wg, prefix[w], cp.pooled, cp.pool_unit};
     E.hz.reset();
     const KernelMeta m = emit_kernel(E, p, cp.wave[w], kname + "_w" + std::to_string(w), 1, false, 0, &cs);
     accum = std::max(accum, m.accum); n_agpr = std::max(n_agpr, m.n_agpr); n_sgpr = std::max(n_sgpr, m.n_sgpr);

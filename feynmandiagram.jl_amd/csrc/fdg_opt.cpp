@@ -1506,9 +1506,12 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
 // Pooled cooperative variant (fdg_opt.h: build_pool_program).
 // =====================================================================================================================
 void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out, uint32_t NW, uint32_t epoch_ops, uint32_t ahead) {
+  const uint32_t unit_in = out.pool_unit;
   out = CoopProgram();
   out.n_wave = NW;
   out.pooled = true;
+  out.pool_unit = unit_in == 2 ? 2 : 1;
+  if (const char *e = std::getenv("FDG_POOL_UNIT")) out.pool_unit = std::atoi(e) == 2 ? 2 : 1;
   const uint32_t L = p.L;
   if (NW < 2 || NW > CoopProgram::MAXW) { out.why = "bad wave count"; return; }
   if (p.sched_group.size() == p.N && p.N) { out.why = "schedule groups are not part of the pooled variant"; return; }
@@ -1653,28 +1656,32 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
   }
   out.n_epoch = n_epoch;
   // ---- the pool: which leaf sits in which slot during which epochs (offline Belady at epoch granularity over all waves' reads) -----------
-  const uint32_t P = out.n_shared;
-  std::vector<std::vector<uint32_t>> read_ep(L);            // [leaf] epochs in which some wave reads it (ascending, unique)
+  // Unit of residency: one leaf (512 bytes of the tile), or -- `pool_unit` 2, tile-major batches only -- a PAIR of leaves 2u, 2u + 1, adjacent
+  // in the tile, brought by ONE 64-lane LDS-direct load into two adjacent slots (a fetch instruction costs the wave that issues it about a
+  // hundred cycles whatever it brings: tools/ubench/vmem_issue.hip; leaf numbers follow the first visit, so a leaf's neighbour is used near it).
+  const uint32_t U = out.pool_unit == 2 ? 2 : 1;
+  const uint32_t P = out.n_shared / U, LU = (L + U - 1) / U;
+  std::vector<std::vector<uint32_t>> read_ep(LU);           // [unit] epochs in which some wave reads it (ascending, unique)
   for (uint32_t w = 0; w < NW; ++w) {
     uint32_t e = 0;
     for (const MOp &o : out.wave[w].ops) {
       if (o.kind == M_BARRIER) { e++; continue; }
-      if (o.kind == M_LD_LEAF) read_ep[o.a].push_back(e);
+      if (o.kind == M_LD_LEAF) read_ep[o.a / U].push_back(e);
       if (o.kind == M_LD_LEAF_ACC) { out.why = "landing slots are not part of the pooled variant"; return; }
     }
   }
-  std::vector<std::vector<uint32_t>> need(n_epoch + 1);     // [epoch] leaves read in it
-  for (uint32_t l = 0; l < L; ++l) {
+  std::vector<std::vector<uint32_t>> need(n_epoch + 1);     // [epoch] units read in it
+  for (uint32_t l = 0; l < LU; ++l) {
     auto &v = read_ep[l];
     std::sort(v.begin(), v.end());
     v.erase(std::unique(v.begin(), v.end()), v.end());
     for (uint32_t e : v) { if (e == 0 || e > n_epoch) { out.why = "internal: a leaf is read outside the compute epochs"; return; } need[e].push_back(l); }
   }
-  struct Fetch { uint32_t leaf, slot, issue, ready; };
+  struct Fetch { uint32_t unit, slot, issue, ready; };
   std::vector<Fetch> fetches;
-  std::vector<uint32_t> slot_of(L, NONE);                   // resident leaf -> slot
-  std::vector<uint32_t> in_slot(P, NONE), last_read(P, 0);  // slot -> leaf; last epoch in which the slot's content is read (as planned so far)
-  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> resid(L);   // [leaf] (first epoch readable, slot) per residency, ascending
+  std::vector<uint32_t> slot_of(LU, NONE);                  // resident unit -> unit slot
+  std::vector<uint32_t> in_slot(P, NONE), last_read(P, 0);  // slot -> unit; last epoch in which the slot's content is read (as planned so far)
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> resid(LU);  // [unit] (first epoch readable, slot) per residency, ascending
   auto next_read = [&](uint32_t l, uint32_t from) -> uint32_t {     // first read epoch >= from
     auto &v = read_ep[l];
     auto it = std::lower_bound(v.begin(), v.end(), from);
@@ -1712,12 +1719,14 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     }
   }
   out.n_fetch = fetches.size();
-  out.n_transfer = fetches.size();
+  out.n_transfer = 0;                                       // leaves brought from memory per tile
+  for (const Fetch &f : fetches) out.n_transfer += std::min<uint32_t>(U, L - f.unit * U);
   if (std::getenv("FDG_POOL_DEBUG")) {
     std::vector<uint32_t> hist(ahead + 2, 0);
     uint64_t sum = 0;
     for (const Fetch &f : fetches) { hist[std::min<uint32_t>(f.ready - f.issue, ahead + 1)]++; sum += f.ready - f.issue; }
-    std::fprintf(stderr, "[pool] %zu fetches, issued %.2f epochs of %u ops ahead on average;", fetches.size(), fetches.empty() ? 0.0 : (double)sum / (double)fetches.size(), epoch_ops);
+    std::fprintf(stderr, "[pool] %zu fetches of %u leaves (%llu leaves in all), issued %.2f epochs of %u ops ahead on average;", fetches.size(), U, (unsigned long long)out.n_transfer,
+                 fetches.empty() ? 0.0 : (double)sum / (double)fetches.size(), epoch_ops);
     for (uint32_t k = 1; k < hist.size(); ++k) std::fprintf(stderr, " %u:%u", k, hist[k]);
     std::fprintf(stderr, "\n");
   }
@@ -1728,17 +1737,17 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     std::vector<MOp> r;
     r.reserve(out.wave[w].ops.size() + fetches.size() / NW + 8);
     uint32_t e = 0;
-    auto put_fetches = [&](uint32_t ep) {
-      for (const Fetch &f : at[w][ep]) { MOp m{M_POOL_FETCH, 0, 0, f.slot, f.leaf, 0, (double)f.ready}; r.push_back(m); }
+    auto put_fetches = [&](uint32_t ep) {      // shared[d .. d + b - 1] = leaf[a .. a + b - 1]
+      for (const Fetch &f : at[w][ep]) { MOp m{M_POOL_FETCH, 0, 0, f.slot * U, f.unit * U, std::min<uint32_t>(U, L - f.unit * U), (double)f.ready}; r.push_back(m); }
     };
     put_fetches(0);       // epoch 0 is what precedes the program's opening barrier
     for (const MOp &o : out.wave[w].ops) {
       if (o.kind == M_BARRIER) { r.push_back(o); e++; if (e <= n_epoch) put_fetches(e); continue; }
       if (o.kind == M_LD_LEAF) {
         uint32_t slot = NONE;
-        for (const auto &pr : resid[o.a]) if (pr.first <= e) slot = pr.second;      // the residency that covers epoch e: the last one that started by then
+        for (const auto &pr : resid[o.a / U]) if (pr.first <= e) slot = pr.second;      // the residency that covers epoch e: the last one that started by then
         if (slot == NONE) { out.why = "internal: leaf read without a residency"; return; }
-        MOp m{M_RECV, 0, 0, o.d, slot, 0, 0.0};
+        MOp m{M_RECV, 0, 0, o.d, slot * U + o.a % U, 0, 0.0};
         r.push_back(m);
         out.wave[w].n_recv++;
         continue;

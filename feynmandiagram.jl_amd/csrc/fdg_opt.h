@@ -156,6 +156,7 @@ struct CoopProgram {
   uint64_t n_duplicate = 0;    // fold steps computed by more than one wave
   bool pooled = false;         // build_pool_program: leaves come through the shared pool (M_POOL_FETCH / M_RECV); needs sample stride 1, leaf
                                // offsets below 2^31 bytes from the tile's base (tile-major batches) and full 64-sample tiles
+  uint32_t pool_unit = 1;      // pooled: leaves per fetch (in: set before build_pool_program; 2 = pairs of adjacent leaves, needs leaf stride 64: tile-major batches)
   uint64_t n_fetch = 0;        // pooled: leaf fetches from memory per tile (>= the live leaves; what exceeds them was evicted from the pool and came again)
   bool supported = false;
   std::string why;

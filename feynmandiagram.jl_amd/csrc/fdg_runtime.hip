@@ -634,7 +634,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // Pooled cooperative variant: one workgroup per CU walks full 64-sample tiles; a leaf's 64 samples must be contiguous (the pool fetch
     // reads 16 bytes per lane) and every leaf within 2^31 bytes of the tile's first -- tile-major batches, or small leaf-major matrices.
     // The last B % 64 samples go through the one-wave kernel.
-    if (mode == 0 && g->has_pool && g->fn_isa_pool && ss == 1 && ls > 0 && (uint64_t)ls * 8u * (uint64_t)std::max<uint32_t>(p.L, 1) < (1ull << 31) && B >= 64 &&
+    if (mode == 0 && g->has_pool && g->fn_isa_pool && ss == 1 && ls > 0 && (g->pool_unit == 1 || ls == 64) && (uint64_t)ls * 8u * (uint64_t)std::max<uint32_t>(p.L, 1) < (1ull << 31) && B >= 64 &&
         !(rs < 0 || rs >= (1ll << 23)) && !std::getenv("FDG_ISA_NO_POOL")) {
       const long n4 = (long)(B & ~(int64_t)63), tail = (long)B - n4;
       long nwg = std::min<long>(n4 / 64, (long)g->n_cu), lss = ss, lls = ls, rrs = rs, rrk = rk;
@@ -1324,7 +1324,8 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
     g->pool_panel_wg = 0;
     for (uint32_t w = 0; w < pool->n_wave; ++w) g->pool_panel_wg += std::max<uint32_t>(pool->wave[w].n_mem_used, 1) * 512u;
     g->pool_threads = 64 * pool->n_wave;
-    g->pool_fetch = (uint32_t)pool->n_fetch;
+    g->pool_fetch = (uint32_t)pool->n_transfer;      // leaves brought from memory per tile
+    g->pool_unit = pool->pool_unit;
     g->pool_valu = 0;
     for (uint32_t w = 0; w < pool->n_wave; ++w) g->pool_valu += pool->wave[w].n_valu;
   }
@@ -1509,8 +1510,10 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
   // buffers in flight.  Budget per wave: 256 registers (120 values + the nine address registers, no AGPR level) and
   // 20 KB of LDS = two staging buffers + eight slots.  Taken when nothing then spills to the HBM panel and two buffers
   // keep re-fetching within a quarter of the chunk count.
+  // (Up to eight chunks -- 128 leaves: with longer rows the two buffers of a wave are too short a window; measured round 4,
+  //  profiles/r04_log_rm_bufs.txt: 111 leaves +20 % over one wave per SIMD, 175 leaves -16 %.)
   const char *ew = std::getenv("FDG_ISA_RM_WAVES");
-  if (!(ew && std::atoi(ew) == 1) && !e) {
+  if (!(ew && std::atoi(ew) == 1) && !e && (n_chunk <= 8 || (ew && std::atoi(ew) == 2))) {
     // (both root orders are tried: in the reference's order the first uses of the leaves walk the row monotonically)
     for (int keep = 0; keep < 2; ++keep) {
       fdg::OptParams q = cfg_A();
@@ -1530,8 +1533,13 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
       if (fetches * 4 <= (uint64_t)n_chunk * 5 + 4 && (fetches * 8192 + gathers * 2048) * 2 <= (uint64_t)g->prog.L * 512 * 5) { if (qsel) *qsel = q; return 2; }
     }
   }
-  for (uint32_t bufs = e ? (uint32_t)std::max(1, std::min(4, std::atoi(e))) : 2u; bufs <= 4; ++bufs) {
-    uint64_t best_cost = ~0ull, best_fetches = 0, best_gathers = 0;
+  // Four buffers first -- the deepest prefetch: +5-18 % on the graphs whose values then still fit the registers and AGPRs (no panel access
+  // with the 14 LDS slots that remain) -- then the fewest buffers that keep re-fetching low (graphs that need their LDS slots:
+  // four buffers -9 % on the 5-loop Parquet self-energy; profiles/r04_log_rm_bufs.txt).
+  const uint32_t first = e ? (uint32_t)std::max(1, std::min(4, std::atoi(e))) : 2u;
+  for (uint32_t pass = e ? 1u : 0u; pass < 2; ++pass)
+  for (uint32_t bufs = pass == 0 ? 4u : first; bufs <= 4; ++bufs) {
+    uint64_t best_cost = ~0ull, best_fetches = 0, best_gathers = 0, best_panel = 0;
     fdg::OptProgram cand;
     for (int keep = 0; keep < 2; ++keep) {
       fdg::OptParams q = cfg_B();
@@ -1543,14 +1551,16 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
       q.keep_root_order = keep != 0;
       q.roots_last = true;             // the R stores of a row back to back: they share cache lines when the roots are row-major too (+7-11 %)
       build_prog(g, q, cand);
-      if (!cand.supported) { if (keep == 0) return 0; continue; }
+      if (!cand.supported) { if (keep == 0 && pass == 1) return 0; continue; }
       uint64_t fetches = 0, gathers = 0;
       fdg::rm_plan_stats(g->prog, cand, bufs, fetches, gathers);
-      if (std::getenv("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] one wave per SIMD (root order %d): %u chunks, %llu fetches, %llu gathers with %u buffers, %llu panel accesses\n", keep, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, bufs, (unsigned long long)(cand.n_ld_mem + cand.n_st_mem));
+      if (std::getenv("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] one wave per SIMD (root order %d): %u chunks, %llu fetches, %llu gathers with %u buffers, %llu panel accesses, %llu LDS and %llu AGPR moves\n", keep, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, bufs, (unsigned long long)(cand.n_ld_mem + cand.n_st_mem),
+                                                  (unsigned long long)(cand.n_ld_lds + cand.n_st_lds), (unsigned long long)(cand.n_ld_acc + cand.n_st_acc));
       const uint64_t cost = fetches * 8192 + gathers * 2048 + (cand.n_ld_mem + cand.n_st_mem) * 1024;
-      if (cost < best_cost) { best_cost = cost; best_fetches = fetches; best_gathers = gathers; pr = std::move(cand); if (qsel) *qsel = q; }
+      if (cost < best_cost) { best_cost = cost; best_fetches = fetches; best_gathers = gathers; best_panel = cand.n_ld_mem + cand.n_st_mem; pr = std::move(cand); if (qsel) *qsel = q; }
     }
     const bool cheap = best_fetches * 4 <= (uint64_t)n_chunk * 5 + 4;
+    if (pass == 0) { if (best_cost != ~0ull && cheap && best_panel == 0) return 4; break; }
     if (!cheap && bufs < 4 && !e) continue;
     if ((best_fetches * 8192 + best_gathers * 2048) * 2 > (uint64_t)g->prog.L * 512 * 5) return 0;
     return bufs;

@@ -352,9 +352,10 @@ def replay_coop(progs, info, leaf, R):
                 if k == 27: break
                 elif k == 25: assert d not in pending; pending[d] = (w, reg[a].copy())
                 elif k == 26: assert a not in fetch, ("pool slot read while its fetch is in flight", a, _epoch); read_slots.add((a, w)); reg[d] = shared[a]
-                elif k == 29:       # pool fetch: shared[d] = leaf[a], readable from epoch imm on; the slot's old content must not be read any more
-                    assert d not in fetch and int(o["imm"]) > _epoch, ("pool slot fetched twice / ready too early", d, _epoch)
-                    fetch[d] = (int(o["imm"]), leaf[:, a].copy()); shared[d] = np.nan; pool_written.add(d)
+                elif k == 29:       # pool fetch: shared[d .. d+b-1] = leaf[a .. a+b-1] (b = 1, or 2: a pair of adjacent leaves by one 64-lane load),
+                    for j in range(max(b, 1)):      # readable from epoch imm on; the slots' old content must not be read any more
+                        assert d + j not in fetch and int(o["imm"]) > _epoch, ("pool slot fetched twice / ready too early", d + j, _epoch)
+                        fetch[d + j] = (int(o["imm"]), leaf[:, a + j].copy()); shared[d + j] = np.nan; pool_written.add(d + j)
                 elif k == 0: reg[d] = leaf[:, a]
                 elif k == 1: reg[d] = lds[a]
                 elif k == 2: reg[d] = mem[a]
@@ -406,7 +407,7 @@ def test_pooled_programs_replay_exactly(libfdg, monkeypatch, name, waves):
     progs, info = h.pool_program()
     assert len(progs) == waves
     assert all(int((p["kind"] == 0).sum()) == 0 for p in progs)            # no LD_LEAF: every leaf read is a pool read
-    n_fetch = sum(int((p["kind"] == 29).sum()) for p in progs)
+    n_fetch = sum(int(np.maximum(p["b"][p["kind"] == 29], 1).sum()) for p in progs)         # leaves brought from memory (a fetch brings b = 1 or 2)
     assert n_fetch == info["n_transfer"] >= h.info()["n_live_leaf"]
     leaf = oracle.philox_uniform(3, t.n_leaf, 81)
     got = replay_coop(progs, info, leaf, t.n_root)
