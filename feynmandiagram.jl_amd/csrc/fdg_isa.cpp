@@ -498,6 +498,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   if (accumulate) E.ins("s_load_dwordx2 " + S2(S_WGT) + ", s[0:1], 0x48");
   const uint32_t n_k = prog.mc_n_k;               // > 0: Monte-Carlo kernel; input columns >= n_k come from the second base
   const bool mc = n_k > 0 || prog.mc_n_t > 0;
+  const bool tm_imm = dbg && std::strstr(dbg, "tmimm") && !mc && !rm_bufs && !rl && !cs && W == 1;
+  int64_t tm_base = -1;
   const int tile_arg = mc ? 0x80 : 0x50;          // lts, rts follow the other arguments
   E.ins("s_load_dwordx2 " + S2(S_LTS) + ", s[0:1], " + hex32((uint32_t)tile_arg));
   if (!accumulate) E.ins("s_load_dwordx2 " + S2(S_RTS) + ", s[0:1], " + hex32((uint32_t)tile_arg + 8));
@@ -859,6 +861,24 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
             E.ins(LD + vall(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_LP) + leaf_policy);
             E.pend[o.d] = {1, ++E.vm_issued};
           }
+          break;
+        }
+        if (tm_imm) {          // experiment: leaf stride 64 assumed (tile-major): leaf i at tile base + 512 i, reached by the instruction's 13-bit offset
+          const int64_t byte = 512ll * (int64_t)o.a;
+          if (tm_base < 0 || byte - tm_base < -4096 || byte - tm_base > 4095) {
+            tm_base = byte + 4096;             // this leaf at -4096, the fifteen behind it up to +3584
+            E.ins("s_add_u32 " + S(S_LP) + ", " + S(S_LT) + ", " + hex32((uint32_t)tm_base));
+            E.ins("s_addc_u32 " + S(S_LP + 1) + ", " + S(S_LT + 1) + ", 0");
+          }
+          const std::string off = " offset:" + std::to_string(byte - tm_base);
+          if (o.kind == M_LD_LEAF_ACC) {
+            E.ins(LD + "a[" + std::to_string(RW * o.d) + ":" + std::to_string(RW * o.d + RW - 1) + "], " + V(V_LEAFOFF) + ", " + S2(S_LP) + off + leaf_policy);
+            if (E.pend_acc.size() <= o.d) E.pend_acc.resize(o.d + 1, 0);
+            E.pend_acc[o.d] = ++E.vm_issued;
+            break;
+          }
+          E.ins(LD + vall(o.d) + ", " + V(V_LEAFOFF) + ", " + S2(S_LP) + off + leaf_policy);
+          E.pend[o.d] = {1, ++E.vm_issued};
           break;
         }
         {

@@ -1613,7 +1613,9 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     q.n_lds = out.n_priv_lds;
     q.n_land = 0;
     q.pool_leaves = true;
-    q.lookahead_leaf = std::min<uint32_t>(prm.lookahead_lds ? prm.lookahead_lds : 32, 64);      // a pool read is an LDS read
+    // a pool read is an LDS read -- of a pool all four waves and the fetches hammer: issued 96 fold steps ahead of its use (32, the
+    // distance of a wave's private LDS slots: -10 %; 200: the landing registers are missed elsewhere, -4 %; profiles/r04_log_la_lds.txt)
+    q.lookahead_leaf = 96;
     if (const char *e = std::getenv("FDG_POOL_READ_AHEAD")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(e));
     if (!fit_registers(B[w]->u, q, out.wave[w])) { out.why = out.wave[w].why; return; }
     Alloc A(p, out.wave[w].params, B[w]->u, B[w]->next_vid, out.wave[w]);

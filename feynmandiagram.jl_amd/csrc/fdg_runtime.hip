@@ -1393,6 +1393,8 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
 // every program of a handle specialised with FDG_SPEC_FAST_MATH fuses products into sums (v_fma_f64)
 static void build_prog(const fdg_graph *g, fdg::OptParams prm, fdg::OptProgram &out) {
   prm.fma = prm.fma || g->isa_fma;
+  if (const char *e = std::getenv("FDG_LA_LDS")) prm.lookahead_lds = (uint32_t)std::max(1, std::atoi(e));       // experiments
+  if (const char *e = std::getenv("FDG_LA_LDS_B")) { if (prm.n_acc) prm.lookahead_lds = (uint32_t)std::max(1, std::atoi(e)); }   // ... one wave per SIMD only
   fdg::build_opt_program(g->prog, prm, out);
 }
 
