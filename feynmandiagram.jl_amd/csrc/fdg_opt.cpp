@@ -1734,7 +1734,15 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
   }
   // ---- fetch ops into the waves' lists (round robin, right after the barrier that opens the issue epoch); leaf reads become pool reads -----
   std::vector<std::vector<std::vector<Fetch>>> at(NW, std::vector<std::vector<Fetch>>(n_epoch + 1));
-  for (size_t i = 0; i < fetches.size(); ++i) at[i % NW][fetches[i].issue].push_back(fetches[i]);
+  {   // dealt epoch by epoch (an issue costs the wave about a hundred cycles: the waves of an epoch should issue equally many), the
+      // surplus of an epoch going to the waves after those that got the last one
+    std::vector<std::vector<size_t>> by_issue(n_epoch + 1);
+    for (size_t i = 0; i < fetches.size(); ++i) by_issue[fetches[i].issue].push_back(i);
+    uint32_t turn = 0;
+    const bool global_rr = std::getenv("FDG_POOL_DEAL_GLOBAL") != nullptr;      // (experiment: the round-3 dealing, by global index)
+    for (uint32_t ep = 0; ep <= n_epoch; ++ep)
+      for (size_t i : by_issue[ep]) { at[global_rr ? i % NW : turn % NW][ep].push_back(fetches[i]); turn++; }
+  }
   for (uint32_t w = 0; w < NW; ++w) {
     std::vector<MOp> r;
     r.reserve(out.wave[w].ops.size() + fetches.size() / NW + 8);

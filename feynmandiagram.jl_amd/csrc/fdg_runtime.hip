@@ -1190,6 +1190,7 @@ static fdg::OptParams pool_params(fdg::OptParams q, uint32_t nw) {
   q.n_acc = nw >= 8 ? 0 : 124;
   q.n_land = 0;
   q.lookahead_lds = 32;
+  if (const char *e = std::getenv("FDG_POOL_LA_LDS")) q.lookahead_lds = (uint32_t)std::max(1, std::atoi(e));       // experiments
   return q;
 }
 
