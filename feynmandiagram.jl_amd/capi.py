@@ -34,7 +34,7 @@ EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
     "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_clock_probe_device", "fdg_graph_specialize_typed", "fdg_eval_device_typed", "fdg_graph_create_complex_view", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
-    "fdg_eval_strided", "fdg_graph_coop_program", "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device",
+    "fdg_eval_strided", "fdg_graph_coop_program", "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device", "fdg_leaf_eval_device_tiled",
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
     "fdg_graph_kernel_info",
@@ -160,6 +160,7 @@ def lib():
     L.fdg_isa_check_hazards.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
     L.fdg_graph_release_device.argtypes = [vp]
     L.fdg_leaf_eval_device.argtypes = [C.POINTER(LeafTables), dp, i64, i64, dp, i64, i64, dp, i64, i64, i64, vp]
+    L.fdg_leaf_eval_device_tiled.argtypes = [C.POINTER(LeafTables), dp, i64, i64, dp, i64, i64, dp, i64, i64, i64, i64, vp]
     L.fdg_graph_set_schedule_groups.argtypes = [vp, C.c_void_p, u32]
     L.fdg_graph_set_opt_params.argtypes = [vp, C.POINTER(OptParams)]
     L.fdg_graph_opt_program.argtypes = [vp, C.POINTER(OptParams), C.POINTER(C.POINTER(MOp)), C.POINTER(C.c_uint64),
@@ -493,3 +494,11 @@ def leaf_eval_device(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, 
     """fdg_leaf_eval_device with the tables of ``FrontEnds.leafstates`` (1-based indices)."""
     t, _keep = make_leaf_tables(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, dim, n_tau, kF, beta, lam)
     check(lib().fdg_leaf_eval_device(C.byref(t), d_K, ks, kc, d_T, ts, tc, d_leaf, ss, ls, B, stream))
+
+
+def leaf_eval_device_tiled(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, dim, n_tau, kF, beta, lam,
+                           d_K: int, ks: int, kc: int, d_T: int, ts: int, tc: int, d_leaf: int, ss: int, ls: int, lts: int, B: int,
+                           stream: int = 0):
+    """fdg_leaf_eval_device_tiled: the leaves of a tile-major batch (sample b of leaf i at ``(b // 64) * lts + (b % 64) * ss + i * ls``)."""
+    t, _keep = make_leaf_tables(leaf_type, leaf_order, tau_in, tau_out, loop_index, basis, dim, n_tau, kF, beta, lam)
+    check(lib().fdg_leaf_eval_device_tiled(C.byref(t), d_K, ks, kc, d_T, ts, tc, d_leaf, ss, ls, lts, B, stream))

@@ -65,7 +65,7 @@ fdg_leaf_kernel(const int32_t *__restrict__ ltype, const int32_t *__restrict__ l
                 const double *__restrict__ basis,
                 uint32_t L, uint32_t n_loop, uint32_t dim, uint32_t n_tau, double kF, double beta, double lambda,
                 const double *__restrict__ K, long ks, long kc, const double *__restrict__ T, long ts, long tc,
-                double *__restrict__ leaf, long ss, long ls, long B) {
+                double *__restrict__ leaf, long ss, long ls, long lts, long B) {
   extern __shared__ double sh[];                 // [(n_loop*dim + n_tau)][64]
   const int t = threadIdx.x;
   double *kk = sh + t;
@@ -75,6 +75,7 @@ fdg_leaf_kernel(const int32_t *__restrict__ ltype, const int32_t *__restrict__ l
     const long b0 = tile * 64 + t;
     const bool valid = b0 < B;
     const long b = valid ? b0 : B - 1;
+    const long bl = tile * lts + (long)t * ss;          // this lane's sample in the leaf batch (tile stride: plain matrices pass 64 ss)
     for (uint32_t c = 0; c < n_loop * dim; ++c) kk[(size_t)c * 64] = K[b * ks + (long)c * kc];
     for (uint32_t i = 0; i < n_tau; ++i) tt[(size_t)i * 64] = T[b * ts + (long)i * tc];
     int32_t cur = -1;
@@ -99,7 +100,7 @@ fdg_leaf_kernel(const int32_t *__restrict__ ltype, const int32_t *__restrict__ l
         double tau = tt[(size_t)(tout[i] - 1) * 64] - tt[(size_t)(tin[i] - 1) * 64];
         if (lorder[i] != 0) {                    // wave-uniform
           v = fdg_fermi_dn(tau, w, beta, lorder[i]);
-          if (valid) leaf[b * ss + (long)oidx[i] * ls] = v;
+          if (valid) leaf[bl + (long)oidx[i] * ls] = v;
           continue;
         }
         if (tau == 0.0) tau = -1e-10;
@@ -113,7 +114,7 @@ fdg_leaf_kernel(const int32_t *__restrict__ ltype, const int32_t *__restrict__ l
         const double invK = 1.0 / (q2 + lambda);
         v = 8.0 * 3.141592653589793 / invK * fdg_powi_impl(lambda * invK, lorder[i] == 0 ? 0 : lorder[i]);
       }
-      if (valid) leaf[b * ss + (long)oidx[i] * ls] = v;
+      if (valid) leaf[bl + (long)oidx[i] * ls] = v;
     }
   }
 }
@@ -178,7 +179,7 @@ static std::string emit_leaf_statements(const fdg_leaf_tables *tab, const std::v
       os << ";\n";
     }
     if (fused) os << "    g" << i << " = v;\n";
-    else os << "    if (valid) leaf[b * ss + " << i << "L * ls] = v;\n";
+    else os << "    if (valid) leaf[bl + " << i << "L * ls] = v;\n";
   }
   return os.str();
 }
@@ -194,10 +195,11 @@ static std::string emit_leaf_source(const fdg_leaf_tables *tab, const std::vecto
   if (needs_fermi_dn(tab)) os << kFermiDnSource << "\n";
   os << "extern \"C\" __global__ void __launch_bounds__(64) fdg_leaf_spec(const double *__restrict__ K, long ks, long kc,\n"
         "    const double *__restrict__ T, long ts, long tc, double *__restrict__ leaf, long ss, long ls, long B,\n"
-        "    double kF, double beta, double lambda) {\n"
+        "    double kF, double beta, double lambda, long lts) {\n"
         "  const long ntile = (B + 63) / 64;\n"
         "  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {\n"
-        "    const long b0 = tile * 64 + threadIdx.x;\n    const bool valid = b0 < B;\n    const long b = valid ? b0 : B - 1;\n";
+        "    const long b0 = tile * 64 + threadIdx.x;\n    const bool valid = b0 < B;\n    const long b = valid ? b0 : B - 1;\n"
+        "    const long bl = tile * lts + (long)threadIdx.x * ss;\n";
   os << emit_leaf_statements(tab, perm, false);
   os << "  }\n}\n";
   return os.str();
@@ -330,12 +332,13 @@ static int leaf_plan(const fdg_leaf_tables *tab, const LeafPlan **out) {
 }
 
 static int leaf_launch(const LeafPlan *p, const fdg_leaf_tables *tab, const double *d_K, int64_t ks, int64_t kc, const double *d_T,
-                       int64_t ts, int64_t tc, double *d_leaf, int64_t ss, int64_t ls, int64_t B, hipStream_t st) {
+                       int64_t ts, int64_t tc, double *d_leaf, int64_t ss, int64_t ls, int64_t B, hipStream_t st, int64_t lts = 0) {
   const long ntile = (long)((B + 63) / 64);
+  if (!lts) lts = 64 * ss;                  // a plain strided matrix
   if (p->fn) {
-    long a_ks = ks, a_kc = kc, a_ts = ts, a_tc = tc, a_ss = ss, a_ls = ls, a_B = B;
+    long a_ks = ks, a_kc = kc, a_ts = ts, a_tc = tc, a_ss = ss, a_ls = ls, a_B = B, a_lts = lts;
     double a_kF = tab->kF, a_beta = tab->beta, a_lambda = tab->lambda;
-    void *args[] = {(void *)&d_K, &a_ks, &a_kc, (void *)&d_T, &a_ts, &a_tc, (void *)&d_leaf, &a_ss, &a_ls, &a_B, &a_kF, &a_beta, &a_lambda};
+    void *args[] = {(void *)&d_K, &a_ks, &a_kc, (void *)&d_T, &a_ts, &a_tc, (void *)&d_leaf, &a_ss, &a_ls, &a_B, &a_kF, &a_beta, &a_lambda, &a_lts};
     const long grid = std::min<long>(ntile, (long)p->n_cu * 32);
     HIP_TRY(hipModuleLaunchKernel(p->fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, st, args, nullptr));
     return FDG_OK;
@@ -348,7 +351,7 @@ static int leaf_launch(const LeafPlan *p, const fdg_leaf_tables *tab, const doub
                      (const int32_t *)(d_tab + 2 * ib), (const int32_t *)(d_tab + 3 * ib), (const int32_t *)(d_tab + 4 * ib),
                      (const int32_t *)(d_tab + 5 * ib),
                      (const double *)(d_tab + p->boff), tab->n_leaf, tab->n_loop, tab->dim, tab->n_tau, tab->kF, tab->beta, tab->lambda, d_K,
-                     (long)ks, (long)kc, d_T, (long)ts, (long)tc, d_leaf, (long)ss, (long)ls, (long)B);
+                     (long)ks, (long)kc, d_T, (long)ts, (long)tc, d_leaf, (long)ss, (long)ls, (long)lts, (long)B);
   HIP_TRY(hipGetLastError());
   return FDG_OK;
 }
@@ -362,6 +365,19 @@ int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t 
   const LeafPlan *p = nullptr;
   { const int rc = leaf_plan(tab, &p); if (rc) return rc; }
   return leaf_launch(p, tab, d_K, ks, kc, d_T, ts, tc, d_leaf, ss, ls, B, (hipStream_t)stream);
+}
+
+// Tile-major leaves (fdg.h: fdg_eval_device_tiled): sample b of leaf i at d_leaf[(b / 64) lts + (b % 64) ss + i ls].
+int fdg_leaf_eval_device_tiled(const fdg_leaf_tables *tab, const double *d_K, int64_t ks, int64_t kc, const double *d_T,
+                               int64_t ts, int64_t tc, double *d_leaf, int64_t ss, int64_t ls, int64_t lts, int64_t B, void *stream) {
+  { const int rc0 = check_leaf_tables(tab); if (rc0) return rc0; }
+  if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
+  if (lts == 0) { set_error("leaf tile stride 0 (a plain matrix goes through fdg_leaf_eval_device)"); return FDG_E_INVALID; }
+  if (B == 0 || tab->n_leaf == 0) return FDG_OK;
+  if (!d_K || !d_T || !d_leaf) { set_error("null device buffer"); return FDG_E_INVALID; }
+  const LeafPlan *p = nullptr;
+  { const int rc = leaf_plan(tab, &p); if (rc) return rc; }
+  return leaf_launch(p, tab, d_K, ks, kc, d_T, ts, tc, d_leaf, ss, ls, B, (hipStream_t)stream, lts);
 }
 
 // ---- fused Monte-Carlo step --------------------------------------------------------------------

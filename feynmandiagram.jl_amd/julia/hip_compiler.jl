@@ -358,3 +358,25 @@ function leaf_eval_device!(d_leaf::Ptr{Float64}, leafType::Vector{Int}, leafOrde
     end
     return nothing
 end
+
+"""
+    leaf_eval_device_tiled!(d_leaf, leafType, ..., d_K, d_T, B; ...)
+
+The same into a tile-major batch `Array{Float64,3}(64, L, cld(B, 64))` (`fdg_leaf_eval_device_tiled`): what `eval_device_tiled!` and
+`accumulate_device_tiled!` read.
+"""
+function leaf_eval_device_tiled!(d_leaf::Ptr{Float64}, leafType::Vector{Int}, leafOrder::Vector{Int}, leafInTau::Vector{Int}, leafOutTau::Vector{Int},
+    leafLoopIndex::Vector{Int}, loopbasis::Matrix{Float64}, d_K::Ptr{Float64}, d_T::Ptr{Float64}, B::Integer;
+    dim::Int=3, n_tau::Int, kF::Float64, beta::Float64, lambda::Float64, stream::Ptr{Cvoid}=C_NULL)
+    a = [Int32.(v) for v in (leafType, leafOrder, leafInTau, leafOutTau, leafLoopIndex)]
+    bs = Matrix{Float64}(loopbasis)
+    L = length(a[1])
+    GC.@preserve a bs begin
+        tab = _FdgLeafTables(L, size(bs, 2), size(bs, 1), dim, n_tau, pointer(a[1]), pointer(a[2]), pointer(a[3]),
+            pointer(a[4]), pointer(a[5]), pointer(bs), kF, beta, lambda)
+        _fdg_check(ccall((:fdg_leaf_eval_device_tiled, _libfdg), Cint,
+            (Ref{_FdgLeafTables}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64, Int64, Int64, Ptr{Cvoid}),
+            tab, d_K, 1, B, d_T, 1, B, d_leaf, 1, 64, 64 * L, B, stream))
+    end
+    return nothing
+end

@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define FDG_VERSION 101 /* 0.1.1: tile-major batches, interpreter association */
+#define FDG_VERSION 102 /* 0.1.1: tile-major batches, interpreter association */
 
 #define FDG_OP_SUM 0u
 #define FDG_OP_PROD 1u
@@ -403,6 +403,14 @@ int fdg_leaf_eval_device(const fdg_leaf_tables *tab, const double *d_K, int64_t 
                          int64_t k_comp_stride, const double *d_T, int64_t t_sample_stride,
                          int64_t t_comp_stride, double *d_leaf, int64_t leaf_sample_stride,
                          int64_t leaf_leaf_stride, int64_t n_sample, void *stream);
+
+/* The same with TILE-MAJOR leaves (fdg_eval_device_tiled): sample b of leaf i is written to
+ * d_leaf[(b / 64) * leaf_tile_stride + (b % 64) * leaf_sample_stride + i * leaf_leaf_stride], so that the Monte-Carlo loop
+ * (K, T) -> leaves -> fdg_accumulate_device_tiled runs on the layout the evaluator streams fastest. */
+int fdg_leaf_eval_device_tiled(const fdg_leaf_tables *tab, const double *d_K, int64_t k_sample_stride,
+                               int64_t k_comp_stride, const double *d_T, int64_t t_sample_stride,
+                               int64_t t_comp_stride, double *d_leaf, int64_t leaf_sample_stride,
+                               int64_t leaf_leaf_stride, int64_t leaf_tile_stride, int64_t n_sample, void *stream);
 
 /* Fused Monte-Carlo step (the integrand of example/benchmark.jl:58-87 in one kernel):
  * the leaves are worked out in registers from the sample's loop momenta K and times T with the formulas

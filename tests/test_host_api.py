@@ -172,7 +172,7 @@ def test_library_exports_every_declared_symbol(libfdg):
     for name in declared:
         assert hasattr(libfdg, name), f"libfdg.so does not export {name}"
     assert sorted(capi.EXPORTS) == declared
-    assert libfdg.fdg_version() == 101
+    assert libfdg.fdg_version() == 102
 
 
 def test_graph_create_validation_and_info(libfdg):

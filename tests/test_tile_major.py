@@ -1,6 +1,8 @@
 """Tile-major batches (include/fdg.h: fdg_eval_device_tiled, fdg_accumulate_device_tiled, fdg_fill_uniform_device_tiled):
 sample b = 64 t + l of leaf i at leaf[t * tile_stride + l * sample_stride + i * leaf_stride] -- a Julia
 Array{Float64,3}(64, L, cld(B, 64)).  Same bits as every other layout; ragged batches; padded strides; the error behaviour."""
+import os
+
 import numpy as np
 import pytest
 
@@ -190,3 +192,44 @@ def test_linear_row_major_variant_on_device(libfdg, cuda, name):
     torch.cuda.synchronize()
     assert f.kernel_info()["last_kernel"] != "fdg_isa_eval_rl"
     assert np.array_equal(got.cpu().numpy(), want[:300])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("B", [64 * 37, 70_001])
+def test_leaves_from_K_T_into_a_tile_major_batch(libfdg, cuda, monkeypatch, B, generic):
+    """fdg_leaf_eval_device_tiled (SURVEY.md 8f row 3 on the layout of 8d): the leaf loop of example/benchmark.jl:58-81 writes a tile-major
+    batch -- the same bits as fdg_leaf_eval_device writes into a plain matrix -- and the tiled evaluator takes it from there: the
+    Monte-Carlo chain (K, T) -> leaves -> roots on the layout that streams fastest, roots equal bit for bit to the plain chain's."""
+    import torch
+    if generic: monkeypatch.setenv("FDG_LEAF_GENERIC", "1")          # the table-driven kernel instead of the one specialised to the tables
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "gv_sigma4_leafstates.npz"))
+    t = workloads.get("gv_sigma4")
+    L, R = t.n_leaf, t.n_root
+    dim, n_loop, n_tau = 3, int(z["basis"].shape[1]), int(z["n_tau"])
+    kF, beta, lam = 1.919, 3.0, 1.2
+    rng = np.random.default_rng(11)
+    K = rng.uniform(-2.0, 2.0, size=(B, n_loop, dim))
+    T = rng.uniform(0.0, beta, size=(B, n_tau)); T[:, 0] = 0.0
+    dK = torch.from_numpy(np.ascontiguousarray(K.reshape(B, n_loop * dim).T)).to(cuda)
+    dT = torch.from_numpy(np.ascontiguousarray(T.T)).to(cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
+    plain = torch.ones((L, B), dtype=torch.float64, device=cuda).t()
+    capi.leaf_eval_device(*args, kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, plain.data_ptr(), plain.stride(0), plain.stride(1), B, st)
+    n_tile = (B + 63) // 64
+    tiled = torch.ones((n_tile, L, 64), dtype=torch.float64, device=cuda)          # type-0 leaves stay 1.0 in both
+    capi.leaf_eval_device_tiled(*args, kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, tiled.data_ptr(), 1, 64, 64 * L, B, st)
+    torch.cuda.synchronize()
+    got = tiled.permute(0, 2, 1).reshape(-1, L)[:B]
+    assert torch.equal(got, plain)
+    if B % 64:
+        assert bool((tiled.permute(0, 2, 1).reshape(-1, L)[B:] == 1.0).all())         # nothing written behind the last sample
+    f = fd.compile_table(t, specialize="isa")
+    want = f(None, plain)
+    root = torch.empty((n_tile, R, 64), dtype=torch.float64, device=cuda)
+    f.eval_tiled(root, tiled, B)
+    torch.cuda.synchronize()
+    assert torch.equal(root.permute(0, 2, 1).reshape(-1, R)[:B], want)
+    with pytest.raises(capi.FdgError):
+        capi.leaf_eval_device_tiled(*args, kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, tiled.data_ptr(), 1, 64, 0, B, st)
