@@ -675,7 +675,7 @@ def main():
         if rank == 0 and world == 1 and not DRY:
             sec = []
             head = (args.workload, args.layout)
-            full = (("parquet_sigma4", "tile_major"), ("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "leaf_major"),
+            full = (("parquet_sigma4", "tile_major"), ("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "tile_major"),
                     ("parquet_sigma4_insdyn", "tile_major"), ("parquet_sigma4_taylor2", "tile_major"), ("parquet_sigma4_taylor2", "leaf_major"), ("parquet_sigma4_taylor2", "tile_major+fma"),
                     ("parquet_sigma5", "tile_major"), ("parquet_ver4_4", "tile_major"), ("gv_ver4_4", "tile_major"), ("gv_ver4_4", "leaf_major"), ("sigma2", "tile_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "tile_major"),
                     ("gv_sigma5", "tile_major"), ("gv_sigma5", "leaf_major"), ("gv_sigma5", "tile_major+fma"),

@@ -144,6 +144,9 @@ struct fdg_graph {
   bool has_rl = false;
   void *fn_isa_rl = nullptr;
   uint32_t isa6_vgpr = 0, isa6_lds_bytes = 0, isa6_mem_slots = 0;
+  bool has_rl_acc = false;           // the linear row-major variant with fused accumulation
+  void *fn_isa_rl_acc = nullptr;
+  uint32_t isa7_vgpr = 0, isa7_lds_bytes = 0, isa7_mem_slots = 0;
   uint64_t rl_valu = 0;
   // pooled cooperative variant: the waves of a CU evaluate one tile, whole roots each, leaves through a shared LDS pool (full tiles, sample stride 1)
   bool has_pool = false;

@@ -1355,7 +1355,7 @@ std::string isa_hazard_table() {
 // `kname`_w2 next to it.
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2,
                      const OptProgram *prog_acc, const OptProgram *prog_rm, uint32_t rm_bufs, const CoopProgram *coop,
-                     const OptProgram *prog_rm_acc, const CoopProgram *pool, const OptProgram *prog_rl) {
+                     const OptProgram *prog_rm_acc, const CoopProgram *pool, const OptProgram *prog_rl, const OptProgram *prog_rl_acc) {
   Emit E;
   E.os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n";
   std::vector<KernelMeta> ks;
@@ -1373,6 +1373,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   if (prog_rm && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm, kname + "_rm", 1, false, rm_bufs));
   if (prog_rm_acc && rm_bufs) ks.push_back(emit_kernel(E, p, *prog_rm_acc, kname + "_rm_acc", 1, true, rm_bufs));
   if (prog_rl) ks.push_back(emit_kernel(E, p, *prog_rl, kname + "_rl", 1, false, 0, nullptr, true));
+  if (prog_rl && prog_rl_acc) ks.push_back(emit_kernel(E, p, *prog_rl_acc, kname + "_rl_acc", 1, true, 0, nullptr, true));
   if (coop && coop->supported) { ks.push_back(emit_coop(E, p, *coop, kname + "_coop")); ks.back().wg = 64 * coop->n_wave; }
   if (pool && pool->supported) { ks.push_back(emit_coop(E, p, *pool, kname + "_pool")); ks.back().wg = 64 * pool->n_wave; }
   std::ostringstream &os = E.os;

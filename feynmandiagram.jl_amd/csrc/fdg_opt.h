@@ -138,7 +138,7 @@ struct CoopProgram;
 std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string &kname, const OptProgram *prog2 = nullptr,
                      const OptProgram *prog_acc = nullptr, const OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0,
                      const CoopProgram *coop = nullptr, const OptProgram *prog_rm_acc = nullptr, const CoopProgram *pool = nullptr,
-                     const OptProgram *prog_rl = nullptr);
+                     const OptProgram *prog_rl = nullptr, const OptProgram *prog_rl_acc = nullptr);
 
 // Cooperative variant: the four waves of a CU (one per SIMD) evaluate ONE 64-sample tile together.  Each wave runs its own
 // straight-line program on its share of the graph with its own registers, AGPRs, private LDS slots and panel; a value

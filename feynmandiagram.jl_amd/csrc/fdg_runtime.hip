@@ -425,6 +425,7 @@ static int ensure_module(fdg_graph *g) {
     if (g->has_coop) { hipFunction_t f5; HIP_TRY(hipModuleGetFunction(&f5, m, "fdg_isa_eval_coop")); g->fn_isa_coop = f5; }
     if (g->has_pool) { hipFunction_t f6; HIP_TRY(hipModuleGetFunction(&f6, m, "fdg_isa_eval_pool")); g->fn_isa_pool = f6; }
     if (g->has_rl) { hipFunction_t f7; HIP_TRY(hipModuleGetFunction(&f7, m, "fdg_isa_eval_rl")); g->fn_isa_rl = f7; }
+    if (g->has_rl_acc) { hipFunction_t f8; HIP_TRY(hipModuleGetFunction(&f8, m, "fdg_isa_eval_rl_acc")); g->fn_isa_rl_acc = f8; }
     return FDG_OK;
   }
   hipFunction_t f1, f2;
@@ -497,8 +498,9 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     set_error("tile-major batch: negative strides or sample strides of 2^23 elements or more are not supported"); return FDG_E_UNSUPPORTED;
   }
 
-  const bool rl_shape = g->has_rl && mode == 0 && ls == 1 && ss == (int64_t)p.L && p.L >= 2 && B >= 64 && ((uintptr_t)d_leaf & 15) == 0 &&
-                        !(rs < 0 || rs >= (1ll << 23)) && !std::getenv("FDG_ISA_NO_RL");      // contiguous rows: the linear variant below
+  const bool rl_rows = g->has_rl && ls == 1 && ss == (int64_t)p.L && p.L >= 2 && B >= 64 && ((uintptr_t)d_leaf & 15) == 0 && !std::getenv("FDG_ISA_NO_RL");
+  const bool rl_shape = rl_rows && ((mode == 0 && !(rs < 0 || rs >= (1ll << 23))) ||                       // contiguous rows: the linear variant below
+                                    (mode == 1 && g->has_rl_acc && g->has_acc && !std::getenv("FDG_ISA_NO_FUSED_ACC")));
   if (!g->code_object.empty() && g->isa && !g->alt_code.empty() && ls == 1 && ss != 1 && p.L > 1 && !tiled && !rl_shape) {
     // sample-major input and a companion: its lanes read their own rows; no transposition pass
     if (!g->alt_module) {
@@ -668,7 +670,26 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // itself -- the matrix is read once, in place -- for evaluation and for fused accumulation alike; the last B % 64 rows
     // go through the plain kernel with the caller's strides (its lanes gather their own rows: fine for under a tile).
     // Contiguous rows (sample stride == L, 16-byte aligned base): full tiles through the linear variant -- the tile's block streamed into an LDS image.
-    if (rl_shape && g->fn_isa_rl && !tiled) {
+    if (rl_shape && mode == 1 && g->fn_isa_rl_acc && !tiled) {
+      const long n4 = (long)(B & ~(int64_t)63), tail = (long)B - n4;
+      const long grid7 = (long)g->n_cu * waves_per_cu(g->isa7_vgpr, g->isa7_lds_bytes);
+      const size_t panel7 = ((size_t)std::max<uint32_t>(g->isa7_mem_slots, 1) * 512u * (size_t)grid7 + 4095) & ~(size_t)4095;
+      // (the partial sums of this launch and of the tail's launch_acc live behind the larger of the two panels)
+      rc = ensure_ws(g, std::max(panel_all, panel7) + (size_t)std::max(std::max(grid3, grid5), grid7) * R * 512u + 4096);
+      if (rc) return rc;
+      void *a_wsp = g->d_ws;
+      double *part = (double *)((char *)g->d_ws + std::max(panel_all, panel7));
+      long nwg = std::min<long>(n4 / 64, grid7), lss = ss, lls = ls, zero = 0, nn = n4, tls = 64 * lss;
+      void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&part, &zero, &zero, &a_wsp, &nn, &nwg, (void *)&d_weight, &tls, &zero};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rl_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+      hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
+      HIP_TRY(hipGetLastError());
+      g->last_kernel = "fdg_isa_eval_rl_acc";
+      named = true;
+      if (tail) { rc = launch_acc(d_leaf + (size_t)n4 * (size_t)ss, lss, lls, d_weight ? d_weight + n4 : nullptr, tail); if (rc) return rc; }
+      return FDG_OK;
+    }
+    if (rl_shape && mode == 0 && g->fn_isa_rl && !tiled) {
       const long n4 = (long)(B & ~(int64_t)63), tail = (long)B - n4;
       const long grid6 = (long)g->n_cu * waves_per_cu(g->isa6_vgpr, g->isa6_lds_bytes);
       rc = ensure_ws(g, std::max(panel_all + (size_t)std::max(grid3, grid5) * R * 512u + 4096, (size_t)std::max<uint32_t>(g->isa6_mem_slots, 1) * 512u * (size_t)grid6 + 4096));
@@ -1272,8 +1293,8 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
                         const fdg::OptProgram *prog_acc = nullptr, const char *kname = "fdg_isa_eval",
                         const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr,
                         const fdg::OptProgram *prog_rm_acc = nullptr, const fdg::CoopProgram *pool = nullptr,
-                        const fdg::OptProgram *prog_rl = nullptr) {
-  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc, prog_rm, rm_bufs, coop, prog_rm_acc, pool, prog_rl);
+                        const fdg::OptProgram *prog_rl = nullptr, const fdg::OptProgram *prog_rl_acc = nullptr) {
+  const std::string src = fdg::emit_isa(g->prog, prog, kname, prog2, prog_acc, prog_rm, rm_bufs, coop, prog_rm_acc, pool, prog_rl, prog_rl_acc);
   char hbuf[40];
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(src, fnv1a("isa")));
   hash = hbuf;
@@ -1307,8 +1328,17 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
                         const fdg::OptProgram *prog2 = nullptr, const fdg::OptProgram *prog_acc = nullptr,
                         const fdg::OptProgram *prog_rm = nullptr, uint32_t rm_bufs = 0, const fdg::CoopProgram *coop = nullptr,
                         const fdg::OptProgram *prog_rm_acc = nullptr, const fdg::CoopProgram *pool = nullptr,
-                        const fdg::OptProgram *prog_rl = nullptr) {
+                        const fdg::OptProgram *prog_rl = nullptr, const fdg::OptProgram *prog_rl_acc = nullptr) {
   if (g->module) { hipModuleUnload((hipModule_t)g->module); g->module = nullptr; }
+  g->has_rl_acc = prog_rl != nullptr && prog_rl_acc != nullptr;
+  g->fn_isa_rl_acc = nullptr;
+  if (g->has_rl_acc) {
+    uint32_t t7 = 0;
+    for (const fdg::MOp &o : prog_rl_acc->ops) t7 = std::max(t7, fdg::mop_tmp_pairs(o.kind));
+    g->isa7_vgpr = ((6 + 2 * std::max<uint32_t>(prog_rl_acc->n_reg_used, 1) + 2 * (g->prog.R + 2) + 2 * t7 + 2 + 3) & ~3u) + 2 * prog_rl_acc->n_acc_used;
+    g->isa7_lds_bytes = ((prog_rl_acc->n_lds_used * 512u + 1023u) & ~1023u) + ((512u * g->prog.L + 1023u) & ~1023u);
+    g->isa7_mem_slots = prog_rl_acc->n_mem_used;
+  }
   g->has_rl = prog_rl != nullptr;
   g->fn_isa_rl = nullptr;
   if (g->has_rl) {
@@ -1572,8 +1602,8 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
 }
 
 struct IsaVariants {
-  fdg::OptProgram p2, pa, pr, pra, prl;
-  bool rl = false;
+  fdg::OptProgram p2, pa, pr, pra, prl, prla;
+  bool rl = false, rl_acc = false;
   fdg::CoopProgram coop, pool;
   bool w2 = false, acc = false, rm_acc = false;
   uint32_t rm_bufs = 0;
@@ -1656,6 +1686,16 @@ static void build_rl(const fdg_graph *g, const fdg::OptParams &chosen, IsaVarian
   if (const char *la = std::getenv("FDG_ISA_RL_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
   build_prog(g, q, V.prl);
   V.rl = V.prl.supported && V.prl.n_ld_mem + V.prl.n_st_mem == 0;
+  // fused accumulation over the same rows: R accumulators, the weight and a temporary above the values
+  V.rl_acc = false;
+  if (V.rl && V.acc && g->prog.R >= 1 && g->prog.R <= 40 && !std::getenv("FDG_ISA_NO_RL_ACC")) {
+    q.reserve_pairs += g->prog.R + 2;
+    q.n_reg = std::min<uint32_t>(q.n_reg, (256u - 6u - 2u * (g->prog.R + 2) - 2u - 8u) / 2u);
+    q.roots_last = false;            // (a root is consumed where it is finished)
+    build_prog(g, q, V.prla);
+    V.rl_acc = V.prla.supported && V.prla.n_ld_mem + V.prla.n_st_mem == 0 &&
+               ((V.prla.n_lds_used * 512u + 1023u) & ~1023u) + ((512u * g->prog.L + 1023u) & ~1023u) <= 160u * 1024u / 3u;
+  }
 }
 static int assemble_and_install(fdg_graph *g, const fdg::OptProgram &prog, const std::string &dir, unsigned flags, IsaVariants &V) {
   std::vector<char> co; std::string hash;
@@ -1665,10 +1705,11 @@ static int assemble_and_install(fdg_graph *g, const fdg::OptProgram &prog, const
   const fdg::CoopProgram *coop = V.coop.supported ? &V.coop : nullptr;
   const fdg::CoopProgram *pool = V.pool.supported ? &V.pool : nullptr;
   const int rc = assemble_isa(g, prog, dir, flags, co, hash, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, "fdg_isa_eval",
-                              V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop, V.rm_acc ? &V.pra : nullptr, pool, V.rl ? &V.prl : nullptr);
+                              V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop, V.rm_acc ? &V.pra : nullptr, pool, V.rl ? &V.prl : nullptr,
+                              V.rl && V.rl_acc ? &V.prla : nullptr);
   if (rc) return rc;
   install_isa(g, prog, co, hash, flags, V.w2 ? &V.p2 : nullptr, V.acc ? &V.pa : nullptr, V.rm_bufs ? &V.pr : nullptr, V.rm_bufs, coop,
-              V.rm_acc ? &V.pra : nullptr, pool, V.rl ? &V.prl : nullptr);
+              V.rm_acc ? &V.pra : nullptr, pool, V.rl ? &V.prl : nullptr, V.rl && V.rl_acc ? &V.prla : nullptr);
   return FDG_OK;
 }
 

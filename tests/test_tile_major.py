@@ -195,6 +195,34 @@ def test_linear_row_major_variant_on_device(libfdg, cuda, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["parquet_sigma4", "sigma2", "parquet_sigma3"])
+def test_linear_row_major_variant_accumulates_on_device(libfdg, cuda, name):
+    """fdg_isa_eval_rl_acc: acc[k] += sum_b w_b root_k(b) over compile_Python's row-major [B, L] with contiguous rows -- the linear variant's image
+    and the fused accumulators in one kernel (the roots are never written; without it the 2- and 3-loop graphs went through a transposition
+    pass: 0.13-0.21 of the HBM roof).  Agrees with the weighted sum of the oracle's roots to 1e-12 of the terms' scale; with and without
+    weights; the last B % 64 rows through the plain accumulating kernel."""
+    import torch
+    t = workloads.get(name)
+    L, R = t.n_leaf, t.n_root
+    f = fd.compile_table(t, specialize="isa")
+    for B, weighted in ((64 * 50, True), (200_003, True), (4099, False)):
+        h_leaf = oracle.philox_uniform(B, L, 97)
+        want = oracle.eval_static(t, h_leaf)
+        w = np.random.default_rng(B).uniform(0.5, 1.5, B) if weighted else np.ones(B)
+        leaf = torch.from_numpy(h_leaf).to(cuda)
+        acc = torch.zeros(R, dtype=torch.float64, device=cuda)
+        f.accumulate(leaf, torch.from_numpy(w).to(cuda) if weighted else None, acc)
+        torch.cuda.synchronize()
+        assert f.kernel_info()["last_kernel"] == "fdg_isa_eval_rl_acc", f.kernel_info()["last_kernel"]
+        terms = want * w[:, None]
+        assert np.all(np.abs(acc.cpu().numpy() - terms.sum(0)) <= 1e-12 * np.maximum(1.0, np.abs(terms).sum(0))), (name, B)
+        # a second call adds to the accumulators
+        f.accumulate(leaf, torch.from_numpy(w).to(cuda) if weighted else None, acc)
+        torch.cuda.synchronize()
+        assert np.all(np.abs(acc.cpu().numpy() - 2 * terms.sum(0)) <= 2e-12 * np.maximum(1.0, np.abs(terms).sum(0))), (name, B)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("B", [64 * 37, 70_001])
 def test_leaves_from_K_T_into_a_tile_major_batch(libfdg, cuda, monkeypatch, B, generic):

@@ -14,7 +14,7 @@ python $R/tools/rocpd_stats.py --last=100 $(find "$OUT/trace_headline" -name "*.
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t -- python $R/bench.py --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/trace.log"
 python $R/tools/rocpd_stats.py $(find "$OUT/trace" -name "*.db") > "$OUT/kernel_stats.txt" 2>&1
 [ "${PROF_TRACE_ONLY:-0}" = 1 ] && { cat "$OUT/kernel_stats_headline.txt" "$OUT/kernel_stats.txt"; exit 0; }
-SPECS=("parquet_sigma4 tile_major" "parquet_sigma4 leaf_major" "parquet_sigma4 sample_major" "parquet_sigma4_dyn leaf_major" "parquet_sigma4_insdyn tile_major"
+SPECS=("parquet_sigma4 tile_major" "parquet_sigma4 leaf_major" "parquet_sigma4 sample_major" "parquet_sigma4_dyn tile_major" "parquet_sigma4_insdyn tile_major"
        "parquet_sigma4_taylor2 tile_major" "parquet_sigma4_taylor2 leaf_major" "parquet_sigma5 tile_major" "parquet_ver4_4 tile_major" "gv_ver4_4 tile_major" "gv_ver4_4 leaf_major"
        "sigma2 tile_major" "sigma4_standin leaf_major" "gv_sigma4 tile_major" "gv_sigma5 tile_major" "gv_sigma5 leaf_major" "gv_sigma6 leaf_major" "gv_sigma4_taylor2 tile_major" "gv_sigma4_taylor2 sample_major")
 for spec in "${SPECS[@]}"; do
