@@ -559,7 +559,12 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     const long grid2 = g->has_w2 ? (long)g->n_cu * waves_per_cu(g->isa2_vgpr, g->isa2_lds_bytes) : 0;
     const size_t panel = std::max((size_t)std::max<uint32_t>(g->isa_mem_slots, 1) * 512u * (size_t)grid,
                                   (size_t)std::max<uint32_t>(g->isa2_mem_slots, 1) * 1024u * (size_t)grid2);
-    const bool fused_acc = mode == 1 && g->has_acc && !std::getenv("FDG_ISA_NO_FUSED_ACC");
+    // pooled cooperative variant: full tiles of batches whose samples of a leaf are contiguous and whose leaves lie within 2 GB of the tile's first
+    const bool pool_ok = g->has_pool && g->fn_isa_pool && ss == 1 && ls > 0 && (g->pool_unit == 1 || ls == 64) &&
+                         (uint64_t)ls * 8u * (uint64_t)std::max<uint32_t>(p.L, 1) < (1ull << 31) && B >= 64 && !std::getenv("FDG_ISA_NO_POOL");
+    // (a graph that has the pooled variant accumulates through it and the root scratch: its fused-accumulation program, with R + 2 fewer value
+    //  registers and no pool, runs the 4-loop GV vertex function at 0.87e8 samples/s where the pooled evaluation + the weighted sum do 1.3e8)
+    const bool fused_acc = mode == 1 && g->has_acc && !std::getenv("FDG_ISA_NO_FUSED_ACC") && !(pool_ok && !std::getenv("FDG_ISA_POOL_NO_ACC"));
     const long grid3 = g->has_acc ? shape(g->st_valu[1], 8ull * p.L, g->isa3_vgpr, g->isa3_lds_bytes, ((size_t)g->isa3_mem_slots + R) * 512u) : 0;
     const size_t panel3 = (size_t)std::max<uint32_t>(g->isa3_mem_slots, 1) * 512u * (size_t)grid3;
     const long grid4 = g->has_rm ? (long)g->n_cu * waves_per_cu(g->isa4_vgpr, g->isa4_lds_bytes) : 0;
@@ -636,21 +641,30 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // Pooled cooperative variant: one workgroup per CU walks full 64-sample tiles; a leaf's 64 samples must be contiguous (the pool fetch
     // reads 16 bytes per lane) and every leaf within 2^31 bytes of the tile's first -- tile-major batches, or small leaf-major matrices.
     // The last B % 64 samples go through the one-wave kernel.
-    if (mode == 0 && g->has_pool && g->fn_isa_pool && ss == 1 && ls > 0 && (g->pool_unit == 1 || ls == 64) && (uint64_t)ls * 8u * (uint64_t)std::max<uint32_t>(p.L, 1) < (1ull << 31) && B >= 64 &&
-        !(rs < 0 || rs >= (1ll << 23)) && !std::getenv("FDG_ISA_NO_POOL")) {
+    // mode 1 without fused accumulation (see fused_acc): the roots go to the column-major scratch, then the weighted sum
+    auto finish_scratch_acc = [&]() -> int {
+      double *partial = roots + (size_t)a_rk * R;
+      const uint32_t pb = (uint32_t)std::min<long>(2048, nblk);
+      hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb), dim3(256), 0, st, roots, a_rk, d_weight, (long)B, R, partial);
+      hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, pb, R, d_acc);
+      HIP_TRY(hipGetLastError());
+      return FDG_OK;
+    };
+    if (pool_ok && ((mode == 0 && !(rs < 0 || rs >= (1ll << 23))) || (mode == 1 && !fused_acc))) {
       const long n4 = (long)(B & ~(int64_t)63), tail = (long)B - n4;
-      long nwg = std::min<long>(n4 / 64, (long)g->n_cu), lss = ss, lls = ls, rrs = rs, rrk = rk;
+      double *rt0 = mode == 0 ? d_root : roots;
+      long nwg = std::min<long>(n4 / 64, (long)g->n_cu), lss = ss, lls = ls, rrs = mode == 0 ? rs : a_rs, rrk = mode == 0 ? rk : a_rk;
       rc = ensure_ws(g, std::max(panel_all + (size_t)grid3 * R * 512u + 4096, (size_t)g->pool_panel_wg * (size_t)nwg + 4096));
       if (rc) return rc;
       void *a_wsp = g->d_ws;
       const double *nowt = nullptr;
-      long tls = lts ? (long)lts : 64 * lss, trs = rts ? (long)rts : 64 * rrs, nn = n4;
-      void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt, &tls, &trs};
+      long tls = lts ? (long)lts : 64 * lss, trs = (mode == 0 && rts) ? (long)rts : 64 * rrs, nn = n4;
+      void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&rt0, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt, &tls, &trs};
       HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_pool, (unsigned)nwg, 1, 1, g->pool_threads, 1, 1, 0, st, args, nullptr));
       g->last_kernel = "fdg_isa_eval_pool";
       named = true;
-      if (tail) { rc = launch_isa(d_leaf + (size_t)(n4 / 64) * (size_t)tls, lss, lls, d_root + (size_t)(n4 / 64) * (size_t)trs, rrs, rrk, tail, lts ? tls : 0, rts ? trs : 0); if (rc) return rc; }
-      return FDG_OK;
+      if (tail) { rc = launch_isa(d_leaf + (size_t)(n4 / 64) * (size_t)tls, lss, lls, rt0 + (size_t)(n4 / 64) * (size_t)trs, rrs, rrk, tail, lts ? tls : 0, (mode == 0 && rts) ? trs : 0); if (rc) return rc; }
+      return mode == 1 ? finish_scratch_acc() : FDG_OK;
     }
     // Cooperative variant: one workgroup of four waves per CU, every workgroup walks tiles of 64 samples; leaf-major input.
     if (mode == 0 && g->has_coop && g->coop_enabled && g->fn_isa_coop && !(ls == 1 && ss != 1 && p.L > 1) && !wide_ss && !(rs < 0 || rs >= (1ll << 23)) &&
@@ -788,13 +802,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
                      : launch_isa(d_leaf, (long)ss, (long)ls, roots, a_rs, a_rk, (long)B, (long)lts, mode == 0 ? (long)rts : 0);
       if (rc) return rc;
     }
-    if (mode == 1 && !fused_acc) {
-      double *partial = roots + (size_t)a_rk * R;
-      const uint32_t pb = (uint32_t)std::min<long>(2048, nblk);
-      hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb), dim3(256), 0, st, roots, a_rk, d_weight, (long)B, R, partial);
-      hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, pb, R, d_acc);
-      HIP_TRY(hipGetLastError());
-    }
+    if (mode == 1 && !fused_acc) return finish_scratch_acc();
     return FDG_OK;
   }
 

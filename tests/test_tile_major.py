@@ -166,6 +166,36 @@ def test_pooled_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_pat
 
 
 @pytest.mark.gpu
+def test_pooled_graph_accumulates_through_the_pool(libfdg, cuda):
+    """A graph with the pooled variant (example/benchmark_GV.jl's vertex function) accumulates through it: pooled evaluation into the
+    column-major root scratch, then the weighted sum -- its fused-accumulation program (26 accumulators taken from the value registers,
+    no pool) is a third slower.  Full tiles and the last B % 64 samples; tile-major and leaf-major batches; within 1e-12 of the terms' scale."""
+    import torch
+    t = workloads.get("gv_ver4_4")
+    L, R = t.n_leaf, t.n_root
+    f = fd.compile_table(t, specialize="isa")
+    assert f.kernel_info()["has_pool"] == 1
+    for B in (64 * 40, 4099):
+        h_leaf = oracle.philox_uniform(B, L, 95)
+        want = oracle.eval_static(t, h_leaf)
+        w = np.random.default_rng(B).uniform(0.5, 1.5, B)
+        terms = want * w[:, None]
+        tol = 1e-12 * np.maximum(1.0, np.abs(terms).sum(0))
+        leaf = torch.from_numpy(to_tiles(h_leaf)).to(cuda)
+        acc = torch.zeros(R, dtype=torch.float64, device=cuda)
+        f.accumulate_tiled(leaf, torch.from_numpy(w).to(cuda), acc, B)
+        torch.cuda.synchronize()
+        assert f.kernel_info()["last_kernel"] == "fdg_isa_eval_pool"
+        assert np.all(np.abs(acc.cpu().numpy() - terms.sum(0)) <= tol), B
+        lm = torch.from_numpy(np.ascontiguousarray(h_leaf.T)).to(cuda).t()
+        acc.zero_()
+        f.accumulate(lm, torch.from_numpy(w).to(cuda), acc)
+        torch.cuda.synchronize()
+        assert f.kernel_info()["last_kernel"] == "fdg_isa_eval_pool"
+        assert np.all(np.abs(acc.cpu().numpy() - terms.sum(0)) <= tol), B
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["parquet_sigma4", "sigma2", "parquet_sigma3", "parquet_sigma2"])
 def test_linear_row_major_variant_on_device(libfdg, cuda, name):
     """fdg_isa_eval_rl: compile_Python's row-major [B, L] with contiguous rows (src/backend/compiler_python.jl:23,28,45-47) -- a tile's 64 rows
