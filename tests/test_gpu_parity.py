@@ -588,8 +588,8 @@ def test_large_real_graphs(libfdg, cuda, name, B):
 @pytest.mark.parametrize("name", ["parquet_sigma4", "parquet_sigma4_dyn", "gv_sigma4_taylor2", "gv_sigma5", "parquet_sigma5"])
 def test_row_major_variant_eval_accumulate_and_ragged_batches(libfdg, cuda, name):
     """compile_Python's row-major [B, L] (compiler_python.jl:23,28,45-47) through the ISA back end never takes a
-    transposition pass: full 64-row tiles are read in place by fdg_isa_eval_rm (evaluation) / fdg_isa_eval_rm_acc (fused
-    accumulation), the last B % 64 rows by the plain kernel with the caller's strides.  Values are the oracle's bits for
+    transposition pass: full 64-row tiles are read in place by fdg_isa_eval_rm / fdg_isa_eval_rl (evaluation) and
+    fdg_isa_eval_rm_acc / fdg_isa_eval_rl_acc (fused accumulation), the last B % 64 rows by the plain kernel with the caller's strides.  Values are the oracle's bits for
     batches of a whole number of tiles, with a ragged tail, of less than one tile, with padded rows and with
     column-major roots; the handle reports the kernel it launched."""
     import torch
@@ -617,8 +617,10 @@ def test_row_major_variant_eval_accumulate_and_ragged_batches(libfdg, cuda, name
         torch.cuda.synchronize()
         wn = w.cpu().numpy()[:, None]
         assert np.all(np.abs(acc.cpu().numpy() - (want * wn).sum(0)) <= TOL * np.maximum(1.0, np.abs(want * wn).sum(0))), (name, B, pitch)
-        if R <= 16 and B >= 64:
-            assert f.kernel_info()["last_kernel"] == "fdg_isa_eval_rm_acc", f.kernel_info()["last_kernel"]
+        if R <= 16 and B >= 64:       # (contiguous rows of a graph with the linear variant accumulate through it: fdg_isa_eval_rl_acc)
+            lin_acc = linear and "rl_acc" in f.kernel_info()["last_kernel"]
+            assert f.kernel_info()["last_kernel"] == ("fdg_isa_eval_rl_acc" if lin_acc else "fdg_isa_eval_rm_acc"), f.kernel_info()["last_kernel"]
+            assert lin_acc == linear
         acc1 = f.accumulate(leaf, None)                                                # weight NULL = 1
         torch.cuda.synchronize()
         assert np.all(np.abs(acc1.cpu().numpy() - want.sum(0)) <= TOL * np.maximum(1.0, np.abs(want).sum(0))), (name, B, "unit weights")
