@@ -197,21 +197,32 @@ fdg_reduce_lane_partials(const double *__restrict__ partial, uint32_t nwave, uin
   }
 }
 
-// partial[blk][k] = sum over the block's samples of w[b] * root_k[b]   (root k of sample b at root[k * ld + b]: the scratch
+// partial[seg][k] = sum over the segment's samples of w[b] * root_k[b]   (root k of sample b at root[k * ld + b]: the scratch
 // matrix is kept column-major, so every pass over a root is a coalesced stream -- with row-major scratch the 180 roots of
-// example/benchmark.jl's vertex function cost 180 strided passes and the reduction took as long as the evaluation)
+// example/benchmark.jl's vertex function cost 180 strided passes and the reduction took as long as the evaluation).
+// One block per (root, segment of the batch): a thread adds a dozen samples or more before the block sum (round 4; one block per 256
+// samples and a block sum per root before: the 180 block sums per block made this pass a third of the accumulation's time).
 __global__ void __launch_bounds__(256)
-fdg_weighted_partials(const double *__restrict__ root, long ld, const double *__restrict__ weight, long B, uint32_t R,
+fdg_weighted_partials(const double *__restrict__ root, long ld, const double *__restrict__ weight, long B, uint32_t R, uint32_t n_seg,
                       double *__restrict__ partial) {
   __shared__ double sh[256];
-  for (uint32_t k = 0; k < R; ++k) {
+  const long seg_len = (((B + n_seg - 1) / n_seg) + 255) & ~255L;
+  for (uint32_t id = blockIdx.x; id < R * n_seg; id += gridDim.x) {
+    const uint32_t k = id % R, seg = id / R;             // neighbouring blocks: the same samples (and weights) of different roots
     const double *rk = root + (size_t)k * (size_t)ld;
+    const long b0 = (long)seg * seg_len, b1 = b0 + seg_len < B ? b0 + seg_len : B;
     double s = 0.0;
-    for (long b = blockIdx.x * 256L + threadIdx.x; b < B; b += (long)gridDim.x * 256L)
+#pragma unroll 4
+    for (long b = b0 + threadIdx.x; b < b1; b += 256L)
       s = s + (weight ? weight[b] : 1.0) * rk[b];
     s = fdg_block_sum256(s, sh);
-    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * R + k] = s;
+    if (threadIdx.x == 0) partial[(size_t)seg * R + k] = s;
   }
+}
+// segments of the batch for fdg_weighted_partials: about 4096 blocks in all, 4096 samples per block or more, at most 2048 segments
+static inline uint32_t weighted_segments(long B, uint32_t R) {
+  const long by_size = (B + 4095) / 4096, by_blocks = std::max<long>(1, 4096 / std::max<uint32_t>(R, 1));
+  return (uint32_t)std::max<long>(1, std::min<long>(std::min<long>(by_size, by_blocks), 2048));
 }
 
 // dst[l * ld + b] = src[b * ss + l * ls]  for b < n, l < L: (usually sample-major, ls = 1) rows -> leaf-major columns,
@@ -644,8 +655,8 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // mode 1 without fused accumulation (see fused_acc): the roots go to the column-major scratch, then the weighted sum
     auto finish_scratch_acc = [&]() -> int {
       double *partial = roots + (size_t)a_rk * R;
-      const uint32_t pb = (uint32_t)std::min<long>(2048, nblk);
-      hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb), dim3(256), 0, st, roots, a_rk, d_weight, (long)B, R, partial);
+      const uint32_t pb = weighted_segments((long)B, R);
+      hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb * R), dim3(256), 0, st, roots, a_rk, d_weight, (long)B, R, pb, partial);
       hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, pb, R, d_acc);
       HIP_TRY(hipGetLastError());
       return FDG_OK;
@@ -2060,8 +2071,8 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
     double *roots = (double *)g->d_ws2, *partial = roots + (size_t)ld * R;
     rc = fdg_mc_isa_run(g, 0, d_K, ks, kc, d_T, ts, tc, kF, beta, lambda, roots, 1, ld, nullptr, nullptr, B, st);
     if (rc) return rc;
-    const uint32_t pb = (uint32_t)std::min<long>(2048, (long)((B + 255) / 256));
-    hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb), dim3(256), 0, st, roots, (long)ld, d_weight, (long)B, R, partial);
+    const uint32_t pb = weighted_segments((long)B, R);
+    hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb * R), dim3(256), 0, st, roots, (long)ld, d_weight, (long)B, R, pb, partial);
     hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, pb, R, d_acc);
     HIP_TRY(hipGetLastError());
     return FDG_OK;
