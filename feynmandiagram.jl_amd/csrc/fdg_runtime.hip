@@ -1548,7 +1548,9 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
 // take the HIP-source companion) nor for graphs of fewer than 16 leaves.
 static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chosen, fdg::OptProgram &pr, fdg::OptParams *qsel = nullptr) {
   if (g->prog.L < 16 || std::getenv("FDG_ISA_NO_RM")) return 0;
-  if (chosen.n_reg < 100) return 0;                              // tiny-graph configuration
+  // (graphs in the tiny-graph configuration too, round 4: their contiguous rows take the linear variant, but rows with padding between them
+  //  had only the transposition pass left -- 0.2 of the HBM roof on the 3-loop self-energy; FDG_ISA_RM_TINY=0 restores that)
+  if (chosen.n_reg < 100 && std::getenv("FDG_ISA_RM_TINY") && std::getenv("FDG_ISA_RM_TINY")[0] == '0') return 0;
   // One wave per SIMD whatever the leaf-major kernel runs with: 40 KB of LDS per wave hold up to four staging buffers -- the
   // stream of first uses plus the few chunks a schedule keeps coming back to -- and the AGPR level makes up for the LDS
   // slots given away.  (Graphs that stream leaves are bound by latency, not by occupancy: DESIGN.md 6.)  The fewest
