@@ -89,6 +89,52 @@ def test_random_graphs_on_device(libfdg, cuda):
                 assert same(got, want), (seed, spec, layout)
 
 
+@pytest.mark.gpu
+def test_random_graphs_every_layout_and_mode_on_device(libfdg, cuda):
+    """Every layout of the boundary (leaf-major, tile-major, row-major with contiguous and with padded rows) x evaluation and accumulation on
+    random graphs of 1 ... 200 leaves -- whole tiles and a ragged last tile -- through the ISA back end: roots the oracle's bits, weighted sums
+    within 1e-12 of the terms' scale.  (The linear row-major kernels' last load is half a wave wide when the leaf count is odd; graphs with
+    absent roots, leaves as roots, roots shared between slots are in the mix.)"""
+    import torch
+    from test_tile_major import to_tiles, from_tiles
+    for seed in list(range(0, 40, 3)) + list(range(1000, 1056, 5)):
+        t = random_table(seed) if seed < 1000 else fuzz_table(seed)[0]
+        L, R = t.n_leaf, t.n_root
+        live = t.root_slot != FDG_NO_ROOT
+        f = fd.compile_table(t, specialize="isa")
+        for B in (64 * 3, 64 * 5 + 17):
+            h_leaf = oracle.philox_uniform(B, L, seed) * 2 - 0.5
+            want = oracle.eval_static(t, h_leaf, np.full((B, R), 9.0))
+            w = np.random.default_rng(seed + B).uniform(0.5, 1.5, B)
+            terms = np.where(np.isfinite(want), want, 0.0) * w[:, None]
+            finite = np.isfinite(want).all(0) & live
+            tol = 1e-12 * np.maximum(1.0, np.abs(terms).sum(0))
+            dw = torch.from_numpy(w).to(cuda)
+            pad = torch.full((B, L + 3), float("nan"), dtype=torch.float64, device=cuda)
+            pad[:, :L] = torch.from_numpy(h_leaf).to(cuda)
+            layouts = {"row-major": torch.from_numpy(h_leaf).to(cuda), "row-major padded": pad[:, :L],
+                       "leaf-major": torch.from_numpy(np.ascontiguousarray(h_leaf.T)).to(cuda).t()}
+            for lay, leaf in layouts.items():
+                root = torch.full((B, R), 9.0, dtype=torch.float64, device=cuda)
+                f(root, leaf)
+                torch.cuda.synchronize()
+                assert same(root.cpu().numpy(), want), (seed, lay, B, f.kernel_info()["last_kernel"])
+                acc = torch.zeros(R, dtype=torch.float64, device=cuda)
+                f.accumulate(leaf, dw, acc)
+                torch.cuda.synchronize()
+                a = acc.cpu().numpy()
+                assert np.all(np.abs(a - terms.sum(0))[finite] <= tol[finite]), (seed, lay, B, f.kernel_info()["last_kernel"])
+            tl = torch.from_numpy(to_tiles(h_leaf)).to(cuda)
+            rt = torch.full(((B + 63) // 64, R, 64), 9.0, dtype=torch.float64, device=cuda)
+            f.eval_tiled(rt, tl, B)
+            torch.cuda.synchronize()
+            assert same(from_tiles(rt.cpu().numpy(), B, R), want), (seed, "tile-major", B)
+            acc = torch.zeros(R, dtype=torch.float64, device=cuda)
+            f.accumulate_tiled(tl, dw, acc, B)
+            torch.cuda.synchronize()
+            assert np.all(np.abs(acc.cpu().numpy() - terms.sum(0))[finite] <= tol[finite]), (seed, "tile-major", B)
+
+
 def fuzz_table(seed: int):
     """Larger random DAGs for the register-pressure fuzz: up to 200 leaves and 1500 nodes, operands near or far."""
     rng = np.random.default_rng(seed)
