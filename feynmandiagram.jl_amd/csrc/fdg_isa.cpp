@@ -543,6 +543,10 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("v_add_u32_e32 v" + std::to_string(rm0) + ", " + hex32(cs->priv_base_bytes) + ", " + V(V_LANE8));
     E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 1) + ", 0x10000, " + V(V_LANE8));
     E.ins("v_lshlrev_b32_e32 v" + std::to_string(rm0 + 2) + ", 4, v0");          // lane * 16: source offset of a pool fetch (lanes 0..31 carry a leaf's 64 samples)
+    if (cs->pooled) {      // (pooled programs load no leaf into a register: the delta table's registers are free)
+      E.ins("s_mov_b32 " + S(S_DELTA + 4) + ", 0");                               // lanes 32..63: the second leaf of a paired fetch (v[rm0 + 3]: its lanes' offsets)
+      E.ins("s_mov_b32 " + S(S_DELTA + 5) + ", 0xffffffff");
+    }
   }
   if (rl) {
     E.ins("v_mul_u32_u24_e32 v" + std::to_string(rm0) + ", " + hex32(8u * p.L) + ", v0");      // lane * 8 L: this lane's row inside the image
@@ -953,8 +957,16 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
           }
           E.ins("s_addc_u32 " + S(S_FA + 1) + ", " + S(S_LT + 1) + ", 0");
         }
+        uint32_t off_reg = rm0 + 2;
+        if (pair && o.negc) {     // the upper half of the wave brings leaf c > a (any leaf): its lanes' offsets are (c - a) leaf strides further
+          E.ins("s_mul_i32 " + S(S_X) + ", " + S(S_LS8) + ", " + hex32(o.c - o.a));
+          E.ins("s_sub_u32 " + S(S_X) + ", " + S(S_X) + ", 0x200");
+          E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 3) + ", " + S(S_X) + ", v" + std::to_string(rm0 + 2));
+          E.ins("v_cndmask_b32_e64 v" + std::to_string(rm0 + 3) + ", v" + std::to_string(rm0 + 2) + ", v" + std::to_string(rm0 + 3) + ", " + S2(S_DELTA + 4));
+          off_reg = rm0 + 3;
+        }
         E.ins("s_mov_b32 m0, " + hex32(o.d * SLOT));
-        E.ins("global_load_lds_dwordx4 v" + std::to_string(rm0 + 2) + ", " + S2(S_FA));
+        E.ins("global_load_lds_dwordx4 v" + std::to_string(off_reg) + ", " + S2(S_FA));
         pool_pending.push_back({++E.vm_issued, (uint32_t)o.imm});
         const bool more = this_op + 1 < prog.ops.size() && prog.ops[this_op + 1].kind == M_POOL_FETCH;
         if (!more && pool_exec_low) { E.ins("s_mov_b64 exec, -1"); pool_exec_low = false; }
@@ -1237,7 +1249,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_endpgm");
 
   // ---- kernel descriptor -------------------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? 3 : 0) + (rl ? 2 : 0), 8);
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? 4 : 0) + (rl ? 2 : 0), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
   const uint32_t n_agpr = RW * prog.n_acc_used;
   if (cs) return KernelMeta{kname, lds_bytes, accum, n_agpr, 12, (mc || has_macro) ? S_END : S_POOL + 2 * 16};

@@ -1679,7 +1679,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     v.erase(std::unique(v.begin(), v.end()), v.end());
     for (uint32_t e : v) { if (e == 0 || e > n_epoch) { out.why = "internal: a leaf is read outside the compute epochs"; return; } need[e].push_back(l); }
   }
-  struct Fetch { uint32_t unit, slot, issue, ready; };
+  struct Fetch { uint32_t unit, slot, issue, ready, unit2; };       // unit2 != NONE: a second, arbitrary leaf by the same instruction into slot + 1
   std::vector<Fetch> fetches;
   std::vector<uint32_t> slot_of(LU, NONE);                  // resident unit -> unit slot
   std::vector<uint32_t> in_slot(P, NONE), last_read(P, 0);  // slot -> unit; last epoch in which the slot's content is read (as planned so far)
@@ -1689,44 +1689,94 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     auto it = std::lower_bound(v.begin(), v.end(), from);
     return it == v.end() ? std::numeric_limits<uint32_t>::max() : *it;
   };
+  // One LDS-direct instruction has 64 lanes of 16 bytes: with single leaves half of them idle.  PAIRED fetches (round 4, second half): the
+  // upper 32 lanes bring ANOTHER leaf -- any leaf: their addresses are their own -- into the slot after the first one's, so two leaves that
+  // miss in the same epoch share one instruction when an aligned pair of slots (2k, 2k + 1) can be given to them at the same issue epoch
+  // (an instruction costs the issuing wave about a hundred cycles whatever it brings).  MEASURED SLOWER, so off unless FDG_POOL_PAIR=1: on the
+  // 4-loop GV vertex function 1 245 instead of 2 195 fetch instructions (+9 % leaves) run 4.16 ms against 3.70; with pairs only into slots whose
+  // content is dead or 64 epochs from its next read 1 694 instructions, no extra leaf, 3.96 ms (profiles/r04_log_pool_anypair.txt).
+  const bool pairing = U == 1 && std::getenv("FDG_POOL_PAIR") && std::getenv("FDG_POOL_PAIR")[0] == '1';
+  static const uint32_t far = std::getenv("FDG_POOL_FAR") ? (uint32_t)std::atoi(std::getenv("FDG_POOL_FAR")) : 64;
+  const uint32_t INF = std::numeric_limits<uint32_t>::max();
+  const uint32_t pair_far = std::getenv("FDG_POOL_PAIR_FAR") ? (uint32_t)std::atoi(std::getenv("FDG_POOL_PAIR_FAR")) : 32;
+  // may slot s2 be given away at `issue` to content first read in epoch e?  key: how late its present content is needed again (0: no)
+  auto victim_key = [&](uint32_t s2, uint32_t issue, uint32_t e) -> uint64_t {
+    if (in_slot[s2] == NONE) return (uint64_t)INF + 2;
+    if (last_read[s2] >= issue) return 0;                              // (still being read when the fetch would be issued)
+    const uint32_t nr = next_read(in_slot[s2], issue);
+    if (nr <= e) return 0;                                             // needed again before (or when) the new content is: keep it
+    // an EARLY fetch only takes a slot whose content is dead or far from its next read: being early must not cost a re-fetch
+    if (issue + 2 < e && nr != INF && nr <= e + far) return 0;
+    return (uint64_t)nr + 1;
+  };
+  auto install = [&](uint32_t l, uint32_t slot, uint32_t e) {
+    if (in_slot[slot] != NONE) slot_of[in_slot[slot]] = NONE;
+    in_slot[slot] = l; slot_of[l] = slot; last_read[slot] = e;
+    resid[l].push_back({e, slot});
+  };
+  uint64_t n_paired = 0;
   for (uint32_t e = 1; e <= n_epoch; ++e) {                 // epoch whose reads must be resident
     const uint32_t first_issue = e > ahead ? e - ahead : 0;
-    static const uint32_t far = std::getenv("FDG_POOL_FAR") ? (uint32_t)std::atoi(std::getenv("FDG_POOL_FAR")) : 64;
+    std::vector<uint32_t> missing;
     for (uint32_t l : need[e]) {
-      if (slot_of[l] != NONE) { last_read[slot_of[l]] = std::max(last_read[slot_of[l]], e); continue; }
+      if (slot_of[l] != NONE) last_read[slot_of[l]] = std::max(last_read[slot_of[l]], e);
+      else missing.push_back(l);
+    }
+    for (size_t i = 0; i < missing.size();) {
       // The fetch is issued `ahead` epochs before the read when a slot is free by then, else as early after that as one becomes free
       // (memory latency is a few epochs; the pool is small: the prefetch distance adapts to how much of it the epochs around need).
       // Victim at a given issue epoch: an empty slot, else the slot nobody reads from that epoch on whose content is needed again farthest
       // in the future (and not before the new content is).
+      if (pairing && i + 1 < missing.size()) {
+        uint32_t best = NONE, issue = first_issue;
+        for (; issue < e && best == NONE; ++issue) {
+          uint64_t best_key = 0;
+          for (uint32_t k = 0; k + 1 < P; k += 2) {
+            const uint64_t k0 = victim_key(k, issue, e), k1 = k0 ? victim_key(k + 1, issue, e) : 0;
+            uint64_t key = std::min(k0, k1);
+            // the pair of slots is a worse victim than the two best single slots would be: only contents that are dead, or not read again
+            // for `pair_far` epochs, make way for a paired fetch (else the instructions saved come back as re-fetches)
+            if (key && key <= (uint64_t)INF && key <= (uint64_t)e + pair_far) key = 0;
+            if (key > best_key) { best_key = key; best = k; }
+          }
+          if (best != NONE) break;
+        }
+        if (best != NONE) {
+          // (a pair is not taken when a single slot would have been free earlier by more than an epoch: latency first)
+          // (the smaller leaf index first: the upper lanes' offsets from the first leaf's address are unsigned)
+          const uint32_t la = std::min(missing[i], missing[i + 1]), lb = std::max(missing[i], missing[i + 1]);
+          install(la, best, e);
+          install(lb, best + 1, e);
+          fetches.push_back(Fetch{la, best, issue, e, lb});
+          n_paired++;
+          i += 2;
+          continue;
+        }
+      }
+      const uint32_t l = missing[i];
       uint32_t best = NONE, issue = first_issue;
       for (; issue < e && best == NONE; ++issue) {
         uint64_t best_key = 0;
         for (uint32_t s2 = 0; s2 < P; ++s2) {
-          if (in_slot[s2] == NONE) { best = s2; break; }
-          if (last_read[s2] >= issue) continue;                          // (still being read when the fetch would be issued)
-          const uint32_t nr = next_read(in_slot[s2], issue);
-          if (nr <= e) continue;                                         // needed again before (or when) the new content is: keep it
-          // an EARLY fetch only takes a slot whose content is dead or far from its next read: being early must not cost a re-fetch
-          if (issue + 2 < e && nr != std::numeric_limits<uint32_t>::max() && nr <= e + far) continue;
-          const uint64_t key = (uint64_t)nr + 1;
-          if (key > best_key) { best_key = key; best = s2; }
+          const uint64_t key = victim_key(s2, issue, e);
+          if (key > best_key) { best_key = key; best = s2; if (in_slot[s2] == NONE) break; }
         }
         if (best != NONE) break;
       }
       if (best == NONE) { out.why = "leaf pool exhausted"; return; }
-      if (in_slot[best] != NONE) slot_of[in_slot[best]] = NONE;
-      in_slot[best] = l; slot_of[l] = best; last_read[best] = e;
-      fetches.push_back(Fetch{l, best, issue, e});
-      resid[l].push_back({e, best});
+      install(l, best, e);
+      fetches.push_back(Fetch{l, best, issue, e, NONE});
+      ++i;
     }
   }
   out.n_fetch = fetches.size();
   out.n_transfer = 0;                                       // leaves brought from memory per tile
-  for (const Fetch &f : fetches) out.n_transfer += std::min<uint32_t>(U, L - f.unit * U);
+  for (const Fetch &f : fetches) out.n_transfer += f.unit2 != NONE ? 2 : std::min<uint32_t>(U, L - f.unit * U);
   if (std::getenv("FDG_POOL_DEBUG")) {
     std::vector<uint32_t> hist(ahead + 2, 0);
     uint64_t sum = 0;
     for (const Fetch &f : fetches) { hist[std::min<uint32_t>(f.ready - f.issue, ahead + 1)]++; sum += f.ready - f.issue; }
+    std::fprintf(stderr, "[pool] %llu of the fetches bring two leaves; ", (unsigned long long)n_paired);
     std::fprintf(stderr, "[pool] %zu fetches of %u leaves (%llu leaves in all), issued %.2f epochs of %u ops ahead on average;", fetches.size(), U, (unsigned long long)out.n_transfer,
                  fetches.empty() ? 0.0 : (double)sum / (double)fetches.size(), epoch_ops);
     for (uint32_t k = 1; k < hist.size(); ++k) std::fprintf(stderr, " %u:%u", k, hist[k]);
@@ -1748,7 +1798,11 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     r.reserve(out.wave[w].ops.size() + fetches.size() / NW + 8);
     uint32_t e = 0;
     auto put_fetches = [&](uint32_t ep) {      // shared[d .. d + b - 1] = leaf[a .. a + b - 1]
-      for (const Fetch &f : at[w][ep]) { MOp m{M_POOL_FETCH, 0, 0, f.slot * U, f.unit * U, std::min<uint32_t>(U, L - f.unit * U), (double)f.ready}; r.push_back(m); }
+      for (const Fetch &f : at[w][ep]) {
+        MOp m{M_POOL_FETCH, 0, 0, f.slot * U, f.unit * U, std::min<uint32_t>(U, L - f.unit * U), (double)f.ready};
+        if (f.unit2 != NONE) { m.b = 2; m.c = f.unit2; m.negc = 1; }         // negc: the second leaf is c (any leaf), not a + 1
+        r.push_back(m);
+      }
     };
     put_fetches(0);       // epoch 0 is what precedes the program's opening barrier
     for (const MOp &o : out.wave[w].ops) {

@@ -354,8 +354,10 @@ def replay_coop(progs, info, leaf, R):
                 elif k == 26: assert a not in fetch, ("pool slot read while its fetch is in flight", a, _epoch); read_slots.add((a, w)); reg[d] = shared[a]
                 elif k == 29:       # pool fetch: shared[d .. d+b-1] = leaf[a .. a+b-1] (b = 1, or 2: a pair of adjacent leaves by one 64-lane load),
                     for j in range(max(b, 1)):      # readable from epoch imm on; the slots' old content must not be read any more
+                        src = int(o["c"]) if (j == 1 and o["negc"]) else a + j        # (negc: the second leaf of the pair is leaf c > a, any leaf)
+                        assert not (j == 1 and o["negc"]) or (src > a and d % 2 == 0), ("paired fetch: second leaf must follow the first, slots aligned", a, src, d)
                         assert d + j not in fetch and int(o["imm"]) > _epoch, ("pool slot fetched twice / ready too early", d + j, _epoch)
-                        fetch[d + j] = (int(o["imm"]), leaf[:, a + j].copy()); shared[d + j] = np.nan; pool_written.add(d + j)
+                        fetch[d + j] = (int(o["imm"]), leaf[:, src].copy()); shared[d + j] = np.nan; pool_written.add(d + j)
                 elif k == 0: reg[d] = leaf[:, a]
                 elif k == 1: reg[d] = lds[a]
                 elif k == 2: reg[d] = mem[a]
@@ -415,6 +417,20 @@ def test_pooled_programs_replay_exactly(libfdg, monkeypatch, name, waves):
     if waves == 4 and name == "gv_ver4_4":      # the graph of example/benchmark_GV.jl: memory-side accesses 3.0 x -> below 1.5 x the algorithmic L + R
         panel = sum(int(np.isin(p["kind"], (2, 4)).sum()) for p in progs)
         assert n_fetch + panel + t.n_root <= 1.5 * (t.n_leaf + t.n_root)
+
+
+def test_pooled_programs_with_paired_fetches_replay_exactly(libfdg, monkeypatch):
+    """FDG_POOL_PAIR=1 (an experiment kept behind a switch: measured slower): one 64-lane fetch brings two arbitrary leaves into an aligned pair of
+    slots.  The replay is exact; the second leaf follows the first in index (the upper lanes' offsets are unsigned)."""
+    monkeypatch.setenv("FDG_POOL_PAIR", "1")
+    monkeypatch.setenv("FDG_POOL_PAIR_FAR", "0")
+    t = workloads.get("parquet_ver4_3")
+    h = capi.GraphHandle(t)
+    progs, info = h.pool_program()
+    pairs = sum(int(((p["kind"] == 29) & (p["b"] == 2) & (p["negc"] == 1)).sum()) for p in progs)
+    assert pairs > 10
+    leaf = oracle.philox_uniform(3, t.n_leaf, 83)
+    assert np.array_equal(replay_coop(progs, info, leaf, t.n_root), oracle.eval_static(t, leaf))
 
 
 def test_pooled_variant_needs_roots_to_deal(libfdg):
