@@ -225,6 +225,62 @@ static inline uint32_t weighted_segments(long B, uint32_t R) {
   return (uint32_t)std::max<long>(1, std::min<long>(std::min<long>(by_size, by_blocks), 2048));
 }
 
+// The same for rows that can be read 16 bytes per lane (leaf stride 1, even sample stride, 16-byte aligned base): 64 x 64 tiles, every row
+// segment one 512-byte run (round 4: the 256-byte runs of the kernel below moved 2.3 TB/s read + written in front of the 4-loop vertex
+// functions' kernels, which cannot overlap with it -- one wave per SIMD with 496 registers and all of the LDS).
+typedef double fdg_pair_d __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256)
+fdg_transpose_rows_wide(const double *__restrict__ src, long ss, double *__restrict__ dst, long ld, long n, uint32_t L) {
+  __shared__ double tile[64][65];          // [column][row]
+  const int t = threadIdx.x;
+  const long ntile_s = (n + 63) / 64, ntile_l = (L + 63) / 64;
+  for (long tid = blockIdx.x; tid < ntile_s * ntile_l; tid += gridDim.x) {
+    const long s0 = (tid / ntile_l) * 64, l0 = (tid % ntile_l) * 64;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const long row = s0 + k * 8 + t / 32, col = l0 + 2 * (t % 32);
+      if (row < n && col + 1 < (long)L) {
+        const fdg_pair_d v = __builtin_nontemporal_load((const fdg_pair_d *)(src + row * ss + col));
+        tile[2 * (t % 32)][k * 8 + t / 32] = v.x;
+        tile[2 * (t % 32) + 1][k * 8 + t / 32] = v.y;
+      } else if (row < n && col < (long)L) {
+        tile[2 * (t % 32)][k * 8 + t / 32] = __builtin_nontemporal_load(src + row * ss + col);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const long col = l0 + k * 4 + t / 64, row = s0 + t % 64;
+      if (row < n && col < (long)L) dst[col * ld + row] = tile[k * 4 + t / 64][t % 64];
+    }
+    __syncthreads();
+  }
+}
+
+// dst[b * rs + k * rk] = src[k * ld + b]  for b < n, k < R: column-major root scratch -> the caller's (usually row-major) root matrix,
+// 64 x 32 tiles through LDS: 512-byte runs read along a root, 256-byte runs written along a row.
+__global__ void __launch_bounds__(256)
+fdg_transpose_from_leaf_major(const double *__restrict__ src, long ld, double *__restrict__ dst, long rs, long rk, long n, uint32_t R) {
+  __shared__ double tile[32][65];
+  const int t = threadIdx.x;
+  const long ntile_s = (n + 63) / 64, ntile_k = (R + 31) / 32;
+  for (long tid = blockIdx.x; tid < ntile_s * ntile_k; tid += gridDim.x) {
+    const long s0 = (tid / ntile_k) * 64, k0 = (tid % ntile_k) * 32;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long k = k0 + j * 4 + t / 64, row = s0 + t % 64;
+      if (row < n && k < (long)R) tile[j * 4 + t / 64][t % 64] = src[k * ld + row];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long row = s0 + j * 8 + t / 32, k = k0 + t % 32;
+      if (row < n && k < (long)R) dst[row * rs + k * rk] = tile[t % 32][j * 8 + t / 32];
+    }
+    __syncthreads();
+  }
+}
+
 // dst[l * ld + b] = src[b * ss + l * ls]  for b < n, l < L: (usually sample-major, ls = 1) rows -> leaf-major columns,
 // 64 x 32 tiles through LDS so that both the reads (256 B runs along a row) and the writes
 // (512 B runs along a column) are coalesced.
@@ -512,6 +568,35 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
   const bool rl_rows = g->has_rl && ls == 1 && ss == (int64_t)p.L && p.L >= 2 && B >= 64 && ((uintptr_t)d_leaf & 15) == 0 && !std::getenv("FDG_ISA_NO_RL");
   const bool rl_shape = rl_rows && ((mode == 0 && !(rs < 0 || rs >= (1ll << 23))) ||                       // contiguous rows: the linear variant below
                                     (mode == 1 && g->has_rl_acc && g->has_acc && !std::getenv("FDG_ISA_NO_FUSED_ACC")));
+  // Roots into a ROW-MAJOR matrix (compile_Python's [B, R]) of a graph with many roots: a root store of the kernels is 64 lanes x 8 bytes, each in
+  // another row -- with R = 180 (example/benchmark.jl's vertex function) the stores doubled the kernel's time.  Such calls evaluate chunk by chunk
+  // into the column-major root scratch (every store one 512-byte run) and a transposition writes the caller's rows (round 4).
+  static const uint32_t scratch_min_roots = std::getenv("FDG_ROOT_SCRATCH_MIN") ? (uint32_t)std::atoi(std::getenv("FDG_ROOT_SCRATCH_MIN")) : 16;
+  if (mode == 0 && !g->code_object.empty() && g->isa && scratch_min_roots && R >= scratch_min_roots && rk == 1 && rs >= (int64_t)R && (rts == 0 || rts == 64 * rs) && B >= 256 &&
+      !(ls == 1 && ss != 1 && (g->alt_code.size() || g->has_rm || rl_rows))) {     // (the row-major variants write a tile's rows together: left alone)
+    const unsigned long long scratch_mb = std::getenv("FDG_ROOT_SCRATCH_MB") ? (unsigned long long)std::max(1, std::atoi(std::getenv("FDG_ROOT_SCRATCH_MB"))) : 256ull;
+    long Bc = std::max<long>(64, (long)((scratch_mb << 20) / (8ull * R)) & ~63l);
+    Bc = std::min<long>(Bc, (long)((B + 63) & ~(int64_t)63));
+    const size_t need = (size_t)Bc * R * sizeof(double) + (size_t)2048 * R * sizeof(double);
+    if (g->ws2_bytes < need) {
+      if (g->d_ws2) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws2)); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
+      if (hipMalloc(&g->d_ws2, need) != hipSuccess) { set_error("hipMalloc(root scratch) failed"); return FDG_E_NOMEM; }
+      g->ws2_bytes = need;
+    }
+    double *scratch = (double *)g->d_ws2;
+    for (long c0 = 0; c0 < (long)B; c0 += Bc) {
+      const long n = std::min<long>(Bc, (long)B - c0);
+      const double *lf = lts ? d_leaf + (size_t)(c0 / 64) * (size_t)lts : d_leaf + (size_t)c0 * (size_t)ss;
+      rc = fdg_run_locked(g, 0, lf, ss, ls, scratch, 1, Bc, nullptr, nullptr, n, st, lts, 0);
+      if (rc) return rc;
+      const long ntile = ((n + 63) / 64) * ((R + 31) / 32);
+      hipLaunchKernelGGL(fdg_transpose_from_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, st,
+                         scratch, Bc, d_root + (size_t)c0 * (size_t)rs, (long)rs, (long)rk, n, R);
+      HIP_TRY(hipGetLastError());
+    }
+    return FDG_OK;
+  }
+
   if (!g->code_object.empty() && g->isa && !g->alt_code.empty() && ls == 1 && ss != 1 && p.L > 1 && !tiled && !rl_shape) {
     // sample-major input and a companion: its lanes read their own rows; no transposition pass
     if (!g->alt_module) {
@@ -785,9 +870,15 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       HIP_TRY(hipStreamWaitEvent(s2, (hipEvent_t)g->ev_in, 0));
       auto transpose = [&](long c0, int buf) {
         const long n = std::min<long>(Bc, B - c0);
-        const long ntile = ((n + 63) / 64) * ((p.L + 31) / 32);
-        hipLaunchKernelGGL(fdg_transpose_to_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, s2,
-                           d_leaf + c0 * ss, (long)ss, (long)ls, (double *)((char *)g->d_ws3 + (size_t)buf * one), Bc, n, p.L);
+        if (ls == 1 && (ss & 1) == 0 && ((uintptr_t)d_leaf & 15) == 0 && p.L >= 32 && !std::getenv("FDG_TRANSPOSE_NARROW")) {
+          const long ntile = ((n + 63) / 64) * ((p.L + 63) / 64);
+          hipLaunchKernelGGL(fdg_transpose_rows_wide, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 8)), dim3(256), 0, s2,
+                             d_leaf + c0 * ss, (long)ss, (double *)((char *)g->d_ws3 + (size_t)buf * one), Bc, n, p.L);
+        } else {
+          const long ntile = ((n + 63) / 64) * ((p.L + 31) / 32);
+          hipLaunchKernelGGL(fdg_transpose_to_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, s2,
+                             d_leaf + c0 * ss, (long)ss, (long)ls, (double *)((char *)g->d_ws3 + (size_t)buf * one), Bc, n, p.L);
+        }
         return hipEventRecord((hipEvent_t)g->ev_t[buf], s2);
       };
       HIP_TRY(transpose(0, 0));
@@ -1616,7 +1707,10 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
     const bool cheap = best_fetches * 4 <= (uint64_t)n_chunk * 5 + 4;
     if (pass == 0) { if (best_cost != ~0ull && cheap && best_panel == 0) return 4; break; }
     if (!cheap && bufs < 4 && !e) continue;
-    if ((best_fetches * 8192 + best_gathers * 2048) * 2 > (uint64_t)g->prog.L * 512 * 5) return 0;
+    {   // (FDG_ISA_RM_MAX_TRAFFIC=<tenths>: the bound on what the variant may move, in tenths of the matrix; default 25)
+      const uint64_t tenths = std::getenv("FDG_ISA_RM_MAX_TRAFFIC") ? (uint64_t)std::max(10, std::atoi(std::getenv("FDG_ISA_RM_MAX_TRAFFIC"))) : 25;
+      if ((best_fetches * 8192 + best_gathers * 2048) * 10 > (uint64_t)g->prog.L * 512 * tenths) return 0;
+    }
     return bufs;
   }
   return 0;

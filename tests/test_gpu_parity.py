@@ -626,6 +626,41 @@ def test_row_major_variant_eval_accumulate_and_ragged_batches(libfdg, cuda, name
         assert np.all(np.abs(acc1.cpu().numpy() - want.sum(0)) <= TOL * np.maximum(1.0, np.abs(want).sum(0))), (name, B, "unit weights")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["leaf_major", "tile_major", "sample_major"])
+def test_many_roots_into_a_row_major_matrix_go_through_the_root_scratch(libfdg, cuda, monkeypatch, layout):
+    """Roots of a graph with 16 roots or more into a row-major [B, R] matrix (compile_Python's root layout, a torch caller's natural tensor): the
+    kernels' root stores would be 64 lanes in 64 different rows, so the call evaluates chunk by chunk into the column-major root scratch and a
+    transposition writes the caller's rows (+24 % on example/benchmark.jl's 180-root vertex function, +48 % on the 3-loop one).  Same bits as
+    column-major roots; several chunks, a ragged last tile, a row pitch wider than R; rows beyond the batch and columns beyond R untouched."""
+    import torch
+    from feynmandiagram_jl_amd.nodetable import synthetic_parquet_like
+    monkeypatch.setenv("FDG_ROOT_SCRATCH_MB", "1")            # 1 MB of scratch: chunks of 2 688 samples
+    t = synthetic_parquet_like(n_node=600, n_leaf=40, n_root=48, seed=5)
+    L, R, B = t.n_leaf, t.n_root, 70_001
+    f = fd.compile_table(t, specialize="isa")
+    h_leaf = oracle.philox_uniform(B, L, 77)
+    want = oracle.eval_static(t, h_leaf)
+    if layout == "tile_major":
+        from test_tile_major import to_tiles
+        leaf = torch.from_numpy(to_tiles(h_leaf)).to(cuda)
+    elif layout == "leaf_major":
+        leaf = torch.from_numpy(np.ascontiguousarray(h_leaf.T)).to(cuda).t()
+    else:
+        leaf = torch.from_numpy(h_leaf).to(cuda)
+    wide = torch.full((B + 5, R + 3), 9.0, dtype=torch.float64, device=cuda)
+    root = wide[:B, :R]
+    st = torch.cuda.current_stream().cuda_stream
+    if layout == "tile_major":
+        f.handle.eval_device_tiled(leaf.data_ptr(), 1, 64, 64 * L, root.data_ptr(), root.stride(0), root.stride(1), 0, B, st)
+    else:
+        f(root, leaf)
+    torch.cuda.synchronize()
+    assert np.array_equal(root.cpu().numpy(), want), layout
+    w = wide.cpu().numpy()
+    assert (w[B:] == 9.0).all() and (w[:, R:] == 9.0).all()
+
+
 @pytest.mark.parametrize("n_root", [24, 48])
 def test_many_roots_accumulate_and_eval(libfdg, cuda, n_root):
     """Up to 40 roots the optimizing back end keeps the weighted sums in registers (fdg_isa_eval_acc); with more, it writes
