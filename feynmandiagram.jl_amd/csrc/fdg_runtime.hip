@@ -639,9 +639,10 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // (one per SIMD) keep 4 x L x 512 bytes in flight per CU -- enough for the latency-bandwidth product -- and the memory system sees a
     // quarter of the concurrent streams (round 4, profiles/r04_log_waves.txt: headline +3-5 %, the 2-loop graph +6-15 %); the graphs at or
     // above the ridge want every wave they can get.  FDG_ISA_MEM_WAVES / FDG_ISA_MEM_OVERSUB / FDG_ISA_MEM_RATIO override (0 waves = off).
-    auto shape = [&](uint64_t valu, uint64_t bytes, uint32_t vgpr, uint32_t lds, size_t bytes_per_wg) -> long {
+    auto shape = [&](uint64_t valu, uint64_t bytes, uint32_t vgpr, uint32_t lds, size_t bytes_per_wg, bool accumulating = false) -> long {
       const long full = (long)waves_per_cu(vgpr, lds);
-      const long mem_waves = std::getenv("FDG_ISA_MEM_WAVES") ? std::atol(std::getenv("FDG_ISA_MEM_WAVES")) : (p.L >= 24 ? 4 : 5);   // (a wave of a tiny graph keeps little in flight)
+      const long mem_waves = std::getenv("FDG_ISA_MEM_WAVES") ? std::atol(std::getenv("FDG_ISA_MEM_WAVES")) : (p.L >= 24 ? 4 : (accumulating ? 8 : 5));   // (a wave of a tiny graph keeps little in flight; without root stores
+                                                                                                                           //  more of them help: the 2-loop graph accumulates at 0.84 instead of 0.73, profiles/r04_log_tiny_acc_waves.txt)
       const long mem_over = std::getenv("FDG_ISA_MEM_OVERSUB") ? std::max(1l, std::atol(std::getenv("FDG_ISA_MEM_OVERSUB"))) : 1;
       const double mem_ratio = std::getenv("FDG_ISA_MEM_RATIO") ? std::atof(std::getenv("FDG_ISA_MEM_RATIO")) : 2.5;
       if (mem_waves > 0 && !std::getenv("FDG_ISA_WAVES_PER_CU") && !std::getenv("FDG_ISA_OVERSUB") && bytes && (double)valu < mem_ratio * (double)bytes && full > mem_waves) {
@@ -661,7 +662,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // (a graph that has the pooled variant accumulates through it and the root scratch: its fused-accumulation program, with R + 2 fewer value
     //  registers and no pool, runs the 4-loop GV vertex function at 0.87e8 samples/s where the pooled evaluation + the weighted sum do 1.3e8)
     const bool fused_acc = mode == 1 && g->has_acc && !std::getenv("FDG_ISA_NO_FUSED_ACC") && !(pool_ok && !std::getenv("FDG_ISA_POOL_NO_ACC"));
-    const long grid3 = g->has_acc ? shape(g->st_valu[1], 8ull * p.L, g->isa3_vgpr, g->isa3_lds_bytes, ((size_t)g->isa3_mem_slots + R) * 512u) : 0;
+    const long grid3 = g->has_acc ? shape(g->st_valu[1], 8ull * p.L, g->isa3_vgpr, g->isa3_lds_bytes, ((size_t)g->isa3_mem_slots + R) * 512u, true) : 0;
     const size_t panel3 = (size_t)std::max<uint32_t>(g->isa3_mem_slots, 1) * 512u * (size_t)grid3;
     const long grid4 = g->has_rm ? (long)g->n_cu * waves_per_cu(g->isa4_vgpr, g->isa4_lds_bytes) : 0;
     const size_t panel4 = (size_t)std::max<uint32_t>(g->isa4_mem_slots, 1) * 512u * (size_t)grid4;
