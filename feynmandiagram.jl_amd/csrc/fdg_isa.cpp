@@ -511,18 +511,37 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   // accumulate mode: R per-lane accumulators, the lane's weight and one temporary live above the value registers
   uint64_t w_seq = 0;
   const uint32_t acc0 = V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1);
-  auto vacc = [&](uint32_t k) { const uint32_t b = acc0 + 2 * k; return "v[" + std::to_string(b) + ":" + std::to_string(b + 1) + "]"; };
-  const std::string vwgt = vacc(p.R), vtmp = vacc(p.R + 1);
+  // (graphs with 41 ... 124 roots: accumulators in AGPR pairs a[A0 + 2k : +1] behind the program's own; the weight and two temporaries in VGPRs)
+  const bool aa = accumulate && prog.params.acc_in_agpr;
+  const uint32_t A0 = RW * prog.n_acc_used;
+  const uint32_t acc_pairs_v = accumulate ? (aa ? 3 : p.R + 2) : 0;          // VGPR pairs above the values
+  const uint32_t wgt0 = aa ? acc0 : acc0 + 2 * p.R;                           // the lane's weight, then the temporary(ies)
+  auto vpair = [&](uint32_t b) { return "v[" + std::to_string(b) + ":" + std::to_string(b + 1) + "]"; };
+  auto vacc = [&](uint32_t k) { return vpair(acc0 + 2 * k); };                 // (VGPR accumulators only)
+  const std::string vwgt = vpair(wgt0), vtmp = vpair(wgt0 + 2), vtmp2 = vpair(wgt0 + 4);
+  auto acc_to_tmp2 = [&](uint32_t k) {       // vtmp2 = accumulator k
+    E.ins("v_accvgpr_read_b32 v" + std::to_string(wgt0 + 4) + ", a" + std::to_string(A0 + 2 * k));
+    E.ins("v_accvgpr_read_b32 v" + std::to_string(wgt0 + 5) + ", a" + std::to_string(A0 + 2 * k + 1));
+  };
+  auto tmp2_to_acc = [&](uint32_t k) {
+    E.ins("v_accvgpr_write_b32 a" + std::to_string(A0 + 2 * k) + ", v" + std::to_string(wgt0 + 4));
+    E.ins("v_accvgpr_write_b32 a" + std::to_string(A0 + 2 * k + 1) + ", v" + std::to_string(wgt0 + 5));
+  };
   // programs with leaf formulas: two more temporaries (register pairs) above those
   bool has_macro = false;
   uint32_t n_tmp_pairs = 0;
   for (const MOp &o : prog.ops) { if (mop_is_macro(o.kind)) has_macro = true; n_tmp_pairs = std::max(n_tmp_pairs, mop_tmp_pairs(o.kind)); }
-  const uint32_t tmp0 = acc0 + (accumulate ? 2 * (p.R + 2) : 0);
+  const uint32_t tmp0 = acc0 + 2 * acc_pairs_v;
   auto tpair = [&](uint32_t k) { return "v[" + std::to_string(tmp0 + 2 * k) + ":" + std::to_string(tmp0 + 2 * k + 1) + "]"; };
   const std::string tA = tpair(0), tB = tpair(1), tC = tpair(2), tD = tpair(3);
   auto tAd = [&](int h) { return "v" + std::to_string(tmp0 + h); };
   if (accumulate)
     for (uint32_t k = 0; k < p.R; ++k) {
+      if (aa) {
+        E.ins("v_accvgpr_write_b32 a" + std::to_string(A0 + 2 * k) + ", 0");
+        E.ins("v_accvgpr_write_b32 a" + std::to_string(A0 + 2 * k + 1) + ", 0");
+        continue;
+      }
       E.ins("v_mov_b32_e32 v" + std::to_string(acc0 + 2 * k) + ", 0");
       E.ins("v_mov_b32_e32 v" + std::to_string(acc0 + 2 * k + 1) + ", 0");
     }
@@ -694,8 +713,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   if (!accumulate) tile_base(S_RT, S_ROOT, S_RTS);
   if (accumulate) {
     // w = weight ? weight[b0 + lane] : 1.0   (consumed at the first root, long after this load)
-    E.ins("v_mov_b32_e32 v" + std::to_string(acc0 + 2 * p.R) + ", 0");
-    E.ins("v_mov_b32_e32 v" + std::to_string(acc0 + 2 * p.R + 1) + ", 0x3ff00000");
+    E.ins("v_mov_b32_e32 v" + std::to_string(wgt0) + ", 0");
+    E.ins("v_mov_b32_e32 v" + std::to_string(wgt0 + 1) + ", 0x3ff00000");
     E.ins("s_cmp_eq_u64 " + S2(S_WGT) + ", 0");
     E.ins("s_cbranch_scc1 .Lnow" + sfx);
     E.ins("s_lshl_b64 " + S2(S_A) + ", " + S2(S_X) + ", 3");
@@ -1166,6 +1185,12 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
             E.vm_done = std::max(E.vm_done, std::max(E.vm_issued - n, w_seq));
           }
           E.ins("v_mul_f64 " + vtmp + ", " + vwgt + ", " + (o.nega ? "-" : "") + vlo(o.a));
+          if (aa) {
+            acc_to_tmp2(o.d);
+            E.ins("v_add_f64 " + vtmp2 + ", " + vtmp2 + ", " + vtmp);
+            tmp2_to_acc(o.d);
+            break;
+          }
           E.ins("v_add_f64 " + vacc(o.d) + ", " + vacc(o.d) + ", " + vtmp);
           break;
         }
@@ -1216,7 +1241,19 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     // then partial[k][wg] = lane 0's value; fdg_reduce_lane_partials adds the waves in fixed order
     E.ins("s_mov_b64 exec, -1");
     E.ins("v_lshlrev_b32_e32 " + V(V_TMP) + ", 2, v0");
-    for (int off = 32; off >= 1; off >>= 1) {
+    if (aa)
+      for (uint32_t k = 0; k < p.R; ++k) {          // root by root: accumulator -> VGPR pair, butterfly, back
+        acc_to_tmp2(k);
+        for (int off = 32; off >= 1; off >>= 1) {
+          E.ins("v_xor_b32_e32 " + V(V_TMP + 1) + ", " + std::to_string(off * 4) + ", " + V(V_TMP));
+          E.ins("ds_bpermute_b32 v" + std::to_string(wgt0 + 2) + ", " + V(V_TMP + 1) + ", v" + std::to_string(wgt0 + 4));
+          E.ins("ds_bpermute_b32 v" + std::to_string(wgt0 + 3) + ", " + V(V_TMP + 1) + ", v" + std::to_string(wgt0 + 5));
+          E.ins("s_waitcnt lgkmcnt(0)");
+          E.ins("v_add_f64 " + vtmp2 + ", " + vtmp2 + ", " + vtmp);
+        }
+        tmp2_to_acc(k);
+      }
+    for (int off = 32; off >= 1 && !aa; off >>= 1) {
       E.ins("v_xor_b32_e32 " + V(V_TMP + 1) + ", " + std::to_string(off * 4) + ", " + V(V_TMP));
       for (uint32_t k = 0; k < p.R; ++k) {
         const uint32_t a = acc0 + 2 * k, t = acc0 + 2 * (p.R + 1);
@@ -1233,7 +1270,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_ROOT + 1) + ", 0");
     E.ins("s_lshl_b32 " + S(S_T) + ", " + S(S_NWG) + ", 3");
     for (uint32_t k = 0; k < p.R; ++k) {
-      E.ins("global_store_dwordx2 " + V(V_TMP) + ", " + vacc(k) + ", " + S2(S_A));
+      if (aa) acc_to_tmp2(k);
+      E.ins("global_store_dwordx2 " + V(V_TMP) + ", " + (aa ? vtmp2 : vacc(k)) + ", " + S2(S_A));
       E.ins("s_add_u32 " + S(S_A) + ", " + S(S_A) + ", " + S(S_T));
       E.ins("s_addc_u32 " + S(S_A + 1) + ", " + S(S_A + 1) + ", 0");
     }
@@ -1249,9 +1287,9 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_endpgm");
 
   // ---- kernel descriptor -------------------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + (accumulate ? 2 * (p.R + 2) : 0) + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? 4 : 0) + (rl ? 2 : 0), 8);
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + 2 * acc_pairs_v + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? 4 : 0) + (rl ? 2 : 0), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
-  const uint32_t n_agpr = RW * prog.n_acc_used;
+  const uint32_t n_agpr = RW * prog.n_acc_used + (aa ? 2 * p.R : 0);
   if (cs) return KernelMeta{kname, lds_bytes, accum, n_agpr, 12, (mc || has_macro) ? S_END : S_POOL + 2 * 16};
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
   os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";

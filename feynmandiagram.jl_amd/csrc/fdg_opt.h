@@ -97,6 +97,8 @@ struct OptParams {
                                   // Float64 in the reference's generic function; as a sign on the operand it would not)
   bool mul_keeps_signs = false;   // schedules for ComplexF64 values: a product consumes a negated operand as it is instead of pulling the sign
                                   // out -- ((-z) w) and -(z w) differ in the sign of a real part that cancels exactly
+  bool acc_in_agpr = false;       // fused-accumulation kernels of graphs with 41 ... 124 roots: the per-lane accumulators live in AGPR pairs (above the
+                                  // program's own), three VGPR pairs (weight, two temporaries) above the values; one wave per SIMD
   bool pool_leaves = false;       // pooled cooperative programs: leaves are re-read from the shared LDS pool (cheap to evict, never parked)
   uint32_t reserve_pairs = 0;     // VGPR pairs the kernel variant keeps above the values (accumulators, weight): the value budget shrinks
                                   // by this and by the temporaries the program's macro ops need, so that everything stays below v256

@@ -1489,7 +1489,9 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
   g->has_acc = prog_acc != nullptr;
   auto tmp_vgprs = [](const fdg::OptProgram &q) { uint32_t t = 0; for (const fdg::MOp &o : q.ops) t = std::max(t, fdg::mop_tmp_pairs(o.kind)); return 2 * t; };
   if (prog_acc) {
-    g->isa3_vgpr = ((6 + 2 * std::max<uint32_t>(prog_acc->n_reg_used, 1) + 2 * (g->prog.R + 2) + tmp_vgprs(*prog_acc) + 3) & ~3u) + 2 * prog_acc->n_acc_used;
+    g->isa3_vgpr = prog_acc->params.acc_in_agpr
+                       ? ((6 + 2 * std::max<uint32_t>(prog_acc->n_reg_used, 1) + 2 * 3 + tmp_vgprs(*prog_acc) + 3) & ~3u) + 2 * (prog_acc->n_acc_used + g->prog.R)
+                       : ((6 + 2 * std::max<uint32_t>(prog_acc->n_reg_used, 1) + 2 * (g->prog.R + 2) + tmp_vgprs(*prog_acc) + 3) & ~3u) + 2 * prog_acc->n_acc_used;
     g->isa3_lds_bytes = prog_acc->n_lds_used * 512u;
     g->isa3_mem_slots = prog_acc->n_mem_used;
   }
@@ -1619,6 +1621,18 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
   //  accumulators would take more than a third of the value registers and the roots go through the column-major scratch)
   // (few roots: eight value registers next to the accumulators are enough -- the tiny-graph configuration of the 2-loop
   //  self-energies keeps 28; many roots must leave the values a working set worth having)
+  if (g->prog.R > 40 && g->prog.R <= 124 && chosen.n_reg >= 100 && !std::getenv("FDG_ISA_NO_FUSED_ACC") && !std::getenv("FDG_ISA_NO_AGPR_ACC")) {
+    // 41 ... 124 roots (round 4): the accumulators in AGPR pairs -- the file a kernel launched with one wave per SIMD has to itself (the graphs
+    // bound by memory are launched that way whatever their registers allow; the one-wave configuration uses it for spills and keeps what
+    // the accumulators leave) -- instead of the detour through the root scratch, which cost the 84-root 3-loop vertex function a third.
+    fdg::OptParams q = chosen;
+    q.acc_in_agpr = true;
+    q.reserve_pairs = 3;                                             // the weight and two temporaries
+    q.n_reg = std::min<uint32_t>(chosen.n_reg, (256 - 6 - 2 * 3 - 8) / 2);
+    if (chosen.n_acc) q.n_acc = std::min<uint32_t>(chosen.n_acc, 124 - g->prog.R);
+    build_prog(g, q, pa);
+    return pa.supported && pa.n_acc_used + g->prog.R <= 124;
+  }
   if (g->prog.R == 0 || g->prog.R > 40 || chosen.n_reg < extra + 8 || (g->prog.R > 16 && chosen.n_reg < extra + 64) || std::getenv("FDG_ISA_NO_FUSED_ACC")) return false;
   fdg::OptParams q = chosen;
   // stay inside the occupancy step of the eval kernel (VGPRs per wave: 64 -> 8 waves/SIMD ... 256 -> 2, 512 -> 1)
