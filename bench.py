@@ -736,14 +736,14 @@ def compact_line(full):
                                 "sample": str(cb.get("sample", ""))[:110], "gpu_matches_cpu_bitwise": cb.get("gpu_matches_cpu_bitwise")}
     sec = full.get("secondary")
     if sec:
-        line["secondary_cols"] = ["workload", "layout", "evals_per_s", "bound", "frac", "frac_hbm", "frac_valu", "traffic_ratio", "bitwise", "clock_ghz"]
+        line["secondary_cols"] = ["workload", "layout", "Mevals_per_s", "bound", "frac", "frac_hbm", "frac_valu", "traffic_ratio", "bitwise", "clock_ghz"]
         rows = []
         for e in sec:
             if "error" in e:
                 rows.append([e.get("workload", "?")[:24], e.get("layout"), None, "error", None, None, None, None, False, None])
                 continue
             r = e["roofline"]
-            rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm", "tile_major": "tm", "tile_major+fma": "tm+fma", "leaf_major+fma": "lm+fma"}.get(e["layout"], e["layout"]), _r(e["value"]),
+            rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm", "tile_major": "tm", "tile_major+fma": "tm+fma", "leaf_major+fma": "lm+fma"}.get(e["layout"], e["layout"]), _r(e["value"] / 1e6),
                          {"hbm": "hbm", "valu_fp64": "valu"}.get(r["bound"], r["bound"]), _r(r["frac"], 3), _r(r.get("frac_hbm"), 3),
                          _r(r.get("frac_valu"), 3), _r(r.get("traffic_over_algorithmic"), 3),
                          (e.get("gpu_matches_cpu_bitwise") if not e.get("contracted") else "fma:%.1e" % (e.get("max_dev_over_Sk") or 0.0)), _r(r.get("clock_ghz"), 3)])
