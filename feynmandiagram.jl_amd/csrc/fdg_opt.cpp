@@ -1036,7 +1036,12 @@ void sort_load_runs(std::vector<MOp> &ops) {
       bool distinct = true;
       for (size_t a = i; a < j && distinct; ++a)
         for (size_t b = a + 1; b < j; ++b) if (ops[a].d == ops[b].d) { distinct = false; break; }
-      if (distinct) std::stable_sort(ops.begin() + i, ops.begin() + j, [](const MOp &x, const MOp &y) { return x.a < y.a; });
+      // (experiment FDG_LOAD_RUN_CHUNK=c: only within chunks of c loads, so that what the first fold steps need is issued first;
+      // loads return in order, and behind a sorted burst of 70 the first fold step waits for whichever of them comes last)
+      const size_t chunk = std::getenv("FDG_LOAD_RUN_CHUNK") ? (size_t)std::max(0, std::atoi(std::getenv("FDG_LOAD_RUN_CHUNK"))) : 0;
+      if (distinct)
+        for (size_t s = i; s < j; s += (chunk ? chunk : j - i))
+          std::stable_sort(ops.begin() + s, ops.begin() + std::min(j, s + (chunk ? chunk : j - i)), [](const MOp &x, const MOp &y) { return x.a < y.a; });
     }
     i = j;
   }
