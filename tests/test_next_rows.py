@@ -253,6 +253,26 @@ def test_eviction_rule_and_landing_slots_replay_exactly(libfdg, monkeypatch, nam
             assert h.last_n_acc == 124
 
 
+@pytest.mark.parametrize("name", ["parquet_sigma4", "parquet_sigma4_insdyn", "gv_sigma5"])
+def test_load_runs_sorted_in_chunks_replay_exactly(libfdg, monkeypatch, name):
+    """FDG_LOAD_RUN_CHUNK (round 4, an experiment that measured neutral): back-to-back leaf loads are sorted by leaf only within
+    chunks of c, so the loads the first fold steps need are issued first.  An order of independent loads: same bits, same loads."""
+    t = workloads.get(name)
+    h = capi.GraphHandle(t)
+    leaf = oracle.philox_uniform(9, t.n_leaf, 83)
+    want = oracle.eval_static(t, leaf)
+    base, nr, nl, nm = h.opt_program(n_reg=120, n_lds=80, n_acc=124)
+    for c in ("4", "16"):
+        monkeypatch.setenv("FDG_LOAD_RUN_CHUNK", c)
+        ops, nr, nl, nm = h.opt_program(n_reg=120, n_lds=80, n_acc=124)
+        assert np.array_equal(replay(ops, nr, nl, nm, h.last_n_acc, leaf, t.n_root), want)
+        assert np.array_equal(np.sort(ops["kind"]), np.sort(base["kind"]))      # the same operations, in another order
+        head = ops["kind"][: int(np.argmax(ops["kind"] != 0))] if (ops["kind"] != 0).any() else ops["kind"]
+        lv = ops["a"][: len(head)]
+        for s0 in range(0, len(lv), int(c)):       # ascending leaf index inside every chunk of the head burst
+            assert np.all(np.diff(lv[s0:s0 + int(c)].astype(np.int64)) > 0)
+
+
 @pytest.mark.parametrize("name,window,cost", [("sigma4_standin", 1000, 4), ("sigma4_standin", 300, 8), ("gv_sigma4_taylor2", 200, 8),
                                               ("synthetic_small", 40, 8), ("gv_sigma5", 100, 16)])
 def test_forget_and_recompute_replays_exactly(libfdg, monkeypatch, name, window, cost):
