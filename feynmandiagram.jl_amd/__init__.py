@@ -11,12 +11,12 @@ generators for tests and bench.py, not product, and not exported here.
 from . import graph as ComputationalGraphs
 from . import compilers as Compilers
 from . import frontends as FrontEnds
-from .graph import (FeynmanGraph, Graph, PostOrderDFS, Power, Prod, Sum, Unitary, constant_graph,
+from .graph import (FeynmanGraph, Graph, PostOrderDFS, Power, Prod, Sum, Unitary, constant_graph, eval_,
                     external_vertex, linear_combination, multi_product)
 from .nodetable import NodeTable, synthetic_parquet_like, from_program
 from .lowering import lower
 from .compilers import GraphFunc, compile_table
 
 __all__ = ["ComputationalGraphs", "Compilers", "FrontEnds", "Graph", "FeynmanGraph", "Sum", "Prod", "Power", "Unitary",
-           "constant_graph", "external_vertex", "linear_combination", "multi_product", "PostOrderDFS",
+           "constant_graph", "eval_", "external_vertex", "linear_combination", "multi_product", "PostOrderDFS",
            "NodeTable", "synthetic_parquet_like", "from_program", "lower", "GraphFunc", "compile_table"]

@@ -353,6 +353,46 @@ def PostOrderDFS(g: Graph) -> Iterator[Graph]:
 
 
 # --------------------------------------------------------------------------- #
+# eval! (src/computational_graph/eval.jl:15-39 for Graph, 42-66 for FeynmanGraph: the same loop).  The reference walks the
+# tree, stores `node.weight` for every node and returns the last one; here the leaves get their weights the same way and
+# every internal node is a root of ONE device evaluation with eval!'s association (apply, eval.jl:1-13: sum(w f),
+# prod(w f), w^N f) -- no arithmetic on the host, no evaluation without the device.
+# --------------------------------------------------------------------------- #
+def eval_(g: Graph, leafmap=None, leaf=None, *, inherit: bool = False, randseed: int = -1, specialize="auto", **kw):
+    """``eval!(g, leafmap, leaf; inherit=false, randseed=-1)``.  ``leafmap``: node id -> index into ``leaf`` (0-based here,
+    1-based in Julia); empty: every leaf weighs 1.0 (``randseed < 0``) or a uniform random number (drawn per visit from numpy's
+    generator seeded with ``randseed`` when it is positive -- Julia's stream is not reproduced); ``inherit``: keep the weights
+    the leaves have.  Sets ``weight`` on every node of the graph and returns the root's."""
+    import numpy as np
+    from . import compilers
+    rng = None
+    if randseed >= 0:
+        rng = np.random.default_rng(randseed if randseed > 0 else None)
+    nodes = list(PostOrderDFS(g))
+    for node in nodes:
+        if node.subgraphs or inherit:
+            continue
+        if not leafmap:
+            node.weight = 1.0 if rng is None else float(rng.random())
+        else:
+            node.weight = leaf[leafmap[node.id]]
+    inner, seen = [], set()
+    for node in nodes:
+        if node.subgraphs and node.id not in seen:
+            seen.add(node.id)
+            inner.append(node)
+    if not inner:
+        return g.weight
+    f, lm = compilers.compile([g], root=[n.id for n in inner], specialize=specialize, association="eval", **kw)
+    leaf_val = np.array([float(lm[k + 1].weight) for k in range(len(lm))], dtype=np.float64)
+    out = np.zeros(len(inner), dtype=np.float64)
+    f(out, leaf_val)
+    for node, w in zip(inner, out):
+        node.weight = float(w)
+    return g.weight
+
+
+# --------------------------------------------------------------------------- #
 # minimal leaf builders for FeynmanGraph KATs (feynmangraph.jl:232-279).  The
 # quantum-operator algebra is out of scope: vertices are opaque labels.
 # --------------------------------------------------------------------------- #

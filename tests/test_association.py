@@ -174,3 +174,62 @@ def test_interp_and_static_handles_differ_on_device_where_the_oracles_do(libfdg,
     b = fd.compile_table(t, specialize="isa", association="eval")(None, leaf).cpu().numpy()
     assert np.array_equal(a, oracle.eval_static(t, h_leaf)) and np.array_equal(b, oracle.eval_interp(t, h_leaf))
     assert (a != b).any()
+
+
+# ---- `eval!` itself: ComputationalGraphs.eval_ (host mirror of eval.jl:15-39) -------------------------------------------------
+def _graph_with_scaled_products():
+    """A small graph in which eval!'s rounding differs from the generated function's (factors that are not powers of two on later
+    operands of products), built with the host mirror's own constructors."""
+    from feynmandiagram_jl_amd.graph import Graph, Prod, Sum, Power
+    a, b, c, d = (Graph([]) for _ in range(4))
+    p1 = Graph([a, b, c], subgraph_factors=[1.0, 3.0, 1.0 / 3.0], operator=Prod())
+    p2 = Graph([d, a, p1], subgraph_factors=[0.7, -7.5, 1e-3], operator=Prod())
+    s = Graph([p1, p2, c], subgraph_factors=[1.0, -1.0, 0.3], operator=Sum())
+    q = Graph([s], subgraph_factors=[1.7], operator=Power(2))
+    top = Graph([q, s, p1], subgraph_factors=[1.0, 1.1, -0.9], operator=Prod())
+    return top, [a, b, c, d]
+
+
+def test_eval_bang_mirror_has_no_cpu_fallback(libfdg):
+    """Without a gfx950 device the call fails loudly (FDG_E_NO_DEVICE); the leaves have their weights by then, as in the reference's loop."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    (g3, _, _), _ = fixtures.kat_evaluation()
+    with pytest.raises(capi.FdgError) as e:
+        fd.eval_(g3)
+    assert e.value.code == capi.FDG_E_NO_DEVICE
+
+
+@pytest.mark.gpu
+def test_eval_bang_mirror_on_device(libfdg, cuda):
+    """test/computational_graph.jl:874-887 through the mirror of the function the reference's test calls: eval!(g3) == 26,
+    eval!(g4) == 27, eval!(g5) == 27 * 26; every node's weight is set; leafmap / leaf, inherit and randseed as eval.jl:15-39."""
+    from feynmandiagram_jl_amd.graph import PostOrderDFS
+    (g3, g4, g5), want = fixtures.kat_evaluation()
+    assert (fd.eval_(g3), fd.eval_(g4), fd.eval_(g5)) == want
+    assert g5.weight == 702.0 and all(n.weight == 1.0 for n in PostOrderDFS(g5) if not n.subgraphs)
+    # a graph on which eval! and the generated function round differently: every node's weight against the oracle's interpreter
+    top, leaves = _graph_with_scaled_products()
+    vals = [0.37, -1.9, 2.4, 0.051]
+    leafmap = {l.id: k for k, l in enumerate(leaves)}
+    got = fd.eval_(top, leafmap, vals)
+    inner, seen = [], set()
+    for n in PostOrderDFS(top):
+        if n.subgraphs and n.id not in seen:
+            seen.add(n.id); inner.append(n)
+    t, lm, _ = lower([top], root=[n.id for n in inner])
+    x = np.array([[vals[leafmap[lm[k + 1].id]] for k in range(len(lm))]])
+    ref = oracle.eval_interp(t, x)[0]
+    assert [n.weight for n in inner] == ref.tolist() and got == ref[-1] == top.weight
+    assert not np.array_equal(ref, oracle.eval_static(t, x)[0])           # (the case separates the two evaluators)
+    assert [l.weight for l in leaves] == vals
+    # inherit=true keeps the leaves' weights; randseed > 0 draws them (reproducibly here, not Julia's stream)
+    for l, v in zip(leaves, (1.5, 2.0, -0.25, 4.0)):
+        l.weight = v
+    r1 = fd.eval_(top, inherit=True)
+    assert [l.weight for l in leaves] == [1.5, 2.0, -0.25, 4.0] and r1 == oracle.eval_interp(t, np.array([[lm[k + 1].weight for k in range(len(lm))]]))[0][-1]
+    r2, w2 = fd.eval_(top, randseed=7), [l.weight for l in leaves]
+    assert fd.eval_(top, randseed=7) == r2 and [l.weight for l in leaves] == w2 and all(0.0 <= w < 1.0 for w in w2)
+    # a bare leaf: its weight, no device call
+    assert fd.eval_(leaves[0], inherit=True) == leaves[0].weight
