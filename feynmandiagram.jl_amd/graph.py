@@ -362,7 +362,9 @@ def eval_(g: Graph, leafmap=None, leaf=None, *, inherit: bool = False, randseed:
     """``eval!(g, leafmap, leaf; inherit=false, randseed=-1)``.  ``leafmap``: node id -> index into ``leaf`` (0-based here,
     1-based in Julia); empty: every leaf weighs 1.0 (``randseed < 0``) or a uniform random number (drawn per visit from numpy's
     generator seeded with ``randseed`` when it is positive -- Julia's stream is not reproduced); ``inherit``: keep the weights
-    the leaves have.  Sets ``weight`` on every node of the graph and returns the root's."""
+    the leaves have.  Sets ``weight`` on every node of the graph and returns the root's.  (A leaf the walk meets several times keeps
+    its last draw and the whole graph is evaluated with it; the reference evaluates each visit's parents with the draw current at that
+    moment -- a difference only under ``randseed >= 0`` on shared leaves, where the values are not comparable with Julia's anyway.)"""
     import numpy as np
     from . import compilers
     rng = None

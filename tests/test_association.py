@@ -233,3 +233,21 @@ def test_eval_bang_mirror_on_device(libfdg, cuda):
     assert fd.eval_(top, randseed=7) == r2 and [l.weight for l in leaves] == w2 and all(0.0 <= w < 1.0 for w in w2)
     # a bare leaf: its weight, no device call
     assert fd.eval_(leaves[0], inherit=True) == leaves[0].weight
+    # test/computational_graph.jl:471-491: the value does not change under optimize!, leaves drawn with the same seed
+    from feynmandiagram_jl_amd.graph import Graph, Prod
+    from feynmandiagram_jl_amd.producers import optimize
+    from test_next_rows import O
+    g1 = Graph([])
+    g2 = 2 * g1
+    g3 = Graph([g2], subgraph_factors=[3], operator=Prod())
+    g4 = Graph([g3], subgraph_factors=[5], operator=Prod())
+    g5 = Graph.new([], factor=3.0, operator=O())
+    h0 = Graph([g1, g4, g5], subgraph_factors=[2, -1, 1])
+    h1 = Graph([h0], operator=Prod(), subgraph_factors=[2])
+    h = Graph([h1, g5])
+    g1p = Graph([], operator=O())
+    _h = Graph([Graph([g1, g1p], subgraph_factors=[-28, 3]), g1p], subgraph_factors=[2, 3])
+    optimize.optimize_([h])
+    assert fd.eval_(h, randseed=2) == pytest.approx(fd.eval_(_h, randseed=2), rel=1e-14)
+    assert fd.eval_(h) == fd.eval_(_h) == (-28 + 3) * 2 + 3
+
