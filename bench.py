@@ -610,6 +610,7 @@ def main():
         out["roofline"]["frac_hbm_min_over_steps"] = fr[0]
         out["roofline"]["frac_hbm_max_over_steps"] = fr[-1]
         out["roofline"]["frac_hbm_median_over_steps"] = fr[len(fr) // 2]
+        out["roofline"]["frac_hbm_p05_over_steps"] = fr[len(fr) // 20]      # (a launch in a hundred runs 10 % slow now and then: the minimum is that launch)
         out["roofline"]["frac_hbm_of_each_step"] = [round(st["bytes_alg"] * B / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for m in kern_ms]     # (detail file only)
         out["roofline"]["placement"] = "single allocation, as it came from the allocator (no trials)"
         try:
@@ -725,7 +726,7 @@ def compact_line(full):
     roof = full.get("roofline")
     if roof:
         keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_kernel_ms",
-                "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_median_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy",
+                "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_p05_over_steps", "frac_hbm_median_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy",
                 "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock")
         line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:60]) for k in keep if k in roof}
         if roof.get("placement"):
