@@ -52,8 +52,9 @@ mutable struct GraphFunc
     n_leaf::Int
     n_root::Int
     last_root::Int          # 1-based index of the root written last, 0 if none
-    function GraphFunc(h, L, R, last)
-        f = new(h, L, R, last)
+    cache_dir::Union{Nothing,String}   # the JIT cache directory given to compile_hip (nothing: the library's per-user default); later specialisations use it too
+    function GraphFunc(h, L, R, last, cache_dir=nothing)
+        f = new(h, L, R, last, cache_dir)
         finalizer(x -> ccall((:fdg_graph_destroy, _libfdg), Cint, (Ptr{Cvoid},), x.handle), f)
         return f
     end
@@ -173,7 +174,7 @@ function compile_hip(graphs::AbstractVector{<:AbstractGraph};
         end
         _fdg_check(rc)
     end
-    return GraphFunc(h[], L, length(root_slot), last_root), leafmap
+    return GraphFunc(h[], L, length(root_slot), last_root, cache_dir), leafmap
 end
 
 # one sample: the calling convention of the generated eval_graph!(root, leafVal)
@@ -216,7 +217,8 @@ function eval_device!(f::GraphFunc, d_root::Ptr{T}, d_leaf::Ptr{T}, B::Integer;
     dt = _FDG_DT[T]
     # (flag 4 = FDG_SPEC_ISA: ComplexF64 batches whose rows are contiguous -- leaf_strides = (L, 1) -- additionally get the graph spelled out on
     #  real and imaginary parts through the assembly back end; a column-major B x L Julia matrix takes the per-type kernel)
-    _fdg_check(ccall((:fdg_graph_specialize_typed, _libfdg), Cint, (Ptr{Cvoid}, Cint, Cstring, Cuint), f.handle, dt, C_NULL, Cuint(4)))
+    cdir = isnothing(f.cache_dir) ? C_NULL : f.cache_dir
+    _fdg_check(ccall((:fdg_graph_specialize_typed, _libfdg), Cint, (Ptr{Cvoid}, Cint, Cstring, Cuint), f.handle, dt, cdir, Cuint(4)))
     _fdg_check(ccall((:fdg_eval_device_typed, _libfdg), Cint,
         (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}),
         f.handle, dt, d_leaf, leaf_strides[1], leaf_strides[2], d_root, root_strides[1], root_strides[2], B, stream))
