@@ -195,7 +195,7 @@ def test_accumulate(libfdg, cuda, spec):
 
 
 @pytest.mark.parametrize("name,B,layout", [("gv_sigma4_taylor2", 300_007, "leaf_major"), ("gv_sigma4", 100_000, "sample_major"),
-                                           ("sigma4_standin", 20_011, "leaf_major")])
+                                           ("sigma4_standin", 20_011, "leaf_major"), ("sigma2", 200_003, "leaf_major"), ("parquet_sigma2", 131_072, "leaf_major")])
 def test_fused_accumulate_isa(libfdg, cuda, name, B, layout, monkeypatch):
     """The optimizing back end sums w_b * root_k(b) in registers (per-lane partials, one store per wave at the
     end) instead of writing roots.  Same roots bit for bit; only the order of the sum over samples differs from
@@ -207,6 +207,7 @@ def test_fused_accumulate_isa(libfdg, cuda, name, B, layout, monkeypatch):
     w = torch.rand(B, dtype=torch.float64, device=cuda) - 0.25
     acc = f.accumulate(leaf, w)
     acc_again = f.accumulate(leaf, w)
+    assert "_acc" in f.kernel_info()["last_kernel"], f.kernel_info()["last_kernel"]      # the fused kernel ran, also on the 2-loop graphs
     acc1 = f.accumulate(leaf, None)
     torch.cuda.synchronize()
     assert torch.equal(acc, acc_again)

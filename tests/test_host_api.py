@@ -473,6 +473,9 @@ def test_kernel_info_names_the_variants(libfdg):
     assert fd.compile_table(t).kernel_info()["n_valu"] == [0, 0, 0]          # the interpreter: nothing installed
     small = fd.compile_table(workloads.get("sigma2"), specialize="auto")     # < 16 leaves: no row-major variant -> companion
     assert small.kernel_info()["has_rm"] == 0
+    # the tiny-graph configuration (28 value registers) keeps its fused accumulation (a bound of R + 2 + 64 registers had dropped it)
+    for name in ("sigma2", "parquet_sigma2", "parquet_sigma3"):
+        assert fd.compile_table(workloads.get(name), specialize="isa").kernel_info()["has_acc"] == 1, name
 
 
 def test_exponent_and_root_count_bounds():
