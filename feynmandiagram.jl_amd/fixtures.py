@@ -119,7 +119,7 @@ def kat_taylor_getdiagram(spin: float = 2.0, D: int = 3):
     return root, (spin - 2.0) / (2 * math.pi) ** D
 
 
-def kat_first_derivatives():
+def kat_first_derivatives(with_graphs: bool = False):
     """test/computational_graph.jl:930-988 (the "forwardAD_root!" set): F3 = g1 + g2, F2 = 2 g1 + g3 + 3 F3 with g3 = 2 * leaf,
     F1 = (3 g1) F2 F3, F0 = F1 F3, F0' = F1 + F3; the reference evaluates the first-derivative graphs of F1, F2, F3, F0, F0' on
     leaf vectors [g1, g2, g3, dg1, dg2, dg3] and holds the values below (exact ==).  The legacy graph AD that builds those graphs
@@ -150,4 +150,9 @@ def kat_first_derivatives():
         for idx, obj in leafmap.items():
             v[idx - 1] = values[where[id(obj)]]
         cases.append((v, want))
+    if with_graphs:      # the call shape of the reference's test: eval!(graph, leafmap, leaf) with leafmap = node id -> index into leaf
+        graphs = [s.coeffs[(1,)] for s in series]
+        id_leafmap = {obj.id: where[id(obj)] for obj in leafmap.values()}
+        vectors = [(1.0, 1.0, 1.0, 1.0, 0.0, 0.0), (5.0, -1.0, 2.0, 0.0, 1.0, 0.0), (5.0, -1.0, 2.0, 0.0, 0.0, 1.0)]
+        return table, cases, graphs, id_leafmap, vectors
     return table, cases

@@ -251,3 +251,16 @@ def test_eval_bang_mirror_on_device(libfdg, cuda):
     assert fd.eval_(h, randseed=2) == pytest.approx(fd.eval_(_h, randseed=2), rel=1e-14)
     assert fd.eval_(h) == fd.eval_(_h) == (-28 + 3) * 2 + 3
 
+
+
+@pytest.mark.gpu
+def test_eval_bang_mirror_with_leafmap_and_leaf_vectors(libfdg, cuda):
+    """test/computational_graph.jl:930-988 in the reference's own call shape, ``eval!(dual[k], leafmap, leaf)``: 120, 5, 1, 300 /
+    570, 3, 1, 3840 / 120, 2, 0, 480, 120 (exact ==) on leaf vectors that are not all ones.  (The derivative graphs come from the
+    restated Taylor pass: fixtures.kat_first_derivatives.)"""
+    _, cases, graphs, leafmap, vectors = fixtures.kat_first_derivatives(with_graphs=True)
+    for (_, want), leaf in zip(cases, vectors):
+        for g, w in zip(graphs, want):
+            if w is not None:
+                assert fd.eval_(g, leafmap, list(leaf)) == w
+
