@@ -358,11 +358,13 @@ def PostOrderDFS(g: Graph) -> Iterator[Graph]:
 # every internal node is a root of ONE device evaluation with eval!'s association (apply, eval.jl:1-13: sum(w f),
 # prod(w f), w^N f) -- no arithmetic on the host, no evaluation without the device.
 # --------------------------------------------------------------------------- #
-def eval_(g: Graph, leafmap=None, leaf=None, *, inherit: bool = False, randseed: int = -1, specialize="auto", **kw):
+def eval_(g: Graph, leafmap=None, leaf=None, *, inherit: bool = False, randseed: int = -1, specialize=False, **kw):
     """``eval!(g, leafmap, leaf; inherit=false, randseed=-1)``.  ``leafmap``: node id -> index into ``leaf`` (0-based here,
     1-based in Julia); empty: every leaf weighs 1.0 (``randseed < 0``) or a uniform random number (drawn per visit from numpy's
     generator seeded with ``randseed`` when it is positive -- Julia's stream is not reproduced); ``inherit``: keep the weights
-    the leaves have.  Sets ``weight`` on every node of the graph and returns the root's.  (A leaf the walk meets several times keeps
+    the leaves have.  Sets ``weight`` on every node of the graph and returns the root's.  ``specialize``: the back end of the one
+    device evaluation -- by default the table interpreter (``fdg_interp``: no JIT for a single sample, any number of roots), or
+    "isa" / "auto" / True as in :class:`compilers.GraphFunc`.  (A leaf the walk meets several times keeps
     its last draw and the whole graph is evaluated with it; the reference evaluates each visit's parents with the draw current at that
     moment -- a difference only under ``randseed >= 0`` on shared leaves, where the values are not comparable with Julia's anyway.)"""
     import numpy as np

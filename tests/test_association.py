@@ -208,12 +208,14 @@ def test_eval_bang_mirror_on_device(libfdg, cuda):
     from feynmandiagram_jl_amd.graph import PostOrderDFS
     (g3, g4, g5), want = fixtures.kat_evaluation()
     assert (fd.eval_(g3), fd.eval_(g4), fd.eval_(g5)) == want
+    assert (fd.eval_(g3, specialize="isa"), fd.eval_(g4, specialize=True), fd.eval_(g5, specialize="auto")) == want      # every back end
     assert g5.weight == 702.0 and all(n.weight == 1.0 for n in PostOrderDFS(g5) if not n.subgraphs)
     # a graph on which eval! and the generated function round differently: every node's weight against the oracle's interpreter
     top, leaves = _graph_with_scaled_products()
     vals = [0.37, -1.9, 2.4, 0.051]
     leafmap = {l.id: k for k, l in enumerate(leaves)}
     got = fd.eval_(top, leafmap, vals)
+    assert fd.eval_(top, leafmap, vals, specialize="isa") == got == fd.eval_(top, leafmap, vals, specialize=True)
     inner, seen = [], set()
     for n in PostOrderDFS(top):
         if n.subgraphs and n.id not in seen:
