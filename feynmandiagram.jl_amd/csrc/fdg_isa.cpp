@@ -489,6 +489,15 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   // experiment (results exact): a wave takes 2^c consecutive tiles, then jumps over the other waves' runs ("chunk<c>", c = 1 .. 9)
   int tile_run = 0;
   if (dbg && std::strstr(dbg, "chunk") && !cs) tile_run = std::max(0, std::min(9, std::atoi(std::strstr(dbg, "chunk") + 5)));
+  // experiment (results exact; grids that are a multiple of eight workgroups): workgroup w, which the dispatcher places on XCD w % 8, takes
+  // its tiles from the eighth of the batch that belongs to that XCD -- ("xcd") every XCD streams one contiguous region
+  const bool tile_xcd = dbg && std::strstr(dbg, "xcd") && !cs && !tile_run;
+  // experiment (results exact; grids that are a power of two): in round j workgroup w takes tile j n + ((w + j r) mod n) -- ("rot<r>") the
+  // residue class mod 8 of the tiles an XCD reads changes from round to round instead of being w mod 8 for the whole launch.
+  // State in the last pair of the constant pool (the experiment is for graphs that leave it free).
+  int tile_rot = 0;
+  if (dbg && std::strstr(dbg, "rot") && !cs && !tile_run && !tile_xcd) tile_rot = std::max(0, std::atoi(std::strstr(dbg, "rot") + 3));
+  const int S_ROTB = S_POOL + 2 * (N_POOL - 1), S_ROTS = S_ROTB + 1;
   E.vm_slack = (dbg && std::strstr(dbg, "noackwait") && !accumulate) ? p.R : 0;
   // ---- prologue ------------------------------------------------------------
   if (cs) E.ins("v_and_b32_e32 v0, 63, v0");          // lane within the wave (the workgroup has four waves)
@@ -650,7 +659,20 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_lshr_b64 " + S2(S_X) + ", " + S2(S_X) + ", " + std::to_string(TSH));
   E.ins("s_mov_b32 " + S(S_NTILES) + ", " + S(S_X));
   if (tile_run) E.ins("s_lshl_b32 " + S(S_TILE) + ", s2, " + std::to_string(tile_run));
-  else E.ins("s_mov_b32 " + S(S_TILE) + ", s2");
+  else if (tile_xcd) {
+    E.ins("s_and_b32 " + S(S_X) + ", s2, 7");                                      // XCD of this workgroup
+    E.ins("s_add_u32 " + S(S_T) + ", " + S(S_NTILES) + ", 7");
+    E.ins("s_lshr_b32 " + S(S_T) + ", " + S(S_T) + ", 3");                         // tiles per XCD
+    E.ins("s_mul_i32 " + S(S_A) + ", " + S(S_X) + ", " + S(S_T));                  // first tile of the XCD's range
+    E.ins("s_lshr_b32 " + S(S_A + 1) + ", s2, 3");                                 // this workgroup's index inside its XCD
+    E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_A) + ", " + S(S_A + 1));
+    E.ins("s_add_u32 " + S(S_A) + ", " + S(S_A) + ", " + S(S_T));
+    E.ins("s_min_u32 " + S(S_NTILES) + ", " + S(S_A) + ", " + S(S_NTILES));        // end of the range (the loop's bound from here on)
+  }
+  else {
+    E.ins("s_mov_b32 " + S(S_TILE) + ", s2");
+    if (tile_rot) { E.ins("s_mov_b32 " + S(S_ROTB) + ", 0"); E.ins("s_mov_b32 " + S(S_ROTS) + ", s2"); }
+  }
   E.ins("s_mul_i32 " + S(S_X) + ", s2, " + hex32(cs ? cs->panel_wg_bytes : panel_bytes_per_wave));
   E.ins("s_mul_hi_u32 " + S(S_X + 1) + ", s2, " + hex32(cs ? cs->panel_wg_bytes : panel_bytes_per_wave));
   E.ins("s_add_u32 " + S(S_PANEL) + ", " + S(S_WS) + ", " + S(S_X));
@@ -1231,6 +1253,15 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", " + S(S_X));
     E.ins("s_sub_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", " + std::to_string(1 << tile_run));
     os << ".Lrun" << sfx << ":\n";
+  } else if (tile_xcd) {
+    E.ins("s_lshr_b32 " + S(S_X) + ", " + S(S_NWG) + ", 3");
+    E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", " + S(S_X));
+  } else if (tile_rot) {
+    E.ins("s_add_u32 " + S(S_ROTB) + ", " + S(S_ROTB) + ", " + S(S_NWG));
+    E.ins("s_add_u32 " + S(S_ROTS) + ", " + S(S_ROTS) + ", " + std::to_string(tile_rot));
+    E.ins("s_sub_u32 " + S(S_X) + ", " + S(S_NWG) + ", 1");
+    E.ins("s_and_b32 " + S(S_ROTS) + ", " + S(S_ROTS) + ", " + S(S_X));
+    E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_ROTB) + ", " + S(S_ROTS));
   } else {
     E.ins("s_add_u32 " + S(S_TILE) + ", " + S(S_TILE) + ", " + S(S_NWG));
   }
