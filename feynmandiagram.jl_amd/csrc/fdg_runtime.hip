@@ -1539,6 +1539,7 @@ static void build_prog(const fdg_graph *g, fdg::OptParams prm, fdg::OptProgram &
   prm.fma = prm.fma || g->isa_fma;
   if (const char *e = std::getenv("FDG_LA_LDS")) prm.lookahead_lds = (uint32_t)std::max(1, std::atoi(e));       // experiments
   if (const char *e = std::getenv("FDG_LA_LDS_B")) { if (prm.n_acc) prm.lookahead_lds = (uint32_t)std::max(1, std::atoi(e)); }   // ... one wave per SIMD only
+  if (std::getenv("FDG_ROOTS_LAST") && !g->isa_fma) prm.roots_last = true;   // experiment: every program's root stores back to back at the tile's end (one block of a tile-major root batch)
   fdg::build_opt_program(g->prog, prm, out);
 }
 
