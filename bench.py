@@ -151,7 +151,7 @@ def probe_stop(probe):
 class Case:
     """One workload resident on the device: handle, leaf batch (synthetic, Philox keyed by the global sample index), root buffer."""
 
-    def __init__(self, workload, layout, B, dev, backend="isa", flags=0, sample_offset=0):
+    def __init__(self, workload, layout, B, dev, backend="isa", flags=0, sample_offset=0, placement="plain"):
         import torch
         import feynmandiagram_jl_amd as fd
         from feynmandiagram_jl_amd import capi, workloads
@@ -160,6 +160,7 @@ class Case:
         self.st = t.stats()
         L, R = t.n_leaf, t.n_root
         self.sample_offset = sample_offset
+        self.placement, self.pair = placement, None
         if DRY:
             self.f, self.stream = DryFunc(B), None
             self.leaf = torch.zeros((1, L), dtype=torch.float64)
@@ -176,6 +177,14 @@ class Case:
         from feynmandiagram_jl_amd import capi
         B, L, R, dev = self.B, self.t.n_leaf, self.t.n_root, self.dev
         st = self.stream.cuda_stream
+        if self.layout == "tile_major" and self.placement == "paired":
+            # the library's own allocator for a tile-major batch (fdg_batch_alloc_pair): every window of the leaves gets a chunk of roots
+            # behind which the handle's kernel was MEASURED at the fast rate; a plain allocation is the "@plain" row
+            self.pair = self.f.tile_major_pair(B, dev, calibrate=True)
+            self.leaf, self.root = self.pair.leaf, self.pair.root
+            self.root.zero_()
+            capi.fill_uniform_device_tiled(self.leaf.data_ptr(), B, L, 1, 64, 64 * L, 1234, self.sample_offset, st)
+            return
         if self.layout == "tile_major":       # fdg_eval_device_tiled: [tile, value, sample in tile] -- a Julia Array{Float64,3}(64, L, cld(B, 64))
             T = (B + 63) // 64
             self.leaf = torch.empty((T, L, 64), dtype=torch.float64, device=dev)
@@ -189,6 +198,12 @@ class Case:
             self.leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
             self.root = torch.empty((R, B), dtype=torch.float64, device=dev).t()
         capi.fill_uniform_device(self.leaf.data_ptr(), B, L, self.leaf.stride(0), self.leaf.stride(1), 1234, self.sample_offset, st)
+
+    def free(self):
+        self.leaf = self.root = None
+        if self.pair is not None:
+            self.pair.free()
+            self.pair = None
 
     def head(self, x, n):
         """The first n samples of a batch (leaf or root) as a host [n, C] array, whatever the layout."""
@@ -350,8 +365,9 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
     try:
         from feynmandiagram_jl_amd import capi
         fma = layout.endswith("+fma")
-        lay = layout[:-4] if fma else layout
-        c = Case(workload, lay, 16_000_000 if workload == "parquet_sigma4" else DEFAULT_B.get(workload, 1_000_000), dev,
+        plain = layout.endswith("@plain")        # the headline's workload at the headline's size on a PLAIN allocation (what hipMalloc hands out)
+        lay = layout[:-4] if fma else (layout[:-6] if plain else layout)
+        c = Case(workload, lay, DEFAULT_B[workload] if plain else (16_000_000 if workload == "parquet_sigma4" else DEFAULT_B.get(workload, 1_000_000)), dev,
                  flags=capi.FDG_SPEC_FAST_MATH if fma else 0)
         ms = c.timed(steps, warm)
         avg = sum(ms) / len(ms) / 1e3
@@ -474,6 +490,9 @@ def main():
                     help="tile_major = the batch as [tile of 64 samples][leaf][sample in tile] (a Julia Array{Float64,3}(64, L, cld(B, 64)); "
                          "fdg_eval_device_tiled): what a Monte-Carlo driver that owns its batch allocates, and the default; "
                          "leaf_major = a Julia column-major B x L matrix; sample_major = compile_Python's row-major [B, L]")
+    ap.add_argument("--placement", default="paired", choices=["paired", "plain"],
+                    help="headline batch (tile-major only): paired = fdg_batch_alloc_pair, the library's allocator that times (leaf window, root chunk) "
+                         "pairs and maps a fast root chunk behind every window; plain = torch.empty, whatever hipMalloc hands out")
     ap.add_argument("--backend", default="isa", choices=["isa", "isa-autotune", "auto", "hip", "interp"],
                     help="isa: optimizing back end, gfx950 assembly; hip: straight-line HIP source via hiprtc; interp: table interpreter")
     ap.add_argument("--interp", action="store_true", help="same as --backend interp")
@@ -531,8 +550,9 @@ def main():
     # per-rank Philox offset: results do not depend on how samples are sharded
     start, count = shard_range(B * world, rank, world)          # weak scaling: B samples per GPU
     assert count == B
+    paired = args.layout == "tile_major" and args.placement == "paired" and args.backend in ("isa", "isa-autotune") and not DRY
     case = Case(args.workload, args.layout, B, dev, backend=args.backend, flags=capi.FDG_SPEC_FAST_MATH if args.fast_math else 0,
-                sample_offset=start)
+                sample_offset=start, placement="paired" if paired else "plain")
     if args.backend == "isa-autotune":
         args.backend = "isa"
     if args.layout == "tile_major" and args.backend not in ("isa", "auto") and not DRY:
@@ -612,7 +632,18 @@ def main():
         out["roofline"]["frac_hbm_median_over_steps"] = fr[len(fr) // 2]
         out["roofline"]["frac_hbm_p05_over_steps"] = fr[len(fr) // 20]      # (a launch in a hundred runs 10 % slow now and then: the minimum is that launch)
         out["roofline"]["frac_hbm_of_each_step"] = [round(st["bytes_alg"] * B / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for m in kern_ms]     # (detail file only)
-        out["roofline"]["placement"] = "single allocation, as it came from the allocator (no trials)"
+        if case.pair is not None:
+            pi = case.pair.info
+            out["roofline"]["placement"] = ("fdg_batch_alloc_pair: leaves one hipMalloc, roots mapped in %d chunks chosen by timing this kernel on (leaf window, root chunk) pairs; "
+                                            "one batch, allocated once" % pi["n_chunk"])
+            out["roofline"]["placement_info"] = {"windows": pi["n_chunk"], "tiles_per_window": pi["chunk_tiles"], "root_chunks_drawn": pi["n_candidate"], "fillers": pi["n_filler"],
+                                                 "pairs_timed": pi["n_probe"], "windows_at_fast_level": pi["n_matched"], "contrast_found": bool(pi["calibrated"]),
+                                                 "pair_frac_best": pi["gbs_fast"] / HBM_PEAK_GBS, "pair_frac_worst": pi["gbs_slow"] / HBM_PEAK_GBS,
+                                                 "draw_order_pairs_frac_mean": pi["gbs_before_mean"] / HBM_PEAK_GBS, "draw_order_pairs_frac_min": pi["gbs_before_min"] / HBM_PEAK_GBS,
+                                                 "mapped_pairs_frac_mean": pi["gbs_after_mean"] / HBM_PEAK_GBS, "mapped_pairs_frac_min": pi["gbs_after_min"] / HBM_PEAK_GBS,
+                                                 "seconds": pi["seconds"]}
+        else:
+            out["roofline"]["placement"] = "single allocation, as it came from the allocator (no trials)"
         try:
             if DRY:
                 raise RuntimeError("dry run")
@@ -664,6 +695,7 @@ def main():
                 del wgt, accv
             except Exception as e:
                 out["accumulate"] = {"error": f"{type(e).__name__}: {e}"}
+    case.free()
     del case, leaf, root, f, step
     if not DRY:
         torch.cuda.empty_cache()
@@ -676,7 +708,7 @@ def main():
         if rank == 0 and world == 1 and not DRY:
             sec = []
             head = (args.workload, args.layout)
-            full = (("parquet_sigma4", "tile_major"), ("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "tile_major"),
+            full = ((args.workload, "tile_major@plain"), ("parquet_sigma4", "tile_major"), ("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "tile_major"),
                     ("parquet_sigma4_insdyn", "tile_major"), ("parquet_sigma4_taylor2", "tile_major"), ("parquet_sigma4_taylor2", "leaf_major"), ("parquet_sigma4_taylor2", "tile_major+fma"),
                     ("parquet_sigma5", "tile_major"), ("parquet_ver4_4", "tile_major"), ("gv_ver4_4", "tile_major"), ("gv_ver4_4", "leaf_major"), ("sigma2", "tile_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "tile_major"),
                     ("gv_sigma5", "tile_major"), ("gv_sigma5", "leaf_major"), ("gv_sigma5", "tile_major+fma"),
@@ -684,6 +716,8 @@ def main():
             for wl, lay in (tuple(tuple(x.split(":")) for x in args.secondary.split(",")) if args.secondary else full):
                 # (the headline's own workload is measured once more as a secondary row when the headline ran another batch size: the
                 #  row-major row of parquet_sigma4 then has its leaf-major partner at the same 1.6e7 samples, in the same process)
+                if lay.endswith("@plain") and not (paired and wl in DEFAULT_B and 8 * DEFAULT_B[wl] * (t.n_leaf + t.n_root) < 0.45 * torch.cuda.mem_get_info(dev)[0]):
+                    continue            # (the plain-allocation partner of a paired headline only)
                 if (wl, lay) != head or (not args.secondary and wl == "parquet_sigma4" and B != 16_000_000):
                     sec.append(secondary_case(wl, lay, dev, copy_gbs=copy_gbs))
             out["secondary"] = sec
@@ -730,7 +764,9 @@ def compact_line(full):
                 "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock")
         line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:60]) for k in keep if k in roof}
         if roof.get("placement"):
-            line["roofline"]["placement"] = "single allocation"
+            pi = roof.get("placement_info")
+            line["roofline"]["placement"] = ("fdg_batch_alloc_pair, one batch: %d/%d windows at the fast level (%.3f)" % (pi["windows_at_fast_level"], pi["windows"], pi["pair_frac_best"])
+                                             if pi else "single allocation")
     cb = full.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
@@ -744,7 +780,7 @@ def compact_line(full):
                 rows.append([e.get("workload", "?")[:24], e.get("layout"), None, "error", None, None, None, None, False, None])
                 continue
             r = e["roofline"]
-            rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm", "tile_major": "tm", "tile_major+fma": "tm+fma", "leaf_major+fma": "lm+fma"}.get(e["layout"], e["layout"]), _r(e["value"] / 1e6),
+            rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm", "tile_major": "tm", "tile_major+fma": "tm+fma", "leaf_major+fma": "lm+fma", "tile_major@plain": "tm@plain"}.get(e["layout"], e["layout"]), _r(e["value"] / 1e6),
                          {"hbm": "hbm", "valu_fp64": "valu"}.get(r["bound"], r["bound"]), _r(r["frac"], 3), _r(r.get("frac_hbm"), 3),
                          _r(r.get("frac_valu"), 3), _r(r.get("traffic_over_algorithmic"), 3),
                          (e.get("gpu_matches_cpu_bitwise") if not e.get("contracted") else "fma:%.1e" % (e.get("max_dev_over_Sk") or 0.0)), _r(r.get("clock_ghz"), 3)])

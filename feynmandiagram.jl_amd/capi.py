@@ -39,7 +39,7 @@ EXPORTS = [
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
     "fdg_graph_kernel_info",
     "fdg_eval_device_tiled", "fdg_accumulate_device_tiled", "fdg_fill_uniform_device_tiled", "fdg_graph_set_association",
-    "fdg_batch_alloc", "fdg_batch_free", "fdg_graph_pool_program",
+    "fdg_batch_alloc", "fdg_batch_free", "fdg_graph_pool_program", "fdg_batch_alloc_pair",
 ]
 COMM_ID_BYTES = 128
 
@@ -106,6 +106,14 @@ MOP_DTYPE = np.dtype([("kind", "u1"), ("nega", "u1"), ("negb", "u1"), ("negc", "
 _lib = None
 
 
+class BatchPairInfo(C.Structure):
+    """fdg_batch_pair_info (include/fdg.h)"""
+    _fields_ = [("leaf_bytes", C.c_uint64), ("root_bytes", C.c_uint64), ("chunk_tiles", C.c_uint64), ("n_chunk", C.c_uint32),
+                ("n_candidate", C.c_uint32), ("n_filler", C.c_uint32), ("n_probe", C.c_uint32), ("n_matched", C.c_uint32),
+                ("calibrated", C.c_uint32), ("gbs_fast", C.c_double), ("gbs_slow", C.c_double), ("gbs_before_mean", C.c_double),
+                ("gbs_before_min", C.c_double), ("gbs_after_mean", C.c_double), ("gbs_after_min", C.c_double), ("seconds", C.c_double)]
+
+
 def lib():
     """Load libfdg.so once; fail loudly when the HIP extension is not built."""
     global _lib
@@ -146,6 +154,7 @@ def lib():
     L.fdg_graph_set_association.argtypes = [vp, C.c_int]
     L.fdg_batch_alloc.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.fdg_batch_free.argtypes = [vp]
+    L.fdg_batch_alloc_pair.argtypes = [vp, C.c_int64, C.c_size_t, C.c_uint, C.POINTER(vp), C.POINTER(vp), C.POINTER(BatchPairInfo)]
     L.fdg_eval_device_tiled.argtypes = [vp, dp, i64, i64, i64, dp, i64, i64, i64, i64, vp]
     L.fdg_accumulate_device_tiled.argtypes = [vp, dp, i64, i64, i64, dp, dp, i64, vp]
     L.fdg_fill_uniform_device_tiled.argtypes = [dp, i64, u32, i64, i64, i64, u64, u64, vp]
@@ -412,6 +421,17 @@ def batch_alloc(n_bytes: int, chunk_bytes: int = 0) -> int:
 
 def batch_free(ptr: int):
     check(lib().fdg_batch_free(ptr))
+
+
+BATCH_PAIR_CALIBRATE = 1
+
+
+def batch_alloc_pair(handle: "GraphHandle", n_sample: int, chunk_bytes: int = 0, calibrate: bool = True, verbose: bool = False):
+    """fdg_batch_alloc_pair: device addresses (leaf, root) of a tile-major batch of ``handle`` whose root chunks were chosen by timing the
+    handle's evaluator on (leaf chunk, root chunk) pairs, and the report as a dict.  Release both with :func:`batch_free`."""
+    pl, pr, info = C.c_void_p(), C.c_void_p(), BatchPairInfo()
+    check(lib().fdg_batch_alloc_pair(handle.ptr, n_sample, chunk_bytes, (BATCH_PAIR_CALIBRATE if calibrate else 0) | (2 if verbose else 0), C.byref(pl), C.byref(pr), C.byref(info)))
+    return int(pl.value), int(pr.value), {k: getattr(info, k) for k, _ in BatchPairInfo._fields_}
 
 
 def isa_check_hazards(asm_text: str):

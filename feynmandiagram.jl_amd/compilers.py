@@ -170,6 +170,13 @@ class GraphFunc:
         import torch
         return torch.empty(((n_sample + 63) // 64, n_col, 64), dtype=dtype or torch.float64, device=device)
 
+    def tile_major_pair(self, n_sample: int, device, calibrate: bool = True, chunk_bytes: int = 0, verbose: bool = False) -> "PairedBatch":
+        """The leaf and root arrays of a tile-major batch of this function, allocated by the library so that every part of the leaves
+        streams next to its part of the roots at the fast rate (``fdg_batch_alloc_pair``: the root chunks are chosen by timing this
+        function's own kernel on (leaf window, root chunk) pairs).  ``.leaf`` / ``.root`` are ``[cld(B, 64), L | R, 64]`` tensors viewing
+        library-owned memory; call ``.free()`` (or drop the object) when done."""
+        return PairedBatch(self, n_sample, device, calibrate, chunk_bytes, verbose)
+
     def _check_tiled(self, x, n_col, what):
         import torch
         if not (_is_torch(x) and x.is_cuda and x.dtype == torch.float64 and x.dim() == 3 and x.shape[2] == 64 and x.shape[1] >= n_col):
@@ -343,3 +350,54 @@ def compile_Python(graphs, filename: str, root=None, func_name: str = "eval_grap
     s, leafmap = to_python_str(graphs, root=root, name=func_name)
     _append(filename, s)
     return leafmap
+
+
+class _DeviceView:
+    """A device address as something ``torch.as_tensor`` can wrap without copying (CUDA array interface v2)."""
+
+    def __init__(self, ptr: int, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class PairedBatch:
+    """``GraphFunc.tile_major_pair``: tile-major leaves and roots backed by ``fdg_batch_alloc_pair`` (include/fdg.h)."""
+
+    def __init__(self, func, n_sample, device, calibrate=True, chunk_bytes=0, verbose=False):
+        import torch
+        device = torch.device(device)
+        if func.handle is None or device.type != "cuda":
+            raise capi.FdgError(capi.FDG_E_UNSUPPORTED, "tile_major_pair needs a device handle specialised with the ISA back end and a CUDA device")
+        L, R = func.n_leaf, func.n_root
+        self.n_sample = int(n_sample)
+        with torch.cuda.device(device):
+            self._lp, self._rp, self.info = capi.batch_alloc_pair(func.handle, self.n_sample, chunk_bytes, calibrate, verbose)
+            T = (self.n_sample + 63) // 64
+            self.leaf = torch.as_tensor(_DeviceView(self._lp, (self.info["leaf_bytes"] // (512 * L), L, 64)), device=device)[:T]
+            self.root = torch.as_tensor(_DeviceView(self._rp, (self.info["root_bytes"] // (512 * R), R, 64)), device=device)[:T]
+        if self.leaf.data_ptr() != self._lp or self.root.data_ptr() != self._rp:
+            self.free()
+            raise capi.FdgError(capi.FDG_E_INTERNAL, "torch copied the library's batch instead of viewing it")
+        self._device = device
+
+    def free(self):
+        import torch
+        lp, rp = getattr(self, "_lp", 0), getattr(self, "_rp", 0)
+        self._lp = self._rp = 0
+        self.leaf = self.root = None
+        if lp or rp:
+            with torch.cuda.device(self._device) if hasattr(self, "_device") else _nullcontext():
+                if lp:
+                    capi.batch_free(lp)
+                if rp:
+                    capi.batch_free(rp)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _nullcontext:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False

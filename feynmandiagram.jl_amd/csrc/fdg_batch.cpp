@@ -5,6 +5,11 @@
 // the call; this allocator builds the batch explicitly through the virtual-memory-management API -- one reserved address range,
 // physical chunks of a stated size created and mapped in address order -- so that the backing is a property of the request and
 // not of the process's allocation history.  The reference has no counterpart (its leaf vector is a Julia Vector).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -54,7 +59,11 @@ int fdg_batch_alloc(size_t bytes, size_t chunk_bytes, void **d_ptr) {
   chunk = (chunk + gran_rec - 1) / gran_rec * gran_rec;
   const size_t total = (bytes + chunk - 1) / chunk * chunk;
   void *base = nullptr;
-  e = hipMemAddressReserve(&base, total, (size_t)1 << 30 > chunk ? chunk : (size_t)1 << 30, nullptr, 0);
+  // alignment: the largest power of two that divides the chunk size (at least the granularity, at most 1 GiB) -- a chunk of 6 MB is not a
+  // valid alignment itself
+  size_t align = chunk & (~chunk + 1);
+  if (align > ((size_t)1 << 30)) align = (size_t)1 << 30;
+  e = hipMemAddressReserve(&base, total, align, nullptr, 0);
   if (e != hipSuccess) return fail("hipMemAddressReserve", e);
   Batch b;
   b.bytes = total; b.chunk = chunk; b.device = dev;
@@ -96,12 +105,315 @@ int fdg_batch_free(void *d_ptr) {
   }
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return fail("hipDeviceSynchronize", e);
+  if (b.chunk == 0) {            // the leaves of fdg_batch_alloc_pair: a plain allocation
+    e = hipFree(d_ptr);
+    return e == hipSuccess ? FDG_OK : fail("hipFree", e);
+  }
   for (size_t i = 0; i < b.handles.size(); ++i) {
     (void)hipMemUnmap((char *)d_ptr + i * b.chunk, b.chunk);
     (void)hipMemRelease(b.handles[i]);
   }
   e = hipMemAddressFree(d_ptr, b.bytes);
   if (e != hipSuccess) return fail("hipMemAddressFree", e);
+  return FDG_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// fdg_batch_alloc_pair: the tile-major leaf and root arrays of one handle, backed chunk by chunk so that every chunk of leaves streams
+// next to ITS chunk of roots at the fast rate (round 5).
+//
+// What round 5 measured (profiles/r05_log_chunk_probe.txt, r05_log_pair_probe.txt, r05_log_pair_matrix.txt): the rate of the evaluation
+// over a piece of the batch is a stable, LOCAL property of the physical pages under that piece -- and a PAIRWISE one: device memory falls
+// into regions of two kinds (gigabytes each), and reading leaves of one kind while writing roots of the same kind runs at 0.75-0.77 of
+// 8 TB/s where the other combination runs at 0.85-0.86 (fused accumulation, which writes nothing: 0.89 everywhere).  hipMalloc hands out
+// whatever regions it has, so a 70 GB batch is a patchwork of matched and mismatched pieces: the "allocation lottery" of rounds 3-4.
+// Physical addresses are not visible to a process, but the rate is: this allocator maps the leaves in chunks, draws more root chunks
+// than it needs, TIMES the handle's own evaluator on (leaf chunk, root chunk) pairs, and maps behind every leaf chunk a root chunk that
+// gives the fast rate.
+namespace {
+struct PairCtx {
+  fdg_graph *g = nullptr;
+  uint32_t L = 0, R = 0;
+  size_t chunk_tiles = 0, leaf_chunk = 0, root_chunk = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint32_t n_probe = 0;
+  // algorithmic GB/s of the handle's evaluation over one chunk: leaves at `leaf`, roots at `root` (min of `reps` launches after one warm-up)
+  int probe(const void *leaf, void *root, double &gbs, int reps = 4) {
+    const int64_t n = (int64_t)chunk_tiles * 64;
+    float best = 0.f;
+    for (int r = 0; r <= reps; ++r) {
+      if (hipEventRecord(ev0, nullptr) != hipSuccess) return FDG_E_NO_DEVICE;
+      const int rc = fdg_eval_device_tiled(g, (const double *)leaf, 1, 64, 64 * (int64_t)L, (double *)root, 1, 64, 64 * (int64_t)R, n, nullptr);
+      if (rc) return rc;
+      if (hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess) return FDG_E_NO_DEVICE;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) return FDG_E_NO_DEVICE;
+      if (r > 0 && (best == 0.f || ms < best)) best = ms;
+    }
+    ++n_probe;
+    gbs = best > 0.f ? 8.0 * (double)(L + R) * (double)n / ((double)best * 1e6) : 0.0;
+    return FDG_OK;
+  }
+};
+size_t gcd_sz(size_t a, size_t b) { while (b) { const size_t t = a % b; a = b; b = t; } return a; }
+}  // namespace
+
+int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint, unsigned flags, void **d_leaf, void **d_root,
+                         fdg_batch_pair_info *info) {
+  if (!g || !d_leaf || !d_root) { fdg::set_error("null argument"); return FDG_E_INVALID; }
+  *d_leaf = *d_root = nullptr;
+  if (info) std::memset(info, 0, sizeof *info);
+  if (n_sample <= 0) { fdg::set_error("empty batch"); return FDG_E_INVALID; }
+  const uint32_t L = g->prog.L, R = g->prog.R;
+  if (L == 0 || R == 0) { fdg::set_error("fdg_batch_alloc_pair: the graph has no leaves or no roots"); return FDG_E_INVALID; }
+  if (!(g->isa && !g->code_object.empty())) { fdg::set_error("fdg_batch_alloc_pair: tile-major batches need a handle specialised with FDG_SPEC_ISA"); return FDG_E_UNSUPPORTED; }
+  const auto t_start = std::chrono::steady_clock::now();
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail("hipGetDevice", e);
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+  if (e != hipSuccess || gran == 0) { e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum); if (e != hipSuccess) return fail("hipMemGetAllocationGranularity", e); }
+  if (gran == 0) gran = (size_t)1 << 21;
+  // The LEAVES are one plain allocation (large physically contiguous pieces: what streams fastest, and what the driver gives a hipMalloc of
+  // tens of GB; 1 GB physical chunks mapped one by one lose 5 % of the pure read rate, profiles/r05_log_pair_alloc_v1_vmm_leaves.txt); a
+  // "chunk" of leaves is a window of it.  The ROOTS are mapped chunk by chunk: a chunk holds the roots of the tiles of one leaf window and
+  // is a whole number of mapping granules.
+  const size_t lt = 512u * (size_t)L, rt = 512u * (size_t)R;                 // bytes of one tile
+  const size_t unit = gran / gcd_sz(gran, rt);                                // tiles per root granule
+  const size_t T = (size_t)((n_sample + 63) / 64);
+  const size_t hint = chunk_bytes_hint ? chunk_bytes_hint : ((size_t)2 << 30);
+  size_t k = std::max<size_t>(1, (hint + unit * lt / 2) / (unit * lt));
+  k = std::min(k, std::max<size_t>(1, (T + unit - 1) / unit));               // a small batch: one chunk
+  const size_t chunk_tiles = unit * k, leaf_chunk = chunk_tiles * lt, root_chunk = chunk_tiles * rt;
+  const size_t n_chunk = (T + chunk_tiles - 1) / chunk_tiles;
+  // (a window of less than ~0.5 GB of leaves is evaluated in too short a launch for the two levels to separate: nothing to calibrate on)
+  const bool calibrate = (flags & FDG_BATCH_PAIR_CALIBRATE) && leaf_chunk >= ((size_t)400 << 20);
+
+  struct Phys { hipMemGenericAllocationHandle_t h; bool mapped = false; int kind = -1; bool used = false; };
+  std::vector<Phys> cand, filler;
+  std::vector<int> pick(n_chunk, -1);
+  std::vector<char> root_mapped(n_chunk, 0);
+  const size_t max_cand = 8 * n_chunk + 64;
+  char *leaf_va = nullptr, *root_va = nullptr, *cand_va = nullptr;
+  hipMemAccessDesc acc = {};
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = dev;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  PairCtx cx;
+  cx.g = g; cx.L = L; cx.R = R; cx.chunk_tiles = chunk_tiles; cx.leaf_chunk = leaf_chunk; cx.root_chunk = root_chunk;
+
+  auto unmap_cand = [&](size_t j) { if (cand[j].mapped) { (void)hipMemUnmap(cand_va + j * root_chunk, root_chunk); cand[j].mapped = false; } };
+  auto cleanup_fail = [&]() {
+    (void)hipDeviceSynchronize();
+    for (size_t i = 0; i < n_chunk; ++i) if (root_mapped[i]) (void)hipMemUnmap(root_va + i * root_chunk, root_chunk);
+    for (size_t j = 0; j < cand.size(); ++j) { unmap_cand(j); (void)hipMemRelease(cand[j].h); }
+    for (Phys &f : filler) (void)hipMemRelease(f.h);
+    if (leaf_va) (void)hipFree(leaf_va);
+    if (root_va) (void)hipMemAddressFree(root_va, n_chunk * root_chunk);
+    if (cand_va) (void)hipMemAddressFree(cand_va, max_cand * root_chunk);
+    if (cx.ev0) (void)hipEventDestroy(cx.ev0);
+    if (cx.ev1) (void)hipEventDestroy(cx.ev1);
+  };
+#define PAIR_TRY(what, expr) do { e = (expr); if (e != hipSuccess) { cleanup_fail(); return fail(what, e); } } while (0)
+  PAIR_TRY("hipMemAddressReserve(roots)", hipMemAddressReserve((void **)&root_va, n_chunk * root_chunk, gran, nullptr, 0));
+  PAIR_TRY("hipMemAddressReserve(root candidates)", hipMemAddressReserve((void **)&cand_va, max_cand * root_chunk, gran, nullptr, 0));
+  PAIR_TRY("hipEventCreate", hipEventCreate(&cx.ev0));
+  PAIR_TRY("hipEventCreate", hipEventCreate(&cx.ev1));
+  auto new_cand = [&]() -> hipError_t {
+    if (cand.size() >= max_cand) return hipErrorOutOfMemory;
+    Phys c;
+    hipError_t ee = hipMemCreate(&c.h, root_chunk, &prop, 0);
+    if (ee != hipSuccess) return ee;
+    const size_t j = cand.size();
+    ee = hipMemMap(cand_va + j * root_chunk, root_chunk, 0, c.h, 0);
+    if (ee != hipSuccess) { (void)hipMemRelease(c.h); return ee; }
+    ee = hipMemSetAccess(cand_va + j * root_chunk, root_chunk, &acc, 1);
+    if (ee != hipSuccess) { (void)hipMemUnmap(cand_va + j * root_chunk, root_chunk); (void)hipMemRelease(c.h); return ee; }
+    c.mapped = true;
+    cand.push_back(c);
+    return hipSuccess;
+  };
+  // a 2 GB filler: moves the driver's allocator on to other regions of the memory (`reserve`: what must stay free besides)
+  const size_t filler_bytes = ((((size_t)2 << 30) + gran - 1) / gran) * gran;
+  auto new_filler = [&](size_t reserve) -> bool {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < filler_bytes + reserve + ((size_t)8 << 30)) return false;
+    Phys f;
+    if (hipMemCreate(&f.h, filler_bytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    filler.push_back(f);
+    return true;
+  };
+  size_t n_filler_total = 0;
+  if (calibrate) {
+    // Root candidates from everywhere the leaves can come from, and beyond: a candidate pair after every 2 GB filler over a span of the batch's
+    // size (at least 64 GB: the kinds of memory alternate in runs of 16-32 GB, profiles/r05_log_chunk_probe.txt) -- then the fillers go back
+    // to the driver and the leaves are allocated into the space they held.
+    const size_t span = std::max<size_t>(n_chunk * leaf_chunk, (size_t)64 << 30) + ((size_t)16 << 30);
+    for (size_t q = 0; q * filler_bytes < span && cand.size() + 2 <= max_cand / 2; ++q) {
+      if (!new_filler(0)) break;
+      PAIR_TRY("hipMemCreate(root candidate)", new_cand());
+      PAIR_TRY("hipMemCreate(root candidate)", new_cand());
+    }
+    n_filler_total = filler.size();
+    for (Phys &f : filler) (void)hipMemRelease(f.h);
+    filler.clear();
+  }
+  while (cand.size() < n_chunk) PAIR_TRY("hipMemCreate(root candidate)", new_cand());
+  PAIR_TRY("hipMalloc(leaves)", hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk));
+  double fast = 0, slow = 0, thr = 0;
+  bool have_contrast = false;
+  std::vector<double> before(n_chunk, 0.0);
+  int rc = FDG_OK;
+#define PROBE(li, cj, out) do { rc = cx.probe(leaf_va + (size_t)(li) * leaf_chunk, cand_va + (size_t)(cj) * root_chunk, out); if (rc) { cleanup_fail(); return rc; } } while (0)
+  size_t n_full_scan = 0;
+  if (calibrate) {
+    // the probes must see what the workload will see: uniform random leaves (a window of zeros or of stale data runs at another clock
+    // and another rate than its neighbours: profiles/r05_log_pair_alloc_v3.txt, rounds 1-2)
+    rc = fdg_fill_uniform_device_tiled((double *)leaf_va, (int64_t)(n_chunk * chunk_tiles) * 64, L, 1, 64, 64 * (int64_t)L, 20240612u, 0, nullptr);
+    if (rc) { cleanup_fail(); return rc; }
+    // the pairs an uncalibrated mapping would make (chunk i with the i-th candidate drawn)
+    for (size_t i = 0; i < n_chunk; ++i) PROBE(i, i, before[i]);
+    // Nothing is assumed about how many kinds of memory there are or how they interact (measured: the rate of a pair takes three levels, as
+    // if a region carried two bits and every bit in which leaves and roots DIFFER bought 5 %; attempts to infer classes from a few reference
+    // probes were at the mercy of the probes' noise: profiles/r05_log_pair_alloc_v[2-5].txt).  PAIRS are measured: a window tries the unused
+    // candidates that ran fastest behind the previous window (neighbouring windows mostly lie in one region), and when three of them
+    // disappoint it times every unused candidate; when even the best of those is below the fast level, more candidates are drawn -- a
+    // leaf-sized filler first, to move the driver on to other regions -- until the budget is spent.
+    std::vector<double> pred;                       // per candidate: its rate in the most recent probe (behind whatever window that was)
+    std::vector<double> got(n_chunk, 0.0);
+    const double rel = 0.965;                       // "at the fast level": within 3.5 % of the best pair seen so far
+    const size_t filler_budget = (size_t)96 << 30;
+    auto probe_pair = [&](size_t i, size_t j, double &r) -> int {
+      const int prc = cx.probe(leaf_va + i * leaf_chunk, cand_va + j * root_chunk, r);
+      if (prc) return prc;
+      if (pred.size() < cand.size()) pred.resize(cand.size(), 0.0);
+      pred[j] = r;
+      fast = std::max(fast, r);
+      slow = slow == 0 ? r : std::min(slow, r);
+      return FDG_OK;
+    };
+    auto full_scan = [&](size_t i, size_t from, int &bj, double &br) -> int {
+      for (size_t j = from; j < cand.size(); ++j) {
+        if (cand[j].used) continue;
+        double r; const int prc = probe_pair(i, j, r); if (prc) return prc;
+        if (r > br) { br = r; bj = (int)j; }
+      }
+      return FDG_OK;
+    };
+    auto place = [&](size_t i) -> int {
+      pred.resize(cand.size(), 0.0);
+      std::vector<size_t> order;
+      for (size_t j = 0; j < cand.size(); ++j) if (!cand[j].used && pred[j] > 0) order.push_back(j);
+      std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return pred[x] > pred[y]; });
+      int bj = -1; double br = 0;
+      for (size_t q = 0; q < std::min<size_t>(order.size(), 3); ++q) {
+        double r; const int prc = probe_pair(i, order[q], r); if (prc) return prc;
+        if (r > br) { br = r; bj = (int)order[q]; }
+        if (r >= rel * fast) break;
+      }
+      if (!(bj >= 0 && br >= rel * fast)) {
+        ++n_full_scan;
+        int prc = full_scan(i, 0, bj, br); if (prc) return prc;
+        while (br < rel * fast && filler.size() * filler_bytes < filler_budget && cand.size() + 2 <= max_cand) {
+          if (!new_filler((size_t)8 << 30)) break;
+          const size_t from = cand.size();
+          bool ok = true;
+          for (int c = 0; c < 2 && ok; ++c) ok = new_cand() == hipSuccess;
+          if (!ok) { (void)hipGetLastError(); break; }
+          pred.resize(cand.size(), 0.0);
+          prc = full_scan(i, from, bj, br); if (prc) return prc;
+        }
+      }
+      if (bj >= 0) { pick[i] = bj; cand[(size_t)bj].used = true; got[i] = br; }
+      return FDG_OK;
+    };
+    for (size_t i = 0; i < n_chunk; ++i) { rc = place(i); if (rc) { cleanup_fail(); return rc; } }
+    // second pass: the level rose while the search went on -- windows that were content with less look again
+    for (size_t i = 0; i < n_chunk; ++i) {
+      if (pick[i] < 0 || got[i] >= rel * fast) continue;
+      int bj = -1; double br = got[i];
+      ++n_full_scan;
+      rc = full_scan(i, 0, bj, br); if (rc) { cleanup_fail(); return rc; }
+      if (bj >= 0 && br > 1.01 * got[i]) { cand[(size_t)pick[i]].used = false; pick[i] = bj; cand[(size_t)bj].used = true; got[i] = br; }
+    }
+    have_contrast = fast > 1.05 * slow;
+    thr = rel * fast;
+  }
+  if (flags & FDG_BATCH_PAIR_VERBOSE)
+    std::fprintf(stderr, "[fdg_batch_alloc_pair] best / worst pair seen %.0f / %.0f GB/s, fast level from %.0f; %zu windows, %zu candidates, %zu fillers, %zu full scans, %u probes\n",
+                 fast, slow, thr, n_chunk, cand.size(), filler.size(), n_full_scan, cx.n_probe);
+  // chunks without a matched partner (calibration off, no contrast found, a window of neither class, or candidates of its kind ran out)
+  {
+    size_t j = 0;
+    for (size_t i = 0; i < n_chunk; ++i) {
+      if (pick[i] >= 0) continue;
+      while (j < cand.size() && cand[j].used) ++j;
+      if (j >= cand.size()) { PAIR_TRY("hipMemCreate(root chunk)", new_cand()); }
+      pick[i] = (int)j; cand[j].used = true;
+    }
+  }
+  // final mapping: the chosen candidates behind their leaf windows; everything else goes back to the driver
+  PAIR_TRY("hipDeviceSynchronize", hipDeviceSynchronize());
+  for (size_t j = 0; j < cand.size(); ++j) unmap_cand(j);
+  for (size_t i = 0; i < n_chunk; ++i) {
+    PAIR_TRY("hipMemMap(roots)", hipMemMap(root_va + i * root_chunk, root_chunk, 0, cand[(size_t)pick[i]].h, 0));
+    root_mapped[i] = 1;
+  }
+  PAIR_TRY("hipMemSetAccess(roots)", hipMemSetAccess(root_va, n_chunk * root_chunk, &acc, 1));
+  for (size_t j = 0; j < cand.size(); ++j) if (!cand[j].used) (void)hipMemRelease(cand[j].h);
+  for (Phys &f : filler) (void)hipMemRelease(f.h);
+  const size_t n_filler = filler.size() + n_filler_total;
+  filler.clear();
+  (void)hipMemAddressFree(cand_va, max_cand * root_chunk);
+  cand_va = nullptr;
+  double after_mean = 0, after_min = 0, before_mean = 0, before_min = 0;
+  uint32_t n_matched = 0;
+  if (calibrate) {
+    for (size_t i = 0; i < n_chunk; ++i) {
+      double r = 0;
+      rc = cx.probe(leaf_va + i * leaf_chunk, root_va + i * root_chunk, r);
+      if (rc) break;
+      after_mean += r / (double)n_chunk; after_min = (i == 0 || r < after_min) ? r : after_min;
+      before_mean += before[i] / (double)n_chunk; before_min = (i == 0 || before[i] < before_min) ? before[i] : before_min;
+      if (r >= 0.95 * fast) ++n_matched;
+      if (flags & FDG_BATCH_PAIR_VERBOSE) std::fprintf(stderr, "%s%.0f", i ? " " : "[fdg_batch_alloc_pair] pairs as mapped, GB/s: ", r);
+    }
+    if (flags & FDG_BATCH_PAIR_VERBOSE) std::fputc('\n', stderr);
+  }
+  (void)hipEventDestroy(cx.ev0); (void)hipEventDestroy(cx.ev1);
+  cx.ev0 = cx.ev1 = nullptr;
+  if (rc) {   // (a probe failed after the final mapping: undo it)
+    (void)hipDeviceSynchronize();
+    for (size_t i = 0; i < n_chunk; ++i) { (void)hipMemUnmap(root_va + i * root_chunk, root_chunk); (void)hipMemRelease(cand[(size_t)pick[i]].h); }
+    (void)hipFree(leaf_va); (void)hipMemAddressFree(root_va, n_chunk * root_chunk);
+    return rc;
+  }
+#undef PROBE
+#undef PAIR_TRY
+  {
+    Batch bl, br;
+    bl.bytes = n_chunk * leaf_chunk; bl.chunk = 0; bl.device = dev;          // chunk 0: a plain allocation (hipFree)
+    br.bytes = n_chunk * root_chunk; br.chunk = root_chunk; br.device = dev;
+    for (size_t i = 0; i < n_chunk; ++i) br.handles.push_back(cand[(size_t)pick[i]].h);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_batches[leaf_va] = std::move(bl);
+    g_batches[root_va] = std::move(br);
+  }
+  *d_leaf = leaf_va; *d_root = root_va;
+  if (info) {
+    info->leaf_bytes = n_chunk * leaf_chunk; info->root_bytes = n_chunk * root_chunk; info->chunk_tiles = chunk_tiles;
+    info->n_chunk = (uint32_t)n_chunk; info->n_candidate = (uint32_t)cand.size(); info->n_filler = (uint32_t)n_filler; info->n_probe = cx.n_probe;
+    info->n_matched = n_matched; info->calibrated = have_contrast ? 1u : 0u;
+    info->gbs_fast = fast; info->gbs_slow = slow;
+    info->gbs_before_mean = before_mean; info->gbs_before_min = before_min; info->gbs_after_mean = after_mean; info->gbs_after_min = after_min;
+    info->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  }
   return FDG_OK;
 }
 

@@ -105,6 +105,7 @@ struct fdg_graph {
   // device state (guarded by mu)
   std::mutex mu;
   void *d_code = nullptr;          // interpreter stream
+  void *d_root_live = nullptr;     // uint8[R]: 0 where root_slot[k] == FDG_NO_ROOT (only allocated for such tables; root scratch paths skip those k)
   void *d_ws = nullptr;            // workspace panels + block partials
   size_t ws_bytes = 0;
   void *module = nullptr;          // hipModule_t

@@ -204,11 +204,15 @@ fdg_reduce_lane_partials(const double *__restrict__ partial, uint32_t nwave, uin
 // samples and a block sum per root before: the 180 block sums per block made this pass a third of the accumulation's time).
 __global__ void __launch_bounds__(256)
 fdg_weighted_partials(const double *__restrict__ root, long ld, const double *__restrict__ weight, long B, uint32_t R, uint32_t n_seg,
-                      double *__restrict__ partial) {
+                      double *__restrict__ partial, const uint8_t *__restrict__ live) {
   __shared__ double sh[256];
   const long seg_len = (((B + n_seg - 1) / n_seg) + 255) & ~255L;
   for (uint32_t id = blockIdx.x; id < R * n_seg; id += gridDim.x) {
     const uint32_t k = id % R, seg = id / R;             // neighbouring blocks: the same samples (and weights) of different roots
+    if (live && !live[k]) {                              // FDG_NO_ROOT: the evaluator never wrote this column of the scratch; acc[k] stays as it is
+      if (threadIdx.x == 0) partial[(size_t)seg * R + k] = 0.0;
+      continue;
+    }
     const double *rk = root + (size_t)k * (size_t)ld;
     const long b0 = (long)seg * seg_len, b1 = b0 + seg_len < B ? b0 + seg_len : B;
     double s = 0.0;
@@ -260,7 +264,8 @@ fdg_transpose_rows_wide(const double *__restrict__ src, long ss, double *__restr
 // dst[b * rs + k * rk] = src[k * ld + b]  for b < n, k < R: column-major root scratch -> the caller's (usually row-major) root matrix,
 // 64 x 32 tiles through LDS: 512-byte runs read along a root, 256-byte runs written along a row.
 __global__ void __launch_bounds__(256)
-fdg_transpose_from_leaf_major(const double *__restrict__ src, long ld, double *__restrict__ dst, long rs, long rk, long n, uint32_t R) {
+fdg_transpose_from_leaf_major(const double *__restrict__ src, long ld, double *__restrict__ dst, long rs, long rk, long n, uint32_t R,
+                              const uint8_t *__restrict__ live) {
   __shared__ double tile[32][65];
   const int t = threadIdx.x;
   const long ntile_s = (n + 63) / 64, ntile_k = (R + 31) / 32;
@@ -275,7 +280,7 @@ fdg_transpose_from_leaf_major(const double *__restrict__ src, long ld, double *_
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const long row = s0 + j * 8 + t / 32, k = k0 + t % 32;
-      if (row < n && k < (long)R) dst[row * rs + k * rk] = tile[t % 32][j * 8 + t / 32];
+      if (row < n && k < (long)R && (!live || live[k])) dst[row * rs + k * rk] = tile[t % 32][j * 8 + t / 32];   // FDG_NO_ROOT: root[k] left untouched (fdg.h)
     }
     __syncthreads();
   }
@@ -474,6 +479,25 @@ static int ensure_code(fdg_graph *g) {
   return FDG_OK;
 }
 
+// Device mask of the roots that exist (root_slot[k] != FDG_NO_ROOT), for the passes over the column-major root scratch: null when every root
+// exists.  (the scratch's columns of missing roots are never written by the evaluator; copying or summing them would overwrite
+// root[k] / add garbage to acc[k], which fdg.h promises to leave alone.)
+static int root_live_mask(fdg_graph *g, const uint8_t **out) {
+  *out = nullptr;
+  const Lowered &p = g->prog;
+  bool any = false;
+  for (uint32_t k = 0; k < p.R; ++k) any = any || p.root_slot[k] == FDG_NO_ROOT;
+  if (!any) return FDG_OK;
+  if (!g->d_root_live) {
+    std::vector<uint8_t> m(p.R);
+    for (uint32_t k = 0; k < p.R; ++k) m[k] = p.root_slot[k] != FDG_NO_ROOT;
+    HIP_TRY(hipMalloc(&g->d_root_live, p.R));
+    HIP_TRY(hipMemcpy(g->d_root_live, m.data(), p.R, hipMemcpyHostToDevice));
+  }
+  *out = (const uint8_t *)g->d_root_live;
+  return FDG_OK;
+}
+
 static int ensure_module(fdg_graph *g) {
   if (g->module || g->code_object.empty()) return FDG_OK;
   hipModule_t m;
@@ -584,6 +608,9 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       g->ws2_bytes = need;
     }
     double *scratch = (double *)g->d_ws2;
+    const uint8_t *live = nullptr;
+    rc = root_live_mask(g, &live);
+    if (rc) return rc;
     for (long c0 = 0; c0 < (long)B; c0 += Bc) {
       const long n = std::min<long>(Bc, (long)B - c0);
       const double *lf = lts ? d_leaf + (size_t)(c0 / 64) * (size_t)lts : d_leaf + (size_t)c0 * (size_t)ss;
@@ -591,7 +618,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       if (rc) return rc;
       const long ntile = ((n + 63) / 64) * ((R + 31) / 32);
       hipLaunchKernelGGL(fdg_transpose_from_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, st,
-                         scratch, Bc, d_root + (size_t)c0 * (size_t)rs, (long)rs, (long)rk, n, R);
+                         scratch, Bc, d_root + (size_t)c0 * (size_t)rs, (long)rs, (long)rk, n, R, live);
       HIP_TRY(hipGetLastError());
     }
     return FDG_OK;
@@ -742,7 +769,10 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     auto finish_scratch_acc = [&]() -> int {
       double *partial = roots + (size_t)a_rk * R;
       const uint32_t pb = weighted_segments((long)B, R);
-      hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb * R), dim3(256), 0, st, roots, a_rk, d_weight, (long)B, R, pb, partial);
+      const uint8_t *live = nullptr;
+      const int rcl = root_live_mask(g, &live);
+      if (rcl) return rcl;
+      hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb * R), dim3(256), 0, st, roots, a_rk, d_weight, (long)B, R, pb, partial, live);
       hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, pb, R, d_acc);
       HIP_TRY(hipGetLastError());
       return FDG_OK;
@@ -1180,6 +1210,7 @@ int fdg_graph_release_device(fdg_graph *g) {
   if (!g) return FDG_OK;
   std::lock_guard<std::mutex> lk(g->mu);
   if (g->d_code) { hipFree(g->d_code); g->d_code = nullptr; }
+  if (g->d_root_live) { hipFree(g->d_root_live); g->d_root_live = nullptr; }
   {
     fdg_ws_set cur;
     park_current_ws(g, cur);
@@ -2194,7 +2225,10 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
     rc = fdg_mc_isa_run(g, 0, d_K, ks, kc, d_T, ts, tc, kF, beta, lambda, roots, 1, ld, nullptr, nullptr, B, st);
     if (rc) return rc;
     const uint32_t pb = weighted_segments((long)B, R);
-    hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb * R), dim3(256), 0, st, roots, (long)ld, d_weight, (long)B, R, pb, partial);
+    const uint8_t *live = nullptr;
+    rc = root_live_mask(g, &live);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb * R), dim3(256), 0, st, roots, (long)ld, d_weight, (long)B, R, pb, partial, live);
     hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, pb, R, d_acc);
     HIP_TRY(hipGetLastError());
     return FDG_OK;

@@ -344,6 +344,37 @@ int fdg_fill_uniform_device_tiled(double *d_leaf, int64_t n_sample, uint32_t n_l
 int fdg_batch_alloc(size_t bytes, size_t chunk_bytes, void **d_ptr);
 int fdg_batch_free(void *d_ptr);
 
+/* The two arrays of a TILE-MAJOR batch of one handle -- leaves (64, L, T) and roots (64, R, T), T = cld(n_sample, 64), strides as in
+ * fdg_eval_device_tiled -- backed so that the evaluation streams at its fast rate over every part of the batch, whatever state the
+ * driver's allocator is in (round 5).  On MI355X the rate at which a piece of leaves is evaluated depends on the physical
+ * pages under that piece AND under the roots it writes: device memory falls into regions of two kinds, and reading one kind while writing
+ * the same kind runs 10-12 % slower than the mixed combination (fused accumulation, which writes no roots, does not care).  Physical
+ * addresses are invisible to a process; the rate is not.  With FDG_BATCH_PAIR_CALIBRATE the allocator maps the leaves in chunks of about
+ * chunk_bytes_hint (0: 1 GB; rounded so that a chunk holds whole tiles of both arrays in whole mapping granules), draws more root chunks
+ * than it needs, times the handle's own evaluator on (leaf chunk, root chunk) pairs -- about a millisecond per pair -- and maps behind every
+ * leaf chunk a root chunk that gives the fast rate; what it drew and did not use goes back to the driver.  Without the flag the chunks are
+ * mapped in the order they were drawn (the A/B case).  Both arrays hold whole chunks (>= the T tiles asked for); release each with
+ * fdg_batch_free.  `info` (may be NULL) reports what was found.  Needs a handle specialised with FDG_SPEC_ISA and the current device.
+ * No counterpart in the reference (its leaf vector and root vector are Julia Vectors on the host, static.jl:100,131). */
+#define FDG_BATCH_PAIR_CALIBRATE 1u
+#define FDG_BATCH_PAIR_VERBOSE 2u   /* the classes found, one line each, on stderr */
+typedef struct fdg_batch_pair_info {
+  uint64_t leaf_bytes, root_bytes;   /* mapped bytes of the two arrays */
+  uint64_t chunk_tiles;              /* 64-sample tiles per chunk */
+  uint32_t n_chunk;                  /* chunks per array */
+  uint32_t n_candidate;              /* root chunks drawn */
+  uint32_t n_filler;                 /* 2 GB allocations held for a while to make the driver hand out other regions (released) */
+  uint32_t n_probe;                  /* timed (leaf chunk, root chunk) pairs */
+  uint32_t n_matched;                /* chunk pairs within 5 % of the best pair timed, as mapped */
+  uint32_t calibrated;               /* 0: calibration off or no contrast between candidates found (nothing to choose) */
+  double gbs_fast, gbs_slow;         /* the two levels (algorithmic GB/s of one chunk's launch) between which the threshold was put */
+  double gbs_before_mean, gbs_before_min;   /* chunk pairs as an uncalibrated mapping would have made them */
+  double gbs_after_mean, gbs_after_min;     /* chunk pairs as mapped */
+  double seconds;                    /* wall time of the call */
+} fdg_batch_pair_info;
+int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint, unsigned flags, void **d_leaf, void **d_root,
+                         fdg_batch_pair_info *info);
+
 /* d_leaf[b*ss + i*ls] = U[0,1) from Philox4x32-10, key = seed, counter =
  * (sample_offset + b, i): independent of launch geometry and of how samples
  * are sharded over GPUs. */
