@@ -180,7 +180,7 @@ class Case:
         if self.layout == "tile_major" and self.placement == "paired":
             # the library's own allocator for a tile-major batch (fdg_batch_alloc_pair): every window of the leaves gets a chunk of roots
             # behind which the handle's kernel was MEASURED at the fast rate; a plain allocation is the "@plain" row
-            self.pair = self.f.tile_major_pair(B, dev, calibrate=True)
+            self.pair = self.f.tile_major_pair(B, dev, calibrate=True, extra_flags=int(os.environ.get("FDG_BENCH_PAIR_FLAGS", "0")))
             self.leaf, self.root = self.pair.leaf, self.pair.root
             self.root.zero_()
             capi.fill_uniform_device_tiled(self.leaf.data_ptr(), B, L, 1, 64, 64 * L, 1234, self.sample_offset, st)
@@ -641,7 +641,7 @@ def main():
                                                  "pair_frac_best": pi["gbs_fast"] / HBM_PEAK_GBS, "pair_frac_worst": pi["gbs_slow"] / HBM_PEAK_GBS,
                                                  "draw_order_pairs_frac_mean": pi["gbs_before_mean"] / HBM_PEAK_GBS, "draw_order_pairs_frac_min": pi["gbs_before_min"] / HBM_PEAK_GBS,
                                                  "mapped_pairs_frac_mean": pi["gbs_after_mean"] / HBM_PEAK_GBS, "mapped_pairs_frac_min": pi["gbs_after_min"] / HBM_PEAK_GBS,
-                                                 "seconds": pi["seconds"]}
+                                                 "seconds": pi["seconds"], "seconds_settling": pi["seconds_settling"]}
         else:
             out["roofline"]["placement"] = "single allocation, as it came from the allocator (no trials)"
         try:

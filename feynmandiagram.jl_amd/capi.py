@@ -111,7 +111,8 @@ class BatchPairInfo(C.Structure):
     _fields_ = [("leaf_bytes", C.c_uint64), ("root_bytes", C.c_uint64), ("chunk_tiles", C.c_uint64), ("n_chunk", C.c_uint32),
                 ("n_candidate", C.c_uint32), ("n_filler", C.c_uint32), ("n_probe", C.c_uint32), ("n_matched", C.c_uint32),
                 ("calibrated", C.c_uint32), ("gbs_fast", C.c_double), ("gbs_slow", C.c_double), ("gbs_before_mean", C.c_double),
-                ("gbs_before_min", C.c_double), ("gbs_after_mean", C.c_double), ("gbs_after_min", C.c_double), ("seconds", C.c_double)]
+                ("gbs_before_min", C.c_double), ("gbs_after_mean", C.c_double), ("gbs_after_min", C.c_double), ("seconds", C.c_double),
+                ("seconds_settling", C.c_double)]
 
 
 def lib():
@@ -426,11 +427,11 @@ def batch_free(ptr: int):
 BATCH_PAIR_CALIBRATE = 1
 
 
-def batch_alloc_pair(handle: "GraphHandle", n_sample: int, chunk_bytes: int = 0, calibrate: bool = True, verbose: bool = False):
+def batch_alloc_pair(handle: "GraphHandle", n_sample: int, chunk_bytes: int = 0, calibrate: bool = True, verbose: bool = False, extra_flags: int = 0):
     """fdg_batch_alloc_pair: device addresses (leaf, root) of a tile-major batch of ``handle`` whose root chunks were chosen by timing the
     handle's evaluator on (leaf chunk, root chunk) pairs, and the report as a dict.  Release both with :func:`batch_free`."""
     pl, pr, info = C.c_void_p(), C.c_void_p(), BatchPairInfo()
-    check(lib().fdg_batch_alloc_pair(handle.ptr, n_sample, chunk_bytes, (BATCH_PAIR_CALIBRATE if calibrate else 0) | (2 if verbose else 0), C.byref(pl), C.byref(pr), C.byref(info)))
+    check(lib().fdg_batch_alloc_pair(handle.ptr, n_sample, chunk_bytes, (BATCH_PAIR_CALIBRATE if calibrate else 0) | (2 if verbose else 0) | extra_flags, C.byref(pl), C.byref(pr), C.byref(info)))
     return int(pl.value), int(pr.value), {k: getattr(info, k) for k, _ in BatchPairInfo._fields_}
 
 

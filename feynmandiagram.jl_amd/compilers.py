@@ -170,12 +170,12 @@ class GraphFunc:
         import torch
         return torch.empty(((n_sample + 63) // 64, n_col, 64), dtype=dtype or torch.float64, device=device)
 
-    def tile_major_pair(self, n_sample: int, device, calibrate: bool = True, chunk_bytes: int = 0, verbose: bool = False) -> "PairedBatch":
+    def tile_major_pair(self, n_sample: int, device, calibrate: bool = True, chunk_bytes: int = 0, verbose: bool = False, extra_flags: int = 0) -> "PairedBatch":
         """The leaf and root arrays of a tile-major batch of this function, allocated by the library so that every part of the leaves
         streams next to its part of the roots at the fast rate (``fdg_batch_alloc_pair``: the root chunks are chosen by timing this
         function's own kernel on (leaf window, root chunk) pairs).  ``.leaf`` / ``.root`` are ``[cld(B, 64), L | R, 64]`` tensors viewing
         library-owned memory; call ``.free()`` (or drop the object) when done."""
-        return PairedBatch(self, n_sample, device, calibrate, chunk_bytes, verbose)
+        return PairedBatch(self, n_sample, device, calibrate, chunk_bytes, verbose, extra_flags)
 
     def _check_tiled(self, x, n_col, what):
         import torch
@@ -362,7 +362,7 @@ class _DeviceView:
 class PairedBatch:
     """``GraphFunc.tile_major_pair``: tile-major leaves and roots backed by ``fdg_batch_alloc_pair`` (include/fdg.h)."""
 
-    def __init__(self, func, n_sample, device, calibrate=True, chunk_bytes=0, verbose=False):
+    def __init__(self, func, n_sample, device, calibrate=True, chunk_bytes=0, verbose=False, extra_flags=0):
         import torch
         device = torch.device(device)
         if func.handle is None or device.type != "cuda":
@@ -370,7 +370,7 @@ class PairedBatch:
         L, R = func.n_leaf, func.n_root
         self.n_sample = int(n_sample)
         with torch.cuda.device(device):
-            self._lp, self._rp, self.info = capi.batch_alloc_pair(func.handle, self.n_sample, chunk_bytes, calibrate, verbose)
+            self._lp, self._rp, self.info = capi.batch_alloc_pair(func.handle, self.n_sample, chunk_bytes, calibrate, verbose, extra_flags)
             T = (self.n_sample + 63) // 64
             self.leaf = torch.as_tensor(_DeviceView(self._lp, (self.info["leaf_bytes"] // (512 * L), L, 64)), device=device)[:T]
             self.root = torch.as_tensor(_DeviceView(self._rp, (self.info["root_bytes"] // (512 * R), R, 64)), device=device)[:T]

@@ -13,6 +13,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -155,6 +156,39 @@ struct PairCtx {
     gbs = best > 0.f ? 8.0 * (double)(L + R) * (double)n / ((double)best * 1e6) : 0.0;
     return FDG_OK;
   }
+  // Wait until the device is quiet.  The driver wipes released memory in the background at 18-28 GB/s, and that write stream depresses every
+  // rate by 2-7 % while it lasts (profiles/r05_log_pair_alloc_settle.txt: 1-4.5 s after 30-90 GB were released, then the batch runs at its
+  // own rate).  First the time the wipe of `released` bytes takes at 16 GB/s, counted from `since`; then the fused accumulation over `n`
+  // samples of the leaves (read-only, ~10 ms for the headline batch) every 50 ms until eight in a row agree to 1.5 % (at most 6 s more).
+  int settle(const void *leaf, int64_t n, size_t released, std::chrono::steady_clock::time_point since, double *waited) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const double need = (double)released / 16e9 - std::chrono::duration<double>(t0 - since).count();
+    if (need > 0) std::this_thread::sleep_for(std::chrono::duration<double>(need));
+    double *d_acc = nullptr;
+    if (hipMalloc((void **)&d_acc, sizeof(double) * std::max<uint32_t>(R, 1)) != hipSuccess) return FDG_E_NOMEM;
+    (void)hipMemset(d_acc, 0, sizeof(double) * R);
+    const auto t1 = std::chrono::steady_clock::now();
+    double hist[8] = {0};
+    int rc = FDG_OK;
+    for (int k = 0;; ++k) {
+      if (hipEventRecord(ev0, nullptr) != hipSuccess) { rc = FDG_E_NO_DEVICE; break; }
+      rc = fdg_accumulate_device_tiled(g, (const double *)leaf, 1, 64, 64 * (int64_t)L, nullptr, d_acc, n, nullptr);
+      if (rc) break;
+      float ms = 0.f;
+      if (hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess || hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) { rc = FDG_E_NO_DEVICE; break; }
+      hist[k % 8] = ms > 0.f ? (double)n / (double)ms : 0.0;
+      if (k >= 7) {
+        double mx = 0, mn = 1e300;
+        for (double x : hist) { mx = std::max(mx, x); mn = std::min(mn, x); }
+        if (mn > 0.985 * mx) break;
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() > 6.0) break;
+      std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    }
+    if (waited) *waited += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    (void)hipFree(d_acc);
+    return rc;
+  }
 };
 size_t gcd_sz(size_t a, size_t b) { while (b) { const size_t t = a % b; a = b; b = t; } return a; }
 }  // namespace
@@ -250,32 +284,42 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
     return true;
   };
   size_t n_filler_total = 0;
+  auto t_released = std::chrono::steady_clock::now();
+  // Root candidates from a wide span of the memory: a candidate pair after every 2 GB filler over 80 GB -- the kinds of memory alternate in
+  // runs of 16-32 GB (profiles/r05_log_chunk_probe.txt), so every kind is among them.  The fillers go back to the driver BEFORE anything is
+  // timed: the driver wipes released memory in the background, and that write stream disturbs the evaluation for a second or so exactly as
+  // the root writes do (profiles/r05_log_pair_alloc_release.txt: the same mapped pairs 2-7 % slower right after 85 GB were released).
+  // Experiment switch (flag 4): the leaves before the sprinkle (pristine blocks) instead of into the space the fillers held.
+  const bool leaves_first = (flags & 4u) != 0;
+  if (leaves_first) PAIR_TRY("hipMalloc(leaves)", hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk));
   if (calibrate) {
-    // Root candidates from everywhere the leaves can come from, and beyond: a candidate pair after every 2 GB filler over a span of the batch's
-    // size (at least 64 GB: the kinds of memory alternate in runs of 16-32 GB, profiles/r05_log_chunk_probe.txt) -- then the fillers go back
-    // to the driver and the leaves are allocated into the space they held.
-    const size_t span = std::max<size_t>(n_chunk * leaf_chunk, (size_t)64 << 30) + ((size_t)16 << 30);
+    const size_t span = (size_t)80 << 30;
     for (size_t q = 0; q * filler_bytes < span && cand.size() + 2 <= max_cand / 2; ++q) {
-      if (!new_filler(0)) break;
+      if (!new_filler((size_t)16 << 30)) break;
       PAIR_TRY("hipMemCreate(root candidate)", new_cand());
       PAIR_TRY("hipMemCreate(root candidate)", new_cand());
     }
     n_filler_total = filler.size();
     for (Phys &f : filler) (void)hipMemRelease(f.h);
     filler.clear();
+    t_released = std::chrono::steady_clock::now();
   }
+  if (!leaves_first) PAIR_TRY("hipMalloc(leaves)", hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk));
   while (cand.size() < n_chunk) PAIR_TRY("hipMemCreate(root candidate)", new_cand());
-  PAIR_TRY("hipMalloc(leaves)", hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk));
   double fast = 0, slow = 0, thr = 0;
   bool have_contrast = false;
   std::vector<double> before(n_chunk, 0.0);
   int rc = FDG_OK;
 #define PROBE(li, cj, out) do { rc = cx.probe(leaf_va + (size_t)(li) * leaf_chunk, cand_va + (size_t)(cj) * root_chunk, out); if (rc) { cleanup_fail(); return rc; } } while (0)
   size_t n_full_scan = 0;
+  double settle_s = 0;
   if (calibrate) {
     // the probes must see what the workload will see: uniform random leaves (a window of zeros or of stale data runs at another clock
     // and another rate than its neighbours: profiles/r05_log_pair_alloc_v3.txt, rounds 1-2)
     rc = fdg_fill_uniform_device_tiled((double *)leaf_va, (int64_t)(n_chunk * chunk_tiles) * 64, L, 1, 64, 64 * (int64_t)L, 20240612u, 0, nullptr);
+    if (rc) { cleanup_fail(); return rc; }
+    // the fillers of the sprinkle were released a moment ago: wait until their wipe is over before anything is timed
+    rc = cx.settle(leaf_va, (int64_t)(n_chunk * chunk_tiles) * 64, n_filler_total * filler_bytes, t_released, &settle_s);
     if (rc) { cleanup_fail(); return rc; }
     // the pairs an uncalibrated mapping would make (chunk i with the i-th candidate drawn)
     for (size_t i = 0; i < n_chunk; ++i) PROBE(i, i, before[i]);
@@ -288,7 +332,7 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
     std::vector<double> pred;                       // per candidate: its rate in the most recent probe (behind whatever window that was)
     std::vector<double> got(n_chunk, 0.0);
     const double rel = 0.965;                       // "at the fast level": within 3.5 % of the best pair seen so far
-    const size_t filler_budget = (size_t)96 << 30;
+    const size_t filler_budget = (size_t)144 << 30;
     auto probe_pair = [&](size_t i, size_t j, double &r) -> int {
       const int prc = cx.probe(leaf_va + i * leaf_chunk, cand_va + j * root_chunk, r);
       if (prc) return prc;
@@ -344,6 +388,13 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
     }
     have_contrast = fast > 1.05 * slow;
     thr = rel * fast;
+    if (flags & FDG_BATCH_PAIR_VERBOSE) {
+      std::fprintf(stderr, "[fdg_batch_alloc_pair] pairs when chosen, GB/s:");
+      for (size_t i = 0; i < n_chunk; ++i) std::fprintf(stderr, " %.0f", got[i]);
+      std::fprintf(stderr, "\n[fdg_batch_alloc_pair] chosen candidate of each window:");
+      for (size_t i = 0; i < n_chunk; ++i) std::fprintf(stderr, " %d", pick[i]);
+      std::fputc('\n', stderr);
+    }
   }
   if (flags & FDG_BATCH_PAIR_VERBOSE)
     std::fprintf(stderr, "[fdg_batch_alloc_pair] best / worst pair seen %.0f / %.0f GB/s, fast level from %.0f; %zu windows, %zu candidates, %zu fillers, %zu full scans, %u probes\n",
@@ -364,14 +415,8 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
   for (size_t i = 0; i < n_chunk; ++i) {
     PAIR_TRY("hipMemMap(roots)", hipMemMap(root_va + i * root_chunk, root_chunk, 0, cand[(size_t)pick[i]].h, 0));
     root_mapped[i] = 1;
+    PAIR_TRY("hipMemSetAccess(roots)", hipMemSetAccess(root_va + i * root_chunk, root_chunk, &acc, 1));    // (chunk by chunk, as the candidates were when they were timed)
   }
-  PAIR_TRY("hipMemSetAccess(roots)", hipMemSetAccess(root_va, n_chunk * root_chunk, &acc, 1));
-  for (size_t j = 0; j < cand.size(); ++j) if (!cand[j].used) (void)hipMemRelease(cand[j].h);
-  for (Phys &f : filler) (void)hipMemRelease(f.h);
-  const size_t n_filler = filler.size() + n_filler_total;
-  filler.clear();
-  (void)hipMemAddressFree(cand_va, max_cand * root_chunk);
-  cand_va = nullptr;
   double after_mean = 0, after_min = 0, before_mean = 0, before_min = 0;
   uint32_t n_matched = 0;
   if (calibrate) {
@@ -386,6 +431,16 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
     }
     if (flags & FDG_BATCH_PAIR_VERBOSE) std::fputc('\n', stderr);
   }
+  // (timed before the release below: the wipe of what is released would disturb it)
+  size_t released_end = filler.size() * filler_bytes;
+  for (size_t j = 0; j < cand.size(); ++j) if (!cand[j].used) { (void)hipMemRelease(cand[j].h); released_end += root_chunk; }
+  for (Phys &f : filler) (void)hipMemRelease(f.h);
+  t_released = std::chrono::steady_clock::now();
+  const size_t n_filler = filler.size() + n_filler_total;
+  filler.clear();
+  (void)hipMemAddressFree(cand_va, max_cand * root_chunk);
+  cand_va = nullptr;
+  if (calibrate && !rc) rc = cx.settle(leaf_va, (int64_t)(n_chunk * chunk_tiles) * 64, released_end, t_released, &settle_s);    // the batch is handed over when the device is quiet again
   (void)hipEventDestroy(cx.ev0); (void)hipEventDestroy(cx.ev1);
   cx.ev0 = cx.ev1 = nullptr;
   if (rc) {   // (a probe failed after the final mapping: undo it)
@@ -413,6 +468,7 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
     info->gbs_fast = fast; info->gbs_slow = slow;
     info->gbs_before_mean = before_mean; info->gbs_before_min = before_min; info->gbs_after_mean = after_mean; info->gbs_after_min = after_min;
     info->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    info->seconds_settling = settle_s;
   }
   return FDG_OK;
 }

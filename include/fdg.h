@@ -371,6 +371,7 @@ typedef struct fdg_batch_pair_info {
   double gbs_before_mean, gbs_before_min;   /* chunk pairs as an uncalibrated mapping would have made them */
   double gbs_after_mean, gbs_after_min;     /* chunk pairs as mapped */
   double seconds;                    /* wall time of the call */
+  double seconds_settling;           /* ... of which: waiting for the driver's background wipe of released memory to end */
 } fdg_batch_pair_info;
 int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint, unsigned flags, void **d_leaf, void **d_root,
                          fdg_batch_pair_info *info);
