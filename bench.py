@@ -75,6 +75,15 @@ def sync():
         torch.cuda.synchronize()
 
 
+def settle_after_free(nbytes):
+    """The driver wipes released device memory in the background at 18-28 GB/s, and while that write stream lasts every kernel runs 2-7 % slower
+    (round 5: profiles/r05_log_pair_alloc_settle.txt).  A measurement that follows the release of a large batch waits for the wipe first."""
+    if not DRY and nbytes > (64 << 20):
+        import torch
+        torch.cuda.synchronize()
+        time.sleep(nbytes / 16e9 + 0.2)
+
+
 class Stamps:
     """n+1 time stamps on the launch stream: HIP events (torch.cuda.Event sees only torch's current stream -- the one
     the kernels are launched on), or host clocks in a dry run."""
@@ -198,6 +207,9 @@ class Case:
             self.leaf = torch.empty((L, B), dtype=torch.float64, device=dev).t()
             self.root = torch.empty((R, B), dtype=torch.float64, device=dev).t()
         capi.fill_uniform_device(self.leaf.data_ptr(), B, L, self.leaf.stride(0), self.leaf.stride(1), 1234, self.sample_offset, st)
+
+    def nbytes(self):
+        return 0 if DRY else 8 * (((self.B + 63) // 64) * 64) * (self.t.n_leaf + self.t.n_root)
 
     def free(self):
         self.leaf = self.root = None
@@ -396,8 +408,11 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
             out["contracted"] = True
             out["max_dev_over_Sk"] = dev_over_sk
             out["gpu_matches_cpu_bitwise"] = None if not ok else True      # (not a claim of this mode; BASELINE's bar is 1e-12 of S_k)
+        freed = c.nbytes()
+        c.free()
         del c
         torch.cuda.empty_cache()
+        settle_after_free(freed)
         return out
     except Exception as e:                      # secondary: never takes the headline line down
         return {"workload": workload, "layout": layout, "error": f"{type(e).__name__}: {e}"}
@@ -465,9 +480,12 @@ def config5(dev, rank, world, dist, comm, steps, warm):
                "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "roofline_rank0": roof,
                "observable": [float(x) for x in acc.cpu()],
                "layout": "tile_major", "what": "fdg_accumulate_device_tiled per step on the rank's shard (tile-major batch); one all-reduce of R doubles after the last step, inside the timed region"}
+        freed = c.nbytes()
+        c.free()
         del c, w
         if not DRY:
             torch.cuda.empty_cache()
+            settle_after_free(freed)
         return out
     except Exception as e:
         return {"workload": "gv_sigma5", "error": f"{type(e).__name__}: {e}"}
@@ -695,10 +713,12 @@ def main():
                 del wgt, accv
             except Exception as e:
                 out["accumulate"] = {"error": f"{type(e).__name__}: {e}"}
+    freed = case.nbytes() + (8 * B if not DRY else 0)
     case.free()
     del case, leaf, root, f, step
     if not DRY:
         torch.cuda.empty_cache()
+        settle_after_free(freed)
     # ---- after and outside the headline's timed region ---------------------------------------------------------
     if args.backend == "isa" and not args.no_secondary and not args.fast_math:
         # config 5 runs on every rank (its one collective needs them all); the rest on rank 0 at N = 1 only

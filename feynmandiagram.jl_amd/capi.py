@@ -39,7 +39,7 @@ EXPORTS = [
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
     "fdg_graph_kernel_info",
     "fdg_eval_device_tiled", "fdg_accumulate_device_tiled", "fdg_fill_uniform_device_tiled", "fdg_graph_set_association",
-    "fdg_batch_alloc", "fdg_batch_free", "fdg_graph_pool_program", "fdg_batch_alloc_pair",
+    "fdg_batch_alloc", "fdg_batch_free", "fdg_graph_pool_program", "fdg_batch_alloc_pair", "fdg_graph_set_option", "fdg_graph_get_option", "fdg_set_default_option", "fdg_get_default_option",
 ]
 COMM_ID_BYTES = 128
 
@@ -135,9 +135,6 @@ def lib():
         except ImportError:
             pass
     # the code objects and tuned parameters shipped with the package: a read-only secondary lookup (fdg_runtime.hip: read_cached)
-    ro = os.environ.get("FDG_CACHE_RO_DIR", "")
-    if KERNEL_CACHE not in ro.split(":"):
-        os.environ["FDG_CACHE_RO_DIR"] = (ro + ":" if ro else "") + KERNEL_CACHE
     L = C.CDLL(LIB_PATH)
     vp, i64, u64, u32, dp = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p
     L.fdg_last_error.restype = C.c_char_p
@@ -155,6 +152,12 @@ def lib():
     L.fdg_graph_set_association.argtypes = [vp, C.c_int]
     L.fdg_batch_alloc.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.fdg_batch_free.argtypes = [vp]
+    L.fdg_graph_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.fdg_graph_get_option.argtypes = [vp, C.c_char_p]
+    L.fdg_graph_get_option.restype = C.c_char_p
+    L.fdg_set_default_option.argtypes = [C.c_char_p, C.c_char_p]
+    L.fdg_get_default_option.argtypes = [C.c_char_p]
+    L.fdg_get_default_option.restype = C.c_char_p
     L.fdg_batch_alloc_pair.argtypes = [vp, C.c_int64, C.c_size_t, C.c_uint, C.POINTER(vp), C.POINTER(vp), C.POINTER(BatchPairInfo)]
     L.fdg_eval_device_tiled.argtypes = [vp, dp, i64, i64, i64, dp, i64, i64, i64, i64, vp]
     L.fdg_accumulate_device_tiled.argtypes = [vp, dp, i64, i64, i64, dp, dp, i64, vp]
@@ -189,6 +192,11 @@ def lib():
     L.fdg_powi.argtypes = [C.c_double, C.c_int32]
     L.fdg_powi.restype = C.c_double
     _lib = L
+    # the code objects and tuned parameters shipped with the package: a read-only secondary lookup (fdg_runtime.hip: read_cached), appended
+    # to what the environment names -- as a process default of the library, not by editing os.environ
+    ro = (L.fdg_get_default_option(b"FDG_CACHE_RO_DIR") or b"").decode()
+    if KERNEL_CACHE not in ro.split(":"):
+        L.fdg_set_default_option(b"FDG_CACHE_RO_DIR", ((ro + ":" if ro else "") + KERNEL_CACHE).encode())
     return L
 
 
@@ -228,6 +236,19 @@ class GraphHandle:
         v.table = complex_to_real(self.table)
         v._h = h
         return v
+
+    def set_option(self, name: str, value=None):
+        """fdg_graph_set_option: one option of this handle (``None`` removes it).  Options replace the FDG_* environment switches: the
+        library reads the environment once per process, for the supported names only."""
+        check(lib().fdg_graph_set_option(self._h, name.encode(), None if value is None else str(value).encode()))
+
+    def set_options(self, options):
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def get_option(self, name: str):
+        v = lib().fdg_graph_get_option(self._h, name.encode())
+        return None if v is None else v.decode()
 
     def set_association(self, assoc: int):
         """FDG_ASSOC_STATIC (the generated code, static.jl) or FDG_ASSOC_INTERP (eval!, eval.jl); before any specialisation."""
@@ -411,6 +432,17 @@ def fill_uniform_device(d_leaf: int, B: int, L: int, ss: int, ls: int, seed: int
 def fill_uniform_device_tiled(d_leaf: int, B: int, L: int, ss: int, ls: int, lts: int, seed: int, sample_offset: int = 0,
                                stream: int = 0):
     check(lib().fdg_fill_uniform_device_tiled(d_leaf, B, L, ss, ls, lts, seed, sample_offset, stream))
+
+
+def set_default_option(name: str, value=None):
+    """fdg_set_default_option: the option every handle created from now on starts with (``None`` removes it); also what the entry points
+    without a handle see.  The library does not look at ``os.environ`` after its first use."""
+    check(lib().fdg_set_default_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_default_option(name: str):
+    v = lib().fdg_get_default_option(name.encode())
+    return None if v is None else v.decode()
 
 
 def batch_alloc(n_bytes: int, chunk_bytes: int = 0) -> int:

@@ -41,10 +41,12 @@ class GraphFunc:
     """Callable evaluator bound to one lowered graph set (one ``fdg_graph``)."""
 
     def __init__(self, table: NodeTable, specialize=False, cache_dir: Optional[str] = None,
-                 flags: int = 0, opt: Optional[dict] = None, association: str = "static"):
+                 flags: int = 0, opt: Optional[dict] = None, association: str = "static", options: Optional[dict] = None):
         """``specialize``: "auto" (ISA, else HIP source), "isa" / "isa-autotune" (optimizing back end,
         gfx950 assembly), True / "hip" (straight-line HIP source through hiprtc), False (table
         interpreter, no JIT).
+        ``options``: handle options set before anything is specialised (``fdg_graph_set_option``; what used to be FDG_* environment
+        switches: ``{"FDG_ISA_W2": "1"}``).
         ``association``: which of the reference's two evaluators the results equal bit for bit -- "static", the function
         ``Compilers.compile`` generates (static.jl:13-46), or "eval", the interpreter ``eval!`` the reference's examples and
         tests call (eval.jl:1-3,15-39; example/benchmark.jl:84-86), whose products fold the already scaled operands."""
@@ -54,6 +56,7 @@ class GraphFunc:
         self._specialize, self._cache_dir, self._flags = specialize, cache_dir, flags
         self.association = association
         self.handle = capi.GraphHandle(self.table)
+        self.handle.set_options(options)
         if association == "eval":
             self.handle.set_association(capi.FDG_ASSOC_INTERP)
         self.n_leaf, self.n_root = self.table.n_leaf, self.table.n_root

@@ -120,7 +120,7 @@ static void emit_node_expr(std::ostringstream &os, const Lowered &p, uint32_t n)
 // graph (Power{N}, N not 2 or 3) and the caller falls back to statement order.
 static bool emit_nodes_scheduled(std::ostringstream &os, const Lowered &p, const std::function<void(std::ostringstream &, uint32_t)> &load_leaf,
                                  const char *decl = "const double", bool keep_minus_one = false, bool mul_keeps_signs = false) {
-  if (std::getenv("FDG_HIP_TABLE_ORDER")) return false;
+  if (fdg::knob("FDG_HIP_TABLE_ORDER")) return false;
   std::vector<SchedOp> ops;
   uint32_t nv = 0;
   std::string why;

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/fdg.h"
+#include "fdg_knobs.h"
 
 namespace fdg {
 
@@ -88,8 +89,26 @@ struct fdg_ws_set {
   uint64_t last_use = 0;
 };
 
+// What the launch path needs of a handle's options, parsed when the handle is created and whenever fdg_graph_set_option changes one: between an
+// evaluation entry point and hipModuleLaunchKernel nothing is looked up by name.
+struct fdg_launch_cfg {
+  bool no_rl = false, no_fused_acc = false, no_pool = false, pool_no_acc = false, no_streaming = false, no_w2 = false, no_coop = false, no_rm = false;
+  bool transpose_narrow = false;
+  uint32_t root_scratch_min = 16;          // roots from which row-major root matrices go through the column-major scratch (0: never)
+  uint64_t root_scratch_mb = 256;
+  int waves_per_cu = 0;                    // > 0: resident waves per CU forced (no oversubscription)
+  int oversub = 0;                         // > 0: oversubscription factor forced
+  long mem_waves = -1;                     // >= 0: resident waves per CU of memory-bound graphs (0: rule off); -1: the library's rule
+  long mem_oversub = 1;
+  double mem_ratio = 2.5;
+  uint64_t sm_chunk_bytes = 1ull << 29;    // row-major input without an in-place variant: bytes of leaves transposed per chunk
+  long long eval_chunk = 0, mc_chunk = 0;  // host-buffer / Monte-Carlo chunk sizes in samples (0: the library's)
+};
+
 struct fdg_graph {
   fdg::Lowered prog;
+  fdg::KnobMap knobs;              // this handle's options (starts as a copy of fdg::env_snapshot(); fdg_graph_set_option)
+  fdg_launch_cfg cfg;
   // tuning knobs set by fdg_graph_set_opt_params (has_opt: the next FDG_SPEC_ISA specialisation uses them as they are)
   fdg_opt_params opt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool has_opt = false;
@@ -202,6 +221,7 @@ struct fdg_graph {
     }                                                                                   \
   } while (0)
 
+void parse_launch_cfg(fdg_graph *g);             // g->knobs -> g->cfg
 int ensure_device(fdg_graph *g);                 // binds the handle to the current gfx950 device
 int fdg_bind_stream_ws(fdg_graph *g, void *stream);   // makes the scratch set of `stream` the current one (caller holds g->mu)
 int ensure_ws(fdg_graph *g, size_t bytes);       // grows the handle's device workspace

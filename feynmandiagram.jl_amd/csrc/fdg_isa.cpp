@@ -461,8 +461,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const std::string LD = W == 2 ? "global_load_dwordx4 " : "global_load_dwordx2 ";
   const std::string ST = W == 2 ? "global_store_dwordx4 " : "global_store_dwordx2 ";
   // cache policy of the leaf stream (experiment knob): FDG_ISA_LEAF_POLICY="nt" / "sc1" / "sc0 sc1" ...
-  const std::string leaf_policy_env = std::getenv("FDG_ISA_LEAF_POLICY") ? std::string(" ") + std::getenv("FDG_ISA_LEAF_POLICY") : std::string();
-  const std::string root_policy = std::getenv("FDG_ISA_ROOT_POLICY") ? std::string(" ") + std::getenv("FDG_ISA_ROOT_POLICY") : std::string(E.streaming ? " nt" : "");
+  const std::string leaf_policy_env = fdg::knob("FDG_ISA_LEAF_POLICY") ? std::string(" ") + fdg::knob("FDG_ISA_LEAF_POLICY") : std::string();
+  const std::string root_policy = fdg::knob("FDG_ISA_ROOT_POLICY") ? std::string(" ") + fdg::knob("FDG_ISA_ROOT_POLICY") : std::string(E.streaming ? " nt" : "");
   // Streaming variant: a leaf's last load of the tile and the root stores are non-temporal -- the lines are not needed again, and
   // a read stream with a few stores in it runs 5-10 % faster that way (tools/ubench/tile_ahead.hip: 5.73 -> 6.32 TB/s).  Only for
   // batches whose tiles are whole cache lines (the runtime checks strides and bases): a line shared by two tiles would be
@@ -477,10 +477,10 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const std::string DSR = W == 2 ? "ds_read_b128 " : "ds_read_b64 ";
   const std::string DSW = W == 2 ? "ds_write_b128 " : "ds_write_b64 ";
 
-  const char *dbg = std::getenv("FDG_ISA_DEBUG");
+  const char *dbg = fdg::knob("FDG_ISA_DEBUG");
   const bool dbg_noleaf = dbg && std::strstr(dbg, "noleaf");
   const bool dbg_nolds = dbg && std::strstr(dbg, "nolds");
-  const bool use_ldexp = std::getenv("FDG_ISA_NO_LDEXP") == nullptr;
+  const bool use_ldexp = fdg::knob("FDG_ISA_NO_LDEXP") == nullptr;
   const bool dbg_novalu = dbg && std::strstr(dbg, "novalu");     // the memory stream of the program alone (waits included)
   const bool dbg_nopanel = dbg && std::strstr(dbg, "nopanel");   // no spill traffic to the HBM panel
   const bool dbg_norecv = dbg && std::strstr(dbg, "norecv");     // pooled / cooperative kernels without their reads of the shared LDS slots
@@ -819,7 +819,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   // 6.1 TB/s in a bare loop over rows that are whole cache lines (tools/ubench/rm_stream.hip), but a row of L doubles is not: the
   // 128-byte segments of consecutive chunks share lines, and a line fetched non-temporally is fetched again from memory for the
   // next chunk (measured: parquet_sigma4 6.2 -> 3.6e9 evals/s).  Plain loads it is.
-  const std::string rm_policy = std::getenv("FDG_ISA_RM_POLICY") && std::getenv("FDG_ISA_RM_POLICY")[0] ? std::string(" ") + std::getenv("FDG_ISA_RM_POLICY") : std::string();
+  const std::string rm_policy = fdg::knob("FDG_ISA_RM_POLICY") && fdg::knob("FDG_ISA_RM_POLICY")[0] ? std::string(" ") + fdg::knob("FDG_ISA_RM_POLICY") : std::string();
   std::vector<uint64_t> rm_ready(rm_bufs, 0);        // vm sequence number of the last load of the chunk in each buffer
   auto rm_emit_fetch = [&](const RmFetch &f) {
     // the buffer's previous readers have been issued; their data must have left the LDS before it is overwritten
@@ -845,7 +845,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   // One s_waitcnt can serve several consumers: when an op has to wait for a load, the wait also covers what
   // the next few ops need of the loads issued so far (they complete in order and were issued long before,
   // so this costs nothing and saves issue slots).
-  const char *wl_env = std::getenv("FDG_ISA_WAIT_LOOKAHEAD");
+  const char *wl_env = fdg::knob("FDG_ISA_WAIT_LOOKAHEAD");
   const size_t wait_look = wl_env ? (size_t)std::max(0, std::atoi(wl_env)) : 6;
   auto vm_seq_needed = [&](const MOp &q) -> uint64_t {
     uint64_t sq = 0;
@@ -1445,7 +1445,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   if (prog_acc) ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc", 1, true));
   // the same programs once more for batches whose tiles are whole cache lines (see `streaming` in emit_kernel); not for programs
   // so long that a second copy would double a minute of assembly
-  if (!std::getenv("FDG_ISA_NO_STREAMING") && prog.ops.size() <= 60000 && prog.mc_n_k == 0 && prog.mc_n_t == 0) {
+  if (!fdg::knob("FDG_ISA_NO_STREAMING") && prog.ops.size() <= 60000 && prog.mc_n_k == 0 && prog.mc_n_t == 0) {
     E.streaming = true;
     ks.push_back(emit_kernel(E, p, prog, kname + "_nt", 1));
     if (prog_acc && prog_acc->ops.size() <= 60000) ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc_nt", 1, true));

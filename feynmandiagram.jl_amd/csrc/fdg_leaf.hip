@@ -236,7 +236,7 @@ struct LeafModule { int dev; std::string key; hipModule_t mod; hipFunction_t fn;
 
 // returns the specialised kernel for these tables on the current device, or nullptr (caller uses the generic one)
 static hipFunction_t leaf_spec_function(const fdg_leaf_tables *tab, const std::vector<int32_t> &perm, int dev) {
-  if (std::getenv("FDG_LEAF_GENERIC")) return nullptr;
+  if (fdg::knob("FDG_LEAF_GENERIC")) return nullptr;
   for (uint32_t i = 0; i < tab->n_leaf; ++i)
     if (tab->leaf_type[i] == 2 && (tab->leaf_order[i] < 0 || tab->leaf_order[i] > 3)) return nullptr;   // pow_body lives in the generic kernel
   const std::string src = emit_leaf_source(tab, perm);
@@ -296,7 +296,7 @@ static int leaf_plan(const fdg_leaf_tables *tab, const LeafPlan **out) {
     const int32_t *src[5] = {tab->leaf_type, tab->leaf_order, tab->tau_in, tab->tau_out, tab->loop_index};
     for (int k = 0; k < 5; ++k) { std::memcpy(w, src[k], ib); w += ib; }
     std::memcpy(w, tab->basis, bb); w += bb;
-    *w = std::getenv("FDG_LEAF_GENERIC") ? 1 : 0;
+    *w = fdg::knob("FDG_LEAF_GENERIC") ? 1 : 0;
   }
   static std::mutex mu;
   static std::vector<LeafPlan *> cache;
@@ -390,13 +390,14 @@ int fdg_graph_specialize_fused(fdg_graph *g, const fdg_leaf_tables *tab, const c
   bool high_order = false;
   for (uint32_t i = 0; i < tab->n_leaf; ++i) high_order = high_order || (tab->leaf_type[i] == 2 && tab->leaf_order[i] > 3);
   std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
   // Route.  1: one compiler-scheduled kernel (leaves in registers, HIP source through hiprtc) -- graphs of up to a few
   // thousand operations.  2: the specialised leaf kernel fills a chunk of leaves that this handle's own evaluator
   // consumes -- larger graphs.  3: a handle specialised with FDG_SPEC_ISA whose leaves the optimizing back end's
   // formulas cover: ONE kernel of that back end with the leaves computed in registers (fdg_runtime.hip) -- measured
   // faster than either, taken for everything but tiny graphs.  FDG_MC_ROUTE=fused|split|isa overrides.
   {
-    const char *env = std::getenv("FDG_MC_ROUTE");
+    const char *env = fdg::knob("FDG_MC_ROUTE");
     const bool env_fused = env && std::strcmp(env, "fused") == 0, env_split = env && std::strcmp(env, "split") == 0,
                env_isa = env && std::strcmp(env, "isa") == 0;
     if (high_order && env_fused) { set_error("interaction order > 3 is not covered by the fused HIP kernel (FDG_MC_ROUTE=isa, split or unset)"); return FDG_E_UNSUPPORTED; }
@@ -456,6 +457,7 @@ static int run_fused(fdg_graph *g, int mode, const double *d_K, int64_t ks, int6
   if (B == 0) return FDG_OK;
   if (!d_K || !d_T || (mode == 0 && !d_root) || (mode == 1 && !d_acc)) { set_error("null device buffer"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
   if (g->mc_route == 0) { set_error("fdg_graph_specialize_fused has not been called on this handle"); return FDG_E_INVALID; }
   int rc = ensure_device(g);
   if (rc) return rc;
@@ -474,7 +476,7 @@ static int run_fused(fdg_graph *g, int mode, const double *d_K, int64_t ks, int6
     if (rc) return rc;
     const size_t L = std::max<uint32_t>(g->prog.L, 1);
     int64_t Bc = std::max<int64_t>(1 << 16, (int64_t)((4ull << 30) / (8ull * L)));     // about 4 GiB of leaves per chunk
-    if (const char *env = std::getenv("FDG_MC_CHUNK")) { const long long v = std::atoll(env); if (v >= 64) Bc = v; }   // samples per chunk (tuning)
+    if (g->cfg.mc_chunk >= 64) Bc = g->cfg.mc_chunk;   // samples per chunk (tuning)
     Bc = std::min<int64_t>((Bc + 63) & ~63ll, (B + 63) & ~63ll);
     const size_t need = (size_t)Bc * L * sizeof(double);
     if (g->ws4_bytes < need) {

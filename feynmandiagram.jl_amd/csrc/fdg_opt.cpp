@@ -176,7 +176,7 @@ struct Builder {
   // steps: five more instructions per quotient, and the quotients are then the reference's bits (FDG_MC_RCP_NEWTON=1: the
   // round-1 form, within an ulp)
   uint32_t rcp(uint32_t a) {
-    static const bool newton = std::getenv("FDG_MC_RCP_NEWTON") != nullptr;
+    const bool newton = fdg::knob("FDG_MC_RCP_NEWTON") != nullptr;
     return opx(newton ? M_RCP : M_DIV1, a & ~1u, 0, 0, 0.0) | (a & 1u);
   }
   // cond(c) ? a : b, cond = c > 0 (ge false) or c >= 0
@@ -336,7 +336,7 @@ struct Builder {
     Tau &tp = tau_pair(t->tau_in[i], t->tau_out[i]);
     const uint32_t a = sel(m.w, tp.u, tp.v, n != 0) ^ 1u;           // green() tests w > 0, green_derive's twin w >= 0
     const uint32_t A = opx(M_EXP, mul(m.w, a), 0, 0, 0.0);
-    if (const char *dbg = std::getenv("FDG_MC_DEBUG_STAGE")) {   // development only: a leaf's intermediate instead of its value
+    if (const char *dbg = fdg::knob("FDG_MC_DEBUG_STAGE")) {   // development only: a leaf's intermediate instead of its value
       const std::string st = dbg;
       const std::pair<const char *, uint32_t> stages[] = {{"w", m.w}, {"g", m.g}, {"tau", tp.tf}, {"a", a}, {"A", A}, {"u", tp.u}, {"v", tp.v}};
       for (const auto &kv : stages) if (st == kv.first) return kv.second;
@@ -383,7 +383,7 @@ struct Frame { uint32_t n, i, acc; };
 // FDG_ROOT_RECENT=w the overlap counts only the cones of the last w roots: what is likely to be on chip still.)
 static void order_roots(const Lowered &p, std::vector<uint32_t> &tops) {
   const uint32_t L = p.L;
-  static const size_t max_roots = std::getenv("FDG_ROOT_ORDER_MAX") ? (size_t)std::atoi(std::getenv("FDG_ROOT_ORDER_MAX")) : 1024;
+  const size_t max_roots = fdg::knob("FDG_ROOT_ORDER_MAX") ? (size_t)std::atoi(fdg::knob("FDG_ROOT_ORDER_MAX")) : 1024;
   if (tops.size() > 1 && tops.size() <= max_roots) {
     const size_t R = tops.size(), W = (p.N + 63) / 64;
     std::vector<std::vector<uint64_t>> cone(R, std::vector<uint64_t>(W, 0));
@@ -401,7 +401,7 @@ static void order_roots(const Lowered &p, std::vector<uint32_t> &tops) {
         }
       }
     }
-    static const size_t recent = std::getenv("FDG_ROOT_RECENT") ? (size_t)std::atoi(std::getenv("FDG_ROOT_RECENT")) : 0;
+    const size_t recent = fdg::knob("FDG_ROOT_RECENT") ? (size_t)std::atoi(fdg::knob("FDG_ROOT_RECENT")) : 0;
     std::vector<uint64_t> done(W, 0);
     std::vector<uint8_t> used(R, 0);
     std::vector<uint32_t> ordered;
@@ -527,7 +527,7 @@ void build_uops(Builder &B) {
   if (B.remat_window) {
     B.remat_limit = 4 * (p.flops_alg + p.N) + 1000;
     B.remat_ok.assign(p.N, 0);
-    const char *ce = std::getenv("FDG_REMAT_COST");
+    const char *ce = fdg::knob("FDG_REMAT_COST");
     const uint32_t max_cost = ce ? (uint32_t)std::atoi(ce) : B.remat_cost;
     for (uint32_t n = 0; n < p.N; ++n) {
       uint32_t cost = p.off[n + 1] - p.off[n] - 1;
@@ -631,7 +631,7 @@ void fuse_fma(std::vector<UOp> &u, uint32_t n_value) {
       const uint8_t k = u[prod[v]].kind;
       // only a product computed just before: fusing moves the multiplication to the sum's position, and the
       // factors of an older product would have to stay in registers until then
-      static const uint32_t reach = std::getenv("FDG_FMA_REACH") ? (uint32_t)std::atoi(std::getenv("FDG_FMA_REACH")) : 6u;
+      const uint32_t reach = fdg::knob("FDG_FMA_REACH") ? (uint32_t)std::atoi(fdg::knob("FDG_FMA_REACH")) : 6u;
       if (j - prod[v] > reach) return -1;
       return (k == M_MUL || k == M_MULC) ? (int64_t)prod[v] : -1;
     };
@@ -676,10 +676,10 @@ struct Alloc {
   // landing slots (home_kind 6): the last n_land AGPR pairs; a leaf sits in one from its M_LD_LEAF_ACC to its move into a register
   std::vector<uint32_t> free_land;
   uint32_t n_land = 0, n_acc_spill = 0;
-  const int evict_cost = std::getenv("FDG_EVICT_COST") ? std::atoi(std::getenv("FDG_EVICT_COST")) : 2;    // read per program (see take_reg)
+  const int evict_cost = fdg::knob("FDG_EVICT_COST") ? std::atoi(fdg::knob("FDG_EVICT_COST")) : 2;    // read per program (see take_reg)
   // pooled programs: a leaf comes back from the shared pool by an LDS read, so it is the cheapest thing to evict and is not parked anywhere
-  const double pool_leaf_cost = std::getenv("FDG_POOL_LEAF_COST") ? std::atof(std::getenv("FDG_POOL_LEAF_COST")) : 0.4;
-  const bool pool_nopark = std::getenv("FDG_POOL_NOPARK") != nullptr;
+  const double pool_leaf_cost = fdg::knob("FDG_POOL_LEAF_COST") ? std::atof(fdg::knob("FDG_POOL_LEAF_COST")) : 0.4;
+  const bool pool_nopark = fdg::knob("FDG_POOL_NOPARK") != nullptr;
   std::vector<MOp> out;
   OptProgram &prog;
 
@@ -1038,7 +1038,7 @@ void sort_load_runs(std::vector<MOp> &ops) {
         for (size_t b = a + 1; b < j; ++b) if (ops[a].d == ops[b].d) { distinct = false; break; }
       // (experiment FDG_LOAD_RUN_CHUNK=c: only within chunks of c loads, so that what the first fold steps need is issued first;
       // loads return in order, and behind a sorted burst of 70 the first fold step waits for whichever of them comes last)
-      const size_t chunk = std::getenv("FDG_LOAD_RUN_CHUNK") ? (size_t)std::max(0, std::atoi(std::getenv("FDG_LOAD_RUN_CHUNK"))) : 0;
+      const size_t chunk = fdg::knob("FDG_LOAD_RUN_CHUNK") ? (size_t)std::max(0, std::atoi(fdg::knob("FDG_LOAD_RUN_CHUNK"))) : 0;
       if (distinct)
         for (size_t s = i; s < j; s += (chunk ? chunk : j - i))
           std::stable_sort(ops.begin() + s, ops.begin() + std::min(j, s + (chunk ? chunk : j - i)), [](const MOp &x, const MOp &y) { return x.a < y.a; });
@@ -1065,13 +1065,13 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
   Builder B0(p);
   B0.value_numbering = prm.vn_window != 1;     // 1 = off, 0 = unlimited, else window in ops
   B0.vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
-  B0.vn_touch = std::getenv("FDG_VN_BIRTH_WINDOW") == nullptr;   // default: the window counts from the last read
+  B0.vn_touch = fdg::knob("FDG_VN_BIRTH_WINDOW") == nullptr;   // default: the window counts from the last read
   B0.remat_window = prm.remat_window;
   B0.remat_cost = prm.remat_cost;
-  B0.keep_root_order = prm.keep_root_order || std::getenv("FDG_KEEP_ROOT_ORDER") != nullptr;     // (the environment switch is for experiments)
-  if (const char *rw = std::getenv("FDG_REMAT_WINDOW")) B0.remat_window = (uint64_t)std::atoll(rw);     // experiments
-  if (const char *tw = std::getenv("FDG_TERM_WINDOW")) B0.term_window = (uint32_t)std::max(1, std::atoi(tw));
-  if (const char *tr = std::getenv("FDG_TERM_RECENT")) B0.term_recent = (uint32_t)std::max(1, std::atoi(tr));
+  B0.keep_root_order = prm.keep_root_order || fdg::knob("FDG_KEEP_ROOT_ORDER") != nullptr;     // (the environment switch is for experiments)
+  if (const char *rw = fdg::knob("FDG_REMAT_WINDOW")) B0.remat_window = (uint64_t)std::atoll(rw);     // experiments
+  if (const char *tw = fdg::knob("FDG_TERM_WINDOW")) B0.term_window = (uint32_t)std::max(1, std::atoi(tw));
+  if (const char *tr = fdg::knob("FDG_TERM_RECENT")) B0.term_recent = (uint32_t)std::max(1, std::atoi(tr));
   build_uops(B0);
   Lowered plain;
   const bool retry = !B0.ok && B0.why == "inconsistent schedule groups";
@@ -1130,7 +1130,7 @@ bool build_schedule(const Lowered &p, const OptParams &prm, std::vector<SchedOp>
   Builder B0(p);
   B0.value_numbering = prm.vn_window != 1;
   B0.vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
-  B0.vn_touch = std::getenv("FDG_VN_BIRTH_WINDOW") == nullptr;
+  B0.vn_touch = fdg::knob("FDG_VN_BIRTH_WINDOW") == nullptr;
   B0.keep_minus_one = prm.keep_minus_one;
   B0.mul_keeps_signs = prm.mul_keeps_signs;
   build_uops(B0);
@@ -1318,8 +1318,8 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
 
 // Shorter epochs keep fewer hand-overs in flight: when the shared slots run out the schedule is rebuilt with a smaller budget.
 void build_coop_program(const Lowered &p, const OptParams &prm, CoopProgram &out, uint32_t n_wave) {
-  const char *te = std::getenv("FDG_COOP_EPOCH_OPS");
-  if (te) { const char *ge = std::getenv("FDG_COOP_GAP"); build_coop_once(p, prm, (size_t)std::max(8, std::atoi(te)), ge ? (uint32_t)std::atoi(ge) : 2u, out, n_wave); return; }
+  const char *te = fdg::knob("FDG_COOP_EPOCH_OPS");
+  if (te) { const char *ge = fdg::knob("FDG_COOP_GAP"); build_coop_once(p, prm, (size_t)std::max(8, std::atoi(te)), ge ? (uint32_t)std::atoi(ge) : 2u, out, n_wave); return; }
   for (size_t budget : {192, 128, 96, 64, 48}) {
     build_coop_once(p, prm, budget, budget > 64 ? 2u : 1u, out, n_wave);
     if (out.supported || out.why != "shared LDS slots exhausted") return;
@@ -1331,7 +1331,7 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
   out.n_wave = NW;
   const uint32_t L = p.L;
   CoopBuild C(p);
-  if (const char *e = std::getenv("FDG_COOP_COPY_WINDOW")) C.copy_window = (uint32_t)std::max(1, std::atoi(e));
+  if (const char *e = fdg::knob("FDG_COOP_COPY_WINDOW")) C.copy_window = (uint32_t)std::max(1, std::atoi(e));
   for (uint32_t k = 0; k < p.R; ++k) if (p.root_slot[k] != FDG_NO_ROOT) C.rootlist.push_back({p.root_slot[k], k});
   std::sort(C.rootlist.begin(), C.rootlist.end());
   for (uint32_t w = 0; w < NW; ++w) {
@@ -1354,7 +1354,7 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
   // on chip (order_roots); with a few roots the terms of each are dealt, a home wave folding them as they arrive.
   size_t n_wide = 0;
   for (uint32_t rn : root_nodes) n_wide += (p.off[rn + 1] - p.off[rn] >= 8 && p.op[rn] != FDG_OP_POWER);
-  const char *rte = std::getenv("FDG_COOP_ROOT_TASKS");
+  const char *rte = fdg::knob("FDG_COOP_ROOT_TASKS");
   const bool root_tasks = rte ? rte[0] == '1' : root_nodes.size() > 4 * (size_t)NW;
   if (root_tasks) order_roots(p, root_nodes);
   std::vector<std::vector<uint32_t>> term_lists;
@@ -1424,7 +1424,7 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
   }
   // ---- publication intervals and shared slots ---------------------------------------------------------------------------
   out.n_priv_lds = NW == 4 ? 16 : (NW == 8 ? 8 : 4);
-  if (const char *e = std::getenv("FDG_COOP_PRIV_LDS")) out.n_priv_lds = (uint32_t)std::max(1, std::min(70, std::atoi(e)));
+  if (const char *e = fdg::knob("FDG_COOP_PRIV_LDS")) out.n_priv_lds = (uint32_t)std::max(1, std::min(70, std::atoi(e)));
   out.n_shared = std::min<uint32_t>(256, 312 - NW * out.n_priv_lds);   // (the emitter addresses shared slots as two banks of 128)
   struct Interval { uint32_t node, start, end, slot; };
   std::vector<Interval> ivs;
@@ -1467,7 +1467,7 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
       free_at[best] = ivs[i].end + 1;
     }
   }
-  if (std::getenv("FDG_COOP_DEBUG")) {
+  if (fdg::knob("FDG_COOP_DEBUG")) {
     std::vector<uint32_t> occ(C.cur_epoch + 2, 0);
     for (const Interval &iv : ivs) for (uint32_t e = iv.start; e <= iv.end && e < occ.size(); ++e) occ[e]++;
     uint64_t sum = 0; uint32_t mx = 0;
@@ -1516,12 +1516,12 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
   out.n_wave = NW;
   out.pooled = true;
   out.pool_unit = unit_in == 2 ? 2 : 1;
-  if (const char *e = std::getenv("FDG_POOL_UNIT")) out.pool_unit = std::atoi(e) == 2 ? 2 : 1;
+  if (const char *e = fdg::knob("FDG_POOL_UNIT")) out.pool_unit = std::atoi(e) == 2 ? 2 : 1;
   const uint32_t L = p.L;
   if (NW < 2 || NW > CoopProgram::MAXW) { out.why = "bad wave count"; return; }
   if (p.sched_group.size() == p.N && p.N) { out.why = "schedule groups are not part of the pooled variant"; return; }
-  if (const char *e = std::getenv("FDG_POOL_EPOCH_OPS")) epoch_ops = (uint32_t)std::max(16, std::atoi(e));
-  if (const char *e = std::getenv("FDG_POOL_AHEAD")) ahead = (uint32_t)std::max(1, std::atoi(e));
+  if (const char *e = fdg::knob("FDG_POOL_EPOCH_OPS")) epoch_ops = (uint32_t)std::max(16, std::atoi(e));
+  if (const char *e = fdg::knob("FDG_POOL_AHEAD")) ahead = (uint32_t)std::max(1, std::atoi(e));
   if (!epoch_ops) epoch_ops = 128;
   if (!ahead) ahead = 8;
   // ---- roots to waves: largest cone first, to the wave where it adds the least to the heaviest load ----------------------------
@@ -1562,7 +1562,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
   // that doubles the duplicated fold steps, 16 617 -> 67 062, and the pool traffic.)
   std::vector<size_t> deal(root_nodes.size());
   for (size_t i = 0; i < deal.size(); ++i) deal[i] = i;
-  if (!(std::getenv("FDG_POOL_DEAL") && std::string(std::getenv("FDG_POOL_DEAL")) == "overlap")) {
+  if (!(fdg::knob("FDG_POOL_DEAL") && std::string(fdg::knob("FDG_POOL_DEAL")) == "overlap")) {
     std::sort(deal.begin(), deal.end(), [&](size_t a, size_t b) { return csize[a] > csize[b] || (csize[a] == csize[b] && a < b); });
   } else {
     std::vector<uint32_t> ordered = root_nodes;
@@ -1574,7 +1574,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
   std::vector<std::vector<uint64_t>> have(NW, std::vector<uint64_t>(W64, 0));
   std::vector<uint64_t> load(NW, 0);
   std::vector<uint32_t> wave_of_node(p.N, NONE);
-  const double affinity = std::getenv("FDG_POOL_AFFINITY") ? std::atof(std::getenv("FDG_POOL_AFFINITY")) : 2.0;
+  const double affinity = fdg::knob("FDG_POOL_AFFINITY") ? std::atof(fdg::knob("FDG_POOL_AFFINITY")) : 2.0;
   for (size_t r : deal) {
     uint32_t best = 0; uint64_t best_load = ~0ull;
     std::vector<uint64_t> add(NW, 0);
@@ -1610,9 +1610,9 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
   }
   // ---- registers per wave: leaves are re-loadable (from the pool: a short LDS read) ---------------------------------------------------------
   out.n_priv_lds = NW <= 4 ? 16 : (NW == 8 ? 8 : 4);
-  if (const char *e = std::getenv("FDG_COOP_PRIV_LDS")) out.n_priv_lds = (uint32_t)std::max(1, std::min(70, std::atoi(e)));
+  if (const char *e = fdg::knob("FDG_COOP_PRIV_LDS")) out.n_priv_lds = (uint32_t)std::max(1, std::min(70, std::atoi(e)));
   out.n_shared = std::min<uint32_t>(256, 312 - NW * out.n_priv_lds);
-  if (const char *e = std::getenv("FDG_POOL_SLOTS")) out.n_shared = (uint32_t)std::max(8, std::min<int>((int)out.n_shared, std::atoi(e)));
+  if (const char *e = fdg::knob("FDG_POOL_SLOTS")) out.n_shared = (uint32_t)std::max(8, std::min<int>((int)out.n_shared, std::atoi(e)));
   for (uint32_t w = 0; w < NW; ++w) {
     OptParams q = prm;
     q.n_lds = out.n_priv_lds;
@@ -1621,7 +1621,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     // a pool read is an LDS read -- of a pool all four waves and the fetches hammer: issued 96 fold steps ahead of its use (32, the
     // distance of a wave's private LDS slots: -10 %; 200: the landing registers are missed elsewhere, -4 %; profiles/r04_log_la_lds.txt)
     q.lookahead_leaf = 96;
-    if (const char *e = std::getenv("FDG_POOL_READ_AHEAD")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(e));
+    if (const char *e = fdg::knob("FDG_POOL_READ_AHEAD")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(e));
     if (!fit_registers(B[w]->u, q, out.wave[w])) { out.why = out.wave[w].why; return; }
     Alloc A(p, out.wave[w].params, B[w]->u, B[w]->next_vid, out.wave[w]);
     A.run();
@@ -1700,10 +1700,10 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
   // (an instruction costs the issuing wave about a hundred cycles whatever it brings).  MEASURED SLOWER, so off unless FDG_POOL_PAIR=1: on the
   // 4-loop GV vertex function 1 245 instead of 2 195 fetch instructions (+9 % leaves) run 4.16 ms against 3.70; with pairs only into slots whose
   // content is dead or 64 epochs from its next read 1 694 instructions, no extra leaf, 3.96 ms (profiles/r04_log_pool_anypair.txt).
-  const bool pairing = U == 1 && std::getenv("FDG_POOL_PAIR") && std::getenv("FDG_POOL_PAIR")[0] == '1';
-  static const uint32_t far = std::getenv("FDG_POOL_FAR") ? (uint32_t)std::atoi(std::getenv("FDG_POOL_FAR")) : 64;
+  const bool pairing = U == 1 && fdg::knob("FDG_POOL_PAIR") && fdg::knob("FDG_POOL_PAIR")[0] == '1';
+  const uint32_t far = fdg::knob("FDG_POOL_FAR") ? (uint32_t)std::atoi(fdg::knob("FDG_POOL_FAR")) : 64;
   const uint32_t INF = std::numeric_limits<uint32_t>::max();
-  const uint32_t pair_far = std::getenv("FDG_POOL_PAIR_FAR") ? (uint32_t)std::atoi(std::getenv("FDG_POOL_PAIR_FAR")) : 32;
+  const uint32_t pair_far = fdg::knob("FDG_POOL_PAIR_FAR") ? (uint32_t)std::atoi(fdg::knob("FDG_POOL_PAIR_FAR")) : 32;
   // may slot s2 be given away at `issue` to content first read in epoch e?  key: how late its present content is needed again (0: no)
   auto victim_key = [&](uint32_t s2, uint32_t issue, uint32_t e) -> uint64_t {
     if (in_slot[s2] == NONE) return (uint64_t)INF + 2;
@@ -1777,7 +1777,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
   out.n_fetch = fetches.size();
   out.n_transfer = 0;                                       // leaves brought from memory per tile
   for (const Fetch &f : fetches) out.n_transfer += f.unit2 != NONE ? 2 : std::min<uint32_t>(U, L - f.unit * U);
-  if (std::getenv("FDG_POOL_DEBUG")) {
+  if (fdg::knob("FDG_POOL_DEBUG")) {
     std::vector<uint32_t> hist(ahead + 2, 0);
     uint64_t sum = 0;
     for (const Fetch &f : fetches) { hist[std::min<uint32_t>(f.ready - f.issue, ahead + 1)]++; sum += f.ready - f.issue; }
@@ -1794,7 +1794,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     std::vector<std::vector<size_t>> by_issue(n_epoch + 1);
     for (size_t i = 0; i < fetches.size(); ++i) by_issue[fetches[i].issue].push_back(i);
     uint32_t turn = 0;
-    const bool global_rr = std::getenv("FDG_POOL_DEAL_GLOBAL") != nullptr;      // (experiment: the round-3 dealing, by global index)
+    const bool global_rr = fdg::knob("FDG_POOL_DEAL_GLOBAL") != nullptr;      // (experiment: the round-3 dealing, by global index)
     for (uint32_t ep = 0; ep <= n_epoch; ++ep)
       for (size_t i : by_issue[ep]) { at[global_rr ? i % NW : turn % NW][ep].push_back(fetches[i]); turn++; }
   }

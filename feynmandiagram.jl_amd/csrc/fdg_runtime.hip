@@ -530,6 +530,32 @@ static int ensure_module(fdg_graph *g) {
   return FDG_OK;
 }
 
+// The launch path's view of the handle's options (fdg_internal.h: fdg_launch_cfg).  Called under g->mu (or before the handle is shared).
+void parse_launch_cfg(fdg_graph *g) {
+  fdg_launch_cfg c;
+  auto get = [&](const char *n) -> const char * { auto it = g->knobs.find(n); return it == g->knobs.end() ? nullptr : it->second.c_str(); };
+  c.no_rl = get("FDG_ISA_NO_RL") != nullptr;
+  c.no_fused_acc = get("FDG_ISA_NO_FUSED_ACC") != nullptr;
+  c.no_pool = get("FDG_ISA_NO_POOL") != nullptr;
+  c.pool_no_acc = get("FDG_ISA_POOL_NO_ACC") != nullptr;
+  c.no_streaming = get("FDG_ISA_NO_STREAMING") != nullptr;
+  c.no_w2 = get("FDG_ISA_NO_W2") != nullptr;
+  c.no_coop = get("FDG_ISA_NO_COOP") != nullptr;
+  c.no_rm = get("FDG_ISA_NO_RM") != nullptr;
+  c.transpose_narrow = get("FDG_TRANSPOSE_NARROW") != nullptr;
+  if (const char *e = get("FDG_ROOT_SCRATCH_MIN")) c.root_scratch_min = (uint32_t)std::max(0, std::atoi(e));
+  if (const char *e = get("FDG_ROOT_SCRATCH_MB")) c.root_scratch_mb = (uint64_t)std::max(1, std::atoi(e));
+  if (const char *e = get("FDG_ISA_WAVES_PER_CU")) c.waves_per_cu = std::max(1, std::atoi(e));
+  if (const char *e = get("FDG_ISA_OVERSUB")) c.oversub = std::max(1, std::atoi(e));
+  if (const char *e = get("FDG_ISA_MEM_WAVES")) c.mem_waves = std::max(0l, std::atol(e));
+  if (const char *e = get("FDG_ISA_MEM_OVERSUB")) c.mem_oversub = std::max(1l, std::atol(e));
+  if (const char *e = get("FDG_ISA_MEM_RATIO")) c.mem_ratio = std::atof(e);
+  if (const char *e = get("FDG_SM_CHUNK_MB")) c.sm_chunk_bytes = (uint64_t)std::max(1, std::atoi(e)) << 20;
+  if (const char *e = get("FDG_EVAL_CHUNK")) c.eval_chunk = std::atoll(e);
+  if (const char *e = get("FDG_MC_CHUNK")) c.mc_chunk = std::atoll(e);
+  g->cfg = c;
+}
+
 // mode 0: roots -> d_root; mode 1: partial sums -> d_acc
 static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
                int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st,
@@ -542,6 +568,7 @@ static int run(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t
   }
   if (mode == 1 && g->prog.R == 0) return FDG_OK;        // no roots: nothing to accumulate
   std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
   { const int rcb = fdg_bind_stream_ws(g, (void *)st); if (rcb) return rcb; }
   return fdg_run_locked(g, mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st, lts, rts);
 }
@@ -589,16 +616,16 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     set_error("tile-major batch: negative strides or sample strides of 2^23 elements or more are not supported"); return FDG_E_UNSUPPORTED;
   }
 
-  const bool rl_rows = g->has_rl && ls == 1 && ss == (int64_t)p.L && p.L >= 2 && B >= 64 && ((uintptr_t)d_leaf & 15) == 0 && !std::getenv("FDG_ISA_NO_RL");
+  const bool rl_rows = g->has_rl && ls == 1 && ss == (int64_t)p.L && p.L >= 2 && B >= 64 && ((uintptr_t)d_leaf & 15) == 0 && !g->cfg.no_rl;
   const bool rl_shape = rl_rows && ((mode == 0 && !(rs < 0 || rs >= (1ll << 23))) ||                       // contiguous rows: the linear variant below
-                                    (mode == 1 && g->has_rl_acc && g->has_acc && !std::getenv("FDG_ISA_NO_FUSED_ACC")));
+                                    (mode == 1 && g->has_rl_acc && g->has_acc && !g->cfg.no_fused_acc));
   // Roots into a ROW-MAJOR matrix (compile_Python's [B, R]) of a graph with many roots: a root store of the kernels is 64 lanes x 8 bytes, each in
   // another row -- with R = 180 (example/benchmark.jl's vertex function) the stores doubled the kernel's time.  Such calls evaluate chunk by chunk
   // into the column-major root scratch (every store one 512-byte run) and a transposition writes the caller's rows (round 4).
-  static const uint32_t scratch_min_roots = std::getenv("FDG_ROOT_SCRATCH_MIN") ? (uint32_t)std::atoi(std::getenv("FDG_ROOT_SCRATCH_MIN")) : 16;
+  const uint32_t scratch_min_roots = g->cfg.root_scratch_min;
   if (mode == 0 && !g->code_object.empty() && g->isa && scratch_min_roots && R >= scratch_min_roots && rk == 1 && rs >= (int64_t)R && (rts == 0 || rts == 64 * rs) && B >= 256 &&
       !(ls == 1 && ss != 1 && (g->alt_code.size() || g->has_rm || rl_rows))) {     // (the row-major variants write a tile's rows together: left alone)
-    const unsigned long long scratch_mb = std::getenv("FDG_ROOT_SCRATCH_MB") ? (unsigned long long)std::max(1, std::atoi(std::getenv("FDG_ROOT_SCRATCH_MB"))) : 256ull;
+    const unsigned long long scratch_mb = g->cfg.root_scratch_mb;
     long Bc = std::max<long>(64, (long)((scratch_mb << 20) / (8ull * R)) & ~63l);
     Bc = std::min<long>(Bc, (long)((B + 63) & ~(int64_t)63));
     const size_t need = (size_t)Bc * R * sizeof(double) + (size_t)2048 * R * sizeof(double);
@@ -646,8 +673,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       uint32_t per_cu = std::min<uint32_t>(8, 512 / valloc) * 4;
       if (lds_bytes) per_cu = std::min<uint32_t>(per_cu, (160u * 1024u) / lds_bytes);
       per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32));
-      const char *env = std::getenv("FDG_ISA_WAVES_PER_CU");
-      if (env) per_cu = (uint32_t)std::max(1, std::atoi(env));
+      if (g->cfg.waves_per_cu > 0) per_cu = (uint32_t)g->cfg.waves_per_cu;
       return per_cu;
     };
     const long ntiles = (long)((B + 63) / 64);
@@ -656,9 +682,8 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // graphs that run against the power budget, +1 % on the headline; profiles/r03_log_oversubscription.txt).  Only while every
     // workgroup keeps a few tiles and the spill panels / partial sums that are sized by the grid stay small.
     auto oversub = [&](long resident, size_t bytes_per_wg) -> long {
-      if (std::getenv("FDG_ISA_WAVES_PER_CU")) return resident;
-      const char *env = std::getenv("FDG_ISA_OVERSUB");
-      long f = env ? std::max(1, std::atoi(env)) : 8;
+      if (g->cfg.waves_per_cu > 0) return resident;
+      long f = g->cfg.oversub > 0 ? g->cfg.oversub : 8;
       while (f > 1 && (ntiles < resident * f * 4 || bytes_per_wg * (size_t)(resident * f) > ((size_t)32 << 20))) f >>= 1;
       return resident * f;
     };
@@ -668,11 +693,11 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     // above the ridge want every wave they can get.  FDG_ISA_MEM_WAVES / FDG_ISA_MEM_OVERSUB / FDG_ISA_MEM_RATIO override (0 waves = off).
     auto shape = [&](uint64_t valu, uint64_t bytes, uint32_t vgpr, uint32_t lds, size_t bytes_per_wg, bool accumulating = false) -> long {
       const long full = (long)waves_per_cu(vgpr, lds);
-      const long mem_waves = std::getenv("FDG_ISA_MEM_WAVES") ? std::atol(std::getenv("FDG_ISA_MEM_WAVES")) : (p.L >= 24 ? 4 : (accumulating ? 8 : 5));   // (a wave of a tiny graph keeps little in flight; without root stores
+      const long mem_waves = g->cfg.mem_waves >= 0 ? g->cfg.mem_waves : (p.L >= 24 ? 4 : (accumulating ? 8 : 5));   // (a wave of a tiny graph keeps little in flight; without root stores
                                                                                                                            //  more of them help: the 2-loop graph accumulates at 0.84 instead of 0.73, profiles/r04_log_tiny_acc_waves.txt)
-      const long mem_over = std::getenv("FDG_ISA_MEM_OVERSUB") ? std::max(1l, std::atol(std::getenv("FDG_ISA_MEM_OVERSUB"))) : 1;
-      const double mem_ratio = std::getenv("FDG_ISA_MEM_RATIO") ? std::atof(std::getenv("FDG_ISA_MEM_RATIO")) : 2.5;
-      if (mem_waves > 0 && !std::getenv("FDG_ISA_WAVES_PER_CU") && !std::getenv("FDG_ISA_OVERSUB") && bytes && (double)valu < mem_ratio * (double)bytes && full > mem_waves) {
+      const long mem_over = g->cfg.mem_oversub;
+      const double mem_ratio = g->cfg.mem_ratio;
+      if (mem_waves > 0 && g->cfg.waves_per_cu <= 0 && g->cfg.oversub <= 0 && bytes && (double)valu < mem_ratio * (double)bytes && full > mem_waves) {
         long f = mem_over;
         while (f > 1 && ntiles < (long)g->n_cu * mem_waves * f * 4) f >>= 1;
         return (long)g->n_cu * mem_waves * f;
@@ -685,10 +710,10 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
                                   (size_t)std::max<uint32_t>(g->isa2_mem_slots, 1) * 1024u * (size_t)grid2);
     // pooled cooperative variant: full tiles of batches whose samples of a leaf are contiguous and whose leaves lie within 2 GB of the tile's first
     const bool pool_ok = g->has_pool && g->fn_isa_pool && ss == 1 && ls > 0 && (g->pool_unit == 1 || ls == 64) &&
-                         (uint64_t)ls * 8u * (uint64_t)std::max<uint32_t>(p.L, 1) < (1ull << 31) && B >= 64 && !std::getenv("FDG_ISA_NO_POOL");
+                         (uint64_t)ls * 8u * (uint64_t)std::max<uint32_t>(p.L, 1) < (1ull << 31) && B >= 64 && !g->cfg.no_pool;
     // (a graph that has the pooled variant accumulates through it and the root scratch: its fused-accumulation program, with R + 2 fewer value
     //  registers and no pool, runs the 4-loop GV vertex function at 0.87e8 samples/s where the pooled evaluation + the weighted sum do 1.3e8)
-    const bool fused_acc = mode == 1 && g->has_acc && !std::getenv("FDG_ISA_NO_FUSED_ACC") && !(pool_ok && !std::getenv("FDG_ISA_POOL_NO_ACC"));
+    const bool fused_acc = mode == 1 && g->has_acc && !g->cfg.no_fused_acc && !(pool_ok && !g->cfg.pool_no_acc);
     const long grid3 = g->has_acc ? shape(g->st_valu[1], 8ull * p.L, g->isa3_vgpr, g->isa3_lds_bytes, ((size_t)g->isa3_mem_slots + R) * 512u, true) : 0;
     const size_t panel3 = (size_t)std::max<uint32_t>(g->isa3_mem_slots, 1) * 512u * (size_t)grid3;
     const long grid4 = g->has_rm ? (long)g->n_cu * waves_per_cu(g->isa4_vgpr, g->isa4_lds_bytes) : 0;
@@ -700,8 +725,9 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     if (rc) return rc;
     // a matrix whose 64-sample tiles are whole 128-byte lines (samples of a column contiguous, column stride a multiple of 16
     // doubles, base on a line): the streaming variants may be used (non-temporal accesses would fetch a shared line twice)
-    auto line_aligned = [](const void *base, long sample_stride, long col_stride) {
-      return sample_stride == 1 && (col_stride & 15) == 0 && ((uintptr_t)base & 127) == 0 && !std::getenv("FDG_ISA_NO_STREAMING");
+    const bool streaming_ok = !g->cfg.no_streaming;
+    auto line_aligned = [streaming_ok](const void *base, long sample_stride, long col_stride) {
+      return sample_stride == 1 && (col_stride & 15) == 0 && ((uintptr_t)base & 127) == 0 && streaming_ok;
     };
     bool named = false;
     // fused accumulation: acc[k] += sum_b w_b root_k(b) with per-lane accumulators inside the evaluator
@@ -723,7 +749,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     auto launch_isa = [&](const double *lf, long lss, long lls, double *rt, long rrs, long rrk, long n, long tls = 0, long trs = 0) -> int {
       void *a_wsp = g->d_ws;
       long done = 0;
-      if (g->has_w2 && lss == 1 && n >= 128 && !tls && !trs && !std::getenv("FDG_ISA_NO_W2")) {
+      if (g->has_w2 && lss == 1 && n >= 128 && !tls && !trs && !g->cfg.no_w2) {
         long n2 = n & ~127l;
         long nwg = std::min<long>(n2 / 128, grid2);
         const double *nowt = nullptr;
@@ -795,7 +821,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     }
     // Cooperative variant: one workgroup of four waves per CU, every workgroup walks tiles of 64 samples; leaf-major input.
     if (mode == 0 && g->has_coop && g->coop_enabled && g->fn_isa_coop && !(ls == 1 && ss != 1 && p.L > 1) && !wide_ss && !(rs < 0 || rs >= (1ll << 23)) &&
-        !std::getenv("FDG_ISA_NO_COOP")) {
+        !g->cfg.no_coop) {
       long nwg = std::min<long>((long)((B + 63) / 64), (long)g->n_cu), lss = ss, lls = ls, rrs = rs, rrk = rk, n = (long)B;
       rc = ensure_ws(g, std::max(panel_all + (size_t)grid3 * R * 512u + 4096, (size_t)g->coop_panel_wg * (size_t)nwg + 4096));
       if (rc) return rc;
@@ -845,7 +871,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       if (tail) { rc = launch_isa(d_leaf + (size_t)n4 * (size_t)ss, lss, lls, d_root + (size_t)n4 * (size_t)rs, rrs, rrk, tail); if (rc) return rc; }
       return FDG_OK;
     }
-    const bool rm_shape = ls == 1 && ss >= (int64_t)p.L && !wide_ss && p.L >= 16 && B >= 64 && !tiled && !std::getenv("FDG_ISA_NO_RM");
+    const bool rm_shape = ls == 1 && ss >= (int64_t)p.L && !wide_ss && p.L >= 16 && B >= 64 && !tiled && !g->cfg.no_rm;
     if (rm_shape && ((mode == 0 && g->has_rm && g->fn_isa_rm && !(rs < 0 || rs >= (1ll << 23))) || (fused_acc && g->has_rm_acc && g->fn_isa_rm_acc))) {
       const long n4 = (long)(B & ~(int64_t)63), lss = ss, lls = ls, tail = (long)B - n4;
       void *a_wsp = g->d_ws;
@@ -877,8 +903,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       // (2 extra HBM passes over the leaves; in-kernel LDS staging would avoid them -- DESIGN.md 8)
       // Chunks are double-buffered: the transposition of chunk c+1 (HBM-bound) runs on an internal
       // stream while the evaluator works on chunk c (fp64-bound for all but tiny graphs).
-      unsigned long long chunk_bytes = 1ull << 29;
-      if (const char *cb = std::getenv("FDG_SM_CHUNK_MB")) chunk_bytes = (unsigned long long)std::max(1, std::atoi(cb)) << 20;
+      const unsigned long long chunk_bytes = g->cfg.sm_chunk_bytes;
       long Bc = std::max<long>((long)g->n_cu * 8 * 64 * 2, (long)(chunk_bytes / (8ull * p.L)));
       Bc = std::min<long>((Bc + 63) & ~63l, (B + 63) & ~63l);
       const size_t one = (size_t)Bc * p.L * sizeof(double);
@@ -901,7 +926,7 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
       HIP_TRY(hipStreamWaitEvent(s2, (hipEvent_t)g->ev_in, 0));
       auto transpose = [&](long c0, int buf) {
         const long n = std::min<long>(Bc, B - c0);
-        if (ls == 1 && (ss & 1) == 0 && ((uintptr_t)d_leaf & 15) == 0 && p.L >= 32 && !std::getenv("FDG_TRANSPOSE_NARROW")) {
+        if (ls == 1 && (ss & 1) == 0 && ((uintptr_t)d_leaf & 15) == 0 && p.L >= 32 && !g->cfg.transpose_narrow) {
           const long ntile = ((n + 63) / 64) * ((p.L + 63) / 64);
           hipLaunchKernelGGL(fdg_transpose_rows_wide, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 8)), dim3(256), 0, s2,
                              d_leaf + c0 * ss, (long)ss, (double *)((char *)g->d_ws3 + (size_t)buf * one), Bc, n, p.L);
@@ -996,7 +1021,7 @@ uint64_t fnv1a(const std::string &s, uint64_t h) {
 // calling user or by root and not writable by everybody are read back.  (The group bit is not tested: the assembler and
 // the linker create their outputs under the caller's umask, 0664/0775 under umask 002, and the directory they sit in is
 // vetted by fdg_cache_dir.  FDG_CACHE_TRUST=1 lifts the ownership test.)
-static bool cache_trust() { static const bool t = std::getenv("FDG_CACHE_TRUST") != nullptr; return t; }
+static bool cache_trust() { return fdg::knob("FDG_CACHE_TRUST") != nullptr; }
 // `deny`: permission bits that disqualify the file -- 002 inside the caller's own vetted cache directory (the assembler and the linker
 // create their outputs under the caller's umask: 0664 under umask 002), 022 for files found through $FDG_CACHE_RO_DIR (nothing legitimate is
 // written there by this process, so a group-writable artefact is not taken).
@@ -1024,7 +1049,7 @@ bool read_file(const std::string &path, std::vector<char> &out) { return read_fi
 // their owner only (no group or world write bit); nothing is ever written there.
 bool read_cached(const std::string &dir, const std::string &fname, std::vector<char> &out) {
   if (!dir.empty() && read_file(dir + "/" + fname, out)) return true;
-  const char *ro = std::getenv("FDG_CACHE_RO_DIR");
+  const char *ro = fdg::knob("FDG_CACHE_RO_DIR");
   if (!ro || !*ro) return false;
   std::string all = ro;
   size_t pos = 0;
@@ -1070,7 +1095,7 @@ bool write_file(const std::string &path, const char *data, size_t n) {
 // name.  Paths with a quote or a newline are refused outright.
 int fdg_cache_dir(const char *arg, std::string &dir) {
   if (arg && *arg) dir = arg;
-  else if (const char *e = std::getenv("FDG_CACHE_DIR")) dir = e;
+  else if (const char *e = fdg::knob("FDG_CACHE_DIR")) dir = e;
   else if (const char *x = std::getenv("XDG_CACHE_HOME")) { dir = std::string(x); mkdir(dir.c_str(), 0700); dir += "/fdg"; }
   else if (const char *h = std::getenv("HOME")) { dir = std::string(h) + "/.cache"; mkdir(dir.c_str(), 0700); dir += "/fdg"; }
   else dir = "/tmp/fdg-cache-" + std::to_string((long)geteuid());
@@ -1141,7 +1166,7 @@ int compile_hiprtc(const std::string &src, bool fast, std::vector<char> &co, std
 }
 
 int compile_hipcc(const std::string &src_path, const std::string &out_path, bool fast, std::string &log) {
-  const char *hipcc = std::getenv("FDG_HIPCC");
+  const char *hipcc = fdg::knob("FDG_HIPCC");
   const std::string tmp = out_path + tmp_suffix();
   const int rc = run_cmd({hipcc ? hipcc : "/opt/rocm/bin/hipcc", "--genco", "--offload-arch=gfx950", "-O3",
                           fast ? "-ffp-contract=fast" : "-ffp-contract=off", "-o", tmp, src_path}, tmp + ".log");
@@ -1155,7 +1180,7 @@ int compile_hipcc(const std::string &src_path, const std::string &out_path, bool
 // is small (8 blocks/CU), otherwise 40 slots = 80 KiB per block (2 blocks/CU)
 static uint32_t interp_lds_budget() {
   uint32_t budget = 40;
-  const char *env = std::getenv("FDG_LDS_SLOTS");
+  const char *env = fdg::knob("FDG_LDS_SLOTS");
   if (env) budget = (uint32_t)std::max(1, std::atoi(env));
   return std::min(budget, 79u);
 }
@@ -1185,8 +1210,34 @@ int fdg_graph_create(const fdg_graph_desc *d, fdg_graph **out) {
   p.root_slot.assign(d->root_slot, d->root_slot + p.R);
   analyse(p);
   build_interpreter_program(p, interp_lds_budget());
+  g->knobs = fdg::env_snapshot();
+  parse_launch_cfg(g);
   *out = g;
   return FDG_OK;
+}
+
+// A handle's options (include/fdg.h).  value == NULL removes the option.
+int fdg_graph_set_option(fdg_graph *g, const char *name, const char *value) {
+  if (!g || !name || !*name) { set_error("null handle or option name"); return FDG_E_INVALID; }
+  if (std::strncmp(name, "FDG_", 4) != 0) { set_error("option names start with FDG_"); return FDG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
+  if (value) g->knobs[name] = value; else g->knobs.erase(name);
+  parse_launch_cfg(g);
+  if (g->cx_twin) { if (value) g->cx_twin->knobs[name] = value; else g->cx_twin->knobs.erase(name); parse_launch_cfg(g->cx_twin); }
+  return FDG_OK;
+}
+// Process defaults: what handles created from now on start with, and what the entry points without a handle see (fdg_leaf_eval_device).
+int fdg_set_default_option(const char *name, const char *value) {
+  if (!name || std::strncmp(name, "FDG_", 4) != 0) { set_error("option names start with FDG_"); return FDG_E_INVALID; }
+  fdg::set_default_knob(name, value);
+  return FDG_OK;
+}
+const char *fdg_get_default_option(const char *name) { return name ? fdg::knob(name) : nullptr; }   // (the calling thread is inside no handle's entry point: the defaults)
+const char *fdg_graph_get_option(const fdg_graph *g, const char *name) {
+  if (!g || !name) return nullptr;
+  auto it = g->knobs.find(name);
+  return it == g->knobs.end() ? nullptr : it->second.c_str();
 }
 
 // Which of the reference's two evaluators the handle reproduces bit for bit (include/fdg.h).  Before any specialisation.
@@ -1194,6 +1245,7 @@ int fdg_graph_set_association(fdg_graph *g, int assoc) {
   if (!g) { set_error("null handle"); return FDG_E_INVALID; }
   if (assoc != FDG_ASSOC_STATIC && assoc != FDG_ASSOC_INTERP) { set_error("unknown association"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
   const bool want = assoc == FDG_ASSOC_INTERP;
   if (g->prog.assoc_interp == want) return FDG_OK;
   if (!g->code_object.empty() || !g->alt_code.empty() || !g->fused_code.empty() || !g->mc_code.empty() || g->cx_twin || g->mc_route ||
@@ -1209,6 +1261,7 @@ int fdg_graph_set_association(fdg_graph *g, int assoc) {
 int fdg_graph_release_device(fdg_graph *g) {
   if (!g) return FDG_OK;
   std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
   if (g->d_code) { hipFree(g->d_code); g->d_code = nullptr; }
   if (g->d_root_live) { hipFree(g->d_root_live); g->d_root_live = nullptr; }
   {
@@ -1254,6 +1307,7 @@ int fdg_graph_query(const fdg_graph *g, fdg_graph_info *o) {
 int fdg_graph_kernel_info(fdg_graph *g, fdg_kernel_info *o) {
   if (!g || !o) { set_error("null argument"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
   std::memset(o, 0, sizeof *o);
   std::snprintf(o->last_kernel, sizeof o->last_kernel, "%s", g->last_kernel ? g->last_kernel : "");
   if (!(g->isa && !g->code_object.empty())) return FDG_OK;
@@ -1274,6 +1328,7 @@ int fdg_graph_kernel_info(fdg_graph *g, fdg_kernel_info *o) {
 }
 
 int fdg_graph_emit_source(const fdg_graph *g, unsigned flags, char **source) {
+  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
   if (!g || !source) { set_error("null argument"); return FDG_E_INVALID; }
   std::string s = emit_hip_source(g->prog, flags);
   char *m = (char *)std::malloc(s.size() + 1);
@@ -1304,6 +1359,7 @@ static fdg::OptParams to_params(const fdg_opt_params *q) {
 int fdg_graph_set_schedule_groups(fdg_graph *g, const uint32_t *group, uint32_t n_node) {
   if (!g) { set_error("null handle"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
   if (!group) { g->prog.sched_group.clear(); return FDG_OK; }
   if (n_node != g->prog.N) { set_error("schedule groups: length differs from n_node"); return FDG_E_INVALID; }
   g->prog.sched_group.assign(group, group + n_node);
@@ -1313,6 +1369,7 @@ int fdg_graph_set_schedule_groups(fdg_graph *g, const uint32_t *group, uint32_t 
 int fdg_graph_set_opt_params(fdg_graph *g, const fdg_opt_params *prm) {
   if (!g || !prm) { set_error("null argument"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
   g->opt = *prm;
   g->has_opt = true;
   return FDG_OK;
@@ -1322,6 +1379,7 @@ static fdg_opt_params get_opt_params(const fdg_graph *g) { return g->opt; }
 
 int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop **ops, uint64_t *n_ops,
                           uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used) {
+  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
   if (!g || !ops || !n_ops) { set_error("null argument"); return FDG_E_INVALID; }
   fdg::OptProgram prog;
   fdg::OptParams prm = to_params(q);
@@ -1343,17 +1401,17 @@ int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop *
 }
 
 // waves of a cooperative workgroup: 8 (two per SIMD, 256 registers each: the second wave covers memory latency) unless asked otherwise
-static uint32_t coop_waves() { const char *e = std::getenv("FDG_COOP_WAVES"); const int n = e ? std::atoi(e) : 8; return n == 4 ? 4u : (n == 16 ? 16u : 8u); }
+static uint32_t coop_waves() { const char *e = fdg::knob("FDG_COOP_WAVES"); const int n = e ? std::atoi(e) : 8; return n == 4 ? 4u : (n == 16 ? 16u : 8u); }
 
 // parameters of the pooled cooperative variant: four waves, one per SIMD, with the AGPR level (eight waves of 256 registers each -- FDG_POOL_WAVES=8 --
 // spill to the panel and compute a quarter of the fold steps twice on the 4-loop vertex functions)
-static uint32_t pool_waves() { const char *e = std::getenv("FDG_POOL_WAVES"); const int n = e ? std::atoi(e) : 4; return n == 8 ? 8u : 4u; }
+static uint32_t pool_waves() { const char *e = fdg::knob("FDG_POOL_WAVES"); const int n = e ? std::atoi(e) : 4; return n == 8 ? 8u : 4u; }
 static fdg::OptParams pool_params(fdg::OptParams q, uint32_t nw) {
   q.n_reg = std::min<uint32_t>(q.n_reg ? q.n_reg : 120, 120);
   q.n_acc = nw >= 8 ? 0 : 124;
   q.n_land = 0;
   q.lookahead_lds = 32;
-  if (const char *e = std::getenv("FDG_POOL_LA_LDS")) q.lookahead_lds = (uint32_t)std::max(1, std::atoi(e));       // experiments
+  if (const char *e = fdg::knob("FDG_POOL_LA_LDS")) q.lookahead_lds = (uint32_t)std::max(1, std::atoi(e));       // experiments
   return q;
 }
 
@@ -1367,6 +1425,7 @@ static void build_pool_auto(const fdg::Lowered &p, const fdg::OptParams &q, fdg:
 }
 
 int fdg_graph_pool_program(const fdg_graph *g, const fdg_opt_params *q, uint32_t wave, fdg_mop **ops, uint64_t *n_ops, uint32_t *info) {
+  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
   if (!g || !ops || !n_ops || wave >= fdg::CoopProgram::MAXW) { set_error("null argument or wave out of range"); return FDG_E_INVALID; }
   fdg::CoopProgram cp;
   const uint32_t nw = pool_waves();
@@ -1377,6 +1436,7 @@ int fdg_graph_pool_program(const fdg_graph *g, const fdg_opt_params *q, uint32_t
 }
 
 int fdg_graph_coop_program(const fdg_graph *g, const fdg_opt_params *q, uint32_t wave, fdg_mop **ops, uint64_t *n_ops, uint32_t *info) {
+  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
   if (!g || !ops || !n_ops || wave >= fdg::CoopProgram::MAXW) { set_error("null argument or wave out of range"); return FDG_E_INVALID; }
   fdg::OptParams prm = to_params(q);
   if (!q || !q->n_acc) prm.n_acc = 124;
@@ -1408,6 +1468,7 @@ static int coop_program_out(const fdg::CoopProgram &cp, uint32_t wave, fdg_mop *
 
 int fdg_graph_mc_program(const fdg_graph *g, const fdg_leaf_tables *tab, const fdg_opt_params *q, fdg_mop **ops, uint64_t *n_ops,
                          uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used) {
+  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
   if (!g || !tab || !ops || !n_ops) { set_error("null argument"); return FDG_E_INVALID; }
   if (tab->n_leaf != g->prog.L) { set_error("leaf tables: n_leaf differs from the graph's"); return FDG_E_INVALID; }
   fdg::LeafSpec ls; ls.tab = tab; ls.kF = tab->kF; ls.beta = tab->beta; ls.lambda = tab->lambda;
@@ -1446,7 +1507,7 @@ static int assemble_isa(const fdg_graph *g, const fdg::OptProgram &prog, const s
     // the code object appears under its final name by rename
     const std::string tmp = base + tmp_suffix();
     if (!write_file(tmp + ".s", src.c_str(), src.size())) { set_error("cannot write " + tmp + ".s"); return FDG_E_JIT; }
-    const char *llvm = std::getenv("FDG_LLVM_BIN");
+    const char *llvm = fdg::knob("FDG_LLVM_BIN");
     const std::string bin = llvm ? llvm : "/opt/rocm/lib/llvm/bin";
     int rc = run_cmd({bin + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", tmp + ".s", "-o", tmp + ".o"}, tmp + ".log");
     if (rc == 0) rc = run_cmd({bin + "/ld.lld", "-shared", tmp + ".o", "-o", tmp + ".hsaco"}, tmp + ".log");
@@ -1568,9 +1629,9 @@ static void install_isa(fdg_graph *g, const fdg::OptProgram &prog, std::vector<c
 // every program of a handle specialised with FDG_SPEC_FAST_MATH fuses products into sums (v_fma_f64)
 static void build_prog(const fdg_graph *g, fdg::OptParams prm, fdg::OptProgram &out) {
   prm.fma = prm.fma || g->isa_fma;
-  if (const char *e = std::getenv("FDG_LA_LDS")) prm.lookahead_lds = (uint32_t)std::max(1, std::atoi(e));       // experiments
-  if (const char *e = std::getenv("FDG_LA_LDS_B")) { if (prm.n_acc) prm.lookahead_lds = (uint32_t)std::max(1, std::atoi(e)); }   // ... one wave per SIMD only
-  if (std::getenv("FDG_ROOTS_LAST") && !g->isa_fma) prm.roots_last = true;   // experiment: every program's root stores back to back at the tile's end (one block of a tile-major root batch)
+  if (const char *e = fdg::knob("FDG_LA_LDS")) prm.lookahead_lds = (uint32_t)std::max(1, std::atoi(e));       // experiments
+  if (const char *e = fdg::knob("FDG_LA_LDS_B")) { if (prm.n_acc) prm.lookahead_lds = (uint32_t)std::max(1, std::atoi(e)); }   // ... one wave per SIMD only
+  if (fdg::knob("FDG_ROOTS_LAST") && !g->isa_fma) prm.roots_last = true;   // experiment: every program's root stores back to back at the tile's end (one block of a tile-major root batch)
   fdg::build_opt_program(g->prog, prm, out);
 }
 
@@ -1583,8 +1644,8 @@ static fdg::OptParams cfg_B() {
 
 // experiment switch: FDG_LAND=<n> AGPR landing slots for the leaf loads of the one-wave configuration (0 = none)
 static void apply_land_env(fdg::OptParams &q) {
-  if (const char *e = std::getenv("FDG_LAND")) q.n_land = q.n_acc ? std::min<uint32_t>((uint32_t)std::max(0, std::atoi(e)), q.n_acc / 2) : 0;
-  if (const char *e = std::getenv("FDG_LAND_LA")) q.lookahead_land = (uint32_t)std::max(1, std::atoi(e));
+  if (const char *e = fdg::knob("FDG_LAND")) q.n_land = q.n_acc ? std::min<uint32_t>((uint32_t)std::max(0, std::atoi(e)), q.n_acc / 2) : 0;
+  if (const char *e = fdg::knob("FDG_LAND_LA")) q.lookahead_land = (uint32_t)std::max(1, std::atoi(e));
 }
 
 static fdg::OptParams auto_program(const fdg_graph *g, fdg::OptProgram &prog) {
@@ -1630,7 +1691,7 @@ static fdg::OptParams cfg_W2T() { fdg::OptParams q; q.n_reg = 14; q.n_lds = 1; q
 static bool auto_program_w2(const fdg_graph *g, fdg::OptProgram &p2) {
   // Measured on MI355X: the wide variant is SLOWER (sigma2 58 % vs 64 % of HBM peak, gv_sigma4 63 % vs
   // 66 %), so it is opt-in (FDG_ISA_W2=1) and kept only as an experiment.
-  if (!std::getenv("FDG_ISA_W2")) return false;
+  if (!fdg::knob("FDG_ISA_W2")) return false;
   const fdg::Lowered &p = g->prog;
   build_prog(g, cfg_W2T(), p2);
   bool ok = p2.supported && p2.n_ld_leaf <= p.n_live_leaf && p2.n_ld_lds + p2.n_st_lds + p2.n_ld_mem + p2.n_st_mem == 0;
@@ -1653,7 +1714,7 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
   //  accumulators would take more than a third of the value registers and the roots go through the column-major scratch)
   // (few roots: eight value registers next to the accumulators are enough -- the tiny-graph configuration of the 2-loop
   //  self-energies keeps 28; many roots must leave the values a working set worth having)
-  if (g->prog.R > 40 && g->prog.R <= 124 && chosen.n_reg >= 100 && !std::getenv("FDG_ISA_NO_FUSED_ACC") && !std::getenv("FDG_ISA_NO_AGPR_ACC")) {
+  if (g->prog.R > 40 && g->prog.R <= 124 && chosen.n_reg >= 100 && !fdg::knob("FDG_ISA_NO_FUSED_ACC") && !fdg::knob("FDG_ISA_NO_AGPR_ACC")) {
     // 41 ... 124 roots (round 4): the accumulators in AGPR pairs -- the file a kernel launched with one wave per SIMD has to itself (the graphs
     // bound by memory are launched that way whatever their registers allow; the one-wave configuration uses it for spills and keeps what
     // the accumulators leave) -- instead of the detour through the root scratch, which cost the 84-root 3-loop vertex function a third.
@@ -1665,7 +1726,7 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
     build_prog(g, q, pa);
     return pa.supported && pa.n_acc_used + g->prog.R <= 124;
   }
-  if (g->prog.R == 0 || g->prog.R > 40 || chosen.n_reg < extra + 8 || (g->prog.R > 16 && chosen.n_reg < extra + 64) || std::getenv("FDG_ISA_NO_FUSED_ACC")) return false;
+  if (g->prog.R == 0 || g->prog.R > 40 || chosen.n_reg < extra + 8 || (g->prog.R > 16 && chosen.n_reg < extra + 64) || fdg::knob("FDG_ISA_NO_FUSED_ACC")) return false;
   fdg::OptParams q = chosen;
   // stay inside the occupancy step of the eval kernel (VGPRs per wave: 64 -> 8 waves/SIMD ... 256 -> 2, 512 -> 1)
   static const uint32_t steps[] = {64, 72, 80, 96, 128, 168, 256, 512};
@@ -1685,10 +1746,10 @@ static bool build_acc_program(const fdg_graph *g, const fdg::OptParams &chosen, 
 // LDS (short prefetch distance).  Not for the tiny-graph configuration (its waves have 5 KB of LDS each; such graphs
 // take the HIP-source companion) nor for graphs of fewer than 16 leaves.
 static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chosen, fdg::OptProgram &pr, fdg::OptParams *qsel = nullptr) {
-  if (g->prog.L < 16 || std::getenv("FDG_ISA_NO_RM")) return 0;
+  if (g->prog.L < 16 || fdg::knob("FDG_ISA_NO_RM")) return 0;
   // (graphs in the tiny-graph configuration too, round 4: their contiguous rows take the linear variant, but rows with padding between them
   //  had only the transposition pass left -- 0.2 of the HBM roof on the 3-loop self-energy; FDG_ISA_RM_TINY=0 restores that)
-  if (chosen.n_reg < 100 && std::getenv("FDG_ISA_RM_TINY") && std::getenv("FDG_ISA_RM_TINY")[0] == '0') return 0;
+  if (chosen.n_reg < 100 && fdg::knob("FDG_ISA_RM_TINY") && fdg::knob("FDG_ISA_RM_TINY")[0] == '0') return 0;
   // One wave per SIMD whatever the leaf-major kernel runs with: 40 KB of LDS per wave hold up to four staging buffers -- the
   // stream of first uses plus the few chunks a schedule keeps coming back to -- and the AGPR level makes up for the LDS
   // slots given away.  (Graphs that stream leaves are bound by latency, not by occupancy: DESIGN.md 6.)  The fewest
@@ -1696,7 +1757,7 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
   // more waves per CU.  A program that would move more than 2.5x the matrix (leaves re-read all over a huge graph)
   // gets no such variant: the chunked transposition in front of the leaf-major kernel is cheaper there.
   const uint32_t n_chunk = (g->prog.L + 15) / 16;
-  const char *e = std::getenv("FDG_ISA_RM_BUFS");
+  const char *e = fdg::knob("FDG_ISA_RM_BUFS");
   // Two waves per SIMD when the program is small enough: the variant is bound by memory latency (one wave per SIMD spends
   // ~46 % of its cycles waiting for its chunks), and what hides latency is a second wave with its own two
   // buffers in flight.  Budget per wave: 256 registers (120 values + the nine address registers, no AGPR level) and
@@ -1704,7 +1765,7 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
   // keep re-fetching within a quarter of the chunk count.
   // (Up to eight chunks -- 128 leaves: with longer rows the two buffers of a wave are too short a window; measured round 4,
   //  profiles/r04_log_rm_bufs.txt: 111 leaves +20 % over one wave per SIMD, 175 leaves -16 %.)
-  const char *ew = std::getenv("FDG_ISA_RM_WAVES");
+  const char *ew = fdg::knob("FDG_ISA_RM_WAVES");
   if (!(ew && std::atoi(ew) == 1) && !e && (n_chunk <= 8 || (ew && std::atoi(ew) == 2))) {
     // (both root orders are tried: in the reference's order the first uses of the leaves walk the row monotonically)
     for (int keep = 0; keep < 2; ++keep) {
@@ -1713,15 +1774,15 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
       q.n_lds = 8;
       q.reserve_pairs = 5;
       q.lookahead_leaf = 48;
-      if (const char *la = std::getenv("FDG_ISA_RM_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
+      if (const char *la = fdg::knob("FDG_ISA_RM_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
       q.keep_root_order = keep != 0;
       q.roots_last = true;             // the R stores of a row back to back: they share cache lines when the roots are row-major too (+7-11 %)
       build_prog(g, q, pr);
-      const char *pp = std::getenv("FDG_ISA_RM_PANEL_PCT");
+      const char *pp = fdg::knob("FDG_ISA_RM_PANEL_PCT");
       if (!pr.supported || (pr.n_ld_mem + pr.n_st_mem) * 100 > pr.n_valu * (uint64_t)(pp ? std::atoi(pp) : 0)) continue;
       uint64_t fetches = 0, gathers = 0;
       fdg::rm_plan_stats(g->prog, pr, 2, fetches, gathers);
-      if (std::getenv("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] two waves per SIMD (root order %d): %u chunks, %llu fetches, %llu gathers with 2 buffers; lds slots %u\n", keep, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, pr.n_lds_used);
+      if (fdg::knob("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] two waves per SIMD (root order %d): %u chunks, %llu fetches, %llu gathers with 2 buffers; lds slots %u\n", keep, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, pr.n_lds_used);
       if (fetches * 4 <= (uint64_t)n_chunk * 5 + 4 && (fetches * 8192 + gathers * 2048) * 2 <= (uint64_t)g->prog.L * 512 * 5) { if (qsel) *qsel = q; return 2; }
     }
   }
@@ -1739,14 +1800,14 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
       q.n_lds = 80u - bufs * 16u - 2u;                             // (two slots lost to the 1 KB alignment of the buffers)
       q.reserve_pairs = 5;
       q.lookahead_leaf = 48;
-      if (const char *la = std::getenv("FDG_ISA_RM_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
+      if (const char *la = fdg::knob("FDG_ISA_RM_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
       q.keep_root_order = keep != 0;
       q.roots_last = true;             // the R stores of a row back to back: they share cache lines when the roots are row-major too (+7-11 %)
       build_prog(g, q, cand);
       if (!cand.supported) { if (keep == 0 && pass == 1) return 0; continue; }
       uint64_t fetches = 0, gathers = 0;
       fdg::rm_plan_stats(g->prog, cand, bufs, fetches, gathers);
-      if (std::getenv("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] one wave per SIMD (root order %d): %u chunks, %llu fetches, %llu gathers with %u buffers, %llu panel accesses, %llu LDS and %llu AGPR moves\n", keep, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, bufs, (unsigned long long)(cand.n_ld_mem + cand.n_st_mem),
+      if (fdg::knob("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] one wave per SIMD (root order %d): %u chunks, %llu fetches, %llu gathers with %u buffers, %llu panel accesses, %llu LDS and %llu AGPR moves\n", keep, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, bufs, (unsigned long long)(cand.n_ld_mem + cand.n_st_mem),
                                                   (unsigned long long)(cand.n_ld_lds + cand.n_st_lds), (unsigned long long)(cand.n_ld_acc + cand.n_st_acc));
       const uint64_t cost = fetches * 8192 + gathers * 2048 + (cand.n_ld_mem + cand.n_st_mem) * 1024;
       if (cost < best_cost) { best_cost = cost; best_fetches = fetches; best_gathers = gathers; best_panel = cand.n_ld_mem + cand.n_st_mem; pr = std::move(cand); if (qsel) *qsel = q; }
@@ -1755,7 +1816,7 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
     if (pass == 0) { if (best_cost != ~0ull && cheap && best_panel == 0) return 4; break; }
     if (!cheap && bufs < 4 && !e) continue;
     {   // (FDG_ISA_RM_MAX_TRAFFIC=<tenths>: the bound on what the variant may move, in tenths of the matrix; default 25)
-      const uint64_t tenths = std::getenv("FDG_ISA_RM_MAX_TRAFFIC") ? (uint64_t)std::max(10, std::atoi(std::getenv("FDG_ISA_RM_MAX_TRAFFIC"))) : 25;
+      const uint64_t tenths = fdg::knob("FDG_ISA_RM_MAX_TRAFFIC") ? (uint64_t)std::max(10, std::atoi(fdg::knob("FDG_ISA_RM_MAX_TRAFFIC"))) : 25;
       if ((best_fetches * 8192 + best_gathers * 2048) * 10 > (uint64_t)g->prog.L * 512 * tenths) return 0;
     }
     return bufs;
@@ -1774,14 +1835,14 @@ struct IsaVariants {
 // The cooperative variant (four waves of a CU on one tile) is assembled for programs whose one-wave form
 // spills to the HBM panel in earnest (more than one panel access per 20 fold steps); FDG_ISA_COOP=1 / 0 forces / forbids.
 static void build_coop(const fdg_graph *g, const fdg::OptProgram &prog, IsaVariants &V) {
-  const char *e = std::getenv("FDG_ISA_COOP");
+  const char *e = fdg::knob("FDG_ISA_COOP");
   if (e && e[0] == '0') return;
   (void)prog;
   fdg::OptParams q = cfg_B();
   q.vn_window = 200;
-  if (const char *x = std::getenv("FDG_COOP_LA_LEAF")) q.lookahead_leaf = (uint32_t)std::atoi(x);
-  if (const char *x = std::getenv("FDG_COOP_LA_MEM")) q.lookahead_mem = (uint32_t)std::atoi(x);
-  if (const char *x = std::getenv("FDG_COOP_LA_LDS")) q.lookahead_lds = (uint32_t)std::atoi(x);
+  if (const char *x = fdg::knob("FDG_COOP_LA_LEAF")) q.lookahead_leaf = (uint32_t)std::atoi(x);
+  if (const char *x = fdg::knob("FDG_COOP_LA_MEM")) q.lookahead_mem = (uint32_t)std::atoi(x);
+  if (const char *x = fdg::knob("FDG_COOP_LA_LDS")) q.lookahead_lds = (uint32_t)std::atoi(x);
   if (!(e && e[0] == '1')) {
     fdg::OptProgram ref;                      // the one-wave program without recomputation decides
     build_prog(g, q, ref);
@@ -1796,13 +1857,13 @@ static void build_coop(const fdg_graph *g, const fdg::OptProgram &prog, IsaVaria
   }
 }
 static void build_variants(const fdg_graph *g, const fdg::OptParams &chosen, bool allow_w2, IsaVariants &V) {
-  V.w2 = allow_w2 && !std::getenv("FDG_ISA_NO_W2") && auto_program_w2(g, V.p2);
+  V.w2 = allow_w2 && !fdg::knob("FDG_ISA_NO_W2") && auto_program_w2(g, V.p2);
   V.acc = build_acc_program(g, chosen, V.pa);
   fdg::OptParams qrm;
   V.rm_bufs = build_rm_program(g, chosen, V.pr, &qrm);
   // fused accumulation of row-major input: the row-major program once more with R + 2 fewer value registers
   V.rm_acc = false;
-  if (V.rm_bufs && V.acc && g->prog.R >= 1 && g->prog.R <= 40 && !std::getenv("FDG_ISA_NO_RM_ACC")) {
+  if (V.rm_bufs && V.acc && g->prog.R >= 1 && g->prog.R <= 40 && !fdg::knob("FDG_ISA_NO_RM_ACC")) {
     qrm.reserve_pairs += g->prog.R + 2;
     qrm.roots_last = false;           // (accumulation: a root is consumed where it is finished)
     build_prog(g, qrm, V.pra);
@@ -1817,7 +1878,7 @@ static void build_variants(const fdg_graph *g, const fdg::OptParams &chosen, boo
 // of the reference's benchmark programs: 2.9 x and 1.1-1.4 x).  FDG_ISA_POOL=1 / 0 forces / forbids.
 static void build_pool(const fdg_graph *g, const fdg::OptProgram &prog, IsaVariants &V) {
   V.pool = fdg::CoopProgram();
-  const char *e = std::getenv("FDG_ISA_POOL");
+  const char *e = fdg::knob("FDG_ISA_POOL");
   if (e && e[0] == '0') return;
   if (g->isa_fma || prog.mc_n_k || prog.mc_n_t) return;
   // (twice the live leaves: the GV vertex function's one-wave program makes 2.9 x, the Parquet one 1.1-1.4 x depending on the configuration
@@ -1827,18 +1888,18 @@ static void build_pool(const fdg_graph *g, const fdg::OptProgram &prog, IsaVaria
   fdg::OptParams q = pool_params(cfg_B(), nw);
   q.vn_window = prog.params.vn_window;
   build_pool_auto(g->prog, q, V.pool, nw);
-  if (std::getenv("FDG_POOL_DEBUG")) std::fprintf(stderr, "[pool] %s: %u waves, %u epochs, %llu fetches for %u leaves, %llu duplicated fold steps (%s)\n", V.pool.supported ? "built" : "not built",
+  if (fdg::knob("FDG_POOL_DEBUG")) std::fprintf(stderr, "[pool] %s: %u waves, %u epochs, %llu fetches for %u leaves, %llu duplicated fold steps (%s)\n", V.pool.supported ? "built" : "not built",
                                                   V.pool.n_wave, V.pool.n_epoch, (unsigned long long)V.pool.n_fetch, g->prog.n_live_leaf, (unsigned long long)V.pool.n_duplicate, V.pool.why.c_str());
 }
 // The linear row-major variant (csrc/fdg_isa.cpp: `rl`): contiguous rows (sample stride == L) of graphs whose 64-row tile, 512 L bytes, leaves
 // room for two waves per CU or more.  One wave per SIMD at most, so the AGPR level is there; a leaf comes back from the image by an LDS read.
 static void build_rl(const fdg_graph *g, const fdg::OptParams &chosen, IsaVariants &V) {
   V.rl = false;
-  const char *e = std::getenv("FDG_ISA_RL");
+  const char *e = fdg::knob("FDG_ISA_RL");
   // Three waves per CU or more (image + eight LDS slots three times into 160 KB: up to 98 leaves): with two, a wave that waits for its
   // tile has one partner to cover it and the variant loses to the chunked one -- measured at 116 and 155 leaves: 2.26 vs 2.75e9 and
   // 2.34 vs 2.72e9 evaluations/s; equal at 111 (profiles/r04_log_rl_big.txt).  FDG_ISA_RL_MAX_KB overrides the bound on the image.
-  const uint32_t rl_max_bytes = std::getenv("FDG_ISA_RL_MAX_KB") ? (uint32_t)std::atoi(std::getenv("FDG_ISA_RL_MAX_KB")) * 1024u : (160u * 1024u / 3u - 8u * 512u);
+  const uint32_t rl_max_bytes = fdg::knob("FDG_ISA_RL_MAX_KB") ? (uint32_t)std::atoi(fdg::knob("FDG_ISA_RL_MAX_KB")) * 1024u : (160u * 1024u / 3u - 8u * 512u);
   if ((e && e[0] == '0') || g->prog.L < 2 || ((512u * g->prog.L + 1023u) & ~1023u) > rl_max_bytes || g->isa_fma) return;
   fdg::OptParams q = cfg_B();
   q.vn_window = chosen.vn_window;
@@ -1847,12 +1908,12 @@ static void build_rl(const fdg_graph *g, const fdg::OptParams &chosen, IsaVarian
   q.lookahead_leaf = 32;
   q.pool_leaves = true;          // (an evicted leaf is read again from the image: cheap, and it is not parked anywhere)
   q.roots_last = true;
-  if (const char *la = std::getenv("FDG_ISA_RL_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
+  if (const char *la = fdg::knob("FDG_ISA_RL_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
   build_prog(g, q, V.prl);
   V.rl = V.prl.supported && V.prl.n_ld_mem + V.prl.n_st_mem == 0;
   // fused accumulation over the same rows: R accumulators, the weight and a temporary above the values
   V.rl_acc = false;
-  if (V.rl && V.acc && g->prog.R >= 1 && g->prog.R <= 40 && !std::getenv("FDG_ISA_NO_RL_ACC")) {
+  if (V.rl && V.acc && g->prog.R >= 1 && g->prog.R <= 40 && !fdg::knob("FDG_ISA_NO_RL_ACC")) {
     q.reserve_pairs += g->prog.R + 2;
     q.n_reg = std::min<uint32_t>(q.n_reg, (256u - 6u - 2u * (g->prog.R + 2) - 2u - 8u) / 2u);
     q.roots_last = false;            // (a root is consumed where it is finished)
@@ -1960,7 +2021,7 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   if (hipMalloc(&d_root, std::max<size_t>(1, (size_t)Bt * p.R) * 8) != hipSuccess) { hipFree(d_leaf); set_error("hipMalloc failed"); return FDG_E_NOMEM; }
   // the batch the candidates are timed on is TILE-MAJOR (round 4: the layout a driver that owns its batch should allocate, bench.py's default;
   // the larger graphs gain 12-14 % over leaf-major on it and do not always prefer the same configuration); FDG_TUNE_LEAF_MAJOR=1: as before
-  const bool tune_tiled = std::getenv("FDG_TUNE_LEAF_MAJOR") == nullptr;
+  const bool tune_tiled = fdg::knob("FDG_TUNE_LEAF_MAJOR") == nullptr;
   if (p.L) {
     if (tune_tiled) hipLaunchKernelGGL(fdg_fill_uniform_tiled, dim3(4096), dim3(256), 0, 0, d_leaf, Bt, p.L, 1L, 64L, 64L * (long)p.L, (uint64_t)1234, (uint64_t)0);
     else hipLaunchKernelGGL(fdg_fill_uniform, dim3(4096), dim3(256), 0, 0, d_leaf, Bt, p.L, 1L, Bt, (uint64_t)1234, (uint64_t)0, 0);
@@ -1979,7 +2040,7 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
     if (c == cand.size()) {
       // second stage (FDG_TUNE_LAND=1 only: measured neutral to -5 % on every one-wave kernel, profiles/r03_log_agpr_landing.txt):
       // the best one-wave configuration once more with AGPR landing slots for its leaf loads
-      if (!std::getenv("FDG_TUNE_LAND") || cand.size() != n_first_stage || best < 0 || cand[best].n_acc < 64) break;
+      if (!fdg::knob("FDG_TUNE_LAND") || cand.size() != n_first_stage || best < 0 || cand[best].n_acc < 64) break;
       for (uint32_t nl : {16u, 32u, 48u}) { fdg::OptParams q = cand[best]; q.n_land = nl; cand.push_back(q); }
     }
     fdg::OptProgram prog;
@@ -2008,7 +2069,7 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
       hipEventElapsedTime(&ms, e0, e1);
       ms_min = std::min(ms_min, ms);
     }
-    if (std::getenv("FDG_TUNE_VERBOSE")) std::fprintf(stderr, "[tune] %s land %u: %.3f ms per 8 launches of %ld (%llu ops, %llu leaf loads, %llu panel)\n", to_line(cand[c]).c_str(), cand[c].n_land, ms_min, Bt,
+    if (fdg::knob("FDG_TUNE_VERBOSE")) std::fprintf(stderr, "[tune] %s land %u: %.3f ms per 8 launches of %ld (%llu ops, %llu leaf loads, %llu panel)\n", to_line(cand[c]).c_str(), cand[c].n_land, ms_min, Bt,
                                                       (unsigned long long)prog.n_valu, (unsigned long long)prog.n_ld_leaf, (unsigned long long)(prog.n_ld_mem + prog.n_st_mem));
     if (ms_min < best_ms) { best_ms = ms_min; best = (int)c; }
   }
@@ -2064,7 +2125,7 @@ static int autotune_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
 
 static int specialize_isa(fdg_graph *g, const std::string &dir, unsigned flags) {
   if (!has_opt_params(g)) {
-    if (!std::getenv("FDG_IGNORE_TUNED")) {          // (with the switch and FDG_SPEC_AUTOTUNE: tune again, overwriting the remembered choice)
+    if (!fdg::knob("FDG_IGNORE_TUNED")) {          // (with the switch and FDG_SPEC_AUTOTUNE: tune again, overwriting the remembered choice)
       const int t = use_tuned(g, dir, flags);        // a remembered on-device choice wins (no device needed to use it)
       if (t != 0) return t < 0 ? t : FDG_OK;
     }
@@ -2121,7 +2182,7 @@ bool fdg_mc_isa_supported(fdg_graph *g, const fdg_leaf_tables *tab, std::string 
   // (measured: 5-loop self-energy, 13 000 ops, one kernel 1.67x faster; its Taylor expansion, 479 leaves and 79 000 ops, 0.9x;
   // the 4-loop vertex function of example/benchmark.jl, 984 leaves and 65 000 ops, 1.68x).  The other route writes and reads
   // 16 bytes per leaf and sample, which is worth some tens of fold steps: the budget grows with the number of leaves.
-  if (std::getenv("FDG_MC_DEBUG"))
+  if (fdg::knob("FDG_MC_DEBUG"))
     std::fprintf(stderr, "[mc] one-kernel program: valu %llu ld_leaf %llu ld_mem %llu st_mem %llu ld_lds %llu st_lds %llu\n", (unsigned long long)prog.n_valu,
                  (unsigned long long)prog.n_ld_leaf, (unsigned long long)prog.n_ld_mem, (unsigned long long)prog.n_st_mem, (unsigned long long)prog.n_ld_lds, (unsigned long long)prog.n_st_lds);
   if (recommended) *recommended = prog.supported && prog.n_valu <= 40000 + 30ull * g->prog.L;
@@ -2245,7 +2306,7 @@ int fdg_mc_isa_run(fdg_graph *g, int mode, const double *d_K, int64_t ks, int64_
   // first (8 (n_k + n_tau) bytes per sample each way).
   const bool in_place = ks == 1 && ts == 1;
   int64_t Bc = std::min<int64_t>((B + 63) & ~63ll, 1ll << 22);
-  if (const char *env = std::getenv("FDG_MC_CHUNK")) { const long long c = std::atoll(env); if (c >= 64) Bc = std::min<int64_t>((c + 63) & ~63ll, (B + 63) & ~63ll); }
+  if (g->cfg.mc_chunk >= 64) Bc = std::min<int64_t>((g->cfg.mc_chunk + 63) & ~63ll, (B + 63) & ~63ll);
   if (!in_place) {
     const size_t need = (size_t)Bc * n_in * sizeof(double);
     if (g->ws4_bytes < need) {
@@ -2303,6 +2364,7 @@ extern "C" {
 int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
   if (!g) { set_error("null handle"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
   if (flags & FDG_SPEC_ISA) {
     g->isa_fma = (flags & FDG_SPEC_FAST_MATH) != 0;
     std::string dir0;
@@ -2321,7 +2383,7 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
   std::vector<char> co;
   if (!read_cached(dir, std::string("fdg_") + hbuf + ".hsaco", co)) {
     std::string log;
-    const char *force = std::getenv("FDG_JIT");  // "hipcc" forces the subprocess path
+    const char *force = fdg::knob("FDG_JIT");  // "hipcc" forces the subprocess path
     int rc = -1;
     if (!(force && std::strcmp(force, "hipcc") == 0)) rc = compile_hiprtc(src, fast, co, log);
     if (rc != 0) {
@@ -2358,6 +2420,7 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
 }
 
 int fdg_graph_create_complex_view(const fdg_graph *g, fdg_graph **out) {
+  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
   if (!g || !out) { set_error("null argument"); return FDG_E_INVALID; }
   *out = nullptr;
   fdg::RealTwinTable t;
@@ -2369,7 +2432,9 @@ int fdg_graph_create_complex_view(const fdg_graph *g, fdg_graph **out) {
   d.op = t.op.empty() ? &no_op : t.op.data(); d.power = t.power.empty() ? &no_pw : t.power.data();
   d.child_off = t.off.data(); d.child_idx = t.idx.empty() ? &no_u : t.idx.data(); d.child_fac = t.fac.empty() ? &no_f : t.fac.data();
   d.root_slot = t.root_slot.empty() ? &no_u : t.root_slot.data();
-  return fdg_graph_create(&d, out);
+  const int rc_twin = fdg_graph_create(&d, out);
+  if (!rc_twin && *out) { (*out)->knobs = g->knobs; parse_launch_cfg(*out); }     // the view inherits the handle's options
+  return rc_twin;
 }
 
 // Element types other than Float64: one HIP-source kernel per (graph, type), JIT-compiled like the Float64 HIP-source kernels
@@ -2379,6 +2444,7 @@ int fdg_graph_specialize_typed(fdg_graph *g, int dtype, const char *cache_dir, u
   if (dtype == FDG_DT_F64) return FDG_OK;                       // the handle's ordinary kernels
   if (dtype < 0 || dtype > FDG_DT_C32) { set_error("unknown element type"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
   if (dtype == FDG_DT_C64 && (flags & FDG_SPEC_ISA) && !g->cx_twin_tried) {
     // ComplexF64 rows (a row of a row-major [B, L] matrix is 2 L doubles re, im, ...): the graph spelled out on real and imaginary
     // parts is an ordinary Float64 graph; when the optimizing back end gives it the in-place row-major variant, such rows take that
@@ -2405,7 +2471,7 @@ int fdg_graph_specialize_typed(fdg_graph *g, int dtype, const char *cache_dir, u
   std::vector<char> co;
   if (!read_cached(dir, std::string("fdg_") + hbuf + ".hsaco", co)) {
     std::string log;
-    const char *force = std::getenv("FDG_JIT");
+    const char *force = fdg::knob("FDG_JIT");
     int rc = -1;
     if (!(force && std::strcmp(force, "hipcc") == 0)) rc = compile_hiprtc(src, false, co, log);
     if (rc != 0) {
@@ -2431,6 +2497,7 @@ int fdg_eval_device_typed(fdg_graph *g, int dtype, const void *d_leaf, int64_t s
   if (dtype < 0 || dtype > FDG_DT_C32) { set_error("unknown element type"); return FDG_E_INVALID; }
   if (B < 0) { set_error("n_sample < 0"); return FDG_E_INVALID; }
   std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs);
   if (g->typed_code[dtype].empty()) { set_error("fdg_eval_device_typed: call fdg_graph_specialize_typed for this element type first"); return FDG_E_INVALID; }
   if (B == 0 || g->prog.R == 0) return FDG_OK;
   if ((g->prog.L && !d_leaf) || !d_root) { set_error("null device buffer"); return FDG_E_INVALID; }
@@ -2514,12 +2581,13 @@ int fdg_eval_strided(fdg_graph *g, const double *leaf, int64_t ss, int64_t ls, d
     set_error("host matrices must be row-major (value stride 1, sample stride >= row length) or column-major (sample stride 1, value stride >= n_sample)");
     return FDG_E_INVALID;
   }
-  { std::lock_guard<std::mutex> lk(g->mu); int rc = ensure_device(g); if (rc) return rc; }
+  { std::lock_guard<std::mutex> lk(g->mu);
+  fdg::KnobScope knob_scope(&g->knobs); int rc = ensure_device(g); if (rc) return rc; }
   // host buffers of any size: the batch goes through the device in chunks of at most ~2 GiB (FDG_EVAL_CHUNK
   // samples overrides, for tests), so device memory bounds nothing.  The device copy keeps the host's layout: a
   // column-major (Julia) matrix arrives leaf-major, the layout the ISA kernel is built around -- no transposition anywhere.
   int64_t chunk = std::max<int64_t>(65536, (int64_t)((2ull << 30) / (8ull * (uint64_t)std::max<int64_t>(L + R, 1))));
-  if (const char *e = std::getenv("FDG_EVAL_CHUNK")) chunk = std::max<int64_t>(1, std::atoll(e));
+  if (g->cfg.eval_chunk) chunk = std::max<int64_t>(1, (int64_t)g->cfg.eval_chunk);
   chunk = std::min<int64_t>(chunk, B);
   double *dl = nullptr, *dr = nullptr;
   HIP_TRY(hipMalloc(&dl, (size_t)std::max<int64_t>(1, chunk * L) * 8));
@@ -2565,7 +2633,7 @@ int fdg_copy_device(double *d_dst, const double *d_src, int64_t n, void *stream)
   if (!d_dst || !d_src || (((uintptr_t)d_dst | (uintptr_t)d_src) & 15)) { set_error("fdg_copy_device: null or not 16-byte aligned"); return FDG_E_INVALID; }
   const long n16 = (long)(n / 2);
   const long grid = std::max<long>(1, std::min<long>(n16 / 1024, 65536L));
-  if (!std::getenv("FDG_COPY_PLAIN"))     // non-temporal accesses: 5.96 TB/s against 5.53 (the ceiling a stream is measured against)
+  if (!fdg::knob("FDG_COPY_PLAIN"))     // non-temporal accesses: 5.96 TB/s against 5.53 (the ceiling a stream is measured against)
     hipLaunchKernelGGL(fdg_copy16_nt, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const fdg_v2d *)d_src, (fdg_v2d *)d_dst, n16);
   else
     hipLaunchKernelGGL(fdg_copy16, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const fdg_v2d *)d_src, (fdg_v2d *)d_dst, n16);

@@ -247,6 +247,23 @@ function batch_alloc(bytes::Integer; chunk_bytes::Integer=0)
 end
 batch_free(p::Ptr{Cvoid}) = _fdg_check(ccall((:fdg_batch_free, _libfdg), Cint, (Ptr{Cvoid},), p))
 
+# The two arrays of a tile-major batch of `f` -- Array{Float64,3}(64, L, T) and (64, R, T) on the device -- with the root chunks chosen by
+# timing f's own kernel on (leaf window, root chunk) pairs (fdg_batch_alloc_pair, include/fdg.h).  Returns (d_leaf, d_root, info bytes);
+# release each pointer with batch_free.  What a Monte-Carlo driver that evaluates (not only accumulates) should allocate its batch with.
+function batch_alloc_pair(f::GraphFunc, n_sample::Integer; chunk_bytes::Integer=0, calibrate::Bool=true)
+    dl = Ref{Ptr{Cvoid}}(C_NULL); dr = Ref{Ptr{Cvoid}}(C_NULL)
+    info = zeros(UInt8, 128)                 # fdg_batch_pair_info (112 bytes)
+    _fdg_check(ccall((:fdg_batch_alloc_pair, _libfdg), Cint, (Ptr{Cvoid}, Int64, Csize_t, Cuint, Ref{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}, Ptr{UInt8}),
+        f.handle, n_sample, chunk_bytes, Cuint(calibrate ? 1 : 0), dl, dr, info))
+    return Ptr{Float64}(dl[]), Ptr{Float64}(dr[]), info
+end
+
+# Options of a handle (what used to be FDG_* environment switches; the library reads the environment once per process): set_option!(f, "FDG_ISA_NO_POOL", "1")
+set_option!(f::GraphFunc, name::AbstractString, value::AbstractString) =
+    _fdg_check(ccall((:fdg_graph_set_option, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Cstring), f.handle, name, value))
+unset_option!(f::GraphFunc, name::AbstractString) =
+    _fdg_check(ccall((:fdg_graph_set_option, _libfdg), Cint, (Ptr{Cvoid}, Cstring, Ptr{UInt8}), f.handle, name, C_NULL))
+
 # acc[k] += sum_b weight[b] * root_k(b), everything on device
 function accumulate_device!(f::GraphFunc, d_acc::Ptr{Float64}, d_leaf::Ptr{Float64}, d_weight::Ptr{Float64}, B::Integer;
     leaf_strides=(1, B), stream::Ptr{Cvoid}=C_NULL)

@@ -150,6 +150,24 @@ int fdg_graph_query(const fdg_graph *g, fdg_graph_info *info);
 #define FDG_ASSOC_INTERP 1
 int fdg_graph_set_association(fdg_graph *g, int assoc);
 
+/* Options of a handle.  The library never reads the process environment while it specialises or launches: the FDG_* variables an
+ * installation may set (FDG_CACHE_DIR, FDG_CACHE_RO_DIR, FDG_CACHE_TRUST, FDG_LLVM_BIN, FDG_HIPCC, FDG_JIT, FDG_MC_ROUTE,
+ * FDG_EVAL_CHUNK, FDG_MC_CHUNK, FDG_SM_CHUNK_MB, FDG_IGNORE_TUNED, FDG_LEAF_GENERIC, FDG_TUNE_VERBOSE, FDG_ISA_[NO_]POOL, FDG_ISA_[NO_]RL)
+ * are copied ONCE per process, every handle starts with a copy, and a handle's behaviour is a function of its own options from then on.
+ * fdg_graph_set_option changes one (value NULL: removes it) -- the same names, plus the variant selectors and tuning knobs the tests and dev
+ * tools use (FDG_ISA_W2, FDG_ISA_COOP, FDG_COOP_WAVES, FDG_ISA_NO_FUSED_ACC, FDG_ROOT_SCRATCH_MB, ...).  Options that shape
+ * a kernel must be set before the fdg_graph_specialize* call that builds it; options of the launch path (FDG_ISA_NO_*, FDG_*_CHUNK*,
+ * FDG_ROOT_SCRATCH_*, FDG_ISA_WAVES_PER_CU, FDG_ISA_OVERSUB, FDG_ISA_MEM_*) take effect with the next call: they are parsed into the
+ * handle here, and between an evaluation entry point and hipModuleLaunchKernel nothing is looked up by name.  Thread-safe against
+ * concurrent launches of the same handle (taken under the handle's mutex).  Names must start with "FDG_".  fdg_graph_get_option returns
+ * the value (owned by the handle, valid until the option changes) or NULL.  No counterpart in the reference. */
+int fdg_graph_set_option(fdg_graph *g, const char *name, const char *value);
+const char *fdg_graph_get_option(const fdg_graph *g, const char *name);
+/* The process defaults: what handles created AFTER the call start with, and what the entry points that take no handle see
+ * (fdg_leaf_eval_device*: FDG_LEAF_GENERIC).  Initialised from the environment at first use (supported names only). */
+int fdg_set_default_option(const char *name, const char *value);
+const char *fdg_get_default_option(const char *name);   /* valid until the calling thread's fourth next call of this function */
+
 /* What the specialised kernels of a handle execute per evaluation and which of them the last device call launched --
  * the figures a roofline needs (bench.py: executed fold steps against the fp64 issue peak, bytes against HBM) without
  * guessing on the host side which variant the library picked.  Counts are per sample (one lane); slot 0 = the evaluator

@@ -79,10 +79,10 @@ def test_interp_association_program_replays_to_eval_interp(libfdg, seed):
 
 
 @pytest.mark.parametrize("name", ["sigma4_standin", "synthetic_small"])
-def test_interp_association_cooperative_program(libfdg, monkeypatch, name):
+def test_interp_association_cooperative_program(libfdg, monkeypatch, name, fdgopt):
     """the stand-ins have thousands of scaled operands inside products (+-0.5, +-2: exact) -- the cooperative schedule keeps
     the interpreter's association too"""
-    monkeypatch.setenv("FDG_COOP_WAVES", "4")
+    fdgopt.set("FDG_COOP_WAVES", "4")
     t = workloads.get(name)
     h = capi.GraphHandle(t)
     h.set_association(capi.FDG_ASSOC_INTERP)
@@ -106,9 +106,9 @@ def test_association_is_chosen_before_specialisation(libfdg, tmp_path):
         fd.compile_table(t, association="julia")
 
 
-def test_interp_association_in_the_emitted_hip_source(libfdg, monkeypatch):
+def test_interp_association_in_the_emitted_hip_source(libfdg, monkeypatch, fdgopt):
     """statement-order text (FDG_HIP_TABLE_ORDER=1): a scaled operand is parenthesised before it is folded"""
-    monkeypatch.setenv("FDG_HIP_TABLE_ORDER", "1")
+    fdgopt.set("FDG_HIP_TABLE_ORDER", "1")
     t = scaled_products_table()
     h = capi.GraphHandle(t)
     static_src = h.emit_source()

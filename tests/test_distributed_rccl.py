@@ -77,3 +77,35 @@ def test_gpus_shard_and_reduce_through_the_c_abi(tmp_path, world):
     assert all(np.array_equal(res[0][0], res[r][0]) for r in range(1, world))         # every rank holds the same total
     assert np.all(np.abs(res[0][0] - ref.sum(axis=0)) <= 1e-12 * scale)             # sum order differs with the rank count
     assert np.allclose(res[0][1], scale, rtol=1e-12)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("comm", ["fdg", "torch"])
+def test_the_drivers_own_multi_gpu_command_line(world, comm):
+    """the first multi-GPU node that runs the suite also runs the driver's exact command -- `python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` --
+    with both carriers of the one collective (RCCL through libfdg's fdg_comm_*, and torch.distributed's nccl backend), and reads the
+    one stdout line: whole-job value, n_gpus, weak scaling, config 5's shards.  No scaling curve exists until this has run on such a node."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--comm", comm, "--samples", "4000000", "--no-mc-step",
+           "--secondary", "sigma2:tile_major"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["steps"] == 2 and line["value"] > 0
+    c5 = line["config5"]
+    assert "error" not in c5 and c5["n_gpus"] == world and c5["total_samples"] >= 1_000_000_000

@@ -196,7 +196,7 @@ def test_accumulate(libfdg, cuda, spec):
 
 @pytest.mark.parametrize("name,B,layout", [("gv_sigma4_taylor2", 300_007, "leaf_major"), ("gv_sigma4", 100_000, "sample_major"),
                                            ("sigma4_standin", 20_011, "leaf_major"), ("sigma2", 200_003, "leaf_major"), ("parquet_sigma2", 131_072, "leaf_major")])
-def test_fused_accumulate_isa(libfdg, cuda, name, B, layout, monkeypatch):
+def test_fused_accumulate_isa(libfdg, cuda, name, B, layout, monkeypatch, fdgopt):
     """The optimizing back end sums w_b * root_k(b) in registers (per-lane partials, one store per wave at the
     end) instead of writing roots.  Same roots bit for bit; only the order of the sum over samples differs from
     the oracle, hence 1e-12 * sum|w root|.  Compared too with the unfused path (roots -> weighted partials)."""
@@ -216,7 +216,7 @@ def test_fused_accumulate_isa(libfdg, cuda, name, B, layout, monkeypatch):
     scale = np.maximum(1.0, np.abs(ref * wn).sum(0))
     assert np.all(np.abs(acc.cpu().numpy() - (ref * wn).sum(0)) <= TOL * scale)
     assert np.all(np.abs(acc1.cpu().numpy() - ref.sum(0)) <= TOL * np.maximum(1.0, np.abs(ref).sum(0)))
-    monkeypatch.setenv("FDG_ISA_NO_FUSED_ACC", "1")
+    fdgopt.set("FDG_ISA_NO_FUSED_ACC", "1")
     f2 = fd.compile_table(t, specialize="isa")
     acc_unfused = f2.accumulate(leaf, w)
     torch.cuda.synchronize()
@@ -280,7 +280,7 @@ def test_config3_parquet_sigma4_at_full_size(libfdg, cuda):
 
 
 @pytest.mark.parametrize("name", ["parquet_sigma4", "gv_sigma4", "gv_sigma5", "sigma2", "gv_sigma4_taylor2"])
-def test_streaming_variant_on_line_aligned_batches(libfdg, cuda, name, monkeypatch):
+def test_streaming_variant_on_line_aligned_batches(libfdg, cuda, name, monkeypatch, fdgopt):
     """Batches whose 64-sample tiles are whole cache lines (column stride a multiple of 16 doubles, bases on a line) take the
     kernels with non-temporal leaf loads and root stores (`fdg_isa_eval_nt`, `fdg_isa_eval_acc_nt`); any other batch the
     plain ones.  Same program, same bits: aligned, misaligned (odd stride; a view that starts 8 bytes into a line) and the
@@ -305,9 +305,12 @@ def test_streaming_variant_on_line_aligned_batches(libfdg, cuda, name, monkeypat
     wr = want * w.cpu().numpy()[:, None]
     for a in (acc, acc_odd):
         assert np.all(np.abs(a.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0)))
-    monkeypatch.setenv("FDG_ISA_NO_STREAMING", "1")
+    f.handle.set_option("FDG_ISA_NO_STREAMING", "1")          # a launch-path option of the existing handle
     assert np.array_equal(run(f, leaf), want)
-    monkeypatch.delenv("FDG_ISA_NO_STREAMING")
+    assert f.kernel_info()["last_kernel"] == "fdg_isa_eval"
+    f.handle.set_option("FDG_ISA_NO_STREAMING", None)
+    assert np.array_equal(run(f, leaf), want)
+    assert f.kernel_info()["last_kernel"] == "fdg_isa_eval_nt"
     # the listing holds both forms
     import tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -385,7 +388,7 @@ def test_config4_taylor_standin_and_special_values(libfdg, cuda, spec):
     assert np.array_equal(np.signbit(got[m]), np.signbit(want[m]))
 
 
-def test_clock_probe_and_oversubscribed_grid(libfdg, cuda, monkeypatch):
+def test_clock_probe_and_oversubscribed_grid(libfdg, cuda, monkeypatch, fdgopt):
     """fdg_clock_probe_device: one sleeping wave on a side stream reports shader-clock ticks per 100 MHz tick while an
     evaluation runs next to it; and the persistent launch gives the same bits whatever the oversubscription factor."""
     import torch
@@ -409,7 +412,8 @@ def test_clock_probe_and_oversubscribed_grid(libfdg, cuda, monkeypatch):
     assert np.array_equal(want, oracle.eval_static(t, leaf[:8192].cpu().numpy()))
     ref = root.clone()
     for fac in ("1", "3", "16"):
-        monkeypatch.setenv("FDG_ISA_OVERSUB", fac)
+        f.handle.set_option("FDG_ISA_OVERSUB", fac)
+        assert f.handle.get_option("FDG_ISA_OVERSUB") == fac
         root.zero_()
         f(root, leaf)
         torch.cuda.synchronize()
@@ -439,7 +443,7 @@ def test_power_of_two_factors_through_ldexp_on_special_values(libfdg, cuda):
     assert not src or "v_ldexp_f64" in src
 
 
-def test_leaf_values_on_device_and_full_mc_step(libfdg, cuda):
+def test_leaf_values_on_device_and_full_mc_step(libfdg, cuda, fdgopt):
     """SURVEY.md 8f row 3 (not fused): (K, T) -> leaves on device with the leafstates tables, then the
     evaluator, then the weighted accumulation -- the loop of example/benchmark.jl:58-87 without leaving the
     GPU.  exp() differs from libm in the last ulp, so this entry point is compared at 1e-13 relative."""
@@ -466,14 +470,14 @@ def test_leaf_values_on_device_and_full_mc_step(libfdg, cuda):
     assert np.isfinite(want).all()
     assert np.all(np.abs(got - want) <= 1e-13 * np.abs(want))
     # the kernel specialised to these tables (default) and the table-driven one give the same bits
-    os.environ["FDG_LEAF_GENERIC"] = "1"
+    fdgopt.set("FDG_LEAF_GENERIC", "1")
     try:
         leaf_g = torch.zeros((L, B), dtype=torch.float64, device=cuda).t()
         capi.leaf_eval_device(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau,
                               kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf_g.data_ptr(), leaf_g.stride(0), leaf_g.stride(1), B, st)
         torch.cuda.synchronize()
     finally:
-        del os.environ["FDG_LEAF_GENERIC"]
+        fdgopt.unset("FDG_LEAF_GENERIC")
     assert torch.equal(leaf_g, leaf)
     # graph on the device-made leaves == oracle on the same (device-made) leaves, bit for bit
     f = fd.compile_table(t, specialize="isa")
@@ -494,11 +498,11 @@ def test_leaf_values_on_device_and_full_mc_step(libfdg, cuda):
     assert e.value.code == capi.FDG_E_UNSUPPORTED
 
 
-def test_two_samples_per_lane_variant(libfdg, cuda, monkeypatch, tmp_path):
+def test_two_samples_per_lane_variant(libfdg, cuda, monkeypatch, tmp_path, fdgopt):
     """The opt-in wide variant of the ISA kernel (FDG_ISA_W2=1; slower on MI355X): full
     128-sample tiles through fdg_isa_eval_w2, the remainder through the 64-sample kernel."""
-    monkeypatch.setenv("FDG_ISA_W2", "1")
-    monkeypatch.setenv("FDG_IGNORE_TUNED", "1")
+    fdgopt.set("FDG_ISA_W2", "1")
+    fdgopt.set("FDG_IGNORE_TUNED", "1")
     for name in ("sigma2", "gv_sigma4"):
         t = workloads.get(name)
         f = fd.compile_table(t, specialize="isa", cache_dir=str(tmp_path), flags=capi.FDG_SPEC_KEEP_SOURCE)
@@ -629,14 +633,14 @@ def test_row_major_variant_eval_accumulate_and_ragged_batches(libfdg, cuda, name
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", ["leaf_major", "tile_major", "sample_major"])
-def test_many_roots_into_a_row_major_matrix_go_through_the_root_scratch(libfdg, cuda, monkeypatch, layout):
+def test_many_roots_into_a_row_major_matrix_go_through_the_root_scratch(libfdg, cuda, monkeypatch, layout, fdgopt):
     """Roots of a graph with 16 roots or more into a row-major [B, R] matrix (compile_Python's root layout, a torch caller's natural tensor): the
     kernels' root stores would be 64 lanes in 64 different rows, so the call evaluates chunk by chunk into the column-major root scratch and a
     transposition writes the caller's rows (+24 % on example/benchmark.jl's 180-root vertex function, +48 % on the 3-loop one).  Same bits as
     column-major roots; several chunks, a ragged last tile, a row pitch wider than R; rows beyond the batch and columns beyond R untouched."""
     import torch
     from feynmandiagram_jl_amd.nodetable import synthetic_parquet_like
-    monkeypatch.setenv("FDG_ROOT_SCRATCH_MB", "1")            # 1 MB of scratch: chunks of 2 688 samples
+    fdgopt.set("FDG_ROOT_SCRATCH_MB", "1")            # 1 MB of scratch: chunks of 2 688 samples
     t = synthetic_parquet_like(n_node=600, n_leaf=40, n_root=48, seed=5)
     L, R, B = t.n_leaf, t.n_root, 70_001
     f = fd.compile_table(t, specialize="isa")
@@ -760,7 +764,7 @@ def test_auto_backend_row_major_companion(libfdg, cuda):
         h.specialize(None, capi.FDG_SPEC_ROW_MAJOR_COMPANION)
 
 
-def test_host_buffers_in_chunks(libfdg, cuda, monkeypatch):
+def test_host_buffers_in_chunks(libfdg, cuda, monkeypatch, fdgopt):
     """fdg_eval (host arrays in, host arrays out) streams the batch through the device in chunks; a tiny chunk
     size must give the same bits, including root entries the graph does not assign."""
     t = workloads.get("synthetic_small")
@@ -768,14 +772,14 @@ def test_host_buffers_in_chunks(libfdg, cuda, monkeypatch):
     want = oracle.eval_static(t, h_leaf, np.full((10_007, t.n_root), -2.5))
     for spec in ("isa", False):
         f = fd.compile_table(t, specialize=spec)
-        monkeypatch.setenv("FDG_EVAL_CHUNK", "999")
+        f.handle.set_option("FDG_EVAL_CHUNK", "999")
         got = f(np.full((10_007, t.n_root), -2.5), h_leaf)
-        monkeypatch.delenv("FDG_EVAL_CHUNK")
+        f.handle.set_option("FDG_EVAL_CHUNK", None)
         assert np.array_equal(got, want)
         assert np.array_equal(f(np.full((10_007, t.n_root), -2.5), h_leaf), want)
 
 
-def test_mc_step_routes_on_large_graph(libfdg, cuda, monkeypatch):
+def test_mc_step_routes_on_large_graph(libfdg, cuda, monkeypatch, fdgopt):
     """The split route of fdg_graph_specialize_fused (specialised leaf kernel -> chunk of leaves -> the handle's ISA
     evaluator, what a large graph gets when the one-kernel ISA route does not apply) and FDG_MC_ROUTE=fused (the single
     compiler-scheduled kernel): both give the bits of the hand-written unfused sequence."""
@@ -802,7 +806,7 @@ def test_mc_step_routes_on_large_graph(libfdg, cuda, monkeypatch):
     assert np.array_equal(want.cpu().numpy(), oracle.eval_static(t, leaf.cpu().numpy()))
     tab, _keep = capi.make_leaf_tables(*args)
     for route in ("split", "fused"):       # (the default on an ISA-specialised handle is the one-kernel route: test below)
-        monkeypatch.setenv("FDG_MC_ROUTE", route)
+        fdgopt.set("FDG_MC_ROUTE", route)
         g = fd.compile_table(t, specialize="isa")
         g.handle.specialize_fused(tab)
         root = torch.zeros((B, R), dtype=torch.float64, device=cuda)
@@ -817,7 +821,7 @@ def test_mc_step_routes_on_large_graph(libfdg, cuda, monkeypatch):
         assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0))), route
 
 
-def test_mc_step_with_high_interaction_orders(libfdg, cuda, monkeypatch):
+def test_mc_step_with_high_interaction_orders(libfdg, cuda, monkeypatch, fdgopt):
     """Interaction counter-terms above order 3 (`^order`, example/benchmark.jl:76-77: pow_body).  The leaf kernel +
     evaluator route gives the bits of the hand-written sequence (leaf kernel, then graph) on any handle; the one-kernel
     route of the optimizing back end -- now the default on an ISA handle for these tables too -- spells pow_body out in
@@ -842,11 +846,11 @@ def test_mc_step_with_high_interaction_orders(libfdg, cuda, monkeypatch):
     tab, _keep = capi.make_leaf_tables(*args)
     for spec, route in (("isa", "split"), (True, None), ("isa", "isa")):
         if route:
-            monkeypatch.setenv("FDG_MC_ROUTE", route)
+            fdgopt.set("FDG_MC_ROUTE", route)
         f = fd.compile_table(t, specialize=spec)
         want = f(None, leaf)
         f.handle.specialize_fused(tab)
-        monkeypatch.delenv("FDG_MC_ROUTE", raising=False)
+        fdgopt.unset("FDG_MC_ROUTE")
         root = torch.zeros((B, R), dtype=torch.float64, device=cuda)
         f.handle.mc_eval_device(dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, kF, beta, lam, root.data_ptr(), R, 1, B, st)
         torch.cuda.synchronize()
@@ -902,13 +906,13 @@ def test_entry_points_are_graph_capturable(libfdg, cuda):
 
 @pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("name", ["sigma4_standin", "sigma4_worstcase", "gv_sigma5", "synthetic_small"])
-def test_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_path, name, waves):
+def test_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_path, name, waves, fdgopt):
     """fdg_isa_eval_coop: four or eight waves of a CU evaluate one 64-sample tile together, each on its share of the graph,
     values crossing through shared LDS slots between s_barrier epochs.  Forced here on graphs that would not
     ask for it; ragged and single-tile batches, more tiles than workgroups; bit for bit against the oracle."""
     import torch
-    monkeypatch.setenv("FDG_ISA_COOP", "1")
-    monkeypatch.setenv("FDG_COOP_WAVES", str(waves))
+    fdgopt.set("FDG_ISA_COOP", "1")
+    fdgopt.set("FDG_COOP_WAVES", str(waves))
     t = workloads.get(name)
     cache = tmp_path / "c"
     cache.mkdir(mode=0o700)
@@ -922,14 +926,14 @@ def test_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_path, name
         torch.cuda.synchronize()
         want = oracle.eval_static(t, leaf.cpu().numpy(), np.full((B, t.n_root), -3.0))
         assert np.array_equal(root.cpu().numpy(), want), (name, B)
-    monkeypatch.setenv("FDG_ISA_NO_COOP", "1")          # the same handle through its one-wave kernel: the same bits
+    f.handle.set_option("FDG_ISA_NO_COOP", "1")          # the same handle through its one-wave kernel: the same bits
     root2 = torch.zeros_like(root)
     f(root2, leaf)
     torch.cuda.synchronize()
     assert torch.equal(root, root2)
 
 
-def test_host_matrices_in_either_order(libfdg, cuda):
+def test_host_matrices_in_either_order(libfdg, cuda, fdgopt):
     """fdg_eval_strided: host matrices row-major (compile_Python's layout) or column-major (a Julia Matrix), leaves and
     roots independently, padded leaf rows, chunked through the device -- the same bits, no transposition copy."""
     t = workloads.get("gv_sigma4")
@@ -937,7 +941,7 @@ def test_host_matrices_in_either_order(libfdg, cuda):
     B, L, R = 10_007, t.n_leaf, t.n_root
     leaf = oracle.philox_uniform(B, L + 3, 31)            # three columns more than the graph reads
     want = oracle.eval_static(t, leaf)
-    os.environ["FDG_EVAL_CHUNK"] = "4096"
+    f.handle.set_option("FDG_EVAL_CHUNK", "4096")
     try:
         for lorder in ("C", "F"):
             for rorder in ("C", "F"):
@@ -945,7 +949,7 @@ def test_host_matrices_in_either_order(libfdg, cuda):
                 out = f(root, np.array(leaf, order=lorder))
                 assert out is root and np.array_equal(root, want), (lorder, rorder)
     finally:
-        del os.environ["FDG_EVAL_CHUNK"]
+        f.handle.set_option("FDG_EVAL_CHUNK", None)
 
 
 def test_one_handle_two_streams_concurrently(libfdg, cuda):
@@ -1008,7 +1012,7 @@ def _taylor2_tables():
     return z
 
 
-def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch):
+def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch, fdgopt):
     """Route 3 of the Monte-Carlo step: on a handle specialised with FDG_SPEC_ISA the leaves are computed inside the
     optimizing back end's kernel from the sample's momenta and times (own exp / reciprocal / selects in gfx950
     assembly).  Two statements.  (1) The graph part is exact: the roots are, bit for bit, the oracle's graph applied to
@@ -1035,14 +1039,14 @@ def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch):
         K = rng.uniform(-2.0, 2.0, size=(B, n_loop, dim))
         args = (z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
         tab, _keep = capi.make_leaf_tables(*args)
-        monkeypatch.setenv("FDG_MC_ROUTE", "isa")            # insist: an unsupported table would raise instead of falling back
+        fdgopt.set("FDG_MC_ROUTE", "isa")            # insist: an unsupported table would raise instead of falling back
         g = fd.compile_table(t, specialize="isa")
         g.handle.specialize_fused(tab)
         t_leaves = NodeTable(L, np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(1, np.uint32), np.zeros(0, np.uint32),
                              np.zeros(0), np.arange(L, dtype=np.uint32), "leaves")
         gl = fd.compile_table(t_leaves, specialize="isa")
         gl.handle.specialize_fused(tab)
-        monkeypatch.delenv("FDG_MC_ROUTE")
+        fdgopt.unset("FDG_MC_ROUTE")
         st = torch.cuda.current_stream().cuda_stream
         for kF, beta, lam in ((1.919, 3.0, 1.2), (1.5, 8.0, 0.7)):
             T = rng.uniform(0.0, beta, size=(B, n_tau))
@@ -1086,7 +1090,7 @@ def test_mc_step_in_one_isa_kernel(libfdg, cuda, monkeypatch):
                 assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0)) <= TOL * np.maximum(1.0, np.abs(wr).sum(0))), (name, lay)
 
 
-def test_isa_leaf_formulas_one_by_one(libfdg, cuda, monkeypatch):
+def test_isa_leaf_formulas_one_by_one(libfdg, cuda, monkeypatch, fdgopt):
     """The formulas of the one-kernel route leaf by leaf -- a graph whose roots ARE its leaves -- with green_derive
     orders 0..5 and interaction counter-terms 0..7 on the 4-loop self-energy's leaves: against the oracle within 1e-12
     of the largest Leibniz term (derivatives) / 1e-13 relative (everything else), like the leaf kernels' own test."""
@@ -1106,7 +1110,7 @@ def test_isa_leaf_formulas_one_by_one(libfdg, cuda, monkeypatch):
     T[:30, 1] = T[:30, 0]
     args = (z["leaf_type"], order, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau)
     tab, _keep = capi.make_leaf_tables(*args)
-    monkeypatch.setenv("FDG_MC_ROUTE", "isa")
+    fdgopt.set("FDG_MC_ROUTE", "isa")
     g = fd.compile_table(t, specialize="isa")
     g.handle.specialize_fused(tab)
     X = torch.from_numpy(np.concatenate([K.reshape(B, n_k).T, T.T], axis=0).copy()).to(cuda)
@@ -1167,7 +1171,7 @@ def test_strides_beyond_four_gibibytes(libfdg, cuda):
     torch.cuda.empty_cache()
 
 
-def test_leaf_kernels_with_green_function_derivatives(libfdg, cuda, monkeypatch):
+def test_leaf_kernels_with_green_function_derivatives(libfdg, cuda, monkeypatch, fdgopt):
     """Fermionic leaves of derivative order 1..5 (green_derive, example/benchmark.jl:93-111; the kernels of
     Lehmann.jl restated from their definition and pinned by mpmath vectors in the CPU suite): specialised and
     table-driven leaf kernels agree bit for bit, match the oracle within 1e-12 of the largest Leibniz term, and
@@ -1194,12 +1198,12 @@ def test_leaf_kernels_with_green_function_derivatives(libfdg, cuda, monkeypatch)
     out = {}
     for mode in ("spec", "generic"):
         if mode == "generic":
-            monkeypatch.setenv("FDG_LEAF_GENERIC", "1")
+            fdgopt.set("FDG_LEAF_GENERIC", "1")
         leaf = torch.ones((L, B), dtype=torch.float64, device=cuda).t()
         capi.leaf_eval_device(*args, kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, leaf.data_ptr(), leaf.stride(0), leaf.stride(1), B, st)
         torch.cuda.synchronize()
         out[mode] = leaf
-    monkeypatch.delenv("FDG_LEAF_GENERIC")
+    fdgopt.unset("FDG_LEAF_GENERIC")
     assert torch.equal(out["spec"], out["generic"])
     got = out["spec"].cpu().numpy()
     want = oracle.leaf_values(*args[:6], K, T, kF, beta, lam)

@@ -217,8 +217,8 @@ def test_dead_code_is_dropped_but_roots_kept(libfdg):
     assert info["n_live_node"] == 2 and info["n_live_leaf"] == 2 and info["flops_alg"] == 4
 
 
-def test_emit_source_and_jit_without_device(libfdg, tmp_path, monkeypatch):
-    monkeypatch.setenv("FDG_CACHE_RO_DIR", "")           # (without the shipped kernel_cache: the point is to compile)
+def test_emit_source_and_jit_without_device(libfdg, tmp_path, monkeypatch, fdgopt):
+    fdgopt.set("FDG_CACHE_RO_DIR", "")           # (without the shipped kernel_cache: the point is to compile)
     t = workloads.get("sigma2")
     h = capi.GraphHandle(t)
     src = h.emit_source()
@@ -275,7 +275,7 @@ def test_fused_step_specializes_without_device(libfdg, tmp_path):
     assert e.value.code == capi.FDG_E_UNSUPPORTED                     # "this leaftype ... not implemented!" (benchmark.jl:79)
 
 
-def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypatch, no_shipped_cache):
+def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypatch, no_shipped_cache, fdgopt):
     """Route 3 of fdg_graph_specialize_fused (handle specialised with FDG_SPEC_ISA): the kernels -- eval and accumulate --
     are assembled right away, host-only, and do not depend on kF, beta, lambda (kernel arguments); the assembly carries
     the exp / reciprocal sequences (v_rndne_f64, v_ldexp_f64, v_rcp_f64 followed by the wait state gfx950 needs) and
@@ -309,7 +309,7 @@ def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypa
     order6 = z["leaf_order"].copy()
     order6[np.nonzero(z["leaf_type"] == 1)[0][0]] = 6         # green_derive beyond order 5: example/benchmark.jl:108 "not implemented!"
     tab0, keep0 = capi.make_leaf_tables(z["leaf_type"], order6, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]))
-    monkeypatch.setenv("FDG_MC_ROUTE", "isa")
+    fdgopt.set("FDG_MC_ROUTE", "isa")
     with pytest.raises(capi.FdgError, match="not implemented"):          # the tables are refused as the reference's green_derive refuses them
         fd.compile_table(t, specialize="isa").handle.specialize_fused(tab0, str(tmp_path))
     # interaction counter-terms of any order are covered (pow_body above x^3), except by the compiler-scheduled fused kernel
@@ -317,10 +317,10 @@ def test_one_kernel_isa_step_assembles_without_device(libfdg, tmp_path, monkeypa
     order4[np.nonzero(z["leaf_type"] == 2)[0][0]] = 4
     tab1, keep1 = capi.make_leaf_tables(z["leaf_type"], order4, z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], 3, int(z["n_tau"]))
     fd.compile_table(t, specialize="isa").handle.specialize_fused(tab1, str(tmp_path))
-    monkeypatch.setenv("FDG_MC_ROUTE", "fused")
+    fdgopt.set("FDG_MC_ROUTE", "fused")
     with pytest.raises(capi.FdgError, match="order > 3"):
         fd.compile_table(t, specialize="isa").handle.specialize_fused(tab1, str(tmp_path))
-    monkeypatch.delenv("FDG_MC_ROUTE")
+    fdgopt.unset("FDG_MC_ROUTE")
     fd.compile_table(t, specialize="isa").handle.specialize_fused(tab1, str(tmp_path))
 
 
@@ -366,13 +366,13 @@ def test_package_tables_equal_golden_fixtures():
     assert not os.path.commonpath([workloads.DATA, gold]) == gold
 
 
-def test_cache_directory_is_vetted(tmp_path, monkeypatch):
+def test_cache_directory_is_vetted(tmp_path, monkeypatch, fdgopt):
     """JIT-ed code objects are read back by predictable name, so the cache directory must belong to the caller and must
     not be writable by anybody else; a world-writable artefact inside it is ignored and rebuilt; no shell sees the path."""
     import stat
     from feynmandiagram_jl_amd import capi, workloads
     capi.lib()
-    monkeypatch.setenv("FDG_CACHE_RO_DIR", "")
+    fdgopt.set("FDG_CACHE_RO_DIR", "")
     t = workloads.get("sigma2")
     good = tmp_path / "cache"
     good.mkdir(mode=0o700)
@@ -399,7 +399,7 @@ def test_cache_directory_is_vetted(tmp_path, monkeypatch):
     assert e.value.code == capi.FDG_E_INVALID
 
 
-def test_artefacts_pass_the_vetting_under_any_umask_and_shipped_cache_is_read_only(tmp_path, monkeypatch):
+def test_artefacts_pass_the_vetting_under_any_umask_and_shipped_cache_is_read_only(tmp_path, monkeypatch, fdgopt):
     """ The linker creates its output under the caller's umask -- 0775 under umask 002 --, which the vetting of
     the cache used to refuse, so every specialisation failed after a successful assembly.  The artefact is chmod'ed before
     it is renamed into place, and reads only insist on "owned by the caller or root, not world-writable".  The kernel_cache
@@ -408,7 +408,7 @@ def test_artefacts_pass_the_vetting_under_any_umask_and_shipped_cache_is_read_on
     import stat
     from feynmandiagram_jl_amd import capi, workloads
     capi.lib()
-    monkeypatch.setenv("FDG_CACHE_RO_DIR", "")
+    fdgopt.set("FDG_CACHE_RO_DIR", "")
     t = workloads.get("sigma2")
     old = os.umask(0o002)
     try:
@@ -427,7 +427,7 @@ def test_artefacts_pass_the_vetting_under_any_umask_and_shipped_cache_is_read_on
     # the shipped cache as a read-only secondary: nothing is written into the primary on a hit, nothing ever into the secondary.
     #  What is found THROUGH $FDG_CACHE_RO_DIR must be writable by its owner only -- nothing legitimate is written there under
     # the caller's umask --: the group-writable artefact is not taken (the kernel is assembled again into the primary), the 0644 one is.
-    monkeypatch.setenv("FDG_CACHE_RO_DIR", "/nonexistent:" + str(a))
+    fdgopt.set("FDG_CACHE_RO_DIR", "/nonexistent:" + str(a))
     os.chmod(a, 0o555)
     c = tmp_path / "c"
     c.mkdir(mode=0o700)
@@ -448,8 +448,8 @@ def test_artefacts_pass_the_vetting_under_any_umask_and_shipped_cache_is_read_on
     # no directory given: the library's per-user default, not the package directory
     monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "xdg"))
     (tmp_path / "xdg").mkdir(mode=0o700)
-    monkeypatch.setenv("FDG_CACHE_RO_DIR", "")
-    monkeypatch.delenv("FDG_CACHE_DIR", raising=False)
+    fdgopt.set("FDG_CACHE_RO_DIR", "")
+    fdgopt.unset("FDG_CACHE_DIR")
     capi.GraphHandle(t).specialize(None, capi.FDG_SPEC_ISA)
     assert [p for p in (tmp_path / "xdg" / "fdg").iterdir() if p.suffix == ".hsaco"]
     # an unusable default location (here: group-writable) does not fail the call: a private directory of the process is used
@@ -540,3 +540,41 @@ int main(void) {
     assert v[4] == v[0] and v[5] == v[1]
     leafmap = Compilers.compile_C(graphs, str(tmp_path / "out.c"), datatype="Float32")
     assert "float *root" in (tmp_path / "out.c").read_text() and len(leafmap) == 8
+
+
+def test_handle_options_replace_the_environment(libfdg, monkeypatch):
+    """a handle's behaviour is a function of its own options.  The FDG_* environment is read once per process (the
+    supported names only); after that neither a launch nor a specialisation looks at it -- options travel through fdg_graph_set_option /
+    fdg_set_default_option -- and no source of the library calls getenv on an FDG_* name."""
+    import glob
+    import re
+    t = workloads.get("sigma2")
+    h = capi.GraphHandle(t)
+    assert h.get_option("FDG_ISA_W2") is None
+    monkeypatch.setenv("FDG_ISA_W2", "1")                        # the environment after the library's first use: not seen by anything
+    monkeypatch.setenv("FDG_MC_ROUTE", "isa")
+    assert capi.GraphHandle(t).get_option("FDG_ISA_W2") is None and capi.get_default_option("FDG_MC_ROUTE") is None
+    h.set_option("FDG_ISA_W2", "1")
+    assert h.get_option("FDG_ISA_W2") == "1" and capi.GraphHandle(t).get_option("FDG_ISA_W2") is None      # per handle
+    h.set_option("FDG_ISA_W2", None)
+    assert h.get_option("FDG_ISA_W2") is None
+    capi.set_default_option("FDG_ISA_OVERSUB", "3")               # process default: handles created from now on
+    try:
+        assert capi.GraphHandle(t).get_option("FDG_ISA_OVERSUB") == "3" and h.get_option("FDG_ISA_OVERSUB") is None
+    finally:
+        capi.set_default_option("FDG_ISA_OVERSUB", None)
+    assert capi.GraphHandle(t).get_option("FDG_ISA_OVERSUB") is None
+    with pytest.raises(capi.FdgError):
+        h.set_option("PATH", "x")                                 # names start with FDG_
+    # the shipped kernel cache reaches the library as a default option, not through os.environ
+    assert capi.KERNEL_CACHE in (capi.get_default_option("FDG_CACHE_RO_DIR") or "").split(":")
+    src = os.path.join(os.path.dirname(capi.__file__), "csrc")
+    for f in glob.glob(os.path.join(src, "*")):
+        if f.endswith(("fdg_knobs.cpp", "fdg_knobs.h", "Makefile")):
+            continue
+        text = open(f, errors="replace").read()
+        assert not re.search(r'getenv\("FDG_', text), f
+    # the launch path (fdg_run_locked ... the launches) does not even look an option up by name
+    rt = open(os.path.join(src, "fdg_runtime.hip")).read()
+    body = rt[rt.index("int fdg_run_locked("):rt.index("// JIT\n")]
+    assert "knob(" not in body and "getenv" not in body

@@ -51,9 +51,9 @@ def test_monte_carlo_kernels_have_no_hazard(tmp_path):
         assert seen_trans, "no listing of the Monte-Carlo kernel was kept"
 
 
-def test_two_samples_per_lane_variant_has_no_hazard(tmp_path, monkeypatch):
+def test_two_samples_per_lane_variant_has_no_hazard(tmp_path, monkeypatch, fdgopt):
     """FDG_ISA_W2: every access is 16 bytes per lane (wide panel / LDS stores whose data registers the next VALU op may overwrite)."""
-    monkeypatch.setenv("FDG_ISA_W2", "1")
+    fdgopt.set("FDG_ISA_W2", "1")
     h = capi.GraphHandle(workloads.get("sigma2"))
     h.specialize(str(tmp_path), capi.FDG_SPEC_ISA | capi.FDG_SPEC_KEEP_SOURCE)
     texts = [open(f).read() for f in _listings(tmp_path)]

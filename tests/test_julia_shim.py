@@ -109,6 +109,14 @@ def test_the_entry_points_of_round_4_are_bound():
         assert sym in bound, sym
 
 
+def test_the_entry_points_of_round_5_are_bound():
+    bound = {c[0] for c in jl_ccalls()}
+    for sym in ("fdg_batch_alloc_pair", "fdg_graph_set_option"):
+        assert sym in bound, sym
+    m = re.search(r"info = zeros\(UInt8, (\d+)\)", open(JL).read())
+    assert m and int(m.group(1)) >= C.sizeof(capi.BatchPairInfo)          # the report buffer the shim hands to fdg_batch_alloc_pair
+
+
 def test_kernel_info_offsets_read_by_the_shim():
     """hip_compiler.jl reads has_rm out of the raw fdg_kernel_info bytes (`ki[125:128]`: 1-based, offset 124) into a buffer of 256 bytes."""
     text = open(JL).read()

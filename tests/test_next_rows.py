@@ -234,17 +234,17 @@ def test_allocated_program_replays_exactly(libfdg, name, budget):
 
 @pytest.mark.parametrize("name", ["parquet_sigma5", "gv_sigma5", "parquet_ver4_4"])
 @pytest.mark.parametrize("evict_cost", ["0", "2", "3"])
-def test_eviction_rule_and_landing_slots_replay_exactly(libfdg, monkeypatch, name, evict_cost):
+def test_eviction_rule_and_landing_slots_replay_exactly(libfdg, monkeypatch, name, evict_cost, fdgopt):
     """Two allocator choices of round 3 move values, never change them: the eviction rule that counts a spill without a home as
     two accesses (FDG_EVICT_COST, default 2) and the experimental AGPR landing slots of the leaf loads (FDG_LAND, op kind 28).
     Both switches are read per program."""
     t = workloads.get(name)
     h = capi.GraphHandle(t)
-    monkeypatch.setenv("FDG_EVICT_COST", evict_cost)
+    h.set_option("FDG_EVICT_COST", evict_cost)
     leaf = oracle.philox_uniform(9, t.n_leaf, 79)
     want = oracle.eval_static(t, leaf)
     for land in ("0", "16", "40"):
-        monkeypatch.setenv("FDG_LAND", land)
+        h.set_option("FDG_LAND", land)
         ops, nr, nl, nm = h.opt_program(n_reg=120, n_lds=80, n_acc=124, vn_window=2000)
         assert np.array_equal(replay(ops, nr, nl, nm, h.last_n_acc, leaf, t.n_root), want)
         n_land = int((ops["kind"] == 28).sum())
@@ -254,7 +254,7 @@ def test_eviction_rule_and_landing_slots_replay_exactly(libfdg, monkeypatch, nam
 
 
 @pytest.mark.parametrize("name", ["parquet_sigma4", "parquet_sigma4_insdyn", "gv_sigma5"])
-def test_load_runs_sorted_in_chunks_replay_exactly(libfdg, monkeypatch, name):
+def test_load_runs_sorted_in_chunks_replay_exactly(libfdg, monkeypatch, name, fdgopt):
     """FDG_LOAD_RUN_CHUNK (round 4, an experiment that measured neutral): back-to-back leaf loads are sorted by leaf only within
     chunks of c, so the loads the first fold steps need are issued first.  An order of independent loads: same bits, same loads."""
     t = workloads.get(name)
@@ -263,7 +263,7 @@ def test_load_runs_sorted_in_chunks_replay_exactly(libfdg, monkeypatch, name):
     want = oracle.eval_static(t, leaf)
     base, nr, nl, nm = h.opt_program(n_reg=120, n_lds=80, n_acc=124)
     for c in ("4", "16"):
-        monkeypatch.setenv("FDG_LOAD_RUN_CHUNK", c)
+        h.set_option("FDG_LOAD_RUN_CHUNK", c)
         ops, nr, nl, nm = h.opt_program(n_reg=120, n_lds=80, n_acc=124)
         assert np.array_equal(replay(ops, nr, nl, nm, h.last_n_acc, leaf, t.n_root), want)
         assert np.array_equal(np.sort(ops["kind"]), np.sort(base["kind"]))      # the same operations, in another order
@@ -275,15 +275,15 @@ def test_load_runs_sorted_in_chunks_replay_exactly(libfdg, monkeypatch, name):
 
 @pytest.mark.parametrize("name,window,cost", [("sigma4_standin", 1000, 4), ("sigma4_standin", 300, 8), ("gv_sigma4_taylor2", 200, 8),
                                               ("synthetic_small", 40, 8), ("gv_sigma5", 100, 16)])
-def test_forget_and_recompute_replays_exactly(libfdg, monkeypatch, name, window, cost):
+def test_forget_and_recompute_replays_exactly(libfdg, monkeypatch, name, window, cost, fdgopt):
     """FDG_REMAT_WINDOW: the value of a cheap node that has not been read for `window` ops is forgotten and computed
     again by its next consumer (also inside the grouped schedule of the Taylor graphs).  Same operations on the same
     operands: the replayed program still gives the oracle's bits, with more arithmetic and fewer spill slots."""
     t = workloads.get(name)
     h = capi.GraphHandle(t)
     base_ops, _, _, base_mem = h.opt_program(n_reg=60, n_lds=10)
-    monkeypatch.setenv("FDG_REMAT_WINDOW", str(window))
-    monkeypatch.setenv("FDG_REMAT_COST", str(cost))
+    h.set_option("FDG_REMAT_WINDOW", str(window))
+    h.set_option("FDG_REMAT_COST", str(cost))
     ops, nr, nl, nm = h.opt_program(n_reg=60, n_lds=10)
     leaf = oracle.philox_uniform(9, t.n_leaf, 78)
     got = replay(ops, nr, nl, nm, h.last_n_acc, leaf, t.n_root)
@@ -401,12 +401,12 @@ def replay_coop(progs, info, leaf, R):
 
 @pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("name", ["sigma4_standin", "gv_sigma5", "sigma4_worstcase", "synthetic_small", "parquet_ver4_3"])
-def test_cooperative_programs_replay_exactly(libfdg, monkeypatch, name, waves):
+def test_cooperative_programs_replay_exactly(libfdg, monkeypatch, name, waves, fdgopt):
     """The cooperative variant (four waves of a CU on one tile): who computes a term changes, the folds do not.
     (With many roots -- the 84 rows of the 3-loop Parquet vertex function -- whole roots are dealt to the waves instead.)
     The four programs replayed with their barriers give the oracle's bits; every wave's program has the same number of
     barriers; nothing is read from a shared slot in the epoch in which it is rewritten."""
-    monkeypatch.setenv("FDG_COOP_WAVES", str(waves))      # one or two waves per SIMD (two: 256 registers each, no AGPR level)
+    fdgopt.set("FDG_COOP_WAVES", str(waves))      # one or two waves per SIMD (two: 256 registers each, no AGPR level)
     t = workloads.get(name)
     h = capi.GraphHandle(t)
     progs, info = h.coop_program()
@@ -419,11 +419,11 @@ def test_cooperative_programs_replay_exactly(libfdg, monkeypatch, name, waves):
 
 @pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("name", ["parquet_ver4_3", "parquet_ver4_4", "gv_ver4_4"])
-def test_pooled_programs_replay_exactly(libfdg, monkeypatch, name, waves):
+def test_pooled_programs_replay_exactly(libfdg, monkeypatch, name, waves, fdgopt):
     """The pooled cooperative variant (fdg_opt.h: build_pool_program): whole roots per wave, leaves through the shared LDS pool.  The
     programs replayed epoch by epoch give the oracle's bits; no wave reads a leaf from memory; a pool slot is never read between the
     issue of a fetch into it and the epoch from which that fetch is readable; every live leaf is fetched at least once."""
-    monkeypatch.setenv("FDG_POOL_WAVES", str(waves))
+    fdgopt.set("FDG_POOL_WAVES", str(waves))
     t = workloads.get(name)
     h = capi.GraphHandle(t)
     progs, info = h.pool_program()
@@ -439,11 +439,11 @@ def test_pooled_programs_replay_exactly(libfdg, monkeypatch, name, waves):
         assert n_fetch + panel + t.n_root <= 1.5 * (t.n_leaf + t.n_root)
 
 
-def test_pooled_programs_with_paired_fetches_replay_exactly(libfdg, monkeypatch):
+def test_pooled_programs_with_paired_fetches_replay_exactly(libfdg, monkeypatch, fdgopt):
     """FDG_POOL_PAIR=1 (an experiment kept behind a switch: measured slower): one 64-lane fetch brings two arbitrary leaves into an aligned pair of
     slots.  The replay is exact; the second leaf follows the first in index (the upper lanes' offsets are unsigned)."""
-    monkeypatch.setenv("FDG_POOL_PAIR", "1")
-    monkeypatch.setenv("FDG_POOL_PAIR_FAR", "0")
+    fdgopt.set("FDG_POOL_PAIR", "1")
+    fdgopt.set("FDG_POOL_PAIR_FAR", "0")
     t = workloads.get("parquet_ver4_3")
     h = capi.GraphHandle(t)
     progs, info = h.pool_program()

@@ -163,7 +163,7 @@ def fuzz_table(seed: int):
 FUZZ_SEEDS = list(range(1000, 1056))
 
 
-def test_cooperative_programs_on_random_graphs(libfdg):
+def test_cooperative_programs_on_random_graphs(libfdg, fdgopt):
     """The cooperative variant's four programs (tests/test_next_rows.py: replay_coop) on the fuzz graphs that have a wide
     root: oracle bits including the sign of zeros, equal barrier counts, no shared slot rewritten in an epoch in which another
     wave still reads it (a node whose value is a received copy publishes that copy: its M_SEND keeps the copy's slot alive)."""
@@ -171,7 +171,7 @@ def test_cooperative_programs_on_random_graphs(libfdg):
     n = 0
     for seed in list(FUZZ_SEEDS) + list(range(2000, 2030)):
         t, _ = fuzz_table(seed)
-        os.environ["FDG_COOP_WAVES"] = "4" if seed % 2 else "8"
+        fdgopt.set("FDG_COOP_WAVES", "4" if seed % 2 else "8")
         h = capi.GraphHandle(t)
         try:
             progs, info = h.coop_program()
@@ -185,12 +185,12 @@ def test_cooperative_programs_on_random_graphs(libfdg):
             got = replay_coop(progs, info, leaf, t.n_root)
         live = t.root_slot != FDG_NO_ROOT
         assert same(got[:, live], want[:, live]), seed
-    os.environ.pop("FDG_COOP_WAVES", None)
+    fdgopt.unset("FDG_COOP_WAVES")
     assert n >= 10
 
 
 @pytest.mark.gpu
-def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch):
+def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch, fdgopt):
     """The optimizing back end under random register / LDS / AGPR budgets (spills through every level), value-numbering
     windows, the forget-and-recompute window, and -- every fourth seed -- the two-samples-per-lane variant: evaluation in
     both layouts bit for bit against the oracle, fused accumulation within the stated tolerance, and every listing clean
@@ -207,13 +207,13 @@ def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch
         opts = [dict(n_reg=int(rng.integers(6, 40)), n_lds=int(rng.integers(1, 30)), vn_window=int(rng.choice([1, 20, 200, 1000]))),
                 dict(n_reg=int(rng.integers(30, 120)), n_lds=int(rng.integers(1, 80)), n_acc=int(rng.integers(1, 124)))]
         if seed % 4 == 0:
-            monkeypatch.setenv("FDG_ISA_W2", "1")
+            fdgopt.set("FDG_ISA_W2", "1")
             opts.append(None)
         if seed % 3 == 0:
-            monkeypatch.setenv("FDG_REMAT_WINDOW", str(int(rng.choice([8, 60, 400]))))
+            fdgopt.set("FDG_REMAT_WINDOW", str(int(rng.choice([8, 60, 400]))))
         if seed % 2 == 1:                  # the cooperative variant wherever the graph has a wide root sum (it then takes the leaf-major calls)
-            monkeypatch.setenv("FDG_ISA_COOP", "1")
-            monkeypatch.setenv("FDG_COOP_WAVES", "4" if seed % 4 == 1 else "8")
+            fdgopt.set("FDG_ISA_COOP", "1")
+            fdgopt.set("FDG_COOP_WAVES", "4" if seed % 4 == 1 else "8")
         for opt in opts:
             f = fd.compile_table(t, specialize="isa", opt=opt, cache_dir=str(cache), flags=capi.FDG_SPEC_KEEP_SOURCE)
             for layout in ("leaf_major", "sample_major"):
@@ -231,10 +231,10 @@ def test_fuzz_isa_register_budgets_on_device(libfdg, cuda, tmp_path, monkeypatch
                 live = t.root_slot != FDG_NO_ROOT
                 wr = want * w.cpu().numpy()[:, None]
                 assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0))[live] <= 1e-12 * np.maximum(1.0, np.abs(wr).sum(0))[live]), (seed, opt)
-        monkeypatch.delenv("FDG_ISA_W2", raising=False)
-        monkeypatch.delenv("FDG_REMAT_WINDOW", raising=False)
-        monkeypatch.delenv("FDG_ISA_COOP", raising=False)
-        monkeypatch.delenv("FDG_COOP_WAVES", raising=False)
+        fdgopt.unset("FDG_ISA_W2")
+        fdgopt.unset("FDG_REMAT_WINDOW")
+        fdgopt.unset("FDG_ISA_COOP")
+        fdgopt.unset("FDG_COOP_WAVES")
         for lst in glob.glob(str(cache / "*.s")):
             n, rep = capi.isa_check_hazards(open(lst).read())
             assert n == 0, (seed, rep)
@@ -324,10 +324,10 @@ def test_random_mc_program_replays(libfdg, seed):
 
 
 @pytest.mark.gpu
-def test_random_mc_step_on_device(libfdg, cuda, monkeypatch):
+def test_random_mc_step_on_device(libfdg, cuda, monkeypatch, fdgopt):
     """The same statements for the kernels: eval and accumulate of the one-kernel route on random graphs and tables."""
     import torch
-    monkeypatch.setenv("FDG_MC_ROUTE", "isa")
+    fdgopt.set("FDG_MC_ROUTE", "isa")
     st = torch.cuda.current_stream().cuda_stream
     for seed in MC_SEEDS:
         t = random_table(seed)

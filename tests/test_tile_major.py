@@ -125,7 +125,7 @@ def test_tile_major_batch_of_config_2_size(libfdg, cuda):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,force", [("parquet_ver4_3", True), ("parquet_ver4_4", True), ("gv_ver4_4", False)])
-def test_pooled_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_path, name, force):
+def test_pooled_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_path, name, force, fdgopt):
     """fdg_isa_eval_pool: the four waves of a CU evaluate one tile, whole roots each, the tile's leaves fetched once into
     a shared LDS pool.  Taken for full tiles of tile-major batches (and of leaf-major matrices whose leaves lie within 2 GB); the last
     B % 64 samples go through the one-wave kernel.  Bit-exact; the graphs of example/benchmark.jl and example/benchmark_GV.jl get it by
@@ -133,7 +133,7 @@ def test_pooled_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_pat
     (example/benchmark.jl's moves 1.3 x and is faster left alone: profiles/r04_log_pool_pick.txt)."""
     import torch
     if force:
-        monkeypatch.setenv("FDG_ISA_POOL", "1")
+        fdgopt.set("FDG_ISA_POOL", "1")
     t = workloads.get(name)
     L, R = t.n_leaf, t.n_root
     f = fd.compile_table(t, specialize="isa", cache_dir=str(tmp_path) if force else None)
@@ -158,7 +158,7 @@ def test_pooled_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_pat
     torch.cuda.synchronize()
     assert f.kernel_info()["last_kernel"] == "fdg_isa_eval_pool"
     assert np.array_equal(got.cpu().numpy(), oracle.eval_static(t, h_leaf))
-    monkeypatch.setenv("FDG_ISA_NO_POOL", "1")
+    f.handle.set_option("FDG_ISA_NO_POOL", "1")
     got = f(None, leaf)
     torch.cuda.synchronize()
     assert f.kernel_info()["last_kernel"].startswith("fdg_isa_eval") and f.kernel_info()["last_kernel"] != "fdg_isa_eval_pool"
@@ -255,12 +255,12 @@ def test_linear_row_major_variant_accumulates_on_device(libfdg, cuda, name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("B", [64 * 37, 70_001])
-def test_leaves_from_K_T_into_a_tile_major_batch(libfdg, cuda, monkeypatch, B, generic):
+def test_leaves_from_K_T_into_a_tile_major_batch(libfdg, cuda, monkeypatch, B, generic, fdgopt):
     """fdg_leaf_eval_device_tiled (SURVEY.md 8f row 3 on the layout of 8d): the leaf loop of example/benchmark.jl:58-81 writes a tile-major
     batch -- the same bits as fdg_leaf_eval_device writes into a plain matrix -- and the tiled evaluator takes it from there: the
     Monte-Carlo chain (K, T) -> leaves -> roots on the layout that streams fastest, roots equal bit for bit to the plain chain's."""
     import torch
-    if generic: monkeypatch.setenv("FDG_LEAF_GENERIC", "1")          # the table-driven kernel instead of the one specialised to the tables
+    if generic: fdgopt.set("FDG_LEAF_GENERIC", "1")          # the table-driven kernel instead of the one specialised to the tables
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "gv_sigma4_leafstates.npz"))
     t = workloads.get("gv_sigma4")
     L, R = t.n_leaf, t.n_root
