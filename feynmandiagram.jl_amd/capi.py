@@ -17,7 +17,7 @@ import numpy as np
 from .nodetable import NodeTable
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfdg.so")
+LIB_PATH = os.environ.get("FDG_LIBRARY") or os.path.join(_HERE, "lib", "libfdg.so")      # (FDG_LIBRARY: the dev tools point at lib/libfdg_dev.so, `make -C csrc dev`)
 KERNEL_CACHE = os.path.join(_HERE, "kernel_cache")
 
 FDG_OK = 0
