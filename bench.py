@@ -62,6 +62,8 @@ DEFAULT_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcas
              "parquet_sigma4_dyn": 8_000_000, "parquet_sigma4_insdyn": 4_000_000, "parquet_sigma4_taylor2": 8_000_000,
              "parquet_sigma4_dyn_taylor2": 2_000_000, "parquet_sigma4_insdyn_taylor2": 1_000_000, "parquet_sigma5": 2_000_000,
              "parquet_ver4_4": 512_000, "gv_ver4_4": 512_000}          # (whole 64-sample tiles: the pooled cooperative kernel takes full tiles)
+PAIRED_ROWS = {("parquet_sigma4", "tile_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "tile_major"), ("sigma2", "tile_major"),
+               ("gv_sigma4", "tile_major")}
 PARITY_NOTE = ("bit-exact vs our restatement of the Julia evaluator (oracle/); the reference's known-answer tests pin structure, "
                "leaf numbering and factors, not the rounding of the n-ary folds")
 
@@ -193,6 +195,11 @@ class Case:
             self.leaf, self.root = self.pair.leaf, self.pair.root
             self.root.zero_()
             capi.fill_uniform_device_tiled(self.leaf.data_ptr(), B, L, 1, 64, 64 * L, 1234, self.sample_offset, st)
+            return
+        if self.layout == "sample_major" and self.placement == "paired":      # the same allocator for compile_Python's row-major [B, L] / [B, R]
+            self.pair = self.f.row_major_pair(B, dev, calibrate=True)
+            self.leaf, self.root = self.pair.leaf, self.pair.root
+            capi.fill_uniform_device(self.leaf.data_ptr(), B, L, self.leaf.stride(0), self.leaf.stride(1), 1234, self.sample_offset, st)
             return
         if self.layout == "tile_major":       # fdg_eval_device_tiled: [tile, value, sample in tile] -- a Julia Array{Float64,3}(64, L, cld(B, 64))
             T = (B + 63) // 64
@@ -379,8 +386,10 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
         fma = layout.endswith("+fma")
         plain = layout.endswith("@plain")        # the headline's workload at the headline's size on a PLAIN allocation (what hipMalloc hands out)
         lay = layout[:-4] if fma else (layout[:-6] if plain else layout)
+        # the memory-bound graphs with root stores get their batch from the library's allocator (fdg_batch_alloc_pair), as the headline does
+        paired = (workload, lay) in PAIRED_ROWS and not plain and not fma
         c = Case(workload, lay, DEFAULT_B[workload] if plain else (16_000_000 if workload == "parquet_sigma4" else DEFAULT_B.get(workload, 1_000_000)), dev,
-                 flags=capi.FDG_SPEC_FAST_MATH if fma else 0)
+                 flags=capi.FDG_SPEC_FAST_MATH if fma else 0, placement="paired" if paired else "plain")
         ms = c.timed(steps, warm)
         avg = sum(ms) / len(ms) / 1e3
         ok, dev_max, n = c.parity_sample()
@@ -403,7 +412,10 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
                "roofline": roof,
                "valu_fp64_tflops": c.st["flops_alg"] * c.B / avg / 1e12,
                "kernel_info": {k: info[k] for k in ("max_live", "spec_vgpr", "spec_lds_bytes")},
-               "gpu_matches_cpu_bitwise": ok, "max_abs_dev": dev_max, "parity_samples": n}
+               "gpu_matches_cpu_bitwise": ok, "max_abs_dev": dev_max, "parity_samples": n,
+               "placement": ("fdg_batch_alloc_pair" if c.pair is not None else "plain allocation")}
+        if c.pair is not None:
+            out["placement_info"] = {k: c.pair.info[k] for k in ("n_chunk", "n_candidate", "n_probe", "n_matched", "calibrated", "seconds", "seconds_settling")}
         if fma:
             out["contracted"] = True
             out["max_dev_over_Sk"] = dev_over_sk
@@ -741,7 +753,8 @@ def main():
                 if (wl, lay) != head or (not args.secondary and wl == "parquet_sigma4" and B != 16_000_000):
                     sec.append(secondary_case(wl, lay, dev, copy_gbs=copy_gbs))
             out["secondary"] = sec
-            out["secondary_note"] = ("measured in this process after the headline's timed region (30 untimed + 20 timed launches each, HIP events on the "
+            out["secondary_note"] = ("layout with a * = batch from fdg_batch_alloc_pair like the headline's (the memory-bound graphs with root stores), otherwise a plain allocation; "
+                                     "measured in this process after the headline's timed region (30 untimed + 20 timed launches each, HIP events on the "
                                      "launch stream); never part of `value`.  " + PARITY_NOTE)
     if rank == 0:
         if world == 1 and not args.no_mc_step and args.backend == "isa":
@@ -800,7 +813,7 @@ def compact_line(full):
                 rows.append([e.get("workload", "?")[:24], e.get("layout"), None, "error", None, None, None, None, False, None])
                 continue
             r = e["roofline"]
-            rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm", "tile_major": "tm", "tile_major+fma": "tm+fma", "leaf_major+fma": "lm+fma", "tile_major@plain": "tm@plain"}.get(e["layout"], e["layout"]), _r(e["value"] / 1e6),
+            rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm", "tile_major": "tm", "tile_major+fma": "tm+fma", "leaf_major+fma": "lm+fma", "tile_major@plain": "tm@plain"}.get(e["layout"], e["layout"]) + ("*" if e.get("placement") == "fdg_batch_alloc_pair" else ""), _r(e["value"] / 1e6),
                          {"hbm": "hbm", "valu_fp64": "valu"}.get(r["bound"], r["bound"]), _r(r["frac"], 3), _r(r.get("frac_hbm"), 3),
                          _r(r.get("frac_valu"), 3), _r(r.get("traffic_over_algorithmic"), 3),
                          (e.get("gpu_matches_cpu_bitwise") if not e.get("contracted") else "fma:%.1e" % (e.get("max_dev_over_Sk") or 0.0)), _r(r.get("clock_ghz"), 3)])

@@ -173,6 +173,10 @@ class GraphFunc:
         import torch
         return torch.empty(((n_sample + 63) // 64, n_col, 64), dtype=dtype or torch.float64, device=device)
 
+    def row_major_pair(self, n_sample: int, device, calibrate: bool = True, chunk_bytes: int = 0, verbose: bool = False) -> "PairedBatch":
+        """The same for ``compile_Python``'s row-major layout: ``.leaf`` is ``[B, L]``, ``.root`` ``[B, R]`` (rows contiguous)."""
+        return PairedBatch(self, n_sample, device, calibrate, chunk_bytes, verbose, capi.BATCH_PAIR_ROW_MAJOR)
+
     def tile_major_pair(self, n_sample: int, device, calibrate: bool = True, chunk_bytes: int = 0, verbose: bool = False, extra_flags: int = 0) -> "PairedBatch":
         """The leaf and root arrays of a tile-major batch of this function, allocated by the library so that every part of the leaves
         streams next to its part of the roots at the fast rate (``fdg_batch_alloc_pair``: the root chunks are chosen by timing this
@@ -375,8 +379,12 @@ class PairedBatch:
         with torch.cuda.device(device):
             self._lp, self._rp, self.info = capi.batch_alloc_pair(func.handle, self.n_sample, chunk_bytes, calibrate, verbose, extra_flags)
             T = (self.n_sample + 63) // 64
-            self.leaf = torch.as_tensor(_DeviceView(self._lp, (self.info["leaf_bytes"] // (512 * L), L, 64)), device=device)[:T]
-            self.root = torch.as_tensor(_DeviceView(self._rp, (self.info["root_bytes"] // (512 * R), R, 64)), device=device)[:T]
+            if extra_flags & capi.BATCH_PAIR_ROW_MAJOR:
+                self.leaf = torch.as_tensor(_DeviceView(self._lp, (self.info["leaf_bytes"] // (8 * L), L)), device=device)[:self.n_sample]
+                self.root = torch.as_tensor(_DeviceView(self._rp, (self.info["root_bytes"] // (8 * R), R)), device=device)[:self.n_sample]
+            else:
+                self.leaf = torch.as_tensor(_DeviceView(self._lp, (self.info["leaf_bytes"] // (512 * L), L, 64)), device=device)[:T]
+                self.root = torch.as_tensor(_DeviceView(self._rp, (self.info["root_bytes"] // (512 * R), R, 64)), device=device)[:T]
         if self.leaf.data_ptr() != self._lp or self.root.data_ptr() != self._rp:
             self.free()
             raise capi.FdgError(capi.FDG_E_INTERNAL, "torch copied the library's batch instead of viewing it")

@@ -139,13 +139,26 @@ struct PairCtx {
   size_t chunk_tiles = 0, leaf_chunk = 0, root_chunk = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint32_t n_probe = 0;
+  bool row_major = false;      // FDG_BATCH_PAIR_ROW_MAJOR: compile_Python's [B, L] / [B, R] instead of the tile-major arrays (64 rows = one "tile")
+  int eval(const void *leaf, void *root, int64_t n) {
+    return row_major ? fdg_eval_device(g, (const double *)leaf, (int64_t)L, 1, (double *)root, (int64_t)R, 1, n, nullptr)
+                     : fdg_eval_device_tiled(g, (const double *)leaf, 1, 64, 64 * (int64_t)L, (double *)root, 1, 64, 64 * (int64_t)R, n, nullptr);
+  }
+  int accumulate(const void *leaf, double *d_acc, int64_t n) {
+    return row_major ? fdg_accumulate_device(g, (const double *)leaf, (int64_t)L, 1, nullptr, d_acc, n, nullptr)
+                     : fdg_accumulate_device_tiled(g, (const double *)leaf, 1, 64, 64 * (int64_t)L, nullptr, d_acc, n, nullptr);
+  }
+  int fill(void *leaf, int64_t n) {
+    return row_major ? fdg_fill_uniform_device((double *)leaf, n, L, (int64_t)L, 1, 20240612u, 0, nullptr)
+                     : fdg_fill_uniform_device_tiled((double *)leaf, n, L, 1, 64, 64 * (int64_t)L, 20240612u, 0, nullptr);
+  }
   // algorithmic GB/s of the handle's evaluation over one chunk: leaves at `leaf`, roots at `root` (min of `reps` launches after one warm-up)
   int probe(const void *leaf, void *root, double &gbs, int reps = 4) {
     const int64_t n = (int64_t)chunk_tiles * 64;
     float best = 0.f;
     for (int r = 0; r <= reps; ++r) {
       if (hipEventRecord(ev0, nullptr) != hipSuccess) return FDG_E_NO_DEVICE;
-      const int rc = fdg_eval_device_tiled(g, (const double *)leaf, 1, 64, 64 * (int64_t)L, (double *)root, 1, 64, 64 * (int64_t)R, n, nullptr);
+      const int rc = eval(leaf, root, n);
       if (rc) return rc;
       if (hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess) return FDG_E_NO_DEVICE;
       float ms = 0.f;
@@ -172,7 +185,7 @@ struct PairCtx {
     int rc = FDG_OK;
     for (int k = 0;; ++k) {
       if (hipEventRecord(ev0, nullptr) != hipSuccess) { rc = FDG_E_NO_DEVICE; break; }
-      rc = fdg_accumulate_device_tiled(g, (const double *)leaf, 1, 64, 64 * (int64_t)L, nullptr, d_acc, n, nullptr);
+      rc = accumulate(leaf, d_acc, n);
       if (rc) break;
       float ms = 0.f;
       if (hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess || hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) { rc = FDG_E_NO_DEVICE; break; }
@@ -240,6 +253,7 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
   acc.location.id = dev;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   PairCtx cx;
+  cx.row_major = (flags & FDG_BATCH_PAIR_ROW_MAJOR) != 0;
   cx.g = g; cx.L = L; cx.R = R; cx.chunk_tiles = chunk_tiles; cx.leaf_chunk = leaf_chunk; cx.root_chunk = root_chunk;
 
   auto unmap_cand = [&](size_t j) { if (cand[j].mapped) { (void)hipMemUnmap(cand_va + j * root_chunk, root_chunk); cand[j].mapped = false; } };
@@ -316,7 +330,7 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
   if (calibrate) {
     // the probes must see what the workload will see: uniform random leaves (a window of zeros or of stale data runs at another clock
     // and another rate than its neighbours: profiles/r05_log_pair_alloc_v3.txt, rounds 1-2)
-    rc = fdg_fill_uniform_device_tiled((double *)leaf_va, (int64_t)(n_chunk * chunk_tiles) * 64, L, 1, 64, 64 * (int64_t)L, 20240612u, 0, nullptr);
+    rc = cx.fill(leaf_va, (int64_t)(n_chunk * chunk_tiles) * 64);
     if (rc) { cleanup_fail(); return rc; }
     // the fillers of the sprinkle were released a moment ago: wait until their wipe is over before anything is timed
     rc = cx.settle(leaf_va, (int64_t)(n_chunk * chunk_tiles) * 64, n_filler_total * filler_bytes, t_released, &settle_s);

@@ -375,7 +375,9 @@ int fdg_batch_free(void *d_ptr);
  * fdg_batch_free.  `info` (may be NULL) reports what was found.  Needs a handle specialised with FDG_SPEC_ISA and the current device.
  * No counterpart in the reference (its leaf vector and root vector are Julia Vectors on the host, static.jl:100,131). */
 #define FDG_BATCH_PAIR_CALIBRATE 1u
-#define FDG_BATCH_PAIR_VERBOSE 2u   /* the classes found, one line each, on stderr */
+#define FDG_BATCH_PAIR_VERBOSE 2u   /* what the search saw, a few lines on stderr */
+#define FDG_BATCH_PAIR_ROW_MAJOR 8u /* the arrays are compile_Python's row-major [B, L] and [B, R] (compiler_python.jl:23,28,45-47) instead of the
+                                     * tile-major ones: 64 consecutive rows take the place of a tile; everything else is the same */
 typedef struct fdg_batch_pair_info {
   uint64_t leaf_bytes, root_bytes;   /* mapped bytes of the two arrays */
   uint64_t chunk_tiles;              /* 64-sample tiles per chunk */

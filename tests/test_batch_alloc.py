@@ -164,3 +164,32 @@ def test_missing_roots_stay_untouched_through_the_root_scratch(libfdg, cuda, R, 
         terms = want[:, live] * w[:, None]
         assert np.all(np.abs(acc[live] - 3.0 - terms.sum(0)) <= 1e-12 * np.maximum(1.0, np.abs(terms).sum(0))), layout
         assert (acc[~live] == 3.0).all(), layout      # acc[k] of a missing root: exactly what it was
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,chunk_mb,calibrate", [(4099, 0, True), (2_600_000, 512, True)])
+def test_paired_row_major_batch_gives_the_bits_of_a_plain_batch(libfdg, cuda, B, chunk_mb, calibrate):
+    """FDG_BATCH_PAIR_ROW_MAJOR: the same allocator for compile_Python's [B, L] / [B, R] (compiler_python.jl:23,28,45-47)."""
+    import torch
+    t = workloads.get("parquet_sigma4")
+    L, R = t.n_leaf, t.n_root
+    f = fd.compile_table(t, specialize="isa")
+    st = torch.cuda.current_stream().cuda_stream
+    pb = f.row_major_pair(B, cuda, calibrate=calibrate, chunk_bytes=chunk_mb << 20)
+    try:
+        assert pb.leaf.shape == (B, L) and pb.root.shape == (B, R) and pb.leaf.is_contiguous() and pb.root.is_contiguous()
+        if chunk_mb:
+            assert pb.info["n_chunk"] >= 3 and pb.info["n_probe"] >= pb.info["n_chunk"]
+        pb.root.fill_(7.0)
+        capi.fill_uniform_device(pb.leaf.data_ptr(), B, L, L, 1, 4321, 11, st)
+        f(pb.root, pb.leaf)
+        leaf = torch.empty((B, L), dtype=torch.float64, device=cuda)
+        capi.fill_uniform_device(leaf.data_ptr(), B, L, L, 1, 4321, 11, st)
+        root = f(None, leaf)
+        torch.cuda.synchronize()
+        assert f.kernel_info()["last_kernel"] in ("fdg_isa_eval_rl", "fdg_isa_eval_rm", "fdg_isa_eval", "fdg_isa_eval_nt")
+        assert torch.equal(pb.leaf, leaf) and torch.equal(pb.root, root)
+        n = min(B, 2000)
+        assert np.array_equal(pb.root[B - n:].cpu().numpy(), oracle.eval_static(t, oracle.philox_uniform(B, L, 4321, 11)[B - n:] if B < 10000 else leaf[B - n:].cpu().numpy()))
+    finally:
+        pb.free()
