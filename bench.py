@@ -62,8 +62,9 @@ DEFAULT_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcas
              "parquet_sigma4_dyn": 8_000_000, "parquet_sigma4_insdyn": 4_000_000, "parquet_sigma4_taylor2": 8_000_000,
              "parquet_sigma4_dyn_taylor2": 2_000_000, "parquet_sigma4_insdyn_taylor2": 1_000_000, "parquet_sigma5": 2_000_000,
              "parquet_ver4_4": 512_000, "gv_ver4_4": 512_000}          # (whole 64-sample tiles: the pooled cooperative kernel takes full tiles)
+PAIR_ALL = False         # --pair-all (experiment): every tile-major / row-major secondary row through fdg_batch_alloc_pair
 PAIRED_ROWS = {("parquet_sigma4", "tile_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "tile_major"), ("sigma2", "tile_major"),
-               ("gv_sigma4", "tile_major")}
+               ("gv_sigma4", "tile_major"), ("gv_sigma4_taylor2", "tile_major")}
 PARITY_NOTE = ("bit-exact vs our restatement of the Julia evaluator (oracle/); the reference's known-answer tests pin structure, "
                "leaf numbering and factors, not the rounding of the n-ary folds")
 
@@ -387,7 +388,7 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
         plain = layout.endswith("@plain")        # the headline's workload at the headline's size on a PLAIN allocation (what hipMalloc hands out)
         lay = layout[:-4] if fma else (layout[:-6] if plain else layout)
         # the memory-bound graphs with root stores get their batch from the library's allocator (fdg_batch_alloc_pair), as the headline does
-        paired = (workload, lay) in PAIRED_ROWS and not plain and not fma
+        paired = ((workload, lay) in PAIRED_ROWS or (PAIR_ALL and lay in ("tile_major", "sample_major"))) and not plain and not fma
         c = Case(workload, lay, DEFAULT_B[workload] if plain else (16_000_000 if workload == "parquet_sigma4" else DEFAULT_B.get(workload, 1_000_000)), dev,
                  flags=capi.FDG_SPEC_FAST_MATH if fma else 0, placement="paired" if paired else "plain")
         ms = c.timed(steps, warm)
@@ -523,6 +524,7 @@ def main():
     ap.add_argument("--placement", default="paired", choices=["paired", "plain"],
                     help="headline batch (tile-major only): paired = fdg_batch_alloc_pair, the library's allocator that times (leaf window, root chunk) "
                          "pairs and maps a fast root chunk behind every window; plain = torch.empty, whatever hipMalloc hands out")
+    ap.add_argument("--pair-all", action="store_true", help="experiment: every tile-major / row-major secondary row allocates through fdg_batch_alloc_pair")
     ap.add_argument("--backend", default="isa", choices=["isa", "isa-autotune", "auto", "hip", "interp"],
                     help="isa: optimizing back end, gfx950 assembly; hip: straight-line HIP source via hiprtc; interp: table interpreter")
     ap.add_argument("--interp", action="store_true", help="same as --backend interp")
@@ -540,8 +542,9 @@ def main():
                     help="no device work: one process per rank on the CPU (gloo), the evaluator replaced by a stub that adds the shard's "
                          "sample count to the accumulator; checks sharding, the one collective and the stdout line (tests/test_bench_line.py)")
     args = ap.parse_args()
-    global DRY
+    global DRY, PAIR_ALL
     DRY = bool(args.dry_run)
+    PAIR_ALL = bool(args.pair_all)
 
     import numpy as np
     import torch
