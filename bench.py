@@ -337,7 +337,7 @@ def kernel_of(f, slot=0):
     return name, (ki["n_valu"][slot] or None)
 
 
-TRAFFIC_FILE = "r04_traffic.json"       # this round's PMC summaries only: a workload that is not in it gets traffic = null, never an older round's figure
+TRAFFIC_FILE = "r05_traffic.json"       # this round's PMC summaries only: a workload that is not in it gets traffic = null, never an older round's figure
 
 
 def attach_traffic(roof, workload, layout, B, avg_kernel_s):
@@ -654,6 +654,11 @@ def main():
                    "parallelism": f"samples sharded x{world}, one all-reduce of {R} doubles",
                    "parity": PARITY_NOTE},
     }
+    if not DRY:
+        try:                              # which physical device this line was measured on (the round's lines come from several boxes)
+            out["config"]["device"] = str(torch.cuda.get_device_properties(dev).uuid)[-12:]
+        except Exception:
+            pass
     kname, ops_exec = kernel_of(f)        # the kernel the library actually launched, and what it executes per evaluation
     copy_gbs = None
     if rank == 0:
@@ -790,7 +795,7 @@ def compact_line(full):
     line["ms_per_step"] = _r(line.get("ms_per_step"), 6)
     cfg = full.get("config", {})
     line["config"] = {"workload": SHORT_NOTES.get(cfg.get("workload", "").split(" ")[0], cfg.get("workload", "").split(" ")[0])[:120]}
-    for k in ("n_leaf", "n_node", "n_root", "samples_per_step_per_gpu", "layout", "settle_steps", "parallelism"):
+    for k in ("n_leaf", "n_node", "n_root", "samples_per_step_per_gpu", "layout", "settle_steps", "parallelism", "device"):
         if k in cfg:
             line["config"][k] = cfg[k]
     roof = full.get("roofline")
