@@ -172,7 +172,7 @@ class Case:
         self.st = t.stats()
         L, R = t.n_leaf, t.n_root
         self.sample_offset = sample_offset
-        self.placement, self.pair = placement, None
+        self.placement, self.pair, self.pair_error = placement, None, None
         if DRY:
             self.f, self.stream = DryFunc(B), None
             self.leaf = torch.zeros((1, L), dtype=torch.float64)
@@ -192,16 +192,25 @@ class Case:
         if self.layout == "tile_major" and self.placement == "paired":
             # the library's own allocator for a tile-major batch (fdg_batch_alloc_pair): every window of the leaves gets a chunk of roots
             # behind which the handle's kernel was MEASURED at the fast rate; a plain allocation is the "@plain" row
-            self.pair = self.f.tile_major_pair(B, dev, calibrate=True, extra_flags=int(os.environ.get("FDG_BENCH_PAIR_FLAGS", "0")))
-            self.leaf, self.root = self.pair.leaf, self.pair.root
-            self.root.zero_()
-            capi.fill_uniform_device_tiled(self.leaf.data_ptr(), B, L, 1, 64, 64 * L, 1234, self.sample_offset, st)
-            return
+            try:
+                self.pair = self.f.tile_major_pair(B, dev, calibrate=True, extra_flags=int(os.environ.get("FDG_BENCH_PAIR_FLAGS", "0")))
+            except Exception as e:            # (a driver without the virtual-memory API, too little free memory: the line says so and uses a plain batch)
+                self.pair, self.placement, self.pair_error = None, "plain", f"{type(e).__name__}: {e}"
+                print(f"[bench] fdg_batch_alloc_pair failed ({self.pair_error}): plain allocation instead", file=sys.stderr)
+            if self.pair is not None:
+                self.leaf, self.root = self.pair.leaf, self.pair.root
+                self.root.zero_()
+                capi.fill_uniform_device_tiled(self.leaf.data_ptr(), B, L, 1, 64, 64 * L, 1234, self.sample_offset, st)
+                return
         if self.layout == "sample_major" and self.placement == "paired":      # the same allocator for compile_Python's row-major [B, L] / [B, R]
-            self.pair = self.f.row_major_pair(B, dev, calibrate=True)
-            self.leaf, self.root = self.pair.leaf, self.pair.root
-            capi.fill_uniform_device(self.leaf.data_ptr(), B, L, self.leaf.stride(0), self.leaf.stride(1), 1234, self.sample_offset, st)
-            return
+            try:
+                self.pair = self.f.row_major_pair(B, dev, calibrate=True)
+            except Exception as e:
+                self.pair, self.placement, self.pair_error = None, "plain", f"{type(e).__name__}: {e}"
+            if self.pair is not None:
+                self.leaf, self.root = self.pair.leaf, self.pair.root
+                capi.fill_uniform_device(self.leaf.data_ptr(), B, L, self.leaf.stride(0), self.leaf.stride(1), 1234, self.sample_offset, st)
+                return
         if self.layout == "tile_major":       # fdg_eval_device_tiled: [tile, value, sample in tile] -- a Julia Array{Float64,3}(64, L, cld(B, 64))
             T = (B + 63) // 64
             self.leaf = torch.empty((T, L, 64), dtype=torch.float64, device=dev)
@@ -681,7 +690,7 @@ def main():
                                                  "mapped_pairs_frac_mean": pi["gbs_after_mean"] / HBM_PEAK_GBS, "mapped_pairs_frac_min": pi["gbs_after_min"] / HBM_PEAK_GBS,
                                                  "seconds": pi["seconds"], "seconds_settling": pi["seconds_settling"]}
         else:
-            out["roofline"]["placement"] = "single allocation, as it came from the allocator (no trials)"
+            out["roofline"]["placement"] = "single allocation, as it came from the allocator (no trials)" + (f"; fdg_batch_alloc_pair failed: {case.pair_error}" if case.pair_error else "")
         try:
             if DRY:
                 raise RuntimeError("dry run")

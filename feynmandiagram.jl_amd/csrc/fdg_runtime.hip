@@ -598,385 +598,80 @@ static int launch_hip_source(fdg_graph *g, hipFunction_t fn, int mode, const dou
   return FDG_OK;
 }
 
-int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
-                   int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st,
-                   int64_t lts, int64_t rts) {
-  int rc = ensure_device(g);
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The launch path.  fdg_run_locked validates the call and hands it to ONE of the functions below -- one per kernel family / variant
+// (the 400-line function this used to be is split; nothing here looks an option up by name, see fdg_launch_cfg).
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+// the arguments of one evaluation call (mode 0: roots -> d_root; mode 1: acc[k] += sum_b w_b root_k(b))
+struct RunArgs {
+  int mode;
+  const double *d_leaf; int64_t ss, ls;
+  double *d_root; int64_t rs, rk;
+  const double *d_weight; double *d_acc;
+  int64_t B; hipStream_t st;
+  int64_t lts, rts;                 // tile strides of a tile-major batch (0: a plain strided matrix)
+};
+inline bool root_stride_ok(const RunArgs &a) { return !(a.rs < 0 || a.rs >= (1ll << 23)); }
+
+int ensure_root_scratch(fdg_graph *g, size_t need) {
+  if (g->ws2_bytes >= need) return FDG_OK;
+  if (g->d_ws2) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws2)); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
+  if (hipMalloc(&g->d_ws2, need) != hipSuccess) { set_error("hipMalloc(root scratch) failed"); return FDG_E_NOMEM; }
+  g->ws2_bytes = need;
+  return FDG_OK;
+}
+
+// Roots into a ROW-MAJOR matrix (compile_Python's [B, R]) of a graph with many roots: a root store of the kernels is 64 lanes x 8 bytes, each in
+// another row -- with R = 180 (example/benchmark.jl's vertex function) the stores doubled the kernel's time.  Such calls evaluate chunk by chunk
+// into the column-major root scratch (every store one 512-byte run) and a transposition writes the caller's rows (round 4).
+int run_through_root_scratch(fdg_graph *g, const RunArgs &a) {
+  const uint32_t R = g->prog.R;
+  long Bc = std::max<long>(64, (long)((g->cfg.root_scratch_mb << 20) / (8ull * R)) & ~63l);
+  Bc = std::min<long>(Bc, (long)((a.B + 63) & ~(int64_t)63));
+  int rc = ensure_root_scratch(g, (size_t)Bc * R * sizeof(double) + (size_t)2048 * R * sizeof(double));
   if (rc) return rc;
+  double *scratch = (double *)g->d_ws2;
+  const uint8_t *live = nullptr;
+  rc = root_live_mask(g, &live);
+  if (rc) return rc;
+  for (long c0 = 0; c0 < (long)a.B; c0 += Bc) {
+    const long n = std::min<long>(Bc, (long)a.B - c0);
+    const double *lf = a.lts ? a.d_leaf + (size_t)(c0 / 64) * (size_t)a.lts : a.d_leaf + (size_t)c0 * (size_t)a.ss;
+    rc = fdg_run_locked(g, 0, lf, a.ss, a.ls, scratch, 1, Bc, nullptr, nullptr, n, a.st, a.lts, 0);
+    if (rc) return rc;
+    const long ntile = ((n + 63) / 64) * ((R + 31) / 32);
+    hipLaunchKernelGGL(fdg_transpose_from_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, a.st,
+                       scratch, Bc, a.d_root + (size_t)c0 * (size_t)a.rs, (long)a.rs, (long)a.rk, n, R, live);
+    HIP_TRY(hipGetLastError());
+  }
+  return FDG_OK;
+}
+
+// sample-major input of an ISA handle that carries the HIP-source companion: its lanes read their own rows; no transposition pass
+int run_companion(fdg_graph *g, const RunArgs &a) {
+  if (!g->alt_module) {
+    hipModule_t m; hipFunction_t f1, f2;
+    hipError_t e = hipModuleLoadData(&m, g->alt_code.data());
+    if (e != hipSuccess) { set_error("hipModuleLoadData failed: " + std::string(hipGetErrorString(e))); return FDG_E_JIT; }
+    HIP_TRY(hipModuleGetFunction(&f1, m, "fdg_spec_sm"));
+    HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_spec_gen"));
+    g->alt_module = m; g->fn_alt_sm = f1; g->fn_alt_gen = f2;
+  }
+  g->last_kernel = "fdg_spec_sm";
+  return launch_hip_source(g, (hipFunction_t)g->fn_alt_sm, a.mode, a.d_leaf, a.ss, a.ls, a.d_root, a.rs, a.rk, a.d_weight, a.d_acc, a.B, a.st);
+}
+
+// the generic table interpreter (no JIT)
+int run_interpreter(fdg_graph *g, const RunArgs &a) {
   const Lowered &p = g->prog;
-  const long nblk = (long)((B + 255) / 256);
   const uint32_t R = p.R;
-  // Tile-major batches (fdg_eval_device_tiled): tile t holds samples 64 t .. 64 t + 63 at base + t * tile stride.  Only the
-  // kernels of the optimizing back end take a tile stride; a plain strided matrix is the case tile stride = 64 * sample stride.
-  const bool tiled = lts != 0 || rts != 0;
-  if (tiled && !(!g->code_object.empty() && g->isa)) {
-    set_error("tile-major batches need a handle specialised with FDG_SPEC_ISA"); return FDG_E_UNSUPPORTED;
-  }
-  if (tiled && (lts < 0 || rts < 0 || ss < 0 || ss >= (1ll << 23) || (mode == 0 && (rs < 0 || rs >= (1ll << 23))))) {
-    set_error("tile-major batch: negative strides or sample strides of 2^23 elements or more are not supported"); return FDG_E_UNSUPPORTED;
-  }
-
-  const bool rl_rows = g->has_rl && ls == 1 && ss == (int64_t)p.L && p.L >= 2 && B >= 64 && ((uintptr_t)d_leaf & 15) == 0 && !g->cfg.no_rl;
-  const bool rl_shape = rl_rows && ((mode == 0 && !(rs < 0 || rs >= (1ll << 23))) ||                       // contiguous rows: the linear variant below
-                                    (mode == 1 && g->has_rl_acc && g->has_acc && !g->cfg.no_fused_acc));
-  // Roots into a ROW-MAJOR matrix (compile_Python's [B, R]) of a graph with many roots: a root store of the kernels is 64 lanes x 8 bytes, each in
-  // another row -- with R = 180 (example/benchmark.jl's vertex function) the stores doubled the kernel's time.  Such calls evaluate chunk by chunk
-  // into the column-major root scratch (every store one 512-byte run) and a transposition writes the caller's rows (round 4).
-  const uint32_t scratch_min_roots = g->cfg.root_scratch_min;
-  if (mode == 0 && !g->code_object.empty() && g->isa && scratch_min_roots && R >= scratch_min_roots && rk == 1 && rs >= (int64_t)R && (rts == 0 || rts == 64 * rs) && B >= 256 &&
-      !(ls == 1 && ss != 1 && (g->alt_code.size() || g->has_rm || rl_rows))) {     // (the row-major variants write a tile's rows together: left alone)
-    const unsigned long long scratch_mb = g->cfg.root_scratch_mb;
-    long Bc = std::max<long>(64, (long)((scratch_mb << 20) / (8ull * R)) & ~63l);
-    Bc = std::min<long>(Bc, (long)((B + 63) & ~(int64_t)63));
-    const size_t need = (size_t)Bc * R * sizeof(double) + (size_t)2048 * R * sizeof(double);
-    if (g->ws2_bytes < need) {
-      if (g->d_ws2) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws2)); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
-      if (hipMalloc(&g->d_ws2, need) != hipSuccess) { set_error("hipMalloc(root scratch) failed"); return FDG_E_NOMEM; }
-      g->ws2_bytes = need;
-    }
-    double *scratch = (double *)g->d_ws2;
-    const uint8_t *live = nullptr;
-    rc = root_live_mask(g, &live);
-    if (rc) return rc;
-    for (long c0 = 0; c0 < (long)B; c0 += Bc) {
-      const long n = std::min<long>(Bc, (long)B - c0);
-      const double *lf = lts ? d_leaf + (size_t)(c0 / 64) * (size_t)lts : d_leaf + (size_t)c0 * (size_t)ss;
-      rc = fdg_run_locked(g, 0, lf, ss, ls, scratch, 1, Bc, nullptr, nullptr, n, st, lts, 0);
-      if (rc) return rc;
-      const long ntile = ((n + 63) / 64) * ((R + 31) / 32);
-      hipLaunchKernelGGL(fdg_transpose_from_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, st,
-                         scratch, Bc, d_root + (size_t)c0 * (size_t)rs, (long)rs, (long)rk, n, R, live);
-      HIP_TRY(hipGetLastError());
-    }
-    return FDG_OK;
-  }
-
-  if (!g->code_object.empty() && g->isa && !g->alt_code.empty() && ls == 1 && ss != 1 && p.L > 1 && !tiled && !rl_shape) {
-    // sample-major input and a companion: its lanes read their own rows; no transposition pass
-    if (!g->alt_module) {
-      hipModule_t m; hipFunction_t f1, f2;
-      hipError_t e = hipModuleLoadData(&m, g->alt_code.data());
-      if (e != hipSuccess) { set_error("hipModuleLoadData failed: " + std::string(hipGetErrorString(e))); return FDG_E_JIT; }
-      HIP_TRY(hipModuleGetFunction(&f1, m, "fdg_spec_sm"));
-      HIP_TRY(hipModuleGetFunction(&f2, m, "fdg_spec_gen"));
-      g->alt_module = m; g->fn_alt_sm = f1; g->fn_alt_gen = f2;
-    }
-    g->last_kernel = "fdg_spec_sm";
-    return launch_hip_source(g, (hipFunction_t)g->fn_alt_sm, mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st);
-  }
-  if (!g->code_object.empty() && g->isa) {
-    rc = ensure_module(g);
-    if (rc) return rc;
-    // resident waves: one wave per workgroup; bounded by VGPRs, LDS and 32 waves/CU
-    auto waves_per_cu = [&](uint32_t vgpr, uint32_t lds_bytes) {
-      const uint32_t valloc = std::max<uint32_t>(8, (vgpr + 7) & ~7u);
-      uint32_t per_cu = std::min<uint32_t>(8, 512 / valloc) * 4;
-      if (lds_bytes) per_cu = std::min<uint32_t>(per_cu, (160u * 1024u) / lds_bytes);
-      per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32));
-      if (g->cfg.waves_per_cu > 0) per_cu = (uint32_t)g->cfg.waves_per_cu;
-      return per_cu;
-    };
-    const long ntiles = (long)((B + 63) / 64);
-    // A persistent wave walks tiles w, w + n, ...  With several times as many workgroups as are resident at once the later ones
-    // start as the first finish, which evens out waves that progress at different speeds (oversubscription x8: +2-3 % on the
-    // graphs that run against the power budget, +1 % on the headline; profiles/r03_log_oversubscription.txt).  Only while every
-    // workgroup keeps a few tiles and the spill panels / partial sums that are sized by the grid stay small.
-    auto oversub = [&](long resident, size_t bytes_per_wg) -> long {
-      if (g->cfg.waves_per_cu > 0) return resident;
-      long f = g->cfg.oversub > 0 ? g->cfg.oversub : 8;
-      while (f > 1 && (ntiles < resident * f * 4 || bytes_per_wg * (size_t)(resident * f) > ((size_t)32 << 20))) f >>= 1;
-      return resident * f;
-    };
-    // Graphs bound by memory (fewer than 2.5 executed fold steps per algorithmic byte) stream faster from FEWER resident waves: four per CU
-    // (one per SIMD) keep 4 x L x 512 bytes in flight per CU -- enough for the latency-bandwidth product -- and the memory system sees a
-    // quarter of the concurrent streams (round 4, profiles/r04_log_waves.txt: headline +3-5 %, the 2-loop graph +6-15 %); the graphs at or
-    // above the ridge want every wave they can get.  FDG_ISA_MEM_WAVES / FDG_ISA_MEM_OVERSUB / FDG_ISA_MEM_RATIO override (0 waves = off).
-    auto shape = [&](uint64_t valu, uint64_t bytes, uint32_t vgpr, uint32_t lds, size_t bytes_per_wg, bool accumulating = false) -> long {
-      const long full = (long)waves_per_cu(vgpr, lds);
-      const long mem_waves = g->cfg.mem_waves >= 0 ? g->cfg.mem_waves : (p.L >= 24 ? 4 : (accumulating ? 8 : 5));   // (a wave of a tiny graph keeps little in flight; without root stores
-                                                                                                                           //  more of them help: the 2-loop graph accumulates at 0.84 instead of 0.73, profiles/r04_log_tiny_acc_waves.txt)
-      const long mem_over = g->cfg.mem_oversub;
-      const double mem_ratio = g->cfg.mem_ratio;
-      if (mem_waves > 0 && g->cfg.waves_per_cu <= 0 && g->cfg.oversub <= 0 && bytes && (double)valu < mem_ratio * (double)bytes && full > mem_waves) {
-        long f = mem_over;
-        while (f > 1 && ntiles < (long)g->n_cu * mem_waves * f * 4) f >>= 1;
-        return (long)g->n_cu * mem_waves * f;
-      }
-      return oversub((long)g->n_cu * full, bytes_per_wg);
-    };
-    const long grid = std::min<long>(ntiles, shape(g->st_valu[0], 8ull * (p.L + R), g->isa_vgpr, g->isa_lds_bytes, (size_t)g->isa_mem_slots * 512u));
-    const long grid2 = g->has_w2 ? (long)g->n_cu * waves_per_cu(g->isa2_vgpr, g->isa2_lds_bytes) : 0;
-    const size_t panel = std::max((size_t)std::max<uint32_t>(g->isa_mem_slots, 1) * 512u * (size_t)grid,
-                                  (size_t)std::max<uint32_t>(g->isa2_mem_slots, 1) * 1024u * (size_t)grid2);
-    // pooled cooperative variant: full tiles of batches whose samples of a leaf are contiguous and whose leaves lie within 2 GB of the tile's first
-    const bool pool_ok = g->has_pool && g->fn_isa_pool && ss == 1 && ls > 0 && (g->pool_unit == 1 || ls == 64) &&
-                         (uint64_t)ls * 8u * (uint64_t)std::max<uint32_t>(p.L, 1) < (1ull << 31) && B >= 64 && !g->cfg.no_pool;
-    // (a graph that has the pooled variant accumulates through it and the root scratch: its fused-accumulation program, with R + 2 fewer value
-    //  registers and no pool, runs the 4-loop GV vertex function at 0.87e8 samples/s where the pooled evaluation + the weighted sum do 1.3e8)
-    const bool fused_acc = mode == 1 && g->has_acc && !g->cfg.no_fused_acc && !(pool_ok && !g->cfg.pool_no_acc);
-    const long grid3 = g->has_acc ? shape(g->st_valu[1], 8ull * p.L, g->isa3_vgpr, g->isa3_lds_bytes, ((size_t)g->isa3_mem_slots + R) * 512u, true) : 0;
-    const size_t panel3 = (size_t)std::max<uint32_t>(g->isa3_mem_slots, 1) * 512u * (size_t)grid3;
-    const long grid4 = g->has_rm ? (long)g->n_cu * waves_per_cu(g->isa4_vgpr, g->isa4_lds_bytes) : 0;
-    const size_t panel4 = (size_t)std::max<uint32_t>(g->isa4_mem_slots, 1) * 512u * (size_t)grid4;
-    const long grid5 = g->has_rm_acc ? (long)g->n_cu * waves_per_cu(g->isa5_vgpr, g->isa5_lds_bytes) : 0;
-    const size_t panel5 = (size_t)std::max<uint32_t>(g->isa5_mem_slots, 1) * 512u * (size_t)grid5;
-    const size_t panel_all = (std::max(std::max(panel, panel3), std::max(panel4, panel5)) + 4095) & ~(size_t)4095;
-    rc = ensure_ws(g, panel_all + (size_t)std::max(grid3, grid5) * R * 512u + 4096);
-    if (rc) return rc;
-    // a matrix whose 64-sample tiles are whole 128-byte lines (samples of a column contiguous, column stride a multiple of 16
-    // doubles, base on a line): the streaming variants may be used (non-temporal accesses would fetch a shared line twice)
-    const bool streaming_ok = !g->cfg.no_streaming;
-    auto line_aligned = [streaming_ok](const void *base, long sample_stride, long col_stride) {
-      return sample_stride == 1 && (col_stride & 15) == 0 && ((uintptr_t)base & 127) == 0 && streaming_ok;
-    };
-    bool named = false;
-    // fused accumulation: acc[k] += sum_b w_b root_k(b) with per-lane accumulators inside the evaluator
-    auto launch_acc = [&](const double *lf, long lss, long lls, const double *wt, long n, long tls = 0) -> int {
-      void *a_wsp = g->d_ws;
-      double *part = (double *)((char *)g->d_ws + panel_all);
-      long nwg = std::min<long>((n + 63) / 64, grid3), zero = 0;
-      if (!tls) tls = 64 * lss;
-      void *args[] = {(void *)&lf, &lss, &lls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt, &tls, &zero};
-      void *fn = g->fn_isa_acc_nt && line_aligned(lf, lss, lls) && (tls & 15) == 0 ? g->fn_isa_acc_nt : g->fn_isa_acc;
-      if (!named) g->last_kernel = fn == g->fn_isa_acc ? "fdg_isa_eval_acc" : "fdg_isa_eval_acc_nt";
-      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
-      hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
-      HIP_TRY(hipGetLastError());
-      return FDG_OK;
-    };
-    // one batch with sample stride `lss`: full 128-sample tiles through the two-samples-per-lane kernel
-    // when there is one and the samples of a leaf are contiguous, the rest through the W = 1 kernel
-    auto launch_isa = [&](const double *lf, long lss, long lls, double *rt, long rrs, long rrk, long n, long tls = 0, long trs = 0) -> int {
-      void *a_wsp = g->d_ws;
-      long done = 0;
-      if (g->has_w2 && lss == 1 && n >= 128 && !tls && !trs && !g->cfg.no_w2) {
-        long n2 = n & ~127l;
-        long nwg = std::min<long>(n2 / 128, grid2);
-        const double *nowt = nullptr;
-        long tls2 = 128 * lss, trs2 = 128 * rrs;
-        void *args[] = {(void *)&lf, &lss, &lls, (void *)&rt, &rrs, &rrk, &a_wsp, &n2, &nwg, (void *)&nowt, &tls2, &trs2};
-        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_w2, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
-        g->last_kernel = "fdg_isa_eval_w2";
-        done = n2;
-      }
-      if (done < n) {
-        const double *lf1 = lf + done * lss;
-        double *rt1 = rt + done * rrs;
-        long n1 = n - done;
-        long nwg = std::min<long>((n1 + 63) / 64, grid);
-        const double *nowt = nullptr;
-        if (!tls) tls = 64 * lss;
-        if (!trs) trs = 64 * rrs;
-        void *args[] = {(void *)&lf1, &lss, &lls, (void *)&rt1, &rrs, &rrk, &a_wsp, &n1, &nwg, (void *)&nowt, &tls, &trs};
-        void *fn = g->fn_isa_nt && line_aligned(lf1, lss, lls) && line_aligned(rt1, rrs, rrk) && ((tls | trs) & 15) == 0 ? g->fn_isa_nt : g->fn_isa;
-        if (!named && done == 0) g->last_kernel = fn == g->fn_isa ? "fdg_isa_eval" : "fdg_isa_eval_nt";
-        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
-      }
-      return FDG_OK;
-    };
-    double *roots = d_root;
-    long a_rs = rs, a_rk = rk;
-    if (mode == 1 && !fused_acc) {
-      const size_t need = (size_t)((B + 15) & ~(int64_t)15) * std::max<uint32_t>(R, 1) * sizeof(double) + (size_t)2048 * R * sizeof(double);
-      if (g->ws2_bytes < need) {
-        if (g->d_ws2) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws2)); g->d_ws2 = nullptr; g->ws2_bytes = 0; }
-        if (hipMalloc(&g->d_ws2, need) != hipSuccess) { set_error("hipMalloc(root scratch) failed"); return FDG_E_NOMEM; }
-        g->ws2_bytes = need;
-      }
-      roots = (double *)g->d_ws2; a_rs = 1; a_rk = (long)((B + 15) & ~(int64_t)15);      // column-major scratch: root k of sample b at roots[k * ld + b]
-    }
-    // the kernel forms a lane's offset (lane * stride * 8) in 32 bits: strides that large are brought into the
-    // leaf-major workspace first (leaves) or refused (roots); neither occurs with the layouts of DESIGN.md 2
-    const bool wide_ss = ss < 0 || ss >= (1ll << 23);           // (the offset is unsigned: negative strides too)
-    // Pooled cooperative variant: one workgroup per CU walks full 64-sample tiles; a leaf's 64 samples must be contiguous (the pool fetch
-    // reads 16 bytes per lane) and every leaf within 2^31 bytes of the tile's first -- tile-major batches, or small leaf-major matrices.
-    // The last B % 64 samples go through the one-wave kernel.
-    // mode 1 without fused accumulation (see fused_acc): the roots go to the column-major scratch, then the weighted sum
-    auto finish_scratch_acc = [&]() -> int {
-      double *partial = roots + (size_t)a_rk * R;
-      const uint32_t pb = weighted_segments((long)B, R);
-      const uint8_t *live = nullptr;
-      const int rcl = root_live_mask(g, &live);
-      if (rcl) return rcl;
-      hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb * R), dim3(256), 0, st, roots, a_rk, d_weight, (long)B, R, pb, partial, live);
-      hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial, pb, R, d_acc);
-      HIP_TRY(hipGetLastError());
-      return FDG_OK;
-    };
-    if (pool_ok && ((mode == 0 && !(rs < 0 || rs >= (1ll << 23))) || (mode == 1 && !fused_acc))) {
-      const long n4 = (long)(B & ~(int64_t)63), tail = (long)B - n4;
-      double *rt0 = mode == 0 ? d_root : roots;
-      long nwg = std::min<long>(n4 / 64, (long)g->n_cu), lss = ss, lls = ls, rrs = mode == 0 ? rs : a_rs, rrk = mode == 0 ? rk : a_rk;
-      rc = ensure_ws(g, std::max(panel_all + (size_t)grid3 * R * 512u + 4096, (size_t)g->pool_panel_wg * (size_t)nwg + 4096));
-      if (rc) return rc;
-      void *a_wsp = g->d_ws;
-      const double *nowt = nullptr;
-      long tls = lts ? (long)lts : 64 * lss, trs = (mode == 0 && rts) ? (long)rts : 64 * rrs, nn = n4;
-      void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&rt0, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt, &tls, &trs};
-      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_pool, (unsigned)nwg, 1, 1, g->pool_threads, 1, 1, 0, st, args, nullptr));
-      g->last_kernel = "fdg_isa_eval_pool";
-      named = true;
-      if (tail) { rc = launch_isa(d_leaf + (size_t)(n4 / 64) * (size_t)tls, lss, lls, rt0 + (size_t)(n4 / 64) * (size_t)trs, rrs, rrk, tail, lts ? tls : 0, (mode == 0 && rts) ? trs : 0); if (rc) return rc; }
-      return mode == 1 ? finish_scratch_acc() : FDG_OK;
-    }
-    // Cooperative variant: one workgroup of four waves per CU, every workgroup walks tiles of 64 samples; leaf-major input.
-    if (mode == 0 && g->has_coop && g->coop_enabled && g->fn_isa_coop && !(ls == 1 && ss != 1 && p.L > 1) && !wide_ss && !(rs < 0 || rs >= (1ll << 23)) &&
-        !g->cfg.no_coop) {
-      long nwg = std::min<long>((long)((B + 63) / 64), (long)g->n_cu), lss = ss, lls = ls, rrs = rs, rrk = rk, n = (long)B;
-      rc = ensure_ws(g, std::max(panel_all + (size_t)grid3 * R * 512u + 4096, (size_t)g->coop_panel_wg * (size_t)nwg + 4096));
-      if (rc) return rc;
-      void *a_wsp = g->d_ws;
-      const double *nowt = nullptr;
-      long tls = lts ? (long)lts : 64 * lss, trs = rts ? (long)rts : 64 * rrs;
-      void *args[] = {(void *)&d_leaf, &lss, &lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &n, &nwg, (void *)&nowt, &tls, &trs};
-      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_coop, (unsigned)nwg, 1, 1, g->coop_threads, 1, 1, 0, st, args, nullptr));
-      g->last_kernel = "fdg_isa_eval_coop";
-      return FDG_OK;
-    }
-    // Row-major leaves ([B, L], leaf stride 1): full 64-row tiles go through the variant that stages chunks of rows in LDS
-    // itself -- the matrix is read once, in place -- for evaluation and for fused accumulation alike; the last B % 64 rows
-    // go through the plain kernel with the caller's strides (its lanes gather their own rows: fine for under a tile).
-    // Contiguous rows (sample stride == L, 16-byte aligned base): full tiles through the linear variant -- the tile's block streamed into an LDS image.
-    if (rl_shape && mode == 1 && g->fn_isa_rl_acc && !tiled) {
-      const long n4 = (long)(B & ~(int64_t)63), tail = (long)B - n4;
-      const long grid7 = (long)g->n_cu * waves_per_cu(g->isa7_vgpr, g->isa7_lds_bytes);
-      const size_t panel7 = ((size_t)std::max<uint32_t>(g->isa7_mem_slots, 1) * 512u * (size_t)grid7 + 4095) & ~(size_t)4095;
-      // (the partial sums of this launch and of the tail's launch_acc live behind the larger of the two panels)
-      rc = ensure_ws(g, std::max(panel_all, panel7) + (size_t)std::max(std::max(grid3, grid5), grid7) * R * 512u + 4096);
-      if (rc) return rc;
-      void *a_wsp = g->d_ws;
-      double *part = (double *)((char *)g->d_ws + std::max(panel_all, panel7));
-      long nwg = std::min<long>(n4 / 64, grid7), lss = ss, lls = ls, zero = 0, nn = n4, tls = 64 * lss;
-      void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&part, &zero, &zero, &a_wsp, &nn, &nwg, (void *)&d_weight, &tls, &zero};
-      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rl_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
-      hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
-      HIP_TRY(hipGetLastError());
-      g->last_kernel = "fdg_isa_eval_rl_acc";
-      named = true;
-      if (tail) { rc = launch_acc(d_leaf + (size_t)n4 * (size_t)ss, lss, lls, d_weight ? d_weight + n4 : nullptr, tail); if (rc) return rc; }
-      return FDG_OK;
-    }
-    if (rl_shape && mode == 0 && g->fn_isa_rl && !tiled) {
-      const long n4 = (long)(B & ~(int64_t)63), tail = (long)B - n4;
-      const long grid6 = (long)g->n_cu * waves_per_cu(g->isa6_vgpr, g->isa6_lds_bytes);
-      rc = ensure_ws(g, std::max(panel_all + (size_t)std::max(grid3, grid5) * R * 512u + 4096, (size_t)std::max<uint32_t>(g->isa6_mem_slots, 1) * 512u * (size_t)grid6 + 4096));
-      if (rc) return rc;
-      void *a_wsp = g->d_ws;
-      long nwg = std::min<long>(n4 / 64, grid6), lss = ss, lls = ls, rrs = rs, rrk = rk, nn = n4, tls = 64 * lss, trs = 64 * rrs;
-      const double *nowt = nullptr;
-      void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt, &tls, &trs};
-      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rl, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
-      g->last_kernel = "fdg_isa_eval_rl";
-      named = true;
-      if (tail) { rc = launch_isa(d_leaf + (size_t)n4 * (size_t)ss, lss, lls, d_root + (size_t)n4 * (size_t)rs, rrs, rrk, tail); if (rc) return rc; }
-      return FDG_OK;
-    }
-    const bool rm_shape = ls == 1 && ss >= (int64_t)p.L && !wide_ss && p.L >= 16 && B >= 64 && !tiled && !g->cfg.no_rm;
-    if (rm_shape && ((mode == 0 && g->has_rm && g->fn_isa_rm && !(rs < 0 || rs >= (1ll << 23))) || (fused_acc && g->has_rm_acc && g->fn_isa_rm_acc))) {
-      const long n4 = (long)(B & ~(int64_t)63), lss = ss, lls = ls, tail = (long)B - n4;
-      void *a_wsp = g->d_ws;
-      if (mode == 0) {
-        long nwg = std::min<long>(n4 / 64, grid4), rrs = rs, rrk = rk, nn = n4, tls = 64 * lss, trs = 64 * rrs;
-        const double *nowt = nullptr;
-        void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&d_root, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt, &tls, &trs};
-        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rm, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
-        g->last_kernel = "fdg_isa_eval_rm";
-        named = true;                    // (the last B % 64 rows below do not rename the call)
-        if (tail) { rc = launch_isa(d_leaf + (size_t)n4 * (size_t)ss, lss, lls, d_root + (size_t)n4 * (size_t)rs, rrs, rrk, tail); if (rc) return rc; }
-      } else {
-        double *part = (double *)((char *)g->d_ws + panel_all);
-        long nwg = std::min<long>(n4 / 64, grid5), zero = 0, nn = n4, tls = 64 * lss;
-        void *args[] = {(void *)&d_leaf, (void *)&lss, (void *)&lls, (void *)&part, &zero, &zero, &a_wsp, &nn, &nwg, (void *)&d_weight, &tls, &zero};
-        HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rm_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, st, args, nullptr));
-        hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, part, (uint32_t)nwg, R, d_acc);
-        HIP_TRY(hipGetLastError());
-        g->last_kernel = "fdg_isa_eval_rm_acc";
-        named = true;
-        if (tail) { rc = launch_acc(d_leaf + (size_t)n4 * (size_t)ss, lss, lls, d_weight ? d_weight + n4 : nullptr, tail); if (rc) return rc; }
-      }
-      return FDG_OK;
-    }
-    if (mode == 0 && (rs < 0 || rs >= (1ll << 23))) { set_error("root sample stride negative or of 2^23 elements or more is not supported by the ISA kernel"); return FDG_E_UNSUPPORTED; }
-    if (!tiled && ((ls == 1 && ss != 1 && p.L > 1) || (wide_ss && p.L > 0))) {
-      // sample-major input (compile_Python's [B, L]): the ISA kernel wants a wave's 64 samples of
-      // one leaf contiguous, so chunks of the batch are transposed to leaf-major first
-      // (2 extra HBM passes over the leaves; in-kernel LDS staging would avoid them -- DESIGN.md 8)
-      // Chunks are double-buffered: the transposition of chunk c+1 (HBM-bound) runs on an internal
-      // stream while the evaluator works on chunk c (fp64-bound for all but tiny graphs).
-      const unsigned long long chunk_bytes = g->cfg.sm_chunk_bytes;
-      long Bc = std::max<long>((long)g->n_cu * 8 * 64 * 2, (long)(chunk_bytes / (8ull * p.L)));
-      Bc = std::min<long>((Bc + 63) & ~63l, (B + 63) & ~63l);
-      const size_t one = (size_t)Bc * p.L * sizeof(double);
-      const size_t need3 = 2 * one;
-      if (g->ws3_bytes < need3) {
-        if (g->d_ws3) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws3)); g->d_ws3 = nullptr; g->ws3_bytes = 0; }
-        if (hipMalloc(&g->d_ws3, need3) != hipSuccess) { set_error("hipMalloc(transposed leaves) failed"); return FDG_E_NOMEM; }
-        g->ws3_bytes = need3;
-      }
-      if (!g->s2) {
-        hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); g->s2 = s;
-        for (int i = 0; i < 2; ++i) {
-          hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->ev_t[i] = e;
-          HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->ev_k[i] = e;
-        }
-        hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->ev_in = e;
-      }
-      hipStream_t s2 = (hipStream_t)g->s2;
-      HIP_TRY(hipEventRecord((hipEvent_t)g->ev_in, st));              // the caller's leaves are ready on st
-      HIP_TRY(hipStreamWaitEvent(s2, (hipEvent_t)g->ev_in, 0));
-      auto transpose = [&](long c0, int buf) {
-        const long n = std::min<long>(Bc, B - c0);
-        if (ls == 1 && (ss & 1) == 0 && ((uintptr_t)d_leaf & 15) == 0 && p.L >= 32 && !g->cfg.transpose_narrow) {
-          const long ntile = ((n + 63) / 64) * ((p.L + 63) / 64);
-          hipLaunchKernelGGL(fdg_transpose_rows_wide, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 8)), dim3(256), 0, s2,
-                             d_leaf + c0 * ss, (long)ss, (double *)((char *)g->d_ws3 + (size_t)buf * one), Bc, n, p.L);
-        } else {
-          const long ntile = ((n + 63) / 64) * ((p.L + 31) / 32);
-          hipLaunchKernelGGL(fdg_transpose_to_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, s2,
-                             d_leaf + c0 * ss, (long)ss, (long)ls, (double *)((char *)g->d_ws3 + (size_t)buf * one), Bc, n, p.L);
-        }
-        return hipEventRecord((hipEvent_t)g->ev_t[buf], s2);
-      };
-      HIP_TRY(transpose(0, 0));
-      int c = 0;
-      for (long c0 = 0; c0 < B; c0 += Bc, ++c) {
-        const int buf = c & 1;
-        const long n = std::min<long>(Bc, B - c0);
-        if (c0 + Bc < B) {
-          // buffer buf^1 was last read by the evaluator of chunk c-1
-          if (c >= 1) HIP_TRY(hipStreamWaitEvent(s2, (hipEvent_t)g->ev_k[buf ^ 1], 0));
-          HIP_TRY(transpose(c0 + Bc, buf ^ 1));
-        }
-        HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)g->ev_t[buf], 0));
-        const double *c_leaf = (const double *)((char *)g->d_ws3 + (size_t)buf * one);
-        rc = fused_acc ? launch_acc(c_leaf, 1, Bc, d_weight ? d_weight + c0 : nullptr, n)
-                       : launch_isa(c_leaf, 1, Bc, roots + c0 * a_rs, a_rs, a_rk, n);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord((hipEvent_t)g->ev_k[buf], st));
-      }
-    } else {
-      // (accumulation through the root scratch writes it column-major: an ordinary strided array, whatever the leaves are)
-      rc = fused_acc ? launch_acc(d_leaf, (long)ss, (long)ls, d_weight, (long)B, (long)lts)
-                     : launch_isa(d_leaf, (long)ss, (long)ls, roots, a_rs, a_rk, (long)B, (long)lts, mode == 0 ? (long)rts : 0);
-      if (rc) return rc;
-    }
-    if (mode == 1 && !fused_acc) return finish_scratch_acc();
-    return FDG_OK;
-  }
-
-  if (!g->code_object.empty()) {
-    rc = ensure_module(g);
-    if (rc) return rc;
-    g->last_kernel = ls == 1 ? "fdg_spec_sm" : "fdg_spec_gen";
-    return launch_hip_source(g, (hipFunction_t)((ls == 1) ? g->fn_eval_sm : g->fn_eval_gen), mode, d_leaf, ss, ls, d_root, rs, rk,
-                             d_weight, d_acc, B, st);
-  }
-
-  // interpreter
+  const int mode = a.mode;
+  const long nblk = (long)((a.B + 255) / 256);
   g->last_kernel = "fdg_interp";
-  rc = ensure_code(g);
+  int rc = ensure_code(g);
   if (rc) return rc;
-  const bool staged = (ls == 1 && ss != 1 && p.L > 0);
+  const bool staged = (a.ls == 1 && a.ss != 1 && p.L > 0);
   const size_t lds_bytes = ((size_t)p.lds_slots + (mode ? 1u : 0u)) * 256u * sizeof(double);
   int per_cu = lds_bytes ? (int)std::min<size_t>(8, (160u * 1024u) / lds_bytes) : 8;
   if (per_cu < 1) { set_error("interpreter LDS budget exceeded"); return FDG_E_INTERNAL; }
@@ -993,8 +688,8 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
     if (lds_bytes > 64 * 1024)                                                                        \
       HIP_TRY(hipFuncSetAttribute((const void *)fdg_interp<M, S>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)lds_bytes));                                                   \
-    hipLaunchKernelGGL((fdg_interp<M, S>), dim3((unsigned)grid), dim3(256), lds_bytes, st, code, d_leaf, \
-                       (long)ss, (long)ls, d_root, (long)rs, (long)rk, d_weight, partial, (long)B, ws,  \
+    hipLaunchKernelGGL((fdg_interp<M, S>), dim3((unsigned)grid), dim3(256), lds_bytes, a.st, code, a.d_leaf, \
+                       (long)a.ss, (long)a.ls, a.d_root, (long)a.rs, (long)a.rk, a.d_weight, partial, (long)a.B, ws,  \
                        p.lds_slots, p.mem_slots, p.L, R);                                              \
   } while (0)
   if (mode == 0) { if (staged) FDG_LAUNCH(0, true); else FDG_LAUNCH(0, false); }
@@ -1002,11 +697,396 @@ int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int
 #undef FDG_LAUNCH
   HIP_TRY(hipGetLastError());
   if (mode == 1) {
-    hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, st, partial,
-                       (uint32_t)grid, R, d_acc);
+    hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, a.st, partial,
+                       (uint32_t)grid, R, a.d_acc);
     HIP_TRY(hipGetLastError());
   }
   return FDG_OK;
+}
+
+// ---- the kernels of the optimizing back end (per-graph gfx950 assembly) ---------------------------------------------------------
+// One call's launch plan: grids and workspace offsets of the variants the handle carries, then one method per variant.
+struct IsaRun {
+  fdg_graph *g;
+  const RunArgs &a;
+  const Lowered &p;
+  const uint32_t R;
+  const bool tiled;
+  long ntiles = 0, grid = 0, grid2 = 0, grid3 = 0, grid4 = 0, grid5 = 0;
+  size_t panel_all = 0;
+  bool pool_ok = false, fused_acc = false, wide_ss = false, named = false;
+  double *roots = nullptr;          // where mode 1 without fused accumulation puts the roots: the column-major scratch (roots[k * a_rk + b])
+  long a_rs = 0, a_rk = 0;
+
+  IsaRun(fdg_graph *g_, const RunArgs &a_) : g(g_), a(a_), p(g_->prog), R(g_->prog.R), tiled(a_.lts != 0 || a_.rts != 0) {}
+
+  // resident waves: one wave per workgroup; bounded by VGPRs, LDS and 32 waves/CU
+  uint32_t waves_per_cu(uint32_t vgpr, uint32_t lds_bytes) const {
+    const uint32_t valloc = std::max<uint32_t>(8, (vgpr + 7) & ~7u);
+    uint32_t per_cu = std::min<uint32_t>(8, 512 / valloc) * 4;
+    if (lds_bytes) per_cu = std::min<uint32_t>(per_cu, (160u * 1024u) / lds_bytes);
+    per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32));
+    if (g->cfg.waves_per_cu > 0) per_cu = (uint32_t)g->cfg.waves_per_cu;
+    return per_cu;
+  }
+  // A persistent wave walks tiles w, w + n, ...  With several times as many workgroups as are resident at once the later ones
+  // start as the first finish, which evens out waves that progress at different speeds (oversubscription x8: +2-3 % on the
+  // graphs that run against the power budget, +1 % on the headline; profiles/r03_log_oversubscription.txt).  Only while every
+  // workgroup keeps a few tiles and the spill panels / partial sums that are sized by the grid stay small.
+  long oversub(long resident, size_t bytes_per_wg) const {
+    if (g->cfg.waves_per_cu > 0) return resident;
+    long f = g->cfg.oversub > 0 ? g->cfg.oversub : 8;
+    while (f > 1 && (ntiles < resident * f * 4 || bytes_per_wg * (size_t)(resident * f) > ((size_t)32 << 20))) f >>= 1;
+    return resident * f;
+  }
+  // Graphs bound by memory (fewer than 2.5 executed fold steps per algorithmic byte) stream faster from FEWER resident waves: four per CU
+  // (one per SIMD) keep 4 x L x 512 bytes in flight per CU -- enough for the latency-bandwidth product -- and the memory system sees a
+  // quarter of the concurrent streams (round 4, profiles/r04_log_waves.txt: headline +3-5 %, the 2-loop graph +6-15 %); the graphs at or
+  // above the ridge want every wave they can get.  Options FDG_ISA_MEM_WAVES / FDG_ISA_MEM_OVERSUB / FDG_ISA_MEM_RATIO override (0 waves = off).
+  long shape(uint64_t valu, uint64_t bytes, uint32_t vgpr, uint32_t lds, size_t bytes_per_wg, bool accumulating = false) const {
+    const long full = (long)waves_per_cu(vgpr, lds);
+    // (a wave of a tiny graph keeps little in flight; without root stores more of them help: the 2-loop graph accumulates at 0.84 instead of
+    //  0.73, profiles/r04_log_tiny_acc_waves.txt)
+    const long mem_waves = g->cfg.mem_waves >= 0 ? g->cfg.mem_waves : (p.L >= 24 ? 4 : (accumulating ? 8 : 5));
+    if (mem_waves > 0 && g->cfg.waves_per_cu <= 0 && g->cfg.oversub <= 0 && bytes && (double)valu < g->cfg.mem_ratio * (double)bytes && full > mem_waves) {
+      long f = g->cfg.mem_oversub;
+      while (f > 1 && ntiles < (long)g->n_cu * mem_waves * f * 4) f >>= 1;
+      return (long)g->n_cu * mem_waves * f;
+    }
+    return oversub((long)g->n_cu * full, bytes_per_wg);
+  }
+  // a matrix whose 64-sample tiles are whole 128-byte lines (samples of a column contiguous, column stride a multiple of 16
+  // doubles, base on a line): the streaming variants may be used (non-temporal accesses would fetch a shared line twice)
+  bool line_aligned(const void *base, long sample_stride, long col_stride) const {
+    return sample_stride == 1 && (col_stride & 15) == 0 && ((uintptr_t)base & 127) == 0 && !g->cfg.no_streaming;
+  }
+
+  int plan() {
+    ntiles = (long)((a.B + 63) / 64);
+    grid = std::min<long>(ntiles, shape(g->st_valu[0], 8ull * (p.L + R), g->isa_vgpr, g->isa_lds_bytes, (size_t)g->isa_mem_slots * 512u));
+    grid2 = g->has_w2 ? (long)g->n_cu * waves_per_cu(g->isa2_vgpr, g->isa2_lds_bytes) : 0;
+    const size_t panel = std::max((size_t)std::max<uint32_t>(g->isa_mem_slots, 1) * 512u * (size_t)grid,
+                                  (size_t)std::max<uint32_t>(g->isa2_mem_slots, 1) * 1024u * (size_t)grid2);
+    // pooled cooperative variant: full tiles of batches whose samples of a leaf are contiguous and whose leaves lie within 2 GB of the tile's first
+    pool_ok = g->has_pool && g->fn_isa_pool && a.ss == 1 && a.ls > 0 && (g->pool_unit == 1 || a.ls == 64) &&
+              (uint64_t)a.ls * 8u * (uint64_t)std::max<uint32_t>(p.L, 1) < (1ull << 31) && a.B >= 64 && !g->cfg.no_pool;
+    // (a graph that has the pooled variant accumulates through it and the root scratch: its fused-accumulation program, with R + 2 fewer value
+    //  registers and no pool, runs the 4-loop GV vertex function at 0.87e8 samples/s where the pooled evaluation + the weighted sum do 1.3e8)
+    fused_acc = a.mode == 1 && g->has_acc && !g->cfg.no_fused_acc && !(pool_ok && !g->cfg.pool_no_acc);
+    grid3 = g->has_acc ? shape(g->st_valu[1], 8ull * p.L, g->isa3_vgpr, g->isa3_lds_bytes, ((size_t)g->isa3_mem_slots + R) * 512u, true) : 0;
+    const size_t panel3 = (size_t)std::max<uint32_t>(g->isa3_mem_slots, 1) * 512u * (size_t)grid3;
+    grid4 = g->has_rm ? (long)g->n_cu * waves_per_cu(g->isa4_vgpr, g->isa4_lds_bytes) : 0;
+    const size_t panel4 = (size_t)std::max<uint32_t>(g->isa4_mem_slots, 1) * 512u * (size_t)grid4;
+    grid5 = g->has_rm_acc ? (long)g->n_cu * waves_per_cu(g->isa5_vgpr, g->isa5_lds_bytes) : 0;
+    const size_t panel5 = (size_t)std::max<uint32_t>(g->isa5_mem_slots, 1) * 512u * (size_t)grid5;
+    panel_all = (std::max(std::max(panel, panel3), std::max(panel4, panel5)) + 4095) & ~(size_t)4095;
+    int rc = ensure_ws(g, panel_all + (size_t)std::max(grid3, grid5) * R * 512u + 4096);
+    if (rc) return rc;
+    roots = a.d_root; a_rs = (long)a.rs; a_rk = (long)a.rk;
+    if (a.mode == 1 && !fused_acc) {
+      rc = ensure_root_scratch(g, (size_t)((a.B + 15) & ~(int64_t)15) * std::max<uint32_t>(R, 1) * sizeof(double) + (size_t)2048 * R * sizeof(double));
+      if (rc) return rc;
+      roots = (double *)g->d_ws2; a_rs = 1; a_rk = (long)((a.B + 15) & ~(int64_t)15);      // column-major scratch: root k of sample b at roots[k * ld + b]
+    }
+    // the kernel forms a lane's offset (lane * stride * 8) in 32 bits: strides that large are brought into the
+    // leaf-major workspace first (leaves) or refused (roots); neither occurs with the layouts of DESIGN.md 2
+    wide_ss = a.ss < 0 || a.ss >= (1ll << 23);           // (the offset is unsigned: negative strides too)
+    return FDG_OK;
+  }
+
+  // fused accumulation: acc[k] += sum_b w_b root_k(b) with per-lane accumulators inside the evaluator (fdg_isa_eval_acc[_nt])
+  int launch_acc(const double *lf, long lss, long lls, const double *wt, long n, long tls = 0) {
+    void *a_wsp = g->d_ws;
+    double *part = (double *)((char *)g->d_ws + panel_all);
+    long nwg = std::min<long>((n + 63) / 64, grid3), zero = 0;
+    if (!tls) tls = 64 * lss;
+    void *args[] = {(void *)&lf, &lss, &lls, (void *)&part, &zero, &zero, &a_wsp, &n, &nwg, (void *)&wt, &tls, &zero};
+    void *fn = g->fn_isa_acc_nt && line_aligned(lf, lss, lls) && (tls & 15) == 0 ? g->fn_isa_acc_nt : g->fn_isa_acc;
+    if (!named) g->last_kernel = fn == g->fn_isa_acc ? "fdg_isa_eval_acc" : "fdg_isa_eval_acc_nt";
+    HIP_TRY(hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)nwg, 1, 1, 64, 1, 1, 0, a.st, args, nullptr));
+    hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, a.st, part, (uint32_t)nwg, R, a.d_acc);
+    HIP_TRY(hipGetLastError());
+    return FDG_OK;
+  }
+  // one batch with sample stride `lss` (fdg_isa_eval[_nt]): full 128-sample tiles through the two-samples-per-lane kernel
+  // when there is one and the samples of a leaf are contiguous, the rest through the W = 1 kernel
+  int launch_isa(const double *lf, long lss, long lls, double *rt, long rrs, long rrk, long n, long tls = 0, long trs = 0) {
+    void *a_wsp = g->d_ws;
+    long done = 0;
+    if (g->has_w2 && lss == 1 && n >= 128 && !tls && !trs && !g->cfg.no_w2) {
+      long n2 = n & ~127l;
+      long nwg = std::min<long>(n2 / 128, grid2);
+      const double *nowt = nullptr;
+      long tls2 = 128 * lss, trs2 = 128 * rrs;
+      void *args[] = {(void *)&lf, &lss, &lls, (void *)&rt, &rrs, &rrk, &a_wsp, &n2, &nwg, (void *)&nowt, &tls2, &trs2};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_w2, (unsigned)nwg, 1, 1, 64, 1, 1, 0, a.st, args, nullptr));
+      g->last_kernel = "fdg_isa_eval_w2";
+      done = n2;
+    }
+    if (done < n) {
+      const double *lf1 = lf + done * lss;
+      double *rt1 = rt + done * rrs;
+      long n1 = n - done;
+      long nwg = std::min<long>((n1 + 63) / 64, grid);
+      const double *nowt = nullptr;
+      if (!tls) tls = 64 * lss;
+      if (!trs) trs = 64 * rrs;
+      void *args[] = {(void *)&lf1, &lss, &lls, (void *)&rt1, &rrs, &rrk, &a_wsp, &n1, &nwg, (void *)&nowt, &tls, &trs};
+      void *fn = g->fn_isa_nt && line_aligned(lf1, lss, lls) && line_aligned(rt1, rrs, rrk) && ((tls | trs) & 15) == 0 ? g->fn_isa_nt : g->fn_isa;
+      if (!named && done == 0) g->last_kernel = fn == g->fn_isa ? "fdg_isa_eval" : "fdg_isa_eval_nt";
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)fn, (unsigned)nwg, 1, 1, 64, 1, 1, 0, a.st, args, nullptr));
+    }
+    return FDG_OK;
+  }
+  // mode 1 without fused accumulation: the roots went to the column-major scratch; now the weighted sum
+  int finish_scratch_acc() {
+    double *partial = roots + (size_t)a_rk * R;
+    const uint32_t pb = weighted_segments((long)a.B, R);
+    const uint8_t *live = nullptr;
+    const int rcl = root_live_mask(g, &live);
+    if (rcl) return rcl;
+    hipLaunchKernelGGL(fdg_weighted_partials, dim3(pb * R), dim3(256), 0, a.st, roots, a_rk, a.d_weight, (long)a.B, R, pb, partial, live);
+    hipLaunchKernelGGL(fdg_reduce_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, a.st, partial, pb, R, a.d_acc);
+    HIP_TRY(hipGetLastError());
+    return FDG_OK;
+  }
+
+  // Pooled cooperative variant (fdg_isa_eval_pool): one workgroup per CU walks full 64-sample tiles; a leaf's 64 samples must be contiguous (the
+  // pool fetch reads 16 bytes per lane) and every leaf within 2^31 bytes of the tile's first -- tile-major batches, or small leaf-major matrices.
+  // The last B % 64 samples go through the one-wave kernel.
+  bool wants_pool() const { return pool_ok && ((a.mode == 0 && root_stride_ok(a)) || (a.mode == 1 && !fused_acc)); }
+  int run_pool() {
+    const int mode = a.mode;
+    const long n4 = (long)(a.B & ~(int64_t)63), tail = (long)a.B - n4;
+    double *rt0 = mode == 0 ? a.d_root : roots;
+    const double *lf = a.d_leaf;
+    long nwg = std::min<long>(n4 / 64, (long)g->n_cu), lss = a.ss, lls = a.ls, rrs = mode == 0 ? a.rs : a_rs, rrk = mode == 0 ? a.rk : a_rk;
+    int rc = ensure_ws(g, std::max(panel_all + (size_t)grid3 * R * 512u + 4096, (size_t)g->pool_panel_wg * (size_t)nwg + 4096));
+    if (rc) return rc;
+    void *a_wsp = g->d_ws;
+    const double *nowt = nullptr;
+    long tls = a.lts ? (long)a.lts : 64 * lss, trs = (mode == 0 && a.rts) ? (long)a.rts : 64 * rrs, nn = n4;
+    void *args[] = {(void *)&lf, &lss, &lls, (void *)&rt0, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt, &tls, &trs};
+    HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_pool, (unsigned)nwg, 1, 1, g->pool_threads, 1, 1, 0, a.st, args, nullptr));
+    g->last_kernel = "fdg_isa_eval_pool";
+    named = true;
+    if (tail) { rc = launch_isa(a.d_leaf + (size_t)(n4 / 64) * (size_t)tls, lss, lls, rt0 + (size_t)(n4 / 64) * (size_t)trs, rrs, rrk, tail, a.lts ? tls : 0, (mode == 0 && a.rts) ? trs : 0); if (rc) return rc; }
+    return mode == 1 ? finish_scratch_acc() : FDG_OK;
+  }
+
+  // Cooperative variant (fdg_isa_eval_coop): one workgroup of four waves per CU, every workgroup walks tiles of 64 samples; leaf-major input.
+  bool wants_coop() const {
+    return a.mode == 0 && g->has_coop && g->coop_enabled && g->fn_isa_coop && !(a.ls == 1 && a.ss != 1 && p.L > 1) && !wide_ss && root_stride_ok(a) && !g->cfg.no_coop;
+  }
+  int run_coop() {
+    const double *lf = a.d_leaf; double *rt = a.d_root;
+    long nwg = std::min<long>((long)((a.B + 63) / 64), (long)g->n_cu), lss = a.ss, lls = a.ls, rrs = a.rs, rrk = a.rk, n = (long)a.B;
+    int rc = ensure_ws(g, std::max(panel_all + (size_t)grid3 * R * 512u + 4096, (size_t)g->coop_panel_wg * (size_t)nwg + 4096));
+    if (rc) return rc;
+    void *a_wsp = g->d_ws;
+    const double *nowt = nullptr;
+    long tls = a.lts ? (long)a.lts : 64 * lss, trs = a.rts ? (long)a.rts : 64 * rrs;
+    void *args[] = {(void *)&lf, &lss, &lls, (void *)&rt, &rrs, &rrk, &a_wsp, &n, &nwg, (void *)&nowt, &tls, &trs};
+    HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_coop, (unsigned)nwg, 1, 1, g->coop_threads, 1, 1, 0, a.st, args, nullptr));
+    g->last_kernel = "fdg_isa_eval_coop";
+    return FDG_OK;
+  }
+
+  // Linear row-major variant with fused accumulation (fdg_isa_eval_rl_acc): contiguous rows ([B, L], sample stride == L, 16-byte aligned base);
+  // full tiles stream the tile's block into an LDS image, the last B % 64 rows go through launch_acc with the caller's strides
+  int run_rl_acc() {
+    const long n4 = (long)(a.B & ~(int64_t)63), tail = (long)a.B - n4;
+    const long grid7 = (long)g->n_cu * waves_per_cu(g->isa7_vgpr, g->isa7_lds_bytes);
+    const size_t panel7 = ((size_t)std::max<uint32_t>(g->isa7_mem_slots, 1) * 512u * (size_t)grid7 + 4095) & ~(size_t)4095;
+    // (the partial sums of this launch and of the tail's launch_acc live behind the larger of the two panels)
+    int rc = ensure_ws(g, std::max(panel_all, panel7) + (size_t)std::max(std::max(grid3, grid5), grid7) * R * 512u + 4096);
+    if (rc) return rc;
+    void *a_wsp = g->d_ws;
+    double *part = (double *)((char *)g->d_ws + std::max(panel_all, panel7));
+    const double *lf = a.d_leaf, *wt = a.d_weight;
+    long nwg = std::min<long>(n4 / 64, grid7), lss = a.ss, lls = a.ls, zero = 0, nn = n4, tls = 64 * lss;
+    void *args[] = {(void *)&lf, (void *)&lss, (void *)&lls, (void *)&part, &zero, &zero, &a_wsp, &nn, &nwg, (void *)&wt, &tls, &zero};
+    HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rl_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, a.st, args, nullptr));
+    hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, a.st, part, (uint32_t)nwg, R, a.d_acc);
+    HIP_TRY(hipGetLastError());
+    g->last_kernel = "fdg_isa_eval_rl_acc";
+    named = true;
+    if (tail) { rc = launch_acc(a.d_leaf + (size_t)n4 * (size_t)a.ss, lss, lls, a.d_weight ? a.d_weight + n4 : nullptr, tail); if (rc) return rc; }
+    return FDG_OK;
+  }
+  // ... and the evaluation (fdg_isa_eval_rl)
+  int run_rl() {
+    const long n4 = (long)(a.B & ~(int64_t)63), tail = (long)a.B - n4;
+    const long grid6 = (long)g->n_cu * waves_per_cu(g->isa6_vgpr, g->isa6_lds_bytes);
+    int rc = ensure_ws(g, std::max(panel_all + (size_t)std::max(grid3, grid5) * R * 512u + 4096, (size_t)std::max<uint32_t>(g->isa6_mem_slots, 1) * 512u * (size_t)grid6 + 4096));
+    if (rc) return rc;
+    void *a_wsp = g->d_ws;
+    const double *lf = a.d_leaf; double *rt = a.d_root;
+    long nwg = std::min<long>(n4 / 64, grid6), lss = a.ss, lls = a.ls, rrs = a.rs, rrk = a.rk, nn = n4, tls = 64 * lss, trs = 64 * rrs;
+    const double *nowt = nullptr;
+    void *args[] = {(void *)&lf, (void *)&lss, (void *)&lls, (void *)&rt, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt, &tls, &trs};
+    HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rl, (unsigned)nwg, 1, 1, 64, 1, 1, 0, a.st, args, nullptr));
+    g->last_kernel = "fdg_isa_eval_rl";
+    named = true;
+    if (tail) { rc = launch_isa(a.d_leaf + (size_t)n4 * (size_t)a.ss, lss, lls, a.d_root + (size_t)n4 * (size_t)a.rs, rrs, rrk, tail); if (rc) return rc; }
+    return FDG_OK;
+  }
+
+  // Row-major leaves ([B, L], leaf stride 1, any row pitch): full 64-row tiles go through the variant that stages chunks of rows in LDS
+  // itself (fdg_isa_eval_rm / _rm_acc) -- the matrix is read once, in place -- for evaluation and for fused accumulation alike; the last
+  // B % 64 rows go through the plain kernel with the caller's strides (its lanes gather their own rows: fine for under a tile).
+  bool wants_rm() const {
+    const bool rm_shape = a.ls == 1 && a.ss >= (int64_t)p.L && !wide_ss && p.L >= 16 && a.B >= 64 && !tiled && !g->cfg.no_rm;
+    return rm_shape && ((a.mode == 0 && g->has_rm && g->fn_isa_rm && root_stride_ok(a)) || (fused_acc && g->has_rm_acc && g->fn_isa_rm_acc));
+  }
+  int run_rm() {
+    const long n4 = (long)(a.B & ~(int64_t)63), lss = a.ss, lls = a.ls, tail = (long)a.B - n4;
+    void *a_wsp = g->d_ws;
+    const double *lf = a.d_leaf;
+    int rc;
+    if (a.mode == 0) {
+      double *rt = a.d_root;
+      long nwg = std::min<long>(n4 / 64, grid4), rrs = a.rs, rrk = a.rk, nn = n4, tls = 64 * lss, trs = 64 * rrs;
+      const double *nowt = nullptr;
+      void *args[] = {(void *)&lf, (void *)&lss, (void *)&lls, (void *)&rt, &rrs, &rrk, &a_wsp, &nn, &nwg, (void *)&nowt, &tls, &trs};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rm, (unsigned)nwg, 1, 1, 64, 1, 1, 0, a.st, args, nullptr));
+      g->last_kernel = "fdg_isa_eval_rm";
+      named = true;                    // (the last B % 64 rows below do not rename the call)
+      if (tail) { rc = launch_isa(a.d_leaf + (size_t)n4 * (size_t)a.ss, lss, lls, a.d_root + (size_t)n4 * (size_t)a.rs, rrs, rrk, tail); if (rc) return rc; }
+    } else {
+      double *part = (double *)((char *)g->d_ws + panel_all);
+      const double *wt = a.d_weight;
+      long nwg = std::min<long>(n4 / 64, grid5), zero = 0, nn = n4, tls = 64 * lss;
+      void *args[] = {(void *)&lf, (void *)&lss, (void *)&lls, (void *)&part, &zero, &zero, &a_wsp, &nn, &nwg, (void *)&wt, &tls, &zero};
+      HIP_TRY(hipModuleLaunchKernel((hipFunction_t)g->fn_isa_rm_acc, (unsigned)nwg, 1, 1, 64, 1, 1, 0, a.st, args, nullptr));
+      hipLaunchKernelGGL(fdg_reduce_lane_partials, dim3(std::min<uint32_t>(R, 64u)), dim3(256), 0, a.st, part, (uint32_t)nwg, R, a.d_acc);
+      HIP_TRY(hipGetLastError());
+      g->last_kernel = "fdg_isa_eval_rm_acc";
+      named = true;
+      if (tail) { rc = launch_acc(a.d_leaf + (size_t)n4 * (size_t)a.ss, lss, lls, a.d_weight ? a.d_weight + n4 : nullptr, tail); if (rc) return rc; }
+    }
+    return FDG_OK;
+  }
+
+  // Sample-major input (compile_Python's [B, L]) of a program without a row-major variant, or a sample stride too wide for the kernel's 32-bit
+  // lane offset: the ISA kernel wants a wave's 64 samples of one leaf contiguous, so chunks of the batch are transposed to leaf-major first
+  // (2 extra HBM passes over the leaves).  Chunks are double-buffered: the transposition of chunk c+1 (HBM-bound) runs on an internal
+  // stream while the evaluator works on chunk c (fp64-bound for all but tiny graphs).
+  bool wants_transposition() const { return !tiled && ((a.ls == 1 && a.ss != 1 && p.L > 1) || (wide_ss && p.L > 0)); }
+  int run_transposed() {
+    const int64_t B = a.B, ss = a.ss, ls = a.ls;
+    const hipStream_t st = a.st;
+    long Bc = std::max<long>((long)g->n_cu * 8 * 64 * 2, (long)(g->cfg.sm_chunk_bytes / (8ull * p.L)));
+    Bc = std::min<long>((Bc + 63) & ~63l, (B + 63) & ~63l);
+    const size_t one = (size_t)Bc * p.L * sizeof(double);
+    const size_t need3 = 2 * one;
+    if (g->ws3_bytes < need3) {
+      if (g->d_ws3) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g->d_ws3)); g->d_ws3 = nullptr; g->ws3_bytes = 0; }
+      if (hipMalloc(&g->d_ws3, need3) != hipSuccess) { set_error("hipMalloc(transposed leaves) failed"); return FDG_E_NOMEM; }
+      g->ws3_bytes = need3;
+    }
+    if (!g->s2) {
+      hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); g->s2 = s;
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->ev_t[i] = e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->ev_k[i] = e;
+      }
+      hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->ev_in = e;
+    }
+    hipStream_t s2 = (hipStream_t)g->s2;
+    HIP_TRY(hipEventRecord((hipEvent_t)g->ev_in, st));              // the caller's leaves are ready on st
+    HIP_TRY(hipStreamWaitEvent(s2, (hipEvent_t)g->ev_in, 0));
+    auto transpose = [&](long c0, int buf) {
+      const long n = std::min<long>(Bc, B - c0);
+      if (ls == 1 && (ss & 1) == 0 && ((uintptr_t)a.d_leaf & 15) == 0 && p.L >= 32 && !g->cfg.transpose_narrow) {
+        const long ntile = ((n + 63) / 64) * ((p.L + 63) / 64);
+        hipLaunchKernelGGL(fdg_transpose_rows_wide, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 8)), dim3(256), 0, s2,
+                           a.d_leaf + c0 * ss, (long)ss, (double *)((char *)g->d_ws3 + (size_t)buf * one), Bc, n, p.L);
+      } else {
+        const long ntile = ((n + 63) / 64) * ((p.L + 31) / 32);
+        hipLaunchKernelGGL(fdg_transpose_to_leaf_major, dim3((unsigned)std::min<long>(ntile, (long)g->n_cu * 16)), dim3(256), 0, s2,
+                           a.d_leaf + c0 * ss, (long)ss, (long)ls, (double *)((char *)g->d_ws3 + (size_t)buf * one), Bc, n, p.L);
+      }
+      return hipEventRecord((hipEvent_t)g->ev_t[buf], s2);
+    };
+    HIP_TRY(transpose(0, 0));
+    int c = 0, rc;
+    for (long c0 = 0; c0 < B; c0 += Bc, ++c) {
+      const int buf = c & 1;
+      const long n = std::min<long>(Bc, B - c0);
+      if (c0 + Bc < B) {
+        // buffer buf^1 was last read by the evaluator of chunk c-1
+        if (c >= 1) HIP_TRY(hipStreamWaitEvent(s2, (hipEvent_t)g->ev_k[buf ^ 1], 0));
+        HIP_TRY(transpose(c0 + Bc, buf ^ 1));
+      }
+      HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)g->ev_t[buf], 0));
+      const double *c_leaf = (const double *)((char *)g->d_ws3 + (size_t)buf * one);
+      rc = fused_acc ? launch_acc(c_leaf, 1, Bc, a.d_weight ? a.d_weight + c0 : nullptr, n)
+                     : launch_isa(c_leaf, 1, Bc, roots + c0 * a_rs, a_rs, a_rk, n);
+      if (rc) return rc;
+      HIP_TRY(hipEventRecord((hipEvent_t)g->ev_k[buf], st));
+    }
+    return FDG_OK;
+  }
+
+  // the caller's batch as it is: the plain / streaming kernels (a strided matrix or a tile-major batch), fused accumulation or roots
+  int run_direct() {
+    // (accumulation through the root scratch writes it column-major: an ordinary strided array, whatever the leaves are)
+    return fused_acc ? launch_acc(a.d_leaf, (long)a.ss, (long)a.ls, a.d_weight, (long)a.B, (long)a.lts)
+                     : launch_isa(a.d_leaf, (long)a.ss, (long)a.ls, roots, a_rs, a_rk, (long)a.B, (long)a.lts, a.mode == 0 ? (long)a.rts : 0);
+  }
+};
+
+int run_isa(fdg_graph *g, const RunArgs &a, bool rl_shape) {
+  int rc = ensure_module(g);
+  if (rc) return rc;
+  IsaRun r(g, a);
+  rc = r.plan();
+  if (rc) return rc;
+  if (r.wants_pool()) return r.run_pool();
+  if (r.wants_coop()) return r.run_coop();
+  if (rl_shape && a.mode == 1 && g->fn_isa_rl_acc && !r.tiled) return r.run_rl_acc();
+  if (rl_shape && a.mode == 0 && g->fn_isa_rl && !r.tiled) return r.run_rl();
+  if (r.wants_rm()) return r.run_rm();
+  if (a.mode == 0 && !root_stride_ok(a)) { set_error("root sample stride negative or of 2^23 elements or more is not supported by the ISA kernel"); return FDG_E_UNSUPPORTED; }
+  rc = r.wants_transposition() ? r.run_transposed() : r.run_direct();
+  if (rc) return rc;
+  if (a.mode == 1 && !r.fused_acc) return r.finish_scratch_acc();
+  return FDG_OK;
+}
+}  // namespace
+
+int fdg_run_locked(fdg_graph *g, int mode, const double *d_leaf, int64_t ss, int64_t ls, double *d_root,
+                   int64_t rs, int64_t rk, const double *d_weight, double *d_acc, int64_t B, hipStream_t st,
+                   int64_t lts, int64_t rts) {
+  int rc = ensure_device(g);
+  if (rc) return rc;
+  const Lowered &p = g->prog;
+  const uint32_t R = p.R;
+  const RunArgs a{mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st, lts, rts};
+  const bool isa = !g->code_object.empty() && g->isa;
+  // Tile-major batches (fdg_eval_device_tiled): tile t holds samples 64 t .. 64 t + 63 at base + t * tile stride.  Only the
+  // kernels of the optimizing back end take a tile stride; a plain strided matrix is the case tile stride = 64 * sample stride.
+  const bool tiled = lts != 0 || rts != 0;
+  if (tiled && !isa) { set_error("tile-major batches need a handle specialised with FDG_SPEC_ISA"); return FDG_E_UNSUPPORTED; }
+  if (tiled && (lts < 0 || rts < 0 || ss < 0 || ss >= (1ll << 23) || (mode == 0 && !root_stride_ok(a)))) {
+    set_error("tile-major batch: negative strides or sample strides of 2^23 elements or more are not supported"); return FDG_E_UNSUPPORTED;
+  }
+  // contiguous rows ([B, L] with sample stride L): the linear row-major variant
+  const bool rl_rows = g->has_rl && ls == 1 && ss == (int64_t)p.L && p.L >= 2 && B >= 64 && ((uintptr_t)d_leaf & 15) == 0 && !g->cfg.no_rl;
+  const bool rl_shape = rl_rows && ((mode == 0 && root_stride_ok(a)) || (mode == 1 && g->has_rl_acc && g->has_acc && !g->cfg.no_fused_acc));
+  if (mode == 0 && isa && g->cfg.root_scratch_min && R >= g->cfg.root_scratch_min && rk == 1 && rs >= (int64_t)R && (rts == 0 || rts == 64 * rs) && B >= 256 &&
+      !(ls == 1 && ss != 1 && (g->alt_code.size() || g->has_rm || rl_rows)))     // (the row-major variants write a tile's rows together: left alone)
+    return run_through_root_scratch(g, a);
+  if (isa && !g->alt_code.empty() && ls == 1 && ss != 1 && p.L > 1 && !tiled && !rl_shape) return run_companion(g, a);
+  if (isa) return run_isa(g, a, rl_shape);
+  if (!g->code_object.empty()) {      // the compiler-scheduled per-graph kernels (HIP source through hiprtc)
+    rc = ensure_module(g);
+    if (rc) return rc;
+    g->last_kernel = ls == 1 ? "fdg_spec_sm" : "fdg_spec_gen";
+    return launch_hip_source(g, (hipFunction_t)((ls == 1) ? g->fn_eval_sm : g->fn_eval_gen), mode, d_leaf, ss, ls, d_root, rs, rk, d_weight, d_acc, B, st);
+  }
+  return run_interpreter(g, a);
 }
 
 // ---------------------------------------------------------------------------

@@ -576,5 +576,5 @@ def test_handle_options_replace_the_environment(libfdg, monkeypatch):
         assert not re.search(r'getenv\("FDG_', text), f
     # the launch path (fdg_run_locked ... the launches) does not even look an option up by name
     rt = open(os.path.join(src, "fdg_runtime.hip")).read()
-    body = rt[rt.index("int fdg_run_locked("):rt.index("// JIT\n")]
+    body = rt[rt.index("// The launch path."):rt.index("// JIT\n")]
     assert "knob(" not in body and "getenv" not in body
