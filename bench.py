@@ -28,7 +28,7 @@ FP64_NOFMA_PEAK_TOPS = 39.3
 SPEC_CLOCK_GHZ = 2.4            # the clock the 39.3 is quoted at; roofline.clock_ghz is what the chip sustained (power budget)
 FP64_NOFMA_MEASURED_TOPS = 38.0
 CONFIG5_TOTAL_SAMPLES = 1_000_000_000     # BASELINE.json config 5: 10^9 samples over the GPUs of the node
-LINE_LIMIT = 3600                         # bytes of the stdout line (the driver keeps the last ~8 KB of stdout)
+LINE_LIMIT = 4000                         # bytes of the stdout line (the driver keeps the last ~8 KB of stdout)
 DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
 
 
@@ -253,6 +253,24 @@ class Case:
             return self.f.accumulate_tiled(self.leaf, w, acc, self.B)
         return self.f.accumulate(self.leaf, w, acc)
 
+    def settle(self, step=None, max_s=4.0):
+        """Launches until the rate is steady: eight launches in a row within 1.5 % of each other (at most `max_s` seconds).  A batch is
+        allocated and filled moments before it is measured, and the driver may still be wiping what the previous measurement released
+        (settle_after_free waits by the clock; this waits by the kernel's own rate: profiles/r05_log_alloc_sensitivity_latency_bound.txt)."""
+        if DRY:
+            return
+        import torch
+        step = step or self.step
+        t0 = time.perf_counter()
+        hist = []
+        while time.perf_counter() - t0 < max_s:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream); step(); e1.record(self.stream)
+            e1.synchronize()
+            hist.append(e0.elapsed_time(e1))
+            if len(hist) >= 8 and min(hist[-8:]) > 0.985 * max(hist[-8:]):
+                break
+
     def timed(self, steps, warm, step=None):
         """`warm` untimed launches, then `steps` launches bracketed by HIP events on the launch stream.  Returns ms per launch (list).
         Next to the timed launches one sleeping wave on a side stream (fdg_clock_probe_device) reads the shader clock the chip
@@ -268,7 +286,14 @@ class Case:
             pre = Stamps(2, self.stream)          # two more untimed launches give the length of the region the probe has to cover
             pre.record(0); step(); pre.record(1); step(); pre.record(2)
             sync()
-            probe = probe_start(self.dev, 0.85 * min(pre.ms()) * 1e-3 * steps)
+            # starting the probe costs a synchronisation and a few milliseconds of idle device: the memory side's clocks fall back and need tens of
+            # milliseconds of load to return (round 5: rows measured right after that gap ran 5-10 % slow at a HIGH shader clock) -- so the
+            # timed launches are preceded by ~40 ms of untimed ones inside the probe's window
+            per = min(pre.ms())
+            rewarm = min(400, max(10, int(40.0 / max(per, 1e-3)) + 1))
+            probe = probe_start(self.dev, 0.9 * per * 1e-3 * (steps + rewarm))
+            for _ in range(rewarm):
+                step()
         ev = Stamps(steps, self.stream)
         ev.record(0)
         for i in range(steps):
@@ -400,6 +425,8 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
         paired = ((workload, lay) in PAIRED_ROWS or (PAIR_ALL and lay in ("tile_major", "sample_major"))) and not plain and not fma
         c = Case(workload, lay, DEFAULT_B[workload] if plain else (16_000_000 if workload == "parquet_sigma4" else DEFAULT_B.get(workload, 1_000_000)), dev,
                  flags=capi.FDG_SPEC_FAST_MATH if fma else 0, placement="paired" if paired else "plain")
+        settle_after_free(c.nbytes())        # (by the clock: whatever was released to make room for this batch is being wiped)
+        c.settle()                           # (by the kernel's own rate)
         ms = c.timed(steps, warm)
         avg = sum(ms) / len(ms) / 1e3
         ok, dev_max, n = c.parity_sample()
@@ -459,6 +486,8 @@ def config5(dev, rank, world, dist, comm, steps, warm):
         c = Case("gv_sigma5", "tile_major", count, dev, sample_offset=start)
         w = torch.rand(1 if DRY else count, dtype=torch.float64, device=dev)
         acc = torch.zeros(c.t.n_root, dtype=torch.float64, device=dev)
+        settle_after_free(c.nbytes())
+        c.settle(lambda: c.accumulate(w, acc))
         pre = Stamps(warm, c.stream)
         pre.record(0)
         for i in range(warm):
@@ -469,7 +498,13 @@ def config5(dev, rank, world, dist, comm, steps, warm):
         if dist:
             dist.barrier()
             sync()
-        probe = probe_start(dev, 0.85 * min(pre.ms()) * 1e-3 * steps) if warm else None     # (a sleeping wave on a side stream: the clock under this load)
+        per = min(pre.ms()) if warm else 1.0
+        rewarm = min(400, max(10, int(40.0 / max(per, 1e-3)) + 1)) if not DRY else 0
+        probe = probe_start(dev, 0.9 * per * 1e-3 * (steps + rewarm)) if warm else None     # (a sleeping wave on a side stream: the clock under this load)
+        for _ in range(rewarm):               # (the synchronisations above left the device idle for a moment: see Case.timed)
+            c.accumulate(w, acc)
+        acc.zero_()
+        sync()                                # (the wall clock below must not start while these are still running; a bare synchronisation is microseconds)
         ev = Stamps(steps, c.stream)
         t0 = time.perf_counter()
         ev.record(0)
