@@ -391,8 +391,10 @@ def eval_(g: Graph, leafmap=None, leaf=None, *, inherit: bool = False, randseed:
     leaf_val = np.array([float(lm[k + 1].weight) for k in range(len(lm))], dtype=np.float64)
     out = np.zeros(len(inner), dtype=np.float64)
     f(out, leaf_val)
-    for node, w in zip(inner, out):
-        node.weight = float(w)
+    by_id = {node.id: float(w) for node, w in zip(inner, out)}
+    for node in nodes:                      # every visited object, as the reference's loop assigns node.weight on every visit: distinct
+        if node.subgraphs:                  # objects that share an id (a structurally duplicated sub-graph) all get the value
+            node.weight = by_id[node.id]
     return g.weight
 
 

@@ -252,6 +252,16 @@ def test_eval_bang_mirror_on_device(libfdg, cuda):
     optimize.optimize_([h])
     assert fd.eval_(h, randseed=2) == pytest.approx(fd.eval_(_h, randseed=2), rel=1e-14)
     assert fd.eval_(h) == fd.eval_(_h) == (-28 + 3) * 2 + 3
+    # distinct objects that carry the same id (a structurally duplicated sub-graph) all get their weight, as eval! assigns
+    # node.weight on every visit
+    import copy
+    la, lb = Graph([]), Graph([])
+    sm = Graph([la, lb], subgraph_factors=[2, 3])
+    sm2 = copy.copy(sm)
+    assert sm2 is not sm and sm2.id == sm.id
+    top2 = Graph([sm, sm2], operator=Prod())
+    la.weight, lb.weight = 1.5, -0.5
+    assert fd.eval_(top2, inherit=True) == 1.5 * 1.5 and sm.weight == sm2.weight == 1.5
 
 
 
