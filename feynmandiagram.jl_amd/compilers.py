@@ -61,8 +61,8 @@ class GraphFunc:
             self.handle.set_association(capi.FDG_ASSOC_INTERP)
         self.n_leaf, self.n_root = self.table.n_leaf, self.table.n_root
         if specialize == "auto":
-            # best available: gfx950 assembly; graphs it does not cover (Power{N}, N not in {2,3}) go
-            # through the HIP-source JIT.  Both are JIT back ends of the same ABI, not fallbacks to a CPU.
+            # best available: gfx950 assembly (every Power{N}: pow_body spelled out); a graph it refuses for another reason (too few
+            # registers for its roots, ...) goes through the HIP-source JIT.  Both are JIT back ends of the same ABI, not fallbacks to a CPU.
             try:
                 self.handle.specialize(cache_dir, flags | capi.FDG_SPEC_ISA)
                 # compile_Python's row-major [B, L] is the reference's batched layout.  Most graphs read it in place through
