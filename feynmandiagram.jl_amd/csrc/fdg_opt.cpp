@@ -1496,6 +1496,8 @@ static void build_coop_once(const Lowered &p, const OptParams &prm, size_t budge
     }
     OptParams q = prm;
     q.n_lds = out.n_priv_lds;
+    q.reserve_pairs = std::max<uint32_t>(q.reserve_pairs, 2);      // the cooperative section's own registers above the temporaries (v[rm0 .. rm0 + 3], fdg_isa.cpp): with
+                                                                   // pow_body's four temporary pairs they ran past v255 (round 5 fuzz with Power{N}, |N| >= 4)
     if (!fit_registers(u, q, out.wave[w])) { out.why = out.wave[w].why; return; }
     Alloc A(p, out.wave[w].params, u, C.B[w]->next_vid, out.wave[w]);
     A.run();
@@ -1622,6 +1624,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     // distance of a wave's private LDS slots: -10 %; 200: the landing registers are missed elsewhere, -4 %; profiles/r04_log_la_lds.txt)
     q.lookahead_leaf = 96;
     if (const char *e = fdg::knob("FDG_POOL_READ_AHEAD")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(e));
+    q.reserve_pairs = std::max<uint32_t>(q.reserve_pairs, 2);      // (as in build_coop_program)
     if (!fit_registers(B[w]->u, q, out.wave[w])) { out.why = out.wave[w].why; return; }
     Alloc A(p, out.wave[w].params, B[w]->u, B[w]->next_vid, out.wave[w]);
     A.run();

@@ -362,3 +362,48 @@ def test_random_mc_step_on_device(libfdg, cuda, monkeypatch, fdgopt):
         wr = np.where(live[None, :], got, 0.0) * w.cpu().numpy()[:, None]
         fin = np.isfinite(wr).all(axis=0) & live
         assert np.all(np.abs(acc.cpu().numpy() - wr.sum(0))[fin] <= 1e-12 * np.maximum(1.0, np.abs(wr).sum(0))[fin]), seed
+
+
+def power_table(seed: int, N: int = 300):
+    """A random graph whose Power nodes take every kind of exponent: literal_pow (2, 3, -1, -2) and pow_body (4, 5, 7, -3, -4)."""
+    rng = np.random.default_rng(seed)
+    L = int(rng.integers(20, 120))
+    facs = [1.0, 1.0, -1.0, 2.0, -0.5, 0.25, 3.0, 1.0 / 3.0]
+    nodes = []
+    for n in range(N):
+        nv = L + n
+        r = rng.random()
+        if r < 0.10:
+            nodes.append((OP_POWER, int(rng.choice([2, 3, 4, 5, 7, -1, -2, -3, -4])), [(int(rng.integers(0, nv)), float(rng.choice(facs)))]))
+            continue
+        op = OP_SUM if r < 0.55 else OP_PROD
+        k = int(rng.choice([2, 2, 3, 4, 9]))
+        ch = [(int(nv - 1 - min(nv - 1, int(rng.exponential(25)))) if rng.random() < 0.7 else int(rng.integers(0, nv)), float(rng.choice(facs))) for _ in range(k)]
+        nodes.append((op, 0, ch))
+    R = int(rng.choice([2, 7, 30]))
+    roots = [int(rng.integers(L, L + N)) for _ in range(R)]
+    roots[0] = L + N - 1
+    return from_program(L, nodes, roots, f"power_{seed}")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_pow_body_powers_in_every_kernel_variant_assemble(libfdg, tmp_path, seed):
+    """Round 5 (found by the device fuzz once it drew exponents outside {2, 3}): pow_body's temporaries (four register pairs for the
+    correctly rounded division) and the cooperative section's own registers together ran past v255 -- the assembler refused the code
+    object.  Every variant the handle builds (one-wave, accumulate, streaming, row-major, linear row-major, cooperative forced on) must
+    assemble, keep the hazard table, and the allocated one-wave program must replay to the oracle's bits."""
+    os.chmod(tmp_path, 0o700)
+    t = power_table(seed)
+    f = fd.compile_table(t, specialize="isa", cache_dir=str(tmp_path), flags=capi.FDG_SPEC_KEEP_SOURCE,
+                         options={"FDG_ISA_COOP": "1", "FDG_CACHE_RO_DIR": ""})
+    ki = f.kernel_info()
+    asm = [x for x in os.listdir(tmp_path) if x.endswith(".s")]
+    assert asm
+    text = open(os.path.join(tmp_path, asm[0])).read()
+    assert capi.isa_check_hazards(text)[0] == 0
+    assert "v_div_fixup_f64" in text                                   # a negative exponent: the correctly rounded reciprocal
+    leaf = oracle.philox_uniform(9, t.n_leaf, seed) + 0.4
+    ops, nr, nl, nm = f.handle.opt_program()
+    with np.errstate(all="ignore"):
+        got = replay(ops, nr, nl, nm, f.handle.last_n_acc, leaf, t.n_root)
+    assert same(got, oracle.eval_static(t, leaf))

@@ -19,7 +19,7 @@ def table(seed):
     for n in range(N):
         nv = L + n; r = rng.random()
         if r < 0.05:
-            nodes.append((OP_POWER, int(rng.choice([2, 3])), [(int(rng.integers(0, nv)), float(rng.choice(facs)))])); continue
+            nodes.append((OP_POWER, int(rng.choice([2, 3, 2, 3, 4, 5, -1, -2, -3])), [(int(rng.integers(0, nv)), float(rng.choice(facs)))])); continue
         op = OP_SUM if r < 0.45 else OP_PROD
         k = int(rng.choice([1, 2, 2, 2, 3, 3, 4, 7, 30]))
         spread = float(rng.choice([3, 20, 200]))

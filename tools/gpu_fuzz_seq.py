@@ -17,10 +17,10 @@ for seed in range(first, last + 1):
     want = oracle.eval_static(t, h_leaf, np.full((B, t.n_root), 9.0))
     opts = [dict(n_reg=int(rng.integers(6, 40)), n_lds=int(rng.integers(1, 30)), vn_window=int(rng.choice([1, 20, 200, 1000]))),
             dict(n_reg=int(rng.integers(30, 120)), n_lds=int(rng.integers(1, 80)), n_acc=int(rng.integers(1, 124)))]
-    for k in ("FDG_ISA_W2", "FDG_REMAT_WINDOW", "FDG_ISA_COOP"): os.environ.pop(k, None)
-    if seed % 4 == 0: os.environ["FDG_ISA_W2"] = "1"; opts.append(None)
-    if seed % 3 == 0: os.environ["FDG_REMAT_WINDOW"] = str(int(rng.choice([8, 60, 400])))
-    if seed % 2 == 1: os.environ["FDG_ISA_COOP"] = "1"
+    for k in ("FDG_ISA_W2", "FDG_REMAT_WINDOW", "FDG_ISA_COOP"): capi.set_default_option(k, None)
+    if seed % 4 == 0: capi.set_default_option("FDG_ISA_W2", "1"); opts.append(None)
+    if seed % 3 == 0: capi.set_default_option("FDG_REMAT_WINDOW", str(int(rng.choice([8, 60, 400]))))
+    if seed % 2 == 1: capi.set_default_option("FDG_ISA_COOP", "1")
     for opt in opts:
         f = fd.compile_table(t, specialize="isa", opt=opt, cache_dir="/tmp/fzs", flags=capi.FDG_SPEC_KEEP_SOURCE)
         for layout in ("leaf_major", "sample_major"):
