@@ -407,3 +407,32 @@ def test_pow_body_powers_in_every_kernel_variant_assemble(libfdg, tmp_path, seed
     with np.errstate(all="ignore"):
         got = replay(ops, nr, nl, nm, f.handle.last_n_acc, leaf, t.n_root)
     assert same(got, oracle.eval_static(t, leaf))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("coop", [False, True])
+def test_pow_body_powers_on_device_in_every_layout(libfdg, cuda, seed, coop):
+    """The same graphs on the device: leaf-major, row-major and tile-major evaluation bit for bit (NaNs in place, zeros signed) and fused
+    accumulation within 1e-12 of the terms' scale, with the cooperative variant forced on and left to the library."""
+    import torch
+    from test_tile_major import to_tiles, from_tiles
+    t = power_table(seed)
+    L, R = t.n_leaf, t.n_root
+    f = fd.compile_table(t, specialize="isa", options={"FDG_ISA_COOP": "1"} if coop else None)
+    for B in (64 * 5 + 17, 4099):
+        h_leaf = oracle.philox_uniform(B, L, seed) + 0.4
+        with np.errstate(all="ignore"):
+            want = oracle.eval_static(t, h_leaf)
+        lm = torch.from_numpy(np.ascontiguousarray(h_leaf.T)).to(cuda).t()
+        assert same(f(None, lm).cpu().numpy(), want), ("leaf-major", f.kernel_info()["last_kernel"])
+        rm = torch.from_numpy(h_leaf).to(cuda)
+        assert same(f(None, rm).cpu().numpy(), want), ("row-major", f.kernel_info()["last_kernel"])
+        tm = torch.from_numpy(to_tiles(h_leaf)).to(cuda)
+        rt = f.eval_tiled(None, tm, B)
+        assert same(from_tiles(rt.cpu().numpy(), B, R), want), ("tile-major", f.kernel_info()["last_kernel"])
+        if np.isfinite(want).all():
+            w = np.random.default_rng(seed).uniform(0.5, 1.5, B)
+            acc = f.accumulate_tiled(tm, torch.from_numpy(w).to(cuda), None, B).cpu().numpy()
+            terms = want * w[:, None]
+            assert np.all(np.abs(acc - terms.sum(0)) <= 1e-12 * np.maximum(1.0, np.abs(terms).sum(0)))
