@@ -193,7 +193,7 @@ class Case:
             # the library's own allocator for a tile-major batch (fdg_batch_alloc_pair): every window of the leaves gets a chunk of roots
             # behind which the handle's kernel was MEASURED at the fast rate; a plain allocation is the "@plain" row
             try:
-                self.pair = self.f.tile_major_pair(B, dev, calibrate=True, extra_flags=int(os.environ.get("FDG_BENCH_PAIR_FLAGS", "0")))
+                self.pair = self.f.tile_major_pair(B, dev, calibrate=True)
             except Exception as e:            # (a driver without the virtual-memory API, too little free memory: the line says so and uses a plain batch)
                 self.pair, self.placement, self.pair_error = None, "plain", f"{type(e).__name__}: {e}"
                 print(f"[bench] fdg_batch_alloc_pair failed ({self.pair_error}): plain allocation instead", file=sys.stderr)

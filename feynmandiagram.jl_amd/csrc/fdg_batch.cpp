@@ -242,7 +242,7 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
   // (a window of less than ~0.5 GB of leaves is evaluated in too short a launch for the two levels to separate: nothing to calibrate on)
   const bool calibrate = (flags & FDG_BATCH_PAIR_CALIBRATE) && leaf_chunk >= ((size_t)400 << 20);
 
-  struct Phys { hipMemGenericAllocationHandle_t h; bool mapped = false; int kind = -1; bool used = false; };
+  struct Phys { hipMemGenericAllocationHandle_t h; bool mapped = false; bool used = false; };
   std::vector<Phys> cand, filler;
   std::vector<int> pick(n_chunk, -1);
   std::vector<char> root_mapped(n_chunk, 0);
@@ -303,9 +303,8 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
   // runs of 16-32 GB (profiles/r05_log_chunk_probe.txt), so every kind is among them.  The fillers go back to the driver BEFORE anything is
   // timed: the driver wipes released memory in the background, and that write stream disturbs the evaluation for a second or so exactly as
   // the root writes do (profiles/r05_log_pair_alloc_release.txt: the same mapped pairs 2-7 % slower right after 85 GB were released).
-  // Experiment switch (flag 4): the leaves before the sprinkle (pristine blocks) instead of into the space the fillers held.
-  const bool leaves_first = (flags & 4u) != 0;
-  if (leaves_first) PAIR_TRY("hipMalloc(leaves)", hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk));
+  // Then the leaves, into the space the fillers held (allocated BEFORE the sprinkle instead, the headline ran 0.814-0.818 against
+  // 0.816-0.828 in eight alternating processes: profiles/r05_b_*): the candidates then lie among the leaves' own regions.
   if (calibrate) {
     const size_t span = (size_t)80 << 30;
     for (size_t q = 0; q * filler_bytes < span && cand.size() + 2 <= max_cand / 2; ++q) {
@@ -318,7 +317,7 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
     filler.clear();
     t_released = std::chrono::steady_clock::now();
   }
-  if (!leaves_first) PAIR_TRY("hipMalloc(leaves)", hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk));
+  PAIR_TRY("hipMalloc(leaves)", hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk));
   while (cand.size() < n_chunk) PAIR_TRY("hipMemCreate(root candidate)", new_cand());
   double fast = 0, slow = 0, thr = 0;
   bool have_contrast = false;
