@@ -206,283 +206,319 @@ struct PairCtx {
 size_t gcd_sz(size_t a, size_t b) { while (b) { const size_t t = a % b; a = b; b = t; } return a; }
 }  // namespace
 
-int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint, unsigned flags, void **d_leaf, void **d_root,
-                         fdg_batch_pair_info *info) {
-  if (!g || !d_leaf || !d_root) { fdg::set_error("null argument"); return FDG_E_INVALID; }
-  *d_leaf = *d_root = nullptr;
-  if (info) std::memset(info, 0, sizeof *info);
-  if (n_sample <= 0) { fdg::set_error("empty batch"); return FDG_E_INVALID; }
-  const uint32_t L = g->prog.L, R = g->prog.R;
-  if (L == 0 || R == 0) { fdg::set_error("fdg_batch_alloc_pair: the graph has no leaves or no roots"); return FDG_E_INVALID; }
-  if (!(g->isa && !g->code_object.empty())) { fdg::set_error("fdg_batch_alloc_pair: tile-major batches need a handle specialised with FDG_SPEC_ISA"); return FDG_E_UNSUPPORTED; }
-  const auto t_start = std::chrono::steady_clock::now();
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return fail("hipGetDevice", e);
+// The allocation as an object: geometry, the address ranges, the candidates; one method per phase, abort() undoes whatever has been done.
+namespace {
+struct PairAllocator {
+  struct Phys { hipMemGenericAllocationHandle_t h; bool mapped = false; bool used = false; };
+  // request
+  fdg_graph *g; unsigned flags; int dev = 0;
+  // geometry
+  size_t gran = 0, chunk_tiles = 0, leaf_chunk = 0, root_chunk = 0, n_chunk = 0, max_cand = 0, filler_bytes = 0;
+  bool calibrate = false;
+  // state
   hipMemAllocationProp prop = {};
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = dev;
-  size_t gran = 0;
-  e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
-  if (e != hipSuccess || gran == 0) { e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum); if (e != hipSuccess) return fail("hipMemGetAllocationGranularity", e); }
-  if (gran == 0) gran = (size_t)1 << 21;
+  hipMemAccessDesc acc = {};
+  char *leaf_va = nullptr, *root_va = nullptr, *cand_va = nullptr;
+  std::vector<Phys> cand, filler;
+  std::vector<int> pick;                 // [window] candidate mapped behind it
+  std::vector<char> root_mapped;
+  PairCtx cx;
+  // what the search saw
+  double fast = 0, slow = 0, settle_s = 0;
+  std::vector<double> before, got, pred;  // [window] pair in draw order / pair when chosen; [candidate] its most recent rate
+  size_t n_full_scan = 0, n_filler_total = 0;
+  std::chrono::steady_clock::time_point t_released = std::chrono::steady_clock::now();
+  static constexpr double kFastLevel = 0.965;      // "at the fast level": within 3.5 % of the best pair seen so far
+  bool verbose() const { return (flags & FDG_BATCH_PAIR_VERBOSE) != 0; }
+  int64_t n_all() const { return (int64_t)(n_chunk * chunk_tiles) * 64; }
+  char *leaf_at(size_t i) const { return leaf_va + i * leaf_chunk; }
+  char *cand_at(size_t j) const { return cand_va + j * root_chunk; }
+  char *root_at(size_t i) const { return root_va + i * root_chunk; }
+
+  int hip_fail(const char *what, hipError_t e) { abort(); return fail(what, e); }
+  void abort() {
+    (void)hipDeviceSynchronize();
+    for (size_t i = 0; i < root_mapped.size(); ++i) if (root_mapped[i]) (void)hipMemUnmap(root_at(i), root_chunk);
+    for (size_t j = 0; j < cand.size(); ++j) { if (cand[j].mapped) (void)hipMemUnmap(cand_at(j), root_chunk); (void)hipMemRelease(cand[j].h); }
+    for (Phys &f : filler) (void)hipMemRelease(f.h);
+    cand.clear(); filler.clear(); root_mapped.assign(root_mapped.size(), 0);
+    if (leaf_va) (void)hipFree(leaf_va);
+    if (root_va) (void)hipMemAddressFree(root_va, n_chunk * root_chunk);
+    if (cand_va) (void)hipMemAddressFree(cand_va, max_cand * root_chunk);
+    leaf_va = root_va = cand_va = nullptr;
+    if (cx.ev0) (void)hipEventDestroy(cx.ev0);
+    if (cx.ev1) (void)hipEventDestroy(cx.ev1);
+    cx.ev0 = cx.ev1 = nullptr;
+  }
+
   // The LEAVES are one plain allocation (large physically contiguous pieces: what streams fastest, and what the driver gives a hipMalloc of
   // tens of GB; 1 GB physical chunks mapped one by one lose 5 % of the pure read rate, profiles/r05_log_pair_alloc_v1_vmm_leaves.txt); a
   // "chunk" of leaves is a window of it.  The ROOTS are mapped chunk by chunk: a chunk holds the roots of the tiles of one leaf window and
   // is a whole number of mapping granules.
-  const size_t lt = 512u * (size_t)L, rt = 512u * (size_t)R;                 // bytes of one tile
-  const size_t unit = gran / gcd_sz(gran, rt);                                // tiles per root granule
-  const size_t T = (size_t)((n_sample + 63) / 64);
-  const size_t hint = chunk_bytes_hint ? chunk_bytes_hint : ((size_t)2 << 30);
-  size_t k = std::max<size_t>(1, (hint + unit * lt / 2) / (unit * lt));
-  k = std::min(k, std::max<size_t>(1, (T + unit - 1) / unit));               // a small batch: one chunk
-  const size_t chunk_tiles = unit * k, leaf_chunk = chunk_tiles * lt, root_chunk = chunk_tiles * rt;
-  const size_t n_chunk = (T + chunk_tiles - 1) / chunk_tiles;
-  // (a window of less than ~0.5 GB of leaves is evaluated in too short a launch for the two levels to separate: nothing to calibrate on)
-  const bool calibrate = (flags & FDG_BATCH_PAIR_CALIBRATE) && leaf_chunk >= ((size_t)400 << 20);
+  int geometry(int64_t n_sample, size_t chunk_bytes_hint) {
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail("hipGetDevice", e);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = dev;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+    if (e != hipSuccess || gran == 0) { e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum); if (e != hipSuccess) return fail("hipMemGetAllocationGranularity", e); }
+    if (gran == 0) gran = (size_t)1 << 21;
+    const uint32_t L = g->prog.L, R = g->prog.R;
+    const size_t lt = 512u * (size_t)L, rt = 512u * (size_t)R;                 // bytes of one tile
+    const size_t unit = gran / gcd_sz(gran, rt);                                // tiles per root granule
+    const size_t T = (size_t)((n_sample + 63) / 64);
+    const size_t hint = chunk_bytes_hint ? chunk_bytes_hint : ((size_t)2 << 30);
+    size_t k = std::max<size_t>(1, (hint + unit * lt / 2) / (unit * lt));
+    k = std::min(k, std::max<size_t>(1, (T + unit - 1) / unit));               // a small batch: one chunk
+    chunk_tiles = unit * k; leaf_chunk = chunk_tiles * lt; root_chunk = chunk_tiles * rt;
+    n_chunk = (T + chunk_tiles - 1) / chunk_tiles;
+    max_cand = 8 * n_chunk + 64;
+    filler_bytes = ((((size_t)2 << 30) + gran - 1) / gran) * gran;
+    // (a window of less than ~0.5 GB of leaves is evaluated in too short a launch for the levels to separate: nothing to calibrate on)
+    calibrate = (flags & FDG_BATCH_PAIR_CALIBRATE) && leaf_chunk >= ((size_t)400 << 20);
+    pick.assign(n_chunk, -1); root_mapped.assign(n_chunk, 0); before.assign(n_chunk, 0.0); got.assign(n_chunk, 0.0);
+    cx.row_major = (flags & FDG_BATCH_PAIR_ROW_MAJOR) != 0;
+    cx.g = g; cx.L = L; cx.R = R; cx.chunk_tiles = chunk_tiles; cx.leaf_chunk = leaf_chunk; cx.root_chunk = root_chunk;
+    return FDG_OK;
+  }
 
-  struct Phys { hipMemGenericAllocationHandle_t h; bool mapped = false; bool used = false; };
-  std::vector<Phys> cand, filler;
-  std::vector<int> pick(n_chunk, -1);
-  std::vector<char> root_mapped(n_chunk, 0);
-  const size_t max_cand = 8 * n_chunk + 64;
-  char *leaf_va = nullptr, *root_va = nullptr, *cand_va = nullptr;
-  hipMemAccessDesc acc = {};
-  acc.location.type = hipMemLocationTypeDevice;
-  acc.location.id = dev;
-  acc.flags = hipMemAccessFlagsProtReadWrite;
-  PairCtx cx;
-  cx.row_major = (flags & FDG_BATCH_PAIR_ROW_MAJOR) != 0;
-  cx.g = g; cx.L = L; cx.R = R; cx.chunk_tiles = chunk_tiles; cx.leaf_chunk = leaf_chunk; cx.root_chunk = root_chunk;
-
-  auto unmap_cand = [&](size_t j) { if (cand[j].mapped) { (void)hipMemUnmap(cand_va + j * root_chunk, root_chunk); cand[j].mapped = false; } };
-  auto cleanup_fail = [&]() {
-    (void)hipDeviceSynchronize();
-    for (size_t i = 0; i < n_chunk; ++i) if (root_mapped[i]) (void)hipMemUnmap(root_va + i * root_chunk, root_chunk);
-    for (size_t j = 0; j < cand.size(); ++j) { unmap_cand(j); (void)hipMemRelease(cand[j].h); }
-    for (Phys &f : filler) (void)hipMemRelease(f.h);
-    if (leaf_va) (void)hipFree(leaf_va);
-    if (root_va) (void)hipMemAddressFree(root_va, n_chunk * root_chunk);
-    if (cand_va) (void)hipMemAddressFree(cand_va, max_cand * root_chunk);
-    if (cx.ev0) (void)hipEventDestroy(cx.ev0);
-    if (cx.ev1) (void)hipEventDestroy(cx.ev1);
-  };
-#define PAIR_TRY(what, expr) do { e = (expr); if (e != hipSuccess) { cleanup_fail(); return fail(what, e); } } while (0)
-  PAIR_TRY("hipMemAddressReserve(roots)", hipMemAddressReserve((void **)&root_va, n_chunk * root_chunk, gran, nullptr, 0));
-  PAIR_TRY("hipMemAddressReserve(root candidates)", hipMemAddressReserve((void **)&cand_va, max_cand * root_chunk, gran, nullptr, 0));
-  PAIR_TRY("hipEventCreate", hipEventCreate(&cx.ev0));
-  PAIR_TRY("hipEventCreate", hipEventCreate(&cx.ev1));
-  auto new_cand = [&]() -> hipError_t {
+  hipError_t new_cand() {
     if (cand.size() >= max_cand) return hipErrorOutOfMemory;
     Phys c;
-    hipError_t ee = hipMemCreate(&c.h, root_chunk, &prop, 0);
-    if (ee != hipSuccess) return ee;
+    hipError_t e = hipMemCreate(&c.h, root_chunk, &prop, 0);
+    if (e != hipSuccess) return e;
     const size_t j = cand.size();
-    ee = hipMemMap(cand_va + j * root_chunk, root_chunk, 0, c.h, 0);
-    if (ee != hipSuccess) { (void)hipMemRelease(c.h); return ee; }
-    ee = hipMemSetAccess(cand_va + j * root_chunk, root_chunk, &acc, 1);
-    if (ee != hipSuccess) { (void)hipMemUnmap(cand_va + j * root_chunk, root_chunk); (void)hipMemRelease(c.h); return ee; }
+    e = hipMemMap(cand_at(j), root_chunk, 0, c.h, 0);
+    if (e != hipSuccess) { (void)hipMemRelease(c.h); return e; }
+    e = hipMemSetAccess(cand_at(j), root_chunk, &acc, 1);
+    if (e != hipSuccess) { (void)hipMemUnmap(cand_at(j), root_chunk); (void)hipMemRelease(c.h); return e; }
     c.mapped = true;
     cand.push_back(c);
     return hipSuccess;
-  };
+  }
   // a 2 GB filler: moves the driver's allocator on to other regions of the memory (`reserve`: what must stay free besides)
-  const size_t filler_bytes = ((((size_t)2 << 30) + gran - 1) / gran) * gran;
-  auto new_filler = [&](size_t reserve) -> bool {
+  bool new_filler(size_t reserve) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < filler_bytes + reserve + ((size_t)8 << 30)) return false;
     Phys f;
     if (hipMemCreate(&f.h, filler_bytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
     filler.push_back(f);
     return true;
-  };
-  size_t n_filler_total = 0;
-  auto t_released = std::chrono::steady_clock::now();
-  // Root candidates from a wide span of the memory: a candidate pair after every 2 GB filler over 80 GB -- the kinds of memory alternate in
-  // runs of 16-32 GB (profiles/r05_log_chunk_probe.txt), so every kind is among them.  The fillers go back to the driver BEFORE anything is
-  // timed: the driver wipes released memory in the background, and that write stream disturbs the evaluation for a second or so exactly as
-  // the root writes do (profiles/r05_log_pair_alloc_release.txt: the same mapped pairs 2-7 % slower right after 85 GB were released).
-  // Then the leaves, into the space the fillers held (allocated BEFORE the sprinkle instead, the headline ran 0.814-0.818 against
-  // 0.816-0.828 in eight alternating processes: profiles/r05_b_*): the candidates then lie among the leaves' own regions.
-  if (calibrate) {
-    const size_t span = (size_t)80 << 30;
-    for (size_t q = 0; q * filler_bytes < span && cand.size() + 2 <= max_cand / 2; ++q) {
-      if (!new_filler((size_t)16 << 30)) break;
-      PAIR_TRY("hipMemCreate(root candidate)", new_cand());
-      PAIR_TRY("hipMemCreate(root candidate)", new_cand());
-    }
-    n_filler_total = filler.size();
-    for (Phys &f : filler) (void)hipMemRelease(f.h);
-    filler.clear();
-    t_released = std::chrono::steady_clock::now();
   }
-  PAIR_TRY("hipMalloc(leaves)", hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk));
-  while (cand.size() < n_chunk) PAIR_TRY("hipMemCreate(root candidate)", new_cand());
-  double fast = 0, slow = 0, thr = 0;
-  bool have_contrast = false;
-  std::vector<double> before(n_chunk, 0.0);
-  int rc = FDG_OK;
-#define PROBE(li, cj, out) do { rc = cx.probe(leaf_va + (size_t)(li) * leaf_chunk, cand_va + (size_t)(cj) * root_chunk, out); if (rc) { cleanup_fail(); return rc; } } while (0)
-  size_t n_full_scan = 0;
-  double settle_s = 0;
-  if (calibrate) {
+
+  // Address ranges; root candidates from a wide span of the memory -- a candidate pair after every 2 GB filler over 80 GB: the kinds of memory
+  // alternate in runs of 16-32 GB (profiles/r05_log_chunk_probe.txt), so every kind is among them --; the fillers go back to the driver BEFORE
+  // anything is timed (its background wipe of released memory disturbs the evaluation exactly as the root writes do:
+  // profiles/r05_log_pair_alloc_release.txt); then the leaves, into the space the fillers held (allocated before the sprinkle instead, the
+  // headline ran 0.814-0.818 against 0.816-0.828 in eight alternating processes: profiles/r05_b_*).
+  int draw() {
+    hipError_t e;
+    if ((e = hipMemAddressReserve((void **)&root_va, n_chunk * root_chunk, gran, nullptr, 0)) != hipSuccess) return hip_fail("hipMemAddressReserve(roots)", e);
+    if ((e = hipMemAddressReserve((void **)&cand_va, max_cand * root_chunk, gran, nullptr, 0)) != hipSuccess) return hip_fail("hipMemAddressReserve(root candidates)", e);
+    if ((e = hipEventCreate(&cx.ev0)) != hipSuccess || (e = hipEventCreate(&cx.ev1)) != hipSuccess) return hip_fail("hipEventCreate", e);
+    if (calibrate) {
+      const size_t span = (size_t)80 << 30;
+      for (size_t q = 0; q * filler_bytes < span && cand.size() + 2 <= max_cand / 2; ++q) {
+        if (!new_filler((size_t)16 << 30)) break;
+        for (int c = 0; c < 2; ++c) if ((e = new_cand()) != hipSuccess) return hip_fail("hipMemCreate(root candidate)", e);
+      }
+      n_filler_total = filler.size();
+      for (Phys &f : filler) (void)hipMemRelease(f.h);
+      filler.clear();
+      t_released = std::chrono::steady_clock::now();
+    }
+    if ((e = hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk)) != hipSuccess) return hip_fail("hipMalloc(leaves)", e);
+    while (cand.size() < n_chunk) if ((e = new_cand()) != hipSuccess) return hip_fail("hipMemCreate(root candidate)", e);
+    return FDG_OK;
+  }
+
+  int probe_pair(size_t i, size_t j, double &r) {
+    const int rc = cx.probe(leaf_at(i), cand_at(j), r);
+    if (rc) return rc;
+    if (pred.size() < cand.size()) pred.resize(cand.size(), 0.0);
+    pred[j] = r;
+    fast = std::max(fast, r);
+    slow = slow == 0 ? r : std::min(slow, r);
+    return FDG_OK;
+  }
+  // every unused candidate from `from` on behind window i: the best one
+  int full_scan(size_t i, size_t from, int &bj, double &br) {
+    for (size_t j = from; j < cand.size(); ++j) {
+      if (cand[j].used) continue;
+      double r; const int rc = probe_pair(i, j, r); if (rc) return rc;
+      if (r > br) { br = r; bj = (int)j; }
+    }
+    return FDG_OK;
+  }
+  // A window first tries the unused candidates that ran fastest behind the previous window (neighbouring windows mostly lie in one region);
+  // when three of them disappoint it times every unused candidate; when even the best of those is below the fast level, more candidates are
+  // drawn -- a filler first, to move the driver on to other regions -- until the budget is spent.
+  int place(size_t i) {
+    pred.resize(cand.size(), 0.0);
+    std::vector<size_t> order;
+    for (size_t j = 0; j < cand.size(); ++j) if (!cand[j].used && pred[j] > 0) order.push_back(j);
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return pred[x] > pred[y]; });
+    int bj = -1; double br = 0;
+    for (size_t q = 0; q < std::min<size_t>(order.size(), 3); ++q) {
+      double r; const int rc = probe_pair(i, order[q], r); if (rc) return rc;
+      if (r > br) { br = r; bj = (int)order[q]; }
+      if (r >= kFastLevel * fast) break;
+    }
+    if (!(bj >= 0 && br >= kFastLevel * fast)) {
+      ++n_full_scan;
+      int rc = full_scan(i, 0, bj, br); if (rc) return rc;
+      const size_t filler_budget = (size_t)144 << 30;
+      while (br < kFastLevel * fast && filler.size() * filler_bytes < filler_budget && cand.size() + 2 <= max_cand) {
+        if (!new_filler((size_t)8 << 30)) break;
+        const size_t from = cand.size();
+        bool ok = true;
+        for (int c = 0; c < 2 && ok; ++c) ok = new_cand() == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); break; }
+        pred.resize(cand.size(), 0.0);
+        rc = full_scan(i, from, bj, br); if (rc) return rc;
+      }
+    }
+    if (bj >= 0) { pick[i] = bj; cand[(size_t)bj].used = true; got[i] = br; }
+    return FDG_OK;
+  }
+
+  // Nothing is assumed about how many kinds of memory there are or how they interact (measured: the rate of a pair takes three levels, as
+  // if a region carried two bits and every bit in which leaves and roots DIFFER bought 5 %; attempts to infer classes from a few reference
+  // probes were at the mercy of the probes' noise: profiles/r05_log_pair_alloc_v[2-5].txt).  PAIRS are measured.
+  int search() {
     // the probes must see what the workload will see: uniform random leaves (a window of zeros or of stale data runs at another clock
     // and another rate than its neighbours: profiles/r05_log_pair_alloc_v3.txt, rounds 1-2)
-    rc = cx.fill(leaf_va, (int64_t)(n_chunk * chunk_tiles) * 64);
-    if (rc) { cleanup_fail(); return rc; }
+    int rc = cx.fill(leaf_va, n_all());
+    if (rc) return rc;
     // the fillers of the sprinkle were released a moment ago: wait until their wipe is over before anything is timed
-    rc = cx.settle(leaf_va, (int64_t)(n_chunk * chunk_tiles) * 64, n_filler_total * filler_bytes, t_released, &settle_s);
-    if (rc) { cleanup_fail(); return rc; }
+    rc = cx.settle(leaf_va, n_all(), n_filler_total * filler_bytes, t_released, &settle_s);
+    if (rc) return rc;
     // the pairs an uncalibrated mapping would make (chunk i with the i-th candidate drawn)
-    for (size_t i = 0; i < n_chunk; ++i) PROBE(i, i, before[i]);
-    // Nothing is assumed about how many kinds of memory there are or how they interact (measured: the rate of a pair takes three levels, as
-    // if a region carried two bits and every bit in which leaves and roots DIFFER bought 5 %; attempts to infer classes from a few reference
-    // probes were at the mercy of the probes' noise: profiles/r05_log_pair_alloc_v[2-5].txt).  PAIRS are measured: a window tries the unused
-    // candidates that ran fastest behind the previous window (neighbouring windows mostly lie in one region), and when three of them
-    // disappoint it times every unused candidate; when even the best of those is below the fast level, more candidates are drawn -- a
-    // leaf-sized filler first, to move the driver on to other regions -- until the budget is spent.
-    std::vector<double> pred;                       // per candidate: its rate in the most recent probe (behind whatever window that was)
-    std::vector<double> got(n_chunk, 0.0);
-    const double rel = 0.965;                       // "at the fast level": within 3.5 % of the best pair seen so far
-    const size_t filler_budget = (size_t)144 << 30;
-    auto probe_pair = [&](size_t i, size_t j, double &r) -> int {
-      const int prc = cx.probe(leaf_va + i * leaf_chunk, cand_va + j * root_chunk, r);
-      if (prc) return prc;
-      if (pred.size() < cand.size()) pred.resize(cand.size(), 0.0);
-      pred[j] = r;
-      fast = std::max(fast, r);
-      slow = slow == 0 ? r : std::min(slow, r);
-      return FDG_OK;
-    };
-    auto full_scan = [&](size_t i, size_t from, int &bj, double &br) -> int {
-      for (size_t j = from; j < cand.size(); ++j) {
-        if (cand[j].used) continue;
-        double r; const int prc = probe_pair(i, j, r); if (prc) return prc;
-        if (r > br) { br = r; bj = (int)j; }
-      }
-      return FDG_OK;
-    };
-    auto place = [&](size_t i) -> int {
-      pred.resize(cand.size(), 0.0);
-      std::vector<size_t> order;
-      for (size_t j = 0; j < cand.size(); ++j) if (!cand[j].used && pred[j] > 0) order.push_back(j);
-      std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return pred[x] > pred[y]; });
-      int bj = -1; double br = 0;
-      for (size_t q = 0; q < std::min<size_t>(order.size(), 3); ++q) {
-        double r; const int prc = probe_pair(i, order[q], r); if (prc) return prc;
-        if (r > br) { br = r; bj = (int)order[q]; }
-        if (r >= rel * fast) break;
-      }
-      if (!(bj >= 0 && br >= rel * fast)) {
-        ++n_full_scan;
-        int prc = full_scan(i, 0, bj, br); if (prc) return prc;
-        while (br < rel * fast && filler.size() * filler_bytes < filler_budget && cand.size() + 2 <= max_cand) {
-          if (!new_filler((size_t)8 << 30)) break;
-          const size_t from = cand.size();
-          bool ok = true;
-          for (int c = 0; c < 2 && ok; ++c) ok = new_cand() == hipSuccess;
-          if (!ok) { (void)hipGetLastError(); break; }
-          pred.resize(cand.size(), 0.0);
-          prc = full_scan(i, from, bj, br); if (prc) return prc;
-        }
-      }
-      if (bj >= 0) { pick[i] = bj; cand[(size_t)bj].used = true; got[i] = br; }
-      return FDG_OK;
-    };
-    for (size_t i = 0; i < n_chunk; ++i) { rc = place(i); if (rc) { cleanup_fail(); return rc; } }
+    for (size_t i = 0; i < n_chunk; ++i) { rc = cx.probe(leaf_at(i), cand_at(i), before[i]); if (rc) return rc; }
+    for (size_t i = 0; i < n_chunk; ++i) { rc = place(i); if (rc) return rc; }
     // second pass: the level rose while the search went on -- windows that were content with less look again
     for (size_t i = 0; i < n_chunk; ++i) {
-      if (pick[i] < 0 || got[i] >= rel * fast) continue;
+      if (pick[i] < 0 || got[i] >= kFastLevel * fast) continue;
       int bj = -1; double br = got[i];
       ++n_full_scan;
-      rc = full_scan(i, 0, bj, br); if (rc) { cleanup_fail(); return rc; }
+      rc = full_scan(i, 0, bj, br); if (rc) return rc;
       if (bj >= 0 && br > 1.01 * got[i]) { cand[(size_t)pick[i]].used = false; pick[i] = bj; cand[(size_t)bj].used = true; got[i] = br; }
     }
-    have_contrast = fast > 1.05 * slow;
-    thr = rel * fast;
-    if (flags & FDG_BATCH_PAIR_VERBOSE) {
+    if (verbose()) {
       std::fprintf(stderr, "[fdg_batch_alloc_pair] pairs when chosen, GB/s:");
       for (size_t i = 0; i < n_chunk; ++i) std::fprintf(stderr, " %.0f", got[i]);
       std::fprintf(stderr, "\n[fdg_batch_alloc_pair] chosen candidate of each window:");
       for (size_t i = 0; i < n_chunk; ++i) std::fprintf(stderr, " %d", pick[i]);
-      std::fputc('\n', stderr);
+      std::fprintf(stderr, "\n[fdg_batch_alloc_pair] best / worst pair seen %.0f / %.0f GB/s; %zu windows, %zu candidates, %zu + %zu fillers, %zu full scans, %u probes\n",
+                   fast, slow, n_chunk, cand.size(), n_filler_total, filler.size(), n_full_scan, cx.n_probe);
     }
+    return FDG_OK;
   }
-  if (flags & FDG_BATCH_PAIR_VERBOSE)
-    std::fprintf(stderr, "[fdg_batch_alloc_pair] best / worst pair seen %.0f / %.0f GB/s, fast level from %.0f; %zu windows, %zu candidates, %zu fillers, %zu full scans, %u probes\n",
-                 fast, slow, thr, n_chunk, cand.size(), filler.size(), n_full_scan, cx.n_probe);
-  // chunks without a matched partner (calibration off, no contrast found, a window of neither class, or candidates of its kind ran out)
-  {
+
+  // the chosen candidates behind their leaf windows (windows without one -- calibration off, candidates ran out -- take what is left)
+  int map_chosen() {
+    hipError_t e;
     size_t j = 0;
     for (size_t i = 0; i < n_chunk; ++i) {
       if (pick[i] >= 0) continue;
       while (j < cand.size() && cand[j].used) ++j;
-      if (j >= cand.size()) { PAIR_TRY("hipMemCreate(root chunk)", new_cand()); }
+      if (j >= cand.size() && (e = new_cand()) != hipSuccess) return hip_fail("hipMemCreate(root chunk)", e);
       pick[i] = (int)j; cand[j].used = true;
     }
-  }
-  // final mapping: the chosen candidates behind their leaf windows; everything else goes back to the driver
-  PAIR_TRY("hipDeviceSynchronize", hipDeviceSynchronize());
-  for (size_t j = 0; j < cand.size(); ++j) unmap_cand(j);
-  for (size_t i = 0; i < n_chunk; ++i) {
-    PAIR_TRY("hipMemMap(roots)", hipMemMap(root_va + i * root_chunk, root_chunk, 0, cand[(size_t)pick[i]].h, 0));
-    root_mapped[i] = 1;
-    PAIR_TRY("hipMemSetAccess(roots)", hipMemSetAccess(root_va + i * root_chunk, root_chunk, &acc, 1));    // (chunk by chunk, as the candidates were when they were timed)
-  }
-  double after_mean = 0, after_min = 0, before_mean = 0, before_min = 0;
-  uint32_t n_matched = 0;
-  if (calibrate) {
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail("hipDeviceSynchronize", e);
+    for (size_t c = 0; c < cand.size(); ++c) if (cand[c].mapped) { (void)hipMemUnmap(cand_at(c), root_chunk); cand[c].mapped = false; }
     for (size_t i = 0; i < n_chunk; ++i) {
-      double r = 0;
-      rc = cx.probe(leaf_va + i * leaf_chunk, root_va + i * root_chunk, r);
-      if (rc) break;
-      after_mean += r / (double)n_chunk; after_min = (i == 0 || r < after_min) ? r : after_min;
-      before_mean += before[i] / (double)n_chunk; before_min = (i == 0 || before[i] < before_min) ? before[i] : before_min;
-      if (r >= 0.95 * fast) ++n_matched;
-      if (flags & FDG_BATCH_PAIR_VERBOSE) std::fprintf(stderr, "%s%.0f", i ? " " : "[fdg_batch_alloc_pair] pairs as mapped, GB/s: ", r);
+      if ((e = hipMemMap(root_at(i), root_chunk, 0, cand[(size_t)pick[i]].h, 0)) != hipSuccess) return hip_fail("hipMemMap(roots)", e);
+      root_mapped[i] = 1;
+      if ((e = hipMemSetAccess(root_at(i), root_chunk, &acc, 1)) != hipSuccess) return hip_fail("hipMemSetAccess(roots)", e);     // (chunk by chunk, as the candidates were when they were timed)
     }
-    if (flags & FDG_BATCH_PAIR_VERBOSE) std::fputc('\n', stderr);
+    return FDG_OK;
   }
-  // (timed before the release below: the wipe of what is released would disturb it)
-  size_t released_end = filler.size() * filler_bytes;
-  for (size_t j = 0; j < cand.size(); ++j) if (!cand[j].used) { (void)hipMemRelease(cand[j].h); released_end += root_chunk; }
-  for (Phys &f : filler) (void)hipMemRelease(f.h);
-  t_released = std::chrono::steady_clock::now();
-  const size_t n_filler = filler.size() + n_filler_total;
-  filler.clear();
-  (void)hipMemAddressFree(cand_va, max_cand * root_chunk);
-  cand_va = nullptr;
-  if (calibrate && !rc) rc = cx.settle(leaf_va, (int64_t)(n_chunk * chunk_tiles) * 64, released_end, t_released, &settle_s);    // the batch is handed over when the device is quiet again
-  (void)hipEventDestroy(cx.ev0); (void)hipEventDestroy(cx.ev1);
-  cx.ev0 = cx.ev1 = nullptr;
-  if (rc) {   // (a probe failed after the final mapping: undo it)
-    (void)hipDeviceSynchronize();
-    for (size_t i = 0; i < n_chunk; ++i) { (void)hipMemUnmap(root_va + i * root_chunk, root_chunk); (void)hipMemRelease(cand[(size_t)pick[i]].h); }
-    (void)hipFree(leaf_va); (void)hipMemAddressFree(root_va, n_chunk * root_chunk);
-    return rc;
+
+  // the mapped pairs once more (BEFORE anything else is released: the wipe of what is released would disturb it), then everything that was not
+  // used goes back to the driver, and the batch is handed over when the device is quiet again
+  int verify_and_release(fdg_batch_pair_info *info) {
+    double after_mean = 0, after_min = 0, before_mean = 0, before_min = 0;
+    uint32_t n_matched = 0;
+    int rc = FDG_OK;
+    if (calibrate) {
+      for (size_t i = 0; i < n_chunk && !rc; ++i) {
+        double r = 0;
+        rc = cx.probe(leaf_at(i), root_at(i), r);
+        after_mean += r / (double)n_chunk; after_min = (i == 0 || r < after_min) ? r : after_min;
+        before_mean += before[i] / (double)n_chunk; before_min = (i == 0 || before[i] < before_min) ? before[i] : before_min;
+        if (r >= 0.95 * fast) ++n_matched;
+        if (verbose()) std::fprintf(stderr, "%s%.0f", i ? " " : "[fdg_batch_alloc_pair] pairs as mapped, GB/s: ", r);
+      }
+      if (verbose()) std::fputc('\n', stderr);
+    }
+    size_t released = filler.size() * filler_bytes;
+    const size_t n_filler = filler.size() + n_filler_total, n_cand = cand.size();
+    for (Phys &c : cand) if (!c.used) { (void)hipMemRelease(c.h); released += root_chunk; }
+    for (Phys &f : filler) (void)hipMemRelease(f.h);
+    filler.clear();
+    t_released = std::chrono::steady_clock::now();
+    (void)hipMemAddressFree(cand_va, max_cand * root_chunk);
+    cand_va = nullptr;
+    if (calibrate && !rc) rc = cx.settle(leaf_va, n_all(), released, t_released, &settle_s);
+    if (rc) {      // undo the final mapping (the unused candidates are gone already)
+      std::vector<Phys> kept;
+      for (size_t i = 0; i < n_chunk; ++i) kept.push_back(cand[(size_t)pick[i]]);
+      cand.swap(kept);
+      for (Phys &c : cand) c.mapped = false;
+      abort();
+      return rc;
+    }
+    (void)hipEventDestroy(cx.ev0); (void)hipEventDestroy(cx.ev1);
+    cx.ev0 = cx.ev1 = nullptr;
+    if (info) {
+      info->leaf_bytes = n_chunk * leaf_chunk; info->root_bytes = n_chunk * root_chunk; info->chunk_tiles = chunk_tiles;
+      info->n_chunk = (uint32_t)n_chunk; info->n_candidate = (uint32_t)n_cand; info->n_filler = (uint32_t)n_filler; info->n_probe = cx.n_probe;
+      info->n_matched = n_matched; info->calibrated = fast > 1.05 * slow ? 1u : 0u;
+      info->gbs_fast = fast; info->gbs_slow = slow;
+      info->gbs_before_mean = before_mean; info->gbs_before_min = before_min; info->gbs_after_mean = after_mean; info->gbs_after_min = after_min;
+      info->seconds_settling = settle_s;
+    }
+    return FDG_OK;
   }
-#undef PROBE
-#undef PAIR_TRY
+};
+}  // namespace
+
+int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint, unsigned flags, void **d_leaf, void **d_root,
+                         fdg_batch_pair_info *info) {
+  if (!g || !d_leaf || !d_root) { fdg::set_error("null argument"); return FDG_E_INVALID; }
+  *d_leaf = *d_root = nullptr;
+  if (info) std::memset(info, 0, sizeof *info);
+  if (n_sample <= 0) { fdg::set_error("empty batch"); return FDG_E_INVALID; }
+  if (g->prog.L == 0 || g->prog.R == 0) { fdg::set_error("fdg_batch_alloc_pair: the graph has no leaves or no roots"); return FDG_E_INVALID; }
+  if (!(g->isa && !g->code_object.empty())) { fdg::set_error("fdg_batch_alloc_pair: tile-major batches need a handle specialised with FDG_SPEC_ISA"); return FDG_E_UNSUPPORTED; }
+  const auto t_start = std::chrono::steady_clock::now();
+  PairAllocator A;
+  A.g = g; A.flags = flags;
+  int rc = A.geometry(n_sample, chunk_bytes_hint);
+  if (rc) return rc;
+  rc = A.draw();
+  if (rc) return rc;
+  if (A.calibrate) { rc = A.search(); if (rc) { A.abort(); return rc; } }
+  rc = A.map_chosen();
+  if (rc) return rc;
+  rc = A.verify_and_release(info);
+  if (rc) return rc;
   {
     Batch bl, br;
-    bl.bytes = n_chunk * leaf_chunk; bl.chunk = 0; bl.device = dev;          // chunk 0: a plain allocation (hipFree)
-    br.bytes = n_chunk * root_chunk; br.chunk = root_chunk; br.device = dev;
-    for (size_t i = 0; i < n_chunk; ++i) br.handles.push_back(cand[(size_t)pick[i]].h);
+    bl.bytes = A.n_chunk * A.leaf_chunk; bl.chunk = 0; bl.device = A.dev;          // chunk 0: a plain allocation (hipFree)
+    br.bytes = A.n_chunk * A.root_chunk; br.chunk = A.root_chunk; br.device = A.dev;
+    for (size_t i = 0; i < A.n_chunk; ++i) br.handles.push_back(A.cand[(size_t)A.pick[i]].h);
     std::lock_guard<std::mutex> lk(g_mu);
-    g_batches[leaf_va] = std::move(bl);
-    g_batches[root_va] = std::move(br);
+    g_batches[A.leaf_va] = std::move(bl);
+    g_batches[A.root_va] = std::move(br);
   }
-  *d_leaf = leaf_va; *d_root = root_va;
-  if (info) {
-    info->leaf_bytes = n_chunk * leaf_chunk; info->root_bytes = n_chunk * root_chunk; info->chunk_tiles = chunk_tiles;
-    info->n_chunk = (uint32_t)n_chunk; info->n_candidate = (uint32_t)cand.size(); info->n_filler = (uint32_t)n_filler; info->n_probe = cx.n_probe;
-    info->n_matched = n_matched; info->calibrated = have_contrast ? 1u : 0u;
-    info->gbs_fast = fast; info->gbs_slow = slow;
-    info->gbs_before_mean = before_mean; info->gbs_before_min = before_min; info->gbs_after_mean = after_mean; info->gbs_after_min = after_min;
-    info->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-    info->seconds_settling = settle_s;
-  }
+  *d_leaf = A.leaf_va; *d_root = A.root_va;
+  if (info) info->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   return FDG_OK;
 }
 
