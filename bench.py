@@ -915,9 +915,11 @@ def mc_step(t, workload, B, dev, fast_math):
             return None
         dim, n_loop, n_tau = 3, int(z["basis"].shape[1]), int(z["n_tau"])
         kF, beta, lam = 1.919, 3.0, 1.2
-        dK = torch.rand((n_loop * dim, B), dtype=torch.float64, device=dev) * 4 - 2        # component-major, like a Julia B x n matrix
-        dT = torch.rand((n_tau, B), dtype=torch.float64, device=dev) * beta
-        w = torch.rand(B, dtype=torch.float64, device=dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234)                      # (the same momenta and times in every run: the reported deviations are then reproducible)
+        dK = torch.rand((n_loop * dim, B), dtype=torch.float64, device=dev, generator=gen) * 4 - 2        # component-major, like a Julia B x n matrix
+        dT = torch.rand((n_tau, B), dtype=torch.float64, device=dev, generator=gen) * beta
+        w = torch.rand(B, dtype=torch.float64, device=dev, generator=gen)
         acc = torch.zeros(t.n_root, dtype=torch.float64, device=dev)
         tab, _keep = capi.make_leaf_tables(z["leaf_type"], z["leaf_order"], z["tau_in"], z["tau_out"], z["loop_index"], z["basis"], dim, n_tau,
                                            kF, beta, lam)
