@@ -63,7 +63,7 @@ DEFAULT_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcas
              "parquet_sigma4_dyn_taylor2": 2_000_000, "parquet_sigma4_insdyn_taylor2": 1_000_000, "parquet_sigma5": 2_000_000,
              "parquet_ver4_4": 512_000, "gv_ver4_4": 512_000}          # (whole 64-sample tiles: the pooled cooperative kernel takes full tiles)
 PAIR_ALL = False         # --pair-all (experiment): every tile-major / row-major secondary row through fdg_batch_alloc_pair
-PAIRED_ROWS = {("parquet_sigma4", "tile_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "tile_major"), ("sigma2", "tile_major"),
+PAIRED_ROWS = {("parquet_sigma4", "tile_major"), ("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "tile_major"), ("sigma2", "tile_major"),
                ("gv_sigma4", "tile_major"), ("gv_sigma4_taylor2", "tile_major")}
 PARITY_NOTE = ("bit-exact vs our restatement of the Julia evaluator (oracle/); the reference's known-answer tests pin structure, "
                "leaf numbering and factors, not the rounding of the n-ary folds")
@@ -205,6 +205,15 @@ class Case:
         if self.layout == "sample_major" and self.placement == "paired":      # the same allocator for compile_Python's row-major [B, L] / [B, R]
             try:
                 self.pair = self.f.row_major_pair(B, dev, calibrate=True)
+            except Exception as e:
+                self.pair, self.placement, self.pair_error = None, "plain", f"{type(e).__name__}: {e}"
+            if self.pair is not None:
+                self.leaf, self.root = self.pair.leaf, self.pair.root
+                capi.fill_uniform_device(self.leaf.data_ptr(), B, L, self.leaf.stride(0), self.leaf.stride(1), 1234, self.sample_offset, st)
+                return
+        if self.layout == "leaf_major" and self.placement == "paired":        # ... and for a Julia column-major pair (one window: the whole batch)
+            try:
+                self.pair = self.f.leaf_major_pair(B, dev, calibrate=True)
             except Exception as e:
                 self.pair, self.placement, self.pair_error = None, "plain", f"{type(e).__name__}: {e}"
             if self.pair is not None:
@@ -422,7 +431,7 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
         plain = layout.endswith("@plain")        # the headline's workload at the headline's size on a PLAIN allocation (what hipMalloc hands out)
         lay = layout[:-4] if fma else (layout[:-6] if plain else layout)
         # the memory-bound graphs with root stores get their batch from the library's allocator (fdg_batch_alloc_pair), as the headline does
-        paired = ((workload, lay) in PAIRED_ROWS or (PAIR_ALL and lay in ("tile_major", "sample_major"))) and not plain and not fma
+        paired = ((workload, lay) in PAIRED_ROWS or (PAIR_ALL and lay in ("tile_major", "sample_major", "leaf_major"))) and not plain and not fma
         c = Case(workload, lay, DEFAULT_B[workload] if plain else (16_000_000 if workload == "parquet_sigma4" else DEFAULT_B.get(workload, 1_000_000)), dev,
                  flags=capi.FDG_SPEC_FAST_MATH if fma else 0, placement="paired" if paired else "plain")
         settle_after_free(c.nbytes())        # (by the clock: whatever was released to make room for this batch is being wiped)

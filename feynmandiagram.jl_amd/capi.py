@@ -458,6 +458,7 @@ def batch_free(ptr: int):
 
 BATCH_PAIR_CALIBRATE = 1
 BATCH_PAIR_ROW_MAJOR = 8
+BATCH_PAIR_LEAF_MAJOR = 16
 
 
 def batch_alloc_pair(handle: "GraphHandle", n_sample: int, chunk_bytes: int = 0, calibrate: bool = True, verbose: bool = False, extra_flags: int = 0):

@@ -177,6 +177,12 @@ class GraphFunc:
         """The same for ``compile_Python``'s row-major layout: ``.leaf`` is ``[B, L]``, ``.root`` ``[B, R]`` (rows contiguous)."""
         return PairedBatch(self, n_sample, device, calibrate, chunk_bytes, verbose, capi.BATCH_PAIR_ROW_MAJOR)
 
+    def leaf_major_pair(self, n_sample: int, device, calibrate: bool = True, verbose: bool = False) -> "PairedBatch":
+        """The same for a Julia column-major pair: ``.leaf`` is ``[B, L]`` with strides ``(1, B')``, ``.root`` ``[B, R]`` with ``(1, B')``
+        (``B'``: the mapped sample count).  One window -- the whole batch --, whole root matrices as candidates: pays for batches of up to a
+        few tens of GB."""
+        return PairedBatch(self, n_sample, device, calibrate, 0, verbose, capi.BATCH_PAIR_LEAF_MAJOR)
+
     def tile_major_pair(self, n_sample: int, device, calibrate: bool = True, chunk_bytes: int = 0, verbose: bool = False, extra_flags: int = 0) -> "PairedBatch":
         """The leaf and root arrays of a tile-major batch of this function, allocated by the library so that every part of the leaves
         streams next to its part of the roots at the fast rate (``fdg_batch_alloc_pair``: the root chunks are chosen by timing this
@@ -379,7 +385,11 @@ class PairedBatch:
         with torch.cuda.device(device):
             self._lp, self._rp, self.info = capi.batch_alloc_pair(func.handle, self.n_sample, chunk_bytes, calibrate, verbose, extra_flags)
             T = (self.n_sample + 63) // 64
-            if extra_flags & capi.BATCH_PAIR_ROW_MAJOR:
+            if extra_flags & capi.BATCH_PAIR_LEAF_MAJOR:
+                Bp = int(self.info["chunk_tiles"]) * 64
+                self.leaf = torch.as_tensor(_DeviceView(self._lp, (L, Bp)), device=device).t()[:self.n_sample]
+                self.root = torch.as_tensor(_DeviceView(self._rp, (R, Bp)), device=device).t()[:self.n_sample]
+            elif extra_flags & capi.BATCH_PAIR_ROW_MAJOR:
                 self.leaf = torch.as_tensor(_DeviceView(self._lp, (self.info["leaf_bytes"] // (8 * L), L)), device=device)[:self.n_sample]
                 self.root = torch.as_tensor(_DeviceView(self._rp, (self.info["root_bytes"] // (8 * R), R)), device=device)[:self.n_sample]
             else:

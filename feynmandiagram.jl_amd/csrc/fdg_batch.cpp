@@ -140,15 +140,19 @@ struct PairCtx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint32_t n_probe = 0;
   bool row_major = false;      // FDG_BATCH_PAIR_ROW_MAJOR: compile_Python's [B, L] / [B, R] instead of the tile-major arrays (64 rows = one "tile")
+  int64_t ld = 0;              // FDG_BATCH_PAIR_LEAF_MAJOR: > 0 = column stride (samples) of a Julia column-major B x L / B x R pair; one window: the whole batch
   int eval(const void *leaf, void *root, int64_t n) {
+    if (ld) return fdg_eval_device(g, (const double *)leaf, 1, ld, (double *)root, 1, ld, n, nullptr);
     return row_major ? fdg_eval_device(g, (const double *)leaf, (int64_t)L, 1, (double *)root, (int64_t)R, 1, n, nullptr)
                      : fdg_eval_device_tiled(g, (const double *)leaf, 1, 64, 64 * (int64_t)L, (double *)root, 1, 64, 64 * (int64_t)R, n, nullptr);
   }
   int accumulate(const void *leaf, double *d_acc, int64_t n) {
+    if (ld) return fdg_accumulate_device(g, (const double *)leaf, 1, ld, nullptr, d_acc, n, nullptr);
     return row_major ? fdg_accumulate_device(g, (const double *)leaf, (int64_t)L, 1, nullptr, d_acc, n, nullptr)
                      : fdg_accumulate_device_tiled(g, (const double *)leaf, 1, 64, 64 * (int64_t)L, nullptr, d_acc, n, nullptr);
   }
   int fill(void *leaf, int64_t n) {
+    if (ld) return fdg_fill_uniform_device((double *)leaf, n, L, 1, ld, 20240612u, 0, nullptr);
     return row_major ? fdg_fill_uniform_device((double *)leaf, n, L, (int64_t)L, 1, 20240612u, 0, nullptr)
                      : fdg_fill_uniform_device_tiled((double *)leaf, n, L, 1, 64, 64 * (int64_t)L, 20240612u, 0, nullptr);
   }
@@ -172,7 +176,7 @@ struct PairCtx {
   // Wait until the device is quiet.  The driver wipes released memory in the background at 18-28 GB/s, and that write stream depresses every
   // rate by 2-7 % while it lasts (profiles/r05_log_pair_alloc_settle.txt: 1-4.5 s after 30-90 GB were released, then the batch runs at its
   // own rate).  First the time the wipe of `released` bytes takes at 16 GB/s, counted from `since`; then the fused accumulation over `n`
-  // samples of the leaves (read-only, ~10 ms for the headline batch) every 50 ms until eight in a row agree to 1.5 % (at most 6 s more).
+  // samples of the leaves (read-only, ~10 ms for the headline batch), launch after launch, until eight samples in a row agree to 1.5 % (at most 6 s more).
   int settle(const void *leaf, int64_t n, size_t released, std::chrono::steady_clock::time_point since, double *waited) {
     const auto t0 = std::chrono::steady_clock::now();
     const double need = (double)released / 16e9 - std::chrono::duration<double>(t0 - since).count();
@@ -181,13 +185,17 @@ struct PairCtx {
     if (hipMalloc((void **)&d_acc, sizeof(double) * std::max<uint32_t>(R, 1)) != hipSuccess) return FDG_E_NOMEM;
     (void)hipMemset(d_acc, 0, sizeof(double) * R);
     const auto t1 = std::chrono::steady_clock::now();
+    // One sample = four launches back to back, the time of the last one (no pauses between samples either: a device left idle for tens of
+    // milliseconds answers the next launch at other clocks, and the samples would never agree).
     double hist[8] = {0};
     int rc = FDG_OK;
-    for (int k = 0;; ++k) {
-      if (hipEventRecord(ev0, nullptr) != hipSuccess) { rc = FDG_E_NO_DEVICE; break; }
-      rc = accumulate(leaf, d_acc, n);
-      if (rc) break;
+    for (int k = 0; rc == FDG_OK; ++k) {
       float ms = 0.f;
+      for (int l = 0; l < 4 && rc == FDG_OK; ++l) {
+        if (l == 3 && hipEventRecord(ev0, nullptr) != hipSuccess) { rc = FDG_E_NO_DEVICE; break; }
+        rc = accumulate(leaf, d_acc, n);
+      }
+      if (rc) break;
       if (hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess || hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) { rc = FDG_E_NO_DEVICE; break; }
       hist[k % 8] = ms > 0.f ? (double)n / (double)ms : 0.0;
       if (k >= 7) {
@@ -196,7 +204,6 @@ struct PairCtx {
         if (mn > 0.985 * mx) break;
       }
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() > 6.0) break;
-      std::this_thread::sleep_for(std::chrono::milliseconds(50));
     }
     if (waited) *waited += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     (void)hipFree(d_acc);
@@ -276,10 +283,19 @@ struct PairAllocator {
     k = std::min(k, std::max<size_t>(1, (T + unit - 1) / unit));               // a small batch: one chunk
     chunk_tiles = unit * k; leaf_chunk = chunk_tiles * lt; root_chunk = chunk_tiles * rt;
     n_chunk = (T + chunk_tiles - 1) / chunk_tiles;
+    if (flags & FDG_BATCH_PAIR_LEAF_MAJOR) {
+      // a Julia column-major pair: the leaves of any window of samples are L pieces spread over the whole matrix, so there is ONE window -- the
+      // batch -- and the candidates are whole root matrices.  Pays while the leaf matrix lies in one or two regions of the memory (a few tens of
+      // GB); a 70 GB matrix spans every kind and no root matrix suits all of it.
+      chunk_tiles = (T + unit - 1) / unit * unit; n_chunk = 1;
+      leaf_chunk = chunk_tiles * lt; root_chunk = chunk_tiles * rt;
+      cx.ld = (int64_t)chunk_tiles * 64;
+    }
     max_cand = 8 * n_chunk + 64;
     filler_bytes = ((((size_t)2 << 30) + gran - 1) / gran) * gran;
     // (a window of less than ~0.5 GB of leaves is evaluated in too short a launch for the levels to separate: nothing to calibrate on)
     calibrate = (flags & FDG_BATCH_PAIR_CALIBRATE) && leaf_chunk >= ((size_t)400 << 20);
+    if ((flags & FDG_BATCH_PAIR_LEAF_MAJOR) && root_chunk > ((size_t)1 << 30)) calibrate = false;      // (see above: nothing to choose for a matrix that large)
     pick.assign(n_chunk, -1); root_mapped.assign(n_chunk, 0); before.assign(n_chunk, 0.0); got.assign(n_chunk, 0.0);
     cx.row_major = (flags & FDG_BATCH_PAIR_ROW_MAJOR) != 0;
     cx.g = g; cx.L = L; cx.R = R; cx.chunk_tiles = chunk_tiles; cx.leaf_chunk = leaf_chunk; cx.root_chunk = root_chunk;
@@ -354,6 +370,23 @@ struct PairAllocator {
     }
     return FDG_OK;
   }
+  // every unused candidate behind window i; while even the best of them is below the fast level, more candidates are drawn -- a filler first,
+  // to move the driver on to other regions of the memory -- until the budget is spent
+  int scan_and_draw(size_t i, int &bj, double &br) {
+    ++n_full_scan;
+    int rc = full_scan(i, 0, bj, br); if (rc) return rc;
+    const size_t filler_budget = (size_t)144 << 30;
+    while (br < kFastLevel * fast && filler.size() * filler_bytes < filler_budget && cand.size() + 2 <= max_cand) {
+      if (!new_filler((size_t)8 << 30)) break;
+      const size_t from = cand.size();
+      bool ok = true;
+      for (int c = 0; c < 2 && ok; ++c) ok = new_cand() == hipSuccess;
+      if (!ok) { (void)hipGetLastError(); break; }
+      pred.resize(cand.size(), 0.0);
+      rc = full_scan(i, from, bj, br); if (rc) return rc;
+    }
+    return FDG_OK;
+  }
   // A window first tries the unused candidates that ran fastest behind the previous window (neighbouring windows mostly lie in one region);
   // when three of them disappoint it times every unused candidate; when even the best of those is below the fast level, more candidates are
   // drawn -- a filler first, to move the driver on to other regions -- until the budget is spent.
@@ -368,20 +401,7 @@ struct PairAllocator {
       if (r > br) { br = r; bj = (int)order[q]; }
       if (r >= kFastLevel * fast) break;
     }
-    if (!(bj >= 0 && br >= kFastLevel * fast)) {
-      ++n_full_scan;
-      int rc = full_scan(i, 0, bj, br); if (rc) return rc;
-      const size_t filler_budget = (size_t)144 << 30;
-      while (br < kFastLevel * fast && filler.size() * filler_bytes < filler_budget && cand.size() + 2 <= max_cand) {
-        if (!new_filler((size_t)8 << 30)) break;
-        const size_t from = cand.size();
-        bool ok = true;
-        for (int c = 0; c < 2 && ok; ++c) ok = new_cand() == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); break; }
-        pred.resize(cand.size(), 0.0);
-        rc = full_scan(i, from, bj, br); if (rc) return rc;
-      }
-    }
+    if (!(bj >= 0 && br >= kFastLevel * fast)) { const int rc = scan_and_draw(i, bj, br); if (rc) return rc; }
     if (bj >= 0) { pick[i] = bj; cand[(size_t)bj].used = true; got[i] = br; }
     return FDG_OK;
   }
@@ -400,12 +420,12 @@ struct PairAllocator {
     // the pairs an uncalibrated mapping would make (chunk i with the i-th candidate drawn)
     for (size_t i = 0; i < n_chunk; ++i) { rc = cx.probe(leaf_at(i), cand_at(i), before[i]); if (rc) return rc; }
     for (size_t i = 0; i < n_chunk; ++i) { rc = place(i); if (rc) return rc; }
-    // second pass: the level rose while the search went on -- windows that were content with less look again
+    // second pass: the level rose while the search went on -- windows that were content with less look again, and draw more candidates if need be
     for (size_t i = 0; i < n_chunk; ++i) {
       if (pick[i] < 0 || got[i] >= kFastLevel * fast) continue;
       int bj = -1; double br = got[i];
-      ++n_full_scan;
-      rc = full_scan(i, 0, bj, br); if (rc) return rc;
+      rc = scan_and_draw(i, bj, br); if (rc) return rc;      // (its kind of partner may not have been among the candidates when it was placed:
+                                                             //  one process of twenty ended with half its windows at the middle level that way)
       if (bj >= 0 && br > 1.01 * got[i]) { cand[(size_t)pick[i]].used = false; pick[i] = bj; cand[(size_t)bj].used = true; got[i] = br; }
     }
     if (verbose()) {

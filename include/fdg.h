@@ -376,6 +376,9 @@ int fdg_batch_free(void *d_ptr);
  * No counterpart in the reference (its leaf vector and root vector are Julia Vectors on the host, static.jl:100,131). */
 #define FDG_BATCH_PAIR_CALIBRATE 1u
 #define FDG_BATCH_PAIR_VERBOSE 2u   /* what the search saw, a few lines on stderr */
+#define FDG_BATCH_PAIR_LEAF_MAJOR 16u /* the arrays are a Julia column-major pair B' x L and B' x R (strides (1, B'), B' = the mapped sample count: info->chunk_tiles * 64):
+                                       * one window -- the whole batch --, the candidates are whole root matrices; pays while the leaf matrix lies in one or
+                                       * two regions of the memory (up to a few tens of GB) */
 #define FDG_BATCH_PAIR_ROW_MAJOR 8u /* the arrays are compile_Python's row-major [B, L] and [B, R] (compiler_python.jl:23,28,45-47) instead of the
                                      * tile-major ones: 64 consecutive rows take the place of a tile; everything else is the same */
 typedef struct fdg_batch_pair_info {

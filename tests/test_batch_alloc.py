@@ -193,3 +193,35 @@ def test_paired_row_major_batch_gives_the_bits_of_a_plain_batch(libfdg, cuda, B,
         assert np.array_equal(pb.root[B - n:].cpu().numpy(), oracle.eval_static(t, oracle.philox_uniform(B, L, 4321, 11)[B - n:] if B < 10000 else leaf[B - n:].cpu().numpy()))
     finally:
         pb.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,calibrate", [(4099, True), (1_000_037, True)])
+def test_paired_leaf_major_batch_gives_the_bits_of_a_plain_batch(libfdg, cuda, B, calibrate):
+    """FDG_BATCH_PAIR_LEAF_MAJOR: a Julia column-major pair B' x L / B' x R (strides (1, B')); one window, whole root matrices as
+    candidates (the second case, 670 MB of leaves, runs the search)."""
+    import torch
+    t = workloads.get("parquet_sigma4")
+    L, R = t.n_leaf, t.n_root
+    f = fd.compile_table(t, specialize="isa")
+    st = torch.cuda.current_stream().cuda_stream
+    pb = f.leaf_major_pair(B, cuda, calibrate=calibrate)
+    try:
+        Bp = pb.info["chunk_tiles"] * 64
+        assert pb.info["n_chunk"] == 1 and Bp >= B
+        assert pb.leaf.shape == (B, L) and pb.leaf.stride() == (1, Bp) and pb.root.shape == (B, R) and pb.root.stride() == (1, Bp)
+        if B > 1_000_000:
+            assert pb.info["n_probe"] >= 10 and pb.info["n_candidate"] >= 10
+        pb.root.fill_(7.0)
+        capi.fill_uniform_device(pb.leaf.data_ptr(), B, L, 1, Bp, 4321, 11, st)
+        f(pb.root, pb.leaf)
+        leaf = torch.empty((L, B), dtype=torch.float64, device=cuda).t()
+        capi.fill_uniform_device(leaf.data_ptr(), B, L, 1, B, 4321, 11, st)
+        root = torch.empty((R, B), dtype=torch.float64, device=cuda).t()
+        f(root, leaf)
+        torch.cuda.synchronize()
+        assert torch.equal(pb.leaf, leaf) and torch.equal(pb.root, root)
+        n = min(B, 2000)
+        assert np.array_equal(pb.root[B - n:].cpu().numpy(), oracle.eval_static(t, leaf[B - n:].cpu().numpy()))
+    finally:
+        pb.free()
