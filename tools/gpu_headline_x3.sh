@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-for i in 1 2 3; do
+for i in 1 2 3 4 5; do
 timeout 600 python bench.py --steps 20 --warmup 5 --no-secondary --no-mc-step --no-cpu-baseline > gpurun_out/r05_l_bench_line_$i.json 2>gpurun_out/r05_l_$i.err
 python - <<PY
 import json
