@@ -39,7 +39,7 @@ EXPORTS = [
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
     "fdg_graph_kernel_info",
     "fdg_eval_device_tiled", "fdg_accumulate_device_tiled", "fdg_fill_uniform_device_tiled", "fdg_graph_set_association",
-    "fdg_batch_alloc", "fdg_batch_free", "fdg_graph_pool_program", "fdg_batch_alloc_pair", "fdg_graph_set_option", "fdg_graph_get_option", "fdg_set_default_option", "fdg_get_default_option",
+    "fdg_batch_alloc", "fdg_batch_free", "fdg_graph_pool_program", "fdg_batch_alloc_pair", "fdg_graph_set_option", "fdg_graph_get_option", "fdg_set_default_option", "fdg_get_default_option", "fdg_selftest_pair_search",
 ]
 COMM_ID_BYTES = 128
 
@@ -158,6 +158,7 @@ def lib():
     L.fdg_set_default_option.argtypes = [C.c_char_p, C.c_char_p]
     L.fdg_get_default_option.argtypes = [C.c_char_p]
     L.fdg_get_default_option.restype = C.c_char_p
+    L.fdg_selftest_pair_search.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.fdg_batch_alloc_pair.argtypes = [vp, C.c_int64, C.c_size_t, C.c_uint, C.POINTER(vp), C.POINTER(vp), C.POINTER(BatchPairInfo)]
     L.fdg_eval_device_tiled.argtypes = [vp, dp, i64, i64, i64, dp, i64, i64, i64, i64, vp]
     L.fdg_accumulate_device_tiled.argtypes = [vp, dp, i64, i64, i64, dp, dp, i64, vp]

@@ -398,6 +398,10 @@ typedef struct fdg_batch_pair_info {
 } fdg_batch_pair_info;
 int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint, unsigned flags, void **d_leaf, void **d_root,
                          fdg_batch_pair_info *info);
+/* test hook (host only): the allocator's search on a MODEL of the memory -- regions of four kinds, three pair levels, noise, further candidates
+ * only behind further draws (scenario 0 ... 3, csrc/fdg_batch.cpp); returns how many of n_window windows ended with a candidate of the
+ * complementary kind, *n_probe = pairs "timed".  So that the search is tested where there is no device. */
+int fdg_selftest_pair_search(uint64_t seed, uint32_t scenario, uint32_t n_window, uint32_t *n_probe);
 
 /* d_leaf[b*ss + i*ls] = U[0,1) from Philox4x32-10, key = seed, counter =
  * (sample_offset + b, i): independent of launch geometry and of how samples

@@ -225,3 +225,20 @@ def test_paired_leaf_major_batch_gives_the_bits_of_a_plain_batch(libfdg, cuda, B
         assert np.array_equal(pb.root[B - n:].cpu().numpy(), oracle.eval_static(t, leaf[B - n:].cpu().numpy()))
     finally:
         pb.free()
+
+
+@pytest.mark.parametrize("scenario", [0, 1, 2, 3])
+def test_the_allocators_search_on_a_model_of_the_memory(libfdg, scenario):
+    """fdg_selftest_pair_search: PairSearch (csrc/fdg_batch.cpp) -- the part of fdg_batch_alloc_pair that chooses -- on a model: regions of four
+    kinds, pair levels 0.855 / 0.80 / 0.765 by the number of bits in which window and candidate differ, noise.  Every window must end with a
+    candidate of the complementary kind:
+      0  every kind among the first candidates;
+      1  NO complementary kind among them (every pair at the middle level at best): the exploration rule must keep drawing;
+      2  the first windows' complement absent, the later windows' present: the second pass must draw (a bench process ended at 0.749 without it);
+      3  as 0 with 1.5 % noise."""
+    import ctypes as C
+    for seed in range(12):
+        n = C.c_uint32()
+        top = libfdg.fdg_selftest_pair_search(seed, scenario, 32, C.byref(n))
+        assert top == 32, (scenario, seed, top)
+        assert 32 <= n.value <= (400 if scenario in (0, 3) else 4000)       # a few probes per window when the candidates are there
