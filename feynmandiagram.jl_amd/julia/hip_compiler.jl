@@ -250,11 +250,12 @@ batch_free(p::Ptr{Cvoid}) = _fdg_check(ccall((:fdg_batch_free, _libfdg), Cint, (
 # The two arrays of a tile-major batch of `f` -- Array{Float64,3}(64, L, T) and (64, R, T) on the device -- with the root chunks chosen by
 # timing f's own kernel on (leaf window, root chunk) pairs (fdg_batch_alloc_pair, include/fdg.h).  Returns (d_leaf, d_root, info bytes);
 # release each pointer with batch_free.  What a Monte-Carlo driver that evaluates (not only accumulates) should allocate its batch with.
-function batch_alloc_pair(f::GraphFunc, n_sample::Integer; chunk_bytes::Integer=0, calibrate::Bool=true)
+# layout = :leaf_major: a Julia Matrix pair B' x L / B' x R (B' = 64 * the info's chunk_tiles), for batches of up to a few tens of GB; :row_major: compile_Python's.
+function batch_alloc_pair(f::GraphFunc, n_sample::Integer; chunk_bytes::Integer=0, calibrate::Bool=true, layout::Symbol=:tile_major)
     dl = Ref{Ptr{Cvoid}}(C_NULL); dr = Ref{Ptr{Cvoid}}(C_NULL)
     info = zeros(UInt8, 128)                 # fdg_batch_pair_info (112 bytes)
     _fdg_check(ccall((:fdg_batch_alloc_pair, _libfdg), Cint, (Ptr{Cvoid}, Int64, Csize_t, Cuint, Ref{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}, Ptr{UInt8}),
-        f.handle, n_sample, chunk_bytes, Cuint(calibrate ? 1 : 0), dl, dr, info))
+        f.handle, n_sample, chunk_bytes, Cuint((calibrate ? 1 : 0) | (layout == :row_major ? 8 : 0) | (layout == :leaf_major ? 16 : 0)), dl, dr, info))
     return Ptr{Float64}(dl[]), Ptr{Float64}(dr[]), info
 end
 
