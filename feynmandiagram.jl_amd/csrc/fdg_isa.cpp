@@ -22,7 +22,9 @@
 //   (the _acc variant keeps acc_k += w * root_k in registers and writes one partial per wave and root to `root`)
 //   leaf value i of sample b: leaf[b*ss + i*ls]; root k: root[b*rs + k*rk]
 #include <algorithm>
+#include <cctype>
 #include <cinttypes>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -270,9 +272,68 @@ struct HzTracker {
   void reset() { past.clear(); }
 };
 
+// ---- encoded size of a printed instruction -----------------------------------------------------------------------------------
+// Round 5 (tools/ubench/valu_align.hip, profiles/r05_ubench_valu_align.txt): an 8-byte instruction that straddles a 64-byte line of the
+// instruction stream costs a lone wave about 8 cycles (two issue slots) -- a stream displaced by 4 bytes runs its fp64 operations at 5.08
+// instead of 4.13 cycles; an s_nop costs 4.  The printer therefore keeps count of where it is within the line (every kernel starts at
+// .p2align 8 and every instruction goes through Emit::ins) and puts one s_nop in front of an instruction that would straddle.  Only the
+// forms this file prints are classified: VOP1/VOP2 carry their _e32 / _e64 suffix, everything else starting with v_ is VOP3;
+// tests/test_isa_alignment.py holds the classification against the assembler's own listing.
+static bool isa_operand_is_literal(std::string t) {
+  while (!t.empty() && (t.front() == ' ' || t.front() == '\t')) t.erase(t.begin());
+  while (!t.empty() && (t.back() == ' ' || t.back() == '\t')) t.pop_back();
+  if (t.empty()) return false;
+  std::string u = t;
+  if (u[0] == '-' || u[0] == '|') u.erase(u.begin());
+  if (!u.empty() && (u[0] == 's' || u[0] == 'v' || u[0] == 'a') && u.size() > 1 && (std::isdigit((unsigned char)u[1]) || u[1] == '[')) return false;
+  for (const char *r : {"vcc", "exec", "m0", "scc", "off", "null", "vmcnt", "lgkmcnt", "expcnt", "src_"}) if (u.compare(0, std::strlen(r), r) == 0) return false;
+  char *end = nullptr;
+  const long long v = std::strtoll(t.c_str(), &end, 0);
+  if (end && *end == 0 && end != t.c_str()) return v < -16 || v > 64;
+  const double f = std::strtod(t.c_str(), &end);
+  if (end && *end == 0 && end != t.c_str()) { const double a = std::fabs(f); return !(a == 0.5 || a == 1.0 || a == 2.0 || a == 4.0); }
+  return true;                                   // an expression over symbols
+}
+static int isa_size(const std::string &s) {
+  const size_t e = s.find_first_of(" \t");
+  const std::string mn = s.substr(0, e);
+  auto starts = [&](const char *p) { return mn.compare(0, std::strlen(p), p) == 0; };
+  auto ends = [&](const char *p) { const size_t n = std::strlen(p); return mn.size() >= n && mn.compare(mn.size() - n, n, p) == 0; };
+  if (starts("ds_") || starts("global_") || starts("buffer_") || starts("flat_") || starts("scratch_")) return 8;
+  if (starts("s_load_") || starts("s_buffer_") || starts("s_store_") || starts("s_dcache") || mn == "s_memtime" || mn == "s_memrealtime") return 8;
+  bool lit = false;
+  if (e != std::string::npos) {
+    size_t a = e;
+    while (a <= s.size()) {
+      size_t c = s.find(',', a);
+      if (c == std::string::npos) c = s.size();
+      if (isa_operand_is_literal(s.substr(a, c - a))) lit = true;
+      a = c + 1;
+    }
+  }
+  if (starts("s_")) {
+    for (const char *q : {"s_nop", "s_waitcnt", "s_barrier", "s_endpgm", "s_branch", "s_cbranch", "s_sleep", "s_setprio", "s_sendmsg", "s_sethalt", "s_trap",
+                          "s_icache_inv", "s_movk", "s_addk", "s_mulk", "s_cmpk", "s_cmovk", "s_getreg", "s_call_b64"})
+      if (starts(q)) return 4;
+    return lit ? 8 : 4;
+  }
+  if (starts("v_")) {
+    if (ends("_e64")) return 8;
+    if (ends("_e32") || mn == "v_readfirstlane_b32" || mn == "v_nop") return lit ? 8 : 4;
+    return 8;
+  }
+  return 4;
+}
+
 struct Emit {
   std::ostringstream os;
   HzTracker hz;
+  uint32_t off = 0;           // bytes printed since the kernel's .p2align 8
+  int align = 1;              // option FDG_ISA_ALIGN: 0 print as rounds 1-4 did, 1 no 8-byte instruction straddles, 2 no fp64 / VOP3 one does
+  bool pad_ok = true;         // false inside the cooperative / pooled kernels: their waves meet at barriers, and the pads cost gv_ver4_4's pooled kernel 12 %
+                              // (profiles/r05_log_align_shift.txt)
+  int shift = 0;              // dev: FDG_ISA_SHIFT=n puts n s_nop at the head of every kernel (how much does the mere position matter?)
+  uint64_t n_align_nop = 0;
   bool streaming = false;     // the kernel being printed is the variant for line-aligned batches: non-temporal leaf loads and root stores
   uint64_t n_auto_nop = 0;
   uint64_t vm_issued = 0, lg_issued = 0, vm_done = 0, lg_done = 0;
@@ -286,7 +347,10 @@ struct Emit {
   void ins(const std::string &s) {
     const HzInst I = hz_decode(s);
     const int need = hz.missing(I);
-    if (need > 0) { os << "\ts_nop " << (need - 1) << "\n"; HzInst N; N.salu = true; N.nop = need; hz.issue(N); n_auto_nop++; }
+    if (need > 0) { os << "\ts_nop " << (need - 1) << "\n"; HzInst N; N.salu = true; N.nop = need; hz.issue(N); n_auto_nop++; off += 4; }
+    const int sz = isa_size(s);
+    if (align && pad_ok && sz == 8 && (off & 63u) == 60u && (align == 1 || s.compare(0, 2, "v_") == 0)) { os << "\ts_nop 0\n"; HzInst N; N.salu = true; N.nop = 1; hz.issue(N); n_align_nop++; off += 4; }
+    off += (uint32_t)sz;
     hz.issue(I);
     os << "\t" << s << "\n";
   }
@@ -449,6 +513,9 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   if (!cs) {
     os << "\t.text\n\t.protected\t" << kname << "\n\t.globl\t" << kname << "\n\t.p2align\t8\n\t.type\t" << kname << ",@function\n";
     os << kname << ":\n";
+    E.off = 0;
+    E.pad_ok = true;
+    for (int i = 0; i < E.shift; ++i) E.ins("s_nop 0");
   } else {
     os << ".Lsec" << sfx << ":\n";
   }
@@ -1346,6 +1413,8 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
   std::ostringstream &os = E.os;
   os << "\t.text\n\t.protected\t" << kname << "\n\t.globl\t" << kname << "\n\t.p2align\t8\n\t.type\t" << kname << ",@function\n";
   os << kname << ":\n";
+  E.off = 0;
+  E.pad_ok = false;
   E.hz.reset();
   E.ins("v_lshrrev_b32_e32 v1, 6, v0");
   E.ins("v_readfirstlane_b32 s3, v1");
@@ -1438,6 +1507,8 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
                      const OptProgram *prog_acc, const OptProgram *prog_rm, uint32_t rm_bufs, const CoopProgram *coop,
                      const OptProgram *prog_rm_acc, const CoopProgram *pool, const OptProgram *prog_rl, const OptProgram *prog_rl_acc) {
   Emit E;
+  { const char *a = fdg::knob("FDG_ISA_ALIGN"); E.align = a && a[0] >= '0' && a[0] <= '2' ? a[0] - '0' : 1; }
+  { const char *a = fdg::knob("FDG_ISA_SHIFT"); E.shift = a ? std::atoi(a) : 0; }
   E.os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n";
   std::vector<KernelMeta> ks;
   ks.push_back(emit_kernel(E, p, prog, kname, 1));

@@ -12,7 +12,7 @@ thread_local const KnobMap *t_active = nullptr;
 // what an installation may set through the environment; everything else is an experiment switch
 const char *const kSupported[] = {"FDG_CACHE_DIR", "FDG_CACHE_RO_DIR", "FDG_CACHE_TRUST", "FDG_LLVM_BIN", "FDG_HIPCC", "FDG_JIT", "FDG_MC_ROUTE",
                                   "FDG_EVAL_CHUNK", "FDG_MC_CHUNK", "FDG_SM_CHUNK_MB", "FDG_IGNORE_TUNED", "FDG_LEAF_GENERIC", "FDG_TUNE_VERBOSE",
-                                  "FDG_ISA_NO_POOL", "FDG_ISA_POOL", "FDG_ISA_NO_RL", "FDG_ISA_RL"};
+                                  "FDG_ISA_NO_POOL", "FDG_ISA_POOL", "FDG_ISA_NO_RL", "FDG_ISA_RL", "FDG_ISA_ALIGN"};
 }  // namespace
 
 bool knob_supported_from_env(const std::string &name) {

@@ -1,0 +1,70 @@
+"""Round 5: no 8-byte instruction of a printed kernel straddles a 64-byte line of the instruction stream (a lone wave pays about two issue
+slots for each: tools/ubench/valu_align.hip, profiles/r05_ubench_valu_align.txt).  The printer counts encoded bytes itself
+(csrc/fdg_isa.cpp: isa_size); this test holds that count against the assembler: the listing is assembled and disassembled, and every
+instruction's real address and size are checked.  Without the pads (option FDG_ISA_ALIGN=0) the same listings do straddle, and the two
+listings differ by `s_nop 0` lines only."""
+import glob
+import os
+import re
+import subprocess
+
+import pytest
+
+import feynmandiagram_jl_amd as fd
+from feynmandiagram_jl_amd import capi, workloads
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+pytestmark = pytest.mark.skipif(not os.path.exists(LLVM + "/llvm-objdump"), reason="no llvm-objdump")
+
+
+def listing(name, tmp, align):
+    d = os.path.join(str(tmp), f"{name}_{align}")
+    os.makedirs(d)
+    fd.compile_table(workloads.get(name), specialize="isa", cache_dir=d, flags=capi.FDG_SPEC_KEEP_SOURCE, options={"FDG_ISA_ALIGN": align})
+    (src,) = glob.glob(d + "/fdg_isa_*.s")
+    return src
+
+
+def layout(src):
+    """{kernel: [(mnemonic, address, size)]} from the assembler's own view of the listing."""
+    obj = src[:-2] + ".o"
+    subprocess.run([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", src, "-o", obj], check=True)
+    out = subprocess.run([LLVM + "/llvm-objdump", "-d", obj], capture_output=True, text=True, check=True).stdout
+    kernels, cur = {}, None
+    for ln in out.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\w+)>:", ln)
+        if m:
+            cur = kernels.setdefault(m.group(1), [])
+            continue
+        m = re.match(r"^\s+(\S+).*//\s*([0-9A-F]+):\s*((?:[0-9A-F]{8}\s*)+)$", ln)
+        if m and cur is not None:
+            cur.append((m.group(1), int(m.group(2), 16), 4 * len(m.group(3).split())))
+    return kernels
+
+
+def straddlers(insts):
+    return [(mn, a) for mn, a, sz in insts if sz >= 8 and a // 64 != (a + sz - 1) // 64]
+
+
+@pytest.mark.parametrize("name", ["sigma2", "parquet_sigma4", "gv_sigma4", "parquet_sigma4_dyn"])
+def test_no_instruction_straddles_a_line(name, tmp_path):
+    padded, plain = layout(listing(name, tmp_path, "1")), layout(listing(name, tmp_path, "0"))
+    assert set(padded) == set(plain) and any(k.endswith("_nt") for k in padded)
+    n_plain = 0
+    for k, insts in padded.items():
+        if k.endswith("_coop") or k.endswith("_pool"):
+            continue                                     # waves that meet at barriers are left alone
+        assert len(insts) > 20 and all(sz in (4, 8) for _, _, sz in insts), k
+        assert straddlers(insts) == [], (name, k)
+        n_plain += len(straddlers(plain[k]))
+        # the pads are the only difference (the assembler's own fill after the last s_endpgm aside)
+        strip = lambda L: [mn for mn, _, _ in L if mn != "s_nop"]
+        assert strip(insts) == strip(plain[k]), (name, k)
+    if name != "sigma2":
+        assert n_plain > 10, "the unpadded listings were expected to straddle: is the check blind?"
+
+
+def test_the_pads_count_as_wait_states_and_the_listing_passes_the_hazard_table(tmp_path):
+    text = open(listing("parquet_sigma4", tmp_path, "1")).read()
+    rc, report = capi.isa_check_hazards(text)
+    assert rc == 0, report[:2000]

@@ -15,6 +15,7 @@ st = torch.cuda.current_stream().cuda_stream
 leaf = torch.empty((T, L, 64), dtype=torch.float64, device=dev)
 capi.fill_uniform_device_tiled(leaf.data_ptr(), B, L, 1, 64, 64 * L, 1234, 0, st)
 ref = None
+root = torch.zeros((T, R, 64), dtype=torch.float64, device=dev)      # ONE root array for every set: the rate depends on the (leaf pages, root pages) pair
 for spec in sets:
     opts = {} if spec == "-" else dict(kv.split("=") for kv in spec.split(","))
     opts["FDG_IGNORE_TUNED"] = opts.get("FDG_IGNORE_TUNED", None)
@@ -25,7 +26,7 @@ for spec in sets:
     except capi.FdgError as e:
         print(f"{name} [{spec}] specialize failed: {str(e)[:120]}", flush=True); continue
     tc = time.time() - t0
-    root = torch.zeros((T, R, 64), dtype=torch.float64, device=dev)
+    root.zero_()
     for _ in range(40): f.eval_tiled(root, leaf, B)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
