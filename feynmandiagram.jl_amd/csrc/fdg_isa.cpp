@@ -553,6 +553,8 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const bool dbg_norecv = dbg && std::strstr(dbg, "norecv");     // pooled / cooperative kernels without their reads of the shared LDS slots
   const bool dbg_nofetch = dbg && std::strstr(dbg, "nopoolfetch");   // ... without the fetches into the pool
   const bool dbg_noacc = dbg && std::strstr(dbg, "noacc");       // no AGPR moves
+  const bool dbg_nohead = dbg && std::strstr(dbg, "nohead");     // the loads at the head of a tile count as arrived when the first other operation issues
+  bool in_head = true;                                           // (what would hiding the head's memory latency behind the previous tile buy?)
   // experiment (results exact): a wave takes 2^c consecutive tiles, then jumps over the other waves' runs ("chunk<c>", c = 1 .. 9)
   int tile_run = 0;
   if (dbg && std::strstr(dbg, "chunk") && !cs) tile_run = std::max(0, std::min(9, std::atoi(std::strstr(dbg, "chunk") + 5)));
@@ -939,6 +941,10 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   for (const MOp &o : prog.ops) {
     if (rm_bufs) for (const RmFetch &f : rm_fetch[op_index]) rm_emit_fetch(f);
     const size_t this_op = op_index;
+    if (in_head && o.kind != M_LD_LEAF && o.kind != M_LD_LEAF_ACC) {
+      in_head = false;
+      if (dbg_nohead) { E.vm_done = E.vm_issued; for (auto &pp : E.pend) if (pp.first == 1) pp.first = 0; for (auto &pa : E.pend_acc) pa = 0; }
+    }
     {
       const size_t i = op_index++;
       uint64_t need = vm_seq_needed(o);
