@@ -68,3 +68,29 @@ def test_the_pads_count_as_wait_states_and_the_listing_passes_the_hazard_table(t
     text = open(listing("parquet_sigma4", tmp_path, "1")).read()
     rc, report = capi.isa_check_hazards(text)
     assert rc == 0, report[:2000]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["parquet_sigma4", "parquet_sigma5"])
+def test_padded_and_unpadded_kernels_give_the_oracles_bits(libfdg, cuda, name):
+    """The pads are wait states, nothing else: both listings against the oracle on the device (evaluation and fused accumulation)."""
+    import numpy as np
+    import torch
+    import oracle
+    t = workloads.get(name)
+    L, R, B = t.n_leaf, t.n_root, 4099
+    h_leaf = oracle.philox_uniform(B, L, 91)
+    want = oracle.eval_static(t, h_leaf)
+    w = oracle.philox_uniform(B, 1, 92)[:, 0]
+    leaf = torch.from_numpy(np.ascontiguousarray(h_leaf.T)).to(cuda).t()
+    for align in ("1", "0"):
+        f = fd.compile_table(t, specialize="isa", options={"FDG_ISA_ALIGN": align})
+        root = torch.zeros((R, B), dtype=torch.float64, device=cuda).t()
+        f(root, leaf)
+        torch.cuda.synchronize()
+        assert f.kernel_info()["last_kernel"].startswith("fdg_isa_eval"), align
+        assert np.array_equal(root.cpu().numpy(), want), (name, align)
+        acc = f.accumulate(leaf, torch.from_numpy(w).to(cuda)).cpu().numpy()
+        assert f.kernel_info()["last_kernel"].startswith("fdg_isa_eval_acc"), align
+        terms = want * w[:, None]
+        assert np.all(np.abs(acc - terms.sum(0)) <= 1e-12 * np.abs(terms).sum(0)), (name, align)
