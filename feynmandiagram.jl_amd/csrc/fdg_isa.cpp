@@ -337,6 +337,8 @@ struct Emit {
   bool streaming = false;     // the kernel being printed is the variant for line-aligned batches: non-temporal leaf loads and root stores
   uint64_t n_auto_nop = 0;
   uint64_t vm_issued = 0, lg_issued = 0, vm_done = 0, lg_done = 0;
+  bool no_vm_wait = false;    // FDG_ISA_DEBUG=novmwait (timing experiment, results are garbage): no wait for a load's data -- what a wave whose loads always
+                              // arrived in time would run at (the loads are still issued)
   uint64_t vm_slack = 0;      // FDG_ISA_DEBUG=noackwait (timing experiment, results may be garbage): waits let this many more operations stay
                               // outstanding -- the tile's root stores -- to see what a wave that never waits for store acknowledgements would run at
   // pending[reg] = (kind 0 none / 1 vm / 2 lgkm, seq)
@@ -365,6 +367,7 @@ struct Emit {
   }
   void wait_reg(uint32_t r) {
     auto &p = pend[r];
+    if (p.first == 1 && no_vm_wait) { p.first = 0; return; }
     if (p.first == 1 && p.second > vm_done) {
       uint64_t n = vm_issued - p.second + vm_slack;            // ops issued after it may stay outstanding
       if (n > 63) n = 63;
@@ -381,7 +384,7 @@ struct Emit {
     p.first = 0;
   }
   void wait_vm(uint64_t seq) {
-    if (seq <= vm_done) return;
+    if (seq <= vm_done || no_vm_wait) return;
     uint64_t n = std::min<uint64_t>(vm_issued - seq + vm_slack, 63);
     ins("s_waitcnt vmcnt(" + std::to_string(n) + ")");
     vm_done = std::max(std::max(vm_done, vm_issued - n), seq);
@@ -568,6 +571,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   if (dbg && std::strstr(dbg, "rot") && !cs && !tile_run && !tile_xcd) tile_rot = std::max(0, std::atoi(std::strstr(dbg, "rot") + 3));
   const int S_ROTB = S_POOL + 2 * (N_POOL - 1), S_ROTS = S_ROTB + 1;
   E.vm_slack = (dbg && std::strstr(dbg, "noackwait") && !accumulate) ? p.R : 0;
+  E.no_vm_wait = dbg && std::strstr(dbg, "novmwait");
   // ---- prologue ------------------------------------------------------------
   if (cs) E.ins("v_and_b32_e32 v0, 63, v0");          // lane within the wave (the workgroup has four waves)
   E.ins("s_load_dwordx8 s[4:11], s[0:1], 0x0");
