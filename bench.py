@@ -25,6 +25,11 @@ FP64_VALU_PEAK_TFLOPS = 78.6    # AMD spec, FMA counted as 2 (not in the local g
 # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12 lane-operations per second (measured: 38.0e12 at eight waves per SIMD, 36-37.7e12 at one
 # or two waves of a 248-register kernel, straight-line bodies, at 2.39-2.45 GHz: tools/ubench/fp64_issue.hip, profiles/r03_ubench_fp64_issue.txt).
 FP64_NOFMA_PEAK_TOPS = 39.3
+# The power roof (round 5; profiles/r05_log_power_probe.txt, r05_log_power_calib.txt): every row but the smallest graph runs at the package's
+# 1400 W cap with the shader clock pulled down to fit.  Socket power of the evaluator's kernels fits  idle + E_BYTE * (algorithmic bytes/s) + E_OP * (fold steps/s)
+# (calibrated on two rows -- sigma2 at 1120 W, the headline at 1381 W -- and within 7 % of the other memory- and ridge-bound rows), so a graph cannot be
+# evaluated faster than (cap - idle) / (E_BYTE * bytes + E_OP * ops) times a second whatever the schedule.  `frac_power` = achieved / that.
+POWER_CAP_W, POWER_IDLE_W, E_BYTE_J, E_OP_J = 1400.0, 240.0, 134e-12, 25.5e-12
 SPEC_CLOCK_GHZ = 2.4            # the clock the 39.3 is quoted at; roofline.clock_ghz is what the chip sustained (power budget)
 FP64_NOFMA_MEASURED_TOPS = 38.0
 CONFIG5_TOTAL_SAMPLES = 1_000_000_000     # BASELINE.json config 5: 10^9 samples over the GPUs of the node
@@ -356,6 +361,9 @@ def roofline_of(st, B, avg_kernel_s, kernel, accumulate=False, ops_exec=None, cl
         out["frac_valu_of_measured_peak"] = tops / FP64_NOFMA_MEASURED_TOPS
         if out["frac_valu"] > frac_hbm:      # the launch cannot be shorter than ops / peak: the vector ALU is the binding roof
             out.update({"bound": "valu_fp64", "achieved": tops, "peak": FP64_NOFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": out["frac_valu"]})
+    if ops_exec:
+        out["power_roof_evals_per_s"] = (POWER_CAP_W - POWER_IDLE_W) / (E_BYTE_J * bytes_per_eval + E_OP_J * ops_exec)
+        out["frac_power"] = (B / avg_kernel_s) / out["power_roof_evals_per_s"]
     if clock_ghz:
         # the shader clock the chip sustained during the timed launches (one sleeping wave on a side stream): the graphs at the
         # compute/memory ridge run against the power budget (1.8-1.9 GHz), and the vector-ALU roof scales with it
@@ -855,7 +863,7 @@ def compact_line(full):
     if roof:
         keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_kernel_ms",
                 "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_p05_over_steps", "frac_hbm_median_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy",
-                "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock")
+                "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock", "frac_power")
         line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:60]) for k in keep if k in roof}
         if roof.get("placement"):
             pi = roof.get("placement_info")
@@ -867,17 +875,17 @@ def compact_line(full):
                                 "sample": str(cb.get("sample", ""))[:110], "gpu_matches_cpu_bitwise": cb.get("gpu_matches_cpu_bitwise")}
     sec = full.get("secondary")
     if sec:
-        line["secondary_cols"] = ["workload", "layout", "Mevals_per_s", "bound", "frac", "frac_hbm", "frac_valu", "traffic_ratio", "bitwise", "clock_ghz"]
+        line["secondary_cols"] = ["workload", "layout", "Mevals_per_s", "bound", "frac", "frac_hbm", "frac_valu", "traffic_ratio", "bitwise", "clock_ghz", "frac_power"]
         rows = []
         for e in sec:
             if "error" in e:
-                rows.append([e.get("workload", "?")[:24], e.get("layout"), None, "error", None, None, None, None, False, None])
+                rows.append([e.get("workload", "?")[:24], e.get("layout"), None, "error", None, None, None, None, False, None, None])
                 continue
             r = e["roofline"]
             rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm", "tile_major": "tm", "tile_major+fma": "tm+fma", "leaf_major+fma": "lm+fma", "tile_major@plain": "tm@plain"}.get(e["layout"], e["layout"]) + ("*" if e.get("placement") == "fdg_batch_alloc_pair" else ""), _r(e["value"] / 1e6),
                          {"hbm": "hbm", "valu_fp64": "valu"}.get(r["bound"], r["bound"]), _r(r["frac"], 3), _r(r.get("frac_hbm"), 3),
                          _r(r.get("frac_valu"), 3), _r(r.get("traffic_over_algorithmic"), 3),
-                         (e.get("gpu_matches_cpu_bitwise") if not e.get("contracted") else "fma:%.1e" % (e.get("max_dev_over_Sk") or 0.0)), _r(r.get("clock_ghz"), 3)])
+                         (e.get("gpu_matches_cpu_bitwise") if not e.get("contracted") else "fma:%.1e" % (e.get("max_dev_over_Sk") or 0.0)), _r(r.get("clock_ghz"), 3), _r(r.get("frac_power"), 2)])
         line["secondary"] = rows
     c5 = full.get("config5")
     if c5:
@@ -887,7 +895,7 @@ def compact_line(full):
             r = c5.get("roofline_rank0", {})
             line["config5"] = {"workload": "gv_sigma5", "value": _r(c5["value"], 5), "unit": "samples/s", "n_gpus": c5["n_gpus"], "total_samples": c5["total_samples"],
                                "steps": c5["steps"], "bound": r.get("bound"), "frac": _r(r.get("frac"), 3), "frac_hbm": _r(r.get("frac_hbm"), 3),
-                               "frac_valu": _r(r.get("frac_valu"), 3), "clock_ghz": _r(r.get("clock_ghz"), 3)}
+                               "frac_valu": _r(r.get("frac_valu"), 3), "clock_ghz": _r(r.get("clock_ghz"), 3), "frac_power": _r(r.get("frac_power"), 3)}
     ac = full.get("accumulate")
     if ac:
         line["accumulate"] = ({"error": ac["error"][:80]} if "error" in ac else

@@ -1,43 +1,79 @@
-"""GPU dev tool: is a workload's rate set by the power budget?  The same ISA kernel on (a) its normal leaf-major batch of random
-leaves, (b) the same batch zero-filled (same HBM traffic, no toggling in the vector ALUs), (c) one random row broadcast to every
-sample (sample stride 0: same arithmetic on realistic values, next to no HBM traffic), (d) a zero row broadcast.
-python tools/gpu_power_probe.py WORKLOAD [B [random,zero,row]]"""
-import os, sys
+"""GPU dev tool (round 5): socket power and clocks (rocm-smi, sampled twice a second from a side thread) while one workload's evaluation runs back to back for a few
+seconds.  Question: are the rows whose two roofline fractions add up to ~1.0-1.2 sitting on the chip's power cap?
+usage: gpu_power_probe.py seconds "workload B" ..."""
+import json, os, subprocess, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import feynmandiagram_jl_amd as fd
 from feynmandiagram_jl_amd import workloads, capi
-dev = torch.device("cuda:0")
-name = sys.argv[1]
-t = workloads.get(name)
-L, R = t.n_leaf, t.n_root
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_000
-f = fd.compile_table(t, specialize="isa")
-h = f.handle
-st = torch.cuda.current_stream().cuda_stream
-leaf = torch.empty((L, B), dtype=torch.float64, device=dev)
-root = torch.empty((R, B), dtype=torch.float64, device=dev)
-row = torch.empty((L,), dtype=torch.float64, device=dev)
 
-def timed(ss, ls, ptr, n=40, warm=25):
-    for _ in range(warm): h.eval_device(ptr, ss, ls, root.data_ptr(), 1, B, B, st)
+dev = torch.device("cuda:0")
+secs = float(sys.argv[1])
+SMI = "/opt/rocm/bin/rocm-smi"
+
+
+def sample():
+    try:
+        out = subprocess.run([SMI, "--showpower", "--showclocks", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+        d = json.loads(out)
+        c = d[sorted(d)[0]]
+        return c
+    except Exception as e:
+        return {"error": str(e)}
+
+
+first = sample()
+print("idle sample:", {k: v for k, v in first.items() if any(s in k.lower() for s in ("power", "sclk", "mclk", "fclk"))}, flush=True)
+for spec in sys.argv[2:]:
+    name, B = spec.split(); B = int(B)
+    t = workloads.get(name); L, R = t.n_leaf, t.n_root
+    T = (B + 63) // 64
+    st = torch.cuda.current_stream().cuda_stream
+    f = fd.compile_table(t, specialize="isa")
+    leaf = torch.empty((T, L, 64), dtype=torch.float64, device=dev)
+    capi.fill_uniform_device_tiled(leaf.data_ptr(), B, L, 1, 64, 64 * L, 1234, 0, st)
+    root = torch.zeros((T, R, 64), dtype=torch.float64, device=dev)
+    stop, samples = [False], []
+
+    def poll():
+        while not stop[0]:
+            samples.append(sample()); time.sleep(0.15)
+    th = threading.Thread(target=poll); th.start()
+    for _ in range(20): f.eval_tiled(root, leaf, B)
     torch.cuda.synchronize()
+    n = 0; t0 = time.time()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n): h.eval_device(ptr, ss, ls, root.data_ptr(), 1, B, B, st)
+    while time.time() - t0 < secs:
+        for _ in range(50): f.eval_tiled(root, leaf, B)
+        torch.cuda.synchronize(); n += 50
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
-
-modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["random", "zero"]
-for label, fill in (("random leaves", True), ("zero leaves", False)):
-    if label.split()[0] not in modes: continue
-    if fill:
-        capi.fill_uniform_device(leaf.data_ptr(), B, L, 1, B, 11, 0, st)
-        capi.fill_uniform_device(row.data_ptr(), 1, L, L, 1, 12, 0, st)
-    else:
-        leaf.zero_(); row.zero_()
-    ms = timed(1, B, leaf.data_ptr())
-    print(f"{name} {label:14s} leaf-major batch      {ms:.3f} ms  {B / ms * 1e3:.3e} evals/s  kernel {h.kernel_info()['last_kernel'] if hasattr(h, 'kernel_info') else ''}", flush=True)
-    if "row" in modes:
-        ms = timed(0, 1, row.data_ptr())
-        print(f"{name} {label:14s} one row for every sample {ms:.3f} ms  {B / ms * 1e3:.3e} evals/s", flush=True)
+    ms = e0.elapsed_time(e1) / n
+    stop[0] = True; th.join()
+    ki = f.kernel_info()
+    st_ = t.stats() if hasattr(t, "stats") else {}
+    def num(s, key):
+        for k, v in s.items():
+            if key in k.lower():
+                try: return float(str(v).strip("()MmHhzWw ").split()[0].replace("Mhz", "").replace("MHz", ""))
+                except Exception: pass
+        return float("nan")
+    mid = samples[len(samples) // 3:]
+    pw = [num(s, "power (w)") if "error" not in s else float("nan") for s in mid]
+    keys = sorted({k for s in mid for k in s})
+    print(f"{name:26s} {ki['last_kernel']:18s} {ms:7.3f} ms {B / ms / 1e3:8.1f} Mevals/s frac_hbm {8 * (L + R) * B / ms / 1e6 / 8000:.3f} | {len(mid)} samples", flush=True)
+    if mid:
+        import statistics as S
+        def col(key):
+            v = []
+            for smp in mid:
+                for k, x in smp.items():
+                    if key in k.lower() and "max" not in k.lower():
+                        try: v.append(float(str(x).strip("()").lower().replace("mhz", "")))
+                        except Exception: pass
+            return v
+        for key, unit in (("power (w)", "W"), ("sclk clock speed", "MHz"), ("mclk clock speed", "MHz"), ("fclk clock speed", "MHz")):
+            v = col(key)
+            if v: print(f"      {key:18s} mean {S.mean(v):7.0f} min {min(v):6.0f} max {max(v):6.0f} {unit}   {[int(x) for x in v]}", flush=True)
+    del leaf, root, f
+    torch.cuda.empty_cache(); time.sleep(3)
