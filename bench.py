@@ -156,6 +156,60 @@ def probe_start(dev, seconds):
         return None
 
 
+def power_leg(step, seconds=1.5):
+    """Socket power and shader clock (rocm-smi, from a side thread) while `step` runs back to back for about `seconds` -- AFTER and outside the timed
+    region.  Returns {"power_w", "sclk_mhz", "power_cap_w", "samples"} or None (no rocm-smi, a different output format, a dry run): never an error."""
+    if DRY:
+        return None
+    import json as _json
+    import subprocess
+    import threading
+    smi = "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    card = "card%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    got, stop = [], [False]
+
+    def poll():
+        while not stop[0]:
+            try:
+                d = _json.loads(subprocess.run([smi, "--showpower", "--showclocks", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=5).stdout)
+                c = d.get(card) or d[sorted(d)[0]]
+                rec = {}
+                for k, v in c.items():
+                    kl = k.lower()
+                    try:
+                        if "max graphics package power" in kl: rec["cap"] = float(v)
+                        elif "power (w)" in kl: rec["w"] = float(v)
+                        elif "sclk clock speed" in kl: rec["sclk"] = float(str(v).strip("()").lower().replace("mhz", ""))
+                    except ValueError:
+                        pass
+                if "w" in rec:
+                    got.append(rec)
+            except Exception:
+                return
+            time.sleep(0.05)
+    try:
+        th = threading.Thread(target=poll, daemon=True)
+        t0 = time.perf_counter()
+        th.start()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(8):
+                step()
+            sync()
+        stop[0] = True
+        th.join(timeout=10)
+        use = got[1:] if len(got) > 2 else got          # (the first sample may predate the load)
+        if not use:
+            return None
+        out = {"power_w": sum(r["w"] for r in use) / len(use), "samples": len(use)}
+        if all("sclk" in r for r in use): out["sclk_mhz"] = sum(r["sclk"] for r in use) / len(use)
+        if "cap" in use[-1]: out["power_cap_w"] = use[-1]["cap"]
+        return out
+    except Exception:
+        return None
+
+
 def probe_stop(probe):
     """Shader clock in GHz the probe saw (s_memtime ticks per 100 MHz tick), None without a probe."""
     if not probe:
@@ -760,6 +814,11 @@ def main():
                 out["roofline"]["clock_ghz"] = case.clock_ghz
                 if out["roofline"].get("frac_valu") is not None:
                     out["roofline"]["frac_valu_at_clock"] = out["roofline"]["valu_tops"] / (FP64_NOFMA_PEAK_TOPS * case.clock_ghz / SPEC_CLOCK_GHZ)
+        if not DRY and world == 1:
+            # what the package draws under the headline launch (rocm-smi; after and outside the timed region): the rows of this line run at the cap
+            pw = power_leg(case.step)
+            if pw:
+                out["roofline"].update({"power_w": pw["power_w"], "power_cap_w": pw.get("power_cap_w"), "sclk_mhz": pw.get("sclk_mhz"), "power_samples": pw["samples"]})
         if args.backend == "isa":
             attach_traffic(out["roofline"], args.workload, args.layout, B, avg_kernel_s)
         out["valu_fp64"] = {"achieved_tflops": st["flops_alg"] * B / avg_kernel_s / 1e12,
@@ -863,7 +922,7 @@ def compact_line(full):
     if roof:
         keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_kernel_ms",
                 "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_p05_over_steps", "frac_hbm_median_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy",
-                "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock", "frac_power")
+                "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock", "frac_power", "power_w", "power_cap_w", "sclk_mhz")
         line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:60]) for k in keep if k in roof}
         if roof.get("placement"):
             pi = roof.get("placement_info")
