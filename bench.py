@@ -463,6 +463,24 @@ def attach_traffic(roof, workload, layout, B, avg_kernel_s):
                                          "), per evaluation, scaled to this batch")
 
 
+def measured_read(dev):
+    """The memory system's ceiling for a READ stream (the evaluator's traffic is 95 % reads): 4 GiB through fdg_read_device (8 bytes per lane, non-temporal)."""
+    import torch
+    from feynmandiagram_jl_amd import capi
+    a = torch.zeros(1 << 29, dtype=torch.float64, device=dev)
+    sink = torch.zeros(1, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        capi.read_device(a.data_ptr(), a.numel(), sink.data_ptr(), st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        capi.read_device(a.data_ptr(), a.numel(), sink.data_ptr(), st)
+    e1.record()
+    torch.cuda.synchronize()
+    return 20 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def measured_copy(dev):
     """The box's own streaming ceiling: a 2 GiB device-to-device copy by fdg_copy_device (16 bytes per lane), read + write counted."""
     import torch
@@ -804,6 +822,9 @@ def main():
             out["roofline"]["measured_copy_gbs"] = copy_gbs
             out["roofline"]["measured_copy_kernel"] = "fdg_copy_device (16 B per lane, non-temporal loads and stores, 2 GiB, read + write counted)"
             out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+            read_gbs = measured_read(dev)
+            out["roofline"]["measured_read_gbs"] = read_gbs            # (a read-only non-temporal stream: what the memory system gives the evaluator's kind of traffic)
+            out["roofline"]["frac_of_measured_read"] = achieved / read_gbs
         except RuntimeError:
             pass
         if not DRY:
@@ -921,7 +942,7 @@ def compact_line(full):
     roof = full.get("roofline")
     if roof:
         keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_kernel_ms",
-                "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_p05_over_steps", "frac_hbm_median_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy",
+                "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_p05_over_steps", "frac_hbm_median_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy", "measured_read_gbs", "frac_of_measured_read",
                 "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock", "frac_power", "power_w", "power_cap_w", "sclk_mhz")
         line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:60]) for k in keep if k in roof}
         if roof.get("placement"):

@@ -33,7 +33,7 @@ FDG_TILE_SAMPLES = 64
 EXPORTS = [
     "fdg_last_error", "fdg_version", "fdg_graph_create", "fdg_graph_destroy", "fdg_graph_query",
     "fdg_graph_emit_source", "fdg_free", "fdg_graph_specialize", "fdg_eval_device", "fdg_eval",
-    "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_clock_probe_device", "fdg_graph_specialize_typed", "fdg_eval_device_typed", "fdg_graph_create_complex_view", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
+    "fdg_accumulate_device", "fdg_fill_uniform_device", "fdg_copy_device", "fdg_read_device", "fdg_clock_probe_device", "fdg_graph_specialize_typed", "fdg_eval_device_typed", "fdg_graph_create_complex_view", "fdg_isa_check_hazards", "fdg_graph_release_device", "fdg_powi",
     "fdg_eval_strided", "fdg_graph_coop_program", "fdg_graph_set_opt_params", "fdg_graph_opt_program", "fdg_graph_set_schedule_groups", "fdg_leaf_eval_device", "fdg_leaf_eval_device_tiled",
     "fdg_comm_unique_id", "fdg_comm_create", "fdg_comm_destroy", "fdg_reduce_device",
     "fdg_graph_specialize_fused", "fdg_mc_eval_device", "fdg_mc_accumulate_device", "fdg_graph_mc_program",
@@ -167,6 +167,7 @@ def lib():
     L.fdg_accumulate_device.argtypes = [vp, dp, i64, i64, dp, dp, i64, vp]
     L.fdg_fill_uniform_device.argtypes = [dp, i64, u32, i64, i64, u64, u64, vp]
     L.fdg_copy_device.argtypes = [dp, dp, i64, vp]
+    L.fdg_read_device.argtypes = [dp, i64, dp, vp]
     L.fdg_clock_probe_device.argtypes = [C.c_double, vp, vp]
     L.fdg_graph_specialize_typed.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint]
     L.fdg_eval_device_typed.argtypes = [vp, C.c_int, vp, i64, i64, vp, i64, i64, i64, vp]
@@ -485,6 +486,11 @@ def isa_check_hazards(asm_text: str):
 
 def copy_device(d_dst: int, d_src: int, n: int, stream: int = 0):
     check(lib().fdg_copy_device(d_dst, d_src, n, stream))
+
+
+def read_device(d_src: int, n: int, d_sink: int, stream: int = 0):
+    """Harness: a non-temporal read-only stream over n doubles (the memory system's ceiling for reads)."""
+    check(lib().fdg_read_device(d_src, n, d_sink, stream))
 
 
 def clock_probe_device(seconds: float, d_ticks: int, stream: int):

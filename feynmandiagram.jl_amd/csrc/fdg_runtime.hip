@@ -379,6 +379,22 @@ __device__ __forceinline__ void fdg_copy16_body(const fdg_v2d *__restrict__ src,
   }
 }
 __global__ void __launch_bounds__(256) fdg_copy16(const fdg_v2d *__restrict__ src, fdg_v2d *__restrict__ dst, long n16) { fdg_copy16_body<false>(src, dst, n16); }
+// Harness: a read-only stream (8 bytes per lane, non-temporal, eight loads in flight per lane) -- the memory system's ceiling for the evaluator's kind of traffic,
+// which is 95 % reads (round 5: 6.65 TB/s where the copy reaches 5.5-6.0; tools/ubench/stream_power.hip).  Nothing is written unless the data says so.
+__global__ void __launch_bounds__(256) fdg_read8_nt(const double *__restrict__ src, double *__restrict__ sink, long n) {
+  const long stride = (long)gridDim.x * 256L;
+  double acc = 0.0;
+  long i = blockIdx.x * 256L + threadIdx.x;
+  for (; i + 7 * stride < n; i += 8 * stride) {
+    double r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += r[u];
+  }
+  for (; i < n; i += stride) acc += __builtin_nontemporal_load(src + i);
+  if (acc == 0x1.23456789abcdp+777) sink[0] = acc;
+}
 __global__ void __launch_bounds__(256) fdg_copy16_nt(const fdg_v2d *__restrict__ src, fdg_v2d *__restrict__ dst, long n16) { fdg_copy16_body<true>(src, dst, n16); }
 
 // ============================================================================
@@ -2717,6 +2733,15 @@ int fdg_copy_device(double *d_dst, const double *d_src, int64_t n, void *stream)
     hipLaunchKernelGGL(fdg_copy16_nt, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const fdg_v2d *)d_src, (fdg_v2d *)d_dst, n16);
   else
     hipLaunchKernelGGL(fdg_copy16, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const fdg_v2d *)d_src, (fdg_v2d *)d_dst, n16);
+  HIP_TRY(hipGetLastError());
+  return FDG_OK;
+}
+
+int fdg_read_device(const double *d_src, int64_t n, double *d_sink, void *stream) {
+  if (n < 0) { set_error("fdg_read_device: n must be >= 0"); return FDG_E_INVALID; }
+  if (n == 0) return FDG_OK;
+  if (!d_src || !d_sink) { set_error("fdg_read_device: null pointer"); return FDG_E_INVALID; }
+  hipLaunchKernelGGL(fdg_read8_nt, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, d_src, d_sink, (long)n);
   HIP_TRY(hipGetLastError());
   return FDG_OK;
 }

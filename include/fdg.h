@@ -422,6 +422,11 @@ int fdg_isa_check_hazards(const char *asm_text, char **report);
  * (the reference has no counterpart). */
 int fdg_copy_device(double *d_dst, const double *d_src, int64_t n, void *stream);
 
+/* Harness only (bench.py's `roofline.measured_read_gbs`): streams d_src[0..n) through the chip with non-temporal loads and writes nothing
+ * (d_sink: one double, written only if the data sums to a value it cannot have).  The memory system's ceiling for a read stream --
+ * the evaluator's traffic is 95 % reads -- which is above what a copy reaches.  No counterpart in the reference. */
+int fdg_read_device(const double *d_src, int64_t n, double *d_sink, void *stream);
+
 /* Harness only (bench.py's `roofline.clock_ghz`): enqueues ONE wave on `stream` that sleeps for `seconds` of wall time
  * (0 < seconds <= 30) and then writes d_ticks[0] = shader-clock ticks, d_ticks[1] = 100 MHz ticks that went by: launched on
  * a side stream next to the evaluator it reports the clock the chip sustained under that load (the graphs at the

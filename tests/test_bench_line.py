@@ -153,6 +153,7 @@ def test_bench_line_on_the_device(tmp_path):
     assert abs(r["achieved"] - got["value"] * 704 / 1e9) / r["achieved"] < 0.1          # 8 (L + R) bytes per evaluation, HIP events vs wall clock
     assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3 and r["frac_hbm_min_over_steps"] <= r["frac"] + 1e-9 <= r["frac_hbm_max_over_steps"] + 2e-9
     assert got["value"] > 1e9 and r["frac"] > 0.3                                        # (a smaller batch than the default: not the headline's figure)
+    assert r["measured_read_gbs"] > 3000 and 0.3 < r["frac_of_measured_read"] < 1.2          # fdg_read_device: the memory system's ceiling for a read stream on this box
     assert r.get("power_w") is None or (200 < r["power_w"] <= 1.05 * (r.get("power_cap_w") or 1400))        # rocm-smi next to the headline launch, when there is one
     assert 0.3 < r["frac_power"] < 1.3 and "frac_power" in got["secondary_cols"]         # the power roof: 1160 W / (134 pJ x bytes + 25.5 pJ x fold steps)
     c = got["cpu_baseline"]
