@@ -942,9 +942,9 @@ def compact_line(full):
     roof = full.get("roofline")
     if roof:
         keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_kernel_ms",
-                "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_p05_over_steps", "frac_hbm_median_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy", "measured_read_gbs", "frac_of_measured_read",
+                "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy", "measured_read_gbs", "frac_of_measured_read",
                 "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock", "frac_power", "power_w", "power_cap_w", "sclk_mhz")
-        line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:60]) for k in keep if k in roof}
+        line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:44]) for k in keep if k in roof}
         if roof.get("placement"):
             pi = roof.get("placement_info")
             line["roofline"]["placement"] = ("fdg_batch_alloc_pair, one batch: %d/%d windows at the fast level (%.3f)" % (pi["windows_at_fast_level"], pi["windows"], pi["pair_frac_best"])
