@@ -40,6 +40,7 @@ EXPORTS = [
     "fdg_graph_kernel_info",
     "fdg_eval_device_tiled", "fdg_accumulate_device_tiled", "fdg_fill_uniform_device_tiled", "fdg_graph_set_association",
     "fdg_batch_alloc", "fdg_batch_free", "fdg_graph_pool_program", "fdg_batch_alloc_pair", "fdg_graph_set_option", "fdg_graph_get_option", "fdg_set_default_option", "fdg_get_default_option", "fdg_selftest_pair_search",
+    "fdg_repack_tile_major", "fdg_unpack_tile_major",
 ]
 COMM_ID_BYTES = 128
 
@@ -112,7 +113,7 @@ class BatchPairInfo(C.Structure):
                 ("n_candidate", C.c_uint32), ("n_filler", C.c_uint32), ("n_probe", C.c_uint32), ("n_matched", C.c_uint32),
                 ("calibrated", C.c_uint32), ("gbs_fast", C.c_double), ("gbs_slow", C.c_double), ("gbs_before_mean", C.c_double),
                 ("gbs_before_min", C.c_double), ("gbs_after_mean", C.c_double), ("gbs_after_min", C.c_double), ("seconds", C.c_double),
-                ("seconds_settling", C.c_double)]
+                ("seconds_settling", C.c_double), ("level_reached", C.c_uint32), ("span_gb", C.c_uint32)]
 
 
 def lib():
@@ -168,6 +169,8 @@ def lib():
     L.fdg_fill_uniform_device.argtypes = [dp, i64, u32, i64, i64, u64, u64, vp]
     L.fdg_copy_device.argtypes = [dp, dp, i64, vp]
     L.fdg_read_device.argtypes = [dp, i64, dp, vp]
+    L.fdg_repack_tile_major.argtypes = [dp, i64, i64, dp, i64, C.c_uint32, vp]
+    L.fdg_unpack_tile_major.argtypes = [dp, dp, i64, i64, i64, C.c_uint32, vp]
     L.fdg_clock_probe_device.argtypes = [C.c_double, vp, vp]
     L.fdg_graph_specialize_typed.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint]
     L.fdg_eval_device_typed.argtypes = [vp, C.c_int, vp, i64, i64, vp, i64, i64, i64, vp]
@@ -486,6 +489,16 @@ def isa_check_hazards(asm_text: str):
 
 def copy_device(d_dst: int, d_src: int, n: int, stream: int = 0):
     check(lib().fdg_copy_device(d_dst, d_src, n, stream))
+
+
+def repack_tile_major(d_src: int, ss: int, cs: int, d_tiled: int, n_sample: int, n_col: int, stream: int = 0):
+    """fdg_repack_tile_major: matrix m[b*ss + c*cs] -> tile-major (64, n_col, cld(n_sample, 64))."""
+    check(lib().fdg_repack_tile_major(d_src, ss, cs, d_tiled, n_sample, n_col, stream))
+
+
+def unpack_tile_major(d_tiled: int, d_dst: int, ss: int, cs: int, n_sample: int, n_col: int, stream: int = 0):
+    """fdg_unpack_tile_major: tile-major (64, n_col, cld(n_sample, 64)) -> matrix m[b*ss + c*cs]."""
+    check(lib().fdg_unpack_tile_major(d_tiled, d_dst, ss, cs, n_sample, n_col, stream))
 
 
 def read_device(d_src: int, n: int, d_sink: int, stream: int = 0):

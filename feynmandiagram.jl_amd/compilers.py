@@ -190,6 +190,40 @@ class GraphFunc:
         library-owned memory; call ``.free()`` (or drop the object) when done."""
         return PairedBatch(self, n_sample, device, calibrate, chunk_bytes, verbose, extra_flags)
 
+    @staticmethod
+    def tile_major_(dst, src, n_sample: Optional[int] = None):
+        """``tile_major!(dst, src)``: a matrix in one of the reference's layouts -- ``src[b, c]`` with any strides: a Julia column-major
+        ``B x C`` matrix (torch: ``x.t()`` of a ``[C, B]`` tensor) or ``compile_Python``'s row-major ``[B, C]`` -- into the tile-major
+        ``dst[t, c, l]`` (:meth:`tile_major_empty`).  One pass at copy speed (``fdg_repack_tile_major``); returns ``dst``."""
+        import torch
+        if not (_is_torch(src) and src.is_cuda and src.dtype == torch.float64 and src.dim() == 2):
+            raise ValueError("src must be a 2-d float64 CUDA tensor [samples, columns]")
+        B = src.shape[0] if n_sample is None else int(n_sample)
+        C_ = src.shape[1]
+        if dst is None:
+            dst = GraphFunc.tile_major_empty(B, C_, src.device)
+        if not (_is_torch(dst) and dst.is_cuda and dst.dtype == torch.float64 and dst.dim() == 3 and dst.shape[2] == 64 and dst.shape[1] == C_
+                and dst.is_contiguous() and dst.shape[0] >= (B + 63) // 64 and B <= src.shape[0]):
+            raise ValueError("dst must be a contiguous float64 CUDA tensor [cld(B, 64), columns, 64]")
+        with torch.cuda.device(src.device):
+            capi.repack_tile_major(src.data_ptr(), src.stride(0), src.stride(1), dst.data_ptr(), B, C_, torch.cuda.current_stream(src.device).cuda_stream)
+        return dst
+
+    @staticmethod
+    def from_tile_major_(dst, src, n_sample: Optional[int] = None):
+        """``from_tile_major!(dst, src)``: the inverse of :meth:`tile_major_` -- tile-major ``src[t, c, l]`` into the matrix ``dst[b, c]`` (any strides)."""
+        import torch
+        if not (_is_torch(dst) and dst.is_cuda and dst.dtype == torch.float64 and dst.dim() == 2):
+            raise ValueError("dst must be a 2-d float64 CUDA tensor [samples, columns]")
+        B = dst.shape[0] if n_sample is None else int(n_sample)
+        C_ = dst.shape[1]
+        if not (_is_torch(src) and src.is_cuda and src.dtype == torch.float64 and src.dim() == 3 and src.shape[2] == 64 and src.shape[1] == C_
+                and src.is_contiguous() and src.shape[0] >= (B + 63) // 64 and B <= dst.shape[0]):
+            raise ValueError("src must be a contiguous float64 CUDA tensor [cld(B, 64), columns, 64]")
+        with torch.cuda.device(dst.device):
+            capi.unpack_tile_major(src.data_ptr(), dst.data_ptr(), dst.stride(0), dst.stride(1), B, C_, torch.cuda.current_stream(dst.device).cuda_stream)
+        return dst
+
     def _check_tiled(self, x, n_col, what):
         import torch
         if not (_is_torch(x) and x.is_cuda and x.dtype == torch.float64 and x.dim() == 3 and x.shape[2] == 64 and x.shape[1] >= n_col):

@@ -355,6 +355,15 @@ struct PairAllocator : PairSearch {
   double settle_s = 0;
   std::vector<double> before;             // [window] pair in draw order
   size_t n_filler_total = 0;
+  bool span_cut = false;                  // the sprinkle ended before its 80 GB: free memory (less what the batch itself still needs) ran out
+  bool leaves_retried = false;            // hipMalloc(leaves) failed with the candidates of the sprinkle held: they were given back and the batch mapped uncalibrated
+  // what the batch itself still has to allocate: never promised to a filler or to a surplus candidate
+  size_t still_needed() const {
+    size_t need = leaf_va ? 0 : n_chunk * leaf_chunk;
+    if (cand.size() < n_chunk) need += (n_chunk - cand.size()) * root_chunk;
+    return need;
+  }
+  static size_t free_bytes() { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess ? f : 0; }
   std::chrono::steady_clock::time_point t_released = std::chrono::steady_clock::now();
   bool verbose() const { return (flags & FDG_BATCH_PAIR_VERBOSE) != 0; }
   int64_t n_all() const { return (int64_t)(n_chunk * chunk_tiles) * 64; }
@@ -422,8 +431,10 @@ struct PairAllocator : PairSearch {
     return FDG_OK;
   }
 
-  hipError_t new_cand() {
+  // `surplus`: a candidate beyond the n_chunk the batch needs -- only while the device keeps what the batch still has to allocate plus 4 GB free
+  hipError_t new_cand(bool surplus = false) {
     if (cand.size() >= max_cand) return hipErrorOutOfMemory;
+    if (surplus && free_bytes() < root_chunk + still_needed() + ((size_t)4 << 30)) return hipErrorOutOfMemory;
     Phys c;
     hipError_t e = hipMemCreate(&c.h, root_chunk, &prop, 0);
     if (e != hipSuccess) return e;
@@ -439,7 +450,7 @@ struct PairAllocator : PairSearch {
   // a 2 GB filler: moves the driver's allocator on to other regions of the memory (`reserve`: what must stay free besides)
   bool new_filler(size_t reserve) {
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < filler_bytes + reserve + ((size_t)8 << 30)) return false;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < filler_bytes + reserve + still_needed() + ((size_t)8 << 30)) return false;
     Phys f;
     if (hipMemCreate(&f.h, filler_bytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
     filler.push_back(f);
@@ -458,16 +469,30 @@ struct PairAllocator : PairSearch {
     if ((e = hipEventCreate(&cx.ev0)) != hipSuccess || (e = hipEventCreate(&cx.ev1)) != hipSuccess) return hip_fail("hipEventCreate", e);
     if (calibrate) {
       const size_t span = (size_t)80 << 30;
+      // (the sprinkle takes only what the device can spare -- a filler or a surplus candidate that does not fit ends it, it is not
+      //  an error: a batch next to other allocations gets a shorter span and the best pairs found within it)
       for (size_t q = 0; q * filler_bytes < span && cand.size() + 2 <= max_cand / 2; ++q) {
-        if (!new_filler((size_t)16 << 30)) break;
-        for (int c = 0; c < 2; ++c) if ((e = new_cand()) != hipSuccess) return hip_fail("hipMemCreate(root candidate)", e);
+        if (!new_filler((size_t)8 << 30)) { span_cut = true; break; }
+        bool both = true;
+        for (int c = 0; c < 2 && both; ++c) if (new_cand(cand.size() >= n_chunk) != hipSuccess) { (void)hipGetLastError(); both = false; }
+        if (!both) { span_cut = true; break; }
       }
       n_filler_total = filler.size();
       for (Phys &f : filler) (void)hipMemRelease(f.h);
       filler.clear();
       t_released = std::chrono::steady_clock::now();
     }
-    if ((e = hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk)) != hipSuccess) return hip_fail("hipMalloc(leaves)", e);
+    if ((e = hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk)) != hipSuccess) {
+      // the leaves do not fit next to what the sprinkle holds (fragmentation, or another process took memory meanwhile): everything drawn
+      // goes back, the leaves are allocated first and the roots mapped in draw order -- a plain batch instead of no batch
+      (void)hipGetLastError();
+      leaf_va = nullptr;
+      for (size_t j = 0; j < cand.size(); ++j) { if (cand[j].mapped) (void)hipMemUnmap(cand_at(j), root_chunk); (void)hipMemRelease(cand[j].h); }
+      cand.clear();
+      leaves_retried = true; calibrate = false;
+      (void)hipDeviceSynchronize();
+      if ((e = hipMalloc((void **)&leaf_va, n_chunk * leaf_chunk)) != hipSuccess) { leaf_va = nullptr; return hip_fail("hipMalloc(leaves)", e); }
+    }
     while (cand.size() < n_chunk) if ((e = new_cand()) != hipSuccess) return hip_fail("hipMemCreate(root candidate)", e);
     return FDG_OK;
   }
@@ -479,8 +504,8 @@ struct PairAllocator : PairSearch {
   bool draw_more() override {
     const size_t filler_budget = (size_t)144 << 30;
     if (!(filler.size() * filler_bytes < filler_budget && cand.size() + 2 <= max_cand)) return false;
-    if (!new_filler((size_t)8 << 30)) return false;
-    for (int c = 0; c < 2; ++c) if (new_cand() != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (!new_filler((size_t)8 << 30)) { span_cut = true; return false; }
+    for (int c = 0; c < 2; ++c) if (new_cand(true) != hipSuccess) { (void)hipGetLastError(); span_cut = true; return c > 0; }      // (one more candidate is still one more)
     return true;
   }
 
@@ -577,6 +602,10 @@ struct PairAllocator : PairSearch {
       info->gbs_fast = fast; info->gbs_slow = slow;
       info->gbs_before_mean = before_mean; info->gbs_before_min = before_min; info->gbs_after_mean = after_mean; info->gbs_after_min = after_min;
       info->seconds_settling = settle_s;
+      info->span_gb = (uint32_t)((n_filler * filler_bytes) >> 30);
+      // 0: no calibration asked for (or the window too small to time).  1: asked for, but the batch was mapped in draw order: the leaves only fitted
+      // once the candidates were given back.  2: calibrated over a span cut short by the free memory (the best pairs found within it).  3: the full search.
+      info->level_reached = !(flags & FDG_BATCH_PAIR_CALIBRATE) ? 0u : (leaves_retried ? 1u : (!calibrate ? 0u : (span_cut ? 2u : 3u)));
     }
     return FDG_OK;
   }
@@ -590,7 +619,7 @@ int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint
   if (info) std::memset(info, 0, sizeof *info);
   if (n_sample <= 0) { fdg::set_error("empty batch"); return FDG_E_INVALID; }
   if (g->prog.L == 0 || g->prog.R == 0) { fdg::set_error("fdg_batch_alloc_pair: the graph has no leaves or no roots"); return FDG_E_INVALID; }
-  if (!(g->isa && !g->code_object.empty())) { fdg::set_error("fdg_batch_alloc_pair: tile-major batches need a handle specialised with FDG_SPEC_ISA"); return FDG_E_UNSUPPORTED; }
+  if (!(g->isa && !g->code_object.empty())) { fdg::set_error("fdg_batch_alloc_pair: the pairs are timed with the handle's own kernels: it must be specialised with FDG_SPEC_ISA first"); return FDG_E_UNSUPPORTED; }
   const auto t_start = std::chrono::steady_clock::now();
   PairAllocator A;
   A.g = g; A.flags = flags;

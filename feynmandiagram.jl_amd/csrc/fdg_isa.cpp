@@ -532,16 +532,27 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   const std::string ST = W == 2 ? "global_store_dwordx4 " : "global_store_dwordx2 ";
   // cache policy of the leaf stream (experiment knob): FDG_ISA_LEAF_POLICY="nt" / "sc1" / "sc0 sc1" ...
   const std::string leaf_policy_env = fdg::knob("FDG_ISA_LEAF_POLICY") ? std::string(" ") + fdg::knob("FDG_ISA_LEAF_POLICY") : std::string();
-  const std::string root_policy = fdg::knob("FDG_ISA_ROOT_POLICY") ? std::string(" ") + fdg::knob("FDG_ISA_ROOT_POLICY") : std::string(E.streaming ? " nt" : "");
+  const std::string root_policy = fdg::knob("FDG_ISA_ROOT_POLICY") ? std::string(" ") + fdg::knob("FDG_ISA_ROOT_POLICY") : std::string(E.streaming || (cs && cs->pooled) ? " nt" : "");
   // Streaming variant: a leaf's last load of the tile and the root stores are non-temporal -- the lines are not needed again, and
   // a read stream with a few stores in it runs 5-10 % faster that way (tools/ubench/tile_ahead.hip: 5.73 -> 6.32 TB/s).  Only for
   // batches whose tiles are whole cache lines (the runtime checks strides and bases): a line shared by two tiles would be
   // fetched twice.  Earlier loads of a leaf that is loaded again stay as they are (the re-load may still find the line in L2).
+  // Round 6: a load whose leaf IS loaded again in this tile is non-temporal too when that next load comes more than FDG_ISA_NT_DIST (48) leaf loads
+  // later -- by then the XCD's 4 MB of L2, which its 128 resident waves share, has been turned over and the line would be fetched from memory
+  // anyway, while keeping it costs the stream what every retained line costs (gv_ver4_4's one-wave kernel, leaves re-loaded 2.2 x: every load
+  // non-temporal 3.49 ms, last loads only 3.99, none 4.26; parquet_ver4_4 and gv_sigma5, re-loaded 1.3 x soon after: every load non-temporal
+  // loses 4 %; profiles/r06_log_nt_sweep.txt, r06_log_sweep_c.txt).
   std::vector<uint8_t> final_load(prog.ops.size(), 0);
   if (E.streaming) {
-    std::vector<uint8_t> seen(p.L + 1, 0);
+    const long nt_dist = fdg::knob("FDG_ISA_NT_DIST") ? std::atol(fdg::knob("FDG_ISA_NT_DIST")) : 48;
+    std::vector<long> next_at(p.L + 1, -1);     // ordinal (among the tile's leaf loads, counted from the end) of the leaf's next load
+    long ord = 0;
     for (size_t i = prog.ops.size(); i-- > 0;)
-      if ((prog.ops[i].kind == M_LD_LEAF || prog.ops[i].kind == M_LD_LEAF_ACC) && prog.ops[i].a < seen.size() && !seen[prog.ops[i].a]) { seen[prog.ops[i].a] = 1; final_load[i] = 1; }
+      if ((prog.ops[i].kind == M_LD_LEAF || prog.ops[i].kind == M_LD_LEAF_ACC) && prog.ops[i].a < next_at.size()) {
+        const uint32_t a = prog.ops[i].a;
+        if (next_at[a] < 0 || (nt_dist >= 0 && ord - next_at[a] > nt_dist)) final_load[i] = 1;
+        next_at[a] = ord++;
+      }
   }
   std::string leaf_policy = leaf_policy_env;
   const std::string DSR = W == 2 ? "ds_read_b128 " : "ds_read_b64 ";
@@ -892,6 +903,14 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   // 6.1 TB/s in a bare loop over rows that are whole cache lines (tools/ubench/rm_stream.hip), but a row of L doubles is not: the
   // 128-byte segments of consecutive chunks share lines, and a line fetched non-temporally is fetched again from memory for the
   // next chunk (measured: parquet_sigma4 6.2 -> 3.6e9 evals/s).  Plain loads it is.
+  // Cache policy of the pooled kernels' fetches: NON-TEMPORAL (round 6).  A fetch lands in LDS and is read from there; its line is of no use to
+  // the caches, and a plain LDS-direct load costs the CU far more than a streaming one: gv_ver4_4 3.65 -> 3.06 ms per 524 288 samples, bit for
+  // bit the same (profiles/r06_log_pool_sweep.txt; "sc1" / "sc0 sc1" change nothing, "sc0 sc1 nt" = "nt").  The fetches cost the same with one
+  // or two waves per SIMD and whichever waves issue them -- a property of the CU's path to memory, not of the issuing wave.
+  // FDG_POOL_FETCH_POLICY="plain" / "sc1" / ... overrides.
+  const std::string panel_policy = fdg::knob("FDG_ISA_PANEL_POLICY") && fdg::knob("FDG_ISA_PANEL_POLICY")[0] ? std::string(" ") + fdg::knob("FDG_ISA_PANEL_POLICY") : std::string();   // (experiment)
+  const char *pool_policy_env = fdg::knob("FDG_POOL_FETCH_POLICY");
+  const std::string pool_policy = !pool_policy_env ? std::string(" nt") : (std::string(pool_policy_env) == "plain" || !pool_policy_env[0] ? std::string() : std::string(" ") + pool_policy_env);
   const std::string rm_policy = fdg::knob("FDG_ISA_RM_POLICY") && fdg::knob("FDG_ISA_RM_POLICY")[0] ? std::string(" ") + fdg::knob("FDG_ISA_RM_POLICY") : std::string();
   std::vector<uint64_t> rm_ready(rm_bufs, 0);        // vm sequence number of the last load of the chunk in each buffer
   auto rm_emit_fetch = [&](const RmFetch &f) {
@@ -1035,7 +1054,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         if (dbg_nopanel) break;
         E.wait_reg(o.d);
         const std::string opnd = panel_operand(o.a);
-        E.ins(LD + vall(o.d) + ", " + V(V_LANE8) + ", " + opnd);
+        E.ins(LD + vall(o.d) + ", " + V(V_LANE8) + ", " + opnd + panel_policy);
         E.pend[o.d] = {1, ++E.vm_issued};
         break;
       }
@@ -1043,7 +1062,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         if (dbg_nopanel) break;
         E.wait_reg(o.a);
         const std::string opnd = panel_operand(o.d);
-        E.ins(ST + V(V_LANE8) + ", " + vall(o.a) + ", " + opnd);
+        E.ins(ST + V(V_LANE8) + ", " + vall(o.a) + ", " + opnd + panel_policy);
         ++E.vm_issued;
         break;
       }
@@ -1064,27 +1083,46 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         const bool pair = o.b == 2;          // 64 lanes: two leaves adjacent in the tile (leaf stride 64, checked at launch) into two adjacent slots
         if (!pair && !pool_exec_low) { E.ins("s_mov_b64 exec, 0xffffffff"); pool_exec_low = true; }
         if (pair && pool_exec_low) { E.ins("s_mov_b64 exec, -1"); pool_exec_low = false; }
-        // the tile's leaves lie within 2 GB of its first (checked at launch): a 32-bit product; with pairs the stride is known
-        if (o.a == 0) {
-          E.ins("s_mov_b64 " + S2(S_FA) + ", " + S2(S_LT));
-        } else {
+        // The tile's leaves lie within 2 GB of its first (checked at launch), so a leaf's place is a 32-bit offset from the tile's base: it goes
+        // into the lanes' offset register by ONE vector add (round 6: M0 first -- the wait state it needs before the load is then filled by the
+        // address arithmetic --, no 64-bit scalar address: four instructions per fetch instead of seven; the fetch sequences are issue overhead
+        // of a lone wave now that the loads themselves are non-temporal).
+        E.ins("s_mov_b32 m0, " + hex32(o.d * SLOT));
+        std::string saddr = S2(S_LT);
+        uint32_t off_reg = rm0 + 2;
+        if (pair && o.negc) {     // the upper half of the wave brings leaf c > a (any leaf): its lanes' offsets are (c - a) leaf strides further
+          if (o.a != 0) {
+            E.ins("s_mul_i32 " + S(S_X) + ", " + S(S_LS8) + ", " + hex32(o.a));
+            E.ins("s_add_u32 " + S(S_FA) + ", " + S(S_LT) + ", " + S(S_X));
+            E.ins("s_addc_u32 " + S(S_FA + 1) + ", " + S(S_LT + 1) + ", 0");
+            saddr = S2(S_FA);
+          }
+          E.ins("s_mul_i32 " + S(S_X) + ", " + S(S_LS8) + ", " + hex32(o.c - o.a));
+          E.ins("s_sub_u32 " + S(S_X) + ", " + S(S_X) + ", 0x200");
+          E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 3) + ", " + S(S_X) + ", v" + std::to_string(rm0 + 2));
+          E.ins("v_cndmask_b32_e64 v" + std::to_string(rm0 + 3) + ", v" + std::to_string(rm0 + 2) + ", v" + std::to_string(rm0 + 3) + ", " + S2(S_DELTA + 4));
+          off_reg = rm0 + 3;
+        } else if (o.a != 0 && !(fdg::knob("FDG_POOL_VADDR") && fdg::knob("FDG_POOL_VADDR")[0] == '1')) {
+          // (scalar address arithmetic: measured 1.5 % faster than one vector add into the offset register -- FDG_POOL_VADDR=1 -- although that is
+          //  two instructions fewer: the scalar unit's instructions cost a lone wave less than a vector one, profiles/r06_log_sweep_c.txt)
           if (cs->pool_unit == 2) E.ins("s_add_u32 " + S(S_FA) + ", " + S(S_LT) + ", " + hex32(o.a * 512u));
           else {
             E.ins("s_mul_i32 " + S(S_X) + ", " + S(S_LS8) + ", " + hex32(o.a));
             E.ins("s_add_u32 " + S(S_FA) + ", " + S(S_LT) + ", " + S(S_X));
           }
           E.ins("s_addc_u32 " + S(S_FA + 1) + ", " + S(S_LT + 1) + ", 0");
-        }
-        uint32_t off_reg = rm0 + 2;
-        if (pair && o.negc) {     // the upper half of the wave brings leaf c > a (any leaf): its lanes' offsets are (c - a) leaf strides further
-          E.ins("s_mul_i32 " + S(S_X) + ", " + S(S_LS8) + ", " + hex32(o.c - o.a));
-          E.ins("s_sub_u32 " + S(S_X) + ", " + S(S_X) + ", 0x200");
-          E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 3) + ", " + S(S_X) + ", v" + std::to_string(rm0 + 2));
-          E.ins("v_cndmask_b32_e64 v" + std::to_string(rm0 + 3) + ", v" + std::to_string(rm0 + 2) + ", v" + std::to_string(rm0 + 3) + ", " + S2(S_DELTA + 4));
+          saddr = S2(S_FA);
+        } else if (o.a != 0) {
+          if (cs->pool_unit == 2) E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 3) + ", " + hex32(o.a * 512u) + ", v" + std::to_string(rm0 + 2));
+          else {
+            E.ins("s_mul_i32 " + S(S_X) + ", " + S(S_LS8) + ", " + hex32(o.a));
+            E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 3) + ", " + S(S_X) + ", v" + std::to_string(rm0 + 2));
+          }
           off_reg = rm0 + 3;
+        } else {
+          E.ins("s_nop 0");       // (leaf 0: nothing to compute between the write of M0 and the load)
         }
-        E.ins("s_mov_b32 m0, " + hex32(o.d * SLOT));
-        E.ins("global_load_lds_dwordx4 v" + std::to_string(off_reg) + ", " + S2(S_FA));
+        E.ins("global_load_lds_dwordx4 v" + std::to_string(off_reg) + ", " + saddr + pool_policy);
         pool_pending.push_back({++E.vm_issued, (uint32_t)o.imm});
         const bool more = this_op + 1 < prog.ops.size() && prog.ops[this_op + 1].kind == M_POOL_FETCH;
         if (!more && pool_exec_low) { E.ins("s_mov_b64 exec, -1"); pool_exec_low = false; }
@@ -1424,7 +1462,7 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
   os << "\t.text\n\t.protected\t" << kname << "\n\t.globl\t" << kname << "\n\t.p2align\t8\n\t.type\t" << kname << ",@function\n";
   os << kname << ":\n";
   E.off = 0;
-  E.pad_ok = false;
+  E.pad_ok = fdg::knob("FDG_COOP_ALIGN") != nullptr;     // (experiment: the alignment pads inside the barrier-synchronised kernels)
   E.hz.reset();
   E.ins("v_lshrrev_b32_e32 v1, 6, v0");
   E.ins("v_readfirstlane_b32 s3, v1");
@@ -1521,9 +1559,20 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   { const char *a = fdg::knob("FDG_ISA_SHIFT"); E.shift = a ? std::atoi(a) : 0; }
   E.os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n";
   std::vector<KernelMeta> ks;
+  // Programs too long for a second copy (below) get their ONE kernel with the streaming policy (round 6): a leaf's last load of the tile and the
+  // root stores non-temporal.  On a batch whose tiles are not whole cache lines that costs a second fetch of the lines two tiles share; the plain
+  // policy costs these graphs -- thousands of leaves, re-loaded several times over -- far more on every batch (gv_ver4_4, one-wave: 4.24 -> 3.49 ms
+  // with every leaf load non-temporal, profiles/r06_log_pool_sweep2.txt; gv_sigma6 4.61 -> 4.35, profiles/r06_log_nt_sweep.txt).
+  const bool long_program = prog.ops.size() > 60000 && prog.mc_n_k == 0 && prog.mc_n_t == 0 && !fdg::knob("FDG_ISA_NO_STREAMING");
+  E.streaming = long_program;
   ks.push_back(emit_kernel(E, p, prog, kname, 1));
+  E.streaming = false;
   if (prog2) ks.push_back(emit_kernel(E, p, *prog2, kname + "_w2", 2));
-  if (prog_acc) ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc", 1, true));
+  if (prog_acc) {
+    E.streaming = long_program && prog_acc->ops.size() > 60000;
+    ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc", 1, true));
+    E.streaming = false;
+  }
   // the same programs once more for batches whose tiles are whole cache lines (see `streaming` in emit_kernel); not for programs
   // so long that a second copy would double a minute of assembly
   if (!fdg::knob("FDG_ISA_NO_STREAMING") && prog.ops.size() <= 60000 && prog.mc_n_k == 0 && prog.mc_n_t == 0) {

@@ -807,7 +807,7 @@ struct Alloc {
       case 2: out.push_back(MOp{M_LD_MEM, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_mem++; break;
       case 4: out.push_back(MOp{M_LD_ACC, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_acc++; break;
       case 5: out.push_back(MOp{M_RECV, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_recv++; break;          // still in its shared slot
-      default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v - leaf_lo, 0, 0.0}); prog.n_ld_leaf++; break;   // leaves only
+      default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v - leaf_lo, 0, 0.0}); prog.n_ld_leaf++; if (prm.leaves_once) home_kind[v] = 0; break;   // leaves only
     }
     reg_of[v] = r; owner[r] = v; lock[r] = pos;
     return r;
@@ -821,7 +821,7 @@ struct Alloc {
       case 1: out.push_back(MOp{M_LD_LDS, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_lds++; break;
       case 2: out.push_back(MOp{M_LD_MEM, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_ld_mem++; break;
       case 5: out.push_back(MOp{M_RECV, 0, 0, r, home_slot[v], 0, 0.0}); prog.n_recv++; break;
-      default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v - leaf_lo, 0, 0.0}); prog.n_ld_leaf++; break;
+      default: out.push_back(MOp{M_LD_LEAF, 0, 0, r, v - leaf_lo, 0, 0.0}); prog.n_ld_leaf++; if (prm.leaves_once) home_kind[v] = 0; break;
     }
     reg_of[v] = r; owner[r] = v;
   }
@@ -1798,8 +1798,10 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     for (size_t i = 0; i < fetches.size(); ++i) by_issue[fetches[i].issue].push_back(i);
     uint32_t turn = 0;
     const bool global_rr = fdg::knob("FDG_POOL_DEAL_GLOBAL") != nullptr;      // (experiment: the round-3 dealing, by global index)
+    // (experiment FDG_POOL_FETCH_WAVES=n: only the first n waves issue fetches -- is what a fetch costs its wave a property of the wave or of the CU?)
+    const uint32_t NF = fdg::knob("FDG_POOL_FETCH_WAVES") ? (uint32_t)std::max(1, std::min<int>((int)NW, std::atoi(fdg::knob("FDG_POOL_FETCH_WAVES")))) : NW;
     for (uint32_t ep = 0; ep <= n_epoch; ++ep)
-      for (size_t i : by_issue[ep]) { at[global_rr ? i % NW : turn % NW][ep].push_back(fetches[i]); turn++; }
+      for (size_t i : by_issue[ep]) { at[global_rr ? i % NF : turn % NF][ep].push_back(fetches[i]); turn++; }
   }
   for (uint32_t w = 0; w < NW; ++w) {
     std::vector<MOp> r;

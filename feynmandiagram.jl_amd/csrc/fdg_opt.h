@@ -100,6 +100,10 @@ struct OptParams {
   bool acc_in_agpr = false;       // fused-accumulation kernels of graphs with 41 ... 124 roots: the per-lane accumulators live in AGPR pairs (above the
                                   // program's own), three VGPR pairs (weight, two temporaries) above the values; one wave per SIMD
   bool pool_leaves = false;       // pooled cooperative programs: leaves are re-read from the shared LDS pool (cheap to evict, never parked)
+  bool leaves_once = false;       // row-major programs (round 6): a leaf is loaded ONCE, while its 16-leaf chunk of the rows sits in a staging buffer, and is
+                                  // from then on a value like any other -- evicted to an LDS slot, an AGPR pair or the panel (512 bytes, coalesced) instead of
+                                  // being dropped and "re-loaded", which for a row-major matrix means fetching its whole chunk (8 KB) again or gathering
+                                  // 64 cache lines for 64 doubles (parquet_sigma5 row-major: 33 chunk fetches + 13 gathers for 18 chunks)
   uint32_t reserve_pairs = 0;     // VGPR pairs the kernel variant keeps above the values (accumulators, weight): the value budget shrinks
                                   // by this and by the temporaries the program's macro ops need, so that everything stays below v256
 };

@@ -312,6 +312,66 @@ fdg_transpose_to_leaf_major(const double *__restrict__ src, long ss, long ls, do
   }
 }
 
+// ---- a matrix of the reference's layouts <-> the tile-major batch (round 6: fdg_repack_tile_major / fdg_unpack_tile_major) -----------------
+// tiled[t][c][l] (64 samples of column c of tile t contiguous) against a strided matrix m[b * ss + c * cs], b = 64 t + l.
+// Column-major matrices (ss == 1: a Julia B x C Matrix) need no transposition: the 64 samples of (t, c) are one 512-byte run on both sides,
+// 32 lanes of 16 bytes each, eight runs per block and pass (runs cut short by the matrix's end or not 16-byte aligned go lane by lane).
+template <bool TO_TILED>
+__global__ void __launch_bounds__(256)
+fdg_repack_runs(double *__restrict__ mat, long cs, double *__restrict__ tiled, long n, uint32_t C) {
+  const long ntile = (n + 63) / 64, nrun = ntile * (long)C;
+  const int sub = threadIdx.x >> 5, l2 = (threadIdx.x & 31) * 2;
+  const bool aligned = ((((uintptr_t)mat) & 15) == 0) && ((cs & 1) == 0);
+  for (long r = (long)blockIdx.x * 8 + sub; r < nrun; r += (long)gridDim.x * 8) {
+    const long t = r / C, c = r - t * C, b = 64 * t + l2;
+    double *m = mat + c * cs + b, *q = tiled + r * 64 + l2;
+    if (b + 1 < n && aligned) {
+      if (TO_TILED) __builtin_nontemporal_store(__builtin_nontemporal_load((const fdg_pair_d *)m), (fdg_pair_d *)q);
+      else __builtin_nontemporal_store(__builtin_nontemporal_load((const fdg_pair_d *)q), (fdg_pair_d *)m);
+    } else {
+      for (int k = 0; k < 2; ++k) if (b + k < n) { if (TO_TILED) q[k] = m[k]; else m[k] = q[k]; }
+    }
+  }
+}
+// Any other strides (row-major [B, C]: cs == 1) go through a 64 x 64 LDS tile: rows read / written along their columns (256-byte runs and
+// up), tile-major runs of 512 bytes on the other side.
+template <bool TO_TILED>
+__global__ void __launch_bounds__(256)
+fdg_repack_transpose(double *__restrict__ mat, long ss, long cs, double *__restrict__ tiled, long n, uint32_t C) {
+  __shared__ double tile[64][65];          // [column][row]
+  const int t = threadIdx.x;
+  const long ntile_s = (n + 63) / 64, ntile_c = ((long)C + 63) / 64;
+  for (long tid = blockIdx.x; tid < ntile_s * ntile_c; tid += gridDim.x) {
+    const long ts = tid / ntile_c, s0 = ts * 64, c0 = (tid % ntile_c) * 64;
+    if (TO_TILED) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const long row = s0 + k * 4 + t / 64, col = c0 + t % 64;
+        if (row < n && col < (long)C) tile[t % 64][k * 4 + t / 64] = __builtin_nontemporal_load(mat + row * ss + col * cs);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const long col = c0 + k * 4 + t / 64, row = s0 + t % 64;
+        if (row < n && col < (long)C) tiled[(ts * (long)C + col) * 64 + t % 64] = tile[k * 4 + t / 64][t % 64];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const long col = c0 + k * 4 + t / 64, row = s0 + t % 64;
+        if (row < n && col < (long)C) tile[k * 4 + t / 64][t % 64] = __builtin_nontemporal_load(tiled + (ts * (long)C + col) * 64 + t % 64);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const long row = s0 + k * 4 + t / 64, col = c0 + t % 64;
+        if (row < n && col < (long)C) mat[row * ss + col * cs] = tile[t % 64][k * 4 + t / 64];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Philox4x32-10 (Salmon et al., SC'11), key = seed, counter = (sample, leaf)
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -1890,22 +1950,28 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
   for (uint32_t bufs = pass == 0 ? 4u : first; bufs <= 4; ++bufs) {
     uint64_t best_cost = ~0ull, best_fetches = 0, best_gathers = 0, best_panel = 0;
     fdg::OptProgram cand;
-    for (int keep = 0; keep < 2; ++keep) {
+    // (round 6: each root order also with LEAVES LOADED ONCE -- fdg_opt.h: leaves_once -- so that a leaf is never fetched a second time through
+    //  its 8 KB chunk or a 64-line gather; FDG_RM_LEAVES_ONCE=0 / 1 forces one form)
+    const char *lo_env = fdg::knob("FDG_RM_LEAVES_ONCE");
+    for (int variant = 0; variant < 4; ++variant) {
+      const int keep = variant & 1, once = variant >> 1;
+      if (lo_env && (lo_env[0] == '1') != (once != 0)) continue;
       fdg::OptParams q = cfg_B();
       q.vn_window = chosen.vn_window;
       q.n_lds = 80u - bufs * 16u - 2u;                             // (two slots lost to the 1 KB alignment of the buffers)
       q.reserve_pairs = 5;
       q.lookahead_leaf = 48;
       if (const char *la = fdg::knob("FDG_ISA_RM_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
+      q.leaves_once = once != 0;
       q.keep_root_order = keep != 0;
       q.roots_last = true;             // the R stores of a row back to back: they share cache lines when the roots are row-major too (+7-11 %)
       build_prog(g, q, cand);
-      if (!cand.supported) { if (keep == 0 && pass == 1) return 0; continue; }
+      if (!cand.supported) { if (variant == 0 && pass == 1) return 0; continue; }
       uint64_t fetches = 0, gathers = 0;
       fdg::rm_plan_stats(g->prog, cand, bufs, fetches, gathers);
-      if (fdg::knob("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] one wave per SIMD (root order %d): %u chunks, %llu fetches, %llu gathers with %u buffers, %llu panel accesses, %llu LDS and %llu AGPR moves\n", keep, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, bufs, (unsigned long long)(cand.n_ld_mem + cand.n_st_mem),
+      if (fdg::knob("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] one wave per SIMD (root order %d, leaves once %d): %u chunks, %llu fetches, %llu gathers with %u buffers, %llu panel accesses, %llu LDS and %llu AGPR moves\n", keep, once, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, bufs, (unsigned long long)(cand.n_ld_mem + cand.n_st_mem),
                                                   (unsigned long long)(cand.n_ld_lds + cand.n_st_lds), (unsigned long long)(cand.n_ld_acc + cand.n_st_acc));
-      const uint64_t cost = fetches * 8192 + gathers * 2048 + (cand.n_ld_mem + cand.n_st_mem) * 1024;
+      const uint64_t cost = fetches * 8192 + gathers * 4096 + (cand.n_ld_mem + cand.n_st_mem) * 512;     // (a gather touches 64 lines for 64 doubles; a panel access is 512 bytes that stay in L2)
       if (cost < best_cost) { best_cost = cost; best_fetches = fetches; best_gathers = gathers; best_panel = cand.n_ld_mem + cand.n_st_mem; pr = std::move(cand); if (qsel) *qsel = q; }
     }
     const bool cheap = best_fetches * 4 <= (uint64_t)n_chunk * 5 + 4;
@@ -2735,6 +2801,37 @@ int fdg_copy_device(double *d_dst, const double *d_src, int64_t n, void *stream)
     hipLaunchKernelGGL(fdg_copy16, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const fdg_v2d *)d_src, (fdg_v2d *)d_dst, n16);
   HIP_TRY(hipGetLastError());
   return FDG_OK;
+}
+
+static int repack_launch(bool to_tiled, double *mat, int64_t ss, int64_t cs, double *tiled, int64_t n, uint32_t C, void *stream, const char *who) {
+  if (n < 0 || ss < 0 || cs < 0) { set_error(std::string(who) + ": negative size or stride"); return FDG_E_INVALID; }
+  if (n == 0 || C == 0) return FDG_OK;
+  if (!mat || !tiled) { set_error(std::string(who) + ": null device buffer"); return FDG_E_INVALID; }
+  if (((uintptr_t)tiled) & 15) { set_error(std::string(who) + ": the tile-major array must be 16-byte aligned"); return FDG_E_INVALID; }
+  int dev = 0, n_cu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+  const long ntile = (long)((n + 63) / 64);
+  if (ss == 1) {
+    const long nrun = ntile * (long)C;
+    const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((nrun + 7) / 8, (long)n_cu * 32));
+    if (to_tiled) hipLaunchKernelGGL(fdg_repack_runs<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, mat, (long)cs, tiled, (long)n, C);
+    else hipLaunchKernelGGL(fdg_repack_runs<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, mat, (long)cs, tiled, (long)n, C);
+  } else {
+    const long nt = ntile * (((long)C + 63) / 64);
+    const unsigned grid = (unsigned)std::max<long>(1, std::min<long>(nt, (long)n_cu * 16));
+    if (to_tiled) hipLaunchKernelGGL(fdg_repack_transpose<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, mat, (long)ss, (long)cs, tiled, (long)n, C);
+    else hipLaunchKernelGGL(fdg_repack_transpose<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, mat, (long)ss, (long)cs, tiled, (long)n, C);
+  }
+  HIP_TRY(hipGetLastError());
+  return FDG_OK;
+}
+
+int fdg_repack_tile_major(const double *d_src, int64_t sample_stride, int64_t col_stride, double *d_tiled, int64_t n_sample, uint32_t n_col, void *stream) {
+  return repack_launch(true, const_cast<double *>(d_src), sample_stride, col_stride, d_tiled, n_sample, n_col, stream, "fdg_repack_tile_major");
+}
+
+int fdg_unpack_tile_major(const double *d_tiled, double *d_dst, int64_t sample_stride, int64_t col_stride, int64_t n_sample, uint32_t n_col, void *stream) {
+  return repack_launch(false, d_dst, sample_stride, col_stride, const_cast<double *>(d_tiled), n_sample, n_col, stream, "fdg_unpack_tile_major");
 }
 
 int fdg_read_device(const double *d_src, int64_t n, double *d_sink, void *stream) {

@@ -253,10 +253,24 @@ batch_free(p::Ptr{Cvoid}) = _fdg_check(ccall((:fdg_batch_free, _libfdg), Cint, (
 # layout = :leaf_major: a Julia Matrix pair B' x L / B' x R (B' = 64 * the info's chunk_tiles), for batches of up to a few tens of GB; :row_major: compile_Python's.
 function batch_alloc_pair(f::GraphFunc, n_sample::Integer; chunk_bytes::Integer=0, calibrate::Bool=true, layout::Symbol=:tile_major)
     dl = Ref{Ptr{Cvoid}}(C_NULL); dr = Ref{Ptr{Cvoid}}(C_NULL)
-    info = zeros(UInt8, 128)                 # fdg_batch_pair_info (112 bytes)
+    info = zeros(UInt8, 128)                 # fdg_batch_pair_info (120 bytes; the last two UInt32: level_reached -- 3 the full search, 2 a span cut
+                                             # short by the free memory, 1 mapped in draw order, 0 not calibrated -- and span_gb)
     _fdg_check(ccall((:fdg_batch_alloc_pair, _libfdg), Cint, (Ptr{Cvoid}, Int64, Csize_t, Cuint, Ref{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}, Ptr{UInt8}),
         f.handle, n_sample, chunk_bytes, Cuint((calibrate ? 1 : 0) | (layout == :row_major ? 8 : 0) | (layout == :leaf_major ? 16 : 0)), dl, dr, info))
     return Ptr{Float64}(dl[]), Ptr{Float64}(dr[]), info
+end
+
+# tile_major!(d_tiled, d_src, B, C; strides): a device matrix in one of the reference's layouts -- a Julia column-major B x C Matrix{Float64}
+# (strides = (1, B), the default) or compile_Python's row-major [B, C] (strides = (C, 1)) -- into the tile-major Array{Float64,3}(64, C, cld(B, 64))
+# that eval_device_tiled! takes; from_tile_major! is the way back (roots).  One pass at copy speed each (fdg_repack_tile_major / fdg_unpack_tile_major):
+# worth it for a batch that is evaluated several times; a producer that can write tile-major itself (the fused Monte-Carlo step does) should.
+function tile_major!(d_tiled::Ptr{Float64}, d_src::Ptr{Float64}, B::Integer, C::Integer; strides=(1, B), stream::Ptr{Cvoid}=C_NULL)
+    _fdg_check(ccall((:fdg_repack_tile_major, _libfdg), Cint, (Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, UInt32, Ptr{Cvoid}),
+        d_src, strides[1], strides[2], d_tiled, B, UInt32(C), stream))
+end
+function from_tile_major!(d_dst::Ptr{Float64}, d_tiled::Ptr{Float64}, B::Integer, C::Integer; strides=(1, B), stream::Ptr{Cvoid}=C_NULL)
+    _fdg_check(ccall((:fdg_unpack_tile_major, _libfdg), Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, UInt32, Ptr{Cvoid}),
+        d_tiled, d_dst, strides[1], strides[2], B, UInt32(C), stream))
 end
 
 # Options of a handle (what used to be FDG_* environment switches; the library reads the environment once per process): set_option!(f, "FDG_ISA_NO_POOL", "1")
@@ -273,7 +287,7 @@ function accumulate_device!(f::GraphFunc, d_acc::Ptr{Float64}, d_leaf::Ptr{Float
         f.handle, d_leaf, leaf_strides[1], leaf_strides[2], d_weight, d_acc, B, stream))
 end
 
-export compile_hip, GraphFunc, eval_device!, accumulate_device!, eval_device_tiled!, accumulate_device_tiled!, batch_alloc, batch_free
+export compile_hip, GraphFunc, eval_device!, accumulate_device!, eval_device_tiled!, accumulate_device_tiled!, batch_alloc, batch_free, tile_major!, from_tile_major!
 
 # ---- multi-GPU: one Julia process per GPU, ONE reduction of the accumulated observable ------------ #
 # (include/fdg.h, "multi-GPU").  Rank 0 calls `comm_unique_id()` and ships the 128 bytes to the other

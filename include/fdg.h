@@ -353,6 +353,19 @@ int fdg_fill_uniform_device_tiled(double *d_leaf, int64_t n_sample, uint32_t n_l
                                   int64_t leaf_leaf_stride, int64_t leaf_tile_stride, uint64_t seed, uint64_t sample_offset,
                                   void *stream);
 
+/* A matrix in one of the reference's layouts -> the tile-major batch, and back (round 6).  d_tiled is (64, n_col, cld(n_sample, 64)) as
+ * fdg_eval_device_tiled takes it; the matrix is m[b * sample_stride + c * col_stride]: a Julia column-major B x C Matrix{Float64} is
+ * (1, B) -- its 512-byte runs are copied as they are --, compile_Python's row-major [B, C] is (C, 1) -- 64 x 64 tiles through LDS.  One pass
+ * at copy speed (read + written 5-6 TB/s): 2.3 x the time of ONE evaluation of the headline graph over the same batch, so it pays for a
+ * batch that is evaluated several times, or when the producer of the leaves cannot write tile-major itself (fdg_leaf_eval_device_tiled
+ * and the fused Monte-Carlo step do); DESIGN.md 6f has the measured cost.  Lanes past n_sample of the last tile are not written.
+ * Stands in for nothing in the reference (its batched layout is compile_Python's [B, L], compiler_python.jl:23,28,45-47); the Julia shim
+ * exposes them as tile_major!(dst, src) / from_tile_major!(dst, src). */
+int fdg_repack_tile_major(const double *d_src, int64_t sample_stride, int64_t col_stride, double *d_tiled, int64_t n_sample,
+                          uint32_t n_col, void *stream);
+int fdg_unpack_tile_major(const double *d_tiled, double *d_dst, int64_t sample_stride, int64_t col_stride, int64_t n_sample,
+                          uint32_t n_col, void *stream);
+
 /* Device memory for a sample batch, backed explicitly (HIP virtual-memory management: one reserved address range, physical
  * chunks of chunk_bytes created and mapped in address order; chunk_bytes 0 = one physical allocation for the whole batch) instead
  * of by whatever state the driver's allocator is in when hipMalloc is called -- how a batch of tens of GB is backed decides
@@ -368,10 +381,14 @@ int fdg_batch_free(void *d_ptr);
  * pages under that piece AND under the roots it writes: device memory falls into regions of two kinds, and reading one kind while writing
  * the same kind runs 10-12 % slower than the mixed combination (fused accumulation, which writes no roots, does not care).  Physical
  * addresses are invisible to a process; the rate is not.  With FDG_BATCH_PAIR_CALIBRATE the allocator maps the leaves in chunks of about
- * chunk_bytes_hint (0: 1 GB; rounded so that a chunk holds whole tiles of both arrays in whole mapping granules), draws more root chunks
- * than it needs, times the handle's own evaluator on (leaf chunk, root chunk) pairs -- about a millisecond per pair -- and maps behind every
- * leaf chunk a root chunk that gives the fast rate; what it drew and did not use goes back to the driver.  Without the flag the chunks are
- * mapped in the order they were drawn (the A/B case).  Both arrays hold whole chunks (>= the T tiles asked for); release each with
+ * chunk_bytes_hint (0: 2 GB; rounded so that a chunk holds whole tiles of both arrays in whole mapping granules), draws more root chunks
+ * than it needs -- from an 80 GB span of the device memory, or as much of it as is free beyond what the batch itself needs --, times the
+ * handle's own evaluator on (leaf chunk, root chunk) pairs -- about a millisecond per pair -- and maps behind every leaf chunk the fastest
+ * unused root chunk, drawing more while even the best is more than 3.5 % below the best pair seen (three levels were measured: 0.855 /
+ * 0.80 / 0.765 of 8 TB/s on the headline graph; nothing is assumed about their number); what it drew and did not use goes back to the
+ * driver.  When memory is short the search shrinks instead of failing (info->level_reached).  Monte-Carlo callers that only ACCUMULATE
+ * (fdg_accumulate_device_tiled: no root is written) gain nothing from the pairing -- 0.89 of 8 TB/s on any allocation -- and should skip the
+ * 7-9 s: allocate without the flag.  Without the flag the chunks are mapped in the order they were drawn (the A/B case).  Both arrays hold whole chunks (>= the T tiles asked for); release each with
  * fdg_batch_free.  `info` (may be NULL) reports what was found.  Needs a handle specialised with FDG_SPEC_ISA and the current device.
  * No counterpart in the reference (its leaf vector and root vector are Julia Vectors on the host, static.jl:100,131). */
 #define FDG_BATCH_PAIR_CALIBRATE 1u
@@ -389,12 +406,17 @@ typedef struct fdg_batch_pair_info {
   uint32_t n_filler;                 /* 2 GB allocations held for a while to make the driver hand out other regions (released) */
   uint32_t n_probe;                  /* timed (leaf chunk, root chunk) pairs */
   uint32_t n_matched;                /* chunk pairs within 5 % of the best pair timed, as mapped */
-  uint32_t calibrated;               /* 0: calibration off or no contrast between candidates found (nothing to choose) */
-  double gbs_fast, gbs_slow;         /* the two levels (algorithmic GB/s of one chunk's launch) between which the threshold was put */
+  uint32_t calibrated;               /* 1: the candidates differed by more than 5 % (there was something to choose); 0: calibration off or no contrast */
+  double gbs_fast, gbs_slow;         /* the best and the worst pair timed (algorithmic GB/s of one chunk's launch); "fast level" = within 3.5 % of gbs_fast */
   double gbs_before_mean, gbs_before_min;   /* chunk pairs as an uncalibrated mapping would have made them */
   double gbs_after_mean, gbs_after_min;     /* chunk pairs as mapped */
   double seconds;                    /* wall time of the call */
   double seconds_settling;           /* ... of which: waiting for the driver's background wipe of released memory to end */
+  uint32_t level_reached;            /* how far the search got (round 6: it degrades, it does not fail, when memory is short).  0: no calibration (not asked
+                                      * for, or windows too small to time); 1: asked for, but the leaves only fitted once every candidate had been given
+                                      * back: mapped in draw order; 2: calibrated over a span of the memory cut short by what was free (the best pairs
+                                      * found within it); 3: the full search */
+  uint32_t span_gb;                  /* GB of fillers the candidates were drawn behind (80 at first, up to 144 more while the best pair seen is below par) */
 } fdg_batch_pair_info;
 int fdg_batch_alloc_pair(fdg_graph *g, int64_t n_sample, size_t chunk_bytes_hint, unsigned flags, void **d_leaf, void **d_root,
                          fdg_batch_pair_info *info);

@@ -3,6 +3,7 @@
 fdg_batch_alloc_pair is how bench.py's headline batch is allocated since round 5: the leaves one plain allocation, the roots mapped
 chunk by chunk behind leaf windows, each chunk chosen by TIMING the handle's own kernel on (leaf window, root chunk) pairs
 (DESIGN.md 6a).  Whatever it maps, the values must be the bits every other batch gives."""
+import os
 import numpy as np
 import pytest
 
@@ -242,3 +243,48 @@ def test_the_allocators_search_on_a_model_of_the_memory(libfdg, scenario):
         top = libfdg.fdg_selftest_pair_search(seed, scenario, 32, C.byref(n))
         assert top == 32, (scenario, seed, top)
         assert 32 <= n.value <= (400 if scenario in (0, 3) else 4000)       # a few probes per window when the candidates are there
+
+
+def test_pair_info_reports_how_far_the_search_got(libfdg):
+    """fdg_batch_pair_info (round 6): level_reached / span_gb appended; the Julia shim's 128-byte buffer still holds it."""
+    import ctypes as C
+    names = [n for n, _ in capi.BatchPairInfo._fields_]
+    assert names[-2:] == ["level_reached", "span_gb"] and C.sizeof(capi.BatchPairInfo) == 120 <= 128
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fdg.h")).read()
+    body = hdr[hdr.index("typedef struct fdg_batch_pair_info"):hdr.index("} fdg_batch_pair_info;")]
+    assert body.index("seconds_settling") < body.index("level_reached") < body.index("span_gb")
+
+
+@pytest.mark.gpu
+def test_paired_allocator_degrades_when_memory_is_short(libfdg, cuda):
+    """VERDICT r5 item 7 / ADVICE r5 (medium): with only the batch + ~10 GB free, the calibrated allocation must still return a batch -- a shorter
+    span of candidates, or, when even that does not fit, the batch mapped in draw order -- and say so in level_reached; results are unchanged."""
+    import torch
+    t = workloads.get("parquet_sigma4")
+    L, R = t.n_leaf, t.n_root
+    f = fd.compile_table(t, specialize="isa")
+    B = 6_000_000                                              # 4 GB of leaves: two windows, calibration on
+    need = 8 * B * (L + R)
+    torch.cuda.empty_cache()
+    free_b, _total = torch.cuda.mem_get_info(cuda)
+    keep = need + (10 << 30)
+    if free_b < keep + (4 << 30):
+        pytest.skip("not enough free memory to set the scene")
+    ballast = [torch.empty((free_b - keep) // 4 // 8, dtype=torch.float64, device=cuda) for _ in range(4)]      # everything but batch + 10 GB
+    try:
+        pb = f.tile_major_pair(B, cuda, calibrate=True)
+        try:
+            assert pb.info["level_reached"] in (1, 2, 3) and pb.info["n_chunk"] >= 2
+            assert pb.info["span_gb"] <= 12                    # nowhere near the 80 GB a free device would give
+            st = torch.cuda.current_stream().cuda_stream
+            capi.fill_uniform_device_tiled(pb.leaf.data_ptr(), B, L, 1, 64, 64 * L, 77, 0, st)
+            f.eval_tiled(pb.root, pb.leaf, B)
+            n = 2048
+            got = from_tiles(pb.root[:n // 64].cpu().numpy(), n, R)
+            want = oracle.eval_static(t, from_tiles(pb.leaf[:n // 64].cpu().numpy(), n, L))
+            assert np.array_equal(got, want)
+        finally:
+            pb.free()
+    finally:
+        del ballast
+        torch.cuda.empty_cache()

@@ -291,3 +291,51 @@ def test_leaves_from_K_T_into_a_tile_major_batch(libfdg, cuda, monkeypatch, B, g
     assert torch.equal(root.permute(0, 2, 1).reshape(-1, R)[:B], want)
     with pytest.raises(capi.FdgError):
         capi.leaf_eval_device_tiled(*args, kF, beta, lam, dK.data_ptr(), 1, B, dT.data_ptr(), 1, B, tiled.data_ptr(), 1, 64, 0, B, st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C", [(64, 4), (4099, 84), (1000, 1), (130, 67), (20011, 16)])
+def test_repack_tile_major_round_trip(libfdg, cuda, B, C):
+    """fdg_repack_tile_major / fdg_unpack_tile_major (round 6; the Julia shim's tile_major! / from_tile_major!): a Julia column-major
+    B x C matrix (512-byte runs copied as they are), compile_Python's row-major [B, C] (64 x 64 tiles through LDS) and a row-major
+    matrix with padded rows all give the tile-major array of to_tiles(); lanes past B are left alone; the way back restores the matrix."""
+    import torch
+    rng = np.random.default_rng(B * 131 + C)
+    x = rng.standard_normal((B, C))
+    want = to_tiles(x)
+    T = (B + 63) // 64
+    srcs = {"row_major": torch.from_numpy(x).to(cuda),
+            "col_major": torch.from_numpy(np.ascontiguousarray(x.T)).to(cuda).t(),
+            "padded_rows": torch.from_numpy(np.concatenate([x, np.full((B, 3), 7.0)], axis=1)).to(cuda)[:, :C],
+            "odd_column_stride": torch.from_numpy(np.concatenate([x.T, np.full((C, 1), 7.0)], axis=1).copy()).to(cuda)[:, :B].t()}
+    for name, src in srcs.items():
+        assert tuple(src.shape) == (B, C)
+        dst = torch.full((T, C, 64), float("nan"), dtype=torch.float64, device=cuda)
+        fd.GraphFunc.tile_major_(dst, src)
+        got = dst.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want)), name
+        assert np.array_equal(got[~np.isnan(want)], want[~np.isnan(want)]), name
+        back = torch.empty_strided(src.size(), src.stride(), dtype=torch.float64, device=cuda).fill_(5.0)       # the same layout as the source
+        fd.GraphFunc.from_tile_major_(back, dst)
+        assert np.array_equal(back.cpu().numpy(), x), name
+
+
+@pytest.mark.gpu
+def test_repacked_batch_evaluates_to_the_same_bits(libfdg, cuda):
+    """A leaf-major and a row-major matrix repacked with tile_major_ and evaluated tile-major give the bits of the in-place evaluation,
+    and the roots unpacked with from_tile_major_ those of the reference's [B, R]."""
+    import torch
+    t = workloads.get("parquet_sigma4")
+    f = fd.compile_table(t, specialize="isa")
+    B, L, R = 70_001, t.n_leaf, t.n_root
+    leaf = torch.empty((B, L), dtype=torch.float64, device=cuda)
+    capi.fill_uniform_device(leaf.data_ptr(), B, L, L, 1, 99, 0, torch.cuda.current_stream().cuda_stream)
+    want = f(None, leaf)
+    for src in (leaf, leaf.t().contiguous().t()):
+        tl = fd.GraphFunc.tile_major_(None, src)
+        tr = f.eval_tiled(None, tl, B)
+        root = torch.empty((B, R), dtype=torch.float64, device=cuda)
+        fd.GraphFunc.from_tile_major_(root, tr)
+        assert torch.equal(root, want)
+    n = 3000
+    assert np.array_equal(want[:n].cpu().numpy(), oracle.eval_static(t, leaf[:n].cpu().numpy()))
