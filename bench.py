@@ -68,6 +68,7 @@ DEFAULT_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcas
              "parquet_sigma4_dyn_taylor2": 2_000_000, "parquet_sigma4_insdyn_taylor2": 1_000_000, "parquet_sigma5": 2_000_000,
              "parquet_ver4_4": 512_000, "gv_ver4_4": 512_000}          # (whole 64-sample tiles: the pooled cooperative kernel takes full tiles)
 PAIR_ALL = False         # --pair-all (experiment): every tile-major / row-major secondary row through fdg_batch_alloc_pair
+POWER_LEG_S = 0.9        # seconds of back-to-back launches per secondary row under rocm-smi (--power-seconds; 0: off)
 PAIRED_ROWS = {("parquet_sigma4", "tile_major"), ("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "tile_major"), ("sigma2", "tile_major"),
                ("gv_sigma4", "tile_major"), ("gv_sigma4_taylor2", "tile_major")}
 PARITY_NOTE = ("bit-exact vs our restatement of the Julia evaluator (oracle/); the reference's known-answer tests pin structure, "
@@ -509,10 +510,14 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
         from feynmandiagram_jl_amd import capi
         fma = layout.endswith("+fma")
         plain = layout.endswith("@plain")        # the headline's workload at the headline's size on a PLAIN allocation (what hipMalloc hands out)
-        lay = layout[:-4] if fma else (layout[:-6] if plain else layout)
+        # "@1e8" / "@1e8*" (round 6): the reference's own layouts -- a Julia column-major B x L Matrix, compile_Python's row-major
+        # [B, L] -- at the HEADLINE's batch size, on a plain allocation / through fdg_batch_alloc_pair
+        full_plain, full_paired = layout.endswith("@1e8"), layout.endswith("@1e8*")
+        lay = layout[:-4] if (fma or full_plain) else (layout[:-6] if plain else (layout[:-5] if full_paired else layout))
         # the memory-bound graphs with root stores get their batch from the library's allocator (fdg_batch_alloc_pair), as the headline does
-        paired = ((workload, lay) in PAIRED_ROWS or (PAIR_ALL and lay in ("tile_major", "sample_major", "leaf_major"))) and not plain and not fma
-        c = Case(workload, lay, DEFAULT_B[workload] if plain else (16_000_000 if workload == "parquet_sigma4" else DEFAULT_B.get(workload, 1_000_000)), dev,
+        paired = (((workload, lay) in PAIRED_ROWS or (PAIR_ALL and lay in ("tile_major", "sample_major", "leaf_major"))) and not plain and not fma and not full_plain) or full_paired
+        big = plain or full_plain or full_paired
+        c = Case(workload, lay, DEFAULT_B[workload] if big else (16_000_000 if workload == "parquet_sigma4" else DEFAULT_B.get(workload, 1_000_000)), dev,
                  flags=capi.FDG_SPEC_FAST_MATH if fma else 0, placement="paired" if paired else "plain")
         settle_after_free(c.nbytes())        # (by the clock: whatever was released to make room for this batch is being wiped)
         c.settle()                           # (by the kernel's own rate)
@@ -527,7 +532,17 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
             want = oracle.eval_static(c.t, h_leaf)
             dev_over_sk = float(np.max(np.abs(c.head(c.root, n) - want) / np.maximum(1.0, oracle.root_scale(c.t, h_leaf))))
         kern, ops_exec = kernel_of(c.f)
-        roof = roofline_of(c.st, c.B, avg, kern, ops_exec=ops_exec, clock_ghz=c.clock_ghz)
+        # socket power and shader clock from rocm-smi while the row's launch runs back to back (after its timed launches).  The sleeping-wave probe
+        # reads the clock of the ONE XCD it landed on and disagreed with rocm-smi on the ridge rows (gv_sigma5 tile-major 2.40 GHz against
+        # 1655 MHz): rocm-smi's figure is the row's clock_ghz, the probe's stays in the detail file as clock_ghz_probe
+        pw = power_leg(c.step, seconds=POWER_LEG_S) if POWER_LEG_S > 0 else None
+        smi_ghz = pw["sclk_mhz"] / 1e3 if pw and pw.get("sclk_mhz") else None
+        roof = roofline_of(c.st, c.B, avg, kern, ops_exec=ops_exec, clock_ghz=smi_ghz or c.clock_ghz)
+        roof["clock_source"] = "rocm-smi sclk" if smi_ghz else ("sleeping-wave probe" if c.clock_ghz else None)
+        if c.clock_ghz:
+            roof["clock_ghz_probe"] = c.clock_ghz
+        if pw:
+            roof.update({"power_w": pw["power_w"], "sclk_mhz": pw.get("sclk_mhz"), "power_cap_w": pw.get("power_cap_w"), "power_samples": pw["samples"]})
         attach_traffic(roof, workload, lay, c.B, avg)
         if copy_gbs:
             roof["frac_of_measured_copy"] = roof["achieved"] / copy_gbs
@@ -546,6 +561,44 @@ def secondary_case(workload, layout, dev, steps=20, warm=30, copy_gbs=None):
             out["contracted"] = True
             out["max_dev_over_Sk"] = dev_over_sk
             out["gpu_matches_cpu_bitwise"] = None if not ok else True      # (not a claim of this mode; BASELINE's bar is 1e-12 of S_k)
+        if full_plain and lay in ("leaf_major", "sample_major"):
+            # what tile_major! costs (fdg_repack_tile_major: one pass at copy speed) and what the same batch then runs at tile-major, on a plain allocation
+            try:
+                import feynmandiagram_jl_amd as fd
+                T = (c.B + 63) // 64
+                tl = torch.empty((T, c.t.n_leaf, 64), dtype=torch.float64, device=dev)
+                tr = torch.zeros((T, c.t.n_root, 64), dtype=torch.float64, device=dev)
+                for _ in range(2):
+                    fd.GraphFunc.tile_major_(tl, c.leaf)
+                sync()
+                rp = Stamps(5, c.stream)
+                rp.record(0)
+                for i in range(5):
+                    fd.GraphFunc.tile_major_(tl, c.leaf)
+                    rp.record(i + 1)
+                sync()
+                rp_ms = sum(rp.ms()) / 5
+                for _ in range(30):
+                    c.f.eval_tiled(tr, tl, c.B)
+                sync()
+                ev2 = Stamps(steps, c.stream)
+                ev2.record(0)
+                for i in range(steps):
+                    c.f.eval_tiled(tr, tl, c.B)
+                    ev2.record(i + 1)
+                sync()
+                ev_ms = sum(ev2.ms()) / steps
+                back = torch.empty_strided(c.root.size(), c.root.stride(), dtype=torch.float64, device=dev)
+                fd.GraphFunc.from_tile_major_(back, tr)
+                same = bool(torch.equal(back, c.root))
+                out["repack"] = {"what": "fdg_repack_tile_major of this batch's leaves (GraphFunc.tile_major_ / Julia tile_major!), then fdg_eval_device_tiled on the result (plain allocation), roots back through fdg_unpack_tile_major",
+                                 "repack_ms": rp_ms, "repack_gbs_read_plus_written": 2 * 8 * c.B * c.t.n_leaf / (rp_ms * 1e-3) / 1e9,
+                                 "eval_tiled_ms": ev_ms, "eval_tiled_frac_hbm": c.st["bytes_alg"] * c.B / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "in_place_ms": avg * 1e3, "evaluations_to_amortise": (rp_ms / max(avg * 1e3 - ev_ms, 1e-9)) if avg * 1e3 > ev_ms else None,
+                                 "roots_equal_in_place_bits": same}
+                del tl, tr, back
+            except Exception as e:
+                out["repack"] = {"error": f"{type(e).__name__}: {e}"}
         freed = c.nbytes()
         c.free()
         del c
@@ -618,13 +671,22 @@ def config5(dev, rank, world, dist, comm, steps, warm):
             sh = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
             dist.all_gather(sh, torch.tensor([start, count], dtype=torch.int64, device=dev))
             shards = [[int(x[0]), int(x[1])] for x in sh]
+        observable = [float(x) for x in acc.cpu()]
         kern, ops_exec = kernel_of(c.f)
-        roof = roofline_of(c.st, count, avg, kern + " + fdg_reduce_lane_partials", accumulate=True, ops_exec=ops_exec, clock_ghz=probe_stop(probe))
+        probe_ghz = probe_stop(probe)
+        pw = power_leg(lambda: c.accumulate(w, acc), seconds=POWER_LEG_S) if (POWER_LEG_S > 0 and world == 1) else None      # (after the timed region; acc is dead by then)
+        smi_ghz = pw["sclk_mhz"] / 1e3 if pw and pw.get("sclk_mhz") else None
+        roof = roofline_of(c.st, count, avg, kern + " + fdg_reduce_lane_partials", accumulate=True, ops_exec=ops_exec, clock_ghz=smi_ghz or probe_ghz)
+        roof["clock_source"] = "rocm-smi sclk" if smi_ghz else ("sleeping-wave probe" if probe_ghz else None)
+        if probe_ghz:
+            roof["clock_ghz_probe"] = probe_ghz
+        if pw:
+            roof.update({"power_w": pw["power_w"], "sclk_mhz": pw.get("sclk_mhz"), "power_cap_w": pw.get("power_cap_w"), "power_samples": pw["samples"]})
         out = {"workload": "gv_sigma5" + WORKLOAD_NOTES["gv_sigma5"], "value": total / elapsed, "unit": "samples/s (whole job)", "n_gpus": world,
                "steps": steps, "warmup": warm, "samples_per_step_per_gpu": count, "total_samples": total,
                "shard_offset_rank0": start, "shards_of_a_step": shards, "baseline_total_samples": CONFIG5_TOTAL_SAMPLES,
                "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "roofline_rank0": roof,
-               "observable": [float(x) for x in acc.cpu()],
+               "observable": observable,
                "layout": "tile_major", "what": "fdg_accumulate_device_tiled per step on the rank's shard (tile-major batch); one all-reduce of R doubles after the last step, inside the timed region"}
         freed = c.nbytes()
         c.free()
@@ -671,13 +733,15 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the other workloads (config 2, 3 stand-ins, 5, row-major layout) measured after the headline")
     ap.add_argument("--secondary", default="", help="comma-separated workload:layout pairs to measure after the headline instead of the full list")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--power-seconds", type=float, default=0.9, help="per secondary row: seconds of back-to-back launches sampled with rocm-smi (socket power, sclk); 0 = off")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device work: one process per rank on the CPU (gloo), the evaluator replaced by a stub that adds the shard's "
                          "sample count to the accumulator; checks sharding, the one collective and the stdout line (tests/test_bench_line.py)")
     args = ap.parse_args()
-    global DRY, PAIR_ALL
+    global DRY, PAIR_ALL, POWER_LEG_S
     DRY = bool(args.dry_run)
     PAIR_ALL = bool(args.pair_all)
+    POWER_LEG_S = float(args.power_seconds)
 
     import numpy as np
     import torch
@@ -889,7 +953,8 @@ def main():
         if rank == 0 and world == 1 and not DRY:
             sec = []
             head = (args.workload, args.layout)
-            full = ((args.workload, "tile_major@plain"), ("parquet_sigma4", "tile_major"), ("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "tile_major"),
+            full = ((args.workload, "tile_major@plain"), ("parquet_sigma4", "leaf_major@1e8"), ("parquet_sigma4", "sample_major@1e8"), ("parquet_sigma4", "sample_major@1e8*"),
+                    ("parquet_sigma4", "tile_major"), ("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "tile_major"),
                     ("parquet_sigma4_insdyn", "tile_major"), ("parquet_sigma4_taylor2", "tile_major"), ("parquet_sigma4_taylor2", "leaf_major"), ("parquet_sigma4_taylor2", "tile_major+fma"),
                     ("parquet_sigma5", "tile_major"), ("parquet_ver4_4", "tile_major"), ("gv_ver4_4", "tile_major"), ("gv_ver4_4", "leaf_major"), ("sigma2", "tile_major"), ("sigma4_standin", "leaf_major"), ("gv_sigma4", "tile_major"),
                     ("gv_sigma5", "tile_major"), ("gv_sigma5", "leaf_major"), ("gv_sigma5", "tile_major+fma"),
@@ -899,6 +964,8 @@ def main():
                 #  row-major row of parquet_sigma4 then has its leaf-major partner at the same 1.6e7 samples, in the same process)
                 if lay.endswith("@plain") and not (paired and wl in DEFAULT_B and 8 * DEFAULT_B[wl] * (t.n_leaf + t.n_root) < 0.45 * torch.cuda.mem_get_info(dev)[0]):
                     continue            # (the plain-allocation partner of a paired headline only)
+                if "@1e8" in lay and not (wl in DEFAULT_B and 8 * DEFAULT_B[wl] * (t.n_leaf + t.n_root) < 0.45 * torch.cuda.mem_get_info(dev)[0]):
+                    continue            # (the headline-sized rows need the headline's memory)
                 if (wl, lay) != head or (not args.secondary and wl == "parquet_sigma4" and B != 16_000_000):
                     sec.append(secondary_case(wl, lay, dev, copy_gbs=copy_gbs))
             out["secondary"] = sec
@@ -955,18 +1022,30 @@ def compact_line(full):
                                 "sample": str(cb.get("sample", ""))[:110], "gpu_matches_cpu_bitwise": cb.get("gpu_matches_cpu_bitwise")}
     sec = full.get("secondary")
     if sec:
-        line["secondary_cols"] = ["workload", "layout", "Mevals_per_s", "bound", "frac", "frac_hbm", "frac_valu", "traffic_ratio", "bitwise", "clock_ghz", "frac_power"]
+        # (sclk_ghz / power_w: rocm-smi next to the row's own launches, round 6; the self-calibrated frac_power of round 5 stays in bench_detail.json as a diagnostic)
+        line["secondary_cols"] = ["workload", "layout", "Mevals_per_s", "bound", "frac", "frac_hbm", "frac_valu", "traffic_ratio", "bitwise", "sclk_ghz", "power_w"]
         rows = []
         for e in sec:
             if "error" in e:
                 rows.append([e.get("workload", "?")[:24], e.get("layout"), None, "error", None, None, None, None, False, None, None])
                 continue
             r = e["roofline"]
-            rows.append([e["workload"].split(" ")[0], {"leaf_major": "lm", "sample_major": "rm", "tile_major": "tm", "tile_major+fma": "tm+fma", "leaf_major+fma": "lm+fma", "tile_major@plain": "tm@plain"}.get(e["layout"], e["layout"]) + ("*" if e.get("placement") == "fdg_batch_alloc_pair" else ""), _r(e["value"] / 1e6),
+            lay_short = e["layout"].rstrip("*")
+            for long_, short_ in (("leaf_major", "lm"), ("sample_major", "rm"), ("tile_major", "tm")):
+                lay_short = lay_short.replace(long_, short_)
+            rows.append([e["workload"].split(" ")[0], lay_short + ("*" if e.get("placement") == "fdg_batch_alloc_pair" else ""), _r(e["value"] / 1e6),
                          {"hbm": "hbm", "valu_fp64": "valu"}.get(r["bound"], r["bound"]), _r(r["frac"], 3), _r(r.get("frac_hbm"), 3),
                          _r(r.get("frac_valu"), 3), _r(r.get("traffic_over_algorithmic"), 3),
-                         (e.get("gpu_matches_cpu_bitwise") if not e.get("contracted") else "fma:%.1e" % (e.get("max_dev_over_Sk") or 0.0)), _r(r.get("clock_ghz"), 3), _r(r.get("frac_power"), 2)])
+                         (e.get("gpu_matches_cpu_bitwise") if not e.get("contracted") else "fma:%.0e" % (e.get("max_dev_over_Sk") or 0.0)),
+                         _r(r.get("clock_ghz"), 3), (int(round(r["power_w"])) if r.get("power_w") else None)])
         line["secondary"] = rows
+    rp = {}
+    for e in (sec or []):
+        r = e.get("repack") if isinstance(e, dict) else None
+        if r and "error" not in r:
+            rp["lm" if e["layout"].startswith("leaf_major") else "rm"] = [_r(r["repack_ms"], 3), _r(r["eval_tiled_frac_hbm"], 3), _r(r["evaluations_to_amortise"], 3)]
+    if rp:
+        line["tile_major_repack@1e8"] = dict(rp, cols=["repack_ms", "frac_hbm_tile_major_after", "evaluations_to_amortise"])
     c5 = full.get("config5")
     if c5:
         if "error" in c5:
@@ -975,7 +1054,8 @@ def compact_line(full):
             r = c5.get("roofline_rank0", {})
             line["config5"] = {"workload": "gv_sigma5", "value": _r(c5["value"], 5), "unit": "samples/s", "n_gpus": c5["n_gpus"], "total_samples": c5["total_samples"],
                                "steps": c5["steps"], "bound": r.get("bound"), "frac": _r(r.get("frac"), 3), "frac_hbm": _r(r.get("frac_hbm"), 3),
-                               "frac_valu": _r(r.get("frac_valu"), 3), "clock_ghz": _r(r.get("clock_ghz"), 3), "frac_power": _r(r.get("frac_power"), 3)}
+                               "frac_valu": _r(r.get("frac_valu"), 3), "sclk_ghz": _r(r.get("clock_ghz"), 3), "frac_power": _r(r.get("frac_power"), 3),
+                               "power_w": (int(round(r["power_w"])) if r.get("power_w") else None)}
     ac = full.get("accumulate")
     if ac:
         line["accumulate"] = ({"error": ac["error"][:80]} if "error" in ac else
@@ -988,7 +1068,7 @@ def compact_line(full):
     line["detail"] = "bench_detail.json"
     text = json.dumps(line, separators=(",", ":"))
     # never let the line outgrow the driver's capture: drop the optional parts, least important first
-    for k in ("mc_step", "accumulate", "secondary", "secondary_cols", "config5"):
+    for k in ("tile_major_repack@1e8", "mc_step", "accumulate", "secondary", "secondary_cols", "config5"):
         if len(text) <= LINE_LIMIT:
             break
         line.pop(k, None)

@@ -335,6 +335,7 @@ struct Emit {
   int shift = 0;              // dev: FDG_ISA_SHIFT=n puts n s_nop at the head of every kernel (how much does the mere position matter?)
   uint64_t n_align_nop = 0;
   bool streaming = false;     // the kernel being printed is the variant for line-aligned batches: non-temporal leaf loads and root stores
+  long nt_dist = -1;          // streaming kernels of long programs: a re-loaded leaf's earlier load is non-temporal too when the re-load is this many leaf loads away (-1: never)
   uint64_t n_auto_nop = 0;
   uint64_t vm_issued = 0, lg_issued = 0, vm_done = 0, lg_done = 0;
   bool no_vm_wait = false;    // FDG_ISA_DEBUG=novmwait (timing experiment, results are garbage): no wait for a load's data -- what a wave whose loads always
@@ -345,8 +346,13 @@ struct Emit {
   std::vector<std::pair<uint8_t, uint64_t>> pend;
   std::vector<uint64_t> pend_acc;      // [AGPR pair] vm sequence number of the leaf load that lands in it (0: none outstanding)
 
+  std::string klabel;         // label of the kernel being printed (`off` counts from it)
+  bool check_off = false;     // dev: FDG_ISA_CHECK_OFF=1 makes the assembler itself hold `off` against the location counter every 32 instructions
+  uint64_t n_ins = 0;
   // every instruction goes through here: the wait states the hazard table demands are put in front of it
   void ins(const std::string &s) {
+    if (check_off && !klabel.empty() && (n_ins++ & 31u) == 0)
+      os << ".if (. - " << klabel << ") != " << off << "\n.error \"Emit::off is wrong in front of: " << s << "\"\n.endif\n";
     const HzInst I = hz_decode(s);
     const int need = hz.missing(I);
     if (need > 0) { os << "\ts_nop " << (need - 1) << "\n"; HzInst N; N.salu = true; N.nop = need; hz.issue(N); n_auto_nop++; off += 4; }
@@ -517,6 +523,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     os << "\t.text\n\t.protected\t" << kname << "\n\t.globl\t" << kname << "\n\t.p2align\t8\n\t.type\t" << kname << ",@function\n";
     os << kname << ":\n";
     E.off = 0;
+    E.klabel = kname;
     E.pad_ok = true;
     for (int i = 0; i < E.shift; ++i) E.ins("s_nop 0");
   } else {
@@ -537,14 +544,15 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   // a read stream with a few stores in it runs 5-10 % faster that way (tools/ubench/tile_ahead.hip: 5.73 -> 6.32 TB/s).  Only for
   // batches whose tiles are whole cache lines (the runtime checks strides and bases): a line shared by two tiles would be
   // fetched twice.  Earlier loads of a leaf that is loaded again stay as they are (the re-load may still find the line in L2).
-  // Round 6: a load whose leaf IS loaded again in this tile is non-temporal too when that next load comes more than FDG_ISA_NT_DIST (48) leaf loads
-  // later -- by then the XCD's 4 MB of L2, which its 128 resident waves share, has been turned over and the line would be fetched from memory
-  // anyway, while keeping it costs the stream what every retained line costs (gv_ver4_4's one-wave kernel, leaves re-loaded 2.2 x: every load
-  // non-temporal 3.49 ms, last loads only 3.99, none 4.26; parquet_ver4_4 and gv_sigma5, re-loaded 1.3 x soon after: every load non-temporal
-  // loses 4 %; profiles/r06_log_nt_sweep.txt, r06_log_sweep_c.txt).
+  // Round 6, the long programs only (Emit::nt_dist >= 0): a load whose leaf IS loaded again in this tile is non-temporal too when that next load
+  // comes more than nt_dist (512) leaf loads later -- by then the XCD's 4 MB of L2, which its 128 resident waves share, has been turned over and
+  // the line would be fetched from memory anyway, while keeping it costs the stream what every retained line costs (gv_ver4_4's one-wave kernel,
+  // leaves re-loaded 2.2 x: no load non-temporal 4.26 ms, last loads only 3.97, distance 1024: 3.46, 512: 3.33, 128: 3.38-3.44, 48: 3.52, every load 3.54).  The graphs with a
+  // streaming variant of their own re-load 1.3 x, soon after the eviction, and lose 1-4 % by the same rule (parquet_ver4_4 2.83 -> 2.87 / 2.92 at
+  // 128 / 48, gv_sigma5 1.24 -> 1.27 / 1.29): last loads only for them.  profiles/r06_log_nt_sweep.txt, r06_log_sweep_c.txt, r06_log_sweep_d.txt.
   std::vector<uint8_t> final_load(prog.ops.size(), 0);
   if (E.streaming) {
-    const long nt_dist = fdg::knob("FDG_ISA_NT_DIST") ? std::atol(fdg::knob("FDG_ISA_NT_DIST")) : 48;
+    const long nt_dist = fdg::knob("FDG_ISA_NT_DIST") ? std::atol(fdg::knob("FDG_ISA_NT_DIST")) : E.nt_dist;
     std::vector<long> next_at(p.L + 1, -1);     // ordinal (among the tile's leaf loads, counted from the end) of the leaf's next load
     long ord = 0;
     for (size_t i = prog.ops.size(); i-- > 0;)
@@ -657,7 +665,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
     E.ins("v_lshlrev_b32_e32 v" + std::to_string(rm0 + 2) + ", 4, v0");          // lane * 16: source offset of a pool fetch (lanes 0..31 carry a leaf's 64 samples)
     if (cs->pooled) {      // (pooled programs load no leaf into a register: the delta table's registers are free)
       E.ins("s_mov_b32 " + S(S_DELTA + 4) + ", 0");                               // lanes 32..63: the second leaf of a paired fetch (v[rm0 + 3]: its lanes' offsets)
-      E.ins("s_mov_b32 " + S(S_DELTA + 5) + ", 0xffffffff");
+      E.ins("s_mov_b32 " + S(S_DELTA + 5) + ", -1");       // (not 0xffffffff: the assembler makes that the inline constant -1 too, but isa_size would count a literal)
     }
   }
   if (rl) {
@@ -1462,6 +1470,7 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
   os << "\t.text\n\t.protected\t" << kname << "\n\t.globl\t" << kname << "\n\t.p2align\t8\n\t.type\t" << kname << ",@function\n";
   os << kname << ":\n";
   E.off = 0;
+  E.klabel = kname;
   E.pad_ok = fdg::knob("FDG_COOP_ALIGN") != nullptr;     // (experiment: the alignment pads inside the barrier-synchronised kernels)
   E.hz.reset();
   E.ins("v_lshrrev_b32_e32 v1, 6, v0");
@@ -1557,6 +1566,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   Emit E;
   { const char *a = fdg::knob("FDG_ISA_ALIGN"); E.align = a && a[0] >= '0' && a[0] <= '2' ? a[0] - '0' : 1; }
   { const char *a = fdg::knob("FDG_ISA_SHIFT"); E.shift = a ? std::atoi(a) : 0; }
+  E.check_off = fdg::knob("FDG_ISA_CHECK_OFF") != nullptr;
   E.os << "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n\t.amdhsa_code_object_version 6\n";
   std::vector<KernelMeta> ks;
   // Programs too long for a second copy (below) get their ONE kernel with the streaming policy (round 6): a leaf's last load of the tile and the
@@ -1565,6 +1575,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
   // with every leaf load non-temporal, profiles/r06_log_pool_sweep2.txt; gv_sigma6 4.61 -> 4.35, profiles/r06_log_nt_sweep.txt).
   const bool long_program = prog.ops.size() > 60000 && prog.mc_n_k == 0 && prog.mc_n_t == 0 && !fdg::knob("FDG_ISA_NO_STREAMING");
   E.streaming = long_program;
+  E.nt_dist = long_program ? 512 : -1;
   ks.push_back(emit_kernel(E, p, prog, kname, 1));
   E.streaming = false;
   if (prog2) ks.push_back(emit_kernel(E, p, *prog2, kname + "_w2", 2));
@@ -1573,6 +1584,7 @@ std::string emit_isa(const Lowered &p, const OptProgram &prog, const std::string
     ks.push_back(emit_kernel(E, p, *prog_acc, kname + "_acc", 1, true));
     E.streaming = false;
   }
+  E.nt_dist = -1;
   // the same programs once more for batches whose tiles are whole cache lines (see `streaming` in emit_kernel); not for programs
   // so long that a second copy would double a minute of assembly
   if (!fdg::knob("FDG_ISA_NO_STREAMING") && prog.ops.size() <= 60000 && prog.mc_n_k == 0 && prog.mc_n_t == 0) {

@@ -1091,6 +1091,7 @@ void build_opt_program(const Lowered &p, const OptParams &prm, OptProgram &out) 
     std::stable_sort(tail, B.u.end(), [](const UOp &x, const UOp &y) { return x.d < y.d; });
   }
   if (!fit_registers(B.u, prm, out)) return;
+  if (fdg::knob("FDG_LEAVES_ONCE")) out.params.leaves_once = fdg::knob("FDG_LEAVES_ONCE")[0] == '1';     // (experiments through fdg_graph_opt_program)
   Alloc A(p, out.params, B.u, B.next_vid, out);
   A.run();
   out.ops.swap(A.out);

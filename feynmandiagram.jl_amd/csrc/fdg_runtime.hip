@@ -1373,6 +1373,13 @@ int fdg_graph_create(const fdg_graph_desc *d, fdg_graph **out) {
 }
 
 // A handle's options (include/fdg.h).  value == NULL removes the option.
+// the handle's options as they are now, for entry points that take the handle as const and therefore do not hold its mutex while they work
+static fdg::KnobMap knobs_snapshot(const fdg_graph *g) {
+  if (!g) return fdg::KnobMap();
+  std::lock_guard<std::mutex> lk(const_cast<fdg_graph *>(g)->mu);
+  return g->knobs;
+}
+
 int fdg_graph_set_option(fdg_graph *g, const char *name, const char *value) {
   if (!g || !name || !*name) { set_error("null handle or option name"); return FDG_E_INVALID; }
   if (std::strncmp(name, "FDG_", 4) != 0) { set_error("option names start with FDG_"); return FDG_E_INVALID; }
@@ -1380,7 +1387,11 @@ int fdg_graph_set_option(fdg_graph *g, const char *name, const char *value) {
   fdg::KnobScope knob_scope(&g->knobs);
   if (value) g->knobs[name] = value; else g->knobs.erase(name);
   parse_launch_cfg(g);
-  if (g->cx_twin) { if (value) g->cx_twin->knobs[name] = value; else g->cx_twin->knobs.erase(name); parse_launch_cfg(g->cx_twin); }
+  if (g->cx_twin) {       // (the twin's own launches read its options under ITS mutex)
+    std::lock_guard<std::mutex> lk2(g->cx_twin->mu);
+    if (value) g->cx_twin->knobs[name] = value; else g->cx_twin->knobs.erase(name);
+    parse_launch_cfg(g->cx_twin);
+  }
   return FDG_OK;
 }
 // Process defaults: what handles created from now on start with, and what the entry points without a handle see (fdg_leaf_eval_device).
@@ -1392,8 +1403,15 @@ int fdg_set_default_option(const char *name, const char *value) {
 const char *fdg_get_default_option(const char *name) { return name ? fdg::knob(name) : nullptr; }   // (the calling thread is inside no handle's entry point: the defaults)
 const char *fdg_graph_get_option(const fdg_graph *g, const char *name) {
   if (!g || !name) return nullptr;
+  // (copied out under the mutex into one of four slots of the calling thread: the pointer stays valid across a concurrent fdg_graph_set_option)
+  thread_local std::string hold[4];
+  thread_local unsigned slot = 0;
+  std::lock_guard<std::mutex> lk(const_cast<fdg_graph *>(g)->mu);
   auto it = g->knobs.find(name);
-  return it == g->knobs.end() ? nullptr : it->second.c_str();
+  if (it == g->knobs.end()) return nullptr;
+  std::string &h = hold[slot++ & 3u];
+  h = it->second;
+  return h.c_str();
 }
 
 // Which of the reference's two evaluators the handle reproduces bit for bit (include/fdg.h).  Before any specialisation.
@@ -1484,7 +1502,8 @@ int fdg_graph_kernel_info(fdg_graph *g, fdg_kernel_info *o) {
 }
 
 int fdg_graph_emit_source(const fdg_graph *g, unsigned flags, char **source) {
-  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
+  const fdg::KnobMap knobs_now = knobs_snapshot(g);      // (a copy taken under the handle's mutex: fdg_graph_set_option may run on another thread)
+  fdg::KnobScope knob_scope(g ? &knobs_now : nullptr);
   if (!g || !source) { set_error("null argument"); return FDG_E_INVALID; }
   std::string s = emit_hip_source(g->prog, flags);
   char *m = (char *)std::malloc(s.size() + 1);
@@ -1535,7 +1554,8 @@ static fdg_opt_params get_opt_params(const fdg_graph *g) { return g->opt; }
 
 int fdg_graph_opt_program(const fdg_graph *g, const fdg_opt_params *q, fdg_mop **ops, uint64_t *n_ops,
                           uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used) {
-  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
+  const fdg::KnobMap knobs_now = knobs_snapshot(g);      // (a copy taken under the handle's mutex: fdg_graph_set_option may run on another thread)
+  fdg::KnobScope knob_scope(g ? &knobs_now : nullptr);
   if (!g || !ops || !n_ops) { set_error("null argument"); return FDG_E_INVALID; }
   fdg::OptProgram prog;
   fdg::OptParams prm = to_params(q);
@@ -1581,7 +1601,8 @@ static void build_pool_auto(const fdg::Lowered &p, const fdg::OptParams &q, fdg:
 }
 
 int fdg_graph_pool_program(const fdg_graph *g, const fdg_opt_params *q, uint32_t wave, fdg_mop **ops, uint64_t *n_ops, uint32_t *info) {
-  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
+  const fdg::KnobMap knobs_now = knobs_snapshot(g);      // (a copy taken under the handle's mutex: fdg_graph_set_option may run on another thread)
+  fdg::KnobScope knob_scope(g ? &knobs_now : nullptr);
   if (!g || !ops || !n_ops || wave >= fdg::CoopProgram::MAXW) { set_error("null argument or wave out of range"); return FDG_E_INVALID; }
   fdg::CoopProgram cp;
   const uint32_t nw = pool_waves();
@@ -1592,7 +1613,8 @@ int fdg_graph_pool_program(const fdg_graph *g, const fdg_opt_params *q, uint32_t
 }
 
 int fdg_graph_coop_program(const fdg_graph *g, const fdg_opt_params *q, uint32_t wave, fdg_mop **ops, uint64_t *n_ops, uint32_t *info) {
-  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
+  const fdg::KnobMap knobs_now = knobs_snapshot(g);      // (a copy taken under the handle's mutex: fdg_graph_set_option may run on another thread)
+  fdg::KnobScope knob_scope(g ? &knobs_now : nullptr);
   if (!g || !ops || !n_ops || wave >= fdg::CoopProgram::MAXW) { set_error("null argument or wave out of range"); return FDG_E_INVALID; }
   fdg::OptParams prm = to_params(q);
   if (!q || !q->n_acc) prm.n_acc = 124;
@@ -1624,7 +1646,8 @@ static int coop_program_out(const fdg::CoopProgram &cp, uint32_t wave, fdg_mop *
 
 int fdg_graph_mc_program(const fdg_graph *g, const fdg_leaf_tables *tab, const fdg_opt_params *q, fdg_mop **ops, uint64_t *n_ops,
                          uint32_t *n_reg_used, uint32_t *n_lds_used, uint32_t *n_mem_used, uint32_t *n_acc_used) {
-  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
+  const fdg::KnobMap knobs_now = knobs_snapshot(g);      // (a copy taken under the handle's mutex: fdg_graph_set_option may run on another thread)
+  fdg::KnobScope knob_scope(g ? &knobs_now : nullptr);
   if (!g || !tab || !ops || !n_ops) { set_error("null argument"); return FDG_E_INVALID; }
   if (tab->n_leaf != g->prog.L) { set_error("leaf tables: n_leaf differs from the graph's"); return FDG_E_INVALID; }
   fdg::LeafSpec ls; ls.tab = tab; ls.kF = tab->kF; ls.beta = tab->beta; ls.lambda = tab->lambda;
@@ -1946,18 +1969,31 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
   // with the 14 LDS slots that remain) -- then the fewest buffers that keep re-fetching low (graphs that need their LDS slots:
   // four buffers -9 % on the 5-loop Parquet self-energy; profiles/r04_log_rm_bufs.txt).
   const uint32_t first = e ? (uint32_t)std::max(1, std::min(4, std::atoi(e))) : 2u;
+  // Round 6: per buffer count the candidates are {root order} x {leaves re-loadable | loaded once (fdg_opt.h: leaves_once)} x {value-numbering
+  // window: the tile-major kernel's, and shorter ones -- a long window keeps values alive that the staging buffers' share of the LDS no longer
+  // has room for}, compared by an estimate of what a tile costs its wave in cycles: a fold step 4.5, a chunk fetch 800 (eight LDS-direct loads),
+  // a gathered leaf 400 (64 lines for 64 doubles), a panel access 60, an LDS move 8, an AGPR move 12.  (parquet_sigma5: 33 fetches + 13 gathers
+  // + 231 panel accesses with re-loadable leaves and the tile-major window -> 17 fetches and a few dozen panel accesses; 0.22 -> 0.35 of the
+  // HBM roof with leaves_once alone, profiles/r06_log_sweep_d.txt.)  FDG_RM_LEAVES_ONCE=0 / 1, FDG_RM_VN=<window> force one form.
+  const char *lo_env = fdg::knob("FDG_RM_LEAVES_ONCE"), *vn_env = fdg::knob("FDG_RM_VN");
+  std::vector<uint32_t> windows = {chosen.vn_window};
+  if (vn_env) windows = {(uint32_t)std::atoi(vn_env)};
+  else if (g->prog.N <= 60000) for (uint32_t w : {2000u, 1000u, 400u, 200u}) if (chosen.vn_window == 0 || w < chosen.vn_window) windows.push_back(w);
+  auto est_cycles = [](const fdg::OptProgram &c, uint64_t fetches, uint64_t gathers) {
+    return (double)c.n_valu * 4.5 + (double)fetches * 800.0 + (double)gathers * 400.0 + (double)(c.n_ld_mem + c.n_st_mem) * 60.0 +
+           (double)(c.n_ld_lds + c.n_st_lds) * 8.0 + (double)(c.n_ld_acc + c.n_st_acc) * 12.0;
+  };
   for (uint32_t pass = e ? 1u : 0u; pass < 2; ++pass)
   for (uint32_t bufs = pass == 0 ? 4u : first; bufs <= 4; ++bufs) {
-    uint64_t best_cost = ~0ull, best_fetches = 0, best_gathers = 0, best_panel = 0;
+    double best_cost = 1e300; uint64_t best_fetches = 0, best_gathers = 0, best_panel = 0;
+    bool any = false;
     fdg::OptProgram cand;
-    // (round 6: each root order also with LEAVES LOADED ONCE -- fdg_opt.h: leaves_once -- so that a leaf is never fetched a second time through
-    //  its 8 KB chunk or a 64-line gather; FDG_RM_LEAVES_ONCE=0 / 1 forces one form)
-    const char *lo_env = fdg::knob("FDG_RM_LEAVES_ONCE");
+    for (uint32_t vw : windows)
     for (int variant = 0; variant < 4; ++variant) {
       const int keep = variant & 1, once = variant >> 1;
       if (lo_env && (lo_env[0] == '1') != (once != 0)) continue;
       fdg::OptParams q = cfg_B();
-      q.vn_window = chosen.vn_window;
+      q.vn_window = vw;
       q.n_lds = 80u - bufs * 16u - 2u;                             // (two slots lost to the 1 KB alignment of the buffers)
       q.reserve_pairs = 5;
       q.lookahead_leaf = 48;
@@ -1966,16 +2002,18 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
       q.keep_root_order = keep != 0;
       q.roots_last = true;             // the R stores of a row back to back: they share cache lines when the roots are row-major too (+7-11 %)
       build_prog(g, q, cand);
-      if (!cand.supported) { if (variant == 0 && pass == 1) return 0; continue; }
+      if (!cand.supported) { if (!any && variant == 0 && vw == windows[0] && pass == 1) return 0; continue; }
+      any = true;
       uint64_t fetches = 0, gathers = 0;
       fdg::rm_plan_stats(g->prog, cand, bufs, fetches, gathers);
-      if (fdg::knob("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] one wave per SIMD (root order %d, leaves once %d): %u chunks, %llu fetches, %llu gathers with %u buffers, %llu panel accesses, %llu LDS and %llu AGPR moves\n", keep, once, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, bufs, (unsigned long long)(cand.n_ld_mem + cand.n_st_mem),
-                                                  (unsigned long long)(cand.n_ld_lds + cand.n_st_lds), (unsigned long long)(cand.n_ld_acc + cand.n_st_acc));
-      const uint64_t cost = fetches * 8192 + gathers * 4096 + (cand.n_ld_mem + cand.n_st_mem) * 512;     // (a gather touches 64 lines for 64 doubles; a panel access is 512 bytes that stay in L2)
+      const double cost = est_cycles(cand, fetches, gathers);
+      if (fdg::knob("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] one wave per SIMD (root order %d, leaves once %d, vn %u): %u chunks, %llu fetches, %llu gathers with %u buffers, %llu fold steps, %llu panel accesses, %llu LDS and %llu AGPR moves: %.0f cycles\n", keep, once, vw, n_chunk,
+                                                  (unsigned long long)fetches, (unsigned long long)gathers, bufs, (unsigned long long)cand.n_valu, (unsigned long long)(cand.n_ld_mem + cand.n_st_mem),
+                                                  (unsigned long long)(cand.n_ld_lds + cand.n_st_lds), (unsigned long long)(cand.n_ld_acc + cand.n_st_acc), cost);
       if (cost < best_cost) { best_cost = cost; best_fetches = fetches; best_gathers = gathers; best_panel = cand.n_ld_mem + cand.n_st_mem; pr = std::move(cand); if (qsel) *qsel = q; }
     }
     const bool cheap = best_fetches * 4 <= (uint64_t)n_chunk * 5 + 4;
-    if (pass == 0) { if (best_cost != ~0ull && cheap && best_panel == 0) return 4; break; }
+    if (pass == 0) { if (best_cost < 1e300 && cheap && best_panel == 0) return 4; break; }
     if (!cheap && bufs < 4 && !e) continue;
     {   // (FDG_ISA_RM_MAX_TRAFFIC=<tenths>: the bound on what the variant may move, in tenths of the matrix; default 25)
       const uint64_t tenths = fdg::knob("FDG_ISA_RM_MAX_TRAFFIC") ? (uint64_t)std::max(10, std::atoi(fdg::knob("FDG_ISA_RM_MAX_TRAFFIC"))) : 25;
@@ -2582,7 +2620,8 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
 }
 
 int fdg_graph_create_complex_view(const fdg_graph *g, fdg_graph **out) {
-  fdg::KnobScope knob_scope(g ? &g->knobs : nullptr);
+  const fdg::KnobMap knobs_now = knobs_snapshot(g);      // (a copy taken under the handle's mutex: fdg_graph_set_option may run on another thread)
+  fdg::KnobScope knob_scope(g ? &knobs_now : nullptr);
   if (!g || !out) { set_error("null argument"); return FDG_E_INVALID; }
   *out = nullptr;
   fdg::RealTwinTable t;

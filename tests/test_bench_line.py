@@ -155,15 +155,17 @@ def test_bench_line_on_the_device(tmp_path):
     assert got["value"] > 1e9 and r["frac"] > 0.3                                        # (a smaller batch than the default: not the headline's figure)
     assert r["measured_read_gbs"] > 3000 and 0.3 < r["frac_of_measured_read"] < 1.2          # fdg_read_device: the memory system's ceiling for a read stream on this box
     assert r.get("power_w") is None or (200 < r["power_w"] <= 1.05 * (r.get("power_cap_w") or 1400))        # rocm-smi next to the headline launch, when there is one
-    assert 0.3 < r["frac_power"] < 1.3 and "frac_power" in got["secondary_cols"]         # the power roof: 1160 W / (134 pJ x bytes + 25.5 pJ x fold steps)
+    assert 0.3 < r["frac_power"] < 1.3 and "power_w" in got["secondary_cols"]            # the power roof for the headline; the rows carry what rocm-smi read next to them
     c = got["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_matches_cpu_bitwise"] is True
     rows = {(x[0], x[1]): x for x in got["secondary"]}
-    i_bit, i_clk = got["secondary_cols"].index("bitwise"), got["secondary_cols"].index("clock_ghz")
+    i_bit, i_clk, i_pw = got["secondary_cols"].index("bitwise"), got["secondary_cols"].index("sclk_ghz"), got["secondary_cols"].index("power_w")
     # (a star: the row's batch came from fdg_batch_alloc_pair; the parquet_sigma4 rows do, gv_sigma5's does not)
     assert set(rows) == {("parquet_sigma4", "rm*"), ("gv_sigma5", "lm"), ("parquet_sigma4", "lm*")} and all(x[i_bit] is True for x in rows.values())
-    # the probe wave next to the timed launches: a plausible shader clock (the 5th-order graph runs against the power budget)
+    # rocm-smi next to the row's launches (round 6; the sleeping-wave probe of round 5 stays in the detail file): a plausible shader clock and socket power
     assert all(x[i_clk] is None or 1.2 < x[i_clk] < 2.6 for x in rows.values()) and (r.get("clock_ghz") is None or 1.2 < r["clock_ghz"] < 2.6)
+    assert all(x[i_pw] is None or 300 < x[i_pw] < 1500 for x in rows.values())
+    assert any(x[i_pw] is not None for x in rows.values()) or r.get("power_w") is None      # (no rocm-smi on the box: no power anywhere)
     assert got["config5"]["total_samples"] >= 10**9 and got["config5"]["n_gpus"] == 1
     assert got["accumulate"]["kernel"].startswith("fdg_isa_eval_acc") and got["accumulate"]["value"] > got["value"] * 0.8
     assert got["mc_step"]["value"] > 0 and got["mc_step"]["max_dev_over_Sk"] < 1e-11 and got["mc_step"]["max_dev_over_Ak"] < 1e-14

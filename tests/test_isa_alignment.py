@@ -94,3 +94,23 @@ def test_padded_and_unpadded_kernels_give_the_oracles_bits(libfdg, cuda, name):
         assert f.kernel_info()["last_kernel"].startswith("fdg_isa_eval_acc"), align
         terms = want * w[:, None]
         assert np.all(np.abs(acc - terms.sum(0)) <= 1e-12 * np.abs(terms).sum(0)), (name, align)
+
+
+@pytest.mark.parametrize("name,opts", [("parquet_ver4_3", {"FDG_ISA_POOL": "1", "FDG_COOP_ALIGN": "1"}), ("sigma4_standin", {"FDG_COOP_ALIGN": "1"}),
+                                       ("gv_sigma4_taylor2", {}), ("parquet_sigma3", {})])
+def test_the_assembler_agrees_with_the_printers_offsets(name, opts, tmp_path):
+    """Round 6: the printer's running offset (Emit::off) held against the ASSEMBLER's location counter every 32 instructions, in every
+    kernel family -- plain / streaming / accumulating, row-major (rm, rl), cooperative and pooled (option FDG_ISA_CHECK_OFF: an `.if (. - kernel) !=
+    off / .error` in the listing).  The pooled kernels' prologue printed `s_mov_b32 s, 0xffffffff`, which the assembler encodes as the inline
+    constant -1 and isa_size counted as a literal: every pad behind it sat four bytes off, which is why the pads cost those kernels 12 % in
+    round 5 instead of helping."""
+    d = os.path.join(str(tmp_path), name)
+    os.makedirs(d)
+    fd.compile_table(workloads.get(name), specialize="isa", cache_dir=d, flags=capi.FDG_SPEC_KEEP_SOURCE, options=dict(opts, FDG_ISA_CHECK_OFF="1"))      # assembling fails on a mismatch
+    (src,) = glob.glob(d + "/fdg_isa_*.s")
+    text = open(src).read()
+    assert text.count("Emit::off is wrong") > 20
+    if opts.get("FDG_COOP_ALIGN"):
+        kernels = layout(src)
+        k = [x for x in kernels if x.endswith("_pool") or x.endswith("_coop")]
+        assert k and all(straddlers(kernels[x]) == [] for x in k), name

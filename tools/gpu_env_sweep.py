@@ -1,5 +1,17 @@
 """GPU dev tool: time one workload's ISA kernel under several environment settings (FDG_* knobs of the back end),
 checking each against the oracle first.  python tools/gpu_env_sweep.py WORKLOAD "A=1,B=2" "A=3" ...   ("-" = no setting)"""
+def _need_dev_build():
+    """This tool steers the library through FDG_* environment variables AFTER it is loaded: only the dev build (make -C feynmandiagram.jl_amd/csrc dev;
+    FDG_LIBRARY=.../libfdg_dev.so) reads them then -- the product build snapshots the supported ones once per process and would compare a configuration
+    with itself.  Fail loudly instead."""
+    import os, sys
+    if not os.environ.get("FDG_LIBRARY", "").endswith("libfdg_dev.so"):
+        sys.exit(os.path.basename(__file__) + ": needs the dev build (make -C feynmandiagram.jl_amd/csrc dev; export FDG_LIBRARY=$PWD/feynmandiagram.jl_amd/lib/libfdg_dev.so): "
+                 "the product library reads FDG_* once per process, so the switches this tool flips would be silent no-ops")
+
+
+_need_dev_build()
+
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,4 +1,16 @@
 """GPU dev tool: sample-major (row-major [B, L]) input through the ISA kernel for several transposition chunk sizes."""
+def _need_dev_build():
+    """This tool steers the library through FDG_* environment variables AFTER it is loaded: only the dev build (make -C feynmandiagram.jl_amd/csrc dev;
+    FDG_LIBRARY=.../libfdg_dev.so) reads them then -- the product build snapshots the supported ones once per process and would compare a configuration
+    with itself.  Fail loudly instead."""
+    import os, sys
+    if not os.environ.get("FDG_LIBRARY", "").endswith("libfdg_dev.so"):
+        sys.exit(os.path.basename(__file__) + ": needs the dev build (make -C feynmandiagram.jl_amd/csrc dev; export FDG_LIBRARY=$PWD/feynmandiagram.jl_amd/lib/libfdg_dev.so): "
+                 "the product library reads FDG_* once per process, so the switches this tool flips would be silent no-ops")
+
+
+_need_dev_build()
+
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
