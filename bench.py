@@ -68,7 +68,7 @@ DEFAULT_B = {"sigma2": 64_000_000, "sigma4_standin": 2_000_000, "sigma4_worstcas
              "parquet_sigma4_dyn_taylor2": 2_000_000, "parquet_sigma4_insdyn_taylor2": 1_000_000, "parquet_sigma5": 2_000_000,
              "parquet_ver4_4": 512_000, "gv_ver4_4": 512_000}          # (whole 64-sample tiles: the pooled cooperative kernel takes full tiles)
 PAIR_ALL = False         # --pair-all (experiment): every tile-major / row-major secondary row through fdg_batch_alloc_pair
-POWER_LEG_S = 0.9        # seconds of back-to-back launches per secondary row under rocm-smi (--power-seconds; 0: off)
+POWER_LEG_S = 1.5        # seconds of back-to-back launches per secondary row under rocm-smi (--power-seconds; 0: off)
 PAIRED_ROWS = {("parquet_sigma4", "tile_major"), ("parquet_sigma4", "leaf_major"), ("parquet_sigma4", "sample_major"), ("parquet_sigma4_dyn", "tile_major"), ("sigma2", "tile_major"),
                ("gv_sigma4", "tile_major"), ("gv_sigma4_taylor2", "tile_major")}
 PARITY_NOTE = ("bit-exact vs our restatement of the Julia evaluator (oracle/); the reference's known-answer tests pin structure, "
@@ -200,7 +200,7 @@ def power_leg(step, seconds=1.5):
             sync()
         stop[0] = True
         th.join(timeout=10)
-        use = got[1:] if len(got) > 2 else got          # (the first sample may predate the load)
+        use = got[len(got) // 2:] if len(got) > 3 else (got[1:] if len(got) > 2 else got)          # (rocm-smi's power is a moving average: the later samples are the load's)
         if not use:
             return None
         out = {"power_w": sum(r["w"] for r in use) / len(use), "samples": len(use)}
@@ -733,7 +733,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the other workloads (config 2, 3 stand-ins, 5, row-major layout) measured after the headline")
     ap.add_argument("--secondary", default="", help="comma-separated workload:layout pairs to measure after the headline instead of the full list")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--power-seconds", type=float, default=0.9, help="per secondary row: seconds of back-to-back launches sampled with rocm-smi (socket power, sclk); 0 = off")
+    ap.add_argument("--power-seconds", type=float, default=1.5, help="per secondary row: seconds of back-to-back launches sampled with rocm-smi (socket power, sclk); 0 = off")
     ap.add_argument("--dry-run", action="store_true",
                     help="no device work: one process per rank on the CPU (gloo), the evaluator replaced by a stub that adds the shard's "
                          "sample count to the accumulator; checks sharding, the one collective and the stdout line (tests/test_bench_line.py)")
@@ -1009,17 +1009,17 @@ def compact_line(full):
     roof = full.get("roofline")
     if roof:
         keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_kernel_ms",
-                "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "frac_hbm_max_over_steps", "measured_copy_gbs", "frac_of_measured_copy", "measured_read_gbs", "frac_of_measured_read",
-                "ops_exec_per_eval", "clock_ghz", "frac_valu_at_clock", "frac_power", "power_w", "power_cap_w", "sclk_mhz")
-        line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:44]) for k in keep if k in roof}
+                "frac_hbm", "frac_valu", "frac_hbm_min_over_steps", "measured_read_gbs", "frac_of_measured_read",
+                "ops_exec_per_eval", "frac_power", "power_w", "power_cap_w", "sclk_mhz")       # (measured_copy_gbs, the probe's clock_ghz, frac_valu_at_clock: detail file)
+        line["roofline"] = {k: (_r(roof[k], 5) if k != "traffic_source" else str(roof[k])[:26]) for k in keep if k in roof}
         if roof.get("placement"):
             pi = roof.get("placement_info")
-            line["roofline"]["placement"] = ("fdg_batch_alloc_pair, one batch: %d/%d windows at the fast level (%.3f)" % (pi["windows_at_fast_level"], pi["windows"], pi["pair_frac_best"])
+            line["roofline"]["placement"] = ("fdg_batch_alloc_pair, one batch: %d/%d windows fast (%.3f)" % (pi["windows_at_fast_level"], pi["windows"], pi["pair_frac_best"])
                                              if pi else "single allocation")
     cb = full.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
-                                "sample": str(cb.get("sample", ""))[:110], "gpu_matches_cpu_bitwise": cb.get("gpu_matches_cpu_bitwise")}
+                                "sample": str(cb.get("sample", ""))[:64], "gpu_matches_cpu_bitwise": cb.get("gpu_matches_cpu_bitwise")}
     sec = full.get("secondary")
     if sec:
         # (sclk_ghz / power_w: rocm-smi next to the row's own launches, round 6; the self-calibrated frac_power of round 5 stays in bench_detail.json as a diagnostic)
@@ -1036,7 +1036,7 @@ def compact_line(full):
             rows.append([e["workload"].split(" ")[0], lay_short + ("*" if e.get("placement") == "fdg_batch_alloc_pair" else ""), _r(e["value"] / 1e6),
                          {"hbm": "hbm", "valu_fp64": "valu"}.get(r["bound"], r["bound"]), _r(r["frac"], 3), _r(r.get("frac_hbm"), 3),
                          _r(r.get("frac_valu"), 3), _r(r.get("traffic_over_algorithmic"), 3),
-                         (e.get("gpu_matches_cpu_bitwise") if not e.get("contracted") else "fma:%.0e" % (e.get("max_dev_over_Sk") or 0.0)),
+                         ({True: 1, False: 0}.get(e.get("gpu_matches_cpu_bitwise"), e.get("gpu_matches_cpu_bitwise")) if not e.get("contracted") else "fma:%.0e" % (e.get("max_dev_over_Sk") or 0.0)),
                          _r(r.get("clock_ghz"), 3), (int(round(r["power_w"])) if r.get("power_w") else None)])
         line["secondary"] = rows
     rp = {}
@@ -1045,7 +1045,7 @@ def compact_line(full):
         if r and "error" not in r:
             rp["lm" if e["layout"].startswith("leaf_major") else "rm"] = [_r(r["repack_ms"], 3), _r(r["eval_tiled_frac_hbm"], 3), _r(r["evaluations_to_amortise"], 3)]
     if rp:
-        line["tile_major_repack@1e8"] = dict(rp, cols=["repack_ms", "frac_hbm_tile_major_after", "evaluations_to_amortise"])
+        line["repack@1e8"] = dict(rp, cols=["ms", "frac_hbm_after", "evals_to_amortise"])
     c5 = full.get("config5")
     if c5:
         if "error" in c5:
@@ -1063,12 +1063,12 @@ def compact_line(full):
                                "frac_valu": _r(ac["roofline"]["frac_valu"], 3)})
     mc = full.get("mc_step")
     if mc:
-        line["mc_step"] = {"value": _r(mc.get("value"), 5), "unit": "samples/s", "leaf_parity": "unpinned (Lehmann.jl absent)",
+        line["mc_step"] = {"value": _r(mc.get("value"), 5), "unit": "samples/s", "leaf_parity": "unpinned (no Lehmann.jl)",
                            "max_dev_over_Sk": _r(mc.get("max_dev_over_Sk"), 3), "max_dev_over_Ak": _r(mc.get("max_dev_over_Ak"), 3)} if "error" not in mc else {"error": mc["error"][:80]}
     line["detail"] = "bench_detail.json"
     text = json.dumps(line, separators=(",", ":"))
     # never let the line outgrow the driver's capture: drop the optional parts, least important first
-    for k in ("tile_major_repack@1e8", "mc_step", "accumulate", "secondary", "secondary_cols", "config5"):
+    for k in ("repack@1e8", "mc_step", "accumulate", "secondary", "secondary_cols", "config5"):
         if len(text) <= LINE_LIMIT:
             break
         line.pop(k, None)

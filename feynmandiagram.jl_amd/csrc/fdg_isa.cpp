@@ -1471,7 +1471,15 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
   os << kname << ":\n";
   E.off = 0;
   E.klabel = kname;
-  E.pad_ok = fdg::knob("FDG_COOP_ALIGN") != nullptr;     // (experiment: the alignment pads inside the barrier-synchronised kernels)
+  // Alignment pads (round 6): in the POOLED kernels, in front of vector instructions only (Emit::align 2) -- gv_ver4_4 3.12 -> 2.95 ms, +5.6 %
+  // (every 8-byte instruction: 3.01; profiles/r06_log_sweep_f.txt).  Round 5 measured -12 % and left them out: the printer's offsets were four
+  // bytes off behind the prologue's `s_mov_b32 s, 0xffffffff` (the assembler's inline constant -1, counted as a literal), so every pad sat in the
+  // wrong place (tests/test_isa_alignment.py now lets the assembler check the offsets).  The value-passing cooperative kernels lose 2 % with
+  // the pads and stay without.  FDG_COOP_ALIGN=0 / 1 forces.
+  const char *ca = fdg::knob("FDG_COOP_ALIGN");
+  E.pad_ok = ca ? ca[0] == '1' : cp.pooled;
+  const int align_before = E.align;
+  if (cp.pooled && !ca && E.align == 1) E.align = 2;
   E.hz.reset();
   E.ins("v_lshrrev_b32_e32 v1, 6, v0");
   E.ins("v_readfirstlane_b32 s3, v1");
@@ -1498,6 +1506,7 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
     accum = std::max(accum, m.accum); n_agpr = std::max(n_agpr, m.n_agpr); n_sgpr = std::max(n_sgpr, m.n_sgpr);
   }
   const uint32_t lds_bytes = (cp.n_shared + cp.n_wave * cp.n_priv_lds) * 512u;
+  E.align = align_before;
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
   os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";
   os << "\t\t.amdhsa_private_segment_fixed_size 0\n\t\t.amdhsa_kernarg_size 96\n\t\t.amdhsa_user_sgpr_count 2\n";

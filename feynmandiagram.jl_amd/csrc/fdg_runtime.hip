@@ -2619,9 +2619,14 @@ int fdg_graph_specialize(fdg_graph *g, const char *cache_dir, unsigned flags) {
   return FDG_OK;
 }
 
+// (the body: fdg_graph_specialize_typed calls it with the handle's mutex held and the handle's options in scope)
+static int create_complex_view_scoped(const fdg_graph *g, fdg_graph **out);
 int fdg_graph_create_complex_view(const fdg_graph *g, fdg_graph **out) {
   const fdg::KnobMap knobs_now = knobs_snapshot(g);      // (a copy taken under the handle's mutex: fdg_graph_set_option may run on another thread)
   fdg::KnobScope knob_scope(g ? &knobs_now : nullptr);
+  return create_complex_view_scoped(g, out);
+}
+static int create_complex_view_scoped(const fdg_graph *g, fdg_graph **out) {
   if (!g || !out) { set_error("null argument"); return FDG_E_INVALID; }
   *out = nullptr;
   fdg::RealTwinTable t;
@@ -2653,7 +2658,7 @@ int fdg_graph_specialize_typed(fdg_graph *g, int dtype, const char *cache_dir, u
     // leaves the per-type kernel below in charge.
     g->cx_twin_tried = true;
     fdg_graph *tw = nullptr;
-    if (fdg_graph_create_complex_view(g, &tw) == FDG_OK && tw) {
+    if (create_complex_view_scoped(g, &tw) == FDG_OK && tw) {
       fdg_kernel_info ki;
       if (fdg_graph_specialize(tw, cache_dir, FDG_SPEC_ISA) == FDG_OK && fdg_graph_kernel_info(tw, &ki) == FDG_OK && ki.has_rm) g->cx_twin = tw;
       else fdg_graph_destroy(tw);

@@ -48,7 +48,7 @@ def test_line_is_short_and_keeps_the_contract_keys():
     assert set(got["config"]) >= {"workload", "layout", "samples_per_step_per_gpu"} and "model" not in got["config"] and len(got["config"]["workload"]) <= 120
     r = got["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["unit"] == "GB/s" and r["traffic"] == 70400000000.0
-    assert r["kernel"] == "fdg_isa_eval_nt" and len(r["traffic_source"]) <= 60 and 0.70 <= r["frac_hbm_min_over_steps"] <= r["frac"]
+    assert r["kernel"] == "fdg_isa_eval_nt" and len(r["traffic_source"]) <= 30 and 0.70 <= r["frac_hbm_min_over_steps"] <= r["frac"]
     c = got["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 256 and c["value"] > 0 and len(c["sample"]) <= 110
     assert len(got["secondary"]) == 16 and all(len(row) == len(got["secondary_cols"]) for row in got["secondary"])
@@ -151,7 +151,7 @@ def test_bench_line_on_the_device(tmp_path):
     r = got["roofline"]
     assert r["kernel"] == "fdg_isa_eval_nt" and r["bound"] == "hbm" and r["ops_exec_per_eval"] > 0
     assert abs(r["achieved"] - got["value"] * 704 / 1e9) / r["achieved"] < 0.1          # 8 (L + R) bytes per evaluation, HIP events vs wall clock
-    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3 and r["frac_hbm_min_over_steps"] <= r["frac"] + 1e-9 <= r["frac_hbm_max_over_steps"] + 2e-9
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3 and r["frac_hbm_min_over_steps"] <= r["frac"] + 1e-9
     assert got["value"] > 1e9 and r["frac"] > 0.3                                        # (a smaller batch than the default: not the headline's figure)
     assert r["measured_read_gbs"] > 3000 and 0.3 < r["frac_of_measured_read"] < 1.2          # fdg_read_device: the memory system's ceiling for a read stream on this box
     assert r.get("power_w") is None or (200 < r["power_w"] <= 1.05 * (r.get("power_cap_w") or 1400))        # rocm-smi next to the headline launch, when there is one
@@ -161,7 +161,7 @@ def test_bench_line_on_the_device(tmp_path):
     rows = {(x[0], x[1]): x for x in got["secondary"]}
     i_bit, i_clk, i_pw = got["secondary_cols"].index("bitwise"), got["secondary_cols"].index("sclk_ghz"), got["secondary_cols"].index("power_w")
     # (a star: the row's batch came from fdg_batch_alloc_pair; the parquet_sigma4 rows do, gv_sigma5's does not)
-    assert set(rows) == {("parquet_sigma4", "rm*"), ("gv_sigma5", "lm"), ("parquet_sigma4", "lm*")} and all(x[i_bit] is True for x in rows.values())
+    assert set(rows) == {("parquet_sigma4", "rm*"), ("gv_sigma5", "lm"), ("parquet_sigma4", "lm*")} and all(x[i_bit] == 1 for x in rows.values())
     # rocm-smi next to the row's launches (round 6; the sleeping-wave probe of round 5 stays in the detail file): a plausible shader clock and socket power
     assert all(x[i_clk] is None or 1.2 < x[i_clk] < 2.6 for x in rows.values()) and (r.get("clock_ghz") is None or 1.2 < r["clock_ghz"] < 2.6)
     assert all(x[i_pw] is None or 300 < x[i_pw] < 1500 for x in rows.values())

@@ -13,3 +13,4 @@ run gv_ver4_4 524288 FDG_ISA_NO_POOL=1 FDG_ISA_NO_POOL=1,FDG_LEAVES_ONCE=1
 run parquet_ver4_4 1048576 - FDG_LEAVES_ONCE=1 -
 run parquet_sigma4_taylor2 8000000 - FDG_LEAVES_ONCE=1 -
 run sigma4_standin 2000000 FDG_ISA_COOP=0 FDG_ISA_COOP=0,FDG_LEAVES_ONCE=1
+( time timeout 900 python -m pytest tests/test_typed.py tests/test_host_api.py -x -q -m gpu 2>&1 | tail -4 ) 2>&1 | tee -a gpurun_out/r06_log_sweep_f.txt
