@@ -443,7 +443,7 @@ def kernel_of(f, slot=0):
     return name, (ki["n_valu"][slot] or None)
 
 
-TRAFFIC_FILE = "r05_traffic.json"       # this round's PMC summaries only: a workload that is not in it gets traffic = null, never an older round's figure
+TRAFFIC_FILE = "r06_traffic.json"       # this round's PMC summaries only: a workload that is not in it gets traffic = null, never an older round's figure
 
 
 def attach_traffic(roof, workload, layout, B, avg_kernel_s):

@@ -341,13 +341,28 @@ fdg_repack_transpose(double *__restrict__ mat, long ss, long cs, double *__restr
   __shared__ double tile[64][65];          // [column][row]
   const int t = threadIdx.x;
   const long ntile_s = (n + 63) / 64, ntile_c = ((long)C + 63) / 64;
+  const bool wide = cs == 1 && (ss & 1) == 0 && (((uintptr_t)mat) & 15) == 0;
   for (long tid = blockIdx.x; tid < ntile_s * ntile_c; tid += gridDim.x) {
     const long ts = tid / ntile_c, s0 = ts * 64, c0 = (tid % ntile_c) * 64;
     if (TO_TILED) {
+      if (wide) {       // contiguous, 16-byte aligned rows: two columns per lane (512-byte runs along a row)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const long row = s0 + k * 8 + t / 32, col = c0 + 2 * (t % 32);
+          if (row < n && col + 1 < (long)C) {
+            const fdg_pair_d v = __builtin_nontemporal_load((const fdg_pair_d *)(mat + row * ss + col));
+            tile[2 * (t % 32)][k * 8 + t / 32] = v.x;
+            tile[2 * (t % 32) + 1][k * 8 + t / 32] = v.y;
+          } else if (row < n && col < (long)C) {
+            tile[2 * (t % 32)][k * 8 + t / 32] = __builtin_nontemporal_load(mat + row * ss + col);
+          }
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const long row = s0 + k * 4 + t / 64, col = c0 + t % 64;
         if (row < n && col < (long)C) tile[t % 64][k * 4 + t / 64] = __builtin_nontemporal_load(mat + row * ss + col * cs);
+      }
       }
       __syncthreads();
 #pragma unroll
@@ -362,10 +377,23 @@ fdg_repack_transpose(double *__restrict__ mat, long ss, long cs, double *__restr
         if (row < n && col < (long)C) tile[k * 4 + t / 64][t % 64] = __builtin_nontemporal_load(tiled + (ts * (long)C + col) * 64 + t % 64);
       }
       __syncthreads();
+      if (wide) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const long row = s0 + k * 8 + t / 32, col = c0 + 2 * (t % 32);
+          if (row < n && col + 1 < (long)C) {
+            fdg_pair_d v; v.x = tile[2 * (t % 32)][k * 8 + t / 32]; v.y = tile[2 * (t % 32) + 1][k * 8 + t / 32];
+            __builtin_nontemporal_store(v, (fdg_pair_d *)(mat + row * ss + col));
+          } else if (row < n && col < (long)C) {
+            mat[row * ss + col] = tile[2 * (t % 32)][k * 8 + t / 32];
+          }
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const long row = s0 + k * 4 + t / 64, col = c0 + t % 64;
         if (row < n && col < (long)C) mat[row * ss + col * cs] = tile[t % 64][k * 4 + t / 64];
+      }
       }
     }
     __syncthreads();
@@ -1946,24 +1974,41 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
   //  profiles/r04_log_rm_bufs.txt: 111 leaves +20 % over one wave per SIMD, 175 leaves -16 %.)
   const char *ew = fdg::knob("FDG_ISA_RM_WAVES");
   if (!(ew && std::atoi(ew) == 1) && !e && (n_chunk <= 8 || (ew && std::atoi(ew) == 2))) {
-    // (both root orders are tried: in the reference's order the first uses of the leaves walk the row monotonically)
-    for (int keep = 0; keep < 2; ++keep) {
+    // (both root orders are tried: in the reference's order the first uses of the leaves walk the row monotonically; round 6: also with
+    //  the leaves loaded once and with shorter value-numbering windows, as in the one-wave search below)
+    const char *lo_env2 = fdg::knob("FDG_RM_LEAVES_ONCE"), *vn_env2 = fdg::knob("FDG_RM_VN");
+    std::vector<uint32_t> windows2 = {chosen.vn_window};
+    if (vn_env2) windows2 = {(uint32_t)std::atoi(vn_env2)};
+    else if (g->prog.N <= 60000) for (uint32_t w : {1000u, 400u, 200u, 100u}) if (chosen.vn_window == 0 || w < chosen.vn_window) windows2.push_back(w);
+    const char *pp = fdg::knob("FDG_ISA_RM_PANEL_PCT");
+    const uint64_t panel_pct = pp ? (uint64_t)std::atoi(pp) : 0;
+    double best2 = 1e300;
+    fdg::OptProgram cand2;
+    fdg::OptParams qbest;
+    for (uint32_t vw : windows2)
+    for (int variant = 0; variant < 4; ++variant) {
+      const int keep = variant & 1, once = variant >> 1;
+      if (lo_env2 && (lo_env2[0] == '1') != (once != 0)) continue;
       fdg::OptParams q = cfg_A();
-      q.vn_window = chosen.vn_window;
+      q.vn_window = vw;
       q.n_lds = 8;
       q.reserve_pairs = 5;
       q.lookahead_leaf = 48;
       if (const char *la = fdg::knob("FDG_ISA_RM_LA")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(la));
+      q.leaves_once = once != 0;
       q.keep_root_order = keep != 0;
       q.roots_last = true;             // the R stores of a row back to back: they share cache lines when the roots are row-major too (+7-11 %)
-      build_prog(g, q, pr);
-      const char *pp = fdg::knob("FDG_ISA_RM_PANEL_PCT");
-      if (!pr.supported || (pr.n_ld_mem + pr.n_st_mem) * 100 > pr.n_valu * (uint64_t)(pp ? std::atoi(pp) : 0)) continue;
+      build_prog(g, q, cand2);
+      if (!cand2.supported || (cand2.n_ld_mem + cand2.n_st_mem) * 100 > cand2.n_valu * panel_pct) continue;
       uint64_t fetches = 0, gathers = 0;
-      fdg::rm_plan_stats(g->prog, pr, 2, fetches, gathers);
-      if (fdg::knob("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] two waves per SIMD (root order %d): %u chunks, %llu fetches, %llu gathers with 2 buffers; lds slots %u\n", keep, n_chunk, (unsigned long long)fetches, (unsigned long long)gathers, pr.n_lds_used);
-      if (fetches * 4 <= (uint64_t)n_chunk * 5 + 4 && (fetches * 8192 + gathers * 2048) * 2 <= (uint64_t)g->prog.L * 512 * 5) { if (qsel) *qsel = q; return 2; }
+      fdg::rm_plan_stats(g->prog, cand2, 2, fetches, gathers);
+      if (fdg::knob("FDG_RM_DEBUG")) std::fprintf(stderr, "[rm] two waves per SIMD (root order %d, leaves once %d, vn %u): %u chunks, %llu fetches, %llu gathers with 2 buffers, %llu fold steps, %llu panel; lds slots %u\n", keep, once, vw, n_chunk,
+                                                  (unsigned long long)fetches, (unsigned long long)gathers, (unsigned long long)cand2.n_valu, (unsigned long long)(cand2.n_ld_mem + cand2.n_st_mem), cand2.n_lds_used);
+      if (!(fetches * 4 <= (uint64_t)n_chunk * 5 + 4 && (fetches * 8192 + gathers * 2048) * 2 <= (uint64_t)g->prog.L * 512 * 5)) continue;
+      const double cost = (double)cand2.n_valu * 4.5 + (double)fetches * 800.0 + (double)gathers * 400.0 + (double)(cand2.n_ld_mem + cand2.n_st_mem) * 60.0 + (double)(cand2.n_ld_lds + cand2.n_st_lds) * 8.0;
+      if (cost < best2) { best2 = cost; pr = cand2; qbest = q; }
     }
+    if (best2 < 1e300) { if (qsel) *qsel = qbest; return 2; }
   }
   // Four buffers first -- the deepest prefetch: +5-18 % on the graphs whose values then still fit the registers and AGPRs (no panel access
   // with the 14 LDS slots that remain) -- then the fewest buffers that keep re-fetching low (graphs that need their LDS slots:

@@ -15,3 +15,4 @@ for cap in 1100 900; do
   probe
 done
 $smi --autorespond y --resetpoweroverdrive 2>&1 | tail -2 | tee -a $LOG
+timeout 600 python -m pytest tests/test_tile_major.py -x -q -m gpu -k repack 2>&1 | tail -3
