@@ -214,6 +214,28 @@ def replay(ops, n_reg, n_lds, n_mem, n_acc, leaf, R):
     return root
 
 
+@pytest.mark.parametrize("name", ["parquet_sigma5", "gv_sigma5", "gv_sigma4_taylor2", "sigma4_standin"])
+@pytest.mark.parametrize("budget", [dict(n_reg=115, n_lds=46, n_acc=124, lookahead_leaf=48), dict(n_reg=120, n_lds=8, lookahead_leaf=48), dict(n_reg=12, n_lds=3, n_acc=2)])
+def test_programs_that_load_every_leaf_once_replay_exactly(libfdg, name, budget):
+    """Round 6 (fdg_opt.h: leaves_once; the row-major variant's programs): a leaf is loaded exactly once and is a value like any other
+    afterwards -- spilled to an LDS slot, an AGPR pair or the panel when its register is needed, never fetched again.  The replay gives the
+    oracle's bits, no leaf index appears in two loads, and every live leaf is loaded."""
+    t = workloads.get(name)
+    h = capi.GraphHandle(t)
+    h.set_option("FDG_LEAVES_ONCE", "1")
+    h.set_option("FDG_KEEP_ROOT_ORDER", "1")
+    ops, nr, nl, nm = h.opt_program(**budget)
+    loads = ops["a"][np.isin(ops["kind"], (0, 28))]
+    assert len(loads) == len(set(loads.tolist())) == h.info()["n_live_leaf"]
+    leaf = oracle.philox_uniform(7, t.n_leaf, 23) * 2 - 1
+    assert np.array_equal(replay(ops, nr, nl, nm, h.last_n_acc, leaf, t.n_root), oracle.eval_static(t, leaf))
+    h2 = capi.GraphHandle(t)
+    ops2, *_ = h2.opt_program(**budget)
+    loads2 = ops2["a"][np.isin(ops2["kind"], (0, 28))]
+    if budget.get("n_reg", 120) <= 12:
+        assert len(loads2) > len(loads)          # the same budget with re-loadable leaves does fetch leaves again (else the test shows nothing)
+
+
 @pytest.mark.parametrize("name", ["sigma2", "synthetic_small", "sigma4_standin", "sigma4_worstcase", "gv_sigma4", "gv_sigma5",
                                   "gv_sigma4_taylor2", "parquet_sigma4", "parquet_sigma4_insdyn", "parquet_sigma4_taylor2", "parquet_sigma5", "parquet_ver4_4"])
 @pytest.mark.parametrize("budget", [dict(), dict(n_reg=120, n_lds=80, n_acc=124), dict(n_reg=9, n_lds=3, n_acc=2, lookahead_leaf=40)])
