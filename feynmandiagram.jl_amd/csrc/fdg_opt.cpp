@@ -80,6 +80,7 @@ struct Builder {
   // come back through the HBM panel for every use; its operands -- lower-order sub-diagrams that many nodes keep reading --
   // usually are still on chip.  Roots are exempt.
   bool keep_root_order = false;
+  const std::vector<uint32_t> *root_rank = nullptr;  // pool programs (experiment FDG_POOL_SEED): [N] position of a root node in this wave's order of evaluation
   const std::vector<uint8_t> *root_mask = nullptr;   // pool programs: [R] the roots this wave computes and stores (others are not its business)
   uint32_t term_window = 1, term_recent = 400;    // out-of-order evaluation of a wide node's terms (see build_uops)
   uint64_t remat_window = 0;
@@ -450,7 +451,8 @@ void build_uops(Builder &B) {
   std::vector<uint32_t> tops;
   for (auto &rk : rootlist) if (rk.first >= L) tops.push_back(rk.first - L);
   tops.erase(std::unique(tops.begin(), tops.end()), tops.end());
-  if (!B.keep_root_order) order_roots(p, tops);
+  if (B.root_rank) std::stable_sort(tops.begin(), tops.end(), [&](uint32_t x, uint32_t y) { return (*B.root_rank)[x] < (*B.root_rank)[y]; });
+  else if (!B.keep_root_order) order_roots(p, tops);
   // One fold step of frame f (operand already computed).  Returns true when the node is finished.
   auto step = [&](Frame &f) -> bool {
     const uint32_t n = f.n, a = p.off[n], k = p.off[n + 1] - a;
@@ -1574,6 +1576,17 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     for (size_t i = 0; i < root_nodes.size(); ++i) pos[root_nodes[i]] = i;
     for (size_t i = 0; i < ordered.size(); ++i) deal[i] = pos[ordered[i]];
   }
+  // (experiment FDG_POOL_SEED=n > 0: the dealing order and every wave's root order shuffled -- how much do the pool's fetches depend on which roots
+  //  run next to which?)
+  uint64_t pool_seed = fdg::knob("FDG_POOL_SEED") ? (uint64_t)std::atoll(fdg::knob("FDG_POOL_SEED")) : 0;
+  auto rnd = [&]() { pool_seed ^= pool_seed << 13; pool_seed ^= pool_seed >> 7; pool_seed ^= pool_seed << 17; return pool_seed; };
+  std::vector<uint32_t> root_rank;
+  if (pool_seed) {
+    pool_seed = pool_seed * 0x9E3779B97F4A7C15ull + 1;
+    for (size_t i = deal.size(); i > 1; --i) std::swap(deal[i - 1], deal[rnd() % i]);
+    root_rank.assign(p.N, 0);
+    for (size_t i = 0; i < root_nodes.size(); ++i) root_rank[root_nodes[i]] = (uint32_t)(rnd() & 0xffffff);
+  }
   std::vector<std::vector<uint64_t>> have(NW, std::vector<uint64_t>(W64, 0));
   std::vector<uint64_t> load(NW, 0);
   std::vector<uint32_t> wave_of_node(p.N, NONE);
@@ -1608,6 +1621,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     B[w]->value_numbering = prm.vn_window != 1;
     B[w]->vn_window = prm.vn_window > 1 ? prm.vn_window : 0;
     B[w]->root_mask = &mask[w];
+    if (!root_rank.empty()) B[w]->root_rank = &root_rank;
     build_uops(*B[w]);                 // (order_roots inside orders the wave's own roots by what they share)
     if (!B[w]->ok) { out.why = B[w]->why; return; }
   }
