@@ -395,6 +395,13 @@ struct Emit {
     ins("s_waitcnt vmcnt(" + std::to_string(n) + ")");
     vm_done = std::max(std::max(vm_done, vm_issued - n), seq);
   }
+  void wait_lg_seq(uint64_t seq) {       // LDS operations complete in order: everything up to `seq` has returned
+    if (seq <= lg_done) return;
+    const uint64_t n = std::min<uint64_t>(lg_issued - seq, 15);
+    ins("s_waitcnt lgkmcnt(" + std::to_string(n) + ")");
+    lg_done = std::max(std::max(lg_done, lg_issued - n), seq);
+    for (auto &p : pend) if (p.first == 2 && p.second <= lg_done) p.first = 0;
+  }
   void drain() {
     ins("s_waitcnt vmcnt(0) lgkmcnt(0)");
     vm_done = vm_issued;
@@ -502,7 +509,8 @@ static void rm_plan(const Lowered &p, const OptProgram &prog, uint32_t rm_bufs, 
 // One wave's section of the cooperative kernel (emit_coop below): no kernel header or descriptor of its own; lane = thread id
 // & 63; private LDS slots behind the shared ones (addressed through their own base register); the wave's panel inside the
 // workgroup's; M_SEND / M_RECV / M_BARRIER.
-struct CoopSec { uint32_t wave, n_shared, priv_base_bytes, panel_wg_bytes, panel_prefix_bytes; bool pooled = false; uint32_t pool_unit = 1; };
+struct CoopSec { uint32_t wave, n_shared, priv_base_bytes, panel_wg_bytes, panel_prefix_bytes; bool pooled = false; uint32_t pool_unit = 1;
+                 uint32_t slack = 0, flag_base_bytes = 0, n_wave = 4; };     // slack > 0: progress words instead of s_barrier between the epochs of a tile (fdg_opt.h: CoopProgram::slack)
 // rl: the row-major variant for CONTIGUOUS rows (sample stride == L: compile_Python's [B, L] exactly) of graphs whose tile fits the LDS: a
 // tile's 64 rows are one block of 512 L bytes, streamed linearly into an LDS image by LDS-direct loads (1 KB per instruction, every cache
 // line of the matrix requested exactly once, non-temporal), and leaf i of lane = row r is read from image[r * 8 L + 8 i].
@@ -667,6 +675,23 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
       E.ins("s_mov_b32 " + S(S_DELTA + 4) + ", 0");                               // lanes 32..63: the second leaf of a paired fetch (v[rm0 + 3]: its lanes' offsets)
       E.ins("s_mov_b32 " + S(S_DELTA + 5) + ", -1");       // (not 0xffffffff: the assembler makes that the inline constant -1 too, but isa_size would count a literal)
     }
+    if (cs->slack) {
+      // Progress words (round 6): wave w owns the 256 bytes at flag_base + 256 w -- every lane writes its own dword, so the store has no bank
+      // conflict -- and publishes there the number of sync points it has reached (counted over the whole launch, from 1024).  A reader's lane l
+      // looks at wave l % n_wave's first dword: one ds_read_b32 brings every wave's progress, one v_cmp tells whether any of them is behind.
+      E.ins("v_lshlrev_b32_e32 v" + std::to_string(rm0 + 4) + ", 2, v0");
+      E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 4) + ", " + hex32(cs->flag_base_bytes + 256u * cs->wave) + ", v" + std::to_string(rm0 + 4));      // my word of this lane
+      E.ins("v_and_b32_e32 v" + std::to_string(rm0 + 5) + ", " + std::to_string(cs->n_wave - 1) + ", v0");
+      E.ins("v_lshlrev_b32_e32 v" + std::to_string(rm0 + 5) + ", 8, v" + std::to_string(rm0 + 5));
+      E.ins("v_add_u32_e32 v" + std::to_string(rm0 + 5) + ", " + hex32(cs->flag_base_bytes) + ", v" + std::to_string(rm0 + 5));                          // wave (lane % n_wave)'s word
+      E.ins("s_movk_i32 " + S(S_DELTA + 6) + ", 0x400");                          // S_PROG: sync points reached
+      E.ins("v_mov_b32_e32 " + V(V_TMP) + ", " + S(S_DELTA + 6));
+      E.ins("ds_write_b32 v" + std::to_string(rm0 + 4) + ", " + V(V_TMP));
+      E.ins("s_waitcnt lgkmcnt(0)");
+      E.ins("s_barrier");                                                         // every wave's word is initialised before anyone looks
+      E.ins("ds_read_b32 v" + std::to_string(rm0 + 6) + ", v" + std::to_string(rm0 + 5));
+      E.ins("s_waitcnt lgkmcnt(0)");
+    }
   }
   if (rl) {
     E.ins("v_mul_u32_u24_e32 v" + std::to_string(rm0) + ", " + hex32(8u * p.L) + ", v0");      // lane * 8 L: this lane's row inside the image
@@ -799,6 +824,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_cbranch_scc0 .Ltile" + sfx);
   E.ins("s_endpgm");   // (the host never launches more waves than tiles)
   os << ".Ltile" << sfx << ":\n";
+  if (cs && cs->slack) E.ins("s_mov_b32 " + S(S_DELTA + 7) + ", " + S(S_DELTA + 6));      // S_G0: the progress count at the start of this tile
   E.ins("s_mov_b32 " + S(S_X + 1) + ", 0");
   E.ins("s_mov_b32 " + S(S_X) + ", " + S(S_TILE));
   E.ins("s_lshl_b64 " + S2(S_X) + ", " + S2(S_X) + ", " + std::to_string(TSH));                 // b0
@@ -968,6 +994,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   size_t op_index = 0;
   std::vector<std::pair<uint64_t, uint32_t>> pool_pending;      // (vm sequence number, first epoch in which it is read) of this wave's pool fetches in flight
   uint32_t bar_seen = 0;
+  uint64_t flag_seq = 0;      // lgkm sequence number of the pending read of the progress words (flag synchronisation)
   bool pool_exec_low = false;
   for (const MOp &o : prog.ops) {
     if (rm_bufs) for (const RmFetch &f : rm_fetch[op_index]) rm_emit_fetch(f);
@@ -1149,6 +1176,44 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
         }
         if (need_seq && !(dbg && std::strstr(dbg, "nofetchwait"))) E.wait_vm(need_seq);     // (timing experiment: results are garbage without it)
         bar_seen++;
+        if (cs && cs->slack) {
+          // Flag synchronisation (fdg_opt.h: CoopProgram::slack).  Publish first -- the store is queued behind this wave's LDS reads of the epoch,
+          // which therefore have read their slots before anyone sees the new count --, then wait until every other wave has reached sync point
+          // o.a of this tile (o.a = 0: the tile's last sync point, a real barrier).  The others' words were read at the previous sync point; only
+          // when that stale copy is not enough does the wave poll (s_sleep between reads; after 2^14 rounds it goes on, so that a bug shows
+          // as a wrong result and not as a hung device).
+          const std::string vf = "v" + std::to_string(rm0 + 6), vfa = "v" + std::to_string(rm0 + 5), vme = "v" + std::to_string(rm0 + 4);
+          E.ins("s_add_u32 " + S(S_DELTA + 6) + ", " + S(S_DELTA + 6) + ", 1");
+          E.ins("v_mov_b32_e32 " + V(V_TMP) + ", " + S(S_DELTA + 6));
+          E.ins("ds_write_b32 " + vme + ", " + V(V_TMP));
+          ++E.lg_issued;
+          if (o.a == 0) {
+            E.ins("s_waitcnt lgkmcnt(0)");
+            E.lg_done = E.lg_issued;
+            for (auto &pp : E.pend) if (pp.first == 2) pp.first = 0;
+            E.ins("s_barrier");
+          } else {
+            const std::string tag = sfx + "_" + std::to_string(bar_seen);
+            E.ins("s_add_u32 " + S(S_DELTA + 8) + ", " + S(S_DELTA + 7) + ", " + std::to_string(o.a));          // what the others must have reached
+            E.wait_lg_seq(flag_seq);
+            E.ins("v_cmp_gt_u32_e32 vcc, " + S(S_DELTA + 8) + ", " + vf);
+            E.ins("s_cbranch_vccz .Lgo" + tag);
+            E.ins("s_mov_b32 " + S(S_DELTA + 9) + ", 0");
+            os << ".Lpoll" << tag << ":\n";
+            E.ins("s_sleep 1");
+            E.ins("ds_read_b32 " + vf + ", " + vfa);
+            E.ins("s_waitcnt lgkmcnt(0)");
+            E.ins("v_cmp_gt_u32_e32 vcc, " + S(S_DELTA + 8) + ", " + vf);
+            E.ins("s_add_u32 " + S(S_DELTA + 9) + ", " + S(S_DELTA + 9) + ", 1");
+            E.ins("s_bitcmp1_b32 " + S(S_DELTA + 9) + ", 14");
+            E.ins("s_cbranch_scc1 .Lgo" + tag);
+            E.ins("s_cbranch_vccnz .Lpoll" + tag);
+            os << ".Lgo" << tag << ":\n";
+          }
+          E.ins("ds_read_b32 " + vf + ", " + vfa);                      // the others' progress, for the next sync point
+          flag_seq = ++E.lg_issued;
+          break;
+        }
         E.ins("s_waitcnt lgkmcnt(0)");
         E.lg_done = E.lg_issued;
         for (auto &pp : E.pend) if (pp.first == 2) pp.first = 0;
@@ -1441,7 +1506,7 @@ static KernelMeta emit_kernel(Emit &E, const Lowered &p, const OptProgram &prog,
   E.ins("s_endpgm");
 
   // ---- kernel descriptor -------------------------------------------------------
-  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + 2 * acc_pairs_v + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? 4 : 0) + (rl ? 2 : 0), 8);
+  const uint32_t next_vgpr = std::max<uint32_t>(V_BASE + RW * std::max<uint32_t>(prog.n_reg_used, 1) + 2 * acc_pairs_v + 2 * n_tmp_pairs + (rm_bufs ? 10 : 0) + (cs ? (cs->slack ? 7 : 4) : 0) + (rl ? 2 : 0), 8);
   const uint32_t accum = (next_vgpr + 3) & ~3u;
   const uint32_t n_agpr = RW * prog.n_acc_used + (aa ? 2 * p.R : 0);
   if (cs) return KernelMeta{kname, lds_bytes, accum, n_agpr, 12, (mc || has_macro) ? S_END : S_POOL + 2 * 16};
@@ -1500,12 +1565,13 @@ static KernelMeta emit_coop(Emit &E, const Lowered &p, const CoopProgram &cp, co
   uint32_t accum = 0, n_agpr = 0;
   int n_sgpr = 0;
   for (uint32_t w = 0; w < cp.n_wave; ++w) {
-    const CoopSec cs{w, cp.n_shared, (cp.n_shared + w * cp.n_priv_lds) * 512u, panel_wg, prefix[w], cp.pooled, cp.pool_unit};
+    const CoopSec cs{w, cp.n_shared, (cp.n_shared + w * cp.n_priv_lds) * 512u, panel_wg, prefix[w], cp.pooled, cp.pool_unit,
+                     cp.pooled ? cp.slack : 0u, (cp.n_shared + cp.n_wave * cp.n_priv_lds) * 512u, cp.n_wave};
     E.hz.reset();
     const KernelMeta m = emit_kernel(E, p, cp.wave[w], kname + "_w" + std::to_string(w), 1, false, 0, &cs);
     accum = std::max(accum, m.accum); n_agpr = std::max(n_agpr, m.n_agpr); n_sgpr = std::max(n_sgpr, m.n_sgpr);
   }
-  const uint32_t lds_bytes = (cp.n_shared + cp.n_wave * cp.n_priv_lds) * 512u;
+  const uint32_t lds_bytes = (cp.n_shared + cp.n_wave * cp.n_priv_lds) * 512u + (cp.pooled && cp.slack ? 256u * cp.n_wave : 0u);
   E.align = align_before;
   os << "\t.section\t.rodata,\"a\",@progbits\n\t.p2align\t6, 0x0\n\t.amdhsa_kernel " << kname << "\n";
   os << "\t\t.amdhsa_group_segment_fixed_size " << lds_bytes << "\n";

@@ -1529,6 +1529,11 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
   if (const char *e = fdg::knob("FDG_POOL_AHEAD")) ahead = (uint32_t)std::max(1, std::atoi(e));
   if (!epoch_ops) epoch_ops = 128;
   if (!ahead) ahead = 8;
+  // synchronisation between the epochs of a tile: s_barrier (slack 0), or progress words with `slack` epochs of freedom (fdg_opt.h: CoopProgram::slack)
+  uint32_t S = 0;
+  if (const char *e = fdg::knob("FDG_POOL_SYNC")) if (std::string(e) == "flags") S = 2;
+  if (const char *e = fdg::knob("FDG_POOL_SLACK")) if (S) S = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
+  out.slack = S;
   // ---- roots to waves: largest cone first, to the wave where it adds the least to the heaviest load ----------------------------
   std::vector<std::pair<uint32_t, uint32_t>> rootlist;
   for (uint32_t k = 0; k < p.R; ++k) if (p.root_slot[k] != FDG_NO_ROOT) rootlist.push_back({p.root_slot[k], k});
@@ -1639,7 +1644,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
     // distance of a wave's private LDS slots: -10 %; 200: the landing registers are missed elsewhere, -4 %; profiles/r04_log_la_lds.txt)
     q.lookahead_leaf = 96;
     if (const char *e = fdg::knob("FDG_POOL_READ_AHEAD")) q.lookahead_leaf = (uint32_t)std::max(1, std::atoi(e));
-    q.reserve_pairs = std::max<uint32_t>(q.reserve_pairs, 2);      // (as in build_coop_program)
+    q.reserve_pairs = std::max<uint32_t>(q.reserve_pairs, S ? 4u : 2u);      // (as in build_coop_program; three more registers for the progress words)
     if (!fit_registers(B[w]->u, q, out.wave[w])) { out.why = out.wave[w].why; return; }
     Alloc A(p, out.wave[w].params, B[w]->u, B[w]->next_vid, out.wave[w]);
     A.run();
@@ -1725,11 +1730,11 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
   // may slot s2 be given away at `issue` to content first read in epoch e?  key: how late its present content is needed again (0: no)
   auto victim_key = [&](uint32_t s2, uint32_t issue, uint32_t e) -> uint64_t {
     if (in_slot[s2] == NONE) return (uint64_t)INF + 2;
-    if (last_read[s2] >= issue) return 0;                              // (still being read when the fetch would be issued)
-    const uint32_t nr = next_read(in_slot[s2], issue);
+    if (last_read[s2] + S >= issue) return 0;                          // (still being read when the fetch would be issued -- by a wave up to S sync points behind)
+    const uint32_t nr = next_read(in_slot[s2], issue > S ? issue - S : 0);
     if (nr <= e) return 0;                                             // needed again before (or when) the new content is: keep it
     // an EARLY fetch only takes a slot whose content is dead or far from its next read: being early must not cost a re-fetch
-    if (issue + 2 < e && nr != INF && nr <= e + far) return 0;
+    if (issue + 2 + S < e && nr != INF && nr <= e + far) return 0;      // ("early": more than two epochs before the leaf has to have landed, which is S epochs before e)
     return (uint64_t)nr + 1;
   };
   auto install = [&](uint32_t l, uint32_t slot, uint32_t e) {
@@ -1739,7 +1744,12 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
   };
   uint64_t n_paired = 0;
   for (uint32_t e = 1; e <= n_epoch; ++e) {                 // epoch whose reads must be resident
-    const uint32_t first_issue = e > ahead ? e - ahead : 0;
+    // (flag synchronisation: a reader in epoch e only knows that the others have reached sync point max(1, e - S), so the fetch must have been
+    //  confirmed by then: `rdy` takes the place of e as the epoch by which the leaf has landed)
+    //  -- except in the first S + 1 epochs of a tile, whose sync points are strict: the pool starts empty, and everything the first epochs read
+    //  cannot be fetched in front of the opening barrier)
+    const uint32_t rdy = (S && e > S + 1) ? e - S : e;
+    const uint32_t first_issue = rdy > ahead ? rdy - ahead : 0;
     std::vector<uint32_t> missing;
     for (uint32_t l : need[e]) {
       if (slot_of[l] != NONE) last_read[slot_of[l]] = std::max(last_read[slot_of[l]], e);
@@ -1752,7 +1762,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
       // in the future (and not before the new content is).
       if (pairing && i + 1 < missing.size()) {
         uint32_t best = NONE, issue = first_issue;
-        for (; issue < e && best == NONE; ++issue) {
+        for (; issue < rdy && best == NONE; ++issue) {
           uint64_t best_key = 0;
           for (uint32_t k = 0; k + 1 < P; k += 2) {
             const uint64_t k0 = victim_key(k, issue, e), k1 = k0 ? victim_key(k + 1, issue, e) : 0;
@@ -1770,7 +1780,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
           const uint32_t la = std::min(missing[i], missing[i + 1]), lb = std::max(missing[i], missing[i + 1]);
           install(la, best, e);
           install(lb, best + 1, e);
-          fetches.push_back(Fetch{la, best, issue, e, lb});
+          fetches.push_back(Fetch{la, best, issue, rdy, lb});
           n_paired++;
           i += 2;
           continue;
@@ -1778,7 +1788,7 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
       }
       const uint32_t l = missing[i];
       uint32_t best = NONE, issue = first_issue;
-      for (; issue < e && best == NONE; ++issue) {
+      for (; issue < rdy && best == NONE; ++issue) {
         uint64_t best_key = 0;
         for (uint32_t s2 = 0; s2 < P; ++s2) {
           const uint64_t key = victim_key(s2, issue, e);
@@ -1788,10 +1798,15 @@ void build_pool_program(const Lowered &p, const OptParams &prm, CoopProgram &out
       }
       if (best == NONE) { out.why = "leaf pool exhausted"; return; }
       install(l, best, e);
-      fetches.push_back(Fetch{l, best, issue, e, NONE});
+      fetches.push_back(Fetch{l, best, issue, rdy, NONE});
       ++i;
     }
   }
+  if (S)
+    for (uint32_t w = 0; w < NW; ++w) {
+      uint32_t b = 0;
+      for (MOp &o : out.wave[w].ops) if (o.kind == M_BARRIER) { ++b; o.b = b; o.a = b == n_epoch ? 0u : (b <= S + 1 ? b : std::max<uint32_t>(S + 1, b - S)); }
+    }
   out.n_fetch = fetches.size();
   out.n_transfer = 0;                                       // leaves brought from memory per tile
   for (const Fetch &f : fetches) out.n_transfer += f.unit2 != NONE ? 2 : std::min<uint32_t>(U, L - f.unit * U);

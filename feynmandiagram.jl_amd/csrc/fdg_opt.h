@@ -163,6 +163,12 @@ struct CoopProgram {
   bool pooled = false;         // build_pool_program: leaves come through the shared pool (M_POOL_FETCH / M_RECV); needs sample stride 1, leaf
                                // offsets below 2^31 bytes from the tile's base (tile-major batches) and full 64-sample tiles
   uint32_t pool_unit = 1;      // pooled: leaves per fetch (in: set before build_pool_program; 2 = pairs of adjacent leaves, needs leaf stride 64: tile-major batches)
+  uint32_t slack = 0;          // pooled, round 6 (FDG_POOL_SYNC=flags): > 0 = the waves do not meet at s_barrier between the epochs of a tile; every wave publishes
+                               // the number of sync points it has reached in an LDS word of its own and passes sync point b when every other wave has reached
+                               // b (the first slack + 1 sync points of a tile: strict) or max(slack + 1, b - slack) (M_BARRIER with a = that number, b = the
+                               // sync's index; a = 0: a real s_barrier -- the last of a tile).  The
+                               // planner keeps a leaf `slack` epochs longer on both sides: fetched so that it has landed `slack` epochs before its first read,
+                               // its slot given away no earlier than `slack` epochs after its last
   uint64_t n_fetch = 0;        // pooled: leaf fetches from memory per tile (>= the live leaves; what exceeds them was evicted from the pool and came again)
   bool supported = false;
   std::string why;

@@ -461,6 +461,108 @@ def test_pooled_programs_replay_exactly(libfdg, monkeypatch, name, waves, fdgopt
         assert n_fetch + panel + t.n_root <= 1.5 * (t.n_leaf + t.n_root)
 
 
+def replay_pool_flags(progs, info, leaf, R, rng, leader=None):
+    """The pooled programs under FLAG synchronisation (fdg_opt.h: CoopProgram::slack), wave by wave in an arbitrary interleaving: a wave that
+    reaches sync point b publishes b and may go on once every other wave has published at least the number the op carries (a; a = 0: the tile's
+    last sync point, everybody must have reached it).  A fetch is in flight from its issue until the issuing wave reaches the sync point from
+    which it is readable (it waits for it there: the latest it can land -- the adversarial choice); nobody may read the slot meanwhile, and a
+    read returns whatever the slot holds at that moment, so a slot given away while a wave lagging behind still reads it shows up as wrong bits.
+    `leader`: that wave always runs when it can (maximal skew); otherwise the runnable waves take random turns of random length."""
+    B = leaf.shape[0]
+    NW = len(progs)
+    shared = np.full((max(info["n_shared"], 1), B), np.nan)
+    in_flight = {}                      # slot -> (wave that fetches, sync point at which it has landed, values)
+    root = np.zeros((B, R))
+    st = []
+    for w, ops in enumerate(progs):
+        iw = info["waves"][w]
+        st.append(dict(reg=np.full((max(iw["n_reg"], 1), B), np.nan), lds=np.full((max(iw["n_lds"], 1), B), np.nan),
+                       mem=np.full((max(iw["n_mem"], 1), B), np.nan), acc=np.full((max(iw["n_acc"], 1), B), np.nan), pc=0, reached=0, waiting=None))
+    max_lead = 0
+
+    def land(w, b):                     # wave w is at sync point b: its fetches readable from b on have landed
+        for slot in [s_ for s_, (fw, rdy, _v) in in_flight.items() if fw == w and rdy <= b]:
+            shared[slot] = in_flight.pop(slot)[2]
+
+    def runnable(w):
+        s = st[w]
+        if s["pc"] >= len(progs[w]): return False
+        if s["waiting"] is None: return True
+        need, b = s["waiting"]
+        others = [st[y]["reached"] for y in range(NW) if y != w]
+        return all(r >= (b if need == 0 else need) for r in others)
+
+    while any(st[w]["pc"] < len(progs[w]) for w in range(NW)):
+        ready = [w for w in range(NW) if runnable(w)]
+        assert ready, "deadlock: every wave waits"
+        w = leader if (leader is not None and leader in ready) else ready[int(rng.integers(len(ready)))]
+        s = st[w]
+        s["waiting"] = None
+        budget = int(rng.integers(1, 400))
+        reg, lds, mem, acc, ops = s["reg"], s["lds"], s["mem"], s["acc"], progs[w]
+        while s["pc"] < len(ops) and budget > 0:
+            o = ops[s["pc"]]; s["pc"] += 1; budget -= 1
+            k, d, a, b = int(o["kind"]), int(o["d"]), int(o["a"]), int(o["b"])
+            sa = -1.0 if o["nega"] else 1.0
+            sb = -1.0 if o["negb"] else 1.0
+            if k == 27:                 # sync point b: fetches confirmed, progress published, then wait for the others
+                assert b == s["reached"] + 1
+                land(w, b)
+                s["reached"] = b
+                s["waiting"] = (a, b)
+                max_lead = max(max_lead, b - min(st[y]["reached"] for y in range(NW)))
+                break
+            elif k == 26:
+                assert a not in in_flight, ("pool slot read while its fetch is in flight", a, w, s["reached"])
+                reg[d] = shared[a]
+            elif k == 29:
+                assert max(b, 1) == 1, "paired fetches are not part of the flag variant's test"
+                assert d not in in_flight and int(o["imm"]) > s["reached"], ("pool slot fetched twice / ready too early", d)
+                in_flight[d] = (w, int(o["imm"]), leaf[:, a].copy()); shared[d] = np.nan
+            elif k == 1: reg[d] = lds[a]
+            elif k == 2: reg[d] = mem[a]
+            elif k == 3: lds[d] = reg[a]
+            elif k == 4: mem[d] = reg[a]
+            elif k == 5: reg[d] = (sa * reg[a]) * (sb * reg[b])
+            elif k == 6: reg[d] = (sa * reg[a]) + (sb * reg[b])
+            elif k == 7: reg[d] = (sa * reg[a]) * o["imm"]
+            elif k == 8: root[:, d] = sa * reg[a]
+            elif k == 10: reg[d] = acc[a]
+            elif k == 11: acc[d] = reg[a]
+            else: raise AssertionError(k)
+    assert not in_flight
+    return root, max_lead
+
+
+@pytest.mark.parametrize("slack", [1, 2])
+@pytest.mark.parametrize("name", ["parquet_ver4_3", "gv_ver4_4"])
+def test_pooled_programs_with_flag_synchronisation_replay_exactly(libfdg, name, slack, fdgopt):
+    """Round 6 (option FDG_POOL_SYNC=flags): no s_barrier between the epochs of a tile -- every wave publishes the sync points it
+    has reached and waits only until the others are within `slack` of it.  The planner keeps a leaf `slack` epochs longer on both sides.  Replayed
+    under random interleavings and with each wave in turn running as far ahead as the protocol lets it: the oracle's bits, no slot read while its
+    fetch is in flight, no deadlock, the last sync point of a tile strict; and the waves do get ahead of each other (else the test shows nothing)."""
+    fdgopt.set("FDG_POOL_SYNC", "flags")
+    fdgopt.set("FDG_POOL_SLACK", str(slack))
+    t = workloads.get(name)
+    h = capi.GraphHandle(t)
+    progs, info = h.pool_program()
+    bars = [p[p["kind"] == 27] for p in progs]
+    assert all(len(b) == info["n_epoch"] for b in bars)
+    for b in bars:
+        assert int(b["a"][-1]) == 0 and list(b["b"]) == list(range(1, len(b) + 1))
+        assert all(1 <= int(x["a"]) <= int(x["b"]) and (int(x["b"]) <= slack + 1 or int(x["a"]) >= int(x["b"]) - slack) for x in b[:-1])
+        assert any(int(x["a"]) < int(x["b"]) for x in b[:-1])
+    leaf = oracle.philox_uniform(3, t.n_leaf, 87)
+    want = oracle.eval_static(t, leaf)
+    rng = np.random.default_rng(5)
+    leads = []
+    for leader in (None, 0, len(progs) - 1):
+        got, lead = replay_pool_flags(progs, info, leaf, t.n_root, rng, leader)
+        assert np.array_equal(got, want), (name, slack, leader)
+        leads.append(lead)
+    assert max(leads) >= slack          # a wave did run `slack` sync points ahead of the slowest
+
+
 def test_pooled_programs_with_paired_fetches_replay_exactly(libfdg, monkeypatch, fdgopt):
     """FDG_POOL_PAIR=1 (an experiment kept behind a switch: measured slower): one 64-lane fetch brings two arbitrary leaves into an aligned pair of
     slots.  The replay is exact; the second leaf follows the first in index (the upper lanes' offsets are unsigned)."""

@@ -166,6 +166,31 @@ def test_pooled_cooperative_variant_on_device(libfdg, cuda, monkeypatch, tmp_pat
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("name,slack", [("parquet_ver4_3", 1), ("parquet_ver4_3", 2), ("gv_ver4_4", 1)])
+def test_pooled_variant_with_flag_synchronisation_on_device(libfdg, cuda, tmp_path, name, slack):
+    """Option FDG_POOL_SYNC=flags (round 6): the pooled kernel without s_barrier between the epochs of a tile -- every wave
+    publishes the sync points it has reached in an LDS word of its own and polls the others' only when the copy it read one sync point earlier is
+    not enough.  Bit-exact on the device, many tiles per workgroup (the counters run on across tiles), ragged last tile through the one-wave
+    kernel.  Measured 3-7 % SLOWER than the barrier form (profiles/r06_log_sweep_k.txt), so it stays an option; the poll gives up after 2^14
+    rounds, so a protocol bug would show here as wrong bits, not as a hung device."""
+    import torch
+    t = workloads.get(name)
+    L, R = t.n_leaf, t.n_root
+    f = fd.compile_table(t, specialize="isa", cache_dir=str(tmp_path), options={"FDG_ISA_POOL": "1", "FDG_POOL_SYNC": "flags", "FDG_POOL_SLACK": str(slack)})
+    assert f.kernel_info()["has_pool"] == 1
+    for B in (64, 64 * 2100 + 17):           # 2100 tiles on 256 CUs: eight or nine tiles per workgroup
+        h_leaf = oracle.philox_uniform(B, L, 93)
+        leaf = torch.from_numpy(to_tiles(h_leaf)).to(cuda)
+        root = torch.full(((B + 63) // 64, R, 64), 9.0, dtype=torch.float64, device=cuda)
+        for _ in range(3):
+            f.eval_tiled(root, leaf, B)
+        torch.cuda.synchronize()
+        assert f.kernel_info()["last_kernel"] in ("fdg_isa_eval_pool", "fdg_isa_eval", "fdg_isa_eval_nt")
+        assert np.array_equal(from_tiles(root.cpu().numpy(), B, R), oracle.eval_static(t, h_leaf)), (name, slack, B)
+
+
+@pytest.mark.gpu
 def test_pooled_graph_accumulates_through_the_pool(libfdg, cuda):
     """A graph with the pooled variant (example/benchmark_GV.jl's vertex function) accumulates through it: pooled evaluation into the
     column-major root scratch, then the weighted sum -- its fused-accumulation program (26 accumulators taken from the value registers,
