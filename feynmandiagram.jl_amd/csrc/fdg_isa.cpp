@@ -468,40 +468,48 @@ constexpr uint32_t RM_CHUNK = 16, RM_BUF_BYTES = 64 * RM_CHUNK * 8, RM_WINDOW = 
 struct RmFetch { uint32_t chunk, buf; };
 static void rm_plan(const Lowered &p, const OptProgram &prog, uint32_t rm_bufs, std::vector<std::vector<RmFetch>> &rm_fetch,
                     std::vector<int> &rm_ld_buf) {
-  const uint32_t rm_full = p.L / RM_CHUNK, rm_tail = (p.L % RM_CHUNK) ? 1u : 0u;
+  const uint32_t rm_full = p.L / RM_CHUNK, rm_tail = (p.L % RM_CHUNK) ? 1u : 0u, n_chunk = rm_full + rm_tail;
   auto rm_chunk_of = [&](uint32_t leaf) { return leaf < rm_full * RM_CHUNK ? leaf / RM_CHUNK : rm_full; };
+  // Round 6 (OptParams::rm_pair, four buffers): chunks are fetched in PAIRS -- chunks 2u and 2u + 1 back to back into two adjacent buffers.  A
+  // 128-byte row segment of a row that is not a whole number of lines straddles two cache lines, and the line it shares with the next chunk is
+  // requested again when that chunk is fetched -- a chunk's worth of computing later, by which time the XCD's L2 has turned over for a quarter of
+  // them: the chunked variant moves 1.25 x the matrix, and its fetch stream ALONE runs at the memory system's ceiling for that traffic
+  // (profiles/r06_log_sweep_m.txt).  Fetched together, the two halves of a pair ask for their shared line within nanoseconds of each other.
+  const uint32_t G = (prog.params.rm_pair && rm_bufs >= 4 && rm_bufs % 2 == 0) ? 2u : 1u;
+  const uint32_t n_unit = (n_chunk + G - 1) / G, n_ubuf = rm_bufs / G;
   const size_t n_ops = prog.ops.size();
   rm_fetch.assign(n_ops + 1, {});
   rm_ld_buf.assign(n_ops, -1);
-  std::vector<std::vector<size_t>> uses(rm_full + rm_tail);
-  for (size_t q = 0; q < n_ops; ++q) if (prog.ops[q].kind == M_LD_LEAF) uses[rm_chunk_of(prog.ops[q].a)].push_back(q);
+  std::vector<std::vector<size_t>> uses(n_unit);
+  for (size_t q = 0; q < n_ops; ++q) if (prog.ops[q].kind == M_LD_LEAF) uses[rm_chunk_of(prog.ops[q].a) / G].push_back(q);
   std::vector<size_t> cursor(uses.size(), 0);
-  std::vector<int64_t> resident(rm_bufs, -1);
-  std::vector<size_t> free_from(rm_bufs, 0);      // op index from which the buffer may be filled again
+  std::vector<int64_t> resident(n_ubuf, -1);
+  std::vector<size_t> free_from(n_ubuf, 0);      // op index from which the buffer (pair) may be filled again
   for (size_t q = 0; q < n_ops; ++q) {
     if (prog.ops[q].kind != M_LD_LEAF) continue;
-    const uint32_t c = rm_chunk_of(prog.ops[q].a);
-    cursor[c]++;                                   // uses[c][cursor[c]..] are the later ones
+    const uint32_t c = rm_chunk_of(prog.ops[q].a), u = c / G;
+    cursor[u]++;                                   // uses[u][cursor[u]..] are the later ones
     int b = -1;
-    for (uint32_t k = 0; k < rm_bufs; ++k) if (resident[k] == (int64_t)c) b = (int)k;
+    for (uint32_t k = 0; k < n_ubuf; ++k) if (resident[k] == (int64_t)u) b = (int)k;
     if (b < 0) {
       // a chunk is worth a buffer (and eight loads) when at least three of its leaves are read within the next
       // RM_WINDOW ops; stragglers -- a value used again long after its neighbours -- are gathered from memory
       size_t soon = 1;
-      for (size_t k = cursor[c]; k < uses[c].size() && uses[c][k] <= q + RM_WINDOW; ++k) soon++;
+      for (size_t k = cursor[u]; k < uses[u].size() && uses[u][k] <= q + RM_WINDOW; ++k) soon++;
       if (soon < 3) continue;
       // victim: an empty buffer, else the resident chunk whose next use is farthest (none at all first)
       size_t far = 0;
-      for (uint32_t k = 0; k < rm_bufs; ++k) {
+      for (uint32_t k = 0; k < n_ubuf; ++k) {
         size_t nu;
         if (resident[k] < 0) nu = std::numeric_limits<size_t>::max();
-        else { const auto &u = uses[(size_t)resident[k]]; const size_t cu = cursor[(size_t)resident[k]]; nu = cu < u.size() ? u[cu] : std::numeric_limits<size_t>::max() - 1; }
+        else { const auto &uu = uses[(size_t)resident[k]]; const size_t cu = cursor[(size_t)resident[k]]; nu = cu < uu.size() ? uu[cu] : std::numeric_limits<size_t>::max() - 1; }
         if (b < 0 || nu > far) { b = (int)k; far = nu; }
       }
-      rm_fetch[std::min(free_from[(size_t)b], q)].push_back(RmFetch{c, (uint32_t)b});
-      resident[(size_t)b] = c;
+      for (uint32_t k = 0; k < G && G * u + k < n_chunk; ++k)
+        rm_fetch[std::min(free_from[(size_t)b], q)].push_back(RmFetch{G * u + k, G * (uint32_t)b + k});
+      resident[(size_t)b] = u;
     }
-    rm_ld_buf[q] = b;
+    rm_ld_buf[q] = (int)(G * (uint32_t)b + c % G);
     free_from[(size_t)b] = q + 1;
   }
 }

@@ -104,6 +104,7 @@ struct OptParams {
                                   // from then on a value like any other -- evicted to an LDS slot, an AGPR pair or the panel (512 bytes, coalesced) instead of
                                   // being dropped and "re-loaded", which for a row-major matrix means fetching its whole chunk (8 KB) again or gathering
                                   // 64 cache lines for 64 doubles (parquet_sigma5 row-major: 33 chunk fetches + 13 gathers for 18 chunks)
+  bool rm_pair = false;           // row-major programs with four staging buffers: chunks are fetched in pairs (csrc/fdg_isa.cpp: rm_plan)
   uint32_t reserve_pairs = 0;     // VGPR pairs the kernel variant keeps above the values (accumulators, weight): the value budget shrinks
                                   // by this and by the temporaries the program's macro ops need, so that everything stays below v256
 };

@@ -2046,6 +2046,7 @@ static uint32_t build_rm_program(const fdg_graph *g, const fdg::OptParams &chose
       q.leaves_once = once != 0;
       q.keep_root_order = keep != 0;
       q.roots_last = true;             // the R stores of a row back to back: they share cache lines when the roots are row-major too (+7-11 %)
+      q.rm_pair = bufs == 4 && fdg::knob("FDG_RM_PAIR") && fdg::knob("FDG_RM_PAIR")[0] == '1';
       build_prog(g, q, cand);
       if (!cand.supported) { if (!any && variant == 0 && vw == windows[0] && pass == 1) return 0; continue; }
       any = true;
