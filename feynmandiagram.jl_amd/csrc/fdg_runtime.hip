@@ -2133,6 +2133,7 @@ static void build_pool(const fdg_graph *g, const fdg::OptProgram &prog, IsaVaria
   const uint32_t nw = pool_waves();
   fdg::OptParams q = pool_params(cfg_B(), nw);
   q.vn_window = prog.params.vn_window;
+  if (const char *v = fdg::knob("FDG_POOL_VN")) q.vn_window = (uint32_t)std::max(0, std::atoi(v));      // (experiment: the pooled waves' own value-numbering window)
   build_pool_auto(g->prog, q, V.pool, nw);
   if (fdg::knob("FDG_POOL_DEBUG")) std::fprintf(stderr, "[pool] %s: %u waves, %u epochs, %llu fetches for %u leaves, %llu duplicated fold steps (%s)\n", V.pool.supported ? "built" : "not built",
                                                   V.pool.n_wave, V.pool.n_epoch, (unsigned long long)V.pool.n_fetch, g->prog.n_live_leaf, (unsigned long long)V.pool.n_duplicate, V.pool.why.c_str());
